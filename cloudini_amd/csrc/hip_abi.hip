@@ -1,0 +1,645 @@
+// hip_abi.hip -- host side of the C ABI declared in include/cloudini_hip.h.
+//
+// Plan building restates the reference's encoder selection (src/codec_common.cpp:69-153,
+// src/v4_codec.cpp:26-40, src/v5_codec.cpp:719-740, :883-892); everything else is device plumbing: a
+// grow-only workspace, the chunk table of a batch, kernel launches on one HIP stream.
+//
+// There is no CPU implementation behind this ABI: without a GPU every call fails with
+// CLDN_HIP_ERR_NO_DEVICE / CLDN_HIP_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cloudini_hip.h"
+#include "stage1_device.h"
+#include "stage1_launch.h"
+
+using namespace cldn;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) {                                                                         \
+      return fail(_e == hipErrorNoDevice ? CLDN_HIP_ERR_NO_DEVICE : CLDN_HIP_ERR_DEVICE,             \
+                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);       \
+    }                                                                                               \
+  } while (0)
+
+int size_of_type(uint8_t t) {  // include/cloudini_lib/basic_types.hpp:73-95
+  switch (t) {
+    case 1: case 2: return 1;
+    case 3: case 4: return 2;
+    case 5: case 6: case 7: return 4;
+    case 8: case 9: case 10: return 8;
+    default: return 0;
+  }
+}
+bool is_adaptive_int(uint8_t t) {  // src/v5_codec.cpp:83-95
+  return t == 3 || t == 4 || t == 5 || t == 6 || t == 9 || t == 10;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return CLDN_HIP_OK;
+    if (p) {
+      HIP_TRY(hipFree(p));
+      p = nullptr;
+      cap = 0;
+    }
+    const size_t want = (bytes + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(e == hipErrorOutOfMemory ? CLDN_HIP_ERR_NOMEM : CLDN_HIP_ERR_DEVICE,
+                  "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    cap = want;
+    return CLDN_HIP_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return CLDN_HIP_OK;
+    if (p) {
+      HIP_TRY(hipHostFree(p));
+      p = nullptr;
+      cap = 0;
+    }
+    const size_t want = (bytes + 4095) & ~size_t(4095);
+    HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return CLDN_HIP_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct cldn_hip_plan {
+  DevPlan dev;
+  std::vector<cldn_hip_field_t> fields;
+  uint32_t point_step = 0;
+  uint8_t version = 0;
+  uint8_t encoding_opt = 0;
+  bool uses_v5 = false;
+  uint32_t ref_max_point_bytes = 0;  // detail::MaxSerializedPointSize
+};
+
+struct cldn_hip_codec {
+  cldn_hip_plan plan;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // workspace (grow-only)
+  DevBuf d_in, d_out, d_slots, d_chunks, d_cloud_first, d_segs, d_payload, d_dst, d_offsets, d_modes, d_status;
+  DevBuf d_cols[kMaxAdaptive];
+  DevBuf d_ranks[kMaxAdaptive];
+  DevBuf d_dec_meta;
+  PinnedBuf h_stage;   // chunk table upload
+  PinnedBuf h_result;  // offsets / status readback
+  // cached batch shape
+  std::vector<uint64_t> last_cloud_points;
+  uint32_t last_n_chunks = 0;
+  // timing
+  bool timing = false;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+};
+
+extern "C" {
+
+const char* cldn_hip_last_error(void) { return g_error.c_str(); }
+int cldn_hip_abi_version(void) { return CLDN_HIP_ABI_VERSION; }
+
+int cldn_hip_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e == hipErrorNoDevice) return 0;
+  if (e != hipSuccess) return fail(CLDN_HIP_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint32_t point_step, uint8_t version,
+                         uint8_t encoding_opt, cldn_hip_plan_t** out) {
+  if (!out) return fail(CLDN_HIP_ERR_ARG, "plan_create: out is NULL");
+  *out = nullptr;
+  if (point_step == 0) return fail(CLDN_HIP_ERR_ARG, "point_step cannot be 0");  // cloudini.cpp:250-252
+  if (point_step > kMaxPointStep)
+    return fail(CLDN_HIP_ERR_UNSUPPORTED, "point_step %u > %u is not supported by the HIP kernels", point_step,
+                kMaxPointStep);
+  if (n_fields && !fields) return fail(CLDN_HIP_ERR_ARG, "fields is NULL");
+  if (encoding_opt > 2) return fail(CLDN_HIP_ERR_ARG, "invalid encoding_opt %u", encoding_opt);
+
+  cldn_hip_plan* plan = new (std::nothrow) cldn_hip_plan();
+  if (!plan) return fail(CLDN_HIP_ERR_NOMEM, "out of memory");
+  plan->fields.assign(fields, fields + n_fields);
+  plan->point_step = point_step;
+  plan->version = version;
+  plan->encoding_opt = encoding_opt;
+  DevPlan& d = plan->dev;
+  memset(&d, 0, sizeof(d));
+  d.point_step = point_step;
+  const bool lossy = encoding_opt == 1;
+
+  // MaxSerializedPointSize (codec_common.cpp:29-67) -- also validates the field types
+  for (uint32_t i = 0; i < n_fields; ++i) {
+    const cldn_hip_field_t& f = fields[i];
+    const int sz = size_of_type(f.type);
+    if (sz == 0) {
+      delete plan;
+      return fail(CLDN_HIP_ERR_ARG, "Unsupported field type %u (field %u)", f.type, i);
+    }
+    if ((uint64_t)f.offset + (uint64_t)sz > point_step) {
+      delete plan;
+      return fail(CLDN_HIP_ERR_ARG, "field %u (offset %u, %d bytes) exceeds point_step %u", i, f.offset, sz,
+                  point_step);
+    }
+    switch (f.type) {
+      case 7: plan->ref_max_point_bytes += (lossy && f.has_resolution) ? 10 : 7; break;
+      case 8: plan->ref_max_point_bytes += (lossy && f.has_resolution) ? 10 : 11; break;
+      case 1: case 2: plan->ref_max_point_bytes += 1; break;
+      default: plan->ref_max_point_bytes += 10; break;
+    }
+  }
+
+  // LeadingLossyFloatFieldCount (codec_common.cpp:69-82)
+  uint32_t lead = 0;
+  if (lossy) {
+    for (uint32_t i = 0; i < n_fields; ++i) {
+      if (fields[i].type != 7 || !fields[i].has_resolution) break;
+      ++lead;
+    }
+    if (lead != 3 && lead != 4) lead = 0;
+  }
+  // UsesV5Codec (v5_codec.cpp:883-892)
+  plan->uses_v5 = false;
+  if (version >= 5 && lossy) {
+    for (uint32_t i = lead; i < n_fields; ++i) plan->uses_v5 |= is_adaptive_int(fields[i].type);
+  }
+
+  auto add_op = [&](DevOp op) -> int {
+    if (d.n_ops >= (uint32_t)kMaxOps)
+      return fail(CLDN_HIP_ERR_UNSUPPORTED, "more than %d per-point tokens are not supported", kMaxOps);
+    d.ops[d.n_ops++] = op;
+    d.max_regular_bytes += op.max_bytes;
+    return CLDN_HIP_OK;
+  };
+  int rc = CLDN_HIP_OK;
+  d.all_varint = 1;
+  for (uint32_t i = 0; i < n_fields && rc == CLDN_HIP_OK; ++i) {
+    const cldn_hip_field_t& f = fields[i];
+    DevOp op;
+    memset(&op, 0, sizeof(op));
+    op.offset = f.offset;
+    op.type = f.type;
+    op.size = (uint8_t)size_of_type(f.type);
+    if (encoding_opt == 0) {  // BuildV4Encoders, v4_codec.cpp:29-34: everything is a raw copy
+      op.kind = OP_COPY;
+      op.max_bytes = op.size;
+      d.all_varint = 0;
+      d.min_regular_bytes += op.size;
+      rc = add_op(op);
+      continue;
+    }
+    if (i < lead) {  // FieldEncoderFloatN_Lossy lane, field_encoder.cpp:24-40
+      op.kind = OP_QF32;
+      op.mult_f = 1.0F / f.resolution;
+      op.res_f = f.resolution;
+      op.max_bytes = 5;
+      if (!(op.mult_f > 0.0f)) {
+        rc = fail(CLDN_HIP_ERR_ARG, "FieldEncoderFloatN_Lossy requires a resolution with value > 0.0");
+        break;
+      }
+      d.min_regular_bytes += 1;
+      rc = add_op(op);
+      continue;
+    }
+    if (plan->uses_v5 && is_adaptive_int(f.type)) {  // buildV5Plan, v5_codec.cpp:725-737
+      if (d.n_adaptive >= (uint32_t)kMaxAdaptive) {
+        rc = fail(CLDN_HIP_ERR_UNSUPPORTED, "more than %d adaptive integer fields are not supported", kMaxAdaptive);
+        break;
+      }
+      DevAdaptive& a = d.adaptive[d.n_adaptive++];
+      a.offset = f.offset;
+      a.type = f.type;
+      a.bpv = op.size;
+      continue;
+    }
+    switch (f.type) {  // CreateCompatibleEncoder, codec_common.cpp:116-153
+      case 7:
+        if (lossy && f.has_resolution) {
+          if (!(f.resolution > 0.0f)) {
+            rc = fail(CLDN_HIP_ERR_ARG, "FieldEncoder(Float/Lossy) requires a resolution with value > 0.0");
+            break;
+          }
+          op.kind = OP_LOSSY_F32;
+          op.mult_f = (float)(1.0 / (double)f.resolution);  // field_encoder.hpp:101-102
+          op.res_f = f.resolution;
+          op.max_bytes = 10;
+          d.min_regular_bytes += 1;
+        } else if (encoding_opt == 2) {
+          op.kind = OP_XOR32;
+          op.max_bytes = 4;
+          d.all_varint = 0;
+          d.min_regular_bytes += 4;
+        } else {
+          op.kind = OP_COPY;
+          op.max_bytes = 4;
+          d.all_varint = 0;
+          d.min_regular_bytes += 4;
+        }
+        break;
+      case 8:
+        if (lossy && f.has_resolution) {
+          if (!(f.resolution > 0.0f)) {
+            rc = fail(CLDN_HIP_ERR_ARG, "FieldEncoder(Float/Lossy) requires a resolution with value > 0.0");
+            break;
+          }
+          op.kind = OP_LOSSY_F64;
+          op.mult_d = 1.0 / (double)f.resolution;
+          op.res_d = (double)f.resolution;
+          op.max_bytes = 10;
+          d.min_regular_bytes += 1;
+        } else if (!f.has_resolution && version >= 4) {
+          rc = fail(CLDN_HIP_ERR_UNSUPPORTED,
+                    "field %u: FLOAT64 without resolution selects the sequential Gorilla codec "
+                    "(field_encoder.hpp:156-312), which has no HIP kernel yet",
+                    i);
+        } else {
+          op.kind = OP_XOR64;
+          op.max_bytes = 8;
+          d.all_varint = 0;
+          d.min_regular_bytes += 8;
+        }
+        break;
+      case 1: case 2:
+        op.kind = OP_COPY;
+        op.max_bytes = 1;
+        d.all_varint = 0;
+        d.min_regular_bytes += 1;
+        break;
+      default:
+        op.kind = OP_INT;
+        op.max_bytes = 10;
+        d.min_regular_bytes += 1;
+        break;
+    }
+    if (rc == CLDN_HIP_OK) rc = add_op(op);
+  }
+  if (rc != CLDN_HIP_OK) {
+    delete plan;
+    return rc;
+  }
+  *out = plan;
+  return CLDN_HIP_OK;
+}
+
+void cldn_hip_plan_destroy(cldn_hip_plan_t* plan) { delete plan; }
+int cldn_hip_plan_uses_v5(const cldn_hip_plan_t* plan) { return plan && plan->uses_v5 ? 1 : 0; }
+uint32_t cldn_hip_plan_adaptive_fields(const cldn_hip_plan_t* plan) { return plan ? plan->dev.n_adaptive : 0; }
+uint32_t cldn_hip_plan_max_point_bytes(const cldn_hip_plan_t* plan) { return plan ? plan->ref_max_point_bytes : 0; }
+
+uint64_t cldn_hip_stage1_bound(const cldn_hip_plan_t* plan, uint64_t n_points) {  // cloudini.cpp:249-292 (NONE)
+  if (!plan) return 0;
+  uint64_t total = 0, left = n_points;
+  while (left > 0) {
+    const uint64_t in_chunk = std::min<uint64_t>(left, kPointsPerChunk);
+    left -= in_chunk;
+    uint64_t chunk = in_chunk * plan->ref_max_point_bytes;
+    if (plan->uses_v5) chunk += (uint64_t)plan->fields.size() * 32u + 1024u;
+    total += 4 + chunk;
+  }
+  return total;
+}
+
+int cldn_hip_codec_create(const cldn_hip_plan_t* plan, int device, void* hip_stream, cldn_hip_codec_t** out) {
+  if (!plan || !out) return fail(CLDN_HIP_ERR_ARG, "codec_create: NULL argument");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(CLDN_HIP_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                hipGetErrorString(e));
+  if (device < 0) HIP_TRY(hipGetDevice(&device));
+  if (device >= n) return fail(CLDN_HIP_ERR_ARG, "device %d out of range (%d devices)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  cldn_hip_codec* c = new (std::nothrow) cldn_hip_codec();
+  if (!c) return fail(CLDN_HIP_ERR_NOMEM, "out of memory");
+  c->plan = *plan;
+  c->device = device;
+  if (hip_stream) {
+    c->stream = (hipStream_t)hip_stream;
+  } else {
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+      delete c;
+      return fail(CLDN_HIP_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(se));
+    }
+    c->own_stream = true;
+  }
+  int rc = stage1_configure_kernels();
+  if (rc != CLDN_HIP_OK) {
+    cldn_hip_codec_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return CLDN_HIP_OK;
+}
+
+void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_segs,
+                    &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta};
+  for (DevBuf* b : bufs) b->release();
+  for (int a = 0; a < kMaxAdaptive; ++a) {
+    c->d_cols[a].release();
+    c->d_ranks[a].release();
+  }
+  c->h_stage.release();
+  c->h_result.release();
+  for (hipEvent_t& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int cldn_hip_codec_synchronize(cldn_hip_codec_t* c) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return CLDN_HIP_OK;
+}
+
+void* cldn_hip_codec_stream(cldn_hip_codec_t* c) { return c ? (void*)c->stream : nullptr; }
+
+int cldn_hip_codec_enable_timing(cldn_hip_codec_t* c, int enable) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  if (enable && !c->ev[0]) {
+    for (hipEvent_t& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
+  }
+  c->timing = enable != 0;
+  c->ev_valid = false;
+  return CLDN_HIP_OK;
+}
+
+int cldn_hip_codec_last_kernel_ms(cldn_hip_codec_t* c, float* regular_ms, float* sections_ms, float* compact_ms,
+                                  float* total_ms) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if (!c->timing || !c->ev_valid) return fail(CLDN_HIP_ERR_ARG, "no timed call recorded");
+  HIP_TRY(hipEventSynchronize(c->ev[4]));
+  float t = 0.f;
+  if (regular_ms) {
+    HIP_TRY(hipEventElapsedTime(&t, c->ev[1], c->ev[2]));
+    *regular_ms = t;
+  }
+  if (sections_ms) {
+    HIP_TRY(hipEventElapsedTime(&t, c->ev[2], c->ev[3]));
+    *sections_ms = t;
+  }
+  if (compact_ms) {
+    HIP_TRY(hipEventElapsedTime(&t, c->ev[3], c->ev[4]));
+    *compact_ms = t;
+  }
+  if (total_ms) {
+    HIP_TRY(hipEventElapsedTime(&t, c->ev[0], c->ev[4]));
+    *total_ms = t;
+  }
+  return CLDN_HIP_OK;
+}
+
+int cldn_hip_codec_status(cldn_hip_codec_t* c) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->d_status.p) return CLDN_HIP_OK;
+  uint32_t st = 0;
+  HIP_TRY(hipMemcpyAsync(&st, c->d_status.p, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (st & ST_OUT_OVERFLOW) return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for the encoded stream");
+  if (st & ST_CORRUPT) return fail(CLDN_HIP_ERR_CORRUPT, "malformed stage-1 stream");
+  return CLDN_HIP_OK;
+}
+
+// Build (or reuse) the chunk table of a batch. Returns the number of chunks and total points.
+static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, uint32_t n_clouds,
+                              uint32_t* n_chunks_out, uint64_t* n_points_out) {
+  uint64_t total_points = 0;
+  uint64_t n_chunks64 = 0;
+  for (uint32_t k = 0; k < n_clouds; ++k) {
+    total_points += cloud_points[k];
+    n_chunks64 += (cloud_points[k] + kPointsPerChunk - 1) / kPointsPerChunk;
+  }
+  if (n_chunks64 > 0x3fffffffull) return fail(CLDN_HIP_ERR_ARG, "batch too large");
+  const uint32_t n_chunks = (uint32_t)n_chunks64;
+  *n_chunks_out = n_chunks;
+  *n_points_out = total_points;
+  const bool same = c->last_cloud_points.size() == n_clouds && c->last_n_chunks == n_chunks &&
+                    std::equal(c->last_cloud_points.begin(), c->last_cloud_points.end(), cloud_points);
+  int rc;
+  if ((rc = c->d_chunks.ensure(std::max<size_t>(1, n_chunks) * sizeof(ChunkDesc))) != CLDN_HIP_OK) return rc;
+  if ((rc = c->d_cloud_first.ensure((size_t)(n_clouds + 1) * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
+  if (same) return CLDN_HIP_OK;
+
+  const size_t bytes = (size_t)n_chunks * sizeof(ChunkDesc) + (size_t)(n_clouds + 1) * sizeof(uint32_t);
+  // the staging buffer may still be in flight from the previous (asynchronous) call
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if ((rc = c->h_stage.ensure(bytes)) != CLDN_HIP_OK) return rc;
+  ChunkDesc* hc = (ChunkDesc*)c->h_stage.p;
+  uint32_t* hf = (uint32_t*)((uint8_t*)c->h_stage.p + (size_t)n_chunks * sizeof(ChunkDesc));
+  uint64_t first = 0;
+  uint32_t ci = 0;
+  for (uint32_t k = 0; k < n_clouds; ++k) {
+    hf[k] = ci;
+    uint64_t left = cloud_points[k];
+    uint32_t j = 0;
+    while (left > 0) {
+      const uint32_t n = (uint32_t)std::min<uint64_t>(left, kPointsPerChunk);
+      ChunkDesc& cd = hc[ci++];
+      cd.first_point = first;
+      cd.n_points = n;
+      cd.cloud = k;
+      cd.chunk_in_cloud = j++;
+      cd.reserved = 0;
+      first += n;
+      left -= n;
+    }
+  }
+  hf[n_clouds] = ci;
+  if (n_chunks)
+    HIP_TRY(hipMemcpyAsync(c->d_chunks.p, hc, (size_t)n_chunks * sizeof(ChunkDesc), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_cloud_first.p, hf, (size_t)(n_clouds + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
+                         c->stream));
+  c->last_cloud_points.assign(cloud_points, cloud_points + n_clouds);
+  c->last_n_chunks = n_chunks;
+  return CLDN_HIP_OK;
+}
+
+int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_loc, const uint64_t* cloud_points,
+                           uint32_t n_clouds, void* out, uint64_t out_capacity, int out_loc,
+                           uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if (n_clouds && !cloud_points) return fail(CLDN_HIP_ERR_ARG, "cloud_points is NULL");
+  if ((points_loc != CLDN_HIP_HOST && points_loc != CLDN_HIP_DEVICE) ||
+      (out_loc != CLDN_HIP_HOST && out_loc != CLDN_HIP_DEVICE))
+    return fail(CLDN_HIP_ERR_ARG, "invalid memory location tag");
+  HIP_TRY(hipSetDevice(c->device));
+  const DevPlan& plan = c->plan.dev;
+  const uint32_t step = plan.point_step;
+
+  uint32_t n_chunks = 0;
+  uint64_t n_points = 0;
+  int rc = upload_batch_shape(c, cloud_points, n_clouds, &n_chunks, &n_points);
+  if (rc != CLDN_HIP_OK) return rc;
+  if (n_points && !points) return fail(CLDN_HIP_ERR_ARG, "points is NULL");
+
+  // capacity contract of PointcloudEncoder::encode (cloudini.cpp:531-534)
+  uint64_t need = 0;
+  for (uint32_t k = 0; k < n_clouds; ++k) need += cldn_hip_stage1_bound(&c->plan, cloud_points[k]);
+  if (out_capacity < need)
+    return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for worst-case compressed size (%llu < %llu)",
+                (unsigned long long)out_capacity, (unsigned long long)need);
+  if (need && !out) return fail(CLDN_HIP_ERR_ARG, "out is NULL");
+
+  const uint32_t n_adaptive = plan.n_adaptive;
+  const uint32_t segs_per_chunk = 1u + 2u * n_adaptive;
+  const uint64_t reg_stride = (((uint64_t)kPointsPerChunk * plan.max_regular_bytes + 64u) + 255u) & ~uint64_t(255);
+  const uint64_t slot_stride = reg_stride + (uint64_t)n_adaptive * kSectionStride;
+
+  if ((rc = c->d_status.ensure(256)) != CLDN_HIP_OK) return rc;
+  if ((rc = c->d_offsets.ensure((size_t)(n_clouds + 1) * sizeof(uint64_t))) != CLDN_HIP_OK) return rc;
+  if ((rc = c->d_modes.ensure(std::max<size_t>(1, (size_t)n_clouds * std::max(1u, n_adaptive)))) != CLDN_HIP_OK)
+    return rc;
+  HIP_TRY(hipMemsetAsync(c->d_status.p, 0, 256, c->stream));
+
+  const uint8_t* d_points = (const uint8_t*)points;
+  uint8_t* d_outp = (uint8_t*)out;
+  if (n_chunks) {
+    if ((rc = c->d_segs.ensure((size_t)n_chunks * segs_per_chunk * sizeof(Seg))) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_payload.ensure((size_t)n_chunks * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_dst.ensure((size_t)n_chunks * sizeof(uint64_t))) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_slots.ensure((size_t)n_chunks * slot_stride)) != CLDN_HIP_OK) return rc;
+    for (uint32_t a = 0; a < n_adaptive; ++a) {
+      if ((rc = c->d_cols[a].ensure((size_t)n_points * plan.adaptive[a].bpv + 64)) != CLDN_HIP_OK) return rc;
+      if ((rc = c->d_ranks[a].ensure((size_t)n_points * 2 + 64)) != CLDN_HIP_OK) return rc;
+    }
+    if (points_loc == CLDN_HIP_HOST) {
+      if ((rc = c->d_in.ensure((size_t)n_points * step)) != CLDN_HIP_OK) return rc;
+      HIP_TRY(hipMemcpyAsync(c->d_in.p, points, (size_t)n_points * step, hipMemcpyHostToDevice, c->stream));
+      d_points = (const uint8_t*)c->d_in.p;
+    }
+    if (out_loc == CLDN_HIP_HOST) {
+      if ((rc = c->d_out.ensure((size_t)need)) != CLDN_HIP_OK) return rc;
+      d_outp = (uint8_t*)c->d_out.p;
+    }
+    if (n_adaptive) HIP_TRY(hipMemsetAsync(c->d_segs.p, 0, (size_t)n_chunks * segs_per_chunk * sizeof(Seg), c->stream));
+  }
+
+  EncodeLaunch L;
+  memset(&L, 0, sizeof(L));
+  L.plan = &plan;
+  L.stream = c->stream;
+  L.points = d_points;
+  L.points_end = d_points + (size_t)n_points * step;
+  L.chunks = (const ChunkDesc*)c->d_chunks.p;
+  L.n_chunks = n_chunks;
+  L.n_clouds = n_clouds;
+  L.cloud_first_chunk = (const uint32_t*)c->d_cloud_first.p;
+  L.slots = (uint8_t*)c->d_slots.p;
+  L.slot_stride = slot_stride;
+  L.reg_stride = reg_stride;
+  L.segs = (Seg*)c->d_segs.p;
+  L.segs_per_chunk = segs_per_chunk;
+  for (uint32_t a = 0; a < n_adaptive; ++a) {
+    L.cols.p[a] = (uint8_t*)c->d_cols[a].p;
+    L.ranks[a] = (uint16_t*)c->d_ranks[a].p;
+  }
+  L.chunk_payload = (uint32_t*)c->d_payload.p;
+  L.chunk_dst = (uint64_t*)c->d_dst.p;
+  L.stream_offsets = (uint64_t*)c->d_offsets.p;
+  L.modes = (uint8_t*)c->d_modes.p;
+  L.out = d_outp;
+  L.out_capacity = out_capacity;
+  L.status = (uint32_t*)c->d_status.p;
+  L.events = c->timing ? c->ev : nullptr;
+  rc = stage1_launch_encode(L);
+  if (rc != CLDN_HIP_OK) return rc;
+  c->ev_valid = c->timing;
+
+  const size_t modes_bytes = (size_t)n_clouds * n_adaptive;
+  if (out_loc == CLDN_HIP_DEVICE) {
+    if (stream_offsets)
+      HIP_TRY(hipMemcpyAsync(stream_offsets, c->d_offsets.p, (size_t)(n_clouds + 1) * sizeof(uint64_t),
+                             hipMemcpyDeviceToDevice, c->stream));
+    if (chunk_sizes && n_chunks)
+      HIP_TRY(hipMemcpyAsync(chunk_sizes, c->d_payload.p, (size_t)n_chunks * sizeof(uint32_t),
+                             hipMemcpyDeviceToDevice, c->stream));
+    if (modes && modes_bytes)
+      HIP_TRY(hipMemcpyAsync(modes, c->d_modes.p, modes_bytes, hipMemcpyDeviceToDevice, c->stream));
+    return CLDN_HIP_OK;
+  }
+
+  // host outputs: read the sizes back first, then exactly the produced bytes
+  if ((rc = c->h_result.ensure((size_t)(n_clouds + 1) * sizeof(uint64_t) + 64)) != CLDN_HIP_OK) return rc;
+  uint64_t* h_off = (uint64_t*)c->h_result.p;
+  uint32_t* h_status = (uint32_t*)((uint8_t*)c->h_result.p + (size_t)(n_clouds + 1) * sizeof(uint64_t));
+  HIP_TRY(hipMemcpyAsync(h_off, c->d_offsets.p, (size_t)(n_clouds + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                         c->stream));
+  HIP_TRY(hipMemcpyAsync(h_status, c->d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (*h_status & ST_OUT_OVERFLOW)
+    return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for uncompressed chunk");  // chunk_writer.cpp:34-36
+  const uint64_t total = h_off[n_clouds];
+  if (total) HIP_TRY(hipMemcpyAsync(out, d_outp, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+  if (chunk_sizes && n_chunks)
+    HIP_TRY(hipMemcpyAsync(chunk_sizes, c->d_payload.p, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           c->stream));
+  if (modes && modes_bytes) HIP_TRY(hipMemcpyAsync(modes, c->d_modes.p, modes_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (stream_offsets) memcpy(stream_offsets, h_off, (size_t)(n_clouds + 1) * sizeof(uint64_t));
+  return CLDN_HIP_OK;
+}
+
+int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams_loc, const uint64_t* stream_offsets,
+                           const uint64_t* cloud_points, uint32_t n_clouds, void* points_out, uint64_t out_capacity,
+                           int out_loc) {
+  (void)c; (void)streams; (void)streams_loc; (void)stream_offsets; (void)cloud_points; (void)n_clouds;
+  (void)points_out; (void)out_capacity; (void)out_loc;
+  return fail(CLDN_HIP_ERR_UNSUPPORTED, "cldn_hip_decode_stage1: decode kernels not built yet");
+}
+
+}  // extern "C"

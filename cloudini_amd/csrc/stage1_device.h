@@ -1,0 +1,90 @@
+// stage1_device.h -- structures shared by the host side of the C ABI (hip_abi.hip) and the kernels.
+#pragma once
+
+#include <stdint.h>
+
+namespace cldn {
+
+constexpr uint32_t kPointsPerChunk = 32768;  // detail::kPointsPerChunk, src/codec_common.hpp:28
+constexpr uint32_t kProbePoints = 4096;      // kAdaptiveModeProbePoints, src/v5_codec.cpp:76
+constexpr int kMaxOps = 32;                  // regular tokens per point this build supports
+constexpr int kMaxAdaptive = 16;             // V5 adaptive-int fields per schema this build supports
+constexpr uint32_t kMaxPointStep = 256;         // 64-point tiles of a 1024-thread workgroup still fit the LDS tile
+
+// One regular token per point. A FieldEncoderFloatN_Lossy (3 or 4 fused floats) is flattened into 3-4 OP_QF32
+// ops: its lanes are independent (src/field_encoder.cpp:42-91) and emit in lane order.
+enum : uint8_t {
+  OP_QF32 = 0,       // FloatN lane: float32 * m, round-half-even, int32 wrap-around delta, varint / NaN marker
+  OP_LOSSY_F32 = 1,  // FieldEncoderFloat_Lossy<float>: std::round, int64 delta
+  OP_LOSSY_F64 = 2,  // FieldEncoderFloat_Lossy<double>
+  OP_INT = 3,        // FieldEncoderInt<T>: int64 delta varint
+  OP_COPY = 4,       // FieldEncoderCopy: raw bytes
+  OP_XOR32 = 5,      // FieldEncoderFloat_XOR<float>
+  OP_XOR64 = 6       // FieldEncoderFloat_XOR<double>
+};
+
+struct DevOp {
+  uint8_t kind;
+  uint8_t type;       // Cloudini::FieldType (OP_INT)
+  uint8_t size;       // field size in bytes
+  uint8_t max_bytes;  // worst-case encoded bytes
+  uint32_t offset;    // field offset inside the point; 0xFFFFFFFF on decode = kDecodeButSkipStore
+  float mult_f;       // encode multiplier (float paths)
+  float res_f;        // decode multiplier
+  double mult_d;
+  double res_d;
+};
+
+struct DevAdaptive {
+  uint32_t offset;
+  uint8_t type;
+  uint8_t bpv;
+  uint8_t pad[2];
+};
+
+struct DevPlan {
+  uint32_t point_step;
+  uint32_t n_ops;
+  uint32_t n_adaptive;
+  uint32_t max_regular_bytes;  // worst-case regular-stream bytes per point
+  uint32_t min_regular_bytes;  // best case (decode sanity checks)
+  uint32_t all_varint;         // every regular op is a varint/NaN token (decode can find token ends by MSB)
+  DevOp ops[kMaxOps];
+  DevAdaptive adaptive[kMaxAdaptive];
+};
+
+// One 32768-point chunk of one cloud of the batch.
+struct ChunkDesc {
+  uint64_t first_point;     // index into the batch's concatenated point array
+  uint32_t n_points;        // 1..32768
+  uint32_t cloud;           // cloud index in the batch
+  uint32_t chunk_in_cloud;  // 0 = the chunk whose first 4096 points decide the adaptive modes
+  uint32_t reserved;
+};
+
+// A piece of a chunk's payload, produced by one kernel into the chunk's slot; the compaction kernel
+// concatenates a chunk's segments in index order behind the [u32 size] prefix.
+struct Seg {
+  uint32_t off;   // byte offset inside the chunk slot (multiple of 16)
+  uint32_t size;  // bytes
+};
+
+struct ColumnPtrs {
+  uint8_t* p[kMaxAdaptive];  // SoA copies of the adaptive-int fields: value i of the batch at p[a] + i*bpv
+};
+
+// Slot layout of one chunk (all offsets multiples of 256):
+//   [0, reg_stride)                        regular stream
+//   [reg_stride + a*sec_stride, ...)       section of adaptive field a; Palette uses two segments inside it
+constexpr uint32_t kSectionStride = 409600;  // >= 5 + 32768*11 (DeltaRle worst case), and
+                                             // >= align256(3 + 32768*8) + 32768*15/8 (Palette worst case)
+constexpr uint32_t kPaletteIndexOffset = 262400;  // align256(3 + 32768*8)
+
+// status word bits (device side, sticky)
+enum : uint32_t {
+  ST_OUT_OVERFLOW = 1u,   // compacted stream did not fit the output capacity
+  ST_CORRUPT = 2u,        // decode: malformed input
+  ST_PALETTE_FULL = 4u    // internal: LDS palette table overflowed (handled by the global-table path)
+};
+
+}  // namespace cldn

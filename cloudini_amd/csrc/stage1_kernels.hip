@@ -1,0 +1,553 @@
+// stage1_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Cloudini stage-1 encoder.
+//
+// Work decomposition: one workgroup per 32768-point chunk. All encoder state of the reference
+// resets at a chunk boundary (src/v4_codec.cpp:69, src/v5_codec.cpp:910-915), so chunks are independent; inside
+// a chunk the only sequential quantity is the output byte position, which becomes a loop-carried scalar of the
+// workgroup's tile loop plus one block-wide prefix sum per tile.
+//
+//   k_encode_regular   AoS tile -> LDS (coalesced 16 B/lane), per point: quantise / delta against the previous
+//                      point / varint tokens; block scan of token bytes; tokens OR-ed into an LDS byte ring;
+//                      ring flushed with 16 B/lane stores. Also splits the V5 adaptive-int fields out into SoA
+//                      columns (the "AoS->SoA channel split") for the section kernel.
+//   k_chunk_offsets    exclusive scan of (4 + payload) over the batch's chunks.
+//   k_compact          concatenates each chunk's segments behind its [u32 size] prefix into the final framed
+//                      stream (byte-exact, arbitrary destination alignment).
+//
+// This is integer / bit-pack work bounded by HBM bandwidth: no MFMA anywhere.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stage1_device.h"
+#include "stage1_math.h"
+
+namespace cldn {
+
+// ------------------------------------------------------------------------------------------------------------
+// wave / block primitives (wave64)
+// ------------------------------------------------------------------------------------------------------------
+
+// inclusive prefix sum across the 64 lanes of a wave using DPP row shifts + row broadcasts
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+  return x;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(x), 63);
+}
+
+// Block-wide exclusive prefix sum of one uint32 per thread. `wtot` is an LDS array of >= 32 uint32. Contains
+// one __syncthreads(); the caller must separate two consecutive calls (or other uses of wtot) by a barrier.
+template <int T>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t* wtot, uint32_t* total) {
+  constexpr int NW = T / 64;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t incl = wave_inclusive_scan(x);
+  if (lane == 63u) wtot[wave] = incl;
+  __syncthreads();
+  const uint32_t wt = (lane < (uint32_t)NW) ? wtot[lane] : 0u;
+  const uint32_t wincl = wave_inclusive_scan(wt);
+  const uint32_t base = (wave == 0u) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)wincl, (int)wave - 1);
+  *total = (uint32_t)__builtin_amdgcn_readlane((int)wincl, NW - 1);
+  return base + incl - x;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LDS helpers
+// ------------------------------------------------------------------------------------------------------------
+
+// 4 bytes at an arbitrary byte offset of an LDS dword array (reads 2 dwords; buffers carry 8 bytes of slack)
+__device__ __forceinline__ uint32_t lds_u32(const uint32_t* base, uint32_t byte_off) {
+  const uint32_t i = byte_off >> 2;
+  const uint32_t lo = base[i];
+  const uint32_t hi = base[i + 1];
+  return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> ((byte_off & 3u) * 8u));
+}
+__device__ __forceinline__ uint64_t lds_u64(const uint32_t* base, uint32_t byte_off) {
+  const uint32_t i = byte_off >> 2;
+  const uint32_t a = base[i], b = base[i + 1], c = base[i + 2];
+  const uint32_t sh = (byte_off & 3u) * 8u;
+  const uint32_t lo = (uint32_t)(((((uint64_t)b) << 32) | a) >> sh);
+  const uint32_t hi = (uint32_t)(((((uint64_t)c) << 32) | b) >> sh);
+  return (((uint64_t)hi) << 32) | lo;
+}
+__device__ __forceinline__ uint64_t lds_raw(const uint32_t* base, uint32_t byte_off, uint32_t nbytes) {
+  if (nbytes == 8u) return lds_u64(base, byte_off);
+  const uint32_t v = lds_u32(base, byte_off);
+  return nbytes == 4u ? v : (nbytes == 2u ? (v & 0xffffu) : (v & 0xffu));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// byte-stream writer: tokens are OR-ed into a zero-initialised LDS ring at their stream byte offset, the ring
+// is flushed to global memory in whole 16-byte units (coalesced dwordx4 stores) and re-zeroed as it drains.
+// ------------------------------------------------------------------------------------------------------------
+
+constexpr uint32_t kRingBytes = 16384;
+constexpr uint32_t kRingDw = kRingBytes / 4;
+constexpr uint32_t kRingU4 = kRingBytes / 16;
+
+template <bool WINDOWED>
+__device__ __forceinline__ void ring_or(uint32_t* ring, uint32_t g, uint32_t d, uint32_t win_lo_dw) {
+  if (d == 0u) return;
+  if (WINDOWED) {
+    if (g < win_lo_dw || g >= win_lo_dw + kRingDw) return;
+  }
+  atomicOr(&ring[g & (kRingDw - 1u)], d);
+}
+
+// OR token `t` (<= 12 bytes) into the ring at stream byte offset `off`
+template <bool WINDOWED>
+__device__ __forceinline__ void ring_put(uint32_t* ring, uint32_t off, const Tok t, uint32_t win_lo_dw) {
+  const uint32_t sh = (off & 3u) * 8u;
+  const uint32_t g = off >> 2;
+  const uint64_t lo = ((((uint64_t)t.w1) << 32) | t.w0) << sh;
+  ring_or<WINDOWED>(ring, g, (uint32_t)lo, win_lo_dw);
+  if (((off & 3u) + t.len) > 4u) {
+    ring_or<WINDOWED>(ring, g + 1u, (uint32_t)(lo >> 32), win_lo_dw);
+    if (((off & 3u) + t.len) > 8u) {
+      const uint64_t hi = ((((uint64_t)t.w2) << 32) | t.w1) << sh;
+      ring_or<WINDOWED>(ring, g + 2u, (uint32_t)(hi >> 32), win_lo_dw);
+      ring_or<WINDOWED>(ring, g + 3u, (uint32_t)((((uint64_t)t.w2) << sh) >> 32), win_lo_dw);
+    }
+  }
+}
+
+// flush ring bytes [from, to) (both multiples of 16) to dst + offset and zero them in the ring
+template <int T>
+__device__ __forceinline__ void ring_flush(uint32_t* ring, uint8_t* dst, uint32_t from, uint32_t to) {
+  uint4* ring4 = reinterpret_cast<uint4*>(ring);
+  for (uint32_t u = (from >> 4) + threadIdx.x; u < (to >> 4); u += T) {
+    const uint32_t r = u & (kRingU4 - 1u);
+    const uint4 v = ring4[r];
+    *reinterpret_cast<uint4*>(dst + (size_t)u * 16u) = v;
+    ring4[r] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+// State of one output stream of a workgroup (uniform across the block).
+struct StreamState {
+  uint32_t R;  // bytes produced so far
+  uint32_t F;  // bytes flushed so far (multiple of 16, F <= R)
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// k_encode_regular
+// ------------------------------------------------------------------------------------------------------------
+
+struct PointRef {
+  uint32_t cur;       // LDS byte offset of this thread's point
+  uint32_t prev;      // LDS byte offset of the previous point of the chunk (valid if has_prev)
+  bool has_prev;
+};
+
+// Evaluate regular op `op` for one point. EMIT=false: only the token length.
+template <bool EMIT>
+__device__ __forceinline__ Tok eval_op(const DevOp& op, const uint32_t* tile, const PointRef p) {
+  Tok t;
+  t.w0 = t.w1 = t.w2 = 0;
+  t.len = 0;
+  switch (op.kind) {
+    case OP_QF32: {  // src/field_encoder.cpp:42-91
+      const float v = __uint_as_float(lds_u32(tile, p.cur + op.offset));
+      if (is_nan_f32(v)) {
+        t.len = 1;  // marker byte 0x00
+        break;
+      }
+      int32_t prevq = 0;
+      if (p.has_prev) {
+        const float pv = __uint_as_float(lds_u32(tile, p.prev + op.offset));
+        prevq = is_nan_f32(pv) ? 0 : quant_rne_i32(pv, op.mult_f);  // NaN resets that lane's prev to 0
+      }
+      const int32_t d = (int32_t)((uint32_t)quant_rne_i32(v, op.mult_f) - (uint32_t)prevq);
+      if (EMIT) t = varint32_tok(d);
+      else t.len = varint32_len(d);
+    } break;
+    case OP_LOSSY_F32: {  // include/cloudini_lib/field_encoder.hpp:342-357
+      const float v = __uint_as_float(lds_u32(tile, p.cur + op.offset));
+      if (is_nan_f32(v)) {
+        t.len = 1;
+        break;
+      }
+      int64_t prevq = 0;
+      if (p.has_prev) {
+        const float pv = __uint_as_float(lds_u32(tile, p.prev + op.offset));
+        prevq = is_nan_f32(pv) ? 0 : quant_away_i64_f32(pv, op.mult_f);
+      }
+      const int64_t d = (int64_t)((uint64_t)quant_away_i64_f32(v, op.mult_f) - (uint64_t)prevq);
+      if (EMIT) t = varint64_tok(d);
+      else t.len = varint64_len(d);
+    } break;
+    case OP_LOSSY_F64: {
+      const double v = __longlong_as_double((long long)lds_u64(tile, p.cur + op.offset));
+      if (is_nan_f64(v)) {
+        t.len = 1;
+        break;
+      }
+      int64_t prevq = 0;
+      if (p.has_prev) {
+        const double pv = __longlong_as_double((long long)lds_u64(tile, p.prev + op.offset));
+        prevq = is_nan_f64(pv) ? 0 : quant_away_i64_f64(pv, op.mult_d);
+      }
+      const int64_t d = (int64_t)((uint64_t)quant_away_i64_f64(v, op.mult_d) - (uint64_t)prevq);
+      if (EMIT) t = varint64_tok(d);
+      else t.len = varint64_len(d);
+    } break;
+    case OP_INT: {  // include/cloudini_lib/field_encoder.hpp:78-85
+      const int64_t v = int_field_as_i64(lds_raw(tile, p.cur + op.offset, op.size), op.type);
+      const int64_t pv = p.has_prev ? int_field_as_i64(lds_raw(tile, p.prev + op.offset, op.size), op.type) : 0;
+      const int64_t d = (int64_t)((uint64_t)v - (uint64_t)pv);
+      if (EMIT) t = varint64_tok(d);
+      else t.len = varint64_len(d);
+    } break;
+    case OP_COPY: {  // include/cloudini_lib/field_encoder.hpp:56-60
+      if (EMIT) t = raw_tok(lds_raw(tile, p.cur + op.offset, op.size), op.size);
+      else t.len = op.size;
+    } break;
+    case OP_XOR32:
+    case OP_XOR64: {  // include/cloudini_lib/field_encoder.hpp:359-370
+      if (EMIT) {
+        const uint64_t v = lds_raw(tile, p.cur + op.offset, op.size);
+        const uint64_t pv = p.has_prev ? lds_raw(tile, p.prev + op.offset, op.size) : 0;
+        t = raw_tok(v ^ pv, op.size);
+      } else {
+        t.len = op.size;
+      }
+    } break;
+    default:
+      break;
+  }
+  return t;
+}
+
+struct TileGeom {
+  const uint8_t* a0;   // 16-byte aligned global address of the first staged unit
+  uint32_t units;      // 16-byte units to stage
+  uint32_t first_off;  // LDS byte offset of the tile's first point
+  uint32_t npts;       // points in the tile
+  uint32_t p0;         // index of the tile's first point inside the chunk
+};
+
+__device__ __forceinline__ TileGeom tile_geom(const uint8_t* gchunk, uint32_t step, uint32_t P, uint32_t n,
+                                              uint32_t it) {
+  TileGeom g;
+  g.p0 = it * P;
+  g.npts = min(P, n - g.p0);
+  const uint32_t lead = (it > 0u) ? step : 0u;  // stage the previous point too (delta reference)
+  const uint8_t* ga0 = gchunk + (size_t)g.p0 * step - lead;
+  const uint32_t mis = (uint32_t)((uintptr_t)ga0 & 15u);
+  g.a0 = ga0 - mis;
+  g.units = (mis + lead + g.npts * step + 15u) >> 4;
+  g.first_off = mis + lead;
+  return g;
+}
+
+// 16 bytes from global memory; bytes outside [lo, hi) are never touched (first/last unit of a buffer whose
+// base or end is not 16-byte aligned)
+__device__ __forceinline__ uint4 load_unit_guarded(const uint8_t* addr, const uint8_t* lo, const uint8_t* hi) {
+  if (addr >= lo && addr + 16 <= hi) {
+    return *reinterpret_cast<const uint4*>(addr);
+  }
+  uint32_t w[4] = {0u, 0u, 0u, 0u};
+  for (int k = 0; k < 16; ++k) {
+    const uint8_t* q = addr + k;
+    if (q >= lo && q < hi) w[k >> 2] |= ((uint32_t)(*q)) << ((k & 3) * 8);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const uint8_t* __restrict__ points,
+                                                      const uint8_t* points_end,
+                                                      const ChunkDesc* __restrict__ chunks,
+                                                      uint8_t* __restrict__ slots, uint64_t slot_stride,
+                                                      Seg* __restrict__ segs, uint32_t segs_per_chunk,
+                                                      const ColumnPtrs cols) {
+  constexpr uint32_t kTileLds = T * 16u + kMaxPointStep + 48u;  // multiple of 16
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* ring = reinterpret_cast<uint32_t*>(smem + 2u * kTileLds);
+  uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + 2u * kTileLds + kRingBytes);
+
+  const uint32_t tid = threadIdx.x;
+  const ChunkDesc cd = chunks[blockIdx.x];
+  const uint32_t step = plan.point_step;
+  const uint32_t n = cd.n_points;
+  const uint32_t P = min((uint32_t)T, ((T * 16u) / step) & ~63u);  // points per tile (multiple of 64)
+  const uint32_t n_tiles = (n + P - 1u) / P;
+  const uint8_t* gchunk = points + (size_t)cd.first_point * step;
+  uint8_t* slot = slots + (size_t)blockIdx.x * slot_stride;
+
+  // zero the ring
+  for (uint32_t i = tid; i < kRingU4; i += T) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+  // stage tile 0
+  TileGeom g = tile_geom(gchunk, step, P, n, 0u);
+  for (uint32_t u = tid; u < g.units; u += T) {
+    reinterpret_cast<uint4*>(smem)[u] = load_unit_guarded(g.a0 + (size_t)u * 16u, points, points_end);
+  }
+  __syncthreads();
+
+  StreamState ss;
+  ss.R = 0u;
+  ss.F = 0u;
+
+  for (uint32_t it = 0; it < n_tiles; ++it) {
+    const uint32_t* tile = reinterpret_cast<const uint32_t*>(smem + (it & 1u) * kTileLds);
+    uint32_t* tile_next = reinterpret_cast<uint32_t*>(smem + ((it + 1u) & 1u) * kTileLds);
+
+    // issue the global loads of the next tile now; they land in LDS at the end of this iteration
+    TileGeom gn;
+    gn.units = 0u;
+    uint4 pre0 = make_uint4(0u, 0u, 0u, 0u), pre1 = pre0;
+    if (it + 1u < n_tiles) {
+      gn = tile_geom(gchunk, step, P, n, it + 1u);
+      if (tid < gn.units) pre0 = load_unit_guarded(gn.a0 + (size_t)tid * 16u, points, points_end);
+      if (tid + T < gn.units) pre1 = load_unit_guarded(gn.a0 + (size_t)(tid + T) * 16u, points, points_end);
+    }
+
+    const bool active = tid < g.npts;
+    PointRef pr;
+    pr.cur = g.first_off + tid * step;
+    pr.prev = pr.cur - step;
+    pr.has_prev = (g.p0 + tid) > 0u;
+
+    // pass A: bytes this point contributes to the regular stream
+    uint32_t my_len = 0u;
+    if (active) {
+      for (uint32_t k = 0; k < plan.n_ops; ++k) my_len += eval_op<false>(plan.ops[k], tile, pr).len;
+    }
+    uint32_t tile_total;
+    const uint32_t excl = block_exclusive_scan<T>(my_len, wtot, &tile_total);
+
+    const uint32_t r_end = ss.R + tile_total;
+    const bool last = (it + 1u == n_tiles);
+    const uint32_t target = last ? ((r_end + 15u) & ~15u) : (r_end & ~15u);
+
+    if (r_end - ss.F <= kRingBytes) {
+      // common case: the whole tile fits the ring
+      if (active) {
+        uint32_t off = ss.R + excl;
+        for (uint32_t k = 0; k < plan.n_ops; ++k) {
+          const Tok t = eval_op<true>(plan.ops[k], tile, pr);
+          ring_put<false>(ring, off, t, 0u);
+          off += t.len;
+        }
+      }
+      __syncthreads();
+      ring_flush<T>(ring, slot, ss.F, target);
+      ss.F = target;
+    } else {
+      // rare: huge tokens (many wide fields); emit in ring-sized windows
+      for (;;) {
+        if (active) {
+          uint32_t off = ss.R + excl;
+          for (uint32_t k = 0; k < plan.n_ops; ++k) {
+            const Tok t = eval_op<true>(plan.ops[k], tile, pr);
+            ring_put<true>(ring, off, t, ss.F >> 2);
+            off += t.len;
+          }
+        }
+        __syncthreads();
+        const uint32_t nf = min(ss.F + kRingBytes, target);
+        ring_flush<T>(ring, slot, ss.F, nf);
+        const bool done = (ss.F + kRingBytes >= r_end);
+        ss.F = nf;
+        if (done) break;
+        __syncthreads();
+      }
+    }
+    ss.R = r_end;
+
+    // AoS -> SoA split of the adaptive-int fields
+    if (active) {
+      const size_t gi = (size_t)cd.first_point + g.p0 + tid;
+      for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
+        const uint32_t bpv = plan.adaptive[a].bpv;
+        const uint64_t raw = lds_raw(tile, pr.cur + plan.adaptive[a].offset, bpv);
+        uint8_t* col = cols.p[a];
+        if (bpv == 2u) reinterpret_cast<uint16_t*>(col)[gi] = (uint16_t)raw;
+        else if (bpv == 4u) reinterpret_cast<uint32_t*>(col)[gi] = (uint32_t)raw;
+        else reinterpret_cast<uint64_t*>(col)[gi] = raw;
+      }
+    }
+
+    // land the prefetched tile
+    if (it + 1u < n_tiles) {
+      if (tid < gn.units) reinterpret_cast<uint4*>(tile_next)[tid] = pre0;
+      if (tid + T < gn.units) reinterpret_cast<uint4*>(tile_next)[tid + T] = pre1;
+      g = gn;
+    }
+    __syncthreads();
+  }
+
+  if (tid == 0) {
+    Seg s;
+    s.off = 0u;
+    s.size = ss.R;
+    segs[(size_t)blockIdx.x * segs_per_chunk] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_chunk_offsets: payload size of every chunk, exclusive scan of the framed sizes (4 + payload), per-cloud
+// stream offsets. One workgroup.
+// ------------------------------------------------------------------------------------------------------------
+
+template <int T>
+__global__ __launch_bounds__(T) void k_chunk_offsets(const Seg* __restrict__ segs, uint32_t segs_per_chunk,
+                                                     uint32_t n_chunks, const uint32_t* __restrict__ cloud_first_chunk,
+                                                     uint32_t n_clouds, uint32_t* __restrict__ chunk_payload,
+                                                     uint64_t* __restrict__ chunk_dst,
+                                                     uint64_t* __restrict__ stream_offsets) {
+  __shared__ uint32_t wtot[32];
+  uint64_t running = 0;
+  for (uint32_t base = 0; base < n_chunks; base += T) {
+    const uint32_t c = base + threadIdx.x;
+    uint32_t framed = 0u;
+    if (c < n_chunks) {
+      uint32_t payload = 0u;
+      for (uint32_t s = 0; s < segs_per_chunk; ++s) payload += segs[(size_t)c * segs_per_chunk + s].size;
+      chunk_payload[c] = payload;
+      framed = payload + 4u;
+    }
+    uint32_t total;
+    const uint32_t excl = block_exclusive_scan<T>(framed, wtot, &total);
+    if (c < n_chunks) chunk_dst[c] = running + excl;
+    running += total;
+    __syncthreads();
+  }
+  __syncthreads();
+  // stream offset of cloud k = destination of its first chunk (clouds without chunks inherit the next one)
+  for (uint32_t k = threadIdx.x; k <= n_clouds; k += T) {
+    const uint32_t fc = (k < n_clouds) ? cloud_first_chunk[k] : n_chunks;
+    stream_offsets[k] = (fc < n_chunks) ? chunk_dst[fc] : running;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_compact: final framed stream. grid = (n_chunks, splits); each workgroup copies a 1/splits share of every
+// segment. Source segments start 16-byte aligned; the destination position is arbitrary.
+// ------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t funnel_bytes(uint32_t lo, uint32_t hi, uint32_t sb) {
+  return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sb * 8u));
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_compact(const uint8_t* __restrict__ slots, uint64_t slot_stride,
+                                               const Seg* __restrict__ segs, uint32_t segs_per_chunk,
+                                               const uint32_t* __restrict__ chunk_payload,
+                                               const uint64_t* __restrict__ chunk_dst, uint8_t* __restrict__ out,
+                                               uint64_t out_capacity, uint32_t* __restrict__ status) {
+  const uint32_t c = blockIdx.x;
+  const uint32_t payload = chunk_payload[c];
+  const uint64_t dst0 = chunk_dst[c];
+  if (dst0 + 4u + payload > out_capacity) {
+    if (threadIdx.x == 0 && blockIdx.y == 0) atomicOr(status, (uint32_t)ST_OUT_OVERFLOW);
+    return;
+  }
+  if (blockIdx.y == 0 && threadIdx.x < 4u) out[dst0 + threadIdx.x] = (uint8_t)(payload >> (8u * threadIdx.x));
+
+  const uint8_t* slot = slots + (size_t)c * slot_stride;
+  uint64_t d = dst0 + 4u;
+  for (uint32_t s = 0; s < segs_per_chunk; ++s) {
+    const Seg sg = segs[(size_t)c * segs_per_chunk + s];
+    if (sg.size == 0u) continue;
+    const uint8_t* src = slot + sg.off;
+    uint8_t* dst = out + d;
+    const uint32_t size = sg.size;
+    // head: bytes until dst is 16-byte aligned
+    const uint32_t head = min(size, (uint32_t)((16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u));
+    const uint32_t body_units = (size - head) >> 4;
+    const uint32_t tail = (size - head) & 15u;
+    if (blockIdx.y == 0) {
+      if (threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+      if (threadIdx.x >= 32u && threadIdx.x < 32u + tail) {
+        const uint32_t k = head + body_units * 16u + (threadIdx.x - 32u);
+        dst[k] = src[k];
+      }
+    }
+    // body: dst-aligned 16-byte units; source bytes [head + 16j, head + 16j + 16) straddle two aligned units
+    const uint32_t sdw = head >> 2, sb = head & 3u;
+    const uint4* src4 = reinterpret_cast<const uint4*>(src);
+    uint4* dst4 = reinterpret_cast<uint4*>(dst + head);
+    for (uint32_t j = blockIdx.y * T + threadIdx.x; j < body_units; j += gridDim.y * T) {
+      const uint4 a = src4[j];
+      uint4 b = make_uint4(0u, 0u, 0u, 0u);
+      if (head != 0u) b = src4[j + 1u];
+      uint32_t w0, w1, w2, w3, w4;
+      switch (sdw) {
+        case 0: w0 = a.x; w1 = a.y; w2 = a.z; w3 = a.w; w4 = b.x; break;
+        case 1: w0 = a.y; w1 = a.z; w2 = a.w; w3 = b.x; w4 = b.y; break;
+        case 2: w0 = a.z; w1 = a.w; w2 = b.x; w3 = b.y; w4 = b.z; break;
+        default: w0 = a.w; w1 = b.x; w2 = b.y; w3 = b.z; w4 = b.w; break;
+      }
+      uint4 o;
+      o.x = funnel_bytes(w0, w1, sb);
+      o.y = funnel_bytes(w1, w2, sb);
+      o.z = funnel_bytes(w2, w3, sb);
+      o.w = funnel_bytes(w3, w4, sb);
+      dst4[j] = o;
+    }
+    d += size;
+  }
+}
+
+}  // namespace cldn
+
+// ------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------
+#include "cloudini_hip.h"
+#include "stage1_launch.h"
+
+namespace cldn {
+
+namespace {
+constexpr int kRegularThreads = 1024;
+constexpr uint32_t kRegularLds = 2u * (kRegularThreads * 16u + kMaxPointStep + 48u) + kRingBytes + 128u;
+
+int hip_fail(hipError_t e, const char* what) {
+  fprintf(stderr, "[cloudini_hip] %s: %s\n", what, hipGetErrorString(e));
+  return CLDN_HIP_ERR_DEVICE;
+}
+}  // namespace
+
+int stage1_configure_kernels() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_regular<kRegularThreads>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRegularLds);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_regular)");
+  return CLDN_HIP_OK;
+}
+
+int stage1_launch_encode(const EncodeLaunch& L) {
+  hipError_t e;
+  if (L.events) (void)hipEventRecord(L.events[0], L.stream);
+  if (L.events) (void)hipEventRecord(L.events[1], L.stream);
+  if (L.n_chunks) {
+    hipLaunchKernelGGL(k_encode_regular<kRegularThreads>, dim3(L.n_chunks), dim3(kRegularThreads), kRegularLds,
+                       L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots, L.slot_stride, L.segs,
+                       L.segs_per_chunk, L.cols);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_regular");
+  }
+  if (L.events) (void)hipEventRecord(L.events[2], L.stream);
+  if (L.events) (void)hipEventRecord(L.events[3], L.stream);
+  hipLaunchKernelGGL(k_chunk_offsets<1024>, dim3(1), dim3(1024), 0, L.stream, L.segs, L.segs_per_chunk, L.n_chunks,
+                     L.cloud_first_chunk, L.n_clouds, L.chunk_payload, L.chunk_dst, L.stream_offsets);
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_chunk_offsets");
+  if (L.n_chunks) {
+    const uint32_t splits = L.n_chunks >= 1024u ? 1u : (L.n_chunks >= 256u ? 4u : 16u);
+    hipLaunchKernelGGL(k_compact<256>, dim3(L.n_chunks, splits), dim3(256), 0, L.stream, L.slots, L.slot_stride,
+                       L.segs, L.segs_per_chunk, L.chunk_payload, L.chunk_dst, L.out, L.out_capacity, L.status);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_compact");
+  }
+  if (L.events) (void)hipEventRecord(L.events[4], L.stream);
+  return CLDN_HIP_OK;
+}
+
+}  // namespace cldn

@@ -1,0 +1,40 @@
+// stage1_launch.h -- host-callable launchers implemented next to the kernels (stage1_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stage1_device.h"
+
+namespace cldn {
+
+struct EncodeLaunch {
+  const DevPlan* plan;
+  hipStream_t stream;
+  const uint8_t* points;      // device, batch AoS
+  const uint8_t* points_end;
+  const ChunkDesc* chunks;    // device [n_chunks]
+  uint32_t n_chunks;
+  uint32_t n_clouds;
+  const uint32_t* cloud_first_chunk;  // device [n_clouds + 1]
+  uint8_t* slots;             // device [n_chunks * slot_stride]
+  uint64_t slot_stride;
+  uint64_t reg_stride;
+  Seg* segs;                  // device [n_chunks * segs_per_chunk]
+  uint32_t segs_per_chunk;
+  ColumnPtrs cols;
+  uint16_t* ranks[kMaxAdaptive];
+  uint32_t* chunk_payload;    // device [n_chunks]
+  uint64_t* chunk_dst;        // device [n_chunks]
+  uint64_t* stream_offsets;   // device [n_clouds + 1]
+  uint8_t* modes;             // device [n_clouds * n_adaptive]
+  uint8_t* out;               // device, framed streams
+  uint64_t out_capacity;
+  uint32_t* status;           // device status word
+  hipEvent_t* events;         // 5 events (start, after probe, after regular, after sections, end) or NULL
+};
+
+int stage1_configure_kernels();
+int stage1_launch_encode(const EncodeLaunch& L);
+
+}  // namespace cldn

@@ -1,0 +1,128 @@
+/* cloudini_hip.h -- C ABI of the MI355X (gfx950) stage-1 codec: the drop-in boundary.
+ *
+ * What it replaces in the reference (paths under /root/reference/cloudini_lib):
+ *   detail::EncodeV5Stage1(...)        src/v5_codec.hpp:31-34, called from src/cloudini.cpp:590-599
+ *   detail::EncodeV4Stage1Chunk(...)   src/v4_codec.hpp:33-35, called from src/cloudini.cpp:608-614
+ *   detail::DecodeV5Stage1Chunk(...)   src/v5_codec.hpp:40-42, called from src/cloudini.cpp:677-679
+ *   detail::DecodeV4Stage1Chunk(...)   src/v4_codec.hpp:37-40, called from src/cloudini.cpp:680-683
+ * i.e. everything between "a contiguous AoS point buffer + EncodingInfo" and "stage-1 bytes per
+ * 32768-point chunk", in both directions. Header (YAML), [u32 size] framing of *compressed* chunks and
+ * LZ4/ZSTD stay on the host (cloudini_amd/csrc/host/).
+ *
+ * Conventions follow the reference's existing C ABI (include/cloudini_lib/wasm_functions.h:30-93):
+ * plain pointers and sizes, caller-allocated outputs, no exceptions across the boundary. Errors are
+ * negative return codes plus cldn_hip_last_error() (thread-local string).
+ *
+ * Wire format produced/consumed: the *framed stage-1 stream* of one cloud,
+ *     [u32 LE payload_size][payload] per chunk of <= 32768 points,
+ * byte-identical to what PointcloudEncoder::encode writes after its header when
+ * compression_opt == NONE (src/chunk_writer.cpp:32-39). For LZ4/ZSTD the host compresses each payload.
+ *
+ * Memory: every data pointer is tagged CLDN_HIP_HOST or CLDN_HIP_DEVICE. With DEVICE pointers a call only
+ * enqueues work on the codec's HIP stream (no synchronisation, outputs valid after the stream drains);
+ * with HOST outputs the call returns after the results are in host memory.
+ */
+#ifndef CLOUDINI_HIP_H
+#define CLOUDINI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLDN_HIP_ABI_VERSION 1
+#define CLDN_HIP_POINTS_PER_CHUNK 32768u /* detail::kPointsPerChunk, src/codec_common.hpp:28 */
+#define CLDN_HIP_PROBE_POINTS 4096u      /* kAdaptiveModeProbePoints, src/v5_codec.cpp:76 */
+
+/* Return codes. */
+enum {
+  CLDN_HIP_OK = 0,
+  CLDN_HIP_ERR_ARG = -1,          /* invalid argument / schema */
+  CLDN_HIP_ERR_CAPACITY = -2,     /* output buffer smaller than the worst-case bound (cloudini.cpp:531-534) */
+  CLDN_HIP_ERR_UNSUPPORTED = -3,  /* schema needs a codec this library has no kernel for (no CPU fallback) */
+  CLDN_HIP_ERR_DEVICE = -4,       /* HIP runtime error */
+  CLDN_HIP_ERR_NO_DEVICE = -5,    /* no usable GPU */
+  CLDN_HIP_ERR_CORRUPT = -6,      /* decode: malformed stream (truncated, bad mode byte, trailing bytes, ...) */
+  CLDN_HIP_ERR_NOMEM = -7
+};
+
+enum { CLDN_HIP_HOST = 0, CLDN_HIP_DEVICE = 1 };
+
+/* One Cloudini::PointField (include/cloudini_lib/basic_types.hpp:47-67) without its name. `type` is a
+ * Cloudini::FieldType value (1..10, == sensor_msgs/PointField datatype for 1..8). */
+typedef struct cldn_hip_field {
+  uint32_t offset;
+  uint8_t type;
+  uint8_t has_resolution;
+  uint8_t reserved[2];
+  float resolution;
+} cldn_hip_field_t;
+
+typedef struct cldn_hip_plan cldn_hip_plan_t;   /* immutable: schema -> regular ops + adaptive-int fields */
+typedef struct cldn_hip_codec cldn_hip_codec_t; /* execution context: device, stream, workspace. One call at
+                                                   a time per codec (like a PointcloudEncoder instance). */
+
+const char* cldn_hip_last_error(void);
+int cldn_hip_abi_version(void);
+int cldn_hip_device_count(void); /* >= 0, or a negative error */
+
+/* Plan = the encoder/decoder selection of BuildV4Encoders (src/v4_codec.cpp:26-40), buildV5Plan
+ * (src/v5_codec.cpp:719-740) and CreateCompatibleEncoder (src/codec_common.cpp:116-153) for
+ * EncodingInfo{fields, point_step, version, encoding_opt}. encoding_opt: 0 NONE, 1 LOSSY, 2 LOSSLESS. */
+int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint32_t point_step,
+                         uint8_t version, uint8_t encoding_opt, cldn_hip_plan_t** out);
+void cldn_hip_plan_destroy(cldn_hip_plan_t* plan);
+int cldn_hip_plan_uses_v5(const cldn_hip_plan_t* plan);                 /* detail::UsesV5Codec */
+uint32_t cldn_hip_plan_adaptive_fields(const cldn_hip_plan_t* plan);    /* number of V5 adaptive-int fields */
+uint32_t cldn_hip_plan_max_point_bytes(const cldn_hip_plan_t* plan);    /* detail::MaxSerializedPointSize */
+/* MaxCompressedSize(info, n_points, include_header=false) for CompressionOption::NONE
+ * (src/cloudini.cpp:249-292): the capacity the framed stage-1 stream of one cloud must be given. */
+uint64_t cldn_hip_stage1_bound(const cldn_hip_plan_t* plan, uint64_t n_points);
+
+/* device < 0: current device. hip_stream: a hipStream_t (NULL = the codec creates its own stream). */
+int cldn_hip_codec_create(const cldn_hip_plan_t* plan, int device, void* hip_stream, cldn_hip_codec_t** out);
+void cldn_hip_codec_destroy(cldn_hip_codec_t* codec);
+int cldn_hip_codec_synchronize(cldn_hip_codec_t* codec);
+void* cldn_hip_codec_stream(cldn_hip_codec_t* codec);
+
+/* Encode a batch of clouds that share the plan's schema.
+ *   points         n_total_points * point_step bytes, clouds back to back (cloud k has cloud_points[k] points)
+ *   cloud_points   HOST array [n_clouds]
+ *   out            receives the framed stage-1 streams of all clouds, back to back (compact)
+ *   out_capacity   must be >= sum_k cldn_hip_stage1_bound(plan, cloud_points[k])
+ *   stream_offsets [n_clouds + 1] byte offsets of each cloud's stream inside `out` (last = total size)
+ *   chunk_sizes    [total chunks] payload size of every chunk, batch order (optional, may be NULL)
+ *   modes          [n_clouds * adaptive_fields] committed V5 adaptive-int mode per cloud and field
+ *                  (0 DeltaVarint, 1 Palette, 2 Rle, 3 DeltaRle; src/v5_codec.cpp:33-38) (optional)
+ * stream_offsets / chunk_sizes / modes live where `out` lives (out_loc). */
+int cldn_hip_encode_stage1(cldn_hip_codec_t* codec, const void* points, int points_loc,
+                           const uint64_t* cloud_points, uint32_t n_clouds, void* out, uint64_t out_capacity,
+                           int out_loc, uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes);
+
+/* Decode a batch of framed stage-1 streams (inverse of the above).
+ *   streams        the streams back to back; cloud k occupies [stream_offsets[k], stream_offsets[k+1])
+ *   stream_offsets HOST array [n_clouds + 1]
+ *   cloud_points   HOST array [n_clouds] (width*height of each cloud)
+ *   points_out     sum_k cloud_points[k] * point_step bytes; bytes not covered by a field keep their
+ *                  previous content (src/field_decoder.cpp:72-76)
+ * Returns CLDN_HIP_ERR_CORRUPT for malformed input when out_loc == HOST; with DEVICE outputs the status is
+ * reported by the next cldn_hip_codec_status() call. */
+int cldn_hip_decode_stage1(cldn_hip_codec_t* codec, const void* streams, int streams_loc,
+                           const uint64_t* stream_offsets, const uint64_t* cloud_points, uint32_t n_clouds,
+                           void* points_out, uint64_t out_capacity, int out_loc);
+
+/* Synchronise and return the status word of the last asynchronous call (0 or a negative error). */
+int cldn_hip_codec_status(cldn_hip_codec_t* codec);
+
+/* Average device time of the dominant kernel over the last call, measured with HIP events on the codec's
+ * stream (used by bench.py for the roofline line). Optional instrumentation, off unless enabled. */
+int cldn_hip_codec_enable_timing(cldn_hip_codec_t* codec, int enable);
+int cldn_hip_codec_last_kernel_ms(cldn_hip_codec_t* codec, float* encode_regular_ms, float* encode_sections_ms,
+                                  float* compact_ms, float* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLOUDINI_HIP_H */
