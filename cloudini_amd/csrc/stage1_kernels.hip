@@ -501,6 +501,483 @@ __global__ __launch_bounds__(T) void k_compact(const uint8_t* __restrict__ slots
 }  // namespace cldn
 
 // ------------------------------------------------------------------------------------------------------------
+// V5 adaptive-int sections (src/v5_codec.cpp:258-491). One workgroup per (chunk, adaptive field); input is the
+// SoA column written by k_encode_regular. The same device routines serve k_probe_modes (sizes only, over the
+// first <= 4096 values of a cloud) and k_encode_sections (bytes, over a chunk).
+// ------------------------------------------------------------------------------------------------------------
+
+namespace cldn {
+
+constexpr int kSecThreads = 1024;
+constexpr uint32_t kPalSlots = 8192;      // LDS hash table slots (keys u64 + first-index u16)
+constexpr uint32_t kPalCapacity = 6144;   // distinct values one table pass accepts (load factor 0.75)
+constexpr uint32_t kPalEmpty = 0xffffu;
+
+__device__ __forceinline__ uint64_t col_raw(const uint8_t* col, uint32_t bpv, uint32_t i) {
+  if (bpv == 2u) return reinterpret_cast<const uint16_t*>(col)[i];
+  if (bpv == 4u) return reinterpret_cast<const uint32_t*>(col)[i];
+  return reinterpret_cast<const uint64_t*>(col)[i];
+}
+
+// Append up to two tokens per thread (a then b) to the stream, in thread order. EMIT=false only counts.
+template <int T, bool EMIT>
+__device__ __forceinline__ void stream_put2(StreamState& ss, uint32_t* ring, uint32_t* wtot, uint8_t* dst,
+                                            const Tok a, const Tok b) {
+  const uint32_t my_len = a.len + b.len;
+  uint32_t total;
+  const uint32_t excl = block_exclusive_scan<T>(my_len, wtot, &total);
+  const uint32_t r_end = ss.R + total;
+  if (EMIT) {
+    const uint32_t target = r_end & ~15u;
+    if (r_end - ss.F <= kRingBytes) {
+      if (a.len) ring_put<false>(ring, ss.R + excl, a, 0u);
+      if (b.len) ring_put<false>(ring, ss.R + excl + a.len, b, 0u);
+      __syncthreads();
+      ring_flush<T>(ring, dst, ss.F, target);
+      ss.F = target;
+    } else {
+      for (;;) {
+        if (a.len) ring_put<true>(ring, ss.R + excl, a, ss.F >> 2);
+        if (b.len) ring_put<true>(ring, ss.R + excl + a.len, b, ss.F >> 2);
+        __syncthreads();
+        const uint32_t nf = min(ss.F + kRingBytes, target);
+        ring_flush<T>(ring, dst, ss.F, nf);
+        const bool done = (ss.F + kRingBytes >= r_end);
+        ss.F = nf;
+        if (done) break;
+        __syncthreads();
+      }
+    }
+  }
+  ss.R = r_end;
+  __syncthreads();
+}
+
+// flush the last partial 16-byte unit (the slot has slack behind every stream)
+template <int T>
+__device__ __forceinline__ void stream_finish(StreamState& ss, uint32_t* ring, uint8_t* dst) {
+  const uint32_t target = (ss.R + 15u) & ~15u;
+  ring_flush<T>(ring, dst, ss.F, target);
+  ss.F = target;
+  __syncthreads();
+}
+
+// ---- mode 0: DeltaVarint (appendDeltaVarintSection, v5_codec.cpp:423-432) ---------------------------------
+template <int T, bool EMIT>
+__device__ uint32_t section_delta_varint(const uint8_t* col, uint32_t bpv, uint32_t type, uint32_t n, uint32_t* ring,
+                                         uint32_t* wtot, uint8_t* dst) {
+  StreamState ss;
+  ss.R = 1u;  // mode byte 0x00: the ring is zero-initialised
+  ss.F = 0u;
+  for (uint32_t base = 0; base < n; base += T) {
+    const uint32_t i = base + threadIdx.x;
+    Tok t = nan_tok();
+    t.len = 0;
+    if (i < n) {
+      const int64_t v = int_field_as_i64(col_raw(col, bpv, i), type);
+      const int64_t pv = i ? int_field_as_i64(col_raw(col, bpv, i - 1u), type) : 0;
+      const int64_t d = (int64_t)((uint64_t)v - (uint64_t)pv);
+      if (EMIT) t = varint64_tok(d);
+      else t.len = varint64_len(d);
+    }
+    Tok none = t;
+    none.len = 0;
+    stream_put2<T, EMIT>(ss, ring, wtot, dst, t, none);
+  }
+  if (EMIT) stream_finish<T>(ss, ring, dst);
+  return ss.R;
+}
+
+// ---- modes 2/3: Rle and DeltaRle (appendRleSection :471-491, appendDeltaRleSection :447-460) ---------------
+// A run closes when the next run head is seen; heads are compacted into an LDS list per tile, entry 0 being
+// the run left open by the previous tile.
+template <int T, bool EMIT, bool DELTA>
+__device__ uint32_t section_runs(const uint8_t* col, uint32_t bpv, uint32_t type, uint32_t n, uint32_t* ring,
+                                 uint32_t* wtot, uint8_t* dst, uint32_t* list_pos, uint64_t* list_key) {
+  StreamState ss;
+  ss.R = 5u;  // [mode][u32 run_count]; both patched in after the runs are known
+  ss.F = 0u;
+  uint32_t run_count = 0u;
+  uint32_t carry_pos = 0u;
+  uint64_t carry_key = 0u;
+  for (uint32_t base = 0; base < n; base += T) {
+    const uint32_t i = base + threadIdx.x;
+    const bool last_tile = (base + T >= n);
+    uint64_t key = 0u;
+    bool head = false;
+    if (i < n) {
+      if (DELTA) {  // keys are the first differences, values[-1] = 0 (forEachDeltaRun, :269-288)
+        const int64_t v = int_field_as_i64(col_raw(col, bpv, i), type);
+        const int64_t p1 = i >= 1u ? int_field_as_i64(col_raw(col, bpv, i - 1u), type) : 0;
+        const int64_t p2 = i >= 2u ? int_field_as_i64(col_raw(col, bpv, i - 2u), type) : 0;
+        key = (uint64_t)v - (uint64_t)p1;
+        head = (i == 0u) || (key != ((uint64_t)p1 - (uint64_t)p2));
+      } else {
+        key = col_raw(col, bpv, i);
+        head = (i == 0u) || (key != col_raw(col, bpv, i - 1u));
+      }
+    }
+    uint32_t heads;
+    const uint32_t rank = block_exclusive_scan<T>(head ? 1u : 0u, wtot, &heads);
+    const uint32_t carry = base ? 1u : 0u;
+    if (threadIdx.x == 0 && carry) {
+      list_pos[0] = carry_pos;
+      list_key[0] = carry_key;
+    }
+    if (head) {
+      list_pos[carry + rank] = i;
+      list_key[carry + rank] = key;
+    }
+    const uint32_t entries = carry + heads;
+    if (threadIdx.x == 0 && last_tile) list_pos[entries] = n;  // sentinel closing the final run
+    __syncthreads();
+    const uint32_t n_emit = last_tile ? entries : entries - 1u;  // entries >= 1 always (point 0 is a head)
+    for (uint32_t e0 = 0; e0 < n_emit; e0 += T) {
+      const uint32_t e = e0 + threadIdx.x;
+      Tok a = nan_tok(), b = nan_tok();
+      a.len = 0;
+      b.len = 0;
+      if (e < n_emit) {
+        const uint32_t run_len = list_pos[e + 1u] - list_pos[e];
+        const uint64_t k = list_key[e];
+        if (EMIT) {
+          a = DELTA ? varint64_tok((int64_t)k) : raw_tok(k, bpv);
+          b = uvarint32_tok(run_len);
+        } else {
+          a.len = DELTA ? varint64_len((int64_t)k) : bpv;
+          b.len = uvarint32_len(run_len);
+        }
+      }
+      stream_put2<T, EMIT>(ss, ring, wtot, dst, a, b);
+    }
+    run_count += n_emit;
+    carry_pos = list_pos[entries - 1u];
+    carry_key = list_key[entries - 1u];
+    __syncthreads();
+  }
+  if (EMIT) {
+    stream_finish<T>(ss, ring, dst);
+    // patch [mode][run_count]; every earlier store of this workgroup has completed (barrier above)
+    if (threadIdx.x < 5u) {
+      const uint32_t v = threadIdx.x == 0u ? (DELTA ? 3u : 2u) : ((run_count >> (8u * (threadIdx.x - 1u))) & 0xffu);
+      dst[threadIdx.x] = (uint8_t)v;
+    }
+  }
+  return ss.R;
+}
+
+// ---- mode 1: Palette (appendPaletteSection :462-469, buildPaletteIndexes :369-379) -------------------------
+struct PalTable {
+  uint64_t* keys;   // [kPalSlots]
+  uint16_t* first;  // [kPalSlots] index (within the chunk) of the first occurrence, kPalEmpty = free
+};
+
+__device__ __forceinline__ uint32_t pal_probe(const PalTable t, uint64_t v) {
+  uint32_t slot = hash_u64(v) & (kPalSlots - 1u);
+  for (;;) {
+    const uint32_t f = t.first[slot];
+    if (f == kPalEmpty) return kPalEmpty;
+    if (t.keys[slot] == v) return f;
+    slot = (slot + 1u) & (kPalSlots - 1u);
+  }
+}
+
+// Build the table over values [0, n) whose hash partition is `part` (of `parts`), in index order; returns the
+// number of distinct values, or 0xffffffff when the table overflowed. If first_out != nullptr, first_out[i]
+// receives the first-occurrence index of value i (for the values of this partition).
+template <int T>
+__device__ uint32_t palette_pass(const uint8_t* col, uint32_t bpv, uint32_t n, uint32_t part, uint32_t parts,
+                                 PalTable tab, uint64_t* tile_vals, uint64_t* miss_mask, uint32_t* flags,
+                                 uint16_t* first_out) {
+  constexpr int NW = T / 64;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (uint32_t s = threadIdx.x; s < kPalSlots; s += T) tab.first[s] = (uint16_t)kPalEmpty;
+  if (threadIdx.x == 0) {
+    flags[0] = 0u;  // any miss in this tile
+    flags[1] = 0u;  // distinct count
+  }
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += T) {
+    const uint32_t i = base + threadIdx.x;
+    uint64_t v = 0u;
+    bool mine = false;
+    if (i < n) {
+      v = col_raw(col, bpv, i);
+      mine = (parts == 1u) || (((hash_u64(v) >> 20) % parts) == part);
+    }
+    uint32_t f = kPalEmpty;
+    if (mine) f = pal_probe(tab, v);
+    const bool miss = mine && (f == kPalEmpty);
+    const uint64_t mm = __ballot(miss);
+    if (miss) tile_vals[threadIdx.x] = v;
+    if (lane == 0u) {
+      miss_mask[wave] = mm;
+      if (mm) flags[0] = 1u;
+    }
+    __syncthreads();
+    const bool any_miss = flags[0] != 0u;
+    if (any_miss) {
+      if (wave == 0u) {
+        uint32_t count = flags[1];
+        for (uint32_t w = 0; w < (uint32_t)NW; ++w) {
+          const uint64_t m = miss_mask[w];
+          if (m == 0u) continue;
+          bool act = ((m >> lane) & 1u) != 0u;
+          uint64_t val = 0u;
+          if (act) {
+            val = tile_vals[w * 64u + lane];
+            act = pal_probe(tab, val) == kPalEmpty;  // an earlier batch may have inserted it
+          }
+          // leaders: lowest lane of each group of equal values
+          uint64_t todo = __ballot(act);
+          bool leader = false;
+          while (todo) {
+            const int j = __builtin_ctzll(todo);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)val, j);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(val >> 32), j);
+            const uint64_t vj = (((uint64_t)hi) << 32) | lo;
+            const uint64_t same = __ballot(act && val == vj);
+            if ((int)lane == j) leader = true;
+            todo &= ~same;
+          }
+          const uint64_t leaders = __ballot(leader);
+          count += (uint32_t)__builtin_popcountll(leaders);
+          if (count > kPalCapacity) break;  // uniform
+          if (leader) {
+            // distinct new keys: claim the first free slot of the probe sequence, then publish the key
+            const uint32_t idx = base + w * 64u + lane;
+            uint32_t slot = hash_u64(val) & (kPalSlots - 1u);
+            for (;;) {
+              // 16-bit CAS emulated on the containing dword
+              uint32_t* word = reinterpret_cast<uint32_t*>(tab.first) + (slot >> 1);
+              const uint32_t shift = (slot & 1u) * 16u;
+              const uint32_t old = *word;
+              if (((old >> shift) & 0xffffu) == kPalEmpty) {
+                const uint32_t want = (old & ~(0xffffu << shift)) | (idx << shift);
+                if (atomicCAS(word, old, want) == old) {
+                  tab.keys[slot] = val;
+                  break;
+                }
+                continue;  // somebody changed the dword: re-read the same slot
+              }
+              slot = (slot + 1u) & (kPalSlots - 1u);
+            }
+          }
+        }
+        if (lane == 0u) flags[1] = count;
+      }
+      __syncthreads();
+      if (flags[1] > kPalCapacity) return 0xffffffffu;  // uniform
+      if (threadIdx.x == 0) flags[0] = 0u;  // every wave has read any_miss; next write is behind the barrier below
+      if (miss) f = pal_probe(tab, v);
+    }
+    if (mine && first_out) first_out[i] = (uint16_t)f;
+    __syncthreads();  // flags / miss_mask / tile_vals reuse
+  }
+  return flags[1];
+}
+
+// Distinct-value count of values [0, n) (mode analysis). Falls back to 8 hash partitions when one table
+// cannot hold the distinct values.
+template <int T>
+__device__ uint32_t palette_count(const uint8_t* col, uint32_t bpv, uint32_t n, PalTable tab, uint64_t* tile_vals,
+                                  uint64_t* miss_mask, uint32_t* flags) {
+  uint32_t u = palette_pass<T>(col, bpv, n, 0u, 1u, tab, tile_vals, miss_mask, flags, nullptr);
+  if (u != 0xffffffffu) return u;
+  u = 0u;
+  for (uint32_t p = 0; p < 8u; ++p) {
+    __syncthreads();
+    u += palette_pass<T>(col, bpv, n, p, 8u, tab, tile_vals, miss_mask, flags, nullptr);
+  }
+  return u;
+}
+
+// Full palette section of one chunk. Writes segment A ([0x01][u16 U][U values]) at dst and segment B (bit-packed
+// indexes) at dst + kPaletteIndexOffset; returns their sizes.
+template <int T>
+__device__ void section_palette(const uint8_t* col, uint32_t bpv, uint32_t n, uint8_t* dst, uint16_t* first_idx,
+                                uint8_t* lds, uint32_t* wtot, uint32_t* size_a, uint32_t* size_b) {
+  // LDS carve (bytes): keys 64 KiB | first 16 KiB | tile_vals 8 KiB | miss_mask 128 | flags 16
+  PalTable tab;
+  tab.keys = reinterpret_cast<uint64_t*>(lds);
+  tab.first = reinterpret_cast<uint16_t*>(lds + kPalSlots * 8u);
+  uint64_t* tile_vals = reinterpret_cast<uint64_t*>(lds + kPalSlots * 10u);
+  uint64_t* miss_mask = reinterpret_cast<uint64_t*>(lds + kPalSlots * 10u + T * 8u);
+  uint32_t* flags = reinterpret_cast<uint32_t*>(lds + kPalSlots * 10u + T * 8u + 128u);
+
+  uint32_t u = palette_pass<T>(col, bpv, n, 0u, 1u, tab, tile_vals, miss_mask, flags, first_idx);
+  if (u == 0xffffffffu) {
+    for (uint32_t p = 0; p < 8u; ++p) {
+      __syncthreads();
+      (void)palette_pass<T>(col, bpv, n, p, 8u, tab, tile_vals, miss_mask, flags, first_idx);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ranks in first-occurrence order: rank_at[i] for every first-occurrence point i (LDS, reuses the table)
+  uint16_t* rank_at = reinterpret_cast<uint16_t*>(lds);  // [32768]
+  uint32_t running = 0u;
+  for (uint32_t base = 0; base < n; base += T) {
+    const uint32_t i = base + threadIdx.x;
+    const bool is_first = (i < n) && (first_idx[i] == (uint16_t)i);
+    uint32_t total;
+    const uint32_t excl = block_exclusive_scan<T>(is_first ? 1u : 0u, wtot, &total);
+    if (is_first) {
+      const uint32_t r = running + excl;
+      rank_at[i] = (uint16_t)r;
+      // palette value r, little-endian, behind the 3-byte header
+      const uint64_t v = col_raw(col, bpv, i);
+      uint8_t* q = dst + 3u + (size_t)r * bpv;
+      for (uint32_t k = 0; k < bpv; ++k) q[k] = (uint8_t)(v >> (8u * k));
+    }
+    running += total;
+    __syncthreads();
+  }
+  const uint32_t U = running;
+  if (threadIdx.x == 0) {
+    dst[0] = 1u;
+    dst[1] = (uint8_t)(U & 0xffu);
+    dst[2] = (uint8_t)((U >> 8) & 0xffu);  // u16 truncation as in the reference (v5_codec.cpp:464)
+  }
+  const uint32_t bits = palette_bits(U);
+  *size_a = 3u + U * bpv;
+  *size_b = (bits * n + 7u) >> 3;
+  if (bits == 0u) return;
+
+  // bit-pack: thread g packs indexes [32g, 32g+32) into `bits` dwords (appendBitpackedIndexes, :209-227)
+  uint32_t* idx_out = reinterpret_cast<uint32_t*>(dst + kPaletteIndexOffset);
+  for (uint32_t g = threadIdx.x; g * 32u < n; g += T) {
+    const uint32_t cnt = min(32u, n - g * 32u);
+    uint64_t scratch = 0u;
+    uint32_t held = 0u, w = 0u;
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t r = rank_at[first_idx[g * 32u + j]];
+      scratch |= ((uint64_t)r) << held;
+      held += bits;
+      if (held >= 32u) {
+        idx_out[g * bits + w] = (uint32_t)scratch;
+        ++w;
+        scratch >>= 32;
+        held -= 32u;
+      }
+    }
+    if (held > 0u) idx_out[g * bits + w] = (uint32_t)scratch;
+  }
+}
+
+constexpr uint32_t kSecLdsPalette = kPalSlots * 10u + kSecThreads * 8u + 128u + 16u;  // 90256
+constexpr uint32_t kSecLdsLists = (kSecThreads + 2u) * 12u + 16u;
+constexpr uint32_t kSecLdsMain = (kSecLdsPalette > 65536u + 64u ? kSecLdsPalette : 65536u + 64u);
+constexpr uint32_t kSecLdsTotal = ((kSecLdsMain + kSecLdsLists + 15u) & ~15u) + kRingBytes + 128u;
+
+struct SecLds {
+  uint8_t* main;       // palette table / rank_at
+  uint32_t* list_pos;  // run lists
+  uint64_t* list_key;
+  uint32_t* ring;
+  uint32_t* wtot;
+};
+
+__device__ __forceinline__ SecLds sec_lds_carve(uint8_t* smem) {
+  SecLds l;
+  l.main = smem;
+  l.list_key = reinterpret_cast<uint64_t*>(smem + kSecLdsMain);
+  l.list_pos = reinterpret_cast<uint32_t*>(smem + kSecLdsMain + (kSecThreads + 2u) * 8u);
+  const uint32_t ring_off = (kSecLdsMain + kSecLdsLists + 15u) & ~15u;
+  l.ring = reinterpret_cast<uint32_t*>(smem + ring_off);
+  l.wtot = reinterpret_cast<uint32_t*>(smem + ring_off + kRingBytes);
+  return l;
+}
+
+// k_probe_modes: grid = (n_clouds, n_adaptive). analyzeAdaptiveIntField + selectBestAdaptiveIntMode
+// (v5_codec.cpp:387-412) over the first min(4096, n) values of the cloud's first chunk (window rule :934-949).
+__global__ __launch_bounds__(kSecThreads) void k_probe_modes(const DevPlan plan, const ChunkDesc* __restrict__ chunks,
+                                                             const uint32_t* __restrict__ cloud_first_chunk,
+                                                             const ColumnPtrs cols, uint8_t* __restrict__ modes) {
+  constexpr int T = kSecThreads;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const SecLds l = sec_lds_carve(smem);
+  const uint32_t cloud = blockIdx.x, a = blockIdx.y;
+  const uint32_t fc = cloud_first_chunk[cloud];
+  if (fc == cloud_first_chunk[cloud + 1u]) {  // empty cloud
+    if (threadIdx.x == 0) modes[cloud * plan.n_adaptive + a] = 0u;
+    return;
+  }
+  const ChunkDesc cd = chunks[fc];
+  const uint32_t n = cd.n_points > kProbePoints ? kProbePoints : cd.n_points;
+  const uint32_t bpv = plan.adaptive[a].bpv, type = plan.adaptive[a].type;
+  const uint8_t* col = cols.p[a] + (size_t)cd.first_point * bpv;
+
+  const uint32_t delta = section_delta_varint<T, false>(col, bpv, type, n, l.ring, l.wtot, nullptr);
+  __syncthreads();
+  const uint32_t rle = section_runs<T, false, false>(col, bpv, type, n, l.ring, l.wtot, nullptr, l.list_pos, l.list_key);
+  __syncthreads();
+  const uint32_t drle = section_runs<T, false, true>(col, bpv, type, n, l.ring, l.wtot, nullptr, l.list_pos, l.list_key);
+  __syncthreads();
+  PalTable tab;
+  tab.keys = reinterpret_cast<uint64_t*>(l.main);
+  tab.first = reinterpret_cast<uint16_t*>(l.main + kPalSlots * 8u);
+  uint64_t* tile_vals = reinterpret_cast<uint64_t*>(l.main + kPalSlots * 10u);
+  uint64_t* miss_mask = reinterpret_cast<uint64_t*>(l.main + kPalSlots * 10u + T * 8u);
+  uint32_t* flags = reinterpret_cast<uint32_t*>(l.main + kPalSlots * 10u + T * 8u + 128u);
+  const uint32_t U = palette_count<T>(col, bpv, n, tab, tile_vals, miss_mask, flags);
+  const uint32_t pal = 3u + U * bpv + ((palette_bits(U) * n + 7u) >> 3);
+
+  uint32_t mode = 0u, best = delta;  // strict '<' in this order (selectBestAdaptiveIntMode)
+  if (pal < best) { best = pal; mode = 1u; }
+  if (rle < best) { best = rle; mode = 2u; }
+  if (drle < best) { mode = 3u; }
+  if (threadIdx.x == 0) modes[cloud * plan.n_adaptive + a] = (uint8_t)mode;
+}
+
+// k_encode_sections: grid = (n_chunks, n_adaptive)
+__global__ __launch_bounds__(kSecThreads) void k_encode_sections(const DevPlan plan, const ChunkDesc* __restrict__ chunks,
+                                                                 const ColumnPtrs cols, const uint8_t* __restrict__ modes,
+                                                                 uint8_t* __restrict__ slots, uint64_t slot_stride,
+                                                                 uint64_t reg_stride, Seg* __restrict__ segs,
+                                                                 uint32_t segs_per_chunk, const ColumnPtrs rank_cols) {
+  constexpr int T = kSecThreads;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const SecLds l = sec_lds_carve(smem);
+  const uint32_t c = blockIdx.x, a = blockIdx.y;
+  const ChunkDesc cd = chunks[c];
+  const uint32_t n = cd.n_points;
+  const uint32_t bpv = plan.adaptive[a].bpv, type = plan.adaptive[a].type;
+  const uint8_t* col = cols.p[a] + (size_t)cd.first_point * bpv;
+  const uint32_t sec_off = (uint32_t)reg_stride + a * kSectionStride;
+  uint8_t* dst = slots + (size_t)c * slot_stride + sec_off;
+  const uint32_t mode = modes[cd.cloud * plan.n_adaptive + a];
+
+  for (uint32_t i = threadIdx.x; i < kRingU4; i += T) reinterpret_cast<uint4*>(l.ring)[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+
+  uint32_t size_a = 0u, size_b = 0u;
+  if (mode == 0u) {
+    size_a = section_delta_varint<T, true>(col, bpv, type, n, l.ring, l.wtot, dst);
+  } else if (mode == 2u) {
+    size_a = section_runs<T, true, false>(col, bpv, type, n, l.ring, l.wtot, dst, l.list_pos, l.list_key);
+  } else if (mode == 3u) {
+    size_a = section_runs<T, true, true>(col, bpv, type, n, l.ring, l.wtot, dst, l.list_pos, l.list_key);
+  } else {
+    uint16_t* first_idx = reinterpret_cast<uint16_t*>(rank_cols.p[a]) + cd.first_point;
+    section_palette<T>(col, bpv, n, dst, first_idx, l.main, l.wtot, &size_a, &size_b);
+  }
+  if (threadIdx.x == 0) {
+    Seg s;
+    s.off = sec_off;
+    s.size = size_a;
+    segs[(size_t)c * segs_per_chunk + 1u + 2u * a] = s;
+    s.off = sec_off + kPaletteIndexOffset;
+    s.size = size_b;
+    segs[(size_t)c * segs_per_chunk + 2u + 2u * a] = s;
+  }
+}
+
+}  // namespace cldn
+
+// ------------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------------
 #include "cloudini_hip.h"
@@ -522,6 +999,12 @@ int stage1_configure_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_regular<kRegularThreads>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRegularLds);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_regular)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_probe_modes), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kSecLdsTotal);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_probe_modes)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_sections),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSecLdsTotal);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_sections)");
   return CLDN_HIP_OK;
 }
 
@@ -536,6 +1019,18 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_regular");
   }
   if (L.events) (void)hipEventRecord(L.events[2], L.stream);
+  const uint32_t na = L.plan->n_adaptive;
+  if (na && L.n_chunks) {
+    ColumnPtrs rank_cols;
+    for (int a = 0; a < kMaxAdaptive; ++a) rank_cols.p[a] = reinterpret_cast<uint8_t*>(L.ranks[a]);
+    hipLaunchKernelGGL(k_probe_modes, dim3(L.n_clouds, na), dim3(kSecThreads), kSecLdsTotal, L.stream, *L.plan,
+                       L.chunks, L.cloud_first_chunk, L.cols, L.modes);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_modes");
+    hipLaunchKernelGGL(k_encode_sections, dim3(L.n_chunks, na), dim3(kSecThreads), kSecLdsTotal, L.stream, *L.plan,
+                       L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk,
+                       rank_cols);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_sections");
+  }
   if (L.events) (void)hipEventRecord(L.events[3], L.stream);
   hipLaunchKernelGGL(k_chunk_offsets<1024>, dim3(1), dim3(1024), 0, L.stream, L.segs, L.segs_per_chunk, L.n_chunks,
                      L.cloud_first_chunk, L.n_clouds, L.chunk_payload, L.chunk_dst, L.stream_offsets);

@@ -73,3 +73,69 @@ def test_xyzi_float4(oracle):
                         width=n, height=1, point_step=16, encoding_opt=EncodingOptions.LOSSY,
                         compression_opt=CompressionOption.NONE)
     check_encode(oracle, info, [pts.view(np.uint8).reshape(-1)])
+
+
+import cases  # noqa: E402
+
+ALL = cases.encode_cases(small=False)
+
+
+@pytest.mark.parametrize("name,info,data", ALL, ids=[c[0] for c in ALL])
+def test_all_schema_families(oracle, name, info, data):
+    check_encode(oracle, info, [data])
+
+
+def test_known_answer_vectors_gpu():
+    from cloudini_amd import native
+    for name, info, data, payload in cases.kat_vectors():
+        codec = native.Codec(native.Plan(info))
+        streams, chunk_sizes, _ = codec.encode_host([data])
+        assert streams[0].tobytes()[4:] == payload, name
+        assert list(chunk_sizes) == [len(payload)], name
+        codec.close()
+
+
+def test_reference_mode_bytes_gpu():
+    from cloudini_amd import native
+    for name, info, data, want in cases.reference_int_sequences():
+        codec = native.Codec(native.Plan(info))
+        streams, chunk_sizes, modes = codec.encode_host([data])
+        s = streams[0]
+        got = [int(s[4]), int(s[4 + 4 + int(chunk_sizes[0])])]
+        if want is None:
+            assert all(m != 3 for m in got), name
+        else:
+            assert got == want, name
+        codec.close()
+
+
+def test_batch_mixed_clouds_v5(oracle):
+    clouds = []
+    info = None
+    for k, n in enumerate([100, 70000, 0, 4096, 4097, 32768, 33000]):
+        info, data = synth.lidar_xyzi(n, seed=7 + k)
+        clouds.append(data)
+    check_encode(oracle, info, clouds)
+
+
+def test_gorilla_schema_is_rejected_loudly():
+    from cloudini_amd import native
+    info = cases.make_info([("x", 0, FieldType.FLOAT32, 0.001), ("t", 4, FieldType.FLOAT64, None)], 12, 10)
+    with pytest.raises(native.CloudiniHipError) as e:
+        native.Plan(info)
+    assert e.value.code == -3
+
+
+def test_capacity_contract():
+    from cloudini_amd import native
+    import ctypes as C
+    info, data = synth.lidar_xyz(1000)
+    plan = native.Plan(info)
+    codec = native.Codec(plan)
+    npts = np.array([1000], dtype=np.uint64)
+    out = np.zeros(100, dtype=np.uint8)
+    rc = native.lib().cldn_hip_encode_stage1(codec._h, data.ctypes.data_as(C.c_void_p), 0,
+                                             npts.ctypes.data_as(C.POINTER(C.c_uint64)), 1,
+                                             out.ctypes.data_as(C.c_void_p), out.size, 0, None, None, None)
+    assert rc == -2  # cloudini.cpp:531-534: "Output buffer too small for worst-case compressed size"
+    codec.close()

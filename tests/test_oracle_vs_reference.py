@@ -1,0 +1,106 @@
+"""Pins the CPU oracle (oracle/cloudini_oracle.c) to the real reference compiled into oracle/_ref.
+
+Runs without a GPU. When /root/reference is absent and oracle/_ref has not been built these tests skip; the
+golden-fixture tests (test_golden.py) still pin the oracle in that situation.
+"""
+import numpy as np
+import pytest
+
+import cases
+from cloudini_amd.schema import CompressionOption
+
+
+def _chunk_modes(stream, n_adaptive_hint=1):
+    modes, pos = [], 0
+    while pos < len(stream):
+        size = int(np.frombuffer(stream[pos:pos + 4].tobytes(), "<u4")[0])
+        modes.append(int(stream[pos + 4]))
+        pos += 4 + size
+    return modes
+
+
+ALL = cases.encode_cases(small=True)
+
+
+@pytest.mark.parametrize("name,info,data", ALL, ids=[c[0] for c in ALL])
+def test_encode_matches_reference(oracle, reflib, name, info, data):
+    want = reflib.encode_stage1(info, data)
+    got = oracle.encode_stage1(info, data)
+    assert len(got) == len(want)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,info,data", ALL, ids=[c[0] for c in ALL])
+def test_decode_matches_reference(oracle, reflib, name, info, data):
+    n = len(data) // info.point_step
+    full = reflib.encode(info, data)
+    want, _yaml = reflib.decode(full, len(data), fill=0x5A)
+    stream = reflib.encode_stage1(info, data)
+    got = oracle.decode_stage1(info, stream, n, fill=0x5A)
+    assert np.array_equal(got, want)
+
+
+def test_reference_mode_bytes(oracle):
+    """Per-chunk mode bytes pinned by test_field_encoders.cpp:590-674."""
+    for name, info, data, modes in cases.reference_int_sequences():
+        stream = oracle.encode_stage1(info, data)
+        got = _chunk_modes(stream)
+        if modes is None:
+            assert len(got) == 2 and all(m != 3 for m in got), name
+        else:
+            assert got == modes, name
+    for name, info, data in cases.probe_boundaries():
+        assert all(m == 3 for m in _chunk_modes(oracle.encode_stage1(info, data))), name
+
+
+def test_known_answer_vectors(oracle):
+    """SURVEY.md appendix A.8 (bytes produced by the compiled reference)."""
+    for name, info, data, payload in cases.kat_vectors():
+        stream = oracle.encode_stage1(info, data).tobytes()
+        assert stream[4:] == payload, name
+        assert int.from_bytes(stream[:4], "little") == len(payload), name
+
+
+def test_v5_equals_v4_for_float_only(oracle):
+    """PointcloudV5_LossyFloatOnlyRoundTrip (test_field_encoders.cpp:695-769): byte-identical payloads."""
+    info, data = cases.xyzi_struct_4133()
+    a = oracle.encode_stage1(info, data)
+    b = oracle.encode_stage1(info.copy(version=4), data)
+    assert np.array_equal(a, b)
+
+
+def test_bound_matches_reference(oracle, reflib):
+    for name, info, data in ALL[:12]:
+        n = len(data) // info.point_step
+        for pts in (0, 1, n, 32768, 32769, 100000):
+            assert oracle.stage1_bound(info, pts) == reflib.max_compressed_size(
+                info.copy(compression_opt=CompressionOption.NONE), pts, include_header=False), (name, pts)
+
+
+def test_varint_differential(oracle):
+    """decodeVarintOracle differential of test_field_encoders.cpp:165-278, seed 0xC10D1217 (restated):
+    every 1- and 2-byte prefix plus random longer encodings must round-trip or be rejected consistently."""
+    for b0 in range(256):
+        for b1 in range(256):
+            n, val = oracle.decode_varint(bytes([b0, b1]))
+            if b0 < 0x80:
+                uval, want_n = b0, 1
+            elif b1 < 0x80:
+                uval, want_n = (b0 & 0x7F) | (b1 << 7), 2
+            else:
+                assert n < 0  # truncated 3+ byte varint
+                continue
+            if uval == 0:
+                assert n < 0  # the NaN marker is not a varint (encoding_utils.hpp:140-142)
+                continue
+            u = uval - 1
+            assert n == want_n and val == ((u >> 1) ^ -(u & 1))
+    rs = np.random.RandomState(0xC10D1217 & 0x7FFFFFFF)
+    for _ in range(20000):
+        v = int(rs.randint(-2**62, 2**62, dtype=np.int64)) >> int(rs.randint(0, 62))
+        enc = oracle.encode_varint64(v)
+        n, val = oracle.decode_varint(enc)
+        assert n == len(enc) and val == v
+        if len(enc) > 1:
+            n2, _ = oracle.decode_varint(enc, max_size=len(enc) - 1)
+            assert n2 < 0
