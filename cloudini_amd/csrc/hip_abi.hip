@@ -135,9 +135,9 @@ struct cldn_hip_codec {
   std::vector<uint64_t> last_cloud_points;
   uint32_t last_n_chunks = 0;
   // timing
-  bool timing = false;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool ev_valid = false;
+  std::vector<hipEvent_t> events;  // 5 per timing slot
+  std::vector<uint8_t> slot_valid;
+  uint64_t call_index = 0;
 };
 
 extern "C" {
@@ -393,7 +393,7 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   }
   c->h_stage.release();
   c->h_result.release();
-  for (hipEvent_t& ev : c->ev)
+  for (hipEvent_t& ev : c->events)
     if (ev) (void)hipEventDestroy(ev);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -407,39 +407,28 @@ int cldn_hip_codec_synchronize(cldn_hip_codec_t* c) {
 
 void* cldn_hip_codec_stream(cldn_hip_codec_t* c) { return c ? (void*)c->stream : nullptr; }
 
-int cldn_hip_codec_enable_timing(cldn_hip_codec_t* c, int enable) {
+int cldn_hip_codec_enable_timing(cldn_hip_codec_t* c, uint32_t n_slots) {
   if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
   HIP_TRY(hipSetDevice(c->device));
-  if (enable && !c->ev[0]) {
-    for (hipEvent_t& ev : c->ev) HIP_TRY(hipEventCreate(&ev));
-  }
-  c->timing = enable != 0;
-  c->ev_valid = false;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (hipEvent_t& ev : c->events)
+    if (ev) (void)hipEventDestroy(ev);
+  c->events.assign((size_t)n_slots * 5, nullptr);
+  c->slot_valid.assign(n_slots, 0);
+  for (hipEvent_t& ev : c->events) HIP_TRY(hipEventCreate(&ev));
+  c->call_index = 0;
   return CLDN_HIP_OK;
 }
 
-int cldn_hip_codec_last_kernel_ms(cldn_hip_codec_t* c, float* regular_ms, float* sections_ms, float* compact_ms,
-                                  float* total_ms) {
-  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
-  if (!c->timing || !c->ev_valid) return fail(CLDN_HIP_ERR_ARG, "no timed call recorded");
-  HIP_TRY(hipEventSynchronize(c->ev[4]));
-  float t = 0.f;
-  if (regular_ms) {
-    HIP_TRY(hipEventElapsedTime(&t, c->ev[1], c->ev[2]));
-    *regular_ms = t;
-  }
-  if (sections_ms) {
-    HIP_TRY(hipEventElapsedTime(&t, c->ev[2], c->ev[3]));
-    *sections_ms = t;
-  }
-  if (compact_ms) {
-    HIP_TRY(hipEventElapsedTime(&t, c->ev[3], c->ev[4]));
-    *compact_ms = t;
-  }
-  if (total_ms) {
-    HIP_TRY(hipEventElapsedTime(&t, c->ev[0], c->ev[4]));
-    *total_ms = t;
-  }
+int cldn_hip_codec_kernel_ms(cldn_hip_codec_t* c, uint32_t slot, float ms[4]) {
+  if (!c || !ms) return fail(CLDN_HIP_ERR_ARG, "NULL argument");
+  if (slot >= c->slot_valid.size() || !c->slot_valid[slot]) return fail(CLDN_HIP_ERR_ARG, "no timed call in slot %u", slot);
+  hipEvent_t* ev = &c->events[(size_t)slot * 5];
+  HIP_TRY(hipEventSynchronize(ev[4]));
+  HIP_TRY(hipEventElapsedTime(&ms[0], ev[1], ev[2]));
+  HIP_TRY(hipEventElapsedTime(&ms[1], ev[2], ev[3]));
+  HIP_TRY(hipEventElapsedTime(&ms[2], ev[3], ev[4]));
+  HIP_TRY(hipEventElapsedTime(&ms[3], ev[0], ev[4]));
   return CLDN_HIP_OK;
 }
 
@@ -595,10 +584,13 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   L.out = d_outp;
   L.out_capacity = out_capacity;
   L.status = (uint32_t*)c->d_status.p;
-  L.events = c->timing ? c->ev : nullptr;
+  const size_t n_slots = c->slot_valid.size();
+  const size_t slot = n_slots ? (size_t)(c->call_index % n_slots) : 0;
+  L.events = n_slots ? &c->events[slot * 5] : nullptr;
   rc = stage1_launch_encode(L);
   if (rc != CLDN_HIP_OK) return rc;
-  c->ev_valid = c->timing;
+  if (n_slots) c->slot_valid[slot] = 1;
+  ++c->call_index;
 
   const size_t modes_bytes = (size_t)n_clouds * n_adaptive;
   if (out_loc == CLDN_HIP_DEVICE) {

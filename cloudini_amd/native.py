@@ -43,6 +43,12 @@ def lib() -> C.CDLL:
         raise ImportError(
             f"{HIP_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(cloudini_amd has no CPU fallback)")
+    # torch bundles its own HIP runtime (same SONAME, libamdhip64.so.7): whichever copy is loaded first serves the
+    # whole process. When torch is going to provide device memory / streams it must be the first one in.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(HIP_SO)
     vp, u8p, u32p, u64p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
     L.cldn_hip_last_error.restype = C.c_char_p
@@ -71,10 +77,10 @@ def lib() -> C.CDLL:
     L.cldn_hip_codec_stream.restype = vp
     L.cldn_hip_codec_status.argtypes = [vp]
     L.cldn_hip_codec_status.restype = C.c_int
-    L.cldn_hip_codec_enable_timing.argtypes = [vp, C.c_int]
+    L.cldn_hip_codec_enable_timing.argtypes = [vp, C.c_uint32]
     L.cldn_hip_codec_enable_timing.restype = C.c_int
-    L.cldn_hip_codec_last_kernel_ms.argtypes = [vp] + [C.POINTER(C.c_float)] * 4
-    L.cldn_hip_codec_last_kernel_ms.restype = C.c_int
+    L.cldn_hip_codec_kernel_ms.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float)]
+    L.cldn_hip_codec_kernel_ms.restype = C.c_int
     L.cldn_hip_encode_stage1.restype = C.c_int
     L.cldn_hip_encode_stage1.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, vp, C.c_uint64, C.c_int, vp, vp, vp]
     L.cldn_hip_decode_stage1.restype = C.c_int
@@ -157,13 +163,13 @@ class Codec:
     def status(self):
         _check(lib().cldn_hip_codec_status(self._h))
 
-    def enable_timing(self, on: bool = True):
-        _check(lib().cldn_hip_codec_enable_timing(self._h, 1 if on else 0))
+    def enable_timing(self, n_slots: int):
+        _check(lib().cldn_hip_codec_enable_timing(self._h, int(n_slots)))
 
-    def last_kernel_ms(self):
-        v = [C.c_float(0) for _ in range(4)]
-        _check(lib().cldn_hip_codec_last_kernel_ms(self._h, *[C.byref(x) for x in v]))
-        return {"regular": v[0].value, "sections": v[1].value, "compact": v[2].value, "total": v[3].value}
+    def kernel_ms(self, slot: int):
+        v = (C.c_float * 4)()
+        _check(lib().cldn_hip_codec_kernel_ms(self._h, int(slot), v))
+        return {"regular": v[0], "sections": v[1], "compact": v[2], "total": v[3]}
 
     # ---- host buffers (numpy) -------------------------------------------------------------------------
     def encode_host(self, clouds: Sequence[np.ndarray]):

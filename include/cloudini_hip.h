@@ -116,11 +116,12 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* codec, const void* streams, int str
 /* Synchronise and return the status word of the last asynchronous call (0 or a negative error). */
 int cldn_hip_codec_status(cldn_hip_codec_t* codec);
 
-/* Average device time of the dominant kernel over the last call, measured with HIP events on the codec's
- * stream (used by bench.py for the roofline line). Optional instrumentation, off unless enabled. */
-int cldn_hip_codec_enable_timing(cldn_hip_codec_t* codec, int enable);
-int cldn_hip_codec_last_kernel_ms(cldn_hip_codec_t* codec, float* encode_regular_ms, float* encode_sections_ms,
-                                  float* compact_ms, float* total_ms);
+/* Optional instrumentation for bench.py's roofline line: with n_slots > 0 every encode call records HIP
+ * events on the codec's stream around its kernels into slot (call_index % n_slots); n_slots = 0 turns it off.
+ * cldn_hip_codec_kernel_ms waits for that slot's last event and returns milliseconds:
+ *   ms[0] k_encode_regular, ms[1] section kernels (probe + sections), ms[2] offsets + compaction, ms[3] all. */
+int cldn_hip_codec_enable_timing(cldn_hip_codec_t* codec, uint32_t n_slots);
+int cldn_hip_codec_kernel_ms(cldn_hip_codec_t* codec, uint32_t slot, float ms[4]);
 
 #ifdef __cplusplus
 }
