@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "stage1_device.h"
 #include "stage1_math.h"
 
@@ -389,6 +391,232 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
     Seg s;
     s.off = 0u;
     s.size = ss.R;
+    segs[(size_t)blockIdx.x * segs_per_chunk] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_encode_floatn: the hot kernel. Regular stream == one FieldEncoderFloatN_Lossy (3 or 4 fused float32 lanes at
+// consecutive offsets; src/field_encoder.cpp:42-91), 4-byte aligned layout. Differences to the generic kernel:
+//   * no LDS staging of the input: every lane loads its own point straight from global memory (the wave reads
+//     64 consecutive points = one contiguous, coalesced span);
+//   * each wave covers 63 new points plus, in lane 0, the point before them: the delta reference of lane l is
+//     lane l-1's quantised value, fetched with one DPP wave shift -- no second load, no second quantisation, no
+//     cross-wave exchange. Lane 0 never emits;
+//   * PPT rows of 63*NW points per barrier pair; the cross-wave part of the scan is a single wave scan over the
+//     PPT*NW row/wave totals;
+//   * tokens are built once (<= 5 bytes each) and OR-ed into the byte ring, 1-2 LDS atomics per token.
+// ------------------------------------------------------------------------------------------------------------
+
+template <int LANES>
+struct alignas(4) FloatVec {
+  float v[LANES];
+};
+
+__device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);  // wave_shr:1
+}
+
+// token of one FloatN lane; exact for every input incl. NaN (marker byte) and the 33-bit case d == INT32_MIN
+__device__ __forceinline__ void floatn_token(bool is_nan, int32_t d, uint32_t& w0, uint32_t& w1, uint32_t& len) {
+  const uint32_t zz = ((uint32_t)d << 1) ^ (uint32_t)(d >> 31);
+  const bool ov = zz == 0xffffffffu;
+  const uint32_t u = zz + 1u;
+  uint32_t l = groups7(32u - (uint32_t)__clz((int)u));
+  l = ov ? 5u : l;
+  l = is_nan ? 1u : l;
+  // continuation flags in the low (l-1) bytes: 0x0080808080 >> 8*(5-l), taken from a 64-bit constant
+  const uint32_t cont = (uint32_t)(0x0080808080ull >> (8u * (5u - l)));
+  uint32_t a = spread28(u & 0x0fffffffu) | cont;
+  uint32_t b = ov ? 0x10u : (u >> 28);
+  w0 = is_nan ? 0u : a;
+  w1 = is_nan ? 0u : b;
+  len = l;
+}
+
+template <uint32_t RING_BYTES, bool WINDOWED>
+__device__ __forceinline__ void ring_put5(uint32_t* ring, uint32_t off, uint32_t w0, uint32_t w1, uint32_t len,
+                                          uint32_t win_lo_dw) {
+  constexpr uint32_t kMask = RING_BYTES / 4u - 1u;
+  const uint32_t sh = (off & 3u) * 8u;
+  const uint32_t g = off >> 2;
+  const uint64_t v = ((((uint64_t)w1) << 32) | w0) << sh;
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  if (!WINDOWED || (g >= win_lo_dw && g < win_lo_dw + RING_BYTES / 4u)) {
+    if (lo) atomicOr(&ring[g & kMask], lo);
+  }
+  if (((off & 3u) + len) > 4u) {
+    if (!WINDOWED || (g + 1u >= win_lo_dw && g + 1u < win_lo_dw + RING_BYTES / 4u)) {
+      if (hi) atomicOr(&ring[(g + 1u) & kMask], hi);
+    }
+  }
+}
+
+template <int T, uint32_t RING_BYTES>
+__device__ __forceinline__ void ring_flush_n(uint32_t* ring, uint8_t* dst, uint32_t from, uint32_t to) {
+  uint4* ring4 = reinterpret_cast<uint4*>(ring);
+  for (uint32_t u = (from >> 4) + threadIdx.x; u < (to >> 4); u += T) {
+    const uint32_t r = u & (RING_BYTES / 16u - 1u);
+    const uint4 v = ring4[r];
+    *reinterpret_cast<uint4*>(dst + (size_t)u * 16u) = v;
+    ring4[r] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+template <int T, int LANES, int PPT, uint32_t RING_BYTES>
+__global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const uint8_t* __restrict__ points,
+                                                     const ChunkDesc* __restrict__ chunks,
+                                                     uint8_t* __restrict__ slots, uint64_t slot_stride,
+                                                     Seg* __restrict__ segs, uint32_t segs_per_chunk,
+                                                     const ColumnPtrs cols) {
+  constexpr int NW = T / 64;
+  constexpr uint32_t ROW = NW * 63u;
+  constexpr uint32_t TILE = ROW * PPT;
+  static_assert(NW * PPT <= 64, "row/wave totals must fit one wave scan");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* ring = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + RING_BYTES);
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const ChunkDesc cd = chunks[blockIdx.x];
+  const uint32_t step = plan.point_step;
+  const int32_t n = (int32_t)cd.n_points;
+  const uint8_t* gbase = points + (size_t)cd.first_point * step + plan.ops[0].offset;
+  uint8_t* slot = slots + (size_t)blockIdx.x * slot_stride;
+  float mult[LANES];
+#pragma unroll
+  for (int k = 0; k < LANES; ++k) mult[k] = plan.ops[k].mult_f;
+
+  for (uint32_t i = tid; i < RING_BYTES / 16u; i += T) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+  FloatVec<LANES> cur[PPT], nxt[PPT];
+  auto load_tile = [&](uint32_t base, FloatVec<LANES>(&dst)[PPT]) {
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
+      FloatVec<LANES> z;
+#pragma unroll
+      for (int k = 0; k < LANES; ++k) z.v[k] = 0.0f;
+      if (idx >= 0 && idx < n) z = *reinterpret_cast<const FloatVec<LANES>*>(gbase + (size_t)idx * step);
+      dst[j] = z;
+    }
+  };
+  load_tile(0u, cur);
+  __syncthreads();
+
+  uint32_t R = 0u, F = 0u;
+  for (uint32_t base = 0; base < (uint32_t)n; base += TILE) {
+    const bool last = (base + TILE >= (uint32_t)n);
+    if (!last) load_tile(base + TILE, nxt);  // in flight while this tile is encoded
+
+    uint32_t w0[PPT][LANES], w1[PPT][LANES], ln[PPT][LANES], plen[PPT], incl[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
+      const bool emits = (lane > 0u) && (idx < n);
+      uint32_t total = 0u;
+#pragma unroll
+      for (int k = 0; k < LANES; ++k) {
+        const float v = cur[j].v[k];
+        const bool isn = is_nan_f32(v);
+        const int32_t q = quant_rne_i32(v, mult[k]);
+        // delta = q - (previous lane's q, 0 if that point was NaN: a NaN resets the lane's reference).
+        // The neighbour's value travels negated so that the DPP move folds into a commutative v_add_u32_dpp
+        // (hipcc folds "q - dpp(x)" into v_subrev_u32_dpp, which returned dpp(x) - q on gfx950 / ROCm 7.2).
+        const uint32_t nqz = isn ? 0u : (0u - (uint32_t)q);
+        const uint32_t nqp = dpp_wave_shr1(nqz);
+        const int32_t d = (int32_t)((uint32_t)q + nqp);
+        floatn_token(isn, d, w0[j][k], w1[j][k], ln[j][k]);
+        total += ln[j][k];
+      }
+      plen[j] = emits ? total : 0u;
+      incl[j] = wave_inclusive_scan(plen[j]);
+      if (lane == 63u) wtot[j * NW + (int)wave] = incl[j];
+    }
+    __syncthreads();
+    const uint32_t wt = (lane < (uint32_t)(NW * PPT)) ? wtot[lane] : 0u;
+    const uint32_t wincl = wave_inclusive_scan(wt);
+    const uint32_t tile_total = (uint32_t)__builtin_amdgcn_readlane((int)wincl, NW * PPT - 1);
+    const uint32_t r_end = R + tile_total;
+    const uint32_t target = last ? ((r_end + 15u) & ~15u) : (r_end & ~15u);
+
+    auto emit_all = [&](auto windowed, uint32_t win_lo_dw) {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        const int f = j * NW + (int)wave;
+        const uint32_t rowbase = (f == 0) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)wincl, f - 1);
+        if (plen[j]) {
+          uint32_t off = R + rowbase + incl[j] - plen[j];
+#pragma unroll
+          for (int k = 0; k < LANES; ++k) {
+            ring_put5<RING_BYTES, decltype(windowed)::value>(ring, off, w0[j][k], w1[j][k], ln[j][k], win_lo_dw);
+            off += ln[j][k];
+          }
+        }
+      }
+    };
+
+    if (r_end - F <= RING_BYTES) {
+      emit_all(std::false_type{}, 0u);
+      __syncthreads();
+      ring_flush_n<T, RING_BYTES>(ring, slot, F, target);
+      F = target;
+    } else {
+      for (;;) {
+        emit_all(std::true_type{}, F >> 2);
+        __syncthreads();
+        const uint32_t nf = min(F + RING_BYTES, target);
+        ring_flush_n<T, RING_BYTES>(ring, slot, F, nf);
+        const bool done = (F + RING_BYTES >= r_end);
+        F = nf;
+        if (done) break;
+        __syncthreads();
+      }
+    }
+    R = r_end;
+
+    // AoS -> SoA split of the adaptive-int fields (narrow loads hit the lines the point loads just fetched)
+    if (plan.n_adaptive) {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
+        if (lane > 0u && idx < n) {
+          const uint8_t* pt = points + ((size_t)cd.first_point + (size_t)idx) * step;
+          const size_t gi = (size_t)cd.first_point + (size_t)idx;
+          for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
+            const uint32_t bpv = plan.adaptive[a].bpv;
+            const uint8_t* fp = pt + plan.adaptive[a].offset;
+            uint8_t* col = cols.p[a];
+            if (((uintptr_t)fp & (bpv - 1u)) == 0u) {
+              if (bpv == 2u) reinterpret_cast<uint16_t*>(col)[gi] = *reinterpret_cast<const uint16_t*>(fp);
+              else if (bpv == 4u) reinterpret_cast<uint32_t*>(col)[gi] = *reinterpret_cast<const uint32_t*>(fp);
+              else reinterpret_cast<uint64_t*>(col)[gi] = *reinterpret_cast<const uint64_t*>(fp);
+            } else {
+              uint64_t raw = 0u;
+              for (uint32_t b = 0; b < bpv; ++b) raw |= ((uint64_t)fp[b]) << (8u * b);
+              if (bpv == 2u) reinterpret_cast<uint16_t*>(col)[gi] = (uint16_t)raw;
+              else if (bpv == 4u) reinterpret_cast<uint32_t*>(col)[gi] = (uint32_t)raw;
+              else reinterpret_cast<uint64_t*>(col)[gi] = raw;
+            }
+          }
+        }
+      }
+    }
+
+    if (!last) {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) cur[j] = nxt[j];
+    }
+    // No barrier here: the next tile's wtot writes sit behind this tile's second barrier (every wave has read
+    // wtot by then) and its ring ORs sit behind its own first barrier (every wave has finished this flush).
+  }
+
+  if (tid == 0) {
+    Seg s;
+    s.off = 0u;
+    s.size = R;
     segs[(size_t)blockIdx.x * segs_per_chunk] = s;
   }
 }
@@ -988,6 +1216,28 @@ namespace cldn {
 namespace {
 constexpr int kRegularThreads = 1024;
 constexpr uint32_t kRegularLds = 2u * (kRegularThreads * 16u + kMaxPointStep + 48u) + kRingBytes + 128u;
+constexpr uint32_t kFloatnRing = 32768;
+constexpr uint32_t kFloatnLds = kFloatnRing + 256u;
+
+// FloatN fast path: the regular stream is exactly one fused 3/4-lane float encoder on a 4-byte aligned layout
+int floatn_lanes(const DevPlan& p, const uint8_t* points) {
+  const uint32_t lanes = p.n_ops;
+  if (lanes != 3u && lanes != 4u) return 0;
+  for (uint32_t k = 0; k < lanes; ++k) {
+    if (p.ops[k].kind != OP_QF32 || p.ops[k].offset != p.ops[0].offset + 4u * k) return 0;
+  }
+  if ((p.point_step & 3u) || (p.ops[0].offset & 3u) || ((uintptr_t)points & 3u)) return 0;
+  return (int)lanes;
+}
+
+int floatn_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CLDN_HIP_FLOATN_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
 
 int hip_fail(hipError_t e, const char* what) {
   fprintf(stderr, "[cloudini_hip] %s: %s\n", what, hipGetErrorString(e));
@@ -999,6 +1249,16 @@ int stage1_configure_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_regular<kRegularThreads>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRegularLds);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_regular)");
+  const void* fk[] = {reinterpret_cast<const void*>(&k_encode_floatn<512, 3, 4, kFloatnRing>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<512, 4, 4, kFloatnRing>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<1024, 3, 2, kFloatnRing>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<1024, 4, 2, kFloatnRing>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 4, kFloatnRing>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 4, kFloatnRing>)};
+  for (const void* f : fk) {
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFloatnLds);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_floatn)");
+  }
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_probe_modes), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kSecLdsTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_probe_modes)");
@@ -1013,10 +1273,23 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   if (L.events) (void)hipEventRecord(L.events[0], L.stream);
   if (L.events) (void)hipEventRecord(L.events[1], L.stream);
   if (L.n_chunks) {
-    hipLaunchKernelGGL(k_encode_regular<kRegularThreads>, dim3(L.n_chunks), dim3(kRegularThreads), kRegularLds,
-                       L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots, L.slot_stride, L.segs,
-                       L.segs_per_chunk, L.cols);
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_regular");
+    const int lanes = floatn_lanes(*L.plan, L.points);
+    const int variant = floatn_variant();
+#define LAUNCH_FLOATN(TT, LL, PP)                                                                                 \
+  hipLaunchKernelGGL((k_encode_floatn<TT, LL, PP, kFloatnRing>), dim3(L.n_chunks), dim3(TT), kFloatnLds, L.stream, \
+                     *L.plan, L.points, L.chunks, L.slots, L.slot_stride, L.segs, L.segs_per_chunk, L.cols)
+    if (lanes == 3 && variant == 0) LAUNCH_FLOATN(512, 3, 4);
+    else if (lanes == 4 && variant == 0) LAUNCH_FLOATN(512, 4, 4);
+    else if (lanes == 3 && variant == 1) LAUNCH_FLOATN(1024, 3, 2);
+    else if (lanes == 4 && variant == 1) LAUNCH_FLOATN(1024, 4, 2);
+    else if (lanes == 3 && variant == 2) LAUNCH_FLOATN(256, 3, 4);
+    else if (lanes == 4 && variant == 2) LAUNCH_FLOATN(256, 4, 4);
+    else
+      hipLaunchKernelGGL(k_encode_regular<kRegularThreads>, dim3(L.n_chunks), dim3(kRegularThreads), kRegularLds,
+                         L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots, L.slot_stride, L.segs,
+                         L.segs_per_chunk, L.cols);
+#undef LAUNCH_FLOATN
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_regular/floatn");
   }
   if (L.events) (void)hipEventRecord(L.events[2], L.stream);
   const uint32_t na = L.plan->n_adaptive;
