@@ -525,8 +525,19 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   if (need && !out) return fail(CLDN_HIP_ERR_ARG, "out is NULL");
 
   const uint32_t n_adaptive = plan.n_adaptive;
-  const uint32_t segs_per_chunk = 1u + 2u * n_adaptive;
-  const uint64_t reg_stride = (((uint64_t)kPointsPerChunk * plan.max_regular_bytes + 64u) + 255u) & ~uint64_t(255);
+  // Sub-chunks: the regular stream of a chunk is produced as `subs` independent sub-streams (one workgroup each)
+  // that the compaction kernel concatenates; this multiplies the parallelism of small batches at no extra work.
+  uint32_t subs = 1;
+  if (const char* e = getenv("CLDN_HIP_SUBCHUNKS")) {
+    subs = (uint32_t)atoi(e);
+  } else {
+    while (subs < 32u && (uint64_t)n_chunks * subs < 6000u) subs *= 2u;
+  }
+  if (subs < 1u || subs > 32u || (subs & (subs - 1u))) subs = 1u;
+  const uint32_t sub_points = kPointsPerChunk / subs;
+  const uint32_t sub_stride = (uint32_t)((((uint64_t)sub_points * plan.max_regular_bytes + 64u) + 255u) & ~uint64_t(255));
+  const uint32_t segs_per_chunk = subs + 2u * n_adaptive;
+  const uint64_t reg_stride = (uint64_t)subs * sub_stride;
   const uint64_t slot_stride = reg_stride + (uint64_t)n_adaptive * kSectionStride;
 
   if ((rc = c->d_status.ensure(256)) != CLDN_HIP_OK) return rc;
@@ -555,7 +566,7 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
       if ((rc = c->d_out.ensure((size_t)need)) != CLDN_HIP_OK) return rc;
       d_outp = (uint8_t*)c->d_out.p;
     }
-    if (n_adaptive) HIP_TRY(hipMemsetAsync(c->d_segs.p, 0, (size_t)n_chunks * segs_per_chunk * sizeof(Seg), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_segs.p, 0, (size_t)n_chunks * segs_per_chunk * sizeof(Seg), c->stream));
   }
 
   EncodeLaunch L;
@@ -571,6 +582,9 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   L.slots = (uint8_t*)c->d_slots.p;
   L.slot_stride = slot_stride;
   L.reg_stride = reg_stride;
+  L.subs = subs;
+  L.sub_points = sub_points;
+  L.sub_stride = sub_stride;
   L.segs = (Seg*)c->d_segs.p;
   L.segs_per_chunk = segs_per_chunk;
   for (uint32_t a = 0; a < n_adaptive; ++a) {

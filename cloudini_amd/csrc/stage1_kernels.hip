@@ -236,11 +236,11 @@ struct TileGeom {
 };
 
 __device__ __forceinline__ TileGeom tile_geom(const uint8_t* gchunk, uint32_t step, uint32_t P, uint32_t n,
-                                              uint32_t it) {
+                                              uint32_t it, bool first_has_prev) {
   TileGeom g;
   g.p0 = it * P;
   g.npts = min(P, n - g.p0);
-  const uint32_t lead = (it > 0u) ? step : 0u;  // stage the previous point too (delta reference)
+  const uint32_t lead = (it > 0u || first_has_prev) ? step : 0u;  // stage the previous point too (delta reference)
   const uint8_t* ga0 = gchunk + (size_t)g.p0 * step - lead;
   const uint32_t mis = (uint32_t)((uintptr_t)ga0 & 15u);
   g.a0 = ga0 - mis;
@@ -269,26 +269,42 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
                                                       const ChunkDesc* __restrict__ chunks,
                                                       uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                       Seg* __restrict__ segs, uint32_t segs_per_chunk,
-                                                      const ColumnPtrs cols) {
+                                                      const ColumnPtrs cols, uint32_t subs, uint32_t sub_points,
+                                                      uint32_t sub_stride) {
   constexpr uint32_t kTileLds = T * 16u + kMaxPointStep + 48u;  // multiple of 16
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* ring = reinterpret_cast<uint32_t*>(smem + 2u * kTileLds);
   uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + 2u * kTileLds + kRingBytes);
 
   const uint32_t tid = threadIdx.x;
-  const ChunkDesc cd = chunks[blockIdx.x];
+  // one workgroup per sub-chunk: points [sub_first, sub_first + n) of chunk `chunk_id`. Sub-chunks produce
+  // independent byte streams (own segment); only the delta reference of the first point crosses the boundary.
+  const uint32_t chunk_id = blockIdx.x / subs;
+  const uint32_t sub_id = blockIdx.x - chunk_id * subs;
+  const ChunkDesc cd = chunks[chunk_id];
   const uint32_t step = plan.point_step;
-  const uint32_t n = cd.n_points;
+  const uint32_t sub_first = sub_id * sub_points;
+  const uint32_t n = cd.n_points > sub_first ? min(sub_points, cd.n_points - sub_first) : 0u;
   const uint32_t P = min((uint32_t)T, ((T * 16u) / step) & ~63u);  // points per tile (multiple of 64)
   const uint32_t n_tiles = (n + P - 1u) / P;
-  const uint8_t* gchunk = points + (size_t)cd.first_point * step;
-  uint8_t* slot = slots + (size_t)blockIdx.x * slot_stride;
+  const uint8_t* gchunk = points + ((size_t)cd.first_point + sub_first) * step;
+  uint8_t* slot = slots + (size_t)chunk_id * slot_stride + (size_t)sub_id * sub_stride;
+  if (n == 0u) {
+    if (tid == 0) {
+      Seg s;
+      s.off = sub_id * sub_stride;
+      s.size = 0u;
+      segs[(size_t)chunk_id * segs_per_chunk + sub_id] = s;
+    }
+    return;
+  }
 
   // zero the ring
   for (uint32_t i = tid; i < kRingU4; i += T) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0u, 0u, 0u, 0u);
 
   // stage tile 0
-  TileGeom g = tile_geom(gchunk, step, P, n, 0u);
+  const bool sub_has_prev = sub_first > 0u;
+  TileGeom g = tile_geom(gchunk, step, P, n, 0u, sub_has_prev);
   for (uint32_t u = tid; u < g.units; u += T) {
     reinterpret_cast<uint4*>(smem)[u] = load_unit_guarded(g.a0 + (size_t)u * 16u, points, points_end);
   }
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
     gn.units = 0u;
     uint4 pre0 = make_uint4(0u, 0u, 0u, 0u), pre1 = pre0;
     if (it + 1u < n_tiles) {
-      gn = tile_geom(gchunk, step, P, n, it + 1u);
+      gn = tile_geom(gchunk, step, P, n, it + 1u, sub_has_prev);
       if (tid < gn.units) pre0 = load_unit_guarded(gn.a0 + (size_t)tid * 16u, points, points_end);
       if (tid + T < gn.units) pre1 = load_unit_guarded(gn.a0 + (size_t)(tid + T) * 16u, points, points_end);
     }
@@ -316,7 +332,7 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
     PointRef pr;
     pr.cur = g.first_off + tid * step;
     pr.prev = pr.cur - step;
-    pr.has_prev = (g.p0 + tid) > 0u;
+    pr.has_prev = (sub_first + g.p0 + tid) > 0u;
 
     // pass A: bytes this point contributes to the regular stream
     uint32_t my_len = 0u;
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
 
     // AoS -> SoA split of the adaptive-int fields
     if (active) {
-      const size_t gi = (size_t)cd.first_point + g.p0 + tid;
+      const size_t gi = (size_t)cd.first_point + sub_first + g.p0 + tid;
       for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
         const uint32_t bpv = plan.adaptive[a].bpv;
         const uint64_t raw = lds_raw(tile, pr.cur + plan.adaptive[a].offset, bpv);
@@ -389,9 +405,9 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
 
   if (tid == 0) {
     Seg s;
-    s.off = 0u;
+    s.off = sub_id * sub_stride;
     s.size = ss.R;
-    segs[(size_t)blockIdx.x * segs_per_chunk] = s;
+    segs[(size_t)chunk_id * segs_per_chunk + sub_id] = s;
   }
 }
 
@@ -468,7 +484,8 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
                                                      const ChunkDesc* __restrict__ chunks,
                                                      uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                      Seg* __restrict__ segs, uint32_t segs_per_chunk,
-                                                     const ColumnPtrs cols) {
+                                                     const ColumnPtrs cols, uint32_t subs, uint32_t sub_points,
+                                                     uint32_t sub_stride, uint32_t ablate) {
   constexpr int NW = T / 64;
   constexpr uint32_t ROW = NW * 63u;
   constexpr uint32_t TILE = ROW * PPT;
@@ -480,11 +497,25 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const ChunkDesc cd = chunks[blockIdx.x];
+  const uint32_t chunk_id = blockIdx.x / subs;
+  const uint32_t sub_id = blockIdx.x - chunk_id * subs;
+  const ChunkDesc cd = chunks[chunk_id];
   const uint32_t step = plan.point_step;
-  const int32_t n = (int32_t)cd.n_points;
-  const uint8_t* gbase = points + (size_t)cd.first_point * step + plan.ops[0].offset;
-  uint8_t* slot = slots + (size_t)blockIdx.x * slot_stride;
+  const uint32_t sub_first = sub_id * sub_points;  // first point of this workgroup's sub-chunk inside the chunk
+  const int32_t n = cd.n_points > sub_first ? (int32_t)min(sub_points, cd.n_points - sub_first) : 0;
+  const int32_t idx_lo = sub_first > 0u ? -1 : 0;  // the point before the sub-chunk is a valid delta reference
+  const size_t first_point = (size_t)cd.first_point + sub_first;
+  const uint8_t* gbase = points + first_point * step + plan.ops[0].offset;
+  uint8_t* slot = slots + (size_t)chunk_id * slot_stride + (size_t)sub_id * sub_stride;
+  if (n == 0) {  // sub-chunk beyond the end of a short chunk: nothing to read, empty segment
+    if (tid == 0) {
+      Seg s;
+      s.off = sub_id * sub_stride;
+      s.size = 0u;
+      segs[(size_t)chunk_id * segs_per_chunk + sub_id] = s;
+    }
+    return;
+  }
   float mult[LANES];
 #pragma unroll
   for (int k = 0; k < LANES; ++k) mult[k] = plan.ops[k].mult_f;
@@ -499,7 +530,8 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
       FloatVec<LANES> z;
 #pragma unroll
       for (int k = 0; k < LANES; ++k) z.v[k] = 0.0f;
-      if (idx >= 0 && idx < n) z = *reinterpret_cast<const FloatVec<LANES>*>(gbase + (size_t)idx * step);
+      if (idx >= idx_lo && idx < n && !(ablate & 8u))
+        z = *reinterpret_cast<const FloatVec<LANES>*>(gbase + (ptrdiff_t)idx * (ptrdiff_t)step);
       dst[j] = z;
     }
   };
@@ -547,7 +579,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
       for (int j = 0; j < PPT; ++j) {
         const int f = j * NW + (int)wave;
         const uint32_t rowbase = (f == 0) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)wincl, f - 1);
-        if (plen[j]) {
+        if (plen[j] && !(ablate & 2u)) {
           uint32_t off = R + rowbase + incl[j] - plen[j];
 #pragma unroll
           for (int k = 0; k < LANES; ++k) {
@@ -561,7 +593,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
     if (r_end - F <= RING_BYTES) {
       emit_all(std::false_type{}, 0u);
       __syncthreads();
-      ring_flush_n<T, RING_BYTES>(ring, slot, F, target);
+      if (!(ablate & 4u)) ring_flush_n<T, RING_BYTES>(ring, slot, F, target);
       F = target;
     } else {
       for (;;) {
@@ -578,13 +610,13 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
     R = r_end;
 
     // AoS -> SoA split of the adaptive-int fields (narrow loads hit the lines the point loads just fetched)
-    if (plan.n_adaptive) {
+    if (plan.n_adaptive && !(ablate & 1u)) {
 #pragma unroll
       for (int j = 0; j < PPT; ++j) {
         const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
         if (lane > 0u && idx < n) {
-          const uint8_t* pt = points + ((size_t)cd.first_point + (size_t)idx) * step;
-          const size_t gi = (size_t)cd.first_point + (size_t)idx;
+          const uint8_t* pt = points + (first_point + (size_t)idx) * step;
+          const size_t gi = first_point + (size_t)idx;
           for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
             const uint32_t bpv = plan.adaptive[a].bpv;
             const uint8_t* fp = pt + plan.adaptive[a].offset;
@@ -615,9 +647,9 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
 
   if (tid == 0) {
     Seg s;
-    s.off = 0u;
+    s.off = sub_id * sub_stride;
     s.size = R;
-    segs[(size_t)blockIdx.x * segs_per_chunk] = s;
+    segs[(size_t)chunk_id * segs_per_chunk + sub_id] = s;
   }
 }
 
@@ -1165,7 +1197,8 @@ __global__ __launch_bounds__(kSecThreads) void k_encode_sections(const DevPlan p
                                                                  const ColumnPtrs cols, const uint8_t* __restrict__ modes,
                                                                  uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                                  uint64_t reg_stride, Seg* __restrict__ segs,
-                                                                 uint32_t segs_per_chunk, const ColumnPtrs rank_cols) {
+                                                                 uint32_t segs_per_chunk, const ColumnPtrs rank_cols,
+                                                                 uint32_t subs) {
   constexpr int T = kSecThreads;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const SecLds l = sec_lds_carve(smem);
@@ -1196,10 +1229,10 @@ __global__ __launch_bounds__(kSecThreads) void k_encode_sections(const DevPlan p
     Seg s;
     s.off = sec_off;
     s.size = size_a;
-    segs[(size_t)c * segs_per_chunk + 1u + 2u * a] = s;
+    segs[(size_t)c * segs_per_chunk + subs + 2u * a] = s;
     s.off = sec_off + kPaletteIndexOffset;
     s.size = size_b;
-    segs[(size_t)c * segs_per_chunk + 2u + 2u * a] = s;
+    segs[(size_t)c * segs_per_chunk + subs + 1u + 2u * a] = s;
   }
 }
 
@@ -1275,9 +1308,11 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   if (L.n_chunks) {
     const int lanes = floatn_lanes(*L.plan, L.points);
     const int variant = floatn_variant();
+    static const uint32_t ablate = getenv("CLDN_HIP_ABLATE") ? (uint32_t)atoi(getenv("CLDN_HIP_ABLATE")) : 0u;  // profiling only
 #define LAUNCH_FLOATN(TT, LL, PP)                                                                                 \
-  hipLaunchKernelGGL((k_encode_floatn<TT, LL, PP, kFloatnRing>), dim3(L.n_chunks), dim3(TT), kFloatnLds, L.stream, \
-                     *L.plan, L.points, L.chunks, L.slots, L.slot_stride, L.segs, L.segs_per_chunk, L.cols)
+  hipLaunchKernelGGL((k_encode_floatn<TT, LL, PP, kFloatnRing>), dim3(L.n_chunks * L.subs), dim3(TT), kFloatnLds, \
+                     L.stream, *L.plan, L.points, L.chunks, L.slots, L.slot_stride, L.segs, L.segs_per_chunk, L.cols, \
+                     L.subs, L.sub_points, L.sub_stride, ablate)
     if (lanes == 3 && variant == 0) LAUNCH_FLOATN(512, 3, 4);
     else if (lanes == 4 && variant == 0) LAUNCH_FLOATN(512, 4, 4);
     else if (lanes == 3 && variant == 1) LAUNCH_FLOATN(1024, 3, 2);
@@ -1285,9 +1320,9 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     else if (lanes == 3 && variant == 2) LAUNCH_FLOATN(256, 3, 4);
     else if (lanes == 4 && variant == 2) LAUNCH_FLOATN(256, 4, 4);
     else
-      hipLaunchKernelGGL(k_encode_regular<kRegularThreads>, dim3(L.n_chunks), dim3(kRegularThreads), kRegularLds,
-                         L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots, L.slot_stride, L.segs,
-                         L.segs_per_chunk, L.cols);
+      hipLaunchKernelGGL(k_encode_regular<kRegularThreads>, dim3(L.n_chunks * L.subs), dim3(kRegularThreads),
+                         kRegularLds, L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots, L.slot_stride,
+                         L.segs, L.segs_per_chunk, L.cols, L.subs, L.sub_points, L.sub_stride);
 #undef LAUNCH_FLOATN
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_regular/floatn");
   }
@@ -1301,7 +1336,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_modes");
     hipLaunchKernelGGL(k_encode_sections, dim3(L.n_chunks, na), dim3(kSecThreads), kSecLdsTotal, L.stream, *L.plan,
                        L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk,
-                       rank_cols);
+                       rank_cols, L.subs);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_sections");
   }
   if (L.events) (void)hipEventRecord(L.events[3], L.stream);

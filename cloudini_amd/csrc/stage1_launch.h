@@ -19,7 +19,10 @@ struct EncodeLaunch {
   const uint32_t* cloud_first_chunk;  // device [n_clouds + 1]
   uint8_t* slots;             // device [n_chunks * slot_stride]
   uint64_t slot_stride;
-  uint64_t reg_stride;
+  uint64_t reg_stride;        // = subs * sub_stride
+  uint32_t subs;              // sub-chunks (independent regular sub-streams) per chunk, power of two
+  uint32_t sub_points;        // 32768 / subs
+  uint32_t sub_stride;        // bytes reserved per sub-stream
   Seg* segs;                  // device [n_chunks * segs_per_chunk]
   uint32_t segs_per_chunk;
   ColumnPtrs cols;
