@@ -128,7 +128,7 @@ struct cldn_hip_codec {
   DevBuf d_in, d_out, d_slots, d_chunks, d_cloud_first, d_segs, d_payload, d_dst, d_offsets, d_modes, d_status;
   DevBuf d_cols[kMaxAdaptive];
   DevBuf d_ranks[kMaxAdaptive];
-  DevBuf d_dec_meta;
+  DevBuf d_dec_meta, d_fbflags;
   PinnedBuf h_stage;   // chunk table upload
   PinnedBuf h_result;  // offsets / status readback
   // cached batch shape
@@ -385,7 +385,7 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_segs,
-                    &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta};
+                    &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_fbflags};
   for (DevBuf* b : bufs) b->release();
   for (int a = 0; a < kMaxAdaptive; ++a) {
     c->d_cols[a].release();
@@ -553,6 +553,8 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
     if ((rc = c->d_payload.ensure((size_t)n_chunks * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_dst.ensure((size_t)n_chunks * sizeof(uint64_t))) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_slots.ensure((size_t)n_chunks * slot_stride)) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_fbflags.ensure((size_t)n_chunks * std::max(1u, n_adaptive))) != CLDN_HIP_OK) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_fbflags.p, 0, (size_t)n_chunks * std::max(1u, n_adaptive), c->stream));
     for (uint32_t a = 0; a < n_adaptive; ++a) {
       if ((rc = c->d_cols[a].ensure((size_t)n_points * plan.adaptive[a].bpv + 64)) != CLDN_HIP_OK) return rc;
       if ((rc = c->d_ranks[a].ensure((size_t)n_points * 2 + 64)) != CLDN_HIP_OK) return rc;
@@ -595,6 +597,7 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   L.chunk_dst = (uint64_t*)c->d_dst.p;
   L.stream_offsets = (uint64_t*)c->d_offsets.p;
   L.modes = (uint8_t*)c->d_modes.p;
+  L.fallback_flags = (uint8_t*)c->d_fbflags.p;
   L.out = d_outp;
   L.out_capacity = out_capacity;
   L.status = (uint32_t*)c->d_status.p;

@@ -768,6 +768,12 @@ __global__ __launch_bounds__(T) void k_compact(const uint8_t* __restrict__ slots
 
 namespace cldn {
 
+}  // namespace cldn
+
+#include "stage1_sections.h"
+
+namespace cldn {
+
 constexpr int kSecThreads = 1024;
 constexpr uint32_t kPalSlots = 8192;      // LDS hash table slots (keys u64 + first-index u16)
 constexpr uint32_t kPalCapacity = 6144;   // distinct values one table pass accepts (load factor 0.75)
@@ -1198,11 +1204,12 @@ __global__ __launch_bounds__(kSecThreads) void k_encode_sections(const DevPlan p
                                                                  uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                                  uint64_t reg_stride, Seg* __restrict__ segs,
                                                                  uint32_t segs_per_chunk, const ColumnPtrs rank_cols,
-                                                                 uint32_t subs) {
+                                                                 uint32_t subs, const uint8_t* __restrict__ handled_flags) {
   constexpr int T = kSecThreads;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const SecLds l = sec_lds_carve(smem);
   const uint32_t c = blockIdx.x, a = blockIdx.y;
+  if (handled_flags[(size_t)c * plan.n_adaptive + a]) return;  // a fast-path kernel already wrote this section
   const ChunkDesc cd = chunks[c];
   const uint32_t n = cd.n_points;
   const uint32_t bpv = plan.adaptive[a].bpv, type = plan.adaptive[a].type;
@@ -1298,6 +1305,13 @@ int stage1_configure_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_sections),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSecLdsTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_sections)");
+  const void* pk[] = {reinterpret_cast<const void*>(&k_section_palette<uint16_t>),
+                      reinterpret_cast<const void*>(&k_section_palette<uint32_t>),
+                      reinterpret_cast<const void*>(&k_section_palette<uint64_t>)};
+  for (const void* f : pk) {
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS2PalLds);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_palette)");
+  }
   return CLDN_HIP_OK;
 }
 
@@ -1334,9 +1348,22 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     hipLaunchKernelGGL(k_probe_modes, dim3(L.n_clouds, na), dim3(kSecThreads), kSecLdsTotal, L.stream, *L.plan,
                        L.chunks, L.cloud_first_chunk, L.cols, L.modes);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_modes");
+    static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch
+    for (uint32_t a = 0; a < na && !no_fast; ++a) {
+      const uint32_t bpv = L.plan->adaptive[a].bpv;
+#define LAUNCH_PAL(RT)                                                                                              \
+  hipLaunchKernelGGL(k_section_palette<RT>, dim3(L.n_chunks), dim3(kS2Threads), kS2PalLds, L.stream, *L.plan, a,      \
+                     L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs, \
+                     L.fallback_flags)
+      if (bpv == 2u) LAUNCH_PAL(uint16_t);
+      else if (bpv == 4u) LAUNCH_PAL(uint32_t);
+      else LAUNCH_PAL(uint64_t);
+#undef LAUNCH_PAL
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_palette");
+    }
     hipLaunchKernelGGL(k_encode_sections, dim3(L.n_chunks, na), dim3(kSecThreads), kSecLdsTotal, L.stream, *L.plan,
                        L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk,
-                       rank_cols, L.subs);
+                       rank_cols, L.subs, L.fallback_flags);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_sections");
   }
   if (L.events) (void)hipEventRecord(L.events[3], L.stream);
