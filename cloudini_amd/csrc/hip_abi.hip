@@ -609,6 +609,28 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   if (n_slots) c->slot_valid[slot] = 1;
   ++c->call_index;
 
+  if (const char* dump = getenv("CLDN_HIP_DEBUG_DUMP")) {  // diagnostics: segment table of the last call
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<Seg> hs((size_t)n_chunks * segs_per_chunk);
+    std::vector<ChunkDesc> hc(n_chunks);
+    if (n_chunks) {
+      HIP_TRY(hipMemcpy(hs.data(), c->d_segs.p, hs.size() * sizeof(Seg), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(hc.data(), c->d_chunks.p, hc.size() * sizeof(ChunkDesc), hipMemcpyDeviceToHost));
+    }
+    if (FILE* f = fopen(dump, "w")) {
+      fprintf(f, "subs %u sub_points %u sub_stride %u segs_per_chunk %u slot_stride %llu\n", subs, sub_points, sub_stride,
+              segs_per_chunk, (unsigned long long)slot_stride);
+      for (uint32_t ci = 0; ci < n_chunks; ++ci) {
+        fprintf(f, "chunk %u first %llu n %u cloud %u:", ci, (unsigned long long)hc[ci].first_point, hc[ci].n_points,
+                hc[ci].cloud);
+        for (uint32_t k = 0; k < segs_per_chunk; ++k)
+          fprintf(f, " [%u,%u]", hs[(size_t)ci * segs_per_chunk + k].off, hs[(size_t)ci * segs_per_chunk + k].size);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+
   const size_t modes_bytes = (size_t)n_clouds * n_adaptive;
   if (out_loc == CLDN_HIP_DEVICE) {
     if (stream_offsets)

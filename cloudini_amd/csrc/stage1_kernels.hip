@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "stage1_device.h"
@@ -284,7 +285,9 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
   const ChunkDesc cd = chunks[chunk_id];
   const uint32_t step = plan.point_step;
   const uint32_t sub_first = sub_id * sub_points;
-  const uint32_t n = cd.n_points > sub_first ? min(sub_points, cd.n_points - sub_first) : 0u;
+  // points of this sub-chunk; written with a saturating subtraction (hipcc 7.2 folded the guarded form
+  // "n_points > sub_first ? min(sub_points, n_points - sub_first) : 0" into an unguarded unsigned min)
+  const uint32_t n = min(sub_points, cd.n_points - min(cd.n_points, sub_first));
   const uint32_t P = min((uint32_t)T, ((T * 16u) / step) & ~63u);  // points per tile (multiple of 64)
   const uint32_t n_tiles = (n + P - 1u) / P;
   const uint8_t* gchunk = points + ((size_t)cd.first_point + sub_first) * step;
@@ -479,7 +482,26 @@ __device__ __forceinline__ void ring_flush_n(uint32_t* ring, uint8_t* dst, uint3
   }
 }
 
-template <int T, int LANES, int PPT, uint32_t RING_BYTES>
+constexpr uint32_t kStagedCols = 2;  // adaptive fields (2 or 4 bytes wide) whose SoA copy is staged through LDS
+
+__device__ __forceinline__ bool col_staged(const DevPlan& plan, uint32_t a, bool from_regs) {
+  return from_regs && a < kStagedCols && plan.adaptive[a].bpv <= 4u;
+}
+
+// bytes [rel, rel + 8) of the dwords loaded for one point (rel + field size <= 4 * LOADW, guaranteed by the host)
+template <int LOADW>
+__device__ __forceinline__ uint64_t field_from_regs(const FloatVec<LOADW>& pt, uint32_t rel) {
+  const uint32_t di = rel >> 2;
+  uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+  for (int k = 0; k < LOADW; ++k) {
+    if ((uint32_t)k == di) lo = __float_as_uint(pt.v[k]);
+    if ((uint32_t)k == di + 1u) hi = __float_as_uint(pt.v[k]);
+  }
+  return ((((uint64_t)hi) << 32) | lo) >> ((rel & 3u) * 8u);
+}
+
+template <int T, int LANES, int PPT, uint32_t RING_BYTES, int LOADW, bool PREFETCH = true>
 __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const uint8_t* __restrict__ points,
                                                      const ChunkDesc* __restrict__ chunks,
                                                      uint8_t* __restrict__ slots, uint64_t slot_stride,
@@ -493,6 +515,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* ring = reinterpret_cast<uint32_t*>(smem);
   uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + RING_BYTES);
+  uint8_t* colstage = smem + RING_BYTES + 256u;  // [kStagedCols][TILE * 4] SoA staging of the adaptive fields
 
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
@@ -502,7 +525,8 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
   const ChunkDesc cd = chunks[chunk_id];
   const uint32_t step = plan.point_step;
   const uint32_t sub_first = sub_id * sub_points;  // first point of this workgroup's sub-chunk inside the chunk
-  const int32_t n = cd.n_points > sub_first ? (int32_t)min(sub_points, cd.n_points - sub_first) : 0;
+  // points of this sub-chunk (saturating subtraction, see k_encode_regular)
+  const int32_t n = (int32_t)min(sub_points, cd.n_points - min(cd.n_points, sub_first));
   const int32_t idx_lo = sub_first > 0u ? -1 : 0;  // the point before the sub-chunk is a valid delta reference
   const size_t first_point = (size_t)cd.first_point + sub_first;
   const uint8_t* gbase = points + first_point * step + plan.ops[0].offset;
@@ -522,46 +546,73 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
 
   for (uint32_t i = tid; i < RING_BYTES / 16u; i += T) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0u, 0u, 0u, 0u);
 
-  FloatVec<LANES> cur[PPT], nxt[PPT];
-  auto load_tile = [&](uint32_t base, FloatVec<LANES>(&dst)[PPT]) {
+  // LOADW >= LANES dwords are loaded per point (one global_load_dwordx3/x4/...): the extra dwords carry the
+  // adaptive-int fields that live right behind the floats, so their AoS->SoA split needs no second load.
+  FloatVec<LOADW> cur[PPT], nxt[PPT];
+  auto load_tile = [&](uint32_t base, FloatVec<LOADW>(&dst)[PPT]) {
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
-      FloatVec<LANES> z;
+      FloatVec<LOADW> z;
 #pragma unroll
-      for (int k = 0; k < LANES; ++k) z.v[k] = 0.0f;
+      for (int k = 0; k < LOADW; ++k) z.v[k] = 0.0f;
       if (idx >= idx_lo && idx < n && !(ablate & 8u))
-        z = *reinterpret_cast<const FloatVec<LANES>*>(gbase + (ptrdiff_t)idx * (ptrdiff_t)step);
+        z = *reinterpret_cast<const FloatVec<LOADW>*>(gbase + (ptrdiff_t)idx * (ptrdiff_t)step);
       dst[j] = z;
     }
   };
-  load_tile(0u, cur);
+  if (PREFETCH) load_tile(0u, cur);
   __syncthreads();
 
   uint32_t R = 0u, F = 0u;
   for (uint32_t base = 0; base < (uint32_t)n; base += TILE) {
     const bool last = (base + TILE >= (uint32_t)n);
-    if (!last) load_tile(base + TILE, nxt);  // in flight while this tile is encoded
+    if (PREFETCH) {
+      if (!last) load_tile(base + TILE, nxt);  // in flight while this tile is encoded
+    } else {
+      load_tile(base, cur);  // latency is covered by the other workgroups resident on the CU
+    }
 
-    uint32_t w0[PPT][LANES], w1[PPT][LANES], ln[PPT][LANES], plen[PPT], incl[PPT];
+    // Tokens of the row's points. Common case (no NaN in the wave row, every token <= 4 bytes, i.e. |delta| <
+    // 2^27 ticks): one dword per token, built with the short formulas and kept until the scan is done. Rows with a
+    // NaN or a 5-byte token (wave-uniform test) use the general formulas and are rebuilt at emission time.
+    uint32_t tok[PPT][LANES], plen[PPT], incl[PPT];
+    uint32_t rare_rows = 0u;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
       const bool emits = (lane > 0u) && (idx < n);
       uint32_t total = 0u;
+      bool rare = false;
 #pragma unroll
       for (int k = 0; k < LANES; ++k) {
         const float v = cur[j].v[k];
-        const bool isn = is_nan_f32(v);
         const int32_t q = quant_rne_i32(v, mult[k]);
-        // delta = q - (previous lane's q, 0 if that point was NaN: a NaN resets the lane's reference).
-        // The neighbour's value travels negated so that the DPP move folds into a commutative v_add_u32_dpp
-        // (hipcc folds "q - dpp(x)" into v_subrev_u32_dpp, which returned dpp(x) - q on gfx950 / ROCm 7.2).
-        const uint32_t nqz = isn ? 0u : (0u - (uint32_t)q);
-        const uint32_t nqp = dpp_wave_shr1(nqz);
+        // delta = q - previous lane's q; the neighbour's value travels negated so that the DPP move folds into a
+        // commutative v_add_u32_dpp (hipcc folds "q - dpp(x)" into v_subrev_u32_dpp, which returned dpp(x) - q
+        // on gfx950 / ROCm 7.2).
+        const uint32_t nqp = dpp_wave_shr1(0u - (uint32_t)q);
         const int32_t d = (int32_t)((uint32_t)q + nqp);
-        floatn_token(isn, d, w0[j][k], w1[j][k], ln[j][k]);
-        total += ln[j][k];
+        const uint32_t zz = ((uint32_t)d << 1) ^ (uint32_t)(d >> 31);
+        rare |= is_nan_f32(v) | (zz >= 0x0fffffffu);
+        const uint32_t u = zz + 1u;
+        const uint32_t l = groups7(32u - (uint32_t)__clz((int)u));
+        tok[j][k] = spread28(u) | (0x00808080u >> ((32u - 8u * l) & 31u));
+        total += l;
+      }
+      if (__ballot(rare) != 0ull) {
+        rare_rows |= 1u << j;
+        total = 0u;
+#pragma unroll
+        for (int k = 0; k < LANES; ++k) {
+          const float v = cur[j].v[k];
+          const bool isn = is_nan_f32(v);
+          const int32_t q = quant_rne_i32(v, mult[k]);
+          const uint32_t nqp = dpp_wave_shr1(isn ? 0u : (0u - (uint32_t)q));  // a NaN resets that lane's reference
+          uint32_t a0, a1, l;
+          floatn_token(isn, (int32_t)((uint32_t)q + nqp), a0, a1, l);
+          total += l;
+        }
       }
       plen[j] = emits ? total : 0u;
       incl[j] = wave_inclusive_scan(plen[j]);
@@ -574,17 +625,49 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
     const uint32_t r_end = R + tile_total;
     const uint32_t target = last ? ((r_end + 15u) & ~15u) : (r_end & ~15u);
 
+    if (plan.n_adaptive && LOADW > LANES && !(ablate & 1u)) {
+      for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
+        if (!col_staged(plan, a, true)) continue;
+        const uint32_t bpv = plan.adaptive[a].bpv;
+        uint8_t* st = colstage + (size_t)a * (TILE * 4u);
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+          const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
+          if (lane > 0u && idx < n) {
+            const uint32_t t = (uint32_t)idx - base;  // point index inside the tile
+            const uint64_t raw = field_from_regs<LOADW>(cur[j], plan.adaptive[a].offset - plan.ops[0].offset);
+            if (bpv == 2u) reinterpret_cast<uint16_t*>(st)[t] = (uint16_t)raw;
+            else reinterpret_cast<uint32_t*>(st)[t] = (uint32_t)raw;
+          }
+        }
+      }
+    }
+
     auto emit_all = [&](auto windowed, uint32_t win_lo_dw) {
 #pragma unroll
       for (int j = 0; j < PPT; ++j) {
         const int f = j * NW + (int)wave;
         const uint32_t rowbase = (f == 0) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)wincl, f - 1);
-        if (plen[j] && !(ablate & 2u)) {
-          uint32_t off = R + rowbase + incl[j] - plen[j];
+        uint32_t off = R + rowbase + incl[j] - plen[j];
+        if (rare_rows & (1u << j)) {  // wave-uniform: rebuild the general tokens (all lanes take part in the DPP)
 #pragma unroll
           for (int k = 0; k < LANES; ++k) {
-            ring_put5<RING_BYTES, decltype(windowed)::value>(ring, off, w0[j][k], w1[j][k], ln[j][k], win_lo_dw);
-            off += ln[j][k];
+            const float v = cur[j].v[k];
+            const bool isn = is_nan_f32(v);
+            const int32_t q = quant_rne_i32(v, mult[k]);
+            const uint32_t nqp = dpp_wave_shr1(isn ? 0u : (0u - (uint32_t)q));
+            uint32_t a0, a1, l;
+            floatn_token(isn, (int32_t)((uint32_t)q + nqp), a0, a1, l);
+            if (plen[j] && !(ablate & 2u)) ring_put5<RING_BYTES, decltype(windowed)::value>(ring, off, a0, a1, l, win_lo_dw);
+            off += l;
+          }
+        } else if (plen[j] && !(ablate & 2u)) {
+#pragma unroll
+          for (int k = 0; k < LANES; ++k) {
+            const uint32_t t = tok[j][k];
+            const uint32_t l = (39u - (uint32_t)__clz((int)t)) >> 3;  // bytes of a non-zero token dword
+            ring_put5<RING_BYTES, decltype(windowed)::value>(ring, off, t, 0u, l, win_lo_dw);
+            off += l;
           }
         }
       }
@@ -609,35 +692,52 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
     }
     R = r_end;
 
-    // AoS -> SoA split of the adaptive-int fields (narrow loads hit the lines the point loads just fetched)
+    // AoS -> SoA split of the adaptive-int fields. Fields covered by the point load are taken from registers;
+    // 2/4-byte fields are staged in LDS (written before the barrier above) and leave as 16-byte stores.
     if (plan.n_adaptive && !(ablate & 1u)) {
+      const uint32_t tile_pts = min(TILE, (uint32_t)n - base);
+      for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
+        const uint32_t bpv = plan.adaptive[a].bpv;
+        uint8_t* gcol = cols.p[a] + (first_point + base) * bpv;
+        const bool staged = col_staged(plan, a, LOADW > LANES) && (((uintptr_t)gcol & 15u) == 0u);
+        if (staged) {
+          const uint8_t* st = colstage + (size_t)a * (TILE * 4u);
+          const uint32_t bytes = tile_pts * bpv;
+          for (uint32_t u = tid; u < (bytes >> 4); u += T)
+            reinterpret_cast<uint4*>(gcol)[u] = reinterpret_cast<const uint4*>(st)[u];
+          const uint32_t tail0 = bytes & ~15u;
+          if (tid < (bytes & 15u)) gcol[tail0 + tid] = st[tail0 + tid];
+          continue;
+        }
 #pragma unroll
-      for (int j = 0; j < PPT; ++j) {
-        const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
-        if (lane > 0u && idx < n) {
-          const uint8_t* pt = points + (first_point + (size_t)idx) * step;
-          const size_t gi = first_point + (size_t)idx;
-          for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
-            const uint32_t bpv = plan.adaptive[a].bpv;
-            const uint8_t* fp = pt + plan.adaptive[a].offset;
+        for (int j = 0; j < PPT; ++j) {
+          const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
+          if (lane > 0u && idx < n) {
+            const size_t gi = first_point + (size_t)idx;
             uint8_t* col = cols.p[a];
-            if (((uintptr_t)fp & (bpv - 1u)) == 0u) {
-              if (bpv == 2u) reinterpret_cast<uint16_t*>(col)[gi] = *reinterpret_cast<const uint16_t*>(fp);
-              else if (bpv == 4u) reinterpret_cast<uint32_t*>(col)[gi] = *reinterpret_cast<const uint32_t*>(fp);
-              else reinterpret_cast<uint64_t*>(col)[gi] = *reinterpret_cast<const uint64_t*>(fp);
+            uint64_t raw;
+            if (LOADW > LANES) {
+              raw = field_from_regs<LOADW>(cur[j], plan.adaptive[a].offset - plan.ops[0].offset);
             } else {
-              uint64_t raw = 0u;
-              for (uint32_t b = 0; b < bpv; ++b) raw |= ((uint64_t)fp[b]) << (8u * b);
-              if (bpv == 2u) reinterpret_cast<uint16_t*>(col)[gi] = (uint16_t)raw;
-              else if (bpv == 4u) reinterpret_cast<uint32_t*>(col)[gi] = (uint32_t)raw;
-              else reinterpret_cast<uint64_t*>(col)[gi] = raw;
+              const uint8_t* fp = points + gi * step + plan.adaptive[a].offset;
+              raw = 0u;
+              if (((uintptr_t)fp & (bpv - 1u)) == 0u) {
+                if (bpv == 2u) raw = *reinterpret_cast<const uint16_t*>(fp);
+                else if (bpv == 4u) raw = *reinterpret_cast<const uint32_t*>(fp);
+                else raw = *reinterpret_cast<const uint64_t*>(fp);
+              } else {
+                for (uint32_t b = 0; b < bpv; ++b) raw |= ((uint64_t)fp[b]) << (8u * b);
+              }
             }
+            if (bpv == 2u) reinterpret_cast<uint16_t*>(col)[gi] = (uint16_t)raw;
+            else if (bpv == 4u) reinterpret_cast<uint32_t*>(col)[gi] = (uint32_t)raw;
+            else reinterpret_cast<uint64_t*>(col)[gi] = raw;
           }
         }
       }
     }
 
-    if (!last) {
+    if (PREFETCH && !last) {
 #pragma unroll
       for (int j = 0; j < PPT; ++j) cur[j] = nxt[j];
     }
@@ -1256,8 +1356,8 @@ namespace cldn {
 namespace {
 constexpr int kRegularThreads = 1024;
 constexpr uint32_t kRegularLds = 2u * (kRegularThreads * 16u + kMaxPointStep + 48u) + kRingBytes + 128u;
-constexpr uint32_t kFloatnRing = 32768;
-constexpr uint32_t kFloatnLds = kFloatnRing + 256u;
+constexpr uint32_t kFloatnRing = 16384;  // >= one tile of 3-lane points at 5 bytes per token (1008 * 15 B); wider tiles use windows
+constexpr uint32_t kFloatnLds = kFloatnRing + 256u + kStagedCols * (4u * 63u * 2u) * 4u + 64u;  // ring, wtot, staged columns (TILE = 504)
 
 // FloatN fast path: the regular stream is exactly one fused 3/4-lane float encoder on a 4-byte aligned layout
 int floatn_lanes(const DevPlan& p, const uint8_t* points) {
@@ -1270,13 +1370,21 @@ int floatn_lanes(const DevPlan& p, const uint8_t* points) {
   return (int)lanes;
 }
 
-int floatn_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CLDN_HIP_FLOATN_VARIANT");
-    v = e ? atoi(e) : 0;
+// dwords to load per point so that every adaptive-int field is covered by the point load (0 = not possible)
+int floatn_loadw(const DevPlan& p, int lanes) {
+  if (p.n_adaptive == 0) return lanes;
+  uint32_t need = (uint32_t)lanes * 4u;
+  const uint32_t off0 = p.ops[0].offset;
+  for (uint32_t a = 0; a < p.n_adaptive; ++a) {
+    const DevAdaptive& f = p.adaptive[a];
+    if (f.offset < off0) return lanes;
+    if (f.bpv == 8u && ((f.offset - off0) & 3u)) return lanes;
+    need = std::max(need, f.offset - off0 + f.bpv);
   }
-  return v;
+  const int w = (int)((need + 3u) / 4u);
+  const int loadw = w <= lanes ? lanes : (w <= 4 ? 4 : (w <= 8 ? 8 : 0));
+  if (loadw == 0 || off0 + (uint32_t)loadw * 4u > p.point_step) return lanes;  // would read past the point
+  return loadw;
 }
 
 int hip_fail(hipError_t e, const char* what) {
@@ -1289,12 +1397,11 @@ int stage1_configure_kernels() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_regular<kRegularThreads>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRegularLds);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_regular)");
-  const void* fk[] = {reinterpret_cast<const void*>(&k_encode_floatn<512, 3, 4, kFloatnRing>),
-                      reinterpret_cast<const void*>(&k_encode_floatn<512, 4, 4, kFloatnRing>),
-                      reinterpret_cast<const void*>(&k_encode_floatn<1024, 3, 2, kFloatnRing>),
-                      reinterpret_cast<const void*>(&k_encode_floatn<1024, 4, 2, kFloatnRing>),
-                      reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 4, kFloatnRing>),
-                      reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 4, kFloatnRing>)};
+  const void* fk[] = {reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 2, kFloatnRing, 3, false>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 2, kFloatnRing, 4, false>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 2, kFloatnRing, 8, false>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 2, kFloatnRing, 4, false>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 2, kFloatnRing, 8, false>)};
   for (const void* f : fk) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFloatnLds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_floatn)");
@@ -1321,18 +1428,17 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   if (L.events) (void)hipEventRecord(L.events[1], L.stream);
   if (L.n_chunks) {
     const int lanes = floatn_lanes(*L.plan, L.points);
-    const int variant = floatn_variant();
     static const uint32_t ablate = getenv("CLDN_HIP_ABLATE") ? (uint32_t)atoi(getenv("CLDN_HIP_ABLATE")) : 0u;  // profiling only
-#define LAUNCH_FLOATN(TT, LL, PP)                                                                                 \
-  hipLaunchKernelGGL((k_encode_floatn<TT, LL, PP, kFloatnRing>), dim3(L.n_chunks * L.subs), dim3(TT), kFloatnLds, \
+    const int loadw = lanes ? floatn_loadw(*L.plan, lanes) : 0;
+#define LAUNCH_FLOATN(TT, LL, PP, ...)                                                                                          \
+  hipLaunchKernelGGL((k_encode_floatn<TT, LL, PP, kFloatnRing, __VA_ARGS__>), dim3(L.n_chunks * L.subs), dim3(TT), kFloatnLds, \
                      L.stream, *L.plan, L.points, L.chunks, L.slots, L.slot_stride, L.segs, L.segs_per_chunk, L.cols, \
                      L.subs, L.sub_points, L.sub_stride, ablate)
-    if (lanes == 3 && variant == 0) LAUNCH_FLOATN(512, 3, 4);
-    else if (lanes == 4 && variant == 0) LAUNCH_FLOATN(512, 4, 4);
-    else if (lanes == 3 && variant == 1) LAUNCH_FLOATN(1024, 3, 2);
-    else if (lanes == 4 && variant == 1) LAUNCH_FLOATN(1024, 4, 2);
-    else if (lanes == 3 && variant == 2) LAUNCH_FLOATN(256, 3, 4);
-    else if (lanes == 4 && variant == 2) LAUNCH_FLOATN(256, 4, 4);
+    if (lanes == 3 && loadw == 3) LAUNCH_FLOATN(256, 3, 2, 3, false);
+    else if (lanes == 3 && loadw == 4) LAUNCH_FLOATN(256, 3, 2, 4, false);
+    else if (lanes == 3 && loadw == 8) LAUNCH_FLOATN(256, 3, 2, 8, false);
+    else if (lanes == 4 && loadw == 4) LAUNCH_FLOATN(256, 4, 2, 4, false);
+    else if (lanes == 4 && loadw == 8) LAUNCH_FLOATN(256, 4, 2, 8, false);
     else
       hipLaunchKernelGGL(k_encode_regular<kRegularThreads>, dim3(L.n_chunks * L.subs), dim3(kRegularThreads),
                          kRegularLds, L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots, L.slot_stride,
