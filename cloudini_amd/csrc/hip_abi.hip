@@ -117,6 +117,7 @@ struct cldn_hip_plan {
   uint8_t encoding_opt = 0;
   bool uses_v5 = false;
   uint32_t ref_max_point_bytes = 0;  // detail::MaxSerializedPointSize
+  bool has_padding = false;          // some byte of a point is not covered by any field
 };
 
 struct cldn_hip_codec {
@@ -196,6 +197,12 @@ int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint
     }
   }
 
+  {
+    std::vector<uint8_t> covered(point_step, 0);
+    for (uint32_t i = 0; i < n_fields; ++i)
+      for (int b = 0; b < size_of_type(fields[i].type); ++b) covered[fields[i].offset + b] = 1;
+    plan->has_padding = std::find(covered.begin(), covered.end(), 0) != covered.end();
+  }
   // LeadingLossyFloatFieldCount (codec_common.cpp:69-82)
   uint32_t lead = 0;
   if (lossy) {
@@ -668,9 +675,101 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
 int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams_loc, const uint64_t* stream_offsets,
                            const uint64_t* cloud_points, uint32_t n_clouds, void* points_out, uint64_t out_capacity,
                            int out_loc) {
-  (void)c; (void)streams; (void)streams_loc; (void)stream_offsets; (void)cloud_points; (void)n_clouds;
-  (void)points_out; (void)out_capacity; (void)out_loc;
-  return fail(CLDN_HIP_ERR_UNSUPPORTED, "cldn_hip_decode_stage1: decode kernels not built yet");
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if (n_clouds && (!cloud_points || !stream_offsets)) return fail(CLDN_HIP_ERR_ARG, "NULL offsets / cloud_points");
+  if ((streams_loc != CLDN_HIP_HOST && streams_loc != CLDN_HIP_DEVICE) ||
+      (out_loc != CLDN_HIP_HOST && out_loc != CLDN_HIP_DEVICE))
+    return fail(CLDN_HIP_ERR_ARG, "invalid memory location tag");
+  HIP_TRY(hipSetDevice(c->device));
+  const DevPlan& plan = c->plan.dev;
+  const uint32_t step = plan.point_step;
+  if (n_clouds == 0) return CLDN_HIP_OK;
+
+  uint64_t n_points = 0, n_chunks64 = 0;
+  for (uint32_t k = 0; k < n_clouds; ++k) {
+    if (stream_offsets[k + 1] < stream_offsets[k]) return fail(CLDN_HIP_ERR_ARG, "stream_offsets must be ascending");
+    n_points += cloud_points[k];
+    n_chunks64 += (cloud_points[k] + kPointsPerChunk - 1) / kPointsPerChunk;
+  }
+  if (n_chunks64 > 0x3fffffffull) return fail(CLDN_HIP_ERR_ARG, "batch too large");
+  const uint32_t n_chunks = (uint32_t)n_chunks64;
+  const uint64_t need = n_points * step;
+  if (out_capacity < need) return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer is too small to hold the decoded data");
+  if (need && !points_out) return fail(CLDN_HIP_ERR_ARG, "points_out is NULL");
+  const uint64_t stream_bytes = stream_offsets[n_clouds];
+  if (stream_bytes && !streams) return fail(CLDN_HIP_ERR_ARG, "streams is NULL");
+
+  int rc;
+  if ((rc = c->d_status.ensure(256)) != CLDN_HIP_OK) return rc;
+  HIP_TRY(hipMemsetAsync(c->d_status.p, 0, 256, c->stream));
+  // tables: [stream_offsets u64 | cloud_first_point u64 | cloud_first_chunk u32] (n_clouds + 1 entries each)
+  const size_t ne = (size_t)n_clouds + 1;
+  const size_t table_bytes = ne * 8 + ne * 8 + ne * 4;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // staging buffer reuse
+  if ((rc = c->h_stage.ensure(table_bytes)) != CLDN_HIP_OK) return rc;
+  uint64_t* h_so = (uint64_t*)c->h_stage.p;
+  uint64_t* h_fp = h_so + ne;
+  uint32_t* h_fc = (uint32_t*)(h_fp + ne);
+  const uint64_t base_off = stream_offsets[0];
+  uint64_t fp = 0;
+  uint32_t fc = 0;
+  for (uint32_t k = 0; k < n_clouds; ++k) {
+    h_so[k] = stream_offsets[k] - base_off;
+    h_fp[k] = fp;
+    h_fc[k] = fc;
+    fp += cloud_points[k];
+    fc += (uint32_t)((cloud_points[k] + kPointsPerChunk - 1) / kPointsPerChunk);
+  }
+  h_so[n_clouds] = stream_bytes - base_off;
+  h_fp[n_clouds] = fp;
+  h_fc[n_clouds] = fc;
+  if ((rc = c->d_dec_meta.ensure(((table_bytes + 63) & ~size_t(63)) + (size_t)std::max(1u, n_chunks) * kDecChunkBytes)) != CLDN_HIP_OK)
+    return rc;
+  c->last_cloud_points.clear();  // the staging buffer no longer holds the encode chunk table
+  uint8_t* meta = (uint8_t*)c->d_dec_meta.p;
+  HIP_TRY(hipMemcpyAsync(meta, c->h_stage.p, table_bytes, hipMemcpyHostToDevice, c->stream));
+  // the upload invalidates the cached encode batch shape (same staging buffer, different tables on device are fine)
+
+  const uint8_t* d_streams = (const uint8_t*)streams + base_off;
+  if (streams_loc == CLDN_HIP_HOST) {
+    if ((rc = c->d_in.ensure((size_t)std::max<uint64_t>(1, stream_bytes - base_off))) != CLDN_HIP_OK) return rc;
+    if (stream_bytes > base_off)
+      HIP_TRY(hipMemcpyAsync(c->d_in.p, (const uint8_t*)streams + base_off, (size_t)(stream_bytes - base_off),
+                             hipMemcpyHostToDevice, c->stream));
+    d_streams = (const uint8_t*)c->d_in.p;
+  }
+  uint8_t* d_outp = (uint8_t*)points_out;
+  if (out_loc == CLDN_HIP_HOST) {
+    if ((rc = c->d_out.ensure((size_t)std::max<uint64_t>(1, need))) != CLDN_HIP_OK) return rc;
+    d_outp = (uint8_t*)c->d_out.p;
+    // bytes of a point that no field covers keep the caller's content (src/field_decoder.cpp:72-76): bring it along
+    if (need && c->plan.has_padding)
+      HIP_TRY(hipMemcpyAsync(d_outp, points_out, (size_t)need, hipMemcpyHostToDevice, c->stream));
+  }
+
+  DecodeLaunch L;
+  memset(&L, 0, sizeof(L));
+  L.plan = &plan;
+  L.stream = c->stream;
+  L.uses_v5 = c->plan.uses_v5 ? 1u : 0u;
+  L.streams = d_streams;
+  L.stream_offsets = (const uint64_t*)meta;
+  L.cloud_first_point = (const uint64_t*)(meta + ne * 8);
+  L.cloud_first_chunk = (const uint32_t*)(meta + ne * 16);
+  L.n_clouds = n_clouds;
+  L.n_chunks = n_chunks;
+  L.chunks = meta + ((table_bytes + 63) & ~size_t(63));
+  L.out = d_outp;
+  L.status = (uint32_t*)c->d_status.p;
+  if ((rc = stage1_launch_decode(L)) != CLDN_HIP_OK) return rc;
+
+  if (out_loc == CLDN_HIP_DEVICE) return CLDN_HIP_OK;
+  uint32_t st = 0;
+  HIP_TRY(hipMemcpyAsync(&st, c->d_status.p, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (st & ST_CORRUPT) return fail(CLDN_HIP_ERR_CORRUPT, "malformed stage-1 stream (truncated, bad chunk size, bad mode or trailing bytes)");
+  if (need) HIP_TRY(hipMemcpy(points_out, d_outp, (size_t)need, hipMemcpyDeviceToHost));
+  return CLDN_HIP_OK;
 }
 
 }  // extern "C"

@@ -1345,6 +1345,8 @@ __global__ __launch_bounds__(kSecThreads) void k_encode_sections(const DevPlan p
 
 }  // namespace cldn
 
+#include "stage1_decode.h"
+
 // ------------------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------------------
@@ -1483,6 +1485,24 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_compact");
   }
   if (L.events) (void)hipEventRecord(L.events[4], L.stream);
+  return CLDN_HIP_OK;
+}
+
+static_assert(sizeof(DecChunk) <= kDecChunkBytes, "DecodeLaunch::chunks entries must hold a DecChunk");
+
+int stage1_launch_decode(const DecodeLaunch& L) {
+  hipError_t e;
+  if (L.n_clouds == 0) return CLDN_HIP_OK;
+  hipLaunchKernelGGL(k_walk_chunks, dim3((L.n_clouds + 63u) / 64u), dim3(64), 0, L.stream, L.streams, L.stream_offsets,
+                     L.cloud_first_point, L.cloud_first_chunk, L.n_clouds, reinterpret_cast<DecChunk*>(L.chunks),
+                     L.status);
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_walk_chunks");
+  if (L.n_chunks) {
+    hipLaunchKernelGGL(k_decode_general, dim3(L.n_chunks), dim3(64), 0, L.stream, *L.plan, L.streams,
+                       reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.uses_v5, 0u, (const uint32_t*)nullptr,
+                       L.status);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_general");
+  }
   return CLDN_HIP_OK;
 }
 

@@ -38,7 +38,25 @@ struct EncodeLaunch {
   hipEvent_t* events;         // 5 events (start, after probe, after regular, after sections, end) or NULL
 };
 
+struct DecodeLaunch {
+  const DevPlan* plan;
+  hipStream_t stream;
+  uint32_t uses_v5;
+  const uint8_t* streams;             // device: framed stage-1 streams of the batch
+  const uint64_t* stream_offsets;     // device [n_clouds + 1]
+  const uint64_t* cloud_first_point;  // device [n_clouds + 1]
+  const uint32_t* cloud_first_chunk;  // device [n_clouds + 1]
+  uint32_t n_clouds;
+  uint32_t n_chunks;
+  void* chunks;                       // device [n_chunks] DecChunk (48 bytes each)
+  uint8_t* out;                       // device: decoded AoS points
+  uint32_t* status;
+};
+
+constexpr size_t kDecChunkBytes = 48;
+
 int stage1_configure_kernels();
 int stage1_launch_encode(const EncodeLaunch& L);
+int stage1_launch_decode(const DecodeLaunch& L);
 
 }  // namespace cldn
