@@ -1,0 +1,628 @@
+// Host side of the Cloudini API (include/cloudini_lib/cloudini.hpp): header text, chunk framing, stage 2
+// (LZ4 / ZSTD) and the calls into the HIP stage-1 codec (include/cloudini_hip.h).
+//
+// Behaviour follows the reference's codec driver, cloudini_lib/src/cloudini.cpp (header :165-230 / :294-428,
+// MaxCompressedSize :249-292, PointcloudEncoder::encode :501-623, PointcloudDecoder::decode :635-684) and
+// src/chunk_writer.cpp:27-48; the byte layout of everything written here is checked against the compiled reference
+// in tests/test_host_api.py. There is deliberately no CPU implementation of stage 1 in this file.
+#include "cloudini_lib/cloudini.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <sstream>
+#include <stdexcept>
+#include <thread>
+
+#include "cloudini_hip.h"
+#include "yaml_lite.hpp"
+
+// stage-2 libraries: only these entry points are used (prototypes instead of the vendor headers so that the build
+// needs nothing but the shared objects)
+extern "C" {
+int LZ4_compress_default(const char* src, char* dst, int srcSize, int dstCapacity);
+int LZ4_decompress_safe(const char* src, char* dst, int compressedSize, int dstCapacity);
+int LZ4_compressBound(int inputSize);
+size_t ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
+size_t ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);
+size_t ZSTD_compressBound(size_t srcSize);
+unsigned ZSTD_isError(size_t code);
+const char* ZSTD_getErrorName(size_t code);
+}
+
+namespace Cloudini {
+
+namespace {
+
+constexpr size_t kPointsPerChunk = CLDN_HIP_POINTS_PER_CHUNK;
+
+[[noreturn]] void throwHip(const char* what) {
+  throw std::runtime_error(std::string(what) + ": " + cldn_hip_last_error());
+}
+
+template <typename Enum>
+Enum enumFromNumber(std::string_view text, int lo, int hi, const char* what) {
+  int value = 0;
+  try {
+    value = std::stoi(std::string(text));
+  } catch (const std::exception&) {
+    throw std::runtime_error(std::string("Invalid ") + what + " string: " + std::string(text));
+  }
+  if (value < lo || value > hi) throw std::runtime_error(std::string("Invalid ") + what + " string: " + std::string(text));
+  return static_cast<Enum>(value);
+}
+
+// detail::MaxSerializedPointSize (src/codec_common.cpp:29-67)
+size_t maxSerializedPointSize(const EncodingInfo& info) {
+  size_t total = 0;
+  const bool lossy = info.encoding_opt == EncodingOptions::LOSSY;
+  for (const auto& f : info.fields) {
+    switch (f.type) {
+      case FieldType::INT16: case FieldType::UINT16: case FieldType::INT32: case FieldType::UINT32:
+      case FieldType::INT64: case FieldType::UINT64:
+        total += 10;
+        break;
+      case FieldType::FLOAT32:
+        total += (lossy && f.resolution) ? 10 : 7;
+        break;
+      case FieldType::FLOAT64:
+        total += (lossy && f.resolution) ? 10 : 11;
+        break;
+      case FieldType::INT8: case FieldType::UINT8:
+        total += 1;
+        break;
+      default:
+        throw std::runtime_error("Unsupported field type '" + f.name + "' (type=" +
+                                 std::to_string(static_cast<int>(f.type)) + ") in MaxSerializedFieldSize");
+    }
+  }
+  return total;
+}
+
+bool isAdaptiveInt(FieldType t) {
+  return t == FieldType::INT16 || t == FieldType::UINT16 || t == FieldType::INT32 || t == FieldType::UINT32 ||
+         t == FieldType::INT64 || t == FieldType::UINT64;
+}
+
+// detail::UsesV5Codec (src/v5_codec.cpp:883-892)
+bool usesV5(const EncodingInfo& info) {
+  if (info.version < 5 || info.encoding_opt != EncodingOptions::LOSSY) return false;
+  size_t lead = 0;
+  for (const auto& f : info.fields) {
+    if (f.type != FieldType::FLOAT32 || !f.resolution) break;
+    ++lead;
+  }
+  if (lead != 3 && lead != 4) lead = 0;
+  for (size_t i = lead; i < info.fields.size(); ++i)
+    if (isAdaptiveInt(info.fields[i].type)) return true;
+  return false;
+}
+
+struct PlanHandle {
+  cldn_hip_plan_t* plan = nullptr;
+  explicit PlanHandle(const EncodingInfo& info) {
+    std::vector<cldn_hip_field_t> fields(info.fields.size());
+    for (size_t i = 0; i < fields.size(); ++i) {
+      fields[i].offset = info.fields[i].offset;
+      fields[i].type = static_cast<uint8_t>(info.fields[i].type);
+      fields[i].has_resolution = info.fields[i].resolution ? 1 : 0;
+      fields[i].reserved[0] = fields[i].reserved[1] = 0;
+      fields[i].resolution = info.fields[i].resolution.value_or(0.0f);
+    }
+    if (cldn_hip_plan_create(fields.data(), static_cast<uint32_t>(fields.size()), info.point_step, info.version,
+                             static_cast<uint8_t>(info.encoding_opt), &plan) != CLDN_HIP_OK)
+      throwHip("Cloudini (HIP) cannot handle this schema");
+  }
+  ~PlanHandle() { cldn_hip_plan_destroy(plan); }
+  PlanHandle(const PlanHandle&) = delete;
+  PlanHandle& operator=(const PlanHandle&) = delete;
+};
+
+// Codecs own device workspace; creating one per message (as the ROS plugin does with encoders,
+// cloudini_ros/src/cloudini_publisher_plugin.cpp:53-55) would mean a hipMalloc storm, so idle codecs are pooled by schema.
+struct CodecPool {
+  struct Entry {
+    std::string key;
+    cldn_hip_codec_t* codec;
+  };
+  std::mutex mutex;
+  std::vector<Entry> idle;
+
+  static std::string keyOf(const EncodingInfo& info) {
+    std::ostringstream k;
+    k << int(info.version) << '/' << int(info.encoding_opt) << '/' << info.point_step;
+    for (const auto& f : info.fields) {
+      k << '|' << f.offset << ':' << int(f.type) << ':';
+      if (f.resolution) {
+        uint32_t bits;
+        std::memcpy(&bits, &*f.resolution, 4);
+        k << bits;
+      } else {
+        k << 'n';
+      }
+    }
+    return k.str();
+  }
+
+  cldn_hip_codec_t* acquire(const EncodingInfo& info, const PlanHandle& plan) {
+    const std::string key = keyOf(info);
+    {
+      std::lock_guard<std::mutex> lock(mutex);
+      for (size_t i = 0; i < idle.size(); ++i) {
+        if (idle[i].key == key) {
+          cldn_hip_codec_t* c = idle[i].codec;
+          idle.erase(idle.begin() + static_cast<long>(i));
+          return c;
+        }
+      }
+    }
+    cldn_hip_codec_t* c = nullptr;
+    if (cldn_hip_codec_create(plan.plan, -1, nullptr, &c) != CLDN_HIP_OK) throwHip("Cloudini (HIP) cannot create a codec");
+    return c;
+  }
+
+  void release(const EncodingInfo& info, cldn_hip_codec_t* c) {
+    if (!c) return;
+    std::lock_guard<std::mutex> lock(mutex);
+    if (idle.size() >= 16) {
+      cldn_hip_codec_destroy(idle.front().codec);
+      idle.erase(idle.begin());
+    }
+    idle.push_back({keyOf(info), c});
+  }
+
+  ~CodecPool() {
+    // process teardown: the HIP runtime may already be gone; leak the handles on purpose
+  }
+};
+
+CodecPool& pool() {
+  static CodecPool* p = new CodecPool();
+  return *p;
+}
+
+uint32_t compressChunk(CompressionOption opt, const uint8_t* src, size_t src_size, uint8_t* dst, size_t dst_cap) {
+  switch (opt) {  // detail::CompressChunk, src/codec_common.cpp:220-258
+    case CompressionOption::LZ4: {
+      if (src_size > size_t(std::numeric_limits<int>::max()) || dst_cap > size_t(std::numeric_limits<int>::max()))
+        throw std::runtime_error("Chunk size too large for LZ4");
+      const int n = LZ4_compress_default(reinterpret_cast<const char*>(src), reinterpret_cast<char*>(dst),
+                                         static_cast<int>(src_size), static_cast<int>(dst_cap));
+      if (n <= 0) throw std::runtime_error("LZ4 compression failed");
+      return static_cast<uint32_t>(n);
+    }
+    case CompressionOption::ZSTD: {
+      const size_t n = ZSTD_compress(dst, dst_cap, src, src_size, 1);
+      if (ZSTD_isError(n)) throw std::runtime_error("ZSTD compression failed");
+      if (n > std::numeric_limits<uint32_t>::max()) throw std::runtime_error("Compressed chunk too large");
+      return static_cast<uint32_t>(n);
+    }
+    default:
+      throw std::runtime_error("Unsupported compression option");
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// names
+// ---------------------------------------------------------------------------------------------------------------
+
+const char* ToString(const FieldType& type) {
+  static const char* names[] = {"UNKNOWN", "INT8",  "UINT8",   "INT16",   "UINT16", "INT32",
+                                "UINT32",  "FLOAT32", "FLOAT64", "INT64", "UINT64"};
+  const auto i = static_cast<size_t>(type);
+  return i < sizeof(names) / sizeof(names[0]) ? names[i] : "UNKNOWN";
+}
+const char* ToString(const EncodingOptions& opt) {
+  switch (opt) {
+    case EncodingOptions::NONE: return "NONE";
+    case EncodingOptions::LOSSY: return "LOSSY";
+    case EncodingOptions::LOSSLESS: return "LOSSLESS";
+  }
+  return "UNKNOWN";
+}
+const char* ToString(const CompressionOption& opt) {
+  switch (opt) {
+    case CompressionOption::NONE: return "NONE";
+    case CompressionOption::LZ4: return "LZ4";
+    case CompressionOption::ZSTD: return "ZSTD";
+  }
+  return "UNKNOWN";
+}
+
+EncodingOptions EncodingOptionsFromString(std::string_view str) {
+  for (int i = 0; i <= 2; ++i)
+    if (str == ToString(static_cast<EncodingOptions>(i))) return static_cast<EncodingOptions>(i);
+  return enumFromNumber<EncodingOptions>(str, 0, 2, "EncodingOptions");
+}
+CompressionOption CompressionOptionFromString(std::string_view str) {
+  for (int i = 0; i <= 2; ++i)
+    if (str == ToString(static_cast<CompressionOption>(i))) return static_cast<CompressionOption>(i);
+  return enumFromNumber<CompressionOption>(str, 0, 2, "CompressionOption");
+}
+FieldType FieldTypeFromString(std::string_view str) {
+  for (int i = 1; i <= 10; ++i)
+    if (str == ToString(static_cast<FieldType>(i))) return static_cast<FieldType>(i);
+  return enumFromNumber<FieldType>(str, 0, 10, "FieldType");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// header
+// ---------------------------------------------------------------------------------------------------------------
+
+std::string EncodingInfoToYAML(const EncodingInfo& info) {
+  std::ostringstream y;  // default ostream float formatting (6 significant digits), as the reference prints it
+  y << "version: " << int(info.version) << '\n'
+    << "width: " << info.width << '\n'
+    << "height: " << info.height << '\n'
+    << "point_step: " << info.point_step << '\n'
+    << "encoding_opt: " << ToString(info.encoding_opt) << '\n'
+    << "compression_opt: " << ToString(info.compression_opt) << '\n';
+  if (!info.encoding_config.empty()) y << "encoding_config: " << info.encoding_config << '\n';
+  y << "fields:\n";
+  for (const auto& f : info.fields) {
+    y << "  - name: " << f.name << '\n' << "    offset: " << f.offset << '\n' << "    type: " << ToString(f.type) << '\n';
+    if (f.resolution) y << "    resolution: " << *f.resolution << '\n';
+    else y << "    resolution: null\n";
+  }
+  return y.str();
+}
+
+EncodingInfo EncodingInfoFromYAML(std::string_view yaml) {
+  const yaml_lite::Document doc = yaml_lite::parse(yaml);
+  EncodingInfo info;
+  info.version = static_cast<uint8_t>(doc.integer("version"));
+  info.width = static_cast<uint32_t>(doc.integer("width"));
+  info.height = static_cast<uint32_t>(doc.integer("height"));
+  info.point_step = static_cast<uint32_t>(doc.integer("point_step"));
+  info.encoding_opt = EncodingOptionsFromString(doc.scalar("encoding_opt"));
+  info.compression_opt = CompressionOptionFromString(doc.scalar("compression_opt"));
+  if (doc.has("encoding_config")) info.encoding_config = doc.scalar("encoding_config");
+  for (const auto& item : doc.items) {
+    PointField f;
+    f.name = item.scalar("name");
+    f.offset = static_cast<uint32_t>(item.integer("offset"));
+    f.type = FieldTypeFromString(item.scalar("type"));
+    const std::string res = item.scalar("resolution");
+    if (res != "null") f.resolution = std::stof(res);
+    info.fields.push_back(std::move(f));
+  }
+  return info;
+}
+
+void EncodeHeader(const EncodingInfo& header, std::vector<uint8_t>& output, HeaderEncoding encoding) {
+  output.clear();
+  output.insert(output.end(), kMagicHeader, kMagicHeader + kMagicHeaderLength);
+  output.push_back(static_cast<uint8_t>('0' + header.version / 10));
+  output.push_back(static_cast<uint8_t>('0' + header.version % 10));
+  if (encoding == HeaderEncoding::YAML) {
+    const std::string yaml = EncodingInfoToYAML(header);
+    output.push_back('\n');
+    output.insert(output.end(), yaml.begin(), yaml.end());
+    output.push_back('\0');
+    return;
+  }
+  auto put = [&output](const void* p, size_t n) {
+    const auto* b = static_cast<const uint8_t*>(p);
+    output.insert(output.end(), b, b + n);
+  };
+  put(&header.width, 4);
+  put(&header.height, 4);
+  put(&header.point_step, 4);
+  output.push_back(static_cast<uint8_t>(header.encoding_opt));
+  output.push_back(static_cast<uint8_t>(header.compression_opt));
+  const uint16_t count = static_cast<uint16_t>(header.fields.size());
+  put(&count, 2);
+  for (const auto& f : header.fields) {
+    const uint16_t len = static_cast<uint16_t>(f.name.size());
+    put(&len, 2);
+    put(f.name.data(), len);
+    put(&f.offset, 4);
+    output.push_back(static_cast<uint8_t>(f.type));
+    const float res = f.resolution.value_or(-1.0f);
+    put(&res, 4);
+  }
+}
+
+EncodingInfo DecodeHeader(ConstBufferView& input) {
+  if (input.size() < size_t(kMagicHeaderLength + 2)) throw std::runtime_error("Input too small to contain Cloudini header");
+  if (std::memcmp(input.data(), kMagicHeader, kMagicHeaderLength) != 0) {
+    throw std::runtime_error("Invalid magic header. Expected 'CLOUDINI_V', got: " +
+                             std::string(reinterpret_cast<const char*>(input.data()), kMagicHeaderLength));
+  }
+  input.trim_front(kMagicHeaderLength);
+  auto digit = [](uint8_t c) -> uint8_t { return (c >= '0' && c <= '9') ? uint8_t(c - '0') : uint8_t(0); };
+  const uint8_t version = uint8_t(digit(input.data()[0]) * 10 + digit(input.data()[1]));
+  input.trim_front(2);
+  if (version < 2 || version > kEncodingVersion) {
+    throw std::runtime_error("Unsupported encoding version. Current is:" + std::to_string(kEncodingVersion) +
+                             ", got: " + std::to_string(version));
+  }
+  // YAML form: '\n' then text then '\0'. The legacy binary form never starts with "\n" followed by a non-brace.
+  if (input.size() >= 2 && input.data()[0] == '\n' && input.data()[1] != '{') {
+    input.trim_front(1);
+    const auto* text = reinterpret_cast<const char*>(input.data());
+    const void* nul = std::memchr(text, 0, input.size());
+    if (!nul) throw std::runtime_error("Malformed YAML header: missing null terminator");
+    const size_t len = static_cast<size_t>(static_cast<const char*>(nul) - text);
+    EncodingInfo info = EncodingInfoFromYAML(std::string_view(text, len));
+    input.trim_front(len + 1);
+    info.version = version;  // the magic string is authoritative
+    return info;
+  }
+  EncodingInfo info;
+  info.version = version;
+  decode(input, info.width);
+  decode(input, info.height);
+  decode(input, info.point_step);
+  uint8_t stage = 0;
+  decode(input, stage);
+  info.encoding_opt = static_cast<EncodingOptions>(stage);
+  decode(input, stage);
+  info.compression_opt = static_cast<CompressionOption>(stage);
+  uint16_t count = 0;
+  decode(input, count);
+  for (uint16_t i = 0; i < count; ++i) {
+    PointField f;
+    decode(input, f.name);
+    decode(input, f.offset);
+    uint8_t type = 0;
+    decode(input, type);
+    f.type = static_cast<FieldType>(type);
+    float res = 0.0f;
+    decode(input, res);
+    if (res > 0) f.resolution = res;
+    info.fields.push_back(std::move(f));
+  }
+  return info;
+}
+
+size_t MaxCompressedSize(const EncodingInfo& info, size_t points_count, bool include_header) {
+  if (info.point_step == 0) throw std::runtime_error("point_step cannot be 0");
+  const size_t per_point = maxSerializedPointSize(info);
+  const bool v5 = usesV5(info);
+  size_t total = include_header ? (kMagicHeaderLength + 2 + 1 + EncodingInfoToYAML(info).size() + 1) : 0;
+  for (size_t left = points_count; left > 0;) {
+    const size_t in_chunk = std::min(left, kPointsPerChunk);
+    left -= in_chunk;
+    size_t stage1 = in_chunk * per_point;
+    if (v5) stage1 += info.fields.size() * 32u + 1024u;  // mode bytes / section headers of the adaptive sections
+    total += sizeof(uint32_t);
+    switch (info.compression_opt) {
+      case CompressionOption::NONE:
+        total += stage1;
+        break;
+      case CompressionOption::LZ4:
+        if (stage1 > size_t(std::numeric_limits<int>::max())) throw std::runtime_error("Chunk size too large for LZ4");
+        total += static_cast<size_t>(LZ4_compressBound(static_cast<int>(stage1)));
+        break;
+      case CompressionOption::ZSTD:
+        total += ZSTD_compressBound(stage1);
+        break;
+      default:
+        throw std::runtime_error("Unsupported compression option in MaxCompressedSize");
+    }
+  }
+  return total;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// encoder
+// ---------------------------------------------------------------------------------------------------------------
+
+struct PointcloudEncoder::Impl {
+  std::unique_ptr<PlanHandle> plan;
+  cldn_hip_codec_t* codec = nullptr;
+  std::vector<uint8_t> stage1;        // framed stage-1 stream of the last cloud
+  std::vector<uint32_t> chunk_sizes;  // payload size per chunk
+};
+
+PointcloudEncoder::PointcloudEncoder(const EncodingInfo& info) : info_(info), impl_(new Impl()) {
+  EncodeHeader(info_, header_);
+  impl_->plan = std::make_unique<PlanHandle>(info_);
+  impl_->codec = pool().acquire(info_, *impl_->plan);
+}
+
+PointcloudEncoder::~PointcloudEncoder() {
+  if (impl_ && impl_->codec) pool().release(info_, impl_->codec);
+}
+
+size_t PointcloudEncoder::encode(ConstBufferView cloud_data, std::vector<uint8_t>& output) {
+  if (info_.point_step == 0) throw std::runtime_error("point_step cannot be 0");
+  if (cloud_data.size() % info_.point_step != 0)
+    throw std::runtime_error("Input cloud_data size is not a multiple of point_step");
+  output.resize(MaxCompressedSize(info_, cloud_data.size() / info_.point_step, true));
+  BufferView view(output.data(), output.size());
+  const size_t size = encode(cloud_data, view, true);
+  output.resize(size);
+  return size;
+}
+
+size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output, bool write_header) {
+  if (info_.point_step == 0) throw std::runtime_error("point_step cannot be 0");
+  if (cloud_data.size() % info_.point_step != 0)
+    throw std::runtime_error("Input cloud_data size is not a multiple of point_step");
+  const uint64_t points = cloud_data.size() / info_.point_step;
+  const size_t required = MaxCompressedSize(info_, points, false) + (write_header ? header_.size() : 0);
+  if (output.size() < required) throw std::runtime_error("Output buffer too small for worst-case compressed size");
+
+  uint8_t* dst = output.data();
+  size_t written = 0;
+  if (write_header) {
+    std::memcpy(dst, header_.data(), header_.size());
+    written = header_.size();
+  }
+  if (points == 0) return written;
+
+  // stage 1 on the GPU: framed stream [u32 size][payload] per 32768-point chunk
+  const size_t n_chunks = (points + kPointsPerChunk - 1) / kPointsPerChunk;
+  const uint64_t bound = cldn_hip_stage1_bound(impl_->plan->plan, points);
+  const bool direct = info_.compression_opt == CompressionOption::NONE;  // the framed stream IS the payload
+  uint8_t* s1 = dst + written;
+  uint64_t s1_cap = output.size() - written;
+  if (!direct) {
+    if (impl_->stage1.size() < bound) impl_->stage1.resize(bound);
+    s1 = impl_->stage1.data();
+    s1_cap = impl_->stage1.size();
+  }
+  impl_->chunk_sizes.resize(n_chunks);
+  uint64_t offsets[2] = {0, 0};
+  if (cldn_hip_encode_stage1(impl_->codec, cloud_data.data(), CLDN_HIP_HOST, &points, 1, s1, s1_cap, CLDN_HIP_HOST,
+                             offsets, impl_->chunk_sizes.data(), nullptr) != CLDN_HIP_OK)
+    throw std::runtime_error(cldn_hip_last_error());
+  if (direct) return written + static_cast<size_t>(offsets[1]);
+
+  // stage 2 on the host: [u32 compressed size][LZ4 block | ZSTD frame] per chunk (src/chunk_writer.cpp:41-47).
+  // Chunks are independent; with use_threads they are compressed concurrently and laid out in order afterwards.
+  std::vector<size_t> src_off(n_chunks);
+  {
+    size_t pos = 0;
+    for (size_t c = 0; c < n_chunks; ++c) {
+      src_off[c] = pos + 4;
+      pos += 4 + impl_->chunk_sizes[c];
+    }
+  }
+  const unsigned workers =
+      (info_.use_threads && n_chunks > 1) ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), unsigned(n_chunks)) : 1u;
+  if (workers <= 1) {
+    for (size_t c = 0; c < n_chunks; ++c) {
+      uint8_t* size_ptr = dst + written;
+      const size_t cap = output.size() - written - 4;
+      const uint32_t n = compressChunk(info_.compression_opt, s1 + src_off[c], impl_->chunk_sizes[c], size_ptr + 4, cap);
+      std::memcpy(size_ptr, &n, 4);
+      written += 4 + n;
+    }
+    return written;
+  }
+  std::vector<std::vector<uint8_t>> packed(n_chunks);
+  std::atomic<size_t> next{0};
+  std::exception_ptr error;
+  std::mutex error_mutex;
+  auto work = [&] {
+    try {
+      for (size_t c = next.fetch_add(1); c < n_chunks; c = next.fetch_add(1)) {
+        const size_t in = impl_->chunk_sizes[c];
+        const size_t cap = info_.compression_opt == CompressionOption::LZ4 ? size_t(LZ4_compressBound(int(in)))
+                                                                           : ZSTD_compressBound(in);
+        packed[c].resize(cap);
+        packed[c].resize(compressChunk(info_.compression_opt, s1 + src_off[c], in, packed[c].data(), cap));
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lock(error_mutex);
+      if (!error) error = std::current_exception();
+    }
+  };
+  std::vector<std::thread> threads;
+  for (unsigned t = 1; t < workers; ++t) threads.emplace_back(work);
+  work();
+  for (auto& t : threads) t.join();
+  if (error) std::rethrow_exception(error);
+  for (size_t c = 0; c < n_chunks; ++c) {
+    const uint32_t n = static_cast<uint32_t>(packed[c].size());
+    if (output.size() - written < 4u + n) throw std::runtime_error("Output buffer too small for compressed chunk");
+    std::memcpy(dst + written, &n, 4);
+    std::memcpy(dst + written + 4, packed[c].data(), n);
+    written += 4 + n;
+  }
+  return written;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// decoder
+// ---------------------------------------------------------------------------------------------------------------
+
+struct PointcloudDecoder::Impl {
+  std::string key;
+  EncodingInfo info;
+  std::unique_ptr<PlanHandle> plan;
+  cldn_hip_codec_t* codec = nullptr;
+  std::vector<uint8_t> stage1;  // decompressed, re-framed chunks
+
+  void release() {
+    if (codec) pool().release(info, codec);
+    codec = nullptr;
+    plan.reset();
+  }
+};
+
+PointcloudDecoder::PointcloudDecoder() : impl_(new Impl()) {}
+PointcloudDecoder::~PointcloudDecoder() {
+  if (impl_) impl_->release();
+}
+
+void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compressed_data, BufferView output) {
+  if (compressed_data.size() >= size_t(kMagicHeaderLength) &&
+      std::memcmp(compressed_data.data(), kMagicHeader, kMagicHeaderLength) == 0)
+    throw std::runtime_error("compressed_data contains the header. You should use DecodeHeader first");
+  if (info.version < 3)
+    throw std::runtime_error("Cloudini (HIP): streams older than wire version 3 (unchunked) are not supported");
+  if (info.point_step == 0) throw std::runtime_error("point_step cannot be 0");
+
+  const std::string key = CodecPool::keyOf(info);
+  if (!impl_->codec || key != impl_->key) {
+    impl_->release();
+    impl_->info = info;
+    impl_->key = key;
+    impl_->plan = std::make_unique<PlanHandle>(info);
+    impl_->codec = pool().acquire(info, *impl_->plan);
+  }
+
+  const uint64_t points = static_cast<uint64_t>(info.width) * info.height;
+  const uint64_t out_bytes = points * info.point_step;
+  if (output.size() < out_bytes) throw std::runtime_error("Output buffer is too small to hold the decoded data");
+
+  // validate the chunk chain the way the reference does (src/cloudini.cpp:645-664) and undo stage 2
+  const bool direct = info.compression_opt == CompressionOption::NONE;
+  const uint8_t* s1 = compressed_data.data();
+  uint64_t s1_size = compressed_data.size();
+  {
+    ConstBufferView rest = compressed_data;
+    uint64_t remaining = points;
+    size_t produced = 0;
+    if (!direct) impl_->stage1.clear();
+    while (!rest.empty()) {
+      if (remaining == 0) throw std::runtime_error("Encoded data contains more chunks than declared points");
+      uint32_t chunk_size = 0;
+      Cloudini::decode(rest, chunk_size);
+      if (chunk_size > rest.size()) throw std::runtime_error("Invalid chunk size found while decoding");
+      const uint64_t in_chunk = std::min<uint64_t>(remaining, kPointsPerChunk);
+      if (!direct) {
+        // the decompressed stage-1 bytes of a chunk are bounded by its worst case
+        const size_t cap = static_cast<size_t>(cldn_hip_stage1_bound(impl_->plan->plan, in_chunk)) + 64;
+        impl_->stage1.resize(produced + 4 + cap);
+        uint8_t* dst = impl_->stage1.data() + produced + 4;
+        size_t got = 0;
+        if (info.compression_opt == CompressionOption::LZ4) {
+          const int n = LZ4_decompress_safe(reinterpret_cast<const char*>(rest.data()), reinterpret_cast<char*>(dst),
+                                            static_cast<int>(chunk_size), static_cast<int>(cap));
+          if (n < 0) throw std::runtime_error("LZ4 decompression failed");
+          got = static_cast<size_t>(n);
+        } else {
+          got = ZSTD_decompress(dst, cap, rest.data(), chunk_size);
+          if (ZSTD_isError(got)) throw std::runtime_error(std::string("ZSTD decompression failed: ") + ZSTD_getErrorName(got));
+        }
+        const uint32_t got32 = static_cast<uint32_t>(got);
+        std::memcpy(impl_->stage1.data() + produced, &got32, 4);
+        produced += 4 + got;
+      }
+      rest.trim_front(chunk_size);
+      remaining -= in_chunk;
+    }
+    if (remaining != 0) throw std::runtime_error("Encoded data ended before all declared points were decoded");
+    if (!direct) {
+      s1 = impl_->stage1.data();
+      s1_size = produced;
+    }
+  }
+  if (points == 0) return;
+
+  const uint64_t offsets[2] = {0, s1_size};
+  if (cldn_hip_decode_stage1(impl_->codec, s1, CLDN_HIP_HOST, offsets, &points, 1, output.data(), out_bytes,
+                             CLDN_HIP_HOST) != CLDN_HIP_OK)
+    throw std::runtime_error(cldn_hip_last_error());
+}
+
+}  // namespace Cloudini

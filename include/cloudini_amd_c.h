@@ -1,0 +1,60 @@
+/* cloudini_amd_c.h -- flat C access to the C++ host API (Cloudini::PointcloudEncoder / PointcloudDecoder / header
+ * functions / ROS message converters) for language bindings and for the Python test-suite. Every function returns
+ * a byte count (>= 0) or -1 with the std::runtime_error text available from cldn_amd_last_error(). */
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cldn_amd_field {
+  const char* name;
+  uint32_t offset;
+  uint8_t type;           /* Cloudini::FieldType */
+  uint8_t has_resolution;
+  uint8_t reserved[2];
+  float resolution;
+} cldn_amd_field_t;
+
+/* Cloudini::EncodingInfo without its std::vector */
+typedef struct cldn_amd_info {
+  const cldn_amd_field_t* fields;
+  uint32_t n_fields;
+  uint32_t width;
+  uint32_t height;
+  uint32_t point_step;
+  uint8_t encoding_opt;
+  uint8_t compression_opt;
+  uint8_t version;
+  uint8_t use_threads;
+} cldn_amd_info_t;
+
+const char* cldn_amd_last_error(void);
+
+/* MaxCompressedSize(info, n_points, include_header) */
+int64_t cldn_amd_max_compressed_size(const cldn_amd_info_t* info, uint64_t n_points, int include_header);
+/* EncodeHeader(info, out, binary ? BINARY : YAML) */
+int64_t cldn_amd_encode_header(const cldn_amd_info_t* info, int binary, uint8_t* out, uint64_t capacity);
+/* PointcloudEncoder(info).encode(data, out, write_header) */
+int64_t cldn_amd_encode(const cldn_amd_info_t* info, const uint8_t* data, uint64_t size, uint8_t* out,
+                        uint64_t capacity, int write_header);
+/* DecodeHeader + PointcloudDecoder::decode of a full stream; yaml_out (optional) receives EncodingInfoToYAML of the
+ * decoded header, version_out (optional) the wire version */
+int64_t cldn_amd_decode(const uint8_t* stream, uint64_t size, uint8_t* out, uint64_t capacity, char* yaml_out,
+                        uint64_t yaml_capacity, uint8_t* version_out);
+/* PointcloudDecoder::decode(info, data (no header), out) */
+int64_t cldn_amd_decode_noheader(const cldn_amd_info_t* info, const uint8_t* data, uint64_t size, uint8_t* out,
+                                 uint64_t capacity);
+/* getDeserializedPointCloudMessage + applyResolutionProfile({}, fields, resolution) + toEncodingInfo (compression
+ * as given) + convertPointCloud2ToCompressedCloud */
+int64_t cldn_amd_ros_compress(const uint8_t* dds, uint64_t size, float resolution, uint8_t compression_opt,
+                              uint8_t* out, uint64_t capacity);
+/* getDeserializedPointCloudMessage + convertCompressedCloudToPointCloud2 */
+int64_t cldn_amd_ros_decompress(const uint8_t* dds, uint64_t size, uint8_t* out, uint64_t capacity);
+
+#ifdef __cplusplus
+}
+#endif

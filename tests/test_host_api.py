@@ -1,0 +1,242 @@
+"""Host-side mirror of the reference API (include/cloudini_lib/*.hpp, cloudini_amd/csrc/host/): header bytes,
+capacity bounds, error behaviour, stage 2 and the ROS message converters."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cases
+from cloudini_amd import api, synth
+from cloudini_amd.schema import CompressionOption, EncodingInfo, EncodingOptions, FieldType, PointField
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _infos():
+    out = []
+    for name, info, data in cases.encode_cases(small=True)[::4]:
+        out.append((name, info))
+    info = synth.xyzi_info(1234)
+    info.encoding_config = "profile=outdoor"
+    out.append(("with_config", info))
+    out.append(("odd_res", EncodingInfo(fields=[PointField("a", 0, FieldType.FLOAT32, 1e-6),
+                                                PointField("b", 4, FieldType.FLOAT64, 0.25),
+                                                PointField("c", 12, FieldType.FLOAT32, 123456.789)],
+                                        width=7, height=3, point_step=16)))
+    return out
+
+
+INFOS = _infos()
+
+
+# ---------------------------------------------------------------------------------------------------- no GPU
+def test_c_abi_exports_every_declared_symbol():
+    """Both shared libraries load and export what include/*.h declares (no compute without a GPU)."""
+    from cloudini_amd import native
+    hip = native.lib()
+    host = api.lib()
+    decl = re.compile(r"\b(cldn_[A-Za-z0-9_]+)\s*\(")
+    hip_syms = set(decl.findall(open(os.path.join(ROOT, "include", "cloudini_hip.h")).read()))
+    host_syms = set(decl.findall(open(os.path.join(ROOT, "include", "cloudini_amd_c.h")).read()))
+    host_syms |= set(decl.findall(open(os.path.join(ROOT, "include", "cloudini_lib", "wasm_functions.h")).read()))
+    assert len(hip_syms) >= 15 and len(host_syms) >= 18
+    for s in hip_syms:
+        assert hasattr(hip, s), s
+    for s in host_syms:
+        assert hasattr(host, s), s
+    assert hip.cldn_hip_abi_version() == 1
+
+
+@pytest.mark.parametrize("name,info", INFOS, ids=[i[0] for i in INFOS])
+def test_header_bytes_match_reference(reflib, name, info):
+    assert api.EncodeHeader(info) == reflib.header(info)
+    assert api.EncodeHeader(info, binary=True) == reflib.header(info, binary=True)
+
+
+@pytest.mark.parametrize("name,info", INFOS, ids=[i[0] for i in INFOS])
+def test_max_compressed_size_matches_reference(reflib, name, info):
+    for comp in (CompressionOption.NONE, CompressionOption.LZ4, CompressionOption.ZSTD):
+        i2 = info.copy(compression_opt=comp)
+        for n in (0, 1, 32768, 32769, 100000):
+            for hdr in (True, False):
+                assert api.MaxCompressedSize(i2, n, hdr) == reflib.max_compressed_size(i2, n, hdr), (comp, n, hdr)
+
+
+def test_header_magic_and_yaml_shape():
+    """test_header.cpp:107-163: magic CLOUDINI_V05 / V04, YAML text, NUL terminator."""
+    info = synth.xyzi_info(10)
+    h = api.EncodeHeader(info)
+    assert h.startswith(b"CLOUDINI_V05\n") and h.endswith(b"\0")
+    assert api.EncodeHeader(info.copy(version=4)).startswith(b"CLOUDINI_V04\n")
+    y = h[13:-1].decode()
+    assert y.splitlines()[0] == "version: 5" and "resolution: 0.001" in y and "resolution: null" in y
+    back = api.parse_yaml_info(y, 5)
+    assert [f.name for f in back.fields] == ["x", "y", "z", "intensity"] and back.point_step == 16
+
+
+def test_malformed_headers_are_rejected():
+    """HeaderTruncatedInput / HeaderMissingYamlTerminator (test_header.cpp:165, :243) through the reference's C ABI
+    convention (0 on failure)."""
+    L = api.lib()
+    good = np.frombuffer(api.EncodeHeader(synth.xyzi_info(10)), dtype=np.uint8).copy()
+    out = np.zeros(4096, dtype=np.uint8)
+
+    def yaml_of(buf):
+        return L.cldn_GetHeaderAsYAML(buf.ctypes.data, buf.size, out.ctypes.data)
+
+    assert yaml_of(good) > 0
+    assert yaml_of(good[:5].copy()) == 0 and b"too small" in L.cldn_LastError()
+    assert yaml_of(good[:-1].copy()) == 0 and b"null terminator" in L.cldn_LastError()
+    bad = good.copy()
+    bad[0] = ord("X")
+    assert yaml_of(bad) == 0 and b"Invalid magic header" in L.cldn_LastError()
+    bad = good.copy()
+    bad[10:12] = np.frombuffer(b"09", dtype=np.uint8)
+    assert yaml_of(bad) == 0 and b"Unsupported encoding version" in L.cldn_LastError()
+
+
+def test_encoder_argument_errors():
+    info = synth.xyz_info(10)
+    with pytest.raises(RuntimeError, match="point_step cannot be 0"):
+        api.MaxCompressedSize(info.copy(point_step=0), 10)
+
+
+# ------------------------------------------------------------------------------------------------------- GPU
+GPU_CASES = cases.encode_cases(small=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,info,data", GPU_CASES, ids=[c[0] for c in GPU_CASES])
+def test_full_stream_none_equals_reference(reflib, name, info, data):
+    got = api.PointcloudEncoder(info).encode(data)
+    want = reflib.encode(info, data)
+    assert np.array_equal(got, want)
+    dec, hdr = api.PointcloudDecoder().decode_stream(want, fill=0x33)
+    ref_dec, _ = reflib.decode(want, len(data), fill=0x33)
+    assert np.array_equal(dec, ref_dec)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("comp", [CompressionOption.LZ4, CompressionOption.ZSTD])
+@pytest.mark.parametrize("threads", [False, True])
+def test_stage2_streams_equal_reference(reflib, comp, threads):
+    """Both sides link the same liblz4 / libzstd here, so even the compressed bytes must agree."""
+    for info, data in (synth.lidar_xyzi(100000), synth.velodyne_xyzir(70000), cases.mixed_schema(40000, 5)):
+        info = info.copy(compression_opt=comp, use_threads=threads)
+        got = api.PointcloudEncoder(info).encode(data)
+        want = reflib.encode(info, data)
+        assert np.array_equal(got, want)
+        dec, _ = api.PointcloudDecoder().decode_stream(got, fill=0)
+        ref_dec, _ = reflib.decode(want, len(data), fill=0)
+        assert np.array_equal(dec, ref_dec)
+
+
+@pytest.mark.gpu
+def test_roundtrip_tolerance_like_the_reference_tests():
+    """FloatLossy / PCD tolerances: |decoded - original| <= resolution * 1.0001 / 2-ish (test_field_encoders.cpp:129)."""
+    info, data = synth.lidar_xyz(200000)
+    enc = api.PointcloudEncoder(info.copy(compression_opt=CompressionOption.ZSTD)).encode(data)
+    dec, _ = api.PointcloudDecoder().decode_stream(enc)
+    a = data.view(np.float32)
+    b = dec.view(np.float32)
+    assert np.max(np.abs(a - b)) <= 0.001 * 0.5 * 1.01
+
+
+@pytest.mark.gpu
+def test_encoder_errors_match_reference_messages():
+    info, data = synth.lidar_xyz(100)
+    with pytest.raises(RuntimeError, match="not a multiple of point_step"):
+        api.PointcloudEncoder(info).encode(data[:-1])
+    # view overload with a buffer below the worst case (cloudini.cpp:531-534)
+    L = api.lib()
+    ci, _keep = api._c_info(info)
+    out = np.zeros(200, dtype=np.uint8)
+    r = L.cldn_amd_encode(C.byref(ci), data.ctypes.data_as(C.POINTER(C.c_uint8)), data.size,
+                          out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size, 1)
+    assert r == -1 and b"Output buffer too small for worst-case compressed size" in L.cldn_amd_last_error()
+    # a stream that still carries its header must be refused by decode()
+    enc = api.PointcloudEncoder(info).encode(data)
+    with pytest.raises(RuntimeError, match="contains the header"):
+        api.PointcloudDecoder().decode(info, enc)
+    body = enc[len(api.EncodeHeader(info)):]
+    with pytest.raises(RuntimeError, match="ended before all declared points"):
+        api.PointcloudDecoder().decode(info.copy(width=32768 + 5), body)  # a second chunk is declared but missing
+    with pytest.raises(RuntimeError, match="more chunks than declared points"):
+        api.PointcloudDecoder().decode(info, np.concatenate([body, body]))
+    with pytest.raises(RuntimeError, match="malformed stage-1 stream"):
+        api.PointcloudDecoder().decode(info.copy(width=200), body)  # chunk shorter than its declared points
+
+
+def _cdr_pointcloud2(info, data, frame_id="lidar_top", stamp=(1700000000, 123456789), is_dense=True):
+    """Serialise a sensor_msgs/PointCloud2 as little-endian CDR (what a DDS reader hands to the converter)."""
+    out = bytearray(b"\x00\x01\x00\x00")
+
+    def align(n):
+        while (len(out) - 4) % n:
+            out.append(0)
+
+    def u32(v):
+        align(4)
+        out.extend(int(v).to_bytes(4, "little"))
+
+    def string(s):
+        b = s.encode() + b"\0"
+        u32(len(b))
+        out.extend(b)
+
+    align(4)
+    out.extend(int(stamp[0]).to_bytes(4, "little", signed=True))
+    u32(stamp[1])
+    string(frame_id)
+    u32(info.height)
+    u32(info.width)
+    u32(len(info.fields))
+    for f in info.fields:
+        string(f.name)
+        u32(f.offset)
+        out.append(int(f.type))
+        u32(1)
+    out.append(0)  # is_bigendian
+    u32(info.point_step)
+    u32(info.point_step * info.width)
+    u32(len(data))
+    out.extend(bytes(data))
+    out.append(1 if is_dense else 0)
+    return np.frombuffer(bytes(out), dtype=np.uint8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("comp", [CompressionOption.NONE, CompressionOption.ZSTD])
+def test_ros_message_conversion_equals_reference(reflib, comp):
+    """convertPointCloud2ToCompressedCloud / convertCompressedCloudToPointCloud2 (ros_msg_utils.cpp:135-213)."""
+    info, data = synth.lidar_xyzi(50000)
+    msg = _cdr_pointcloud2(info, data)
+    got = api.ros_compress(msg, 0.001, int(comp))
+    want = reflib.ros_compress(msg, 0.001, int(comp))
+    assert np.array_equal(got, want)
+    back = api.ros_decompress(got, msg.size + 4096)
+    ref_back = reflib.ros_decompress(want, msg.size + 4096)
+    assert np.array_equal(back, ref_back)
+    # the reference's own C entry points over the same message
+    L = api.lib()
+    assert L.cldn_GetDecompressedSize(got.ctypes.data, got.size) == data.size
+    out = np.zeros(data.size, dtype=np.uint8)
+    assert L.cldn_DecodeCompressedMessage(got.ctypes.data, got.size, out.ctypes.data) == data.size
+    assert np.max(np.abs(out.view(np.float32).reshape(-1, 4)[:, :3] - data.view(np.float32).reshape(-1, 4)[:, :3])) <= 0.00051
+
+
+@pytest.mark.gpu
+def test_dds_fixture_schema_needs_gorilla():
+    """samples/dds_message.bin carries a FLOAT64 time stamp without resolution (test_ros_msg.cpp:110-125): that
+    selects the sequential Gorilla codec, which the HIP path refuses loudly instead of falling back to a CPU."""
+    fields = [PointField("x", 0, FieldType.FLOAT32, 0.001), PointField("y", 4, FieldType.FLOAT32, 0.001),
+              PointField("z", 8, FieldType.FLOAT32, 0.001), PointField("intensity", 12, FieldType.FLOAT32, 0.001),
+              PointField("ring", 16, FieldType.UINT16, None), PointField("timestamp", 18, FieldType.FLOAT64, None)]
+    info = EncodingInfo(fields=fields, width=10, height=1, point_step=26)
+    with pytest.raises(RuntimeError, match="Gorilla"):
+        api.PointcloudEncoder(info).encode(np.zeros(260, dtype=np.uint8))
+    # with a resolution on the stamp (what applyVizLossyPreprocessing / a profile would set) it encodes
+    fields[5] = PointField("timestamp", 18, FieldType.FLOAT64, 1e-6)
+    api.PointcloudEncoder(EncodingInfo(fields=fields, width=10, height=1, point_step=26)).encode(np.zeros(260, np.uint8))
