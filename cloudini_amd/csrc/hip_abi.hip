@@ -129,7 +129,8 @@ struct cldn_hip_codec {
   DevBuf d_in, d_out, d_slots, d_chunks, d_cloud_first, d_segs, d_payload, d_dst, d_offsets, d_modes, d_status;
   DevBuf d_cols[kMaxAdaptive];
   DevBuf d_ranks[kMaxAdaptive];
-  DevBuf d_dec_meta, d_fbflags;
+  DevBuf d_dec_meta, d_fbflags, d_pre_ptrs;
+  DevBuf d_pre[kMaxGorilla];
   PinnedBuf h_stage;   // chunk table upload
   PinnedBuf h_result;  // offsets / status readback
   // cached batch shape
@@ -302,10 +303,15 @@ int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint
           op.max_bytes = 10;
           d.min_regular_bytes += 1;
         } else if (!f.has_resolution && version >= 4) {
-          rc = fail(CLDN_HIP_ERR_UNSUPPORTED,
-                    "field %u: FLOAT64 without resolution selects the sequential Gorilla codec "
-                    "(field_encoder.hpp:156-312), which has no HIP kernel yet",
-                    i);
+          if (d.n_gorilla >= (uint32_t)kMaxGorilla) {
+            rc = fail(CLDN_HIP_ERR_UNSUPPORTED, "more than %d Gorilla-coded FLOAT64 fields are not supported", kMaxGorilla);
+            break;
+          }
+          op.kind = OP_GORILLA64;  // FieldEncoderFloat_Gorilla<double>
+          op.type = (uint8_t)d.n_gorilla++;
+          op.max_bytes = 10;       // 1 + 1 + 5 + 6 + 64 = 77 bits
+          d.all_varint = 0;
+          d.min_regular_bytes += 1;
         } else {
           op.kind = OP_XOR64;
           op.max_bytes = 8;
@@ -392,7 +398,8 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_segs,
-                    &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_fbflags};
+                    &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_fbflags, &c->d_pre_ptrs,
+                    &c->d_pre[0], &c->d_pre[1], &c->d_pre[2], &c->d_pre[3]};
   for (DevBuf* b : bufs) b->release();
   for (int a = 0; a < kMaxAdaptive; ++a) {
     c->d_cols[a].release();
@@ -566,6 +573,16 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
       if ((rc = c->d_cols[a].ensure((size_t)n_points * plan.adaptive[a].bpv + 64)) != CLDN_HIP_OK) return rc;
       if ((rc = c->d_ranks[a].ensure((size_t)n_points * 2 + 64)) != CLDN_HIP_OK) return rc;
     }
+    if (plan.n_gorilla) {
+      void* ptrs[kMaxGorilla] = {nullptr, nullptr, nullptr, nullptr};
+      for (uint32_t g = 0; g < plan.n_gorilla; ++g) {
+        if ((rc = c->d_pre[g].ensure((size_t)n_points * 16 + 64)) != CLDN_HIP_OK) return rc;
+        ptrs[g] = c->d_pre[g].p;
+      }
+      if ((rc = c->d_pre_ptrs.ensure(sizeof(ptrs))) != CLDN_HIP_OK) return rc;
+      HIP_TRY(hipMemcpyAsync(c->d_pre_ptrs.p, ptrs, sizeof(ptrs), hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));  // `ptrs` lives on this stack frame
+    }
     if (points_loc == CLDN_HIP_HOST) {
       if ((rc = c->d_in.ensure((size_t)n_points * step)) != CLDN_HIP_OK) return rc;
       HIP_TRY(hipMemcpyAsync(c->d_in.p, points, (size_t)n_points * step, hipMemcpyHostToDevice, c->stream));
@@ -600,6 +617,8 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
     L.cols.p[a] = (uint8_t*)c->d_cols[a].p;
     L.ranks[a] = (uint16_t*)c->d_ranks[a].p;
   }
+  for (uint32_t g = 0; g < plan.n_gorilla; ++g) L.pre.p[g] = (const uint4*)c->d_pre[g].p;
+  L.pre_out = (uint4* const*)c->d_pre_ptrs.p;
   L.chunk_payload = (uint32_t*)c->d_payload.p;
   L.chunk_dst = (uint64_t*)c->d_dst.p;
   L.stream_offsets = (uint64_t*)c->d_offsets.p;

@@ -205,7 +205,12 @@ __global__ __launch_bounds__(64) void k_decode_general(const DevPlan plan, const
     else r.p += off;
   } else {
     int64_t prev[kMaxOps];
-    for (uint32_t k = 0; k < plan.n_ops; ++k) prev[k] = 0;
+    uint8_t gor_lead[kMaxOps], gor_trail[kMaxOps];
+    for (uint32_t k = 0; k < plan.n_ops; ++k) {
+      prev[k] = 0;
+      gor_lead[k] = 255;  // kLeadingSentinel
+      gor_trail[k] = 0;
+    }
     for (uint32_t i = 0; i < n && !r.bad; ++i) {
       uint8_t* pt = base + (size_t)i * step;
       // "Truncated encoded data: not enough bytes for a complete point" (v4_codec.cpp:103-105)
@@ -258,6 +263,77 @@ __global__ __launch_bounds__(64) void k_decode_general(const DevPlan plan, const
             const uint64_t v = rd_raw(r, op.size) ^ (uint64_t)prev[k];
             prev[k] = (int64_t)v;
             if (store && !r.bad) st_raw(pt + op.offset, v, op.size);
+          } break;
+          case OP_GORILLA64: {  // FieldDecoderFloat_Gorilla<double>, include/cloudini_lib/field_decoder.hpp:262-305
+            uint64_t value;
+            if (i == 0u) {
+              value = rd_raw(r, 8);  // first value of the chunk: raw bits
+            } else {
+              // bits are packed LSB-first and every point ends on a byte boundary: pull bytes on demand
+              uint64_t lo = 0, hi = 0;
+              uint32_t have = 0;
+              auto need = [&](uint32_t nb) {
+                while (have < nb && !r.bad) {
+                  if (r.p >= r.end) { r.bad = true; break; }
+                  const uint64_t byte = *r.p++;
+                  if (have < 64u) {
+                    lo |= byte << have;
+                    if (have > 56u) hi |= byte >> (64u - have);
+                  } else {
+                    hi |= byte << (have - 64u);
+                  }
+                  have += 8u;
+                }
+              };
+              auto take = [&](uint32_t nb) -> uint64_t {
+                uint64_t v;
+                if (nb >= 64u) {
+                  v = lo;
+                  lo = hi;
+                  hi = 0;
+                } else {
+                  v = lo & ((1ull << nb) - 1ull);
+                  if (nb) {
+                    lo = (lo >> nb) | (hi << (64u - nb));
+                    hi >>= nb;
+                  }
+                }
+                have -= nb;
+                return v;
+              };
+              need(1);
+              if (r.bad) break;
+              if (take(1) == 0) {
+                value = (uint64_t)prev[k];
+              } else {
+                need(1);
+                if (r.bad) break;
+                uint64_t x;
+                if (take(1) == 0) {
+                  const uint32_t pl = gor_lead[k], pt = gor_trail[k];
+                  if (pl > 64u || pl + pt >= 64u) { r.bad = true; break; }  // no window yet / corrupt
+                  const uint32_t m = 64u - pl - pt;
+                  need(m);
+                  if (r.bad) break;
+                  x = take(m) << pt;
+                } else {
+                  need(11);
+                  if (r.bad) break;
+                  const uint32_t sl = (uint32_t)take(5);
+                  const uint32_t m = (uint32_t)take(6) + 1u;
+                  if (sl + m > 64u) { r.bad = true; break; }
+                  need(m);
+                  if (r.bad) break;
+                  const uint32_t tr = 64u - sl - m;
+                  x = take(m) << tr;
+                  gor_lead[k] = (uint8_t)sl;
+                  gor_trail[k] = (uint8_t)tr;
+                }
+                value = x ^ (uint64_t)prev[k];
+              }
+            }
+            prev[k] = (int64_t)value;
+            if (store && !r.bad) st_raw(pt + op.offset, value, 8);
           } break;
           default:
             r.bad = true;

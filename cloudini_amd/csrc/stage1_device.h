@@ -3,6 +3,8 @@
 
 #include <stdint.h>
 
+#include <hip/hip_runtime.h>
+
 namespace cldn {
 
 constexpr uint32_t kPointsPerChunk = 32768;  // detail::kPointsPerChunk, src/codec_common.hpp:28
@@ -20,8 +22,12 @@ enum : uint8_t {
   OP_INT = 3,        // FieldEncoderInt<T>: int64 delta varint
   OP_COPY = 4,       // FieldEncoderCopy: raw bytes
   OP_XOR32 = 5,      // FieldEncoderFloat_XOR<float>
-  OP_XOR64 = 6       // FieldEncoderFloat_XOR<double>
+  OP_XOR64 = 6,      // FieldEncoderFloat_XOR<double>
+  OP_GORILLA64 = 7   // FieldEncoderFloat_Gorilla<double>: tokens precomputed by k_gorilla_tokens (DevOp::mult_f unused,
+                     // DevOp::type = index of the op's token buffer)
 };
+
+constexpr int kMaxGorilla = 4;  // Gorilla-coded FLOAT64 fields per schema
 
 struct DevOp {
   uint8_t kind;
@@ -49,6 +55,7 @@ struct DevPlan {
   uint32_t max_regular_bytes;  // worst-case regular-stream bytes per point
   uint32_t min_regular_bytes;  // best case (decode sanity checks)
   uint32_t all_varint;         // every regular op is a varint/NaN token (decode can find token ends by MSB)
+  uint32_t n_gorilla;          // OP_GORILLA64 ops
   DevOp ops[kMaxOps];
   DevAdaptive adaptive[kMaxAdaptive];
 };
@@ -67,6 +74,10 @@ struct ChunkDesc {
 struct Seg {
   uint32_t off;   // byte offset inside the chunk slot (multiple of 16)
   uint32_t size;  // bytes
+};
+
+struct PreTokenPtrs {
+  const uint4* p[kMaxGorilla];  // per Gorilla op: {w0, w1, w2, len} for every point of the batch
 };
 
 struct ColumnPtrs {

@@ -151,7 +151,8 @@ struct PointRef {
 
 // Evaluate regular op `op` for one point. EMIT=false: only the token length.
 template <bool EMIT>
-__device__ __forceinline__ Tok eval_op(const DevOp& op, const uint32_t* tile, const PointRef p) {
+__device__ __forceinline__ Tok eval_op(const DevOp& op, const uint32_t* tile, const PointRef p, const PreTokenPtrs& pre,
+                                       size_t gi) {
   Tok t;
   t.w0 = t.w1 = t.w2 = 0;
   t.len = 0;
@@ -222,6 +223,13 @@ __device__ __forceinline__ Tok eval_op(const DevOp& op, const uint32_t* tile, co
         t.len = op.size;
       }
     } break;
+    case OP_GORILLA64: {  // bit-packed XOR window codec, tokens built by k_gorilla_tokens
+      const uint4 g = pre.p[op.type][gi];
+      t.w0 = g.x;
+      t.w1 = g.y;
+      t.w2 = g.z;
+      t.len = g.w;
+    } break;
     default:
       break;
   }
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
                                                       uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                       Seg* __restrict__ segs, uint32_t segs_per_chunk,
                                                       const ColumnPtrs cols, uint32_t subs, uint32_t sub_points,
-                                                      uint32_t sub_stride) {
+                                                      uint32_t sub_stride, const PreTokenPtrs pre) {
   constexpr uint32_t kTileLds = T * 16u + kMaxPointStep + 48u;  // multiple of 16
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* ring = reinterpret_cast<uint32_t*>(smem + 2u * kTileLds);
@@ -336,11 +344,12 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
     pr.cur = g.first_off + tid * step;
     pr.prev = pr.cur - step;
     pr.has_prev = (sub_first + g.p0 + tid) > 0u;
+    const size_t gi_point = (size_t)cd.first_point + sub_first + g.p0 + tid;  // index into per-point side buffers
 
     // pass A: bytes this point contributes to the regular stream
     uint32_t my_len = 0u;
     if (active) {
-      for (uint32_t k = 0; k < plan.n_ops; ++k) my_len += eval_op<false>(plan.ops[k], tile, pr).len;
+      for (uint32_t k = 0; k < plan.n_ops; ++k) my_len += eval_op<false>(plan.ops[k], tile, pr, pre, gi_point).len;
     }
     uint32_t tile_total;
     const uint32_t excl = block_exclusive_scan<T>(my_len, wtot, &tile_total);
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
       if (active) {
         uint32_t off = ss.R + excl;
         for (uint32_t k = 0; k < plan.n_ops; ++k) {
-          const Tok t = eval_op<true>(plan.ops[k], tile, pr);
+          const Tok t = eval_op<true>(plan.ops[k], tile, pr, pre, gi_point);
           ring_put<false>(ring, off, t, 0u);
           off += t.len;
         }
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
         if (active) {
           uint32_t off = ss.R + excl;
           for (uint32_t k = 0; k < plan.n_ops; ++k) {
-            const Tok t = eval_op<true>(plan.ops[k], tile, pr);
+            const Tok t = eval_op<true>(plan.ops[k], tile, pr, pre, gi_point);
             ring_put<true>(ring, off, t, ss.F >> 2);
             off += t.len;
           }
@@ -750,6 +759,103 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
     s.off = sub_id * sub_stride;
     s.size = R;
     segs[(size_t)chunk_id * segs_per_chunk + sub_id] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_gorilla_tokens: FieldEncoderFloat_Gorilla<double> (include/cloudini_lib/field_encoder.hpp:156-312). The codec
+// keeps a (leading, trailing) bit window that only changes at "new window" points, so one wave per chunk walks
+// 64 points at a time: every lane XORs with its predecessor and assumes the current window; the lowest lane that
+// would open a new window is resolved, the window is updated, and only the lanes behind it re-check. The bytes of
+// every point (the reference flushes to a byte boundary per point) are stored as a 16-byte token for
+// k_encode_regular to place. grid = (n_chunks, n_gorilla), block = 64.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_gorilla_tokens(const DevPlan plan, const uint8_t* __restrict__ points,
+                                                       const ChunkDesc* __restrict__ chunks, uint4* const* out_tokens) {
+  // find the blockIdx.y-th Gorilla op
+  uint32_t opi = 0, seen = 0;
+  for (; opi < plan.n_ops; ++opi) {
+    if (plan.ops[opi].kind == OP_GORILLA64) {
+      if (seen == blockIdx.y) break;
+      ++seen;
+    }
+  }
+  const DevOp& op = plan.ops[opi];
+  const ChunkDesc cd = chunks[blockIdx.x];
+  const uint32_t n = cd.n_points;
+  const uint32_t step = plan.point_step;
+  const uint32_t lane = threadIdx.x;
+  const uint8_t* base = points + (size_t)cd.first_point * step + op.offset;
+  uint4* out = out_tokens[blockIdx.y] + cd.first_point;
+
+  uint32_t win_lead = 255u, win_trail = 0u;  // kLeadingSentinel: no window yet
+  uint64_t carry = 0u;                       // bits of the last point of the previous batch
+  for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
+    const uint32_t i = b0 + lane;
+    const bool valid = i < n;
+    uint64_t cur = 0u;
+    if (valid) {
+      const uint8_t* q = base + (size_t)i * step;
+      for (int b = 0; b < 8; ++b) cur |= ((uint64_t)q[b]) << (8 * b);
+    }
+    uint64_t prev = __shfl_up((unsigned long long)cur, 1);
+    if (lane == 0u) prev = carry;
+    carry = __shfl((unsigned long long)cur, 63);
+    const uint64_t x = cur ^ prev;
+    const uint32_t lead = x ? (uint32_t)__builtin_clzll(x) : 64u;
+    const uint32_t trail = x ? (uint32_t)__builtin_ctzll(x) : 64u;
+
+    // window in effect before my point, and whether my point opens a new one
+    bool pending = valid && i > 0u && x != 0u;
+    bool opens = false;
+    uint32_t my_lead = win_lead, my_trail = win_trail;
+    for (;;) {
+      const bool would_open = pending && (win_lead == 255u || lead < win_lead || trail < win_trail);
+      const uint64_t ev = __ballot(would_open);
+      if (ev == 0ull) {
+        if (pending) {
+          my_lead = win_lead;
+          my_trail = win_trail;
+        }
+        break;
+      }
+      const uint32_t e = (uint32_t)__builtin_ctzll(ev);
+      if (pending && lane <= e) {
+        my_lead = win_lead;
+        my_trail = win_trail;
+        opens = (lane == e);
+        pending = false;
+      }
+      const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)lead, (int)e);
+      const uint32_t te = (uint32_t)__builtin_amdgcn_readlane((int)trail, (int)e);
+      win_lead = le > 31u ? 31u : le;
+      win_trail = te;
+    }
+
+    if (valid) {
+      uint64_t lo = 0u, hi = 0u;
+      uint32_t nbits;
+      if (i == 0u) {  // first value of the chunk: raw 64 bits
+        lo = cur;
+        nbits = 64u;
+      } else if (x == 0u) {
+        nbits = 1u;  // single '0' bit
+      } else if (!opens) {
+        const uint32_t m = 64u - my_lead - my_trail;  // '1','0', m bits of (x >> trailing)
+        const uint64_t payload = x >> my_trail;
+        lo = 1u | (payload << 2);
+        hi = payload >> 62;
+        nbits = 2u + m;
+      } else {
+        const uint32_t sl = lead > 31u ? 31u : lead;  // '1','1', leading(5), m-1 (6), m bits of (x >> trailing)
+        const uint32_t m = 64u - sl - trail;
+        const uint64_t payload = x >> trail;
+        lo = 3u | ((uint64_t)sl << 2) | ((uint64_t)(m - 1u) << 7) | (payload << 13);
+        hi = payload >> 51;
+        nbits = 13u + m;
+      }
+      out[i] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (nbits + 7u) >> 3);
+    }
   }
 }
 
@@ -1428,6 +1534,11 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   hipError_t e;
   if (L.events) (void)hipEventRecord(L.events[0], L.stream);
   if (L.events) (void)hipEventRecord(L.events[1], L.stream);
+  if (L.n_chunks && L.plan->n_gorilla) {
+    hipLaunchKernelGGL(k_gorilla_tokens, dim3(L.n_chunks, L.plan->n_gorilla), dim3(64), 0, L.stream, *L.plan, L.points,
+                       L.chunks, L.pre_out);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_gorilla_tokens");
+  }
   if (L.n_chunks) {
     const int lanes = floatn_lanes(*L.plan, L.points);
     static const uint32_t ablate = getenv("CLDN_HIP_ABLATE") ? (uint32_t)atoi(getenv("CLDN_HIP_ABLATE")) : 0u;  // profiling only
@@ -1444,7 +1555,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     else
       hipLaunchKernelGGL(k_encode_regular<kRegularThreads>, dim3(L.n_chunks * L.subs), dim3(kRegularThreads),
                          kRegularLds, L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots, L.slot_stride,
-                         L.segs, L.segs_per_chunk, L.cols, L.subs, L.sub_points, L.sub_stride);
+                         L.segs, L.segs_per_chunk, L.cols, L.subs, L.sub_points, L.sub_stride, L.pre);
 #undef LAUNCH_FLOATN
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_regular/floatn");
   }

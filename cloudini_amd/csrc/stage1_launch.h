@@ -26,6 +26,8 @@ struct EncodeLaunch {
   Seg* segs;                  // device [n_chunks * segs_per_chunk]
   uint32_t segs_per_chunk;
   ColumnPtrs cols;
+  PreTokenPtrs pre;           // Gorilla token buffers (read side, by value into the kernels)
+  uint4* const* pre_out;      // device array [n_gorilla] of the same buffers (write side of k_gorilla_tokens)
   uint16_t* ranks[kMaxAdaptive];
   uint32_t* chunk_payload;    // device [n_chunks]
   uint64_t* chunk_dst;        // device [n_chunks]

@@ -248,6 +248,37 @@ def kat_vectors():
            bytes.fromhex("010305d10f9f1fed2ea01fa846f02eb917fd2afb01" + "00c901030303"))
 
 
+def ouster_like(n=40000, seed=37, enc=EncodingOptions.LOSSY):
+    """The layout of the reference's samples/dds_message.bin (test_ros_msg.cpp:110-125): XYZI float32 + ring u16 +
+    FLOAT64 time stamp WITHOUT resolution -> Gorilla codec inside the per-point stream, 26-byte unaligned points."""
+    rs = np.random.RandomState(seed)
+    fields = [("x", 0, F.FLOAT32, 0.001), ("y", 4, F.FLOAT32, 0.001), ("z", 8, F.FLOAT32, 0.001),
+              ("intensity", 12, F.FLOAT32, 0.001), ("ring", 16, F.UINT16, None), ("timestamp", 18, F.FLOAT64, None)]
+    info = make_info(fields, 26, n, enc=enc)
+    i = np.arange(n)
+    t = 1.7e9 + np.cumsum(rs.uniform(0.8e-6, 1.2e-6, n))
+    t[1000:1100] = t[1000]                       # repeated stamps (xor == 0)
+    t[2000:2010] = rs.uniform(0, 1e300, 10)      # wild exponents: window resets, > 31 leading zeros nowhere
+    t[3000:3005] = 0.0
+    t[3005] = np.nan
+    t[4000:4064] = np.frombuffer(rs.bytes(64 * 8), dtype=np.float64)  # random bit patterns
+    cols = {"x": np.cumsum(rs.normal(0, 0.01, n)).astype(np.float32), "y": rs.uniform(-5, 5, n).astype(np.float32),
+            "z": rs.uniform(-1, 1, n).astype(np.float32), "intensity": rs.randint(0, 255, n).astype(np.float32),
+            "ring": (i % 64).astype(np.uint16), "timestamp": t}
+    return info, pack(info, cols, n)
+
+
+def gorilla_pair(n=35000, seed=41):
+    """Two Gorilla-coded doubles (one slowly varying, one with tiny integer steps -> long shared windows) between
+    other fields, LOSSLESS mode (FLOAT32 -> XOR)."""
+    rs = np.random.RandomState(seed)
+    fields = [("a", 0, F.FLOAT64, None), ("f", 8, F.FLOAT32, None), ("b", 12, F.FLOAT64, None), ("k", 20, F.UINT8, None)]
+    info = make_info(fields, 21, n, enc=EncodingOptions.LOSSLESS)
+    cols = {"a": np.sin(np.arange(n) / 500.0) * 1000.0, "f": rs.uniform(-1, 1, n).astype(np.float32),
+            "b": np.floor(np.arange(n) / 7.0) * 0.5, "k": rs.randint(0, 256, n).astype(np.uint8)}
+    return info, pack(info, cols, n)
+
+
 def encode_cases(small=False):
     """(name, info, data) for every schema family; `small` trims sizes for the CPU-only suite."""
     out = []
@@ -265,6 +296,8 @@ def encode_cases(small=False):
     out.append(("mixed_v4", *mixed_schema(40000, 4)))
     out.append(("mixed_lossless", *mixed_schema_lossless(30000)))
     out.append(("mixed_none", *mixed_schema(20000, 5, EncodingOptions.NONE)))
+    out.append(("ouster_like_gorilla", *ouster_like()))
+    out.append(("gorilla_pair_lossless", *gorilla_pair()))
     out.append(("five_floats", *five_floats()))
     out.append(("two_floats_then_ints", *two_floats_then_ints()))
     for kind in ("grows_u16", "all_distinct_u32", "wide_u64", "single_value", "two_values_i16", "u5000_u32"):

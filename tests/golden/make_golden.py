@@ -50,6 +50,36 @@ def small_cases():
     for kind in ("long_and_short", "delta_runs_i64", "drle_then_noise"):
         info, data = cases.rle_stress(kind, n=7000)
         out.append((f"rle_{kind}_7000", info, data))
+    out.append(("ouster_like_gorilla_5000", *cases.ouster_like(5000)))
+    out.extend(reference_sample_slices())
+    return out
+
+
+def reference_sample_slices():
+    """Slices of the reference's two sample files (data, not source): samples/dds_message.bin (CDR PointCloud2,
+    64000 pts, XYZI f32 + ring u16 + f64 stamp -> Gorilla) and samples/lidar.pcd (binary PCD, XYZI f32)."""
+    from cloudini_amd.schema import EncodingInfo, FieldType, PointField
+    from cloudini_amd import api
+    out = []
+    samples = "/root/reference/cloudini_lib/samples"
+    ref = RefLib()
+    dds = np.fromfile(os.path.join(samples, "dds_message.bin"), dtype=np.uint8)
+    yaml, off, size = ref.ros_describe(dds)
+    info = api.parse_yaml_info(yaml, 5)
+    for f in info.fields:
+        if f.type == FieldType.FLOAT32:
+            f.resolution = 0.001  # as cloudini_ros/src/conversion_utils.cpp:39 / test_ros_msg.cpp:135-138 set it
+    n = 6000
+    from cloudini_amd.schema import CompressionOption
+    info = info.copy(width=n, height=1, compression_opt=CompressionOption.NONE, use_threads=False)
+    out.append(("sample_dds_message_6000", info, dds[off: off + n * info.point_step].copy()))
+    raw = open(os.path.join(samples, "lidar.pcd"), "rb").read()
+    hdr_end = raw.index(b"DATA binary\n") + len(b"DATA binary\n")
+    n = 8000
+    fields = [PointField(c, 4 * k, FieldType.FLOAT32, 0.001) for k, c in enumerate(["x", "y", "z", "intensity"])]
+    info = EncodingInfo(fields=fields, width=n, height=1, point_step=16, compression_opt=CompressionOption.NONE,
+                        use_threads=False)
+    out.append(("sample_lidar_pcd_8000", info, np.frombuffer(raw[hdr_end: hdr_end + n * 16], dtype=np.uint8).copy()))
     return out
 
 

@@ -118,9 +118,14 @@ def test_batch_mixed_clouds_v5(oracle):
     check_encode(oracle, info, clouds)
 
 
-def test_gorilla_schema_is_rejected_loudly():
+def test_unsupported_schemas_fail_loudly():
+    """No CPU fallback: what the kernels cannot do is refused with CLDN_HIP_ERR_UNSUPPORTED."""
     from cloudini_amd import native
-    info = cases.make_info([("x", 0, FieldType.FLOAT32, 0.001), ("t", 4, FieldType.FLOAT64, None)], 12, 10)
+    info = cases.make_info([("x", 0, FieldType.FLOAT32, 0.001)], 300, 10)  # point_step beyond the tile staging
+    with pytest.raises(native.CloudiniHipError) as e:
+        native.Plan(info)
+    assert e.value.code == -3
+    info = cases.make_info([(f"g{k}", 8 * k, FieldType.FLOAT64, None) for k in range(5)], 40, 10)  # 5 Gorilla fields
     with pytest.raises(native.CloudiniHipError) as e:
         native.Plan(info)
     assert e.value.code == -3

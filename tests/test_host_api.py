@@ -228,15 +228,13 @@ def test_ros_message_conversion_equals_reference(reflib, comp):
 
 
 @pytest.mark.gpu
-def test_dds_fixture_schema_needs_gorilla():
-    """samples/dds_message.bin carries a FLOAT64 time stamp without resolution (test_ros_msg.cpp:110-125): that
-    selects the sequential Gorilla codec, which the HIP path refuses loudly instead of falling back to a CPU."""
-    fields = [PointField("x", 0, FieldType.FLOAT32, 0.001), PointField("y", 4, FieldType.FLOAT32, 0.001),
-              PointField("z", 8, FieldType.FLOAT32, 0.001), PointField("intensity", 12, FieldType.FLOAT32, 0.001),
-              PointField("ring", 16, FieldType.UINT16, None), PointField("timestamp", 18, FieldType.FLOAT64, None)]
-    info = EncodingInfo(fields=fields, width=10, height=1, point_step=26)
-    with pytest.raises(RuntimeError, match="Gorilla"):
-        api.PointcloudEncoder(info).encode(np.zeros(260, dtype=np.uint8))
-    # with a resolution on the stamp (what applyVizLossyPreprocessing / a profile would set) it encodes
-    fields[5] = PointField("timestamp", 18, FieldType.FLOAT64, 1e-6)
-    api.PointcloudEncoder(EncodingInfo(fields=fields, width=10, height=1, point_step=26)).encode(np.zeros(260, np.uint8))
+def test_dds_fixture_layout_roundtrip(reflib):
+    """The schema of samples/dds_message.bin (test_ros_msg.cpp:91-144): FLOAT64 stamp without resolution -> Gorilla.
+    Full CDR message in, CompressedPointCloud2 out, byte-identical to the reference; and back."""
+    info, data = cases.ouster_like(20000)
+    msg = _cdr_pointcloud2(info, data)
+    got = api.ros_compress(msg, 0.001, int(CompressionOption.ZSTD))
+    want = reflib.ros_compress(msg, 0.001, int(CompressionOption.ZSTD))
+    assert np.array_equal(got, want)
+    back = api.ros_decompress(got, msg.size + 4096)
+    assert np.array_equal(back, reflib.ros_decompress(want, msg.size + 4096))
