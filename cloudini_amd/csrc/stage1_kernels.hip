@@ -1372,6 +1372,8 @@ __global__ __launch_bounds__(kSecThreads) void k_probe_modes(const DevPlan plan,
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const SecLds l = sec_lds_carve(smem);
   const uint32_t cloud = blockIdx.x, a = blockIdx.y;
+  if (modes[cloud * plan.n_adaptive + a] != 0xffu) return;  // decided by k_probe_fast
+  __syncthreads();
   const uint32_t fc = cloud_first_chunk[cloud];
   if (fc == cloud_first_chunk[cloud + 1u]) {  // empty cloud
     if (threadIdx.x == 0) modes[cloud * plan.n_adaptive + a] = 0u;
@@ -1520,6 +1522,9 @@ int stage1_configure_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_sections),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSecLdsTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_sections)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_probe_fast), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kS2PalLds);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_probe_fast)");
   const void* pk[] = {reinterpret_cast<const void*>(&k_section_palette<uint16_t>),
                       reinterpret_cast<const void*>(&k_section_palette<uint32_t>),
                       reinterpret_cast<const void*>(&k_section_palette<uint64_t>)};
@@ -1564,10 +1569,17 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   if (na && L.n_chunks) {
     ColumnPtrs rank_cols;
     for (int a = 0; a < kMaxAdaptive; ++a) rank_cols.p[a] = reinterpret_cast<uint8_t*>(L.ranks[a]);
+    static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
+    if (!no_fast) {
+      hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na), dim3(kS2Threads), kS2PalLds, L.stream, *L.plan, L.chunks,
+                         L.cloud_first_chunk, L.cols, L.modes);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_fast");
+    } else {
+      (void)hipMemsetAsync(L.modes, 0xff, (size_t)L.n_clouds * na, L.stream);
+    }
     hipLaunchKernelGGL(k_probe_modes, dim3(L.n_clouds, na), dim3(kSecThreads), kSecLdsTotal, L.stream, *L.plan,
                        L.chunks, L.cloud_first_chunk, L.cols, L.modes);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_modes");
-    static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch
     for (uint32_t a = 0; a < na && !no_fast; ++a) {
       const uint32_t bpv = L.plan->adaptive[a].bpv;
 #define LAUNCH_PAL(RT)                                                                                              \

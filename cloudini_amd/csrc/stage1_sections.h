@@ -104,6 +104,154 @@ __device__ __forceinline__ void load8(const RawT* col, uint32_t i0, uint32_t n, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Mode probe (analyzeAdaptiveIntField + selectBestAdaptiveIntMode, src/v5_codec.cpp:258-316, :381-412) over the
+// first W <= 4096 values of a cloud: thread t owns values [4t, 4t+4), every size is thread-local work plus one
+// block-wide scan / reduction.
+// ---------------------------------------------------------------------------------------------------------
+
+template <int T>
+__device__ __forceinline__ uint32_t block_sum(uint32_t x, uint32_t* wtot) {
+  uint32_t total;
+  (void)block_exclusive_scan<T>(x, wtot, &total);
+  __syncthreads();
+  return total;
+}
+
+// min over all threads with a larger thread index of their `mine` (kInf if none)
+template <int T>
+__device__ __forceinline__ uint32_t block_suffix_min_exclusive(uint32_t mine, uint32_t* wmin) {
+  constexpr int NW = T / 64;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t s = mine;
+#pragma unroll
+  for (int dlt = 1; dlt < 64; dlt <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_down((int)s, dlt);
+    if (lane + (uint32_t)dlt < 64u) s = min(s, o);
+  }
+  uint32_t excl = (uint32_t)__shfl_down((int)s, 1);
+  if (lane == 63u) excl = kInf;
+  if (lane == 0u) wmin[wave] = s;
+  __syncthreads();
+  uint32_t cross = kInf;
+  for (uint32_t w = wave + 1u; w < (uint32_t)NW; ++w) cross = min(cross, wmin[w]);
+  __syncthreads();
+  return min(excl, cross);
+}
+
+template <typename RawT>
+__device__ __forceinline__ uint8_t probe_mode(const RawT* col, uint32_t n, uint32_t type, uint8_t* smem) {
+  constexpr int T = kS2Threads;
+  const Pal2 p = pal2_carve(smem);
+  uint32_t* wtot = p.wtot;
+  const uint32_t t0 = threadIdx.x * 4u;
+  const uint32_t cnt = t0 < n ? min(4u, n - t0) : 0u;
+  RawT v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = ((uint32_t)j < cnt) ? col[t0 + j] : (RawT)0;
+  const RawT pm1 = (cnt && t0 >= 1u) ? col[t0 - 1u] : (RawT)0;
+  const RawT pm2 = (cnt && t0 >= 2u) ? col[t0 - 2u] : (RawT)0;
+  auto as64 = [&](RawT r) { return int_field_as_i64((uint64_t)r, type); };
+
+  // keys: raw values (Rle) and first differences (DeltaVarint / DeltaRle), values[-1] = 0
+  uint64_t diff[4];
+  {
+    int64_t prev = t0 >= 1u ? as64(pm1) : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t cur = as64(v[j]);
+      diff[j] = (uint64_t)cur - (uint64_t)prev;
+      prev = cur;
+    }
+  }
+  const uint64_t diff_before = (uint64_t)(t0 >= 1u ? as64(pm1) : 0) - (uint64_t)(t0 >= 2u ? as64(pm2) : 0);
+
+  // DeltaVarint: 1 + sum of token lengths
+  uint32_t dv = 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if ((uint32_t)j < cnt) dv += varint64_len((int64_t)diff[j]);
+  const uint32_t delta_size = 1u + block_sum<T>(dv, wtot);
+
+  // run heads of both run codings
+  uint32_t hr = 0u, hd = 0u;
+  {
+    uint64_t kr = (uint64_t)pm1, kd = diff_before;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if ((uint32_t)j < cnt) {
+        const bool first = (t0 + (uint32_t)j) == 0u;
+        if (first || (uint64_t)v[j] != kr) hr |= 1u << j;
+        if (first || diff[j] != kd) hd |= 1u << j;
+        kr = (uint64_t)v[j];
+        kd = diff[j];
+      }
+    }
+  }
+  auto run_bytes = [&](uint32_t heads, bool delta) -> uint32_t {
+    const uint32_t my_first = heads ? (t0 + (uint32_t)__builtin_ctz(heads)) : kInf;
+    uint32_t next_after = block_suffix_min_exclusive<T>(my_first, wtot);
+    if (next_after == kInf) next_after = n;
+    uint32_t bytes = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (heads & (1u << j)) {
+        const uint32_t above = heads & ~((2u << j) - 1u);
+        const uint32_t nxt = above ? (t0 + (uint32_t)__builtin_ctz(above)) : next_after;
+        bytes += (delta ? varint64_len((int64_t)diff[j]) : (uint32_t)sizeof(RawT)) + uvarint32_len(nxt - (t0 + (uint32_t)j));
+      }
+    }
+    return 5u + block_sum<T>(bytes, wtot);
+  };
+  const uint32_t rle_size = run_bytes(hr, false);
+  const uint32_t drle_size = run_bytes(hd, true);
+
+  // Palette: distinct values through the LDS hash table
+  for (uint32_t s = threadIdx.x; s < kS2PalSlots; s += T) p.keys[s] = ~0ull;
+  for (uint32_t s = threadIdx.x; s <= kS2PalSlots; s += T) p.first[s] = kInf;
+  if (threadIdx.x < 4u) p.misc[threadIdx.x] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if ((uint32_t)j < cnt) pal2_insert<RawT>(p, v[j], t0 + (uint32_t)j);
+  __syncthreads();
+  uint32_t U = p.misc[0];
+  if (sizeof(RawT) == 8 && p.first[kS2PalSlots] != kInf) ++U;  // the value ~0 lives outside the key table
+  if (p.misc[1] != 0u || p.misc[0] > kS2PalCapacity) return 0xffu;  // too many distinct values for this table
+  const uint32_t pal_size = 3u + U * (uint32_t)sizeof(RawT) + ((palette_bits(U) * n + 7u) >> 3);
+
+  uint32_t mode = 0u, best = delta_size;  // strict '<' in this order
+  if (pal_size < best) { best = pal_size; mode = 1u; }
+  if (rle_size < best) { best = rle_size; mode = 2u; }
+  if (drle_size < best) { mode = 3u; }
+  return (uint8_t)mode;
+}
+
+// grid = (n_clouds, n_adaptive). Writes 0xff when the window has more distinct values than the table holds; the
+// general probe kernel then redoes that (cloud, field).
+__global__ __launch_bounds__(kS2Threads) void k_probe_fast(const DevPlan plan, const ChunkDesc* __restrict__ chunks,
+                                                           const uint32_t* __restrict__ cloud_first_chunk,
+                                                           const ColumnPtrs cols, uint8_t* __restrict__ modes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t cloud = blockIdx.x, a = blockIdx.y;
+  uint8_t* mode_out = modes + cloud * plan.n_adaptive + a;
+  const uint32_t fc = cloud_first_chunk[cloud];
+  if (fc == cloud_first_chunk[cloud + 1u]) {  // empty cloud
+    if (threadIdx.x == 0) *mode_out = 0u;
+    return;
+  }
+  const ChunkDesc cd = chunks[fc];
+  const uint32_t n = cd.n_points > kProbePoints ? kProbePoints : cd.n_points;
+  const uint32_t bpv = plan.adaptive[a].bpv, type = plan.adaptive[a].type;
+  const uint8_t* col = cols.p[a] + (size_t)cd.first_point * bpv;
+  uint8_t mode;
+  if (bpv == 2u) mode = probe_mode<uint16_t>(reinterpret_cast<const uint16_t*>(col), n, type, smem);
+  else if (bpv == 4u) mode = probe_mode<uint32_t>(reinterpret_cast<const uint32_t*>(col), n, type, smem);
+  else mode = probe_mode<uint64_t>(reinterpret_cast<const uint64_t*>(col), n, type, smem);
+  if (threadIdx.x == 0) *mode_out = mode;
+}
+
 // grid = n_chunks (one launch per adaptive field). Chunks whose mode is not Palette exit at once; chunks whose
 // table overflows exit without setting handled_flags[c * n_adaptive + a] and are encoded by the general kernel.
 template <typename RawT>
