@@ -480,6 +480,24 @@ __device__ __forceinline__ void ring_put5(uint32_t* ring, uint32_t off, uint32_t
   }
 }
 
+// token of <= 4 bytes at byte `off` (whole tile fits the ring): two dword ORs, the second one predicated
+template <uint32_t RING_BYTES>
+__device__ __forceinline__ void ring_put4(uint32_t* ring, uint32_t off, uint32_t t) {
+  const uint64_t v = ((uint64_t)t) << ((off << 3) & 31u);
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  uint8_t* rb = reinterpret_cast<uint8_t*>(ring);
+  atomicOr(reinterpret_cast<uint32_t*>(rb + (off & (RING_BYTES - 4u))), lo);
+  if (hi) atomicOr(reinterpret_cast<uint32_t*>(rb + ((off + 4u) & (RING_BYTES - 4u))), hi);
+}
+
+// u < 2^28 -> its four 7-bit groups in the low 7 bits of the four bytes, continuation bits of a token of `l`
+// bytes set (two bit-field inserts per halving step; the stray bits they leave sit on the continuation positions)
+__device__ __forceinline__ uint32_t token4(uint32_t u, uint32_t l) {
+  const uint32_t x = (u & 0x00003fffu) | ((u << 2) & ~0x00003fffu);
+  const uint32_t y = (x & 0x007f007fu) | ((x << 1) & ~0x007f007fu);
+  return (y & 0x7f7f7f7fu) | (0x00808080u >> ((32u - 8u * l) & 31u));
+}
+
 template <int T, uint32_t RING_BYTES>
 __device__ __forceinline__ void ring_flush_n(uint32_t* ring, uint8_t* dst, uint32_t from, uint32_t to) {
   uint4* ring4 = reinterpret_cast<uint4*>(ring);
@@ -510,8 +528,8 @@ __device__ __forceinline__ uint64_t field_from_regs(const FloatVec<LOADW>& pt, u
   return ((((uint64_t)hi) << 32) | lo) >> ((rel & 3u) * 8u);
 }
 
-template <int T, int LANES, int PPT, uint32_t RING_BYTES, int LOADW, bool PREFETCH = true>
-__global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const uint8_t* __restrict__ points,
+template <int T, int LANES, int PPT, uint32_t RING_BYTES, int LOADW, bool PREFETCH = true, int MINW = 1>
+__global__ __launch_bounds__(T, MINW) void k_encode_floatn(const DevPlan plan, const uint8_t* __restrict__ points,
                                                      const ChunkDesc* __restrict__ chunks,
                                                      uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                      Seg* __restrict__ segs, uint32_t segs_per_chunk,
@@ -585,28 +603,29 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
     // Tokens of the row's points. Common case (no NaN in the wave row, every token <= 4 bytes, i.e. |delta| <
     // 2^27 ticks): one dword per token, built with the short formulas and kept until the scan is done. Rows with a
     // NaN or a 5-byte token (wave-uniform test) use the general formulas and are rebuilt at emission time.
-    uint32_t tok[PPT][LANES], plen[PPT], incl[PPT];
+    uint32_t tok[PPT][LANES], lens[PPT], plen[PPT], incl[PPT];
     uint32_t rare_rows = 0u;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
       const bool emits = (lane > 0u) && (idx < n);
+      lens[j] = 0u;
       uint32_t total = 0u;
       bool rare = false;
 #pragma unroll
       for (int k = 0; k < LANES; ++k) {
-        const float v = cur[j].v[k];
-        const int32_t q = quant_rne_i32(v, mult[k]);
-        // delta = q - previous lane's q; the neighbour's value travels negated so that the DPP move folds into a
-        // commutative v_add_u32_dpp (hipcc folds "q - dpp(x)" into v_subrev_u32_dpp, which returned dpp(x) - q
-        // on gfx950 / ROCm 7.2).
-        const uint32_t nqp = dpp_wave_shr1(0u - (uint32_t)q);
-        const int32_t d = (int32_t)((uint32_t)q + nqp);
-        const uint32_t zz = ((uint32_t)d << 1) ^ (uint32_t)(d >> 31);
-        rare |= is_nan_f32(v) | (zz >= 0x0fffffffu);
-        const uint32_t u = zz + 1u;
-        const uint32_t l = groups7(32u - (uint32_t)__clz((int)u));
-        tok[j][k] = spread28(u) | (0x00808080u >> ((32u - 8u * l) & 31u));
+        // Common case in the float domain: r = rndne(v * m) is an integer-valued float; with |r| < 2^21 on both
+        // sides, r - r_prev, 2d + 0.5 and |.| + 0.5 are all exact, and zigzag(d) + 1 == |2d + 0.5| + 0.5. Anything
+        // else (NaN, Inf, |r| >= 2^21 ticks) marks the row rare. The neighbour's r travels negated so that the DPP
+        // move folds into a commutative add (hipcc's v_subrev_*_dpp returned the operands swapped on gfx950).
+        const float r = rintf(__fmul_rn(cur[j].v[k], mult[k]));
+        rare |= !(fabsf(r) < 2097152.0f);
+        const float nrp = __uint_as_float(dpp_wave_shr1(__float_as_uint(r) ^ 0x80000000u));
+        const float uf = fabsf(__fmaf_rn(__fadd_rn(r, nrp), 2.0f, 0.5f)) + 0.5f;
+        const uint32_t u = (uint32_t)uf;
+        const uint32_t l = groups7((uint32_t)__builtin_amdgcn_frexp_expf(uf));  // frexp exponent == bit length of u
+        tok[j][k] = token4(u, l);
+        lens[j] |= l << (8 * k);
         total += l;
       }
       if (__ballot(rare) != 0ull) {
@@ -624,8 +643,18 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
         }
       }
       plen[j] = emits ? total : 0u;
-      incl[j] = wave_inclusive_scan(plen[j]);
-      if (lane == 63u) wtot[j * NW + (int)wave] = incl[j];
+    }
+    if (PPT == 2) {  // both rows' byte counts (< 2^16 each) ride one wave scan
+      const uint32_t pincl = wave_inclusive_scan(plen[0] | (plen[PPT - 1] << 16));
+      incl[0] = pincl & 0xffffu;
+      incl[PPT - 1] = pincl >> 16;
+    } else {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) incl[j] = wave_inclusive_scan(plen[j]);
+    }
+    if (lane == 63u) {
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) wtot[j * NW + (int)wave] = incl[j];
     }
     __syncthreads();
     const uint32_t wt = (lane < (uint32_t)(NW * PPT)) ? wtot[lane] : 0u;
@@ -644,7 +673,10 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
           const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
           if (lane > 0u && idx < n) {
             const uint32_t t = (uint32_t)idx - base;  // point index inside the tile
-            const uint64_t raw = field_from_regs<LOADW>(cur[j], plan.adaptive[a].offset - plan.ops[0].offset);
+            const uint32_t rel = plan.adaptive[a].offset - plan.ops[0].offset;
+            uint64_t raw;
+            if (LOADW == LANES + 1) raw = __float_as_uint(cur[j].v[LOADW - 1]) >> ((rel & 3u) * 8u);  // the one extra dword
+            else raw = field_from_regs<LOADW>(cur[j], rel);
             if (bpv == 2u) reinterpret_cast<uint16_t*>(st)[t] = (uint16_t)raw;
             else reinterpret_cast<uint32_t*>(st)[t] = (uint32_t)raw;
           }
@@ -674,8 +706,9 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
 #pragma unroll
           for (int k = 0; k < LANES; ++k) {
             const uint32_t t = tok[j][k];
-            const uint32_t l = (39u - (uint32_t)__clz((int)t)) >> 3;  // bytes of a non-zero token dword
-            ring_put5<RING_BYTES, decltype(windowed)::value>(ring, off, t, 0u, l, win_lo_dw);
+            const uint32_t l = (lens[j] >> (8 * k)) & 0xffu;
+            if (decltype(windowed)::value) ring_put5<RING_BYTES, true>(ring, off, t, 0u, l, win_lo_dw);
+            else ring_put4<RING_BYTES>(ring, off, t);
             off += l;
           }
         }

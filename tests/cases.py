@@ -204,6 +204,32 @@ def float_specials(n=6000, seed=3, lanes=3):
     return info, pts.view(np.uint8).reshape(-1)
 
 
+def float_domain_boundary(n=30000, seed=53, lanes=3, with_u16=False):
+    """Values straddling the |ticks| = 2^21 limit of the kernels' float-domain token path (2097.152 m at 1 mm), mixed
+    with quiet stretches, signed zeros and sub-tick values, so wave rows alternate between the two code paths."""
+    rs = np.random.RandomState(seed)
+    pts = rs.uniform(-2300, 2300, size=(n, lanes)).astype(np.float32)
+    pts[: n // 3] = np.cumsum(rs.normal(0, 0.01, size=(n // 3, lanes)), axis=0).astype(np.float32)
+    edge = np.float32(2097.152)
+    for k, val in enumerate((edge, -edge, np.nextafter(edge, np.float32(0)), np.nextafter(-edge, np.float32(0)),
+                             np.nextafter(edge, np.float32(1e9)), np.float32(2097.1515), np.float32(-2097.1525),
+                             np.float32(-0.0), np.float32(0.0), np.float32(-0.0004), np.float32(0.0004),
+                             np.float32(4194.304), np.float32(-4194.303))):
+        pts[rs.randint(n // 3, n, 60), rs.randint(0, lanes, 60)] = val
+        pts[2000 + 7 * k, :] = val                       # also inside the quiet stretch: one rare row among common ones
+    pts[5000:5200] = np.float32(2097.151)                # constant run just below the limit ...
+    pts[5200:5400] = np.float32(-2097.151)               # ... and a 2^22-tick jump between two in-range values
+    fields = [("xyzw"[k], 4 * k, F.FLOAT32, 0.001) for k in range(lanes)]
+    step = 4 * lanes
+    cols = {"xyzw"[k]: pts[:, k].copy() for k in range(lanes)}
+    if with_u16:
+        fields.append(("i", step, F.UINT16, None))
+        cols["i"] = (rs.randint(0, 200, n) * 3).astype(np.uint16)
+        step += 4
+    info = make_info(fields, step, n)
+    return info, pack(info, cols, n)
+
+
 def stride_variants():
     """Same XYZ+u16 content at awkward strides / offsets (unaligned loads, padding untouched)."""
     out = []
@@ -306,6 +332,9 @@ def encode_cases(small=False):
         out.append((f"rle_{kind}", *rle_stress(kind)))
     out.append(("float_specials3", *float_specials(lanes=3)))
     out.append(("float_specials4", *float_specials(lanes=4, seed=4)))
+    out.append(("float_boundary3", *float_domain_boundary(lanes=3)))
+    out.append(("float_boundary4", *float_domain_boundary(lanes=4, seed=54)))
+    out.append(("float_boundary3_u16", *float_domain_boundary(lanes=3, seed=55, with_u16=True)))
     out.extend(stride_variants())
     return out
 
