@@ -1565,6 +1565,12 @@ int stage1_configure_kernels() {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS2PalLds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_palette)");
   }
+  const void* pk32[] = {reinterpret_cast<const void*>(&k_section_palette32<uint16_t>),
+                        reinterpret_cast<const void*>(&k_section_palette32<uint32_t>)};
+  for (const void* f : pk32) {
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Pal32<uint32_t>::kLds);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_palette32)");
+  }
   return CLDN_HIP_OK;
 }
 
@@ -1619,9 +1625,14 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   hipLaunchKernelGGL(k_section_palette<RT>, dim3(L.n_chunks), dim3(kS2Threads), kS2PalLds, L.stream, *L.plan, a,      \
                      L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs, \
                      L.fallback_flags)
-      if (bpv == 2u) LAUNCH_PAL(uint16_t);
-      else if (bpv == 4u) LAUNCH_PAL(uint32_t);
+#define LAUNCH_PAL32(RT)                                                                                            \
+  hipLaunchKernelGGL(k_section_palette32<RT>, dim3(L.n_chunks), dim3(kS2Threads), Pal32<RT>::kLds, L.stream, *L.plan, a, \
+                     L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs, \
+                     L.fallback_flags)
+      if (bpv == 2u) LAUNCH_PAL32(uint16_t);
+      else if (bpv == 4u) LAUNCH_PAL32(uint32_t);
       else LAUNCH_PAL(uint64_t);
+#undef LAUNCH_PAL32
 #undef LAUNCH_PAL
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_palette");
     }

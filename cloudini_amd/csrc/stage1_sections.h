@@ -391,4 +391,241 @@ __global__ __launch_bounds__(kS2Threads) void k_section_palette(const DevPlan pl
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_section_palette32<RawT> (2- and 4-byte fields): same output as k_section_palette, built for few LDS round
+// trips per value and no per-value state in registers. A table word holds key and first-occurrence index
+// together (key << SHIFT | index, all-ones = free): claiming is a CAS, lowering the index an atomicMin on the
+// same word; once the ranks are known the index is replaced by the palette rank.
+//   seed    the chunk's first 4 * T values in index order, one per thread and round: palette-coded fields have
+//           few distinct values, so afterwards (nearly) every key sits at its true first index
+//   pass 1  all values, 8 per thread and step; the home words of the 8 are read together and the CAS / probe /
+//           atomicMin path runs only for new keys or lower indexes
+//   ranks   bitmap over the chunk's indexes with one bit per first occurrence; rank = set bits below (one block scan)
+//   pass 3  thread t packs the ranks of values [32t, 32t+32) into `bits` dwords (appendBitpackedIndexes,
+//           v5_codec.cpp:209-227)
+// ---------------------------------------------------------------------------------------------------------
+template <typename RawT>
+struct Pal32 {
+  using Word = typename std::conditional<sizeof(RawT) == 2, uint32_t, unsigned long long>::type;
+  static constexpr uint32_t kShift = sizeof(RawT) == 2 ? 16u : 32u;
+  static constexpr Word kFree = ~(Word)0;
+  static constexpr uint32_t kLds = kS2PalSlots * (uint32_t)sizeof(Word) + 2u * kS2Threads * 4u + 16u + 256u;
+  Word* tab;         // [kS2PalSlots]
+  uint32_t* bitmap;  // [kS2Threads]  bit i = index i is a first occurrence (32 * kS2Threads = kPointsPerChunk bits)
+  uint32_t* prefix;  // [kS2Threads]  set bits in the words before
+  uint32_t* misc;    // [0] inserted keys, [1] overflow flag
+  uint32_t* wtot;    // [64]
+  __device__ __forceinline__ explicit Pal32(uint8_t* lds) {
+    uint32_t o = 0;
+    tab = reinterpret_cast<Word*>(lds + o);
+    o += kS2PalSlots * (uint32_t)sizeof(Word);
+    bitmap = reinterpret_cast<uint32_t*>(lds + o);
+    o += kS2Threads * 4u;
+    prefix = reinterpret_cast<uint32_t*>(lds + o);
+    o += kS2Threads * 4u;
+    misc = reinterpret_cast<uint32_t*>(lds + o);
+    o += 16u;
+    wtot = reinterpret_cast<uint32_t*>(lds + o);
+  }
+  static __device__ __forceinline__ uint32_t home(uint32_t v) { return (v * 0x9e3779b1u) >> 20; }  // 12 bits
+  static __device__ __forceinline__ uint32_t key_of(Word w) { return (uint32_t)(w >> kShift); }
+  static __device__ __forceinline__ uint32_t low_of(Word w) { return (uint32_t)w & 0xffffu; }  // index, later rank
+
+  // insert (v, index); `w` = the word read at home(v)
+  __device__ __forceinline__ void insert(uint32_t v, uint32_t index, Word w) const {
+    const Word mine = ((Word)v << kShift) | index;
+    uint32_t slot = home(v);
+    uint32_t probes = 0u;
+    for (;;) {
+      if (w == kFree) {
+        w = atomicCAS(&tab[slot], kFree, mine);
+        if (w == kFree) {
+          atomicAdd(&misc[0], 1u);
+          return;
+        }
+      }
+      if (key_of(w) == v) {
+        if (low_of(w) > index) atomicMin(&tab[slot], mine);
+        return;
+      }
+      slot = (slot + 1u) & (kS2PalSlots - 1u);
+      if (++probes > kS2PalSlots) {
+        misc[1] = 1u;
+        return;
+      }
+      w = tab[slot];
+    }
+  }
+  // rank of a present key whose home word `w` holds another key
+  __device__ __forceinline__ uint32_t find_rank(uint32_t v, Word w) const {
+    uint32_t slot = home(v);
+    while (w == kFree || key_of(w) != v) {
+      slot = (slot + 1u) & (kS2PalSlots - 1u);
+      w = tab[slot];
+    }
+    return low_of(w);
+  }
+};
+
+// ranks of values [i0, i0 + cnt) (cnt <= 32) packed BITS bits each into BITS dwords
+template <typename RawT, uint32_t BITS>
+__device__ __forceinline__ void pal32_pack(const Pal32<RawT>& p, const RawT* col, uint32_t i0, uint32_t n, uint32_t cnt,
+                                           uint32_t* out) {
+  using P = Pal32<RawT>;
+  uint32_t w[BITS];
+#pragma unroll
+  for (uint32_t k = 0; k < BITS; ++k) w[k] = 0u;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    RawT v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (RawT)0;
+    if (i0 + 8u * g < n) load8<RawT>(col, i0 + 8u * g, n, v);
+    typename P::Word tw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tw[j] = p.tab[P::home((uint32_t)v[j])];  // independent reads
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t e = (uint32_t)(8 * g + j);
+      uint32_t x = 0u;
+      if (e < cnt) {
+        const bool hit = tw[j] != P::kFree && P::key_of(tw[j]) == (uint32_t)v[j];
+        x = hit ? P::low_of(tw[j]) : p.find_rank((uint32_t)v[j], tw[j]);
+      }
+      const uint32_t bit = e * BITS;
+      w[bit >> 5] |= x << (bit & 31u);
+      if ((bit & 31u) + BITS > 32u) w[(bit >> 5) + 1u] |= x >> (32u - (bit & 31u));
+    }
+  }
+  const uint32_t n_dw = (cnt * BITS + 31u) >> 5;  // a short tail thread stops at its last partial dword
+  if (n_dw == BITS && BITS % 4u == 0u) {
+#pragma unroll
+    for (uint32_t k = 0; k < BITS; k += 4u)
+      *reinterpret_cast<uint4*>(out + k) = make_uint4(w[k], w[k + 1u], w[k + 2u], w[k + 3u]);
+  } else {
+#pragma unroll
+    for (uint32_t k = 0; k < BITS; ++k)
+      if (k < n_dw) out[k] = w[k];
+  }
+}
+
+template <typename RawT>
+__global__ __launch_bounds__(kS2Threads) void k_section_palette32(
+    const DevPlan plan, uint32_t a, const ChunkDesc* __restrict__ chunks, const ColumnPtrs cols,
+    const uint8_t* __restrict__ modes, uint8_t* __restrict__ slots, uint64_t slot_stride, uint64_t reg_stride,
+    Seg* __restrict__ segs, uint32_t segs_per_chunk, uint32_t subs, uint8_t* __restrict__ handled_flags) {
+  static_assert(sizeof(RawT) == 2 || sizeof(RawT) == 4, "16- or 32-bit keys");
+  static_assert(kS2Threads * 32u == 32768u, "one bitmap word per thread covers a chunk");
+  using P = Pal32<RawT>;
+  using Word = typename P::Word;
+  constexpr int T = kS2Threads;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t c = blockIdx.x;
+  const ChunkDesc cd = chunks[c];
+  if (modes[cd.cloud * plan.n_adaptive + a] != 1u) return;
+  const uint32_t n = cd.n_points;
+  const RawT* col = reinterpret_cast<const RawT*>(cols.p[a]) + cd.first_point;
+  const uint32_t sec_off = (uint32_t)reg_stride + a * kSectionStride;
+  uint8_t* dst = slots + (size_t)c * slot_stride + sec_off;
+  const P p(smem);
+  const uint32_t tid = threadIdx.x;
+
+  for (uint32_t s = tid; s < kS2PalSlots; s += T) p.tab[s] = P::kFree;
+  p.bitmap[tid] = 0u;
+  if (tid < 4u) p.misc[tid] = 0u;
+  __syncthreads();
+
+  // seed
+#pragma unroll
+  for (uint32_t r = 0; r < 4u; ++r) {
+    const uint32_t i = r * T + tid;
+    if (i < n) {
+      const uint32_t v = (uint32_t)col[i];
+      p.insert(v, i, p.tab[P::home(v)]);
+    }
+  }
+  __syncthreads();
+
+  // pass 1
+  for (uint32_t s = 0; s < 4u; ++s) {
+    const uint32_t i0 = (s * T + tid) * 8u;
+    if (i0 >= n) break;
+    RawT v[8];
+    load8<RawT>(col, i0, n, v);
+    Word w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = p.tab[P::home((uint32_t)v[j])];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t idx = i0 + (uint32_t)j;
+      const bool settled = w[j] != P::kFree && P::key_of(w[j]) == (uint32_t)v[j] && P::low_of(w[j]) <= idx;
+      if (idx < n && !settled) p.insert((uint32_t)v[j], idx, w[j]);
+    }
+  }
+  __syncthreads();
+  if (p.misc[1] != 0u || p.misc[0] > kS2PalCapacity) return;  // uniform: the general kernel encodes this chunk
+
+  // ranks in first-occurrence order
+#pragma unroll
+  for (uint32_t q = 0; q < kS2PalSlots / T; ++q) {
+    const Word w = p.tab[q * T + tid];
+    if (w != P::kFree) atomicOr(&p.bitmap[P::low_of(w) >> 5], 1u << (P::low_of(w) & 31u));
+  }
+  __syncthreads();
+  uint32_t U;
+  p.prefix[tid] = block_exclusive_scan<T>((uint32_t)__builtin_popcount(p.bitmap[tid]), p.wtot, &U);
+  __syncthreads();
+#pragma unroll
+  for (uint32_t q = 0; q < kS2PalSlots / T; ++q) {
+    const Word w = p.tab[q * T + tid];
+    if (w != P::kFree) {
+      const uint32_t f = P::low_of(w);
+      const uint32_t rk = p.prefix[f >> 5] + (uint32_t)__builtin_popcount(p.bitmap[f >> 5] & ((1u << (f & 31u)) - 1u));
+      p.tab[q * T + tid] = (w & ~(Word)0xffffu) | rk;
+      const uint32_t val = P::key_of(w);
+      uint8_t* out = dst + 3u + (size_t)rk * sizeof(RawT);  // palette value rk behind the 3-byte header
+#pragma unroll
+      for (uint32_t b = 0; b < sizeof(RawT); ++b) out[b] = (uint8_t)(val >> (8u * b));
+    }
+  }
+  if (tid == 0) {
+    dst[0] = 1u;
+    dst[1] = (uint8_t)(U & 0xffu);
+    dst[2] = (uint8_t)((U >> 8) & 0xffu);  // static_cast<uint16_t>(palette.size()), v5_codec.cpp:464
+  }
+  __syncthreads();
+
+  // pass 3
+  const uint32_t bits = palette_bits(U);
+  const uint32_t i0 = tid * 32u;
+  const uint32_t cnt = i0 < n ? min(32u, n - i0) : 0u;
+  if (bits != 0u && cnt != 0u) {
+    uint32_t* idx_out = reinterpret_cast<uint32_t*>(dst + kPaletteIndexOffset) + (size_t)tid * bits;
+    switch (bits) {  // block-uniform
+      case 1: pal32_pack<RawT, 1>(p, col, i0, n, cnt, idx_out); break;
+      case 2: pal32_pack<RawT, 2>(p, col, i0, n, cnt, idx_out); break;
+      case 3: pal32_pack<RawT, 3>(p, col, i0, n, cnt, idx_out); break;
+      case 4: pal32_pack<RawT, 4>(p, col, i0, n, cnt, idx_out); break;
+      case 5: pal32_pack<RawT, 5>(p, col, i0, n, cnt, idx_out); break;
+      case 6: pal32_pack<RawT, 6>(p, col, i0, n, cnt, idx_out); break;
+      case 7: pal32_pack<RawT, 7>(p, col, i0, n, cnt, idx_out); break;
+      case 8: pal32_pack<RawT, 8>(p, col, i0, n, cnt, idx_out); break;
+      case 9: pal32_pack<RawT, 9>(p, col, i0, n, cnt, idx_out); break;
+      case 10: pal32_pack<RawT, 10>(p, col, i0, n, cnt, idx_out); break;
+      case 11: pal32_pack<RawT, 11>(p, col, i0, n, cnt, idx_out); break;
+      default: pal32_pack<RawT, 12>(p, col, i0, n, cnt, idx_out); break;  // U <= kS2PalCapacity = 3072: <= 12 bits
+    }
+  }
+  if (tid == 0) {
+    Seg s;
+    s.off = sec_off;
+    s.size = 3u + U * (uint32_t)sizeof(RawT);
+    segs[(size_t)c * segs_per_chunk + subs + 2u * a] = s;
+    s.off = sec_off + kPaletteIndexOffset;
+    s.size = (bits * n + 7u) >> 3;
+    segs[(size_t)c * segs_per_chunk + subs + 1u + 2u * a] = s;
+    handled_flags[(size_t)c * plan.n_adaptive + a] = 1u;
+  }
+}
+
 }  // namespace cldn
