@@ -588,17 +588,13 @@ __global__ __launch_bounds__(T, MINW) void k_encode_floatn(const DevPlan plan, c
       dst[j] = z;
     }
   };
-  if (PREFETCH) load_tile(0u, cur);
+  load_tile(0u, cur);
   __syncthreads();
 
   uint32_t R = 0u, F = 0u;
   for (uint32_t base = 0; base < (uint32_t)n; base += TILE) {
     const bool last = (base + TILE >= (uint32_t)n);
-    if (PREFETCH) {
-      if (!last) load_tile(base + TILE, nxt);  // in flight while this tile is encoded
-    } else {
-      load_tile(base, cur);  // latency is covered by the other workgroups resident on the CU
-    }
+    if (PREFETCH && !last) load_tile(base + TILE, nxt);  // double buffer: in flight while this tile is encoded
 
     // Tokens of the row's points. Common case (no NaN in the wave row, every token <= 4 bytes, i.e. |delta| <
     // 2^27 ticks): one dword per token, built with the short formulas and kept until the scan is done. Rows with a
@@ -665,7 +661,7 @@ __global__ __launch_bounds__(T, MINW) void k_encode_floatn(const DevPlan plan, c
 
     if (plan.n_adaptive && LOADW > LANES && !(ablate & 1u)) {
       for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
-        if (!col_staged(plan, a, true)) continue;
+        if (!col_staged(plan, a, true) || (ablate & 16u)) continue;
         const uint32_t bpv = plan.adaptive[a].bpv;
         uint8_t* st = colstage + (size_t)a * (TILE * 4u);
 #pragma unroll
@@ -715,9 +711,60 @@ __global__ __launch_bounds__(T, MINW) void k_encode_floatn(const DevPlan plan, c
       }
     };
 
+    // AoS -> SoA split of the adaptive-int fields. Fields covered by the point load are taken from registers;
+    // 2/4-byte fields are staged in LDS (written after the scan barrier) and leave as 16-byte stores.
+    auto write_columns = [&]() {
+      if (plan.n_adaptive && !(ablate & 1u)) {
+        const uint32_t tile_pts = min(TILE, (uint32_t)n - base);
+        for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
+          const uint32_t bpv = plan.adaptive[a].bpv;
+          uint8_t* gcol = cols.p[a] + (first_point + base) * bpv;
+          const bool staged = col_staged(plan, a, LOADW > LANES) && (((uintptr_t)gcol & 15u) == 0u) && !(ablate & 16u);
+          if (staged) {
+            const uint8_t* st = colstage + (size_t)a * (TILE * 4u);
+            const uint32_t bytes = tile_pts * bpv;
+            for (uint32_t u = tid; u < (bytes >> 4); u += T)
+              reinterpret_cast<uint4*>(gcol)[u] = reinterpret_cast<const uint4*>(st)[u];
+            const uint32_t tail0 = bytes & ~15u;
+            if (tid < (bytes & 15u)) gcol[tail0 + tid] = st[tail0 + tid];
+            continue;
+          }
+  #pragma unroll
+          for (int j = 0; j < PPT; ++j) {
+            const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
+            if (lane > 0u && idx < n) {
+              const size_t gi = first_point + (size_t)idx;
+              uint8_t* col = cols.p[a];
+              uint64_t raw;
+              if (LOADW > LANES) {
+                raw = field_from_regs<LOADW>(cur[j], plan.adaptive[a].offset - plan.ops[0].offset);
+              } else {
+                const uint8_t* fp = points + gi * step + plan.adaptive[a].offset;
+                raw = 0u;
+                if (((uintptr_t)fp & (bpv - 1u)) == 0u) {
+                  if (bpv == 2u) raw = *reinterpret_cast<const uint16_t*>(fp);
+                  else if (bpv == 4u) raw = *reinterpret_cast<const uint32_t*>(fp);
+                  else raw = *reinterpret_cast<const uint64_t*>(fp);
+                } else {
+                  for (uint32_t b = 0; b < bpv; ++b) raw |= ((uint64_t)fp[b]) << (8u * b);
+                }
+              }
+              if (bpv == 2u) reinterpret_cast<uint16_t*>(col)[gi] = (uint16_t)raw;
+              else if (bpv == 4u) reinterpret_cast<uint32_t*>(col)[gi] = (uint32_t)raw;
+              else reinterpret_cast<uint64_t*>(col)[gi] = raw;
+            }
+          }
+        }
+      }
+    };
+
+    // Without the double buffer the next tile's points are requested as soon as this tile's registers are dead:
+    // the loads fly during the ring flush and the next scan barrier.
     if (r_end - F <= RING_BYTES) {
       emit_all(std::false_type{}, 0u);
       __syncthreads();
+      write_columns();
+      if (!PREFETCH && !last) load_tile(base + TILE, cur);
       if (!(ablate & 4u)) ring_flush_n<T, RING_BYTES>(ring, slot, F, target);
       F = target;
     } else {
@@ -731,53 +778,10 @@ __global__ __launch_bounds__(T, MINW) void k_encode_floatn(const DevPlan plan, c
         if (done) break;
         __syncthreads();
       }
+      write_columns();
+      if (!PREFETCH && !last) load_tile(base + TILE, cur);
     }
     R = r_end;
-
-    // AoS -> SoA split of the adaptive-int fields. Fields covered by the point load are taken from registers;
-    // 2/4-byte fields are staged in LDS (written before the barrier above) and leave as 16-byte stores.
-    if (plan.n_adaptive && !(ablate & 1u)) {
-      const uint32_t tile_pts = min(TILE, (uint32_t)n - base);
-      for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
-        const uint32_t bpv = plan.adaptive[a].bpv;
-        uint8_t* gcol = cols.p[a] + (first_point + base) * bpv;
-        const bool staged = col_staged(plan, a, LOADW > LANES) && (((uintptr_t)gcol & 15u) == 0u);
-        if (staged) {
-          const uint8_t* st = colstage + (size_t)a * (TILE * 4u);
-          const uint32_t bytes = tile_pts * bpv;
-          for (uint32_t u = tid; u < (bytes >> 4); u += T)
-            reinterpret_cast<uint4*>(gcol)[u] = reinterpret_cast<const uint4*>(st)[u];
-          const uint32_t tail0 = bytes & ~15u;
-          if (tid < (bytes & 15u)) gcol[tail0 + tid] = st[tail0 + tid];
-          continue;
-        }
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-          const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
-          if (lane > 0u && idx < n) {
-            const size_t gi = first_point + (size_t)idx;
-            uint8_t* col = cols.p[a];
-            uint64_t raw;
-            if (LOADW > LANES) {
-              raw = field_from_regs<LOADW>(cur[j], plan.adaptive[a].offset - plan.ops[0].offset);
-            } else {
-              const uint8_t* fp = points + gi * step + plan.adaptive[a].offset;
-              raw = 0u;
-              if (((uintptr_t)fp & (bpv - 1u)) == 0u) {
-                if (bpv == 2u) raw = *reinterpret_cast<const uint16_t*>(fp);
-                else if (bpv == 4u) raw = *reinterpret_cast<const uint32_t*>(fp);
-                else raw = *reinterpret_cast<const uint64_t*>(fp);
-              } else {
-                for (uint32_t b = 0; b < bpv; ++b) raw |= ((uint64_t)fp[b]) << (8u * b);
-              }
-            }
-            if (bpv == 2u) reinterpret_cast<uint16_t*>(col)[gi] = (uint16_t)raw;
-            else if (bpv == 4u) reinterpret_cast<uint32_t*>(col)[gi] = (uint32_t)raw;
-            else reinterpret_cast<uint64_t*>(col)[gi] = raw;
-          }
-        }
-      }
-    }
 
     if (PREFETCH && !last) {
 #pragma unroll
