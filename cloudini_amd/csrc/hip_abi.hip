@@ -133,6 +133,7 @@ struct cldn_hip_codec {
   DevBuf d_pre[kMaxGorilla];
   PinnedBuf h_stage;   // chunk table upload
   PinnedBuf h_result;  // offsets / status readback
+  PinnedBuf h_modes;   // forced modes upload
   // cached batch shape
   std::vector<uint64_t> last_cloud_points;
   uint32_t last_n_chunks = 0;
@@ -140,6 +141,8 @@ struct cldn_hip_codec {
   std::vector<hipEvent_t> events;  // 5 per timing slot
   std::vector<uint8_t> slot_valid;
   uint64_t call_index = 0;
+  // modes committed elsewhere (continuation of a cloud from a chunk boundary); empty = probe
+  std::vector<uint8_t> forced_modes;
 };
 
 extern "C" {
@@ -623,6 +626,16 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   L.chunk_dst = (uint64_t*)c->d_dst.p;
   L.stream_offsets = (uint64_t*)c->d_offsets.p;
   L.modes = (uint8_t*)c->d_modes.p;
+  L.modes_forced = false;
+  if (!c->forced_modes.empty() && n_adaptive && n_clouds) {
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the previous call's upload from h_modes has to be over
+    if ((rc = c->h_modes.ensure((size_t)n_clouds * n_adaptive)) != CLDN_HIP_OK) return rc;
+    for (uint32_t k = 0; k < n_clouds; ++k)
+      memcpy((uint8_t*)c->h_modes.p + (size_t)k * n_adaptive, c->forced_modes.data(), n_adaptive);
+    HIP_TRY(hipMemcpyAsync(c->d_modes.p, c->h_modes.p, (size_t)n_clouds * n_adaptive, hipMemcpyHostToDevice,
+                           c->stream));
+    L.modes_forced = true;
+  }
   L.fallback_flags = (uint8_t*)c->d_fbflags.p;
   L.out = d_outp;
   L.out_capacity = out_capacity;
@@ -688,6 +701,21 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   if (modes && modes_bytes) HIP_TRY(hipMemcpyAsync(modes, c->d_modes.p, modes_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (stream_offsets) memcpy(stream_offsets, h_off, (size_t)(n_clouds + 1) * sizeof(uint64_t));
+  return CLDN_HIP_OK;
+}
+
+int cldn_hip_codec_force_modes(cldn_hip_codec_t* c, const uint8_t* modes, uint32_t n_modes) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if (!modes || n_modes == 0) {
+    c->forced_modes.clear();
+    return CLDN_HIP_OK;
+  }
+  if (n_modes != c->plan.dev.n_adaptive)
+    return fail(CLDN_HIP_ERR_ARG, "force_modes: %u modes given, the plan has %u adaptive fields", n_modes,
+                c->plan.dev.n_adaptive);
+  for (uint32_t a = 0; a < n_modes; ++a)
+    if (modes[a] > 3u) return fail(CLDN_HIP_ERR_ARG, "force_modes: invalid adaptive-int mode %u", modes[a]);
+  c->forced_modes.assign(modes, modes + n_modes);
   return CLDN_HIP_OK;
 }
 

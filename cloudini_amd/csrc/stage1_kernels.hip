@@ -1613,16 +1613,18 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     ColumnPtrs rank_cols;
     for (int a = 0; a < kMaxAdaptive; ++a) rank_cols.p[a] = reinterpret_cast<uint8_t*>(L.ranks[a]);
     static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
-    if (!no_fast) {
-      hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na), dim3(kS2Threads), kS2PalLds, L.stream, *L.plan, L.chunks,
-                         L.cloud_first_chunk, L.cols, L.modes);
-      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_fast");
-    } else {
-      (void)hipMemsetAsync(L.modes, 0xff, (size_t)L.n_clouds * na, L.stream);
+    if (!L.modes_forced) {
+      if (!no_fast) {
+        hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na), dim3(kS2Threads), kS2PalLds, L.stream, *L.plan, L.chunks,
+                           L.cloud_first_chunk, L.cols, L.modes);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_fast");
+      } else {
+        (void)hipMemsetAsync(L.modes, 0xff, (size_t)L.n_clouds * na, L.stream);
+      }
+      hipLaunchKernelGGL(k_probe_modes, dim3(L.n_clouds, na), dim3(kSecThreads), kSecLdsTotal, L.stream, *L.plan,
+                         L.chunks, L.cloud_first_chunk, L.cols, L.modes);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_modes");
     }
-    hipLaunchKernelGGL(k_probe_modes, dim3(L.n_clouds, na), dim3(kSecThreads), kSecLdsTotal, L.stream, *L.plan,
-                       L.chunks, L.cloud_first_chunk, L.cols, L.modes);
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_modes");
     for (uint32_t a = 0; a < na && !no_fast; ++a) {
       const uint32_t bpv = L.plan->adaptive[a].bpv;
 #define LAUNCH_PAL(RT)                                                                                              \

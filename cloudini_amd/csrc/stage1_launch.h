@@ -33,6 +33,7 @@ struct EncodeLaunch {
   uint64_t* chunk_dst;        // device [n_chunks]
   uint64_t* stream_offsets;   // device [n_clouds + 1]
   uint8_t* modes;             // device [n_clouds * n_adaptive]
+  bool modes_forced;          // modes were uploaded by the caller: no probe kernels
   uint8_t* fallback_flags;    // device [n_chunks * n_adaptive], zeroed per call: 1 = section written by a fast path
   uint8_t* out;               // device, framed streams
   uint64_t out_capacity;

@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
     L.cldn_hip_codec_enable_timing.restype = C.c_int
     L.cldn_hip_codec_kernel_ms.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float)]
     L.cldn_hip_codec_kernel_ms.restype = C.c_int
+    L.cldn_hip_codec_force_modes.argtypes = [vp, C.POINTER(C.c_uint8), C.c_uint32]
+    L.cldn_hip_codec_force_modes.restype = C.c_int
     L.cldn_hip_encode_stage1.restype = C.c_int
     L.cldn_hip_encode_stage1.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, vp, C.c_uint64, C.c_int, vp, vp, vp]
     L.cldn_hip_decode_stage1.restype = C.c_int
@@ -162,6 +164,14 @@ class Codec:
 
     def status(self):
         _check(lib().cldn_hip_codec_status(self._h))
+
+    def force_modes(self, modes=None):
+        """Adaptive-int modes committed elsewhere (cldn_hip_codec_force_modes); None / empty returns to probing."""
+        if modes is None or len(modes) == 0:
+            _check(lib().cldn_hip_codec_force_modes(self._h, None, 0))
+            return
+        m = np.ascontiguousarray(modes, dtype=np.uint8)
+        _check(lib().cldn_hip_codec_force_modes(self._h, m.ctypes.data_as(C.POINTER(C.c_uint8)), m.size))
 
     def enable_timing(self, n_slots: int):
         _check(lib().cldn_hip_codec_enable_timing(self._h, int(n_slots)))

@@ -101,6 +101,16 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* codec, const void* points, int poin
                            const uint64_t* cloud_points, uint32_t n_clouds, void* out, uint64_t out_capacity,
                            int out_loc, uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes);
 
+/* Continuation of one cloud across several calls / devices. The reference commits the adaptive-int modes once per
+ * encode() call, on the first <= 4096 points of the cloud (src/v5_codec.cpp:934-949), and resets every other
+ * state at each 32768-point chunk (:910-915). A range of whole chunks of a cloud can therefore be encoded on
+ * its own -- on another GPU -- once the modes are known: pass the `modes` that the cloud's first chunk produced
+ * (cldn_hip_encode_stage1 of its first min(n, 4096) points) and encode the range as if it were a cloud; the
+ * framed chunks are byte-identical to that range of the whole cloud's stream.
+ *   modes   HOST array [adaptive_fields] with values 0..3; NULL / n_modes = 0 returns to probing.
+ * The setting stays until changed and applies to every cloud of the following encode calls. */
+int cldn_hip_codec_force_modes(cldn_hip_codec_t* codec, const uint8_t* modes, uint32_t n_modes);
+
 /* Decode a batch of framed stage-1 streams (inverse of the above).
  *   streams        the streams back to back; cloud k occupies [stream_offsets[k], stream_offsets[k+1])
  *   stream_offsets HOST array [n_clouds + 1]

@@ -73,6 +73,9 @@ class Oracle:
         L.orc_encode_stage1.restype = C.c_int64
         L.orc_encode_stage1.argtypes = [C.POINTER(_OrcSchema), C.POINTER(C.c_uint8), C.c_uint64,
                                         C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint8), C.c_uint32]
+        L.orc_encode_stage1_continued.restype = C.c_int64
+        L.orc_encode_stage1_continued.argtypes = [C.POINTER(_OrcSchema), C.POINTER(C.c_uint8), C.c_uint64,
+                                                  C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint8), C.c_uint32]
         L.orc_decode_stage1.restype = C.c_int64
         L.orc_decode_stage1.argtypes = [C.POINTER(_OrcSchema), C.POINTER(C.c_uint8), C.c_uint64, C.c_uint64,
                                         C.POINTER(C.c_uint8)]
@@ -131,6 +134,22 @@ class Oracle:
         if return_modes:
             return res, modes[: self.adaptive_field_count(info)].copy()
         return res
+
+    def encode_stage1_continued(self, info, cloud, modes) -> np.ndarray:
+        """Chunks of a larger cloud whose first chunk committed `modes` (orc_encode_stage1_continued)."""
+        data = _as_u8(cloud)
+        step = int(info.point_step)
+        assert data.size % step == 0
+        n = data.size // step
+        s, _keep = self._schema(info)
+        cap = int(self.lib.orc_stage1_bound(C.byref(s), n)) + 64 + 32 * n
+        out = np.empty(cap, dtype=np.uint8)
+        m = np.ascontiguousarray(modes, dtype=np.uint8)
+        r = self.lib.orc_encode_stage1_continued(C.byref(s), _ptr(data), n, _ptr(out), cap,
+                                                 _ptr(m) if m.size else None, m.size)
+        if r < 0:
+            raise OracleError(f"orc_encode_stage1_continued failed: {r}")
+        return out[:r].copy()
 
     def decode_stage1(self, info, stream, n_points: int, fill: int = 0) -> np.ndarray:
         st = _as_u8(stream)

@@ -664,8 +664,26 @@ static int afields_build(const orc_schema_t* s, afield_t* a, int max) {
 
 #define ORC_MAX_OPS 256
 
+static int64_t encode_stage1_impl(const orc_schema_t* s, const uint8_t* data, uint64_t n_points, uint8_t* out,
+                                  uint64_t capacity, uint8_t* modes_out, uint32_t modes_capacity,
+                                  const uint8_t* forced_modes, uint32_t n_forced);
+
 int64_t orc_encode_stage1(const orc_schema_t* s, const uint8_t* data, uint64_t n_points, uint8_t* out,
                           uint64_t capacity, uint8_t* modes_out, uint32_t modes_capacity) {
+  return encode_stage1_impl(s, data, n_points, out, capacity, modes_out, modes_capacity, NULL, 0);
+}
+
+/* A range of whole chunks of a larger cloud: the modes were committed on that cloud's first chunk
+ * (v5_codec.cpp:934-949, once per encode call), everything else resets per chunk (:910-915). */
+int64_t orc_encode_stage1_continued(const orc_schema_t* s, const uint8_t* data, uint64_t n_points, uint8_t* out,
+                                    uint64_t capacity, const uint8_t* modes, uint32_t n_modes) {
+  if (!modes && n_modes) return ORC_ERR_ARG;
+  return encode_stage1_impl(s, data, n_points, out, capacity, NULL, 0, modes, n_modes);
+}
+
+static int64_t encode_stage1_impl(const orc_schema_t* s, const uint8_t* data, uint64_t n_points, uint8_t* out,
+                                  uint64_t capacity, uint8_t* modes_out, uint32_t modes_capacity,
+                                  const uint8_t* forced_modes, uint32_t n_forced) {
   if (!s || s->point_step == 0 || (!data && n_points) || (!out && capacity)) return ORC_ERR_ARG;
   const int v5 = orc_uses_v5(s);
   op_t* ops = (op_t*)malloc(sizeof(op_t) * ORC_MAX_OPS);
@@ -676,6 +694,14 @@ int64_t orc_encode_stage1(const orc_schema_t* s, const uint8_t* data, uint64_t n
   if (n_ops < 0) { free(ops); free(af); return n_ops; }
   const int n_af = afields_build(s, af, ORC_MAX_OPS);
   if (n_af < 0) { free(ops); free(af); return n_af; }
+  if (forced_modes) {
+    if ((int)n_forced != n_af) { afields_free(af, n_af); free(ops); free(af); return ORC_ERR_ARG; }
+    for (int a = 0; a < n_af; ++a) {
+      if (forced_modes[a] > 3) { afields_free(af, n_af); free(ops); free(af); return ORC_ERR_ARG; }
+      af[a].mode = forced_modes[a];
+      af[a].committed = 1;
+    }
+  }
 
   uint64_t max_regular = 0; /* worst-case regular bytes per point, for the capacity check */
   for (int k = 0; k < n_ops; ++k) {

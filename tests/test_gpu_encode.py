@@ -144,3 +144,60 @@ def test_capacity_contract():
                                              out.ctypes.data_as(C.c_void_p), out.size, 0, None, None, None)
     assert rc == -2  # cloudini.cpp:531-534: "Output buffer too small for worst-case compressed size"
     codec.close()
+
+
+# ---- one cloud encoded as chunk ranges with the modes of its head (cldn_hip_codec_force_modes) ------------------
+
+def _split_encode(codec, info, data, world):
+    from cloudini_amd import sharding
+    step = info.point_step
+    n = data.size // step
+    modes = None
+    if codec.plan.adaptive_fields:
+        head = min(n, sharding.PROBE_POINTS)
+        codec.force_modes(None)
+        modes = codec.encode_host([data[: head * step]])[2][0]
+        codec.force_modes(modes)
+    parts = []
+    for r in range(world):
+        p0, cnt = sharding.shard_chunks(n, world, r)
+        if cnt:
+            parts.append(codec.encode_host([data[p0 * step:(p0 + cnt) * step]])[0][0])
+    codec.force_modes(None)
+    return np.concatenate(parts) if parts else np.zeros(0, np.uint8), modes
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_chunk_range_parts_equal_whole_cloud(oracle, world):
+    from cloudini_amd import native
+    for info, data in (synth.lidar_xyzi(200_000, seed=9), synth.velodyne_xyzir(130048, seed=10),
+                       synth.depthcam_xyzrgba(640, 400), synth.lidar_xyz(150_000, seed=11)):
+        codec = native.Codec(native.Plan(info))
+        got, modes = _split_encode(codec, info, data, world)
+        want, want_modes = oracle.encode_stage1(info, data, return_modes=True)
+        assert got.size == want.size and np.array_equal(got, want), f"first diff at {_first_diff(got, want)}"
+        if modes is not None:
+            assert list(modes) == list(want_modes)
+        codec.close()
+
+
+def test_forced_modes_override_the_probe(oracle):
+    """Every forced mode must produce what the reference would write had it committed that mode: compare with the
+    oracle's continued encoder, which takes the mode as given."""
+    from cloudini_amd import native
+    info, data = synth.lidar_xyzi(70_000, seed=12)
+    codec = native.Codec(native.Plan(info))
+    for mode in (0, 1, 2, 3):
+        codec.force_modes([mode])
+        got, _sizes, got_modes = codec.encode_host([data])
+        want = oracle.encode_stage1_continued(info, data, [mode])
+        assert np.array_equal(got[0], want), f"mode {mode}: first diff at {_first_diff(got[0], want)}"
+        assert list(got_modes[0]) == [mode]
+    codec.force_modes(None)
+    got, _sizes, got_modes = codec.encode_host([data])
+    assert np.array_equal(got[0], oracle.encode_stage1(info, data))
+    with pytest.raises(native.CloudiniHipError):
+        codec.force_modes([1, 2])       # one adaptive field in this schema
+    with pytest.raises(native.CloudiniHipError):
+        codec.force_modes([7])
+    codec.close()
