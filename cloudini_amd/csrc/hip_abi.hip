@@ -770,7 +770,8 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams
   h_so[n_clouds] = stream_bytes - base_off;
   h_fp[n_clouds] = fp;
   h_fc[n_clouds] = fc;
-  if ((rc = c->d_dec_meta.ensure(((table_bytes + 63) & ~size_t(63)) + (size_t)std::max(1u, n_chunks) * kDecChunkBytes)) != CLDN_HIP_OK)
+  const size_t chunk_table_bytes = ((size_t)std::max(1u, n_chunks) * kDecChunkBytes + 63) & ~size_t(63);
+  if ((rc = c->d_dec_meta.ensure(((table_bytes + 63) & ~size_t(63)) + chunk_table_bytes + (size_t)std::max(1u, n_chunks) * 4u)) != CLDN_HIP_OK)
     return rc;
   c->last_cloud_points.clear();  // the staging buffer no longer holds the encode chunk table
   uint8_t* meta = (uint8_t*)c->d_dec_meta.p;
@@ -806,6 +807,7 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams
   L.n_clouds = n_clouds;
   L.n_chunks = n_chunks;
   L.chunks = meta + ((table_bytes + 63) & ~size_t(63));
+  L.reg_end = (uint32_t*)(meta + ((table_bytes + 63) & ~size_t(63)) + chunk_table_bytes);
   L.out = d_outp;
   L.status = (uint32_t*)c->d_status.p;
   if ((rc = stage1_launch_decode(L)) != CLDN_HIP_OK) return rc;

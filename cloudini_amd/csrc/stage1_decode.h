@@ -199,11 +199,17 @@ __global__ __launch_bounds__(64) void k_decode_general(const DevPlan plan, const
   r.end = r.p + dc.src_size;
   r.bad = false;
   const uint32_t n = dc.n_points;
+  bool regular_done = false;
   if (only_sections) {
     const uint32_t off = reg_end[blockIdx.x];
-    if (off == 0xffffffffu || off > dc.src_size) r.bad = true;
-    else r.p += off;
-  } else {
+    if (off != 0xfffffffeu) {  // kDecRedo: the fast kernel gave up on this chunk
+      if (off > dc.src_size) r.bad = true;
+      else r.p += off;
+      regular_done = true;
+      if (!uses_v5) return;    // V4 wire: nothing behind the regular stream
+    }
+  }
+  if (!regular_done) {
     int64_t prev[kMaxOps];
     uint8_t gor_lead[kMaxOps], gor_trail[kMaxOps];
     for (uint32_t k = 0; k < plan.n_ops; ++k) {
@@ -348,6 +354,285 @@ __global__ __launch_bounds__(64) void k_decode_general(const DevPlan plan, const
     if (!r.bad && r.p != r.end) r.bad = true;  // "V5 chunk has trailing bytes after decode" (v5_codec.cpp:1008-1010)
   }
   if (r.bad) atomicOr(status, (uint32_t)ST_CORRUPT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_decode_varint<NOPS, WIDE>: the regular stream of one chunk by one workgroup, for plans whose regular ops are all
+// varint-coded (FloatN lanes, Float_Lossy scalars, V4 integer fields) and number at most NOPS per point.
+//
+//   tile = 8 bytes per thread. End-of-token flags (MSB clear; the NaN marker 0x00 included) -> one block scan gives
+//   every thread the index of its first token; the tokens ending inside a thread's 8 bytes are consecutive, and the
+//   thread rebuilds each from the 8-byte window that ends at the token's last byte (tokens of more than 7 bytes
+//   send the chunk to k_decode_general). Token values are staged in LDS in token order; then every thread takes a
+//   run of whole points: local sums per op with NaN resets -> segmented block scan -> second walk that adds the
+//   incoming value, converts and stores (FieldDecoderFloatN_Lossy::decode, src/field_decoder.cpp:43-86;
+//   FieldDecoderFloat_Lossy / FieldDecoderInt, include/cloudini_lib/field_decoder.hpp:330-353, :79-106).
+//   Tokens of a point cut by the tile edge wait at the front of the LDS buffer for the next tile.
+//
+// reg_end[c] receives the offset of the first byte behind the regular stream (= first section byte for V5), or
+// kDecRedo when anything looked irregular; k_decode_general then decodes that chunk from scratch, so all error
+// reporting stays with the restatement of the reference's checks.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kDecRedo = 0xfffffffeu;
+constexpr int kDvThreads = 1024;
+constexpr uint32_t kDvTileBytes = kDvThreads * 8u;
+
+template <int NOPS, bool WIDE>
+struct DvLds {
+  using Acc = typename std::conditional<WIDE, long long, int>::type;
+  static constexpr uint32_t kBytesOff = 0;                                  // [16 history + tile] bytes
+  static constexpr uint32_t kValOff = 16u + kDvTileBytes + 16u;             // Acc [8 + tile tokens]
+  static constexpr uint32_t kMarkOff = kValOff + (8u + kDvTileBytes) * (uint32_t)sizeof(Acc);  // u8 [8 + tile tokens]
+  static constexpr uint32_t kScanOff = (kMarkOff + 8u + kDvTileBytes + 15u) & ~15u;  // per wave: Acc[NOPS] + flags
+  static constexpr uint32_t kWaveRec = NOPS * (uint32_t)sizeof(Acc) + 8u;
+  static constexpr uint32_t kMiscOff = kScanOff + 17u * kWaveRec;           // 16 waves + carry record
+  static constexpr uint32_t kTotal = kMiscOff + 256u;  // misc: [0] bad, [1] reg_end, [2..34) block-scan scratch
+};
+
+template <int NOPS, bool WIDE>
+__global__ __launch_bounds__(kDvThreads) void k_decode_varint(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                              const DecChunk* __restrict__ chunks,
+                                                              uint8_t* __restrict__ out, uint32_t* __restrict__ reg_end) {
+  using L = DvLds<NOPS, WIDE>;
+  using Acc = typename L::Acc;
+  using UAcc = typename std::make_unsigned<Acc>::type;
+  constexpr int T = kDvThreads;
+  constexpr int NW = T / 64;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* tileb = reinterpret_cast<uint32_t*>(smem + L::kBytesOff);
+  Acc* val = reinterpret_cast<Acc*>(smem + L::kValOff);
+  uint8_t* mark = smem + L::kMarkOff;
+  uint8_t* scanrec = smem + L::kScanOff;
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + L::kMiscOff);  // [0] bad, [1] reg_end, [2..] block scan scratch
+
+  const uint32_t c = blockIdx.x;
+  const DecChunk dc = chunks[c];
+  if (!dc.valid) return;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t n_ops = plan.n_ops;
+  const uint32_t step = plan.point_step;
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t src_size = dc.src_size;
+  uint8_t* base = out + (size_t)dc.first_point * step;
+  const uint32_t target = dc.n_points * n_ops;  // tokens of the regular stream
+
+  if (tid < 4u) tileb[tid] = 0u;  // history before the payload: token ends
+  if (tid < 16u) misc[tid] = 0u;
+  if (tid == 0) misc[1] = 0xffffffffu;
+  if (tid < (uint32_t)(NOPS * sizeof(Acc) + 8u) / 4u)
+    reinterpret_cast<uint32_t*>(scanrec + 16u * L::kWaveRec)[tid] = 0u;  // carry record: sums 0, no reset
+  __syncthreads();
+
+  uint32_t pos = 0u;        // payload offset of the current tile
+  uint32_t pts_done = 0u;   // points already written
+  uint32_t left = 0u;       // tokens of a cut point waiting at val[0..left)
+  while (pts_done * n_ops + left < target) {
+    if (pos >= src_size) {  // stream ends before all tokens: general kernel reports it
+      if (tid == 0) misc[0] = 1u;
+      break;
+    }
+    // ---- bytes, end flags, token indexes
+    const uint32_t my = pos + tid * 8u;
+    uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu;  // past the end: continuation bytes, no token ends
+    if (my + 8u <= src_size) {
+      const uint8_t* q = src + my;
+      if ((((uintptr_t)q) & 3u) == 0u) {
+        b0 = reinterpret_cast<const uint32_t*>(q)[0];
+        b1 = reinterpret_cast<const uint32_t*>(q)[1];
+      } else {
+        b0 = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+        b1 = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
+      }
+    } else if (my < src_size) {
+      uint64_t w = ~0ull;
+      for (uint32_t k = 0; k < src_size - my; ++k) w = (w & ~(0xffull << (8u * k))) | ((uint64_t)src[my + k] << (8u * k));
+      b0 = (uint32_t)w;
+      b1 = (uint32_t)(w >> 32);
+    }
+    tileb[4u + tid * 2u] = b0;
+    tileb[5u + tid * 2u] = b1;
+    const uint32_t e0 = ~b0 & 0x80808080u, e1 = ~b1 & 0x80808080u;
+    // bit j of `ends` = byte j ends a token
+    const uint32_t ends = (((e0 >> 7) * 0x00204081u) >> 21 & 0xfu) | ((((e1 >> 7) * 0x00204081u) >> 21 & 0xfu) << 4);
+    uint32_t n_tile;
+    const uint32_t tb = block_exclusive_scan<T>((uint32_t)__builtin_popcount(ends), misc + 2, &n_tile);  // has a barrier
+    const uint32_t seen = pts_done * n_ops;  // tokens handed to points so far
+
+    // ---- tokens ending in my bytes
+    for (uint32_t m = ends, r = 0u; m; m &= m - 1u, ++r) {
+      const uint32_t j = (uint32_t)__builtin_ctz(m);
+      const uint32_t kl = left + tb + r;   // index in val[]
+      if (seen + kl >= target) break;      // section bytes from here on
+      const uint32_t e = 16u + tid * 8u + j;           // byte index of the token's last byte in tileb
+      const uint32_t w0 = e - 7u;                      // window [w0, e]
+      const uint32_t d0 = tileb[w0 >> 2], d1 = tileb[(w0 >> 2) + 1u], d2 = tileb[(w0 >> 2) + 2u];
+      const uint32_t sh = (w0 & 3u) * 8u;
+      const uint32_t lo = sh ? ((d0 >> sh) | (d1 << (32u - sh))) : d0;
+      const uint32_t hi = sh ? ((d1 >> sh) | (d2 << (32u - sh))) : d1;
+      // continuation bytes right before the end byte (window bytes 6, 5, ...)
+      const uint32_t c_lo = lo & 0x80808080u, c_hi = hi & 0x00808080u;
+      const uint32_t cm = (((c_lo >> 7) * 0x00204081u) >> 21 & 0xfu) | ((((c_hi >> 7) * 0x00204081u) >> 21 & 0x7u) << 4);
+      const uint32_t lencont = (uint32_t)__builtin_clz(~(cm << 25));  // leading ones of the 7-bit mask
+      if (lencont >= 7u) {
+        misc[0] = 1u;  // token of 8 or more bytes
+        continue;
+      }
+      uint64_t x = ((((uint64_t)hi) << 32) | lo) >> (8u * (7u - lencont));
+      x &= 0x7f7f7f7f7f7f7f7full;
+      x = (x & 0x007f007f007f007full) | ((x & 0x7f007f007f007f00ull) >> 1);
+      x = (x & 0x00003fff00003fffull) | ((x & 0x3fff00003fff0000ull) >> 2);
+      x = (x & 0x000000000fffffffull) | ((x & 0x0fffffff00000000ull) >> 4);
+      const bool marker = (x == 0ull);
+      const uint64_t u1 = x - 1ull;
+      const uint64_t d = (u1 >> 1) ^ (0ull - (u1 & 1ull));
+      val[kl] = marker ? (Acc)0 : (Acc)(UAcc)d;
+      mark[kl] = marker ? 1u : 0u;
+      if (seen + kl + 1u == target) misc[1] = pos + tid * 8u + j + 1u;
+    }
+    __syncthreads();
+
+    // ---- whole points of this tile
+    const uint32_t avail = min(left + n_tile, target - seen);
+    const uint32_t npts = avail / n_ops;
+    const uint32_t per = (npts + T - 1u) / T;
+    const uint32_t p0 = min(npts, tid * per), p1 = min(npts, p0 + per);
+    Acc acc[NOPS];
+    uint32_t fl = 0u;
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) acc[o] = 0;
+    for (uint32_t i = p0; i < p1; ++i) {
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) {
+        if ((uint32_t)o < n_ops) {
+          const uint32_t idx = i * n_ops + (uint32_t)o;
+          if (mark[idx]) {
+            acc[o] = 0;
+            fl |= 1u << o;
+            if (plan.ops[o].kind == OP_INT) misc[0] = 1u;  // the marker is not a valid integer token
+          } else {
+            acc[o] = (Acc)((UAcc)acc[o] + (UAcc)val[idx]);
+          }
+        }
+      }
+    }
+    // segmented inclusive scan over the threads: (f1, v1) o (f2, v2) = (f1 | f2, f2 ? v2 : v1 + v2)
+    Acc inc[NOPS];
+    uint32_t fin = fl;
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) inc[o] = acc[o];
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const uint32_t of = (uint32_t)__shfl_up((int)fin, dlt);
+      Acc ov[NOPS];
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) {
+        if (WIDE) ov[o] = (Acc)__shfl_up((long long)inc[o], dlt);
+        else ov[o] = (Acc)__shfl_up((int)inc[o], dlt);
+      }
+      if (lane >= (uint32_t)dlt) {
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o)
+          if (!(fin & (1u << o))) inc[o] = (Acc)((UAcc)inc[o] + (UAcc)ov[o]);
+        fin |= of;
+      }
+    }
+    if (lane == 63u) {
+      Acc* rec = reinterpret_cast<Acc*>(scanrec + wave * L::kWaveRec);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) rec[o] = inc[o];
+      *reinterpret_cast<uint32_t*>(scanrec + wave * L::kWaveRec + NOPS * sizeof(Acc)) = fin;
+    }
+    __syncthreads();
+    // incoming state of this thread = carry o waves before o lanes before
+    Acc in[NOPS];
+    uint32_t inf;
+    {
+      const Acc* crec = reinterpret_cast<const Acc*>(scanrec + 16u * L::kWaveRec);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) in[o] = crec[o];
+      inf = 0u;  // a reset in earlier tiles is already folded into the carried sums
+      for (uint32_t w = 0; w < wave; ++w) {
+        const Acc* rec = reinterpret_cast<const Acc*>(scanrec + w * L::kWaveRec);
+        const uint32_t rf = *reinterpret_cast<const uint32_t*>(scanrec + w * L::kWaveRec + NOPS * sizeof(Acc));
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) in[o] = (rf & (1u << o)) ? rec[o] : (Acc)((UAcc)in[o] + (UAcc)rec[o]);
+      }
+      // exclusive within the wave: the inclusive state of the previous lane
+      const uint32_t pf = (uint32_t)__shfl_up((int)fin, 1);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) {
+        Acc pv;
+        if (WIDE) pv = (Acc)__shfl_up((long long)inc[o], 1);
+        else pv = (Acc)__shfl_up((int)inc[o], 1);
+        if (lane > 0u) in[o] = (pf & (1u << o)) ? pv : (Acc)((UAcc)in[o] + (UAcc)pv);
+      }
+      (void)inf;
+    }
+    // second walk: final values
+    for (uint32_t i = p0; i < p1; ++i) {
+      uint8_t* pt = base + (size_t)(pts_done + i) * step;
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) {
+        if ((uint32_t)o < n_ops) {
+          const DevOp& op = plan.ops[o];
+          const uint32_t idx = i * n_ops + (uint32_t)o;
+          const bool isnan = mark[idx] != 0u;
+          in[o] = isnan ? (Acc)0 : (Acc)((UAcc)in[o] + (UAcc)val[idx]);
+          if (op.offset != 0xffffffffu) {
+            if (op.kind == OP_QF32) {
+              const uint32_t bits = isnan ? 0x7fc00000u : __float_as_uint(__fmul_rn((float)(int32_t)in[o], op.res_f));
+              if ((op.offset & 3u) == 0u && (step & 3u) == 0u) *reinterpret_cast<uint32_t*>(pt + op.offset) = bits;
+              else st_raw(pt + op.offset, bits, 4);
+            } else if (op.kind == OP_LOSSY_F32) {
+              const uint32_t bits = isnan ? 0x7fc00000u : __float_as_uint(__fmul_rn((float)(long long)in[o], op.res_f));
+              st_raw(pt + op.offset, bits, 4);
+            } else if (op.kind == OP_LOSSY_F64) {
+              const uint64_t bits = isnan ? 0x7ff8000000000000ull
+                                          : (uint64_t)__double_as_longlong(__dmul_rn((double)(long long)in[o], op.res_d));
+              st_raw(pt + op.offset, bits, 8);
+            } else {
+              st_raw(pt + op.offset, (uint64_t)(long long)in[o], op.size);
+            }
+          }
+        }
+      }
+    }
+    // block state after this tile -> carry; the cut point's tokens and the last 16 bytes move to the front
+    const uint32_t used = npts * n_ops;
+    const uint32_t rest = avail - used;  // < n_ops <= 8
+    Acc mv = 0;
+    uint8_t mm = 0;
+    if (tid < rest) {
+      mv = val[used + tid];
+      mm = mark[used + tid];
+    }
+    uint32_t hist = 0u;
+    if (tid < 4u) hist = tileb[4u + (uint32_t)T * 2u - 4u + tid];
+    __syncthreads();
+    if (tid == (uint32_t)T - 1u) {  // the last thread's inclusive state is the block total
+      Acc* crec = reinterpret_cast<Acc*>(scanrec + 16u * L::kWaveRec);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) crec[o] = in[o];
+    }
+    if (tid < rest) {
+      val[tid] = mv;
+      mark[tid] = mm;
+    }
+    if (tid < 4u) tileb[tid] = hist;
+    __syncthreads();
+    pos += kDvTileBytes;
+    pts_done += npts;
+    left = rest;
+    if (misc[0]) break;  // uniform after the barrier
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t re = misc[1];
+    if (target == 0u) re = 0u;
+    reg_end[c] = (misc[0] || re == 0xffffffffu) ? kDecRedo : re;
+  }
 }
 
 }  // namespace cldn

@@ -52,6 +52,7 @@ struct DecodeLaunch {
   uint32_t n_clouds;
   uint32_t n_chunks;
   void* chunks;                       // device [n_chunks] DecChunk (48 bytes each)
+  uint32_t* reg_end;                  // device [n_chunks]: end of the regular stream per chunk (fast path)
   uint8_t* out;                       // device: decoded AoS points
   uint32_t* status;
 };

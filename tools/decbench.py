@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Decode timing (device resident): C5-like 10M-pt XYZ cloud and 32 x 1M-pt XYZI batch."""
+import sys, os, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from cloudini_amd import native, synth
+
+dev = torch.device("cuda", 0)
+for name, (info, data), n_clouds in (("c5 xyz 10M", synth.lidar_xyz(10_000_000), 1), ("c2 xyzi 32x1M", synth.lidar_xyzi(1_000_000), 32)):
+    plan = native.Plan(info)
+    codec = native.Codec(plan, device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    step = info.point_step
+    n = data.size // step
+    host = np.concatenate([data] * n_clouds)
+    d_points = torch.from_numpy(host).to(dev)
+    cloud_points = np.full(n_clouds, n, dtype=np.uint64)
+    cap = plan.stage1_bound(n) * n_clouds
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(n_clouds + 1, dtype=torch.int64, device=dev)
+    codec.encode_device(d_points.data_ptr(), cloud_points, d_out.data_ptr(), cap, d_off.data_ptr(), 0, 0)
+    torch.cuda.synchronize()
+    offs = d_off.cpu().numpy().astype(np.uint64)
+    d_dec = torch.zeros(host.size, dtype=torch.uint8, device=dev)
+    for it in range(3):
+        codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for it in range(reps):
+        codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    codec.status()
+    print(f"{name}: decode {dt*1e3:.3f} ms -> {n*n_clouds/dt/1e6:.0f} Mpoints/s, stream {int(offs[-1])/1e6:.1f} MB")
+    codec.close()
