@@ -206,6 +206,28 @@ def main():
             reg_bpp = (len(fo_stream) - 4 * n_ch) / pts_per_cloud
         alg_bytes = points_per_step * (step + reg_bpp)
         achieved = alg_bytes / (regular_ms * 1e-3) / 1e9
+        # the regular-stream kernel of this plan: k_encode_floatn when the stream is exactly one fused FloatN encoder
+        lead = 0
+        for f in info.fields:
+            if int(f.type) == 7 and f.resolution is not None:
+                lead += 1
+            else:
+                break
+        rest_adaptive = all(int(f.type) in (3, 4, 5, 6, 9, 10) for f in info.fields[lead:])
+        dominant = "k_encode_floatn" if lead in (3, 4) and rest_adaptive and int(info.version) >= 5 else "k_encode_regular"
+        # HBM bytes per launch of the same kernel from the PMC passes of tools/profile_round.sh (rocprofv3 cannot
+        # collect counters from inside this process); only quoted when the committed pass ran this very workload
+        traffic, traffic_src = None, None
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+            if name.endswith("_traffic.json"):
+                try:
+                    t = json.load(open(os.path.join(ROOT, "profiles", name)))
+                except (OSError, ValueError):
+                    continue
+                if (t.get("workload") == args.workload and t.get("clouds_per_gpu") == n_clouds
+                        and t.get("points_per_cloud") == pts_per_cloud):
+                    traffic, traffic_src = float(t["hbm_bytes_per_launch"]), "profiles/" + name
+                    break
         result = {
             "metric": "encode Mpoints/s (stage-1, pre-ZSTD)",
             "value": mpts,
@@ -225,10 +247,11 @@ def main():
                        "parallelism": f"whole clouds sharded over {world} GPU(s), no data-path collective"},
             "input_MBps": total_points_all * step * args.steps / elapsed / 1e6,
             "stage1_bytes_per_point": out_bpp,
-            "device_ms_per_step": {"k_encode_regular": regular_ms, "sections": sections_ms,
+            "device_ms_per_step": {dominant: regular_ms, "sections": sections_ms,
                                    "offsets+compact": compact_ms, "all_kernels": device_ms},
-            "roofline": {"bound": "hbm", "kernel": "k_encode_regular", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "read_only_GBps": points_per_step * step / (regular_ms * 1e-3) / 1e9,
                          "whole_stage1_GBps": points_per_step * (step + out_bpp) / (device_ms * 1e-3) / 1e9},

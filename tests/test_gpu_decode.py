@@ -84,3 +84,94 @@ def test_malformed_streams_are_rejected(oracle, mutation):
     with pytest.raises(Exception):
         oracle.decode_stage1(info, s, n)
     codec.close()
+
+
+def _reframe(payloads):
+    out = []
+    for p in payloads:
+        out.append(np.frombuffer(np.uint32(len(p)).tobytes(), np.uint8))
+        out.append(p)
+    return np.concatenate(out)
+
+
+def _split_chunks(stream):
+    pos, res = 0, []
+    while pos < len(stream):
+        size = int(np.frombuffer(stream[pos:pos + 4].tobytes(), "<u4")[0])
+        res.append(stream[pos + 4:pos + 4 + size].copy())
+        pos += 4 + size
+    return res
+
+
+def _overlong(token, total_len):
+    """The same varint value padded with zero-payload continuation groups to `total_len` bytes (decodeVarint,
+    encoding_utils.hpp:98-148, accepts non-canonical encodings)."""
+    t = list(token)
+    t[-1] |= 0x80
+    t += [0x80] * (total_len - len(t) - 1) + [0x00]
+    return np.array(t, dtype=np.uint8)
+
+
+@pytest.mark.parametrize("pad_to", [5, 7, 8, 9, 10])
+def test_overlong_tokens_decode_like_the_reference(oracle, pad_to):
+    """Tokens longer than the parallel decoder's 7-byte window (legal, non-canonical varints) must come out the
+    same: those chunks fall back to the serial decoder. Shorter paddings stay on the parallel path."""
+    from cloudini_amd import native
+    info, data = synth.lidar_xyz(70000, seed=5)
+    chunks = _split_chunks(oracle.encode_stage1(info, data))
+    rs = np.random.RandomState(pad_to)
+    new_chunks = []
+    for ci, ch in enumerate(chunks):
+        ends = np.nonzero((ch & 0x80) == 0)[0]
+        starts = np.concatenate([[0], ends[:-1] + 1])
+        pick = set(rs.choice(len(ends), 25, replace=False).tolist()) if ci != 1 else set()  # chunk 1 stays canonical
+        parts = []
+        for k, (a, b) in enumerate(zip(starts, ends)):
+            tok = ch[a:b + 1]
+            if k in pick and tok[0] != 0 and len(tok) < pad_to:
+                parts.append(_overlong(tok, pad_to))
+            else:
+                parts.append(tok)
+        new_chunks.append(np.concatenate(parts))
+    s = _reframe(new_chunks)
+    n = 70000
+    want = oracle.decode_stage1(info, s, n, fill=0x11)
+    codec = native.Codec(native.Plan(info))
+    out = np.full(n * info.point_step, 0x11, dtype=np.uint8)
+    got = codec.decode_host([s], [n], out=out)[0]
+    assert np.array_equal(got, want)
+    # and it still is the original cloud's decode
+    assert np.array_equal(want, oracle.decode_stage1(info, oracle.encode_stage1(info, data), n, fill=0x11))
+    codec.close()
+
+
+def test_marker_inside_integer_token_stream_is_rejected(oracle):
+    """V4 wire with an integer field: a 0x00 byte where an integer varint is expected is corrupt data
+    (decodeVarint rejects value 0); the parallel path must hand the chunk to the serial checks."""
+    from cloudini_amd import native
+    from cloudini_amd.schema import FieldType as F
+    n = 5000
+    rs = np.random.RandomState(8)
+    fields = [("u", 0, F.FLOAT32, 0.01), ("v", 4, F.FLOAT32, 0.01), ("a16", 8, F.INT16, None), ("e16", 10, F.UINT16, None)]
+    info = cases.make_info(fields, 12, n, version=4)
+    data = cases.pack(info, {"u": rs.uniform(0, 9, n).astype(np.float32), "v": rs.uniform(0, 9, n).astype(np.float32),
+                             "a16": rs.randint(-300, 300, n).astype(np.int16),
+                             "e16": rs.randint(0, 65536, n).astype(np.uint16)}, n)
+    s = oracle.encode_stage1(info, data).copy()
+    plan = native.Plan(info)
+    ch = _split_chunks(s)[0]
+    ends = np.nonzero((ch & 0x80) == 0)[0]
+    assert len(ends) % n == 0 and len(ends) // n == 4  # two scalar floats + two integers, all varint tokens
+    tpp = len(ends) // n
+    # last token of point 100 belongs to the last (integer) field
+    k = 100 * tpp + (tpp - 1)
+    a = 0 if k == 0 else ends[k - 1] + 1
+    bad = np.concatenate([ch[:a], np.zeros(1, np.uint8), ch[ends[k] + 1:]])
+    s2 = _reframe([bad])
+    codec = native.Codec(plan)
+    with pytest.raises(native.CloudiniHipError) as e:
+        codec.decode_host([s2], [n])
+    assert e.value.code == -6
+    with pytest.raises(Exception):
+        oracle.decode_stage1(info, s2, n)
+    codec.close()
