@@ -704,6 +704,17 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   return CLDN_HIP_OK;
 }
 
+int cldn_hip_codec_decode_stats(cldn_hip_codec_t* c, uint32_t stats[4]) {
+  if (!c || !stats) return fail(CLDN_HIP_ERR_ARG, "decode_stats: NULL argument");
+  memset(stats, 0, 4 * sizeof(uint32_t));
+  if (!c->d_status.p) return CLDN_HIP_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(stats, (const uint32_t*)c->d_status.p + 8, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                         c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return CLDN_HIP_OK;
+}
+
 int cldn_hip_codec_force_modes(cldn_hip_codec_t* c, const uint8_t* modes, uint32_t n_modes) {
   if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
   if (!modes || n_modes == 0) {
@@ -771,7 +782,7 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams
   h_fp[n_clouds] = fp;
   h_fc[n_clouds] = fc;
   const size_t chunk_table_bytes = ((size_t)std::max(1u, n_chunks) * kDecChunkBytes + 63) & ~size_t(63);
-  if ((rc = c->d_dec_meta.ensure(((table_bytes + 63) & ~size_t(63)) + chunk_table_bytes + (size_t)std::max(1u, n_chunks) * 4u)) != CLDN_HIP_OK)
+  if ((rc = c->d_dec_meta.ensure(((table_bytes + 63) & ~size_t(63)) + chunk_table_bytes + (size_t)std::max(1u, n_chunks) * 5u)) != CLDN_HIP_OK)
     return rc;
   c->last_cloud_points.clear();  // the staging buffer no longer holds the encode chunk table
   uint8_t* meta = (uint8_t*)c->d_dec_meta.p;
@@ -808,6 +819,7 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams
   L.n_chunks = n_chunks;
   L.chunks = meta + ((table_bytes + 63) & ~size_t(63));
   L.reg_end = (uint32_t*)(meta + ((table_bytes + 63) & ~size_t(63)) + chunk_table_bytes);
+  L.sec_done = (uint8_t*)(L.reg_end + std::max(1u, n_chunks));
   L.out = d_outp;
   L.status = (uint32_t*)c->d_status.p;
   if ((rc = stage1_launch_decode(L)) != CLDN_HIP_OK) return rc;

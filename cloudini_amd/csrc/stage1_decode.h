@@ -16,6 +16,10 @@
 
 namespace cldn {
 
+// decode statistics behind the status word (uint32 indexes into the codec's status buffer): chunks whose regular
+// stream / sections went through the parallel kernels, and chunks / section sets the serial kernel had to do
+constexpr uint32_t kStatFastRegular = 8, kStatFastSections = 9, kStatSerialChunks = 10, kStatSerialSections = 11;
+
 struct DecChunk {
   uint64_t src_off;   // offset of the payload inside the batch's stream buffer
   uint32_t src_size;  // payload bytes
@@ -188,10 +192,12 @@ __device__ void decode_section_serial(Rd& r, uint8_t* base, uint32_t step, uint3
 __global__ __launch_bounds__(64) void k_decode_general(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                        const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
                                                        uint32_t uses_v5, uint32_t only_sections,
-                                                       const uint32_t* __restrict__ reg_end, uint32_t* __restrict__ status) {
+                                                       const uint32_t* __restrict__ reg_end,
+                                                       const uint8_t* __restrict__ sec_done, uint32_t* __restrict__ status) {
   if (threadIdx.x != 0) return;
   const DecChunk dc = chunks[blockIdx.x];
   if (!dc.valid) return;
+  if (sec_done && sec_done[blockIdx.x]) return;  // regular stream and sections were decoded by the parallel kernels
   const uint32_t step = plan.point_step;
   uint8_t* base = out + (size_t)dc.first_point * step;
   Rd r;
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(64) void k_decode_general(const DevPlan plan, const
       if (!uses_v5) return;    // V4 wire: nothing behind the regular stream
     }
   }
+  atomicAdd(&status[regular_done ? kStatSerialSections : kStatSerialChunks], 1u);
   if (!regular_done) {
     int64_t prev[kMaxOps];
     uint8_t gor_lead[kMaxOps], gor_trail[kMaxOps];
@@ -357,25 +364,103 @@ __global__ __launch_bounds__(64) void k_decode_general(const DevPlan plan, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_decode_varint<NOPS, WIDE>: the regular stream of one chunk by one workgroup, for plans whose regular ops are all
-// varint-coded (FloatN lanes, Float_Lossy scalars, V4 integer fields) and number at most NOPS per point.
+// Parallel decode of varint token streams.
 //
-//   tile = 8 bytes per thread. End-of-token flags (MSB clear; the NaN marker 0x00 included) -> one block scan gives
-//   every thread the index of its first token; the tokens ending inside a thread's 8 bytes are consecutive, and the
-//   thread rebuilds each from the 8-byte window that ends at the token's last byte (tokens of more than 7 bytes
-//   send the chunk to k_decode_general). Token values are staged in LDS in token order; then every thread takes a
-//   run of whole points: local sums per op with NaN resets -> segmented block scan -> second walk that adds the
-//   incoming value, converts and stores (FieldDecoderFloatN_Lossy::decode, src/field_decoder.cpp:43-86;
-//   FieldDecoderFloat_Lossy / FieldDecoderInt, include/cloudini_lib/field_decoder.hpp:330-353, :79-106).
-//   Tokens of a point cut by the tile edge wait at the front of the LDS buffer for the next tile.
+//   dv_tokens_tile    one tile = 8 bytes per thread. End-of-token flags (MSB clear; the NaN marker 0x00 included) ->
+//                     one block scan gives every thread the index of its first token; the tokens ending inside a
+//                     thread's 8 bytes are consecutive, and the thread rebuilds each from the 8-byte window that ends
+//                     at the token's last byte (tokens of more than 7 bytes flag the chunk for the serial decoder).
+//   dv_stream         regular stream / DeltaVarint section: token values staged in LDS in token order; every thread
+//                     then takes a run of whole points: local sums per op with NaN resets -> segmented block scan ->
+//                     second walk that adds the incoming value, converts and stores (FieldDecoderFloatN_Lossy::decode,
+//                     src/field_decoder.cpp:43-86; FieldDecoderFloat_Lossy / FieldDecoderInt,
+//                     include/cloudini_lib/field_decoder.hpp:330-353, :79-106). Tokens of a point cut by the tile
+//                     edge wait at the front of the LDS buffer for the next tile.
+//   k_decode_varint   dv_stream over the regular stream of plans whose regular ops are all varint-coded (<= 8 per point)
+//   k_decode_sections the V5 adaptive-int sections of a chunk, field after field (decodeV5AdaptiveIntSection,
+//                     src/v5_codec.cpp:764-879): DeltaVarint = dv_stream with one integer op; Palette = 32 indexes per
+//                     thread; DeltaRle = (diff, run) token pairs -> run table in LDS (two block scans) -> every output
+//                     finds its run by binary search; Rle = one lane parses the runs from an LDS copy of the bytes,
+//                     then the same fill.
 //
-// reg_end[c] receives the offset of the first byte behind the regular stream (= first section byte for V5), or
-// kDecRedo when anything looked irregular; k_decode_general then decodes that chunk from scratch, so all error
-// reporting stays with the restatement of the reference's checks.
+// reg_end[c] = offset of the first byte behind the regular stream, or kDecRedo when anything looked irregular;
+// sec_done[c] = 1 when all sections were decoded here. k_decode_general redoes whatever is left (whole chunks or
+// their sections), so all error reporting stays with the restatement of the reference's checks.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kDecRedo = 0xfffffffeu;
 constexpr int kDvThreads = 1024;
 constexpr uint32_t kDvTileBytes = kDvThreads * 8u;
+
+// tokens ending in this thread's 8 bytes of the tile at payload offset `pos`. tileb: [16 history bytes + tile].
+// store(kl, x, end_off): kl = index behind the `left` waiting tokens, x = the token's 7-bit groups joined (< 2^49),
+// end_off = payload offset behind the token. Tokens with a global index >= `limit` are left alone. Returns the
+// number of tokens ending in the tile (block-uniform). Contains barriers.
+template <typename Store>
+__device__ __forceinline__ uint32_t dv_tokens_tile(const uint8_t* __restrict__ src, uint32_t src_size, uint32_t pos,
+                                                   uint32_t* tileb, uint32_t* misc, uint32_t left, uint32_t seen,
+                                                   uint32_t limit, Store store) {
+  constexpr int T = kDvThreads;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t my = pos + tid * 8u;
+  uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu;  // past the end: continuation bytes, no token ends
+  if (my + 8u <= src_size) {
+    const uint8_t* q = src + my;
+    if ((((uintptr_t)q) & 3u) == 0u) {
+      b0 = reinterpret_cast<const uint32_t*>(q)[0];
+      b1 = reinterpret_cast<const uint32_t*>(q)[1];
+    } else {
+      b0 = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+      b1 = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
+    }
+  } else if (my < src_size) {
+    uint64_t w = ~0ull;
+    for (uint32_t k = 0; k < src_size - my; ++k) w = (w & ~(0xffull << (8u * k))) | ((uint64_t)src[my + k] << (8u * k));
+    b0 = (uint32_t)w;
+    b1 = (uint32_t)(w >> 32);
+  }
+  tileb[4u + tid * 2u] = b0;
+  tileb[5u + tid * 2u] = b1;
+  const uint32_t e0 = ~b0 & 0x80808080u, e1 = ~b1 & 0x80808080u;
+  // bit j of `ends` = byte j ends a token (the multiply gathers bits 0, 8, 16, 24 into 21..24)
+  const uint32_t ends = (((e0 >> 7) * 0x00204081u) >> 21 & 0xfu) | ((((e1 >> 7) * 0x00204081u) >> 21 & 0xfu) << 4);
+  uint32_t n_tile;
+  const uint32_t tb = block_exclusive_scan<T>((uint32_t)__builtin_popcount(ends), misc + 2, &n_tile);  // has a barrier
+  for (uint32_t m = ends, r = 0u; m; m &= m - 1u, ++r) {
+    const uint32_t j = (uint32_t)__builtin_ctz(m);
+    const uint32_t kl = left + tb + r;
+    if (seen + kl >= limit) break;                   // bytes of whatever follows the token stream
+    const uint32_t e = 16u + tid * 8u + j;           // byte index of the token's last byte in tileb
+    const uint32_t w0 = e - 7u;                      // window [w0, e]
+    const uint32_t d0 = tileb[w0 >> 2], d1 = tileb[(w0 >> 2) + 1u], d2 = tileb[(w0 >> 2) + 2u];
+    const uint32_t sh = (w0 & 3u) * 8u;
+    const uint32_t lo = sh ? ((d0 >> sh) | (d1 << (32u - sh))) : d0;
+    const uint32_t hi = sh ? ((d1 >> sh) | (d2 << (32u - sh))) : d1;
+    // continuation bytes right before the end byte (window bytes 6, 5, ...)
+    const uint32_t c_lo = lo & 0x80808080u, c_hi = hi & 0x00808080u;
+    const uint32_t cm = (((c_lo >> 7) * 0x00204081u) >> 21 & 0xfu) | ((((c_hi >> 7) * 0x00204081u) >> 21 & 0x7u) << 4);
+    const uint32_t lencont = (uint32_t)__builtin_clz(~(cm << 25));  // leading ones of the 7-bit mask
+    if (lencont >= 7u) {
+      misc[0] = 1u;  // token of 8 or more bytes
+      continue;
+    }
+    uint64_t x = ((((uint64_t)hi) << 32) | lo) >> (8u * (7u - lencont));
+    x &= 0x7f7f7f7f7f7f7f7full;
+    x = (x & 0x007f007f007f007full) | ((x & 0x7f007f007f007f00ull) >> 1);
+    x = (x & 0x00003fff00003fffull) | ((x & 0x3fff00003fff0000ull) >> 2);
+    x = (x & 0x000000000fffffffull) | ((x & 0x0fffffff00000000ull) >> 4);
+    store(kl, x, pos + tid * 8u + j + 1u);
+  }
+  __syncthreads();
+  return n_tile;
+}
+
+// after a tile: the last 16 bytes become the history of the next one (barrier included)
+__device__ __forceinline__ void dv_roll_history(uint32_t* tileb) {
+  uint32_t hist = 0u;
+  if (threadIdx.x < 4u) hist = tileb[4u + (uint32_t)kDvThreads * 2u - 4u + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x < 4u) tileb[threadIdx.x] = hist;
+}
 
 template <int NOPS, bool WIDE>
 struct DvLds {
@@ -386,112 +471,57 @@ struct DvLds {
   static constexpr uint32_t kScanOff = (kMarkOff + 8u + kDvTileBytes + 15u) & ~15u;  // per wave: Acc[NOPS] + flags
   static constexpr uint32_t kWaveRec = NOPS * (uint32_t)sizeof(Acc) + 8u;
   static constexpr uint32_t kMiscOff = kScanOff + 17u * kWaveRec;           // 16 waves + carry record
-  static constexpr uint32_t kTotal = kMiscOff + 256u;  // misc: [0] bad, [1] reg_end, [2..34) block-scan scratch
+  static constexpr uint32_t kTotal = kMiscOff + 256u;  // misc: [0] bad, [1] end offset, [2..34) block-scan scratch
 };
 
-template <int NOPS, bool WIDE>
-__global__ __launch_bounds__(kDvThreads) void k_decode_varint(const DevPlan plan, const uint8_t* __restrict__ streams,
-                                                              const DecChunk* __restrict__ chunks,
-                                                              uint8_t* __restrict__ out, uint32_t* __restrict__ reg_end) {
+// One token stream of n_points x n_ops varint tokens that starts at src + start. Results: misc[0] != 0 -> irregular,
+// misc[1] = payload offset behind the last token. op_at(o) -> const DevOp&. Ends with a barrier.
+template <int NOPS, bool WIDE, typename OpAt>
+__device__ __forceinline__ void dv_stream(OpAt op_at, uint32_t n_ops, const uint8_t* __restrict__ src,
+                                          uint32_t src_size, uint32_t start, uint32_t n_points, uint8_t* base,
+                                          uint32_t step, uint8_t* smem) {
   using L = DvLds<NOPS, WIDE>;
   using Acc = typename L::Acc;
   using UAcc = typename std::make_unsigned<Acc>::type;
   constexpr int T = kDvThreads;
-  constexpr int NW = T / 64;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* tileb = reinterpret_cast<uint32_t*>(smem + L::kBytesOff);
   Acc* val = reinterpret_cast<Acc*>(smem + L::kValOff);
   uint8_t* mark = smem + L::kMarkOff;
   uint8_t* scanrec = smem + L::kScanOff;
-  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + L::kMiscOff);  // [0] bad, [1] reg_end, [2..] block scan scratch
-
-  const uint32_t c = blockIdx.x;
-  const DecChunk dc = chunks[c];
-  if (!dc.valid) return;
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + L::kMiscOff);
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t n_ops = plan.n_ops;
-  const uint32_t step = plan.point_step;
-  const uint8_t* src = streams + dc.src_off;
-  const uint32_t src_size = dc.src_size;
-  uint8_t* base = out + (size_t)dc.first_point * step;
-  const uint32_t target = dc.n_points * n_ops;  // tokens of the regular stream
+  const uint32_t target = n_points * n_ops;
 
-  if (tid < 4u) tileb[tid] = 0u;  // history before the payload: token ends
-  if (tid < 16u) misc[tid] = 0u;
-  if (tid == 0) misc[1] = 0xffffffffu;
+  __syncthreads();  // the caller may have used the LDS
+  if (tid < 4u) tileb[tid] = 0u;  // history before the stream: token ends
+  if (tid == 0) {
+    misc[0] = 0u;
+    misc[1] = target == 0u ? start : 0xffffffffu;
+  }
   if (tid < (uint32_t)(NOPS * sizeof(Acc) + 8u) / 4u)
-    reinterpret_cast<uint32_t*>(scanrec + 16u * L::kWaveRec)[tid] = 0u;  // carry record: sums 0, no reset
+    reinterpret_cast<uint32_t*>(scanrec + 16u * L::kWaveRec)[tid] = 0u;  // carry record: sums 0
   __syncthreads();
 
-  uint32_t pos = 0u;        // payload offset of the current tile
+  uint32_t pos = start;     // payload offset of the current tile
   uint32_t pts_done = 0u;   // points already written
   uint32_t left = 0u;       // tokens of a cut point waiting at val[0..left)
   while (pts_done * n_ops + left < target) {
-    if (pos >= src_size) {  // stream ends before all tokens: general kernel reports it
+    if (pos >= src_size) {  // stream ends before all tokens
       if (tid == 0) misc[0] = 1u;
       break;
     }
-    // ---- bytes, end flags, token indexes
-    const uint32_t my = pos + tid * 8u;
-    uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu;  // past the end: continuation bytes, no token ends
-    if (my + 8u <= src_size) {
-      const uint8_t* q = src + my;
-      if ((((uintptr_t)q) & 3u) == 0u) {
-        b0 = reinterpret_cast<const uint32_t*>(q)[0];
-        b1 = reinterpret_cast<const uint32_t*>(q)[1];
-      } else {
-        b0 = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
-        b1 = (uint32_t)q[4] | ((uint32_t)q[5] << 8) | ((uint32_t)q[6] << 16) | ((uint32_t)q[7] << 24);
-      }
-    } else if (my < src_size) {
-      uint64_t w = ~0ull;
-      for (uint32_t k = 0; k < src_size - my; ++k) w = (w & ~(0xffull << (8u * k))) | ((uint64_t)src[my + k] << (8u * k));
-      b0 = (uint32_t)w;
-      b1 = (uint32_t)(w >> 32);
-    }
-    tileb[4u + tid * 2u] = b0;
-    tileb[5u + tid * 2u] = b1;
-    const uint32_t e0 = ~b0 & 0x80808080u, e1 = ~b1 & 0x80808080u;
-    // bit j of `ends` = byte j ends a token
-    const uint32_t ends = (((e0 >> 7) * 0x00204081u) >> 21 & 0xfu) | ((((e1 >> 7) * 0x00204081u) >> 21 & 0xfu) << 4);
-    uint32_t n_tile;
-    const uint32_t tb = block_exclusive_scan<T>((uint32_t)__builtin_popcount(ends), misc + 2, &n_tile);  // has a barrier
     const uint32_t seen = pts_done * n_ops;  // tokens handed to points so far
-
-    // ---- tokens ending in my bytes
-    for (uint32_t m = ends, r = 0u; m; m &= m - 1u, ++r) {
-      const uint32_t j = (uint32_t)__builtin_ctz(m);
-      const uint32_t kl = left + tb + r;   // index in val[]
-      if (seen + kl >= target) break;      // section bytes from here on
-      const uint32_t e = 16u + tid * 8u + j;           // byte index of the token's last byte in tileb
-      const uint32_t w0 = e - 7u;                      // window [w0, e]
-      const uint32_t d0 = tileb[w0 >> 2], d1 = tileb[(w0 >> 2) + 1u], d2 = tileb[(w0 >> 2) + 2u];
-      const uint32_t sh = (w0 & 3u) * 8u;
-      const uint32_t lo = sh ? ((d0 >> sh) | (d1 << (32u - sh))) : d0;
-      const uint32_t hi = sh ? ((d1 >> sh) | (d2 << (32u - sh))) : d1;
-      // continuation bytes right before the end byte (window bytes 6, 5, ...)
-      const uint32_t c_lo = lo & 0x80808080u, c_hi = hi & 0x00808080u;
-      const uint32_t cm = (((c_lo >> 7) * 0x00204081u) >> 21 & 0xfu) | ((((c_hi >> 7) * 0x00204081u) >> 21 & 0x7u) << 4);
-      const uint32_t lencont = (uint32_t)__builtin_clz(~(cm << 25));  // leading ones of the 7-bit mask
-      if (lencont >= 7u) {
-        misc[0] = 1u;  // token of 8 or more bytes
-        continue;
-      }
-      uint64_t x = ((((uint64_t)hi) << 32) | lo) >> (8u * (7u - lencont));
-      x &= 0x7f7f7f7f7f7f7f7full;
-      x = (x & 0x007f007f007f007full) | ((x & 0x7f007f007f007f00ull) >> 1);
-      x = (x & 0x00003fff00003fffull) | ((x & 0x3fff00003fff0000ull) >> 2);
-      x = (x & 0x000000000fffffffull) | ((x & 0x0fffffff00000000ull) >> 4);
-      const bool marker = (x == 0ull);
-      const uint64_t u1 = x - 1ull;
-      const uint64_t d = (u1 >> 1) ^ (0ull - (u1 & 1ull));
-      val[kl] = marker ? (Acc)0 : (Acc)(UAcc)d;
-      mark[kl] = marker ? 1u : 0u;
-      if (seen + kl + 1u == target) misc[1] = pos + tid * 8u + j + 1u;
-    }
-    __syncthreads();
+    const uint32_t n_tile = dv_tokens_tile(src, src_size, pos, tileb, misc, left, seen, target,
+                                           [&](uint32_t kl, uint64_t x, uint32_t end_off) {
+                                             const bool marker = (x == 0ull);
+                                             const uint64_t u1 = x - 1ull;
+                                             const uint64_t d = (u1 >> 1) ^ (0ull - (u1 & 1ull));
+                                             val[kl] = marker ? (Acc)0 : (Acc)(UAcc)d;
+                                             mark[kl] = marker ? 1u : 0u;
+                                             if (seen + kl + 1u == target) misc[1] = end_off;
+                                           });
 
     // ---- whole points of this tile
     const uint32_t avail = min(left + n_tile, target - seen);
@@ -510,7 +540,7 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_varint(const DevPlan plan
           if (mark[idx]) {
             acc[o] = 0;
             fl |= 1u << o;
-            if (plan.ops[o].kind == OP_INT) misc[0] = 1u;  // the marker is not a valid integer token
+            if (op_at(o).kind == OP_INT) misc[0] = 1u;  // the marker is not a valid integer token
           } else {
             acc[o] = (Acc)((UAcc)acc[o] + (UAcc)val[idx]);
           }
@@ -547,12 +577,10 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_varint(const DevPlan plan
     __syncthreads();
     // incoming state of this thread = carry o waves before o lanes before
     Acc in[NOPS];
-    uint32_t inf;
     {
       const Acc* crec = reinterpret_cast<const Acc*>(scanrec + 16u * L::kWaveRec);
 #pragma unroll
       for (int o = 0; o < NOPS; ++o) in[o] = crec[o];
-      inf = 0u;  // a reset in earlier tiles is already folded into the carried sums
       for (uint32_t w = 0; w < wave; ++w) {
         const Acc* rec = reinterpret_cast<const Acc*>(scanrec + w * L::kWaveRec);
         const uint32_t rf = *reinterpret_cast<const uint32_t*>(scanrec + w * L::kWaveRec + NOPS * sizeof(Acc));
@@ -568,7 +596,6 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_varint(const DevPlan plan
         else pv = (Acc)__shfl_up((int)inc[o], 1);
         if (lane > 0u) in[o] = (pf & (1u << o)) ? pv : (Acc)((UAcc)in[o] + (UAcc)pv);
       }
-      (void)inf;
     }
     // second walk: final values
     for (uint32_t i = p0; i < p1; ++i) {
@@ -576,7 +603,7 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_varint(const DevPlan plan
 #pragma unroll
       for (int o = 0; o < NOPS; ++o) {
         if ((uint32_t)o < n_ops) {
-          const DevOp& op = plan.ops[o];
+          const DevOp& op = op_at(o);
           const uint32_t idx = i * n_ops + (uint32_t)o;
           const bool isnan = mark[idx] != 0u;
           in[o] = isnan ? (Acc)0 : (Acc)((UAcc)in[o] + (UAcc)val[idx]);
@@ -608,9 +635,7 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_varint(const DevPlan plan
       mv = val[used + tid];
       mm = mark[used + tid];
     }
-    uint32_t hist = 0u;
-    if (tid < 4u) hist = tileb[4u + (uint32_t)T * 2u - 4u + tid];
-    __syncthreads();
+    dv_roll_history(tileb);  // barrier inside: every thread is done with val / mark / scanrec
     if (tid == (uint32_t)T - 1u) {  // the last thread's inclusive state is the block total
       Acc* crec = reinterpret_cast<Acc*>(scanrec + 16u * L::kWaveRec);
 #pragma unroll
@@ -620,7 +645,6 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_varint(const DevPlan plan
       val[tid] = mv;
       mark[tid] = mm;
     }
-    if (tid < 4u) tileb[tid] = hist;
     __syncthreads();
     pos += kDvTileBytes;
     pts_done += npts;
@@ -628,10 +652,318 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_varint(const DevPlan plan
     if (misc[0]) break;  // uniform after the barrier
   }
   __syncthreads();
-  if (tid == 0) {
-    uint32_t re = misc[1];
-    if (target == 0u) re = 0u;
-    reg_end[c] = (misc[0] || re == 0xffffffffu) ? kDecRedo : re;
+}
+
+template <int NOPS, bool WIDE>
+__global__ __launch_bounds__(kDvThreads) void k_decode_varint(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                              const DecChunk* __restrict__ chunks,
+                                                              uint8_t* __restrict__ out, uint32_t* __restrict__ reg_end,
+                                                              uint32_t* __restrict__ status) {
+  using L = DvLds<NOPS, WIDE>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t c = blockIdx.x;
+  const DecChunk dc = chunks[c];
+  if (!dc.valid) return;
+  uint8_t* base = out + (size_t)dc.first_point * plan.point_step;
+  dv_stream<NOPS, WIDE>([&](int o) -> const DevOp& { return plan.ops[o]; }, plan.n_ops, streams + dc.src_off,
+                        dc.src_size, 0u, dc.n_points, base, plan.point_step, smem);
+  const uint32_t* misc = reinterpret_cast<const uint32_t*>(smem + L::kMiscOff);
+  if (threadIdx.x == 0) {
+    const bool redo = misc[0] || misc[1] == 0xffffffffu;
+    reg_end[c] = redo ? kDecRedo : misc[1];
+    if (!redo) atomicAdd(&status[kStatFastRegular], 1u);
+  }
+}
+
+// ---- sections -------------------------------------------------------------------------------------------------
+constexpr uint32_t kRunTile = 4096;     // DeltaRle: runs per table tile (8192 tokens)
+constexpr uint32_t kRleRunTile = 2048;  // Rle: runs parsed per round
+constexpr uint32_t kRleStage = 16384;   // Rle: section bytes staged per round
+struct DecSecLds {  // the DvLds<1, true> layout (DeltaVarint uses it as is) + a run-start table behind it
+  using DL = DvLds<1, true>;
+  static constexpr uint32_t kRawOff = DL::kValOff;                      // u64 [8 + 8192]: token values, then run table
+  static constexpr uint32_t kStageOff = kRawOff + 2u * kRleRunTile * 8u;  // Rle: staged bytes behind its run table
+  static constexpr uint32_t kStartOff = DL::kTotal;                     // u32 [kRunTile + 4]
+  static constexpr uint32_t kTotal = kStartOff + (kRunTile + 4u) * 4u;
+  static_assert(kStageOff + kRleStage + 16u <= DL::kMarkOff + 8u + kDvTileBytes, "Rle staging fits the token area");
+};
+
+template <int T>
+__device__ __forceinline__ uint64_t block_exclusive_scan_u64(uint64_t x, uint64_t* wtot, uint64_t* total) {
+  constexpr int NW = T / 64;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint64_t incl = x;
+#pragma unroll
+  for (int dlt = 1; dlt < 64; dlt <<= 1) {
+    const uint64_t o = (uint64_t)__shfl_up((long long)incl, dlt);
+    if (lane >= (uint32_t)dlt) incl += o;
+  }
+  if (lane == 63u) wtot[wave] = incl;
+  __syncthreads();
+  uint64_t basev = 0u, tot = 0u;
+  for (uint32_t w = 0; w < (uint32_t)NW; ++w) {
+    const uint64_t t = wtot[w];
+    if (w < wave) basev += t;
+    tot += t;
+  }
+  *total = tot;
+  return basev + incl - x;
+}
+
+// every output index of [s0, s1) finds its run r in start[0..n_runs] (start[n_runs] = s1) and stores
+// tab[2r] + tab[2r+1] * (i - start[r] + 1)   (DeltaRle, v5_codec.cpp:851-872; Rle has tab[2r+1] = 0)
+__device__ __forceinline__ void fill_runs(const uint32_t* start, const uint64_t* tab, uint32_t n_runs, uint32_t s0,
+                                          uint32_t s1, uint8_t* base, uint32_t step, uint32_t field_off, uint32_t bpv) {
+  for (uint32_t i = s0 + threadIdx.x; i < s1; i += kDvThreads) {
+    uint32_t lo = 0u, hi = n_runs;  // last r in [0, n_runs) with start[r] <= i (skips empty runs)
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (start[mid] <= i) lo = mid;
+      else hi = mid;
+    }
+    const uint64_t v = tab[2u * lo] + tab[2u * lo + 1u] * (uint64_t)(i - start[lo] + 1u);
+    st_raw(base + (size_t)i * step + field_off, v, bpv);
+  }
+}
+
+__global__ __launch_bounds__(kDvThreads) void k_decode_sections(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                                const DecChunk* __restrict__ chunks,
+                                                                uint8_t* __restrict__ out,
+                                                                const uint32_t* __restrict__ reg_end,
+                                                                uint8_t* __restrict__ sec_done,
+                                                                uint32_t* __restrict__ status) {
+  using DL = DvLds<1, true>;
+  constexpr int T = kDvThreads;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + DL::kMiscOff);  // [0] bad, [1] end, [2..34) scan, [40..48) handlers
+  uint32_t* tileb = reinterpret_cast<uint32_t*>(smem + DL::kBytesOff);
+  uint64_t* raw = reinterpret_cast<uint64_t*>(smem + DecSecLds::kRawOff);
+  uint32_t* start = reinterpret_cast<uint32_t*>(smem + DecSecLds::kStartOff);
+  uint64_t* scan64 = reinterpret_cast<uint64_t*>(smem + DL::kScanOff);  // 16 wave totals
+  const uint32_t c = blockIdx.x;
+  const DecChunk dc = chunks[c];
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) sec_done[c] = 0u;
+  if (!dc.valid) return;
+  uint32_t off = reg_end[c];
+  if (off == kDecRedo || off > dc.src_size) return;  // the serial decoder owns this chunk
+  const uint32_t n = dc.n_points;
+  const uint32_t step = plan.point_step;
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t src_size = dc.src_size;
+  uint8_t* base = out + (size_t)dc.first_point * step;
+  bool bad = false;  // block-uniform throughout
+
+  for (uint32_t a = 0; a < plan.n_adaptive && !bad; ++a) {
+    const uint32_t field_off = plan.adaptive[a].offset, bpv = plan.adaptive[a].bpv;
+    if (off >= src_size) { bad = true; break; }
+    const uint32_t mode = src[off];
+    ++off;
+    if (mode == 0u) {  // ---- DeltaVarint: n integer tokens
+      DevOp op;
+      op.kind = OP_INT;
+      op.size = (uint8_t)bpv;
+      op.offset = field_off;
+      dv_stream<1, true>([&](int) -> const DevOp& { return op; }, 1u, src, src_size, off, n, base, step, smem);
+      if (misc[0] || misc[1] == 0xffffffffu) bad = true;
+      else off = misc[1];
+      __syncthreads();
+    } else if (mode == 1u) {  // ---- Palette
+      if (src_size - off < 2u) { bad = true; break; }
+      const uint32_t count = (uint32_t)src[off] | ((uint32_t)src[off + 1u] << 8);
+      off += 2u;
+      if (count == 0u || (uint64_t)(src_size - off) < (uint64_t)count * bpv) { bad = true; break; }
+      const uint8_t* pal = src + off;
+      off += count * bpv;
+      const uint32_t bits = palette_bits(count);
+      const uint32_t index_bytes = (uint32_t)(((uint64_t)bits * n + 7u) / 8u);
+      if (src_size - off < index_bytes) { bad = true; break; }
+      const uint8_t* ip = src + off;
+      __syncthreads();
+      if (tid == 0) misc[0] = 0u;
+      __syncthreads();
+      const uint32_t i0 = tid * 32u;
+      if (i0 < n) {
+        const uint32_t cnt = min(32u, n - i0);
+        const uint32_t byte0 = tid * 4u * bits;  // 32 indexes = `bits` dwords
+        uint64_t scratch = 0u;
+        uint32_t held = 0u, k = 0u;
+        for (uint32_t produced = 0u; produced < cnt; ++produced) {
+          uint32_t idx = 0u;
+          if (bits) {
+            if (held < bits) {
+              uint32_t dw = 0u;
+              const uint32_t bo = byte0 + 4u * k;
+#pragma unroll
+              for (uint32_t b = 0; b < 4u; ++b)
+                if (bo + b < index_bytes) dw |= (uint32_t)ip[bo + b] << (8u * b);
+              ++k;
+              scratch |= (uint64_t)dw << held;
+              held += 32u;
+            }
+            idx = (uint32_t)(scratch & ((1ull << bits) - 1ull));
+            scratch >>= bits;
+            held -= bits;
+          }
+          if (idx >= count) {
+            misc[0] = 1u;
+            break;
+          }
+          uint64_t v = 0;
+          for (uint32_t b = 0; b < bpv; ++b) v |= ((uint64_t)pal[(size_t)idx * bpv + b]) << (8u * b);
+          st_raw(base + (size_t)(i0 + produced) * step + field_off, v, bpv);
+        }
+      }
+      __syncthreads();
+      if (misc[0]) bad = true;
+      off += index_bytes;
+    } else if (mode == 2u || mode == 3u) {  // ---- Rle / DeltaRle
+      if (src_size - off < 4u) { bad = true; break; }
+      const uint32_t runs = (uint32_t)src[off] | ((uint32_t)src[off + 1u] << 8) | ((uint32_t)src[off + 2u] << 16) |
+                            ((uint32_t)src[off + 3u] << 24);
+      off += 4u;
+      if (runs > n) { bad = true; break; }  // more runs than elements: empty runs, leave it to the serial decoder
+      __syncthreads();
+      if (tid == 0) {
+        misc[0] = 0u;
+        misc[1] = runs == 0u ? off : 0xffffffffu;
+      }
+      if (tid < 4u) tileb[tid] = 0u;
+      __syncthreads();
+      uint32_t out_index = 0u;  // elements written so far
+      uint32_t runs_done = 0u;
+      if (mode == 3u) {
+        // (diff, run_len) token pairs, all varints: tokens -> LDS; per tile two block scans turn them into the run
+        // table {start, value before the run, diff}, written over the tokens of the run
+        uint64_t prev = 0u;  // value before the next run
+        const uint32_t target = 2u * runs;
+        uint32_t pos = off, left = 0u;
+        while (2u * runs_done + left < target) {
+          if (pos >= src_size) { bad = true; break; }
+          const uint32_t seen = 2u * runs_done;
+          const uint32_t n_tile = dv_tokens_tile(src, src_size, pos, tileb, misc, left, seen, target,
+                                                 [&](uint32_t kl, uint64_t x, uint32_t end_off) {
+                                                   raw[kl] = x;
+                                                   if (seen + kl + 1u == target) misc[1] = end_off;
+                                                 });
+          const uint32_t avail = min(left + n_tile, target - seen);
+          const uint32_t nr = avail / 2u;  // <= 4096
+          const uint32_t per = (nr + T - 1u) / T;
+          const uint32_t r0 = min(nr, tid * per), r1 = min(nr, r0 + per);
+          uint32_t lsum = 0u;
+          uint64_t psum = 0u;
+          for (uint32_t r = r0; r < r1; ++r) {
+            const uint64_t dx = raw[2u * r], len = raw[2u * r + 1u];
+            if (dx == 0ull || len > (uint64_t)n) misc[0] = 1u;  // decodeVarint rejects the marker; run too long
+            const uint64_t u1 = dx - 1ull;
+            const uint64_t d = (u1 >> 1) ^ (0ull - (u1 & 1ull));
+            lsum += (uint32_t)min(len, (uint64_t)n + 1ull);
+            psum += d * len;
+          }
+          uint32_t ltot;
+          const uint32_t lex = block_exclusive_scan<T>(lsum, misc + 2, &ltot);  // barrier inside
+          __syncthreads();
+          uint64_t ptot;
+          const uint64_t pex = block_exclusive_scan_u64<T>(psum, scan64, &ptot);
+          __syncthreads();
+          if (misc[0] || (uint64_t)out_index + ltot > (uint64_t)n) { bad = true; break; }
+          {
+            uint32_t sidx = out_index + lex;
+            uint64_t pv = prev + pex;
+            for (uint32_t r = r0; r < r1; ++r) {
+              const uint64_t dx = raw[2u * r], len = raw[2u * r + 1u];
+              const uint64_t u1 = dx - 1ull;
+              const uint64_t d = (u1 >> 1) ^ (0ull - (u1 & 1ull));
+              start[r] = sidx;
+              raw[2u * r] = pv;
+              raw[2u * r + 1u] = d;
+              sidx += (uint32_t)len;
+              pv += d * len;
+            }
+          }
+          if (tid == 0) start[nr] = out_index + ltot;
+          __syncthreads();
+          if (nr) fill_runs(start, raw, nr, out_index, out_index + ltot, base, step, field_off, bpv);
+          const uint64_t carry_tok = (avail & 1u) ? raw[avail - 1u] : 0ull;  // a run cut by the tile edge
+          dv_roll_history(tileb);  // barrier: everyone is done with the table
+          if ((avail & 1u) && tid == 0) raw[0] = carry_tok;
+          __syncthreads();
+          out_index += ltot;
+          prev += ptot;
+          runs_done += nr;
+          left = avail & 1u;
+          pos += kDvTileBytes;
+        }
+        if (!bad) {
+          if (misc[0] || misc[1] == 0xffffffffu) bad = true;
+          else off = misc[1];
+        }
+      } else {
+        // (raw value, run_len): raw bytes hide the token ends, so one lane walks the runs -- from an LDS copy of the
+        // bytes, kRleRunTile runs per round -- and the workgroup fills
+        uint8_t* stage = smem + DecSecLds::kStageOff;
+        uint32_t pos = off;
+        while (runs_done < runs) {
+          const uint32_t nbytes = min(kRleStage, src_size - pos);
+          for (uint32_t u = tid; u < nbytes; u += T) stage[u] = src[pos + u];
+          __syncthreads();
+          if (tid == 0) {
+            uint32_t p = 0u, r = 0u, sidx = out_index;
+            bool fail = false;
+            const bool tail = (pos + nbytes == src_size);
+            while (runs_done + r < runs && r < kRleRunTile) {
+              if (!tail && nbytes - p < bpv + 10u) break;  // the record may continue behind the staged bytes
+              if (nbytes - p < bpv) { fail = true; break; }
+              uint64_t v = 0;
+              for (uint32_t b = 0; b < bpv; ++b) v |= ((uint64_t)stage[p + b]) << (8u * b);
+              p += bpv;
+              uint64_t len = 0;
+              uint32_t shift = 0;
+              for (;;) {  // readUVarint, src/v5_codec.cpp:176-194
+                if (p >= nbytes) { fail = true; break; }
+                const uint8_t byte = stage[p++];
+                len |= ((uint64_t)(byte & 0x7fu)) << shift;
+                if ((byte & 0x80u) == 0) break;
+                shift += 7u;
+                if (shift >= 64u) { fail = true; break; }
+              }
+              if (fail) break;
+              if ((uint64_t)sidx + len > (uint64_t)n) { fail = true; break; }
+              start[r] = sidx;
+              raw[2u * r] = v;
+              raw[2u * r + 1u] = 0ull;
+              sidx += (uint32_t)len;
+              ++r;
+            }
+            if (r == 0u && !fail) fail = true;  // no progress: a record larger than the stage cannot exist
+            start[r] = sidx;
+            misc[40] = r;
+            misc[41] = p;
+            misc[42] = sidx;
+            if (fail) misc[0] = 1u;
+          }
+          __syncthreads();
+          if (misc[0]) { bad = true; break; }
+          const uint32_t nr = misc[40], used = misc[41], sidx = misc[42];
+          fill_runs(start, raw, nr, out_index, sidx, base, step, field_off, bpv);
+          __syncthreads();
+          out_index = sidx;
+          runs_done += nr;
+          pos += used;
+        }
+        if (!bad) off = pos;
+      }
+      if (!bad && out_index != n) bad = true;
+    } else {
+      bad = true;
+    }
+  }
+  __syncthreads();
+  if (!bad && off != src_size) bad = true;  // trailing bytes: the serial decoder raises the error
+  if (!bad && tid == 0) {
+    sec_done[c] = 1u;
+    atomicAdd(&status[kStatFastSections], 1u);
   }
 }
 

@@ -1575,6 +1575,9 @@ int stage1_configure_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_varint<8, true>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)DvLds<8, true>::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_varint<8>)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sections),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecSecLds::kTotal);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_sections)");
   const void* pk32[] = {reinterpret_cast<const void*>(&k_section_palette32<uint16_t>),
                         reinterpret_cast<const void*>(&k_section_palette32<uint32_t>)};
   for (const void* f : pk32) {
@@ -1681,21 +1684,28 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     // the V5 sections (and whole chunks the fast kernel handed back)
     const DevPlan& P = *L.plan;
     static const bool no_fast = getenv("CLDN_HIP_NO_FAST_DECODE") != nullptr;  // A/B switch
-    bool fast = !no_fast && P.all_varint && P.n_ops >= 1u && P.n_ops <= 8u;
+    bool fast = !no_fast && P.all_varint && P.n_ops <= 8u;  // no regular ops at all (integer-only V5 cloud) is fine too
     bool all_qf32 = true;
     for (uint32_t k = 0; k < P.n_ops; ++k) all_qf32 = all_qf32 && P.ops[k].kind == OP_QF32;
     if (fast) {
       if (all_qf32 && P.n_ops <= 4u)
         hipLaunchKernelGGL((k_decode_varint<4, false>), dim3(L.n_chunks), dim3(kDvThreads), (DvLds<4, false>::kTotal),
-                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end);
+                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status);
       else
         hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (DvLds<8, true>::kTotal),
-                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end);
+                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_varint");
+    }
+    const bool fast_sections = fast && L.uses_v5 && P.n_adaptive > 0u;
+    if (fast_sections) {
+      hipLaunchKernelGGL(k_decode_sections, dim3(L.n_chunks), dim3(kDvThreads), (DecSecLds::kTotal), L.stream, P, L.streams,
+                         reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_sections");
     }
     hipLaunchKernelGGL(k_decode_general, dim3(L.n_chunks), dim3(64), 0, L.stream, P, L.streams,
                        reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.uses_v5, fast ? 1u : 0u,
-                       (const uint32_t*)L.reg_end, L.status);
+                       (const uint32_t*)L.reg_end, fast_sections ? (const uint8_t*)L.sec_done : (const uint8_t*)nullptr,
+                       L.status);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_general");
   }
   return CLDN_HIP_OK;

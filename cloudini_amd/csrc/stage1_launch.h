@@ -53,6 +53,7 @@ struct DecodeLaunch {
   uint32_t n_chunks;
   void* chunks;                       // device [n_chunks] DecChunk (48 bytes each)
   uint32_t* reg_end;                  // device [n_chunks]: end of the regular stream per chunk (fast path)
+  uint8_t* sec_done;                  // device [n_chunks]: 1 = sections decoded by k_decode_sections
   uint8_t* out;                       // device: decoded AoS points
   uint32_t* status;
 };

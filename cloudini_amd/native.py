@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
     L.cldn_hip_codec_enable_timing.restype = C.c_int
     L.cldn_hip_codec_kernel_ms.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float)]
     L.cldn_hip_codec_kernel_ms.restype = C.c_int
+    L.cldn_hip_codec_decode_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.cldn_hip_codec_decode_stats.restype = C.c_int
     L.cldn_hip_codec_force_modes.argtypes = [vp, C.POINTER(C.c_uint8), C.c_uint32]
     L.cldn_hip_codec_force_modes.restype = C.c_int
     L.cldn_hip_encode_stage1.restype = C.c_int
@@ -164,6 +166,12 @@ class Codec:
 
     def status(self):
         _check(lib().cldn_hip_codec_status(self._h))
+
+    def decode_stats(self):
+        """Chunks of the last decode call per kernel: (fast regular, fast sections, serial chunks, serial sections)."""
+        v = (C.c_uint32 * 4)()
+        _check(lib().cldn_hip_codec_decode_stats(self._h, v))
+        return tuple(int(x) for x in v)
 
     def force_modes(self, modes=None):
         """Adaptive-int modes committed elsewhere (cldn_hip_codec_force_modes); None / empty returns to probing."""

@@ -123,6 +123,11 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* codec, const void* streams, int str
                            const uint64_t* stream_offsets, const uint64_t* cloud_points, uint32_t n_clouds,
                            void* points_out, uint64_t out_capacity, int out_loc);
 
+/* Which kernels the last cldn_hip_decode_stage1 call used, in chunks (synchronises):
+ *   stats[0] regular stream by the parallel decoder      stats[1] V5 sections by the parallel decoder
+ *   stats[2] whole chunks by the serial decoder          stats[3] only the sections by the serial decoder */
+int cldn_hip_codec_decode_stats(cldn_hip_codec_t* codec, uint32_t stats[4]);
+
 /* Synchronise and return the status word of the last asynchronous call (0 or a negative error). */
 int cldn_hip_codec_status(cldn_hip_codec_t* codec);
 

@@ -175,3 +175,81 @@ def test_marker_inside_integer_token_stream_is_rejected(oracle):
     with pytest.raises(Exception):
         oracle.decode_stage1(info, s2, n)
     codec.close()
+
+
+def _stats_after_decode(oracle, info, data):
+    from cloudini_amd import native
+    codec = native.Codec(native.Plan(info))
+    step = info.point_step
+    n = data.size // step
+    stream, modes = oracle.encode_stage1(info, data, return_modes=True)
+    out = np.full(max(1, n * step), 0x3C, dtype=np.uint8)
+    got = codec.decode_host([stream], [n], out=out)[0]
+    want = oracle.decode_stage1(info, stream, n, fill=0x3C)
+    assert np.array_equal(got, want)
+    stats = codec.decode_stats()
+    codec.close()
+    return stats, modes.tolist(), (n + 32767) // 32768
+
+
+def test_parallel_kernels_take_the_common_schemas(oracle):
+    """The parallel decoders must really run (decode_stats): regular stream AND sections of every chunk for the
+    BASELINE schemas, whose sections cover Palette (C2), DeltaVarint (C3) and DeltaRle (C4)."""
+    for (info, data), want_mode in ((synth.lidar_xyzi(100_000, seed=3), 1), (synth.depthcam_xyzrgba(320, 240), 0),
+                                    (synth.velodyne_xyzir(130048, seed=4), 3)):
+        stats, modes, n_chunks = _stats_after_decode(oracle, info, data)
+        assert want_mode in modes
+        assert stats == (n_chunks, n_chunks, 0, 0), (stats, modes)
+    stats, _modes, n_chunks = _stats_after_decode(oracle, *synth.lidar_xyz(70_000))
+    assert stats == (n_chunks, 0, 0, 0)
+
+
+@pytest.mark.parametrize("kind", ["constant", "long_and_short", "alternating", "delta_runs_i64", "drle_then_noise"])
+def test_parallel_sections_run_modes(oracle, kind):
+    """Integer-only clouds (no regular tokens at all) in the run-length modes: sections by the parallel kernel,
+    except where a token is longer than its 7-byte window (64-bit deltas) -- those chunks go serial, and still match."""
+    info, data = cases.rle_stress(kind)
+    stats, modes, n_chunks = _stats_after_decode(oracle, info, data)
+    assert stats[0] == n_chunks and stats[2] == 0          # an empty regular stream is trivially parallel
+    assert stats[1] + stats[3] == n_chunks
+    if kind in ("constant", "long_and_short", "alternating"):
+        assert stats[1] == n_chunks, (stats, modes)
+
+
+@pytest.mark.parametrize("kind", ["grows_u16", "all_distinct_u32", "single_value", "two_values_i16", "u5000_u32"])
+def test_parallel_sections_palette_and_delta(oracle, kind):
+    info, data = cases.palette_stress(kind)
+    stats, modes, n_chunks = _stats_after_decode(oracle, info, data)
+    assert stats[0] == n_chunks and stats[1] == n_chunks and stats[2] == 0 and stats[3] == 0, (stats, modes)
+
+
+@pytest.mark.parametrize("what", ["palette_index", "run_too_long", "runs_short"])
+def test_corrupt_sections_are_rejected(oracle, what):
+    """Damage inside a section: the parallel kernel must step aside and the serial checks must fire
+    (decodeV5AdaptiveIntSection, src/v5_codec.cpp:764-879)."""
+    from cloudini_amd import native
+    if what == "palette_index":
+        rs = np.random.RandomState(1)
+        info, data = cases.int_only((rs.randint(0, 3, 5000) * 7).astype(np.uint16), cases.F.UINT16)
+        s = oracle.encode_stage1(info, data).copy()
+        assert s[4] == 1 and s[5] == 3                                # Palette, 3 entries, 2 bits per index
+        s[4 + 1 + 2 + 6 + 10] = 0xFF                                  # index value 3 >= count
+    else:
+        info, data = cases.int_only(np.repeat(np.arange(50, dtype=np.uint16), 100), cases.F.UINT16)
+        s = oracle.encode_stage1(info, data).copy()
+        assert s[4] in (2, 3)
+        if what == "run_too_long":
+            pos = 4 + 1 + 4                                            # first run record
+            pos += 2 if s[4] == 2 else 1                               # raw value (u16) or 1-byte diff token
+            assert s[pos] == 100                                       # run_len 100, one byte
+            s[pos] = 101
+        else:
+            s[4 + 1] = 49                                              # one run less than written: trailing bytes
+    n = data.size // info.point_step
+    codec = native.Codec(native.Plan(info))
+    with pytest.raises(native.CloudiniHipError) as e:
+        codec.decode_host([s], [n])
+    assert e.value.code == -6
+    with pytest.raises(Exception):
+        oracle.decode_stage1(info, s, n)
+    codec.close()
