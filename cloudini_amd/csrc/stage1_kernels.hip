@@ -528,8 +528,12 @@ __device__ __forceinline__ uint64_t field_from_regs(const FloatVec<LOADW>& pt, u
   return ((((uint64_t)hi) << 32) | lo) >> ((rel & 3u) * 8u);
 }
 
-template <int T, int LANES, int PPT, uint32_t RING_BYTES, int LOADW, bool PREFETCH = true, int MINW = 1>
-__global__ __launch_bounds__(T, MINW) void k_encode_floatn(const DevPlan plan, const uint8_t* __restrict__ points,
+// UNAL: points are not 4-byte aligned (odd point_step / offset / base, e.g. packed 18-byte points): every lane loads
+// LOADW + 1 dwords from the aligned address below its point and realigns them with v_alignbyte; the dwords may reach
+// into the next point, so only the last points of the whole batch need the guarded path (points_end).
+template <int T, int LANES, int PPT, uint32_t RING_BYTES, int LOADW, bool PREFETCH = true, bool UNAL = false>
+__global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const uint8_t* __restrict__ points,
+                                                     const uint8_t* __restrict__ points_end,
                                                      const ChunkDesc* __restrict__ chunks,
                                                      uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                      Seg* __restrict__ segs, uint32_t segs_per_chunk,
@@ -583,8 +587,25 @@ __global__ __launch_bounds__(T, MINW) void k_encode_floatn(const DevPlan plan, c
       FloatVec<LOADW> z;
 #pragma unroll
       for (int k = 0; k < LOADW; ++k) z.v[k] = 0.0f;
-      if (idx >= idx_lo && idx < n && !(ablate & 8u))
-        z = *reinterpret_cast<const FloatVec<LOADW>*>(gbase + (ptrdiff_t)idx * (ptrdiff_t)step);
+      if (idx >= idx_lo && idx < n && !(ablate & 8u)) {
+        const uint8_t* a = gbase + (ptrdiff_t)idx * (ptrdiff_t)step;
+        if (!UNAL) {
+          z = *reinterpret_cast<const FloatVec<LOADW>*>(a);
+        } else {
+          const uint32_t mis = (uint32_t)((uintptr_t)a & 3u);
+          const uint32_t* q = reinterpret_cast<const uint32_t*>(a - mis);
+          uint32_t d[LOADW + 1];
+          if (reinterpret_cast<const uint8_t*>(q + LOADW + 1) <= points_end) {
+#pragma unroll
+            for (int k = 0; k <= LOADW; ++k) d[k] = q[k];
+          } else {  // last points of the batch: a dword is read only if it holds at least one byte of the buffer
+#pragma unroll
+            for (int k = 0; k <= LOADW; ++k) d[k] = (reinterpret_cast<const uint8_t*>(q + k) < points_end) ? q[k] : 0u;
+          }
+#pragma unroll
+          for (int k = 0; k < LOADW; ++k) z.v[k] = __uint_as_float(__builtin_amdgcn_alignbyte(d[k + 1], d[k], mis));
+        }
+      }
       dst[j] = z;
     }
   };
@@ -933,13 +954,20 @@ __global__ __launch_bounds__(T) void k_chunk_offsets(const Seg* __restrict__ seg
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_compact: final framed stream. grid = (n_chunks, splits); each workgroup copies a 1/splits share of every
-// segment. Source segments start 16-byte aligned; the destination position is arbitrary.
+// k_compact: final framed stream. grid = (n_chunks, splits). The chunk's segment table is read once into LDS and
+// cut into work items of at most kCompactItemUnits 16-byte units; the waves of the chunk's workgroups take items
+// round-robin, so many small segments (sub-chunked small batches) and one large segment (huge batches) both keep
+// every wave busy without a dependent global load per segment. Source segments start 16-byte aligned; the
+// destination position is arbitrary.
 // ------------------------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ uint32_t funnel_bytes(uint32_t lo, uint32_t hi, uint32_t sb) {
   return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sb * 8u));
 }
+
+constexpr uint32_t kCompactMaxSegs = 32u + 2u * kMaxAdaptive;
+constexpr uint32_t kCompactItemUnits = 512u;  // 8 KiB per item
+constexpr uint32_t kCompactMaxItems = 1024u;
 
 template <int T>
 __global__ __launch_bounds__(T) void k_compact(const uint8_t* __restrict__ slots, uint64_t slot_stride,
@@ -947,6 +975,10 @@ __global__ __launch_bounds__(T) void k_compact(const uint8_t* __restrict__ slots
                                                const uint32_t* __restrict__ chunk_payload,
                                                const uint64_t* __restrict__ chunk_dst, uint8_t* __restrict__ out,
                                                uint64_t out_capacity, uint32_t* __restrict__ status) {
+  __shared__ Seg seg_l[kCompactMaxSegs];
+  __shared__ uint32_t doff_l[kCompactMaxSegs];               // destination offset of every segment behind the size word
+  __shared__ uint32_t item_seg[kCompactMaxItems], item_u0[kCompactMaxItems];
+  __shared__ uint32_t n_items_l;
   const uint32_t c = blockIdx.x;
   const uint32_t payload = chunk_payload[c];
   const uint64_t dst0 = chunk_dst[c];
@@ -955,23 +987,52 @@ __global__ __launch_bounds__(T) void k_compact(const uint8_t* __restrict__ slots
     return;
   }
   if (blockIdx.y == 0 && threadIdx.x < 4u) out[dst0 + threadIdx.x] = (uint8_t)(payload >> (8u * threadIdx.x));
+  if (threadIdx.x < segs_per_chunk) seg_l[threadIdx.x] = segs[(size_t)c * segs_per_chunk + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t d = 0u, n_items = 0u;
+    for (uint32_t s = 0; s < segs_per_chunk; ++s) {
+      doff_l[s] = d;
+      const uint32_t size = seg_l[s].size;
+      if (size) {
+        // items cover the destination-aligned 16-byte units of the segment (+ one item for a segment without any)
+        const uint32_t head = min(size, (uint32_t)((16u - (uint32_t)((dst0 + 4u + d) & 15u)) & 15u));
+        const uint32_t units = (size - head) >> 4;
+        uint32_t u0 = 0u;
+        do {
+          if (n_items < kCompactMaxItems) {
+            item_seg[n_items] = s;
+            item_u0[n_items] = u0;
+            ++n_items;
+          }
+          u0 += kCompactItemUnits;
+        } while (u0 < units);
+      }
+      d += size;
+    }
+    n_items_l = n_items;
+  }
+  __syncthreads();
 
   const uint8_t* slot = slots + (size_t)c * slot_stride;
-  uint64_t d = dst0 + 4u;
-  for (uint32_t s = 0; s < segs_per_chunk; ++s) {
-    const Seg sg = segs[(size_t)c * segs_per_chunk + s];
-    if (sg.size == 0u) continue;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wid = blockIdx.y * (T / 64) + (threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.y * (T / 64);
+  const uint32_t n_items = n_items_l;
+  for (uint32_t it = wid; it < n_items; it += n_waves) {
+    const uint32_t sidx = item_seg[it], u0 = item_u0[it];
+    const Seg sg = seg_l[sidx];
     const uint8_t* src = slot + sg.off;
-    uint8_t* dst = out + d;
+    uint8_t* dst = out + dst0 + 4u + doff_l[sidx];
     const uint32_t size = sg.size;
-    // head: bytes until dst is 16-byte aligned
+    // head: bytes until dst is 16-byte aligned; tail: bytes behind the last whole unit (first item of the segment)
     const uint32_t head = min(size, (uint32_t)((16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u));
     const uint32_t body_units = (size - head) >> 4;
     const uint32_t tail = (size - head) & 15u;
-    if (blockIdx.y == 0) {
-      if (threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
-      if (threadIdx.x >= 32u && threadIdx.x < 32u + tail) {
-        const uint32_t k = head + body_units * 16u + (threadIdx.x - 32u);
+    if (u0 == 0u) {
+      if (lane < head) dst[lane] = src[lane];
+      if (lane >= 32u && lane < 32u + tail) {
+        const uint32_t k = head + body_units * 16u + (lane - 32u);
         dst[k] = src[k];
       }
     }
@@ -979,7 +1040,8 @@ __global__ __launch_bounds__(T) void k_compact(const uint8_t* __restrict__ slots
     const uint32_t sdw = head >> 2, sb = head & 3u;
     const uint4* src4 = reinterpret_cast<const uint4*>(src);
     uint4* dst4 = reinterpret_cast<uint4*>(dst + head);
-    for (uint32_t j = blockIdx.y * T + threadIdx.x; j < body_units; j += gridDim.y * T) {
+    const uint32_t u1 = min(body_units, u0 + kCompactItemUnits);
+    for (uint32_t j = u0 + lane; j < u1; j += 64u) {
       const uint4 a = src4[j];
       uint4 b = make_uint4(0u, 0u, 0u, 0u);
       if (head != 0u) b = src4[j + 1u];
@@ -997,7 +1059,6 @@ __global__ __launch_bounds__(T) void k_compact(const uint8_t* __restrict__ slots
       o.w = funnel_bytes(w3, w4, sb);
       dst4[j] = o;
     }
-    d += size;
   }
 }
 
@@ -1513,13 +1574,16 @@ int floatn_lanes(const DevPlan& p, const uint8_t* points) {
   for (uint32_t k = 0; k < lanes; ++k) {
     if (p.ops[k].kind != OP_QF32 || p.ops[k].offset != p.ops[0].offset + 4u * k) return 0;
   }
-  if ((p.point_step & 3u) || (p.ops[0].offset & 3u) || ((uintptr_t)points & 3u)) return 0;
   return (int)lanes;
 }
 
+bool floatn_unaligned(const DevPlan& p, const uint8_t* points) {
+  return (p.point_step & 3u) || (p.ops[0].offset & 3u) || ((uintptr_t)points & 3u);
+}
+
 // dwords to load per point so that every adaptive-int field is covered by the point load (0 = not possible)
-int floatn_loadw(const DevPlan& p, int lanes) {
-  if (p.n_adaptive == 0) return lanes;
+int floatn_loadw(const DevPlan& p, int lanes, bool unal) {
+  if (p.n_adaptive == 0) return unal && lanes == 3 ? 4 : lanes;
   uint32_t need = (uint32_t)lanes * 4u;
   const uint32_t off0 = p.ops[0].offset;
   for (uint32_t a = 0; a < p.n_adaptive; ++a) {
@@ -1529,6 +1593,10 @@ int floatn_loadw(const DevPlan& p, int lanes) {
     need = std::max(need, f.offset - off0 + f.bpv);
   }
   const int w = (int)((need + 3u) / 4u);
+  if (unal) {  // realigned dword loads may reach into the next point; variants: (3: 4, 8), (4: 5, 8)
+    if (lanes == 3) return w <= 4 ? 4 : (w <= 8 ? 8 : 4);
+    return w <= 5 ? 5 : (w <= 8 ? 8 : 5);
+  }
   const int loadw = w <= lanes ? lanes : (w <= 4 ? 4 : (w <= 8 ? 8 : 0));
   if (loadw == 0 || off0 + (uint32_t)loadw * 4u > p.point_step) return lanes;  // would read past the point
   return loadw;
@@ -1548,7 +1616,11 @@ int stage1_configure_kernels() {
                       reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 2, kFloatnRing, 4, false>),
                       reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 2, kFloatnRing, 8, false>),
                       reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 2, kFloatnRing, 4, false>),
-                      reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 2, kFloatnRing, 8, false>)};
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 2, kFloatnRing, 8, false>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 2, kFloatnRing, 4, false, true>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 2, kFloatnRing, 8, false, true>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 2, kFloatnRing, 5, false, true>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 2, kFloatnRing, 8, false, true>)};
   for (const void* f : fk) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFloatnLds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_floatn)");
@@ -1599,12 +1671,17 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   if (L.n_chunks) {
     const int lanes = floatn_lanes(*L.plan, L.points);
     static const uint32_t ablate = getenv("CLDN_HIP_ABLATE") ? (uint32_t)atoi(getenv("CLDN_HIP_ABLATE")) : 0u;  // profiling only
-    const int loadw = lanes ? floatn_loadw(*L.plan, lanes) : 0;
+    const bool unal = lanes && floatn_unaligned(*L.plan, L.points);
+    const int loadw = lanes ? floatn_loadw(*L.plan, lanes, unal) : 0;
 #define LAUNCH_FLOATN(TT, LL, PP, ...)                                                                                          \
   hipLaunchKernelGGL((k_encode_floatn<TT, LL, PP, kFloatnRing, __VA_ARGS__>), dim3(L.n_chunks * L.subs), dim3(TT), kFloatnLds, \
-                     L.stream, *L.plan, L.points, L.chunks, L.slots, L.slot_stride, L.segs, L.segs_per_chunk, L.cols, \
-                     L.subs, L.sub_points, L.sub_stride, ablate)
-    if (lanes == 3 && loadw == 3) LAUNCH_FLOATN(256, 3, 2, 3, false);
+                     L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots, L.slot_stride, L.segs,          \
+                     L.segs_per_chunk, L.cols, L.subs, L.sub_points, L.sub_stride, ablate)
+    if (unal && lanes == 3 && loadw == 4) LAUNCH_FLOATN(256, 3, 2, 4, false, true);
+    else if (unal && lanes == 3 && loadw == 8) LAUNCH_FLOATN(256, 3, 2, 8, false, true);
+    else if (unal && lanes == 4 && loadw == 5) LAUNCH_FLOATN(256, 4, 2, 5, false, true);
+    else if (unal && lanes == 4 && loadw == 8) LAUNCH_FLOATN(256, 4, 2, 8, false, true);
+    else if (lanes == 3 && loadw == 3) LAUNCH_FLOATN(256, 3, 2, 3, false);
     else if (lanes == 3 && loadw == 4) LAUNCH_FLOATN(256, 3, 2, 4, false);
     else if (lanes == 3 && loadw == 8) LAUNCH_FLOATN(256, 3, 2, 8, false);
     else if (lanes == 4 && loadw == 4) LAUNCH_FLOATN(256, 4, 2, 4, false);
