@@ -966,7 +966,7 @@ __device__ __forceinline__ uint32_t funnel_bytes(uint32_t lo, uint32_t hi, uint3
 }
 
 constexpr uint32_t kCompactMaxSegs = 32u + 2u * kMaxAdaptive;
-constexpr uint32_t kCompactItemUnits = 512u;  // 8 KiB per item
+constexpr uint32_t kCompactItemUnits = 256u;  // 4 KiB per item
 constexpr uint32_t kCompactMaxItems = 1024u;
 
 template <int T>
@@ -1650,6 +1650,12 @@ int stage1_configure_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sections),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecSecLds::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_sections)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_section_delta32<uint16_t>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD32Lds);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_delta32<u16>)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_section_delta32<uint32_t>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD32Lds);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_delta32<u32>)");
   const void* pk32[] = {reinterpret_cast<const void*>(&k_section_palette32<uint16_t>),
                         reinterpret_cast<const void*>(&k_section_palette32<uint32_t>)};
   for (const void* f : pk32) {
@@ -1717,6 +1723,17 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   hipLaunchKernelGGL(k_section_palette<RT>, dim3(L.n_chunks), dim3(kS2Threads), kS2PalLds, L.stream, *L.plan, a,      \
                      L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs, \
                      L.fallback_flags)
+#define LAUNCH_D32(RT)                                                                                              \
+  hipLaunchKernelGGL(k_section_delta32<RT>, dim3(L.n_chunks), dim3(kS2Threads), kD32Lds, L.stream, *L.plan, a,        \
+                     L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs, \
+                     L.fallback_flags);                                                                             \
+  hipLaunchKernelGGL(k_section_runs<RT>, dim3(L.n_chunks), dim3(kS2Threads), 0, L.stream, *L.plan, a, L.chunks,       \
+                     L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs,        \
+                     L.fallback_flags)
+      if (bpv == 2u) { LAUNCH_D32(uint16_t); }
+      else if (bpv == 4u) { LAUNCH_D32(uint32_t); }
+#undef LAUNCH_D32
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_delta32/runs");
 #define LAUNCH_PAL32(RT)                                                                                            \
   hipLaunchKernelGGL(k_section_palette32<RT>, dim3(L.n_chunks), dim3(kS2Threads), Pal32<RT>::kLds, L.stream, *L.plan, a, \
                      L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs, \

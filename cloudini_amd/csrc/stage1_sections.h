@@ -628,4 +628,217 @@ __global__ __launch_bounds__(kS2Threads) void k_section_palette32(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_section_delta32<RawT> (2- and 4-byte fields): DeltaVarint section (appendDeltaVarintSection,
+// src/v5_codec.cpp:423-432) = mode byte 0, then zigzag(+1) varints of the int64 differences. With 16/32-bit
+// values a difference has at most 33 bits -> tokens of 1..5 bytes, two dwords. The chunk is done in quarters of
+// 8 values per thread: token lengths -> block scan -> tokens OR-ed into a zeroed LDS buffer -> the buffer leaves
+// in 16-byte units (the partial last unit stays for the next quarter). The mode byte is the zero the buffer
+// starts with.
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kD32Ring = 65536;  // >= 8192 values * 5 bytes + 16
+constexpr uint32_t kD32Lds = kD32Ring + 256u;
+
+template <typename RawT>
+__global__ __launch_bounds__(kS2Threads) void k_section_delta32(const DevPlan plan, uint32_t a,
+                                                                const ChunkDesc* __restrict__ chunks,
+                                                                const ColumnPtrs cols, const uint8_t* __restrict__ modes,
+                                                                uint8_t* __restrict__ slots, uint64_t slot_stride,
+                                                                uint64_t reg_stride, Seg* __restrict__ segs,
+                                                                uint32_t segs_per_chunk, uint32_t subs,
+                                                                uint8_t* __restrict__ handled_flags) {
+  static_assert(sizeof(RawT) == 2 || sizeof(RawT) == 4, "differences of at most 33 bits");
+  constexpr int T = kS2Threads;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* ring = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + kD32Ring);
+  const uint32_t c = blockIdx.x;
+  const ChunkDesc cd = chunks[c];
+  if (modes[cd.cloud * plan.n_adaptive + a] != 0u) return;
+  const uint32_t n = cd.n_points;
+  const uint32_t type = plan.adaptive[a].type;
+  const RawT* col = reinterpret_cast<const RawT*>(cols.p[a]) + cd.first_point;
+  const uint32_t sec_off = (uint32_t)reg_stride + a * kSectionStride;
+  uint8_t* dst = slots + (size_t)c * slot_stride + sec_off;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < kD32Ring / 16u; i += T) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+
+  uint32_t R = 1u, F = 0u;  // byte 0 = mode 0
+  for (uint32_t q = 0; q < 4u; ++q) {
+    const uint32_t i0 = q * (T * 8u) + tid * 8u;
+    if (q * (T * 8u) >= n) break;
+    RawT v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (RawT)0;
+    if (i0 < n) load8<RawT>(col, i0, n, v);
+    int64_t prev = (i0 > 0u && i0 < n) ? int_field_as_i64((uint64_t)col[i0 - 1u], type) : 0;
+    uint32_t w0[8], w1[8], lens = 0u, total = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t cur = int_field_as_i64((uint64_t)v[j], type);
+      const int64_t d = (int64_t)((uint64_t)cur - (uint64_t)prev);
+      prev = cur;
+      const uint64_t u = (((uint64_t)d << 1) ^ (uint64_t)(d >> 63)) + 1ull;  // <= 34 bits
+      const uint32_t bl = (u >> 32) ? (64u - (uint32_t)__builtin_clzll(u)) : (32u - (uint32_t)__builtin_clz((uint32_t)u));
+      const uint32_t l = (i0 + (uint32_t)j < n) ? groups7(bl) : 0u;
+      w0[j] = spread28((uint32_t)u & 0x0fffffffu) | cont_mask(l ? l - 1u : 0u);
+      w1[j] = (uint32_t)(u >> 28);
+      lens |= l << (4 * j);
+      total += l;
+    }
+    uint32_t tile_total;
+    uint32_t off = R + block_exclusive_scan<T>(total, wtot, &tile_total);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t l = (lens >> (4 * j)) & 0xfu;
+      if (l) ring_put5<kD32Ring, false>(ring, off, w0[j], w1[j], l, 0u);
+      off += l;
+    }
+    const uint32_t r_end = R + tile_total;
+    const bool last = (q + 1u) * (T * 8u) >= n;
+    const uint32_t target = last ? ((r_end + 15u) & ~15u) : (r_end & ~15u);
+    __syncthreads();
+    ring_flush_n<T, kD32Ring>(ring, dst, F, target);
+    F = target;
+    R = r_end;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    Seg sg;
+    sg.off = sec_off;
+    sg.size = R;
+    segs[(size_t)c * segs_per_chunk + subs + 2u * a] = sg;
+    sg.off = sec_off;
+    sg.size = 0u;
+    segs[(size_t)c * segs_per_chunk + subs + 1u + 2u * a] = sg;
+    handled_flags[(size_t)c * plan.n_adaptive + a] = 1u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_section_runs<RawT> (2- and 4-byte fields): Rle and DeltaRle sections (appendRleSection / appendDeltaRleSection,
+// src/v5_codec.cpp:471-491, :447-460): mode byte, u32 run count, then per run {raw value | varint(diff)} and the
+// LEB128 run length. Thread t owns values [32t, 32t+32): run heads = key changes (the key before the thread's
+// first value is read from the column), run index and byte offset from block scans, the length of a thread's last
+// run from a suffix-min over the following threads' first heads. Run-coded sections are small by construction, so
+// the records are written straight to the slot.
+// ---------------------------------------------------------------------------------------------------------
+template <typename RawT>
+__global__ __launch_bounds__(kS2Threads) void k_section_runs(const DevPlan plan, uint32_t a,
+                                                             const ChunkDesc* __restrict__ chunks, const ColumnPtrs cols,
+                                                             const uint8_t* __restrict__ modes,
+                                                             uint8_t* __restrict__ slots, uint64_t slot_stride,
+                                                             uint64_t reg_stride, Seg* __restrict__ segs,
+                                                             uint32_t segs_per_chunk, uint32_t subs,
+                                                             uint8_t* __restrict__ handled_flags) {
+  static_assert(sizeof(RawT) == 2 || sizeof(RawT) == 4, "differences of at most 33 bits");
+  constexpr int T = kS2Threads;
+  __shared__ uint32_t wtot[64];
+  const uint32_t c = blockIdx.x;
+  const ChunkDesc cd = chunks[c];
+  const uint32_t mode = modes[cd.cloud * plan.n_adaptive + a];
+  if (mode != 2u && mode != 3u) return;
+  const bool delta = (mode == 3u);
+  const uint32_t n = cd.n_points;
+  const uint32_t type = plan.adaptive[a].type;
+  const RawT* col = reinterpret_cast<const RawT*>(cols.p[a]) + cd.first_point;
+  const uint32_t sec_off = (uint32_t)reg_stride + a * kSectionStride;
+  uint8_t* dst = slots + (size_t)c * slot_stride + sec_off;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t i0 = tid * 32u;
+  const uint32_t cnt = i0 < n ? min(32u, n - i0) : 0u;
+  auto as64 = [&](RawT r) { return int_field_as_i64((uint64_t)r, type); };
+
+  // keys of my values and of the value before them
+  uint64_t key[32];
+  uint64_t key_before = 0u;
+  {
+    RawT v[32];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      RawT t8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t8[j] = (RawT)0;
+      if (i0 + 8u * g < n) load8<RawT>(col, i0 + 8u * g, n, t8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[8 * g + j] = t8[j];
+    }
+    const RawT pm1 = (cnt && i0 >= 1u) ? col[i0 - 1u] : (RawT)0;
+    const RawT pm2 = (cnt && i0 >= 2u) ? col[i0 - 2u] : (RawT)0;
+    if (delta) {
+      int64_t prev = i0 >= 1u ? as64(pm1) : 0;
+      key_before = (uint64_t)prev - (uint64_t)(i0 >= 2u ? as64(pm2) : 0);
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const int64_t cur = as64(v[j]);
+        key[j] = (uint64_t)cur - (uint64_t)prev;
+        prev = cur;
+      }
+    } else {
+      key_before = (uint64_t)pm1;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) key[j] = (uint64_t)v[j];
+    }
+  }
+  uint32_t heads = 0u;
+  {
+    uint64_t kb = key_before;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      if ((uint32_t)j < cnt && ((i0 + (uint32_t)j) == 0u || key[j] != kb)) heads |= 1u << j;
+      kb = key[j];
+    }
+  }
+  const uint32_t my_first = heads ? (i0 + (uint32_t)__builtin_ctz(heads)) : kInf;
+  uint32_t next_after = block_suffix_min_exclusive<T>(my_first, wtot);  // barriers inside
+  if (next_after == kInf) next_after = n;
+  // bytes of my runs
+  uint32_t bytes = 0u;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    if (heads & (1u << j)) {
+      const uint32_t above = heads & ~((2u << j) - 1u);
+      const uint32_t nxt = above ? (i0 + (uint32_t)__builtin_ctz(above)) : next_after;
+      bytes += (delta ? varint64_len((int64_t)key[j]) : (uint32_t)sizeof(RawT)) + uvarint32_len(nxt - (i0 + (uint32_t)j));
+    }
+  }
+  uint32_t total_bytes, total_runs;
+  uint32_t boff = block_exclusive_scan<T>(bytes, wtot, &total_bytes);
+  __syncthreads();
+  (void)block_exclusive_scan<T>((uint32_t)__builtin_popcount(heads), wtot, &total_runs);
+  uint8_t* out = dst + 5u + boff;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    if (heads & (1u << j)) {
+      const uint32_t above = heads & ~((2u << j) - 1u);
+      const uint32_t nxt = above ? (i0 + (uint32_t)__builtin_ctz(above)) : next_after;
+      if (delta) {
+        const Tok t = varint64_tok((int64_t)key[j]);  // <= 5 bytes here
+        const uint64_t w = ((uint64_t)t.w1 << 32) | t.w0;
+        for (uint32_t b = 0; b < t.len; ++b) *out++ = (uint8_t)(w >> (8u * b));
+      } else {
+#pragma unroll
+        for (uint32_t b = 0; b < sizeof(RawT); ++b) *out++ = (uint8_t)(key[j] >> (8u * b));
+      }
+      const Tok r = uvarint32_tok(nxt - (i0 + (uint32_t)j));
+      for (uint32_t b = 0; b < r.len; ++b) *out++ = (uint8_t)(r.w0 >> (8u * b));  // run <= 32768: 3 bytes
+    }
+  }
+  if (tid == 0) {
+    dst[0] = (uint8_t)mode;
+    dst[1] = (uint8_t)total_runs;
+    dst[2] = (uint8_t)(total_runs >> 8);
+    dst[3] = (uint8_t)(total_runs >> 16);
+    dst[4] = (uint8_t)(total_runs >> 24);
+    Seg sg;
+    sg.off = sec_off;
+    sg.size = 5u + total_bytes;
+    segs[(size_t)c * segs_per_chunk + subs + 2u * a] = sg;
+    sg.size = 0u;
+    segs[(size_t)c * segs_per_chunk + subs + 1u + 2u * a] = sg;
+    handled_flags[(size_t)c * plan.n_adaptive + a] = 1u;
+  }
+}
+
 }  // namespace cldn
