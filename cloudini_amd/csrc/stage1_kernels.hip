@@ -580,7 +580,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
   // LOADW >= LANES dwords are loaded per point (one global_load_dwordx3/x4/...): the extra dwords carry the
   // adaptive-int fields that live right behind the floats, so their AoS->SoA split needs no second load.
   FloatVec<LOADW> cur[PPT], nxt[PPT];
-  auto load_tile = [&](uint32_t base, FloatVec<LOADW>(&dst)[PPT]) {
+  auto load_tile = [&](uint32_t base, FloatVec<LOADW>(&dst)[PPT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       const int32_t idx = (int32_t)(base + (uint32_t)(j * NW + (int)wave) * 63u + lane) - 1;
@@ -612,7 +612,12 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
   load_tile(0u, cur);
   __syncthreads();
 
+  // Two copies of the tile loop. Clouds either have NaNs all over (organised depth images) or none (lidar), so the
+  // first tile decides for the sub-chunk: with NaNs around, rows that fail the short-path test get a second try that
+  // treats NaN lanes as marker bytes; without, that code is not even in the loop (it cost the NaN-free loop 7 %).
   uint32_t R = 0u, F = 0u;
+  auto run_tiles = [&](auto nan_tier_tag) __attribute__((always_inline)) {
+  constexpr bool NAN_TIER = decltype(nan_tier_tag)::value;
   for (uint32_t base = 0; base < (uint32_t)n; base += TILE) {
     const bool last = (base + TILE >= (uint32_t)n);
     if (PREFETCH && !last) load_tile(base + TILE, nxt);  // double buffer: in flight while this tile is encoded
@@ -645,18 +650,42 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
         lens[j] |= l << (8 * k);
         total += l;
       }
-      if (__ballot(rare) != 0ull) {
-        rare_rows |= 1u << j;
-        total = 0u;
+      if (__builtin_expect(__ballot(rare) != 0ull, 0)) {
+        // Second tier: the row only has NaNs (organised clouds with invalid pixels) next to in-range values. A NaN
+        // is the marker byte and hands its neighbour a reference of 0; everything else stays in the float domain
+        // and the tokens still fit one dword, so the row keeps the short emission path.
+        bool hard = !NAN_TIER;
+        uint32_t total2 = 0u, lens2 = 0u;
 #pragma unroll
         for (int k = 0; k < LANES; ++k) {
+          if (!NAN_TIER) break;
           const float v = cur[j].v[k];
           const bool isn = is_nan_f32(v);
-          const int32_t q = quant_rne_i32(v, mult[k]);
-          const uint32_t nqp = dpp_wave_shr1(isn ? 0u : (0u - (uint32_t)q));  // a NaN resets that lane's reference
-          uint32_t a0, a1, l;
-          floatn_token(isn, (int32_t)((uint32_t)q + nqp), a0, a1, l);
-          total += l;
+          const float r = isn ? 0.0f : rintf(__fmul_rn(v, mult[k]));
+          hard |= !(fabsf(r) < 2097152.0f);
+          const float nrp = __uint_as_float(dpp_wave_shr1(__float_as_uint(r) ^ 0x80000000u));
+          const float uf = fabsf(__fmaf_rn(__fadd_rn(r, nrp), 2.0f, 0.5f)) + 0.5f;
+          const uint32_t l = isn ? 1u : groups7((uint32_t)__builtin_amdgcn_frexp_expf(uf));
+          tok[j][k] = isn ? 0u : token4((uint32_t)uf, l);
+          lens2 |= l << (8 * k);
+          total2 += l;
+        }
+        if (NAN_TIER && __ballot(hard) == 0ull) {
+          lens[j] = lens2;
+          total = total2;
+        } else {  // Inf, overflow or a 5-byte token somewhere in the row: general integer formulas
+          rare_rows |= 1u << j;
+          total = 0u;
+#pragma unroll
+          for (int k = 0; k < LANES; ++k) {
+            const float v = cur[j].v[k];
+            const bool isn = is_nan_f32(v);
+            const int32_t q = quant_rne_i32(v, mult[k]);
+            const uint32_t nqp = dpp_wave_shr1(isn ? 0u : (0u - (uint32_t)q));  // a NaN resets that lane's reference
+            uint32_t a0, a1, l;
+            floatn_token(isn, (int32_t)((uint32_t)q + nqp), a0, a1, l);
+            total += l;
+          }
         }
       }
       plen[j] = emits ? total : 0u;
@@ -701,13 +730,13 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
       }
     }
 
-    auto emit_all = [&](auto windowed, uint32_t win_lo_dw) {
+    auto emit_all = [&](auto windowed, uint32_t win_lo_dw) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < PPT; ++j) {
         const int f = j * NW + (int)wave;
         const uint32_t rowbase = (f == 0) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)wincl, f - 1);
         uint32_t off = R + rowbase + incl[j] - plen[j];
-        if (rare_rows & (1u << j)) {  // wave-uniform: rebuild the general tokens (all lanes take part in the DPP)
+        if (__builtin_expect((rare_rows & (1u << j)) != 0u, 0)) {  // wave-uniform: rebuild the general tokens (all lanes take part in the DPP)
 #pragma unroll
           for (int k = 0; k < LANES; ++k) {
             const float v = cur[j].v[k];
@@ -734,7 +763,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
 
     // AoS -> SoA split of the adaptive-int fields. Fields covered by the point load are taken from registers;
     // 2/4-byte fields are staged in LDS (written after the scan barrier) and leave as 16-byte stores.
-    auto write_columns = [&]() {
+    auto write_columns = [&]() __attribute__((always_inline)) {
       if (plan.n_adaptive && !(ablate & 1u)) {
         const uint32_t tile_pts = min(TILE, (uint32_t)n - base);
         for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
@@ -781,7 +810,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
 
     // Without the double buffer the next tile's points are requested as soon as this tile's registers are dead:
     // the loads fly during the ring flush and the next scan barrier.
-    if (r_end - F <= RING_BYTES) {
+    if (__builtin_expect(r_end - F <= RING_BYTES, 1)) {
       emit_all(std::false_type{}, 0u);
       __syncthreads();
       write_columns();
@@ -810,6 +839,18 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
     }
     // No barrier here: the next tile's wtot writes sit behind this tile's second barrier (every wave has read
     // wtot by then) and its ring ORs sit behind its own first barrier (every wave has finished this flush).
+  }
+  };
+  if (LANES == 3) {  // the 4-lane instantiations would lose a wave of occupancy to the second copy
+    bool any_nan = false;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+#pragma unroll
+      for (int k = 0; k < LANES; ++k) any_nan |= is_nan_f32(cur[j].v[k]);
+    if (__syncthreads_or(any_nan ? 1 : 0)) run_tiles(std::true_type{});
+    else run_tiles(std::false_type{});
+  } else {
+    run_tiles(std::false_type{});
   }
 
   if (tid == 0) {

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_SO = os.path.join(HERE, "lib", "libcloudini_hip.so")
+HIP_SO = os.environ.get("CLDN_HIP_LIB_OVERRIDE") or os.path.join(HERE, "lib", "libcloudini_hip.so")  # override: A/B builds
 
 HOST, DEVICE = 0, 1
 
