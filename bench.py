@@ -180,6 +180,22 @@ def main():
 
     offsets = d_offsets.cpu().numpy()
     total_out = int(offsets[-1])
+
+    # extra (not `value`): decode of the streams just produced, device resident, same synchronisation bracket
+    d_dec = torch.empty(host.size, dtype=torch.uint8, device=dev)
+    so = offsets.astype(np.uint64)
+    dec_steps = max(1, args.steps // 2)
+    for _ in range(min(2, args.warmup)):
+        codec.decode_device(d_out.data_ptr(), so, cloud_points, d_dec.data_ptr(), host.size)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(dec_steps):
+        codec.decode_device(d_out.data_ptr(), so, cloud_points, d_dec.data_ptr(), host.size)
+    torch.cuda.synchronize(dev)
+    dec_elapsed = time.perf_counter() - t1
+    codec.status()
+    dec_stats = codec.decode_stats()
+    del d_dec
     chunk_sizes = d_chunk_sizes.cpu().numpy().astype(np.int64)
     points_per_step = n_clouds * pts_per_cloud
     out_bpp = total_out / points_per_step
@@ -246,6 +262,9 @@ def main():
                        "clouds_per_gpu": n_clouds, "points_per_cloud": pts_per_cloud, "point_step": step,
                        "parallelism": f"whole clouds sharded over {world} GPU(s), no data-path collective"},
             "input_MBps": total_points_all * step * args.steps / elapsed / 1e6,
+            "decode": {"value": points_per_step * dec_steps / dec_elapsed / 1e6, "unit": "Mpoints/s (rank 0, stage-1 decode, "
+                       "device resident)", "ms_per_step": dec_elapsed / dec_steps * 1e3,
+                       "chunks_parallel_regular/parallel_sections/serial/serial_sections": list(dec_stats)},
             "stage1_bytes_per_point": out_bpp,
             "device_ms_per_step": {dominant: regular_ms, "sections": sections_ms,
                                    "offsets+compact": compact_ms, "all_kernels": device_ms},
