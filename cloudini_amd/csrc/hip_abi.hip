@@ -134,6 +134,13 @@ struct cldn_hip_codec {
   PinnedBuf h_stage;   // chunk table upload
   PinnedBuf h_result;  // offsets / status readback
   PinnedBuf h_modes;   // forced modes upload
+  // modes of the previous encode call, copied back asynchronously: launch hint for the section kernels
+  PinnedBuf h_last_modes;
+  hipEvent_t ev_last_modes = nullptr;
+  size_t last_modes_count = 0;  // n_clouds * n_adaptive of the copy in flight (0 = none)
+  uint32_t last_modes_fields = 0;
+  uint8_t hint_cache[kMaxAdaptive];  // modes seen by the most recent call whose copy has landed
+  bool hint_valid = false;
   // cached batch shape
   std::vector<uint64_t> last_cloud_points;
   uint32_t last_n_chunks = 0;
@@ -410,6 +417,9 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   }
   c->h_stage.release();
   c->h_result.release();
+  c->h_modes.release();
+  c->h_last_modes.release();
+  if (c->ev_last_modes) (void)hipEventDestroy(c->ev_last_modes);
   for (hipEvent_t& ev : c->events)
     if (ev) (void)hipEventDestroy(ev);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -627,7 +637,21 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   L.stream_offsets = (uint64_t*)c->d_offsets.p;
   L.modes = (uint8_t*)c->d_modes.p;
   L.modes_forced = false;
+  if (c->last_modes_count && c->ev_last_modes && hipEventQuery(c->ev_last_modes) == hipSuccess) {
+    // a copy of an earlier call's modes has landed: it becomes the hint until a newer one lands
+    const uint8_t* lm = (const uint8_t*)c->h_last_modes.p;
+    const uint32_t nf = c->last_modes_fields;
+    for (uint32_t a = 0; a < (uint32_t)kMaxAdaptive; ++a) c->hint_cache[a] = 0;
+    for (size_t k = 0; k < c->last_modes_count; ++k) {
+      const uint8_t m = lm[k];
+      c->hint_cache[k % nf] |= (m <= 3u) ? (uint8_t)(1u << m) : (uint8_t)0xF;
+    }
+    c->hint_valid = true;
+    c->last_modes_count = 0;
+  }
+  for (uint32_t a = 0; a < (uint32_t)kMaxAdaptive; ++a) L.mode_hint[a] = c->hint_valid ? c->hint_cache[a] : (uint8_t)0xF;
   if (!c->forced_modes.empty() && n_adaptive && n_clouds) {
+    for (uint32_t a = 0; a < n_adaptive; ++a) L.mode_hint[a] = (uint8_t)(1u << c->forced_modes[a]);
     HIP_TRY(hipStreamSynchronize(c->stream));  // the previous call's upload from h_modes has to be over
     if ((rc = c->h_modes.ensure((size_t)n_clouds * n_adaptive)) != CLDN_HIP_OK) return rc;
     for (uint32_t k = 0; k < n_clouds; ++k)
@@ -645,6 +669,18 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   L.events = n_slots ? &c->events[slot * 5] : nullptr;
   rc = stage1_launch_encode(L);
   if (rc != CLDN_HIP_OK) return rc;
+  // remember this call's modes for the next call's launch hint (no synchronisation: the copy is only looked at
+  // once its event has fired)
+  if (n_adaptive && n_clouds && (size_t)n_clouds * n_adaptive <= 65536u && c->last_modes_count == 0) {
+    if (!c->ev_last_modes) HIP_TRY(hipEventCreateWithFlags(&c->ev_last_modes, hipEventDisableTiming));
+    if (c->h_last_modes.ensure((size_t)n_clouds * n_adaptive) == CLDN_HIP_OK) {  // no copy in flight: buffer is free
+      HIP_TRY(hipMemcpyAsync(c->h_last_modes.p, c->d_modes.p, (size_t)n_clouds * n_adaptive, hipMemcpyDeviceToHost,
+                             c->stream));
+      HIP_TRY(hipEventRecord(c->ev_last_modes, c->stream));
+      c->last_modes_count = (size_t)n_clouds * n_adaptive;
+      c->last_modes_fields = n_adaptive;
+    }
+  }
   if (n_slots) c->slot_valid[slot] = 1;
   ++c->call_index;
 

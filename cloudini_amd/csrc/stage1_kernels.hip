@@ -1771,17 +1771,22 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   hipLaunchKernelGGL(k_section_runs<RT>, dim3(L.n_chunks), dim3(kS2Threads), 0, L.stream, *L.plan, a, L.chunks,       \
                      L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs,        \
                      L.fallback_flags)
-      if (bpv == 2u) { LAUNCH_D32(uint16_t); }
-      else if (bpv == 4u) { LAUNCH_D32(uint32_t); }
+      const uint32_t hint = L.mode_hint[a];
+      if (hint & 0xDu) {  // DeltaVarint / Rle / DeltaRle expected somewhere
+        if (bpv == 2u) { LAUNCH_D32(uint16_t); }
+        else if (bpv == 4u) { LAUNCH_D32(uint32_t); }
+      }
 #undef LAUNCH_D32
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_delta32/runs");
 #define LAUNCH_PAL32(RT)                                                                                            \
   hipLaunchKernelGGL(k_section_palette32<RT>, dim3(L.n_chunks), dim3(kS2Threads), Pal32<RT>::kLds, L.stream, *L.plan, a, \
                      L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs, \
                      L.fallback_flags)
-      if (bpv == 2u) LAUNCH_PAL32(uint16_t);
-      else if (bpv == 4u) LAUNCH_PAL32(uint32_t);
-      else LAUNCH_PAL(uint64_t);
+      if (hint & 0x2u) {
+        if (bpv == 2u) LAUNCH_PAL32(uint16_t);
+        else if (bpv == 4u) LAUNCH_PAL32(uint32_t);
+        else LAUNCH_PAL(uint64_t);
+      }
 #undef LAUNCH_PAL32
 #undef LAUNCH_PAL
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_palette");

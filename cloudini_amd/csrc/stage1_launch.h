@@ -34,6 +34,9 @@ struct EncodeLaunch {
   uint64_t* stream_offsets;   // device [n_clouds + 1]
   uint8_t* modes;             // device [n_clouds * n_adaptive]
   bool modes_forced;          // modes were uploaded by the caller: no probe kernels
+  // per adaptive field: bit m set = mode m may occur (modes of the previous call, or forced); 0xF = unknown.
+  // Only a launch hint: a fast section kernel that is not launched leaves its chunks to k_encode_sections.
+  uint8_t mode_hint[kMaxAdaptive];
   uint8_t* fallback_flags;    // device [n_chunks * n_adaptive], zeroed per call: 1 = section written by a fast path
   uint8_t* out;               // device, framed streams
   uint64_t out_capacity;

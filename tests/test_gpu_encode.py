@@ -201,3 +201,37 @@ def test_forced_modes_override_the_probe(oracle):
     with pytest.raises(native.CloudiniHipError):
         codec.force_modes([7])
     codec.close()
+
+
+def test_mode_hints_never_change_the_bytes(oracle):
+    """The section kernels launched for a call are picked from the modes an earlier call committed (a launch hint).
+    A wrong hint may only cost time: same codec, clouds whose integer column commits a different mode every call."""
+    from cloudini_amd import native
+    rs = np.random.RandomState(77)
+    n = 70_000
+    base_info, base = synth.lidar_xyzi(n, seed=21)
+    step = base_info.point_step
+    variants = []
+    for kind in ("palette", "delta", "drle", "rle", "palette", "rle", "delta"):
+        data = base.copy().reshape(n, step)
+        if kind == "palette":
+            col = (rs.randint(0, 200, n) * 5).astype(np.uint16)
+        elif kind == "delta":
+            col = rs.randint(0, 65536, n).astype(np.uint16)
+        elif kind == "drle":
+            col = (np.arange(n) % 128).astype(np.uint16)
+        else:
+            col = np.repeat(rs.randint(0, 65536, n // 700 + 1), 700)[:n].astype(np.uint16)
+        data[:, 12:14] = col.view(np.uint8).reshape(n, 2)
+        variants.append((kind, data.reshape(-1)))
+    codec = native.Codec(native.Plan(base_info))
+    seen = set()
+    for kind, data in variants:
+        for _ in range(2):  # second pass runs with the hint of the first
+            streams, _sizes, modes = codec.encode_host([data])
+            want, want_modes = oracle.encode_stage1(base_info, data, return_modes=True)
+            assert np.array_equal(streams[0], want), kind
+            assert list(modes[0]) == list(want_modes)
+        seen.add(int(want_modes[0]))
+    assert seen == {0, 1, 2, 3}
+    codec.close()
