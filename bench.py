@@ -117,7 +117,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run also a single rank takes the RCCL path
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("nccl", device_id=dev)
