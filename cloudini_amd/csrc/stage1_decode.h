@@ -654,19 +654,287 @@ __device__ __forceinline__ void dv_stream(OpAt op_at, uint32_t n_ops, const uint
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// dv_stream2: the same job as dv_stream without staging token values in LDS. The tokens that end inside a thread's
+// BPT bytes are consecutive tokens of the stream, so the thread that decodes them also owns them: it keeps their
+// values in registers (indexed by the byte position of the token's last byte), folds them into one partial sum per
+// op (token g belongs to op g % n_ops), the segmented block scan hands it the running values in front of its first
+// token, and a second walk over the same registers produces and stores the final values -- consecutive tokens are
+// consecutive fields of consecutive points, so the stores of neighbouring threads are neighbours too. Nothing
+// waits at a tile edge: a point cut by it simply continues with the carried per-op state.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NOPS, bool WIDE, int BPT>
+struct Dv2Lds {
+  using Acc = typename std::conditional<WIDE, long long, int>::type;
+  static constexpr uint32_t kTileBytes = kDvThreads * BPT;
+  static constexpr uint32_t kBytesOff = 0;                                 // [16 history + tile + 16] bytes
+  static constexpr uint32_t kScanOff = 16u + kTileBytes + 16u;            // per wave: Acc[NOPS] + flags; [16] = carry
+  static constexpr uint32_t kWaveRec = NOPS * (uint32_t)sizeof(Acc) + 8u;
+  static constexpr uint32_t kMiscOff = (kScanOff + 17u * kWaveRec + 15u) & ~15u;
+  static constexpr uint32_t kTotal = kMiscOff + 256u;  // misc: [0] bad, [1] end offset, [2..34) block-scan scratch
+};
+
+template <int NOPS, bool WIDE, int BPT, typename OpAt>
+__device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uint8_t* __restrict__ src,
+                                           uint32_t src_size, uint32_t start, uint32_t n_points, uint8_t* base,
+                                           uint32_t step, uint8_t* smem) {
+  using L = Dv2Lds<NOPS, WIDE, BPT>;
+  using Acc = typename L::Acc;
+  using UAcc = typename std::make_unsigned<Acc>::type;
+  constexpr int T = kDvThreads;
+  constexpr int DW = BPT / 4;
+  static_assert(BPT == 8 || BPT == 16, "8 or 16 bytes per thread");
+  uint32_t* tileb = reinterpret_cast<uint32_t*>(smem + L::kBytesOff);
+  uint8_t* scanrec = smem + L::kScanOff;
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + L::kMiscOff);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t target = n_points * n_ops;
+
+  __syncthreads();  // the caller may have used the LDS
+  if (tid < 4u) tileb[tid] = 0u;  // history before the stream: token ends
+  if (tid == 0) {
+    misc[0] = 0u;
+    misc[1] = target == 0u ? start : 0xffffffffu;
+  }
+  if (tid < (uint32_t)(NOPS * sizeof(Acc) + 8u) / 4u)
+    reinterpret_cast<uint32_t*>(scanrec + 16u * L::kWaveRec)[tid] = 0u;  // carry record: sums 0
+  __syncthreads();
+
+  uint32_t pos = start;  // payload offset of the current tile
+  uint32_t seen = 0u;    // tokens decoded so far
+  while (seen < target) {
+    if (pos >= src_size) {  // stream ends before all tokens
+      if (tid == 0) misc[0] = 1u;
+      break;
+    }
+    // ---- bytes, end flags, token indexes
+    const uint32_t my = pos + tid * BPT;
+    uint32_t b[DW];
+#pragma unroll
+    for (int k = 0; k < DW; ++k) b[k] = 0xffffffffu;  // past the end: continuation bytes, no token ends
+    if (my + BPT <= src_size) {
+      const uint8_t* q = src + my;
+      if ((((uintptr_t)q) & 3u) == 0u) {
+#pragma unroll
+        for (int k = 0; k < DW; ++k) b[k] = reinterpret_cast<const uint32_t*>(q)[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < DW; ++k)
+          b[k] = (uint32_t)q[4 * k] | ((uint32_t)q[4 * k + 1] << 8) | ((uint32_t)q[4 * k + 2] << 16) |
+                 ((uint32_t)q[4 * k + 3] << 24);
+      }
+    } else if (my < src_size) {
+#pragma unroll
+      for (int k = 0; k < DW; ++k) {
+        uint32_t w = 0xffffffffu;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+          if (my + 4u * k + bb < src_size) w = (w & ~(0xffu << (8 * bb))) | ((uint32_t)src[my + 4u * k + bb] << (8 * bb));
+        b[k] = w;
+      }
+    }
+    uint32_t ends = 0u;  // bit j = byte j ends a token
+#pragma unroll
+    for (int k = 0; k < DW; ++k) {
+      tileb[4u + tid * DW + k] = b[k];
+      ends |= ((((~b[k] & 0x80808080u) >> 7) * 0x00204081u) >> 21 & 0xfu) << (4 * k);
+    }
+    uint32_t n_tile;
+    const uint32_t tb = block_exclusive_scan<T>((uint32_t)__builtin_popcount(ends), misc + 2, &n_tile);  // barrier inside
+    const uint32_t g0 = seen + tb;  // stream index of my first token
+
+    // ---- my tokens -> registers (indexed by the byte position of the token's last byte)
+    Acc d[BPT];
+    uint32_t valid = 0u, marks = 0u;
+    {
+      uint32_t g = g0;
+#pragma unroll
+      for (int j = 0; j < BPT; ++j) {
+        d[j] = 0;
+        if ((ends >> j) & 1u) {
+          if (g < target) {
+            const uint32_t e = 16u + tid * BPT + (uint32_t)j;  // byte index of the token's last byte in tileb
+            const uint32_t w0 = e - 7u;                        // window [w0, e]
+            const uint32_t d0 = tileb[w0 >> 2], d1 = tileb[(w0 >> 2) + 1u], d2 = tileb[(w0 >> 2) + 2u];
+            const uint32_t sh = (w0 & 3u) * 8u;
+            const uint32_t lo = sh ? ((d0 >> sh) | (d1 << (32u - sh))) : d0;
+            const uint32_t hi = sh ? ((d1 >> sh) | (d2 << (32u - sh))) : d1;
+            const uint32_t c_lo = lo & 0x80808080u, c_hi = hi & 0x00808080u;
+            const uint32_t cm = (((c_lo >> 7) * 0x00204081u) >> 21 & 0xfu) | ((((c_hi >> 7) * 0x00204081u) >> 21 & 0x7u) << 4);
+            const uint32_t lencont = (uint32_t)__builtin_clz(~(cm << 25));  // continuation bytes before the end byte
+            if (lencont >= 7u) misc[0] = 1u;                                 // token of 8 or more bytes
+            uint64_t x = ((((uint64_t)hi) << 32) | lo) >> (8u * (7u - min(lencont, 6u)));
+            x &= 0x7f7f7f7f7f7f7f7full;
+            x = (x & 0x007f007f007f007full) | ((x & 0x7f007f007f007f00ull) >> 1);
+            x = (x & 0x00003fff00003fffull) | ((x & 0x3fff00003fff0000ull) >> 2);
+            x = (x & 0x000000000fffffffull) | ((x & 0x0fffffff00000000ull) >> 4);
+            const uint64_t u1 = x - 1ull;
+            d[j] = (Acc)(UAcc)((u1 >> 1) ^ (0ull - (u1 & 1ull)));
+            valid |= 1u << j;
+            if (x == 0ull) marks |= 1u << j;
+            if (g + 1u == target) misc[1] = pos + tid * BPT + (uint32_t)j + 1u;
+          }
+          ++g;
+        }
+      }
+    }
+    const uint32_t p0 = g0 / n_ops, o0 = g0 - p0 * n_ops;  // point and op of my first token
+
+    // ---- partial sums per op with NaN resets
+    Acc acc[NOPS];
+    uint32_t fl = 0u;
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) acc[o] = 0;
+    {
+      uint32_t o = o0;
+#pragma unroll
+      for (int j = 0; j < BPT; ++j) {
+        if ((valid >> j) & 1u) {
+          const bool mk = (marks >> j) & 1u;
+#pragma unroll
+          for (int oo = 0; oo < NOPS; ++oo) {
+            if (o == (uint32_t)oo) {
+              acc[oo] = mk ? (Acc)0 : (Acc)((UAcc)acc[oo] + (UAcc)d[j]);
+              if (mk) {
+                fl |= 1u << oo;
+                if (op_at(oo).kind == OP_INT) misc[0] = 1u;  // the marker is not a valid integer token
+              }
+            }
+          }
+          o = (o + 1u == n_ops) ? 0u : o + 1u;
+        }
+      }
+    }
+    // segmented inclusive scan over the threads: (f1, v1) o (f2, v2) = (f1 | f2, f2 ? v2 : v1 + v2)
+    Acc inc[NOPS];
+    uint32_t fin = fl;
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) inc[o] = acc[o];
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const uint32_t of = (uint32_t)__shfl_up((int)fin, dlt);
+      Acc ov[NOPS];
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) {
+        if (WIDE) ov[o] = (Acc)__shfl_up((long long)inc[o], dlt);
+        else ov[o] = (Acc)__shfl_up((int)inc[o], dlt);
+      }
+      if (lane >= (uint32_t)dlt) {
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o)
+          if (!(fin & (1u << o))) inc[o] = (Acc)((UAcc)inc[o] + (UAcc)ov[o]);
+        fin |= of;
+      }
+    }
+    if (lane == 63u) {
+      Acc* rec = reinterpret_cast<Acc*>(scanrec + wave * L::kWaveRec);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) rec[o] = inc[o];
+      *reinterpret_cast<uint32_t*>(scanrec + wave * L::kWaveRec + NOPS * sizeof(Acc)) = fin;
+    }
+    __syncthreads();
+    // incoming state of this thread = carry o waves before o lanes before
+    Acc in[NOPS];
+    {
+      const Acc* crec = reinterpret_cast<const Acc*>(scanrec + 16u * L::kWaveRec);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) in[o] = crec[o];
+      for (uint32_t w = 0; w < wave; ++w) {
+        const Acc* rec = reinterpret_cast<const Acc*>(scanrec + w * L::kWaveRec);
+        const uint32_t rf = *reinterpret_cast<const uint32_t*>(scanrec + w * L::kWaveRec + NOPS * sizeof(Acc));
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) in[o] = (rf & (1u << o)) ? rec[o] : (Acc)((UAcc)in[o] + (UAcc)rec[o]);
+      }
+      const uint32_t pf = (uint32_t)__shfl_up((int)fin, 1);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) {
+        Acc pv;
+        if (WIDE) pv = (Acc)__shfl_up((long long)inc[o], 1);
+        else pv = (Acc)__shfl_up((int)inc[o], 1);
+        if (lane > 0u) in[o] = (pf & (1u << o)) ? pv : (Acc)((UAcc)in[o] + (UAcc)pv);
+      }
+    }
+    // ---- second walk: final values, converted and stored
+    {
+      uint32_t o = o0;
+      uint8_t* pt = base + (size_t)p0 * step;
+#pragma unroll
+      for (int j = 0; j < BPT; ++j) {
+        if ((valid >> j) & 1u) {
+          const bool mk = (marks >> j) & 1u;
+          Acc cur = 0;
+          uint32_t kind = 0u, size = 0u, off = 0xffffffffu;
+          float resf = 0.0f;
+          double resd = 0.0;
+#pragma unroll
+          for (int oo = 0; oo < NOPS; ++oo) {
+            if (o == (uint32_t)oo) {
+              in[oo] = mk ? (Acc)0 : (Acc)((UAcc)in[oo] + (UAcc)d[j]);
+              cur = in[oo];
+              const DevOp& op = op_at(oo);
+              kind = op.kind;
+              size = op.size;
+              off = op.offset;
+              resf = op.res_f;
+              if (WIDE) resd = op.res_d;
+            }
+          }
+          if (off != 0xffffffffu) {
+            if (!WIDE || kind == OP_QF32) {
+              const uint32_t bits = mk ? 0x7fc00000u : __float_as_uint(__fmul_rn((float)(int32_t)cur, resf));
+              if (((off | step) & 3u) == 0u) *reinterpret_cast<uint32_t*>(pt + off) = bits;
+              else st_raw(pt + off, bits, 4);
+            } else if (kind == OP_LOSSY_F32) {
+              st_raw(pt + off, mk ? 0x7fc00000u : __float_as_uint(__fmul_rn((float)(long long)cur, resf)), 4);
+            } else if (kind == OP_LOSSY_F64) {
+              st_raw(pt + off, mk ? 0x7ff8000000000000ull : (uint64_t)__double_as_longlong(__dmul_rn((double)(long long)cur, resd)), 8);
+            } else {
+              st_raw(pt + off, (uint64_t)(long long)cur, size);
+            }
+          }
+          if (o + 1u == n_ops) {
+            o = 0u;
+            pt += step;
+          } else {
+            ++o;
+          }
+        }
+      }
+    }
+    // block state after this tile -> carry; the last 16 bytes become the next tile's history
+    uint32_t hist = 0u;
+    if (tid < 4u) hist = tileb[4u + (uint32_t)T * DW - 4u + tid];
+    __syncthreads();  // every thread has read the carry record and its window bytes
+    if (tid == (uint32_t)T - 1u) {  // the last thread's running values are the block total
+      Acc* crec = reinterpret_cast<Acc*>(scanrec + 16u * L::kWaveRec);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) crec[o] = in[o];
+    }
+    if (tid < 4u) tileb[tid] = hist;
+    __syncthreads();
+    seen += min(n_tile, target - seen);
+    pos += L::kTileBytes;
+    if (misc[0]) break;  // uniform after the barrier
+  }
+  __syncthreads();
+}
+
 template <int NOPS, bool WIDE>
-__global__ __launch_bounds__(kDvThreads) void k_decode_varint(const DevPlan plan, const uint8_t* __restrict__ streams,
+__global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 : 8, 8))) void k_decode_varint(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                               const DecChunk* __restrict__ chunks,
                                                               uint8_t* __restrict__ out, uint32_t* __restrict__ reg_end,
                                                               uint32_t* __restrict__ status) {
-  using L = DvLds<NOPS, WIDE>;
+  constexpr int BPT = WIDE ? 8 : 16;
+  using L = Dv2Lds<NOPS, WIDE, BPT>;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t c = blockIdx.x;
   const DecChunk dc = chunks[c];
   if (!dc.valid) return;
   uint8_t* base = out + (size_t)dc.first_point * plan.point_step;
-  dv_stream<NOPS, WIDE>([&](int o) -> const DevOp& { return plan.ops[o]; }, plan.n_ops, streams + dc.src_off,
-                        dc.src_size, 0u, dc.n_points, base, plan.point_step, smem);
+  dv_stream2<NOPS, WIDE, BPT>([&](int o) -> const DevOp& { return plan.ops[o]; }, plan.n_ops, streams + dc.src_off,
+                              dc.src_size, 0u, dc.n_points, base, plan.point_step, smem);
   const uint32_t* misc = reinterpret_cast<const uint32_t*>(smem + L::kMiscOff);
   if (threadIdx.x == 0) {
     const bool redo = misc[0] || misc[1] == 0xffffffffu;
@@ -782,23 +1050,39 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_sections(const DevPlan pl
       const uint8_t* ip = src + off;
       __syncthreads();
       if (tid == 0) misc[0] = 0u;
+      // palette -> LDS (the token area is free here) when it fits; values are looked up 32768 times
+      uint64_t* pal_l = raw;
+      const bool pal_in_lds = count <= 8192u;
+      if (pal_in_lds) {
+        for (uint32_t k = tid; k < count; k += T) {
+          uint64_t v = 0;
+          for (uint32_t b = 0; b < bpv; ++b) v |= ((uint64_t)pal[(size_t)k * bpv + b]) << (8u * b);
+          pal_l[k] = v;
+        }
+      }
       __syncthreads();
       const uint32_t i0 = tid * 32u;
       if (i0 < n) {
         const uint32_t cnt = min(32u, n - i0);
         const uint32_t byte0 = tid * 4u * bits;  // 32 indexes = `bits` dwords
+        // index dwords through aligned loads: the stream position is arbitrary, so fetch the aligned dwords around
+        // mine and realign
+        const uint8_t* ib = ip + byte0;
+        const uint32_t mis = (uint32_t)((uintptr_t)ib & 3u);
+        const uint32_t* iq = reinterpret_cast<const uint32_t*>(ib - mis);
+        const uint8_t* ip_end = ip + index_bytes;
+        uint32_t nxt = (reinterpret_cast<const uint8_t*>(iq) < ip_end && bits) ? iq[0] : 0u;
+        const bool st_fast = (bpv == 2u && ((field_off | step) & 1u) == 0u) || (bpv == 4u && ((field_off | step) & 3u) == 0u);
         uint64_t scratch = 0u;
         uint32_t held = 0u, k = 0u;
         for (uint32_t produced = 0u; produced < cnt; ++produced) {
           uint32_t idx = 0u;
           if (bits) {
             if (held < bits) {
-              uint32_t dw = 0u;
-              const uint32_t bo = byte0 + 4u * k;
-#pragma unroll
-              for (uint32_t b = 0; b < 4u; ++b)
-                if (bo + b < index_bytes) dw |= (uint32_t)ip[bo + b] << (8u * b);
+              const uint32_t cur_dw = nxt;
               ++k;
+              nxt = (reinterpret_cast<const uint8_t*>(iq + k) < ip_end) ? iq[k] : 0u;
+              const uint32_t dw = __builtin_amdgcn_alignbyte(nxt, cur_dw, mis);
               scratch |= (uint64_t)dw << held;
               held += 32u;
             }
@@ -811,8 +1095,15 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_sections(const DevPlan pl
             break;
           }
           uint64_t v = 0;
-          for (uint32_t b = 0; b < bpv; ++b) v |= ((uint64_t)pal[(size_t)idx * bpv + b]) << (8u * b);
-          st_raw(base + (size_t)(i0 + produced) * step + field_off, v, bpv);
+          if (pal_in_lds) {
+            v = pal_l[idx];
+          } else {
+            for (uint32_t b = 0; b < bpv; ++b) v |= ((uint64_t)pal[(size_t)idx * bpv + b]) << (8u * b);
+          }
+          uint8_t* o = base + (size_t)(i0 + produced) * step + field_off;
+          if (st_fast && bpv == 2u) *reinterpret_cast<uint16_t*>(o) = (uint16_t)v;
+          else if (st_fast && bpv == 4u) *reinterpret_cast<uint32_t*>(o) = (uint32_t)v;
+          else st_raw(o, v, bpv);
         }
       }
       __syncthreads();

@@ -1683,10 +1683,10 @@ int stage1_configure_kernels() {
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_palette)");
   }
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_varint<4, false>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)DvLds<4, false>::kTotal);
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Dv2Lds<4, false, 16>::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_varint<4>)");
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_varint<8, true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)DvLds<8, true>::kTotal);
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Dv2Lds<8, true, 8>::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_varint<8>)");
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sections),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecSecLds::kTotal);
@@ -1829,10 +1829,10 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     for (uint32_t k = 0; k < P.n_ops; ++k) all_qf32 = all_qf32 && P.ops[k].kind == OP_QF32;
     if (fast) {
       if (all_qf32 && P.n_ops <= 4u)
-        hipLaunchKernelGGL((k_decode_varint<4, false>), dim3(L.n_chunks), dim3(kDvThreads), (DvLds<4, false>::kTotal),
+        hipLaunchKernelGGL((k_decode_varint<4, false>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<4, false, 16>::kTotal),
                            L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status);
       else
-        hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (DvLds<8, true>::kTotal),
+        hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<8, true, 8>::kTotal),
                            L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_varint");
     }
