@@ -58,6 +58,9 @@ def lib() -> C.CDLL:
     L.cldn_amd_ros_compress.argtypes = [u8p, C.c_uint64, C.c_float, C.c_uint8, u8p, C.c_uint64]
     L.cldn_amd_ros_decompress.restype = C.c_int64
     L.cldn_amd_ros_decompress.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64]
+    L.cldn_amd_viz_preprocess.restype = C.c_int64
+    L.cldn_amd_viz_preprocess.argtypes = [C.POINTER(_Info), u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_float),
+                                          C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     for name in ("cldn_GetHeaderAsYAML", "cldn_GetHeaderAsYAMLFromDDS", "cldn_ConvertCompressedMsgToPointCloud2Msg",
                  "cldn_DecodeCompressedData", "cldn_DecodeCompressedMessage"):
         getattr(L, name).restype = C.c_uint32
@@ -212,3 +215,16 @@ def ros_decompress(dds, capacity: int) -> np.ndarray:
     out = np.empty(capacity, dtype=np.uint8)
     n = _check(lib().cldn_amd_ros_decompress(_ptr(msg), msg.size, _ptr(out), out.size))
     return out[:n].copy()
+
+
+def applyVizLossyPreprocessing(info, cloud):
+    """cloudini_ros::applyVizLossyPreprocessing on a bare point buffer -> (surviving bytes, per-field resolution
+    afterwards (None = none), width, height)."""
+    data = _u8(cloud)
+    ci, _keep = _c_info(info)
+    out = np.empty(max(1, data.size), dtype=np.uint8)
+    res = (C.c_float * max(1, len(info.fields)))()
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    n = _check(lib().cldn_amd_viz_preprocess(C.byref(ci), _ptr(data) if data.size else None, data.size, _ptr(out),
+                                             out.size, res, C.byref(w), C.byref(h)))
+    return out[:n].copy(), [None if x != x else float(x) for x in list(res)[: len(info.fields)]], int(w.value), int(h.value)

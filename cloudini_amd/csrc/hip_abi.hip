@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -130,6 +131,7 @@ struct cldn_hip_codec {
   DevBuf d_cols[kMaxAdaptive];
   DevBuf d_ranks[kMaxAdaptive];
   DevBuf d_dec_meta, d_fbflags, d_pre_ptrs;
+  DevBuf d_viz_keys, d_viz_first, d_viz_slot, d_viz_blocks, d_viz_total;  // applyVizLossyPreprocessing workspace
   DevBuf d_pre[kMaxGorilla];
   PinnedBuf h_stage;   // chunk table upload
   PinnedBuf h_result;  // offsets / status readback
@@ -409,7 +411,8 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_segs,
                     &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_fbflags, &c->d_pre_ptrs,
-                    &c->d_pre[0], &c->d_pre[1], &c->d_pre[2], &c->d_pre[3]};
+                    &c->d_pre[0], &c->d_pre[1], &c->d_pre[2], &c->d_pre[3], &c->d_viz_keys, &c->d_viz_first,
+                    &c->d_viz_slot, &c->d_viz_blocks, &c->d_viz_total};
   for (DevBuf* b : bufs) b->release();
   for (int a = 0; a < kMaxAdaptive; ++a) {
     c->d_cols[a].release();
@@ -737,6 +740,68 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   if (modes && modes_bytes) HIP_TRY(hipMemcpyAsync(modes, c->d_modes.p, modes_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (stream_offsets) memcpy(stream_offsets, h_off, (size_t)(n_clouds + 1) * sizeof(uint64_t));
+  return CLDN_HIP_OK;
+}
+
+int cldn_hip_viz_preprocess(cldn_hip_codec_t* c, const void* points, int points_loc, uint64_t n_points,
+                            uint32_t point_step, uint32_t xyz_offset, float resolution, void* out, uint64_t out_capacity,
+                            int out_loc, uint64_t* kept_points) {
+  if (!c || !kept_points) return fail(CLDN_HIP_ERR_ARG, "viz_preprocess: NULL argument");
+  *kept_points = 0;
+  if ((points_loc != CLDN_HIP_HOST && points_loc != CLDN_HIP_DEVICE) ||
+      (out_loc != CLDN_HIP_HOST && out_loc != CLDN_HIP_DEVICE))
+    return fail(CLDN_HIP_ERR_ARG, "invalid memory location tag");
+  if (point_step == 0 || (uint64_t)xyz_offset + 12u > point_step)
+    return fail(CLDN_HIP_ERR_ARG, "viz_preprocess: the x/y/z triple does not fit the point (offset %u, step %u)", xyz_offset,
+                point_step);
+  if (!(resolution > 0.0f) || !std::isfinite(resolution))
+    return fail(CLDN_HIP_ERR_ARG, "viz_preprocess: resolution must be positive and finite");
+  if (n_points >= 0xffffffffull) return fail(CLDN_HIP_ERR_UNSUPPORTED, "viz_preprocess: more than 2^32 - 2 points");
+  if (n_points == 0) return CLDN_HIP_OK;
+  if (!points || !out) return fail(CLDN_HIP_ERR_ARG, "viz_preprocess: NULL buffer");
+  const uint64_t bytes = n_points * point_step;
+  if (out_capacity < bytes)
+    return fail(CLDN_HIP_ERR_CAPACITY, "viz_preprocess: output needs room for every input point (%llu < %llu)",
+                (unsigned long long)out_capacity, (unsigned long long)bytes);
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  const uint8_t* d_points = (const uint8_t*)points;
+  if (points_loc == CLDN_HIP_HOST) {
+    if ((rc = c->d_in.ensure((size_t)bytes)) != CLDN_HIP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_in.p, points, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    d_points = (const uint8_t*)c->d_in.p;
+  }
+  uint8_t* d_out = (uint8_t*)out;
+  if (out_loc == CLDN_HIP_HOST) {
+    if ((rc = c->d_out.ensure((size_t)bytes)) != CLDN_HIP_OK) return rc;
+    d_out = (uint8_t*)c->d_out.p;
+  }
+  const uint64_t cap = viz_table_capacity(n_points);
+  if ((rc = c->d_viz_keys.ensure((size_t)cap * 8u)) != CLDN_HIP_OK) return rc;
+  if ((rc = c->d_viz_first.ensure((size_t)cap * 4u)) != CLDN_HIP_OK) return rc;
+  if ((rc = c->d_viz_slot.ensure((size_t)n_points * 4u)) != CLDN_HIP_OK) return rc;
+  if ((rc = c->d_viz_blocks.ensure((size_t)((n_points + 1023u) / 1024u) * 4u + 16u)) != CLDN_HIP_OK) return rc;
+  if ((rc = c->d_viz_total.ensure(16)) != CLDN_HIP_OK) return rc;
+  VizLaunch L;
+  L.stream = c->stream;
+  L.points = d_points;
+  L.n_points = n_points;
+  L.point_step = point_step;
+  L.xyz_offset = xyz_offset;
+  L.inv_res = 1.0f / resolution;  // const float inv_res = 1.0f / xyz_res (ros_msg_utils.cpp:272)
+  L.keys = (unsigned long long*)c->d_viz_keys.p;
+  L.first = (uint32_t*)c->d_viz_first.p;
+  L.slot_of = (uint32_t*)c->d_viz_slot.p;
+  L.block_count = (uint32_t*)c->d_viz_blocks.p;
+  L.total = (unsigned long long*)c->d_viz_total.p;
+  L.out = d_out;
+  if ((rc = viz_launch(L)) != CLDN_HIP_OK) return rc;
+  unsigned long long kept = 0;
+  HIP_TRY(hipMemcpyAsync(&kept, c->d_viz_total.p, sizeof(kept), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (out_loc == CLDN_HIP_HOST && kept)
+    HIP_TRY(hipMemcpy(out, d_out, (size_t)(kept * point_step), hipMemcpyDeviceToHost));
+  *kept_points = kept;
   return CLDN_HIP_OK;
 }
 

@@ -1,6 +1,7 @@
 // C entry points over the C++ host API: the reference's own `cldn_*` ABI (include/cloudini_lib/wasm_functions.h)
 // and the flat helpers of include/cloudini_amd_c.h used by the Python bindings and tests.
 #include <cstring>
+#include <limits>
 #include <string>
 
 #include "cloudini_amd_c.h"
@@ -139,6 +140,34 @@ CLDN_EXPORT int64_t cldn_amd_ros_decompress(const uint8_t* dds, uint64_t size, u
     std::vector<uint8_t> msg;
     cloudini_ros::convertCompressedCloudToPointCloud2(pc, msg);
     return copyOut(msg, out, capacity);
+  });
+}
+
+CLDN_EXPORT int64_t cldn_amd_viz_preprocess(const cldn_amd_info_t* info, const uint8_t* data, uint64_t size, uint8_t* out,
+                                            uint64_t capacity, float* res_out, uint32_t* width_out, uint32_t* height_out) {
+  return guarded([&] {
+    cloudini_ros::RosPointCloud2 pc;
+    for (uint32_t i = 0; i < info->n_fields; ++i) {
+      Cloudini::PointField f;
+      f.name = info->fields[i].name ? info->fields[i].name : "";
+      f.offset = info->fields[i].offset;
+      f.type = static_cast<Cloudini::FieldType>(info->fields[i].type);
+      if (info->fields[i].has_resolution) f.resolution = info->fields[i].resolution;
+      pc.fields.push_back(f);
+    }
+    pc.point_step = info->point_step;
+    pc.width = info->point_step ? static_cast<uint32_t>(size / info->point_step) : 0;
+    pc.height = 1;
+    pc.row_step = pc.width * pc.point_step;
+    pc.data = Cloudini::ConstBufferView(data, size);
+    cloudini_ros::applyVizLossyPreprocessing(pc);
+    if (pc.data.size() > capacity) throw std::runtime_error("viz_preprocess: output capacity");
+    if (pc.data.size()) std::memcpy(out, pc.data.data(), pc.data.size());
+    for (uint32_t i = 0; i < info->n_fields; ++i)
+      res_out[i] = pc.fields[i].resolution ? *pc.fields[i].resolution : std::numeric_limits<float>::quiet_NaN();
+    *width_out = pc.width;
+    *height_out = pc.height;
+    return static_cast<int64_t>(pc.data.size());
   });
 }
 

@@ -17,6 +17,7 @@
 #include <thread>
 
 #include "cloudini_hip.h"
+#include "host_internal.hpp"
 #include "yaml_lite.hpp"
 
 // stage-2 libraries: only these entry points are used (prototypes instead of the vendor headers so that the build
@@ -624,5 +625,27 @@ void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compres
                              CLDN_HIP_HOST) != CLDN_HIP_OK)
     throw std::runtime_error(cldn_hip_last_error());
 }
+
+namespace amd_detail {
+
+uint64_t vizPreprocessOnDevice(const uint8_t* points, size_t n_points, uint32_t point_step, uint32_t xyz_offset,
+                               float resolution, uint8_t* out, size_t out_capacity) {
+  // any pooled codec can lend its device, stream and workspace; this schema is only the pool key
+  EncodingInfo ctx;
+  ctx.fields.push_back(PointField{"x", 0, FieldType::FLOAT32, 0.001f});
+  ctx.fields.push_back(PointField{"y", 4, FieldType::FLOAT32, 0.001f});
+  ctx.fields.push_back(PointField{"z", 8, FieldType::FLOAT32, 0.001f});
+  ctx.point_step = 12;
+  PlanHandle plan(ctx);
+  cldn_hip_codec_t* codec = pool().acquire(ctx, plan);
+  uint64_t kept = 0;
+  const int rc = cldn_hip_viz_preprocess(codec, points, CLDN_HIP_HOST, n_points, point_step, xyz_offset, resolution, out,
+                                         out_capacity, CLDN_HIP_HOST, &kept);
+  pool().release(ctx, codec);
+  if (rc != CLDN_HIP_OK) throwHip("applyVizLossyPreprocessing (HIP) failed");
+  return kept;
+}
+
+}  // namespace amd_detail
 
 }  // namespace Cloudini

@@ -1,12 +1,15 @@
 // CDR message adapters around PointcloudEncoder / PointcloudDecoder. Follows the reference's
 // cloudini_lib/src/ros_msg_utils.cpp (parse :54-97, header writer :99-121, toEncodingInfo :123-132,
-// decompress :135-165, compress :167-213, resolution profiles :217-238). The visualisation pre-filter
-// (applyVizLossyPreprocessing) is outside the stage-1 hot path and not part of this build.
+// decompress :135-165, compress :167-213, resolution profiles :217-238, applyVizLossyPreprocessing :249-341 -- its
+// data path runs on the GPU through cldn_hip_viz_preprocess).
 #include "cloudini_lib/ros_msg_utils.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
+
+#include "host_internal.hpp"
 
 namespace cloudini_ros {
 
@@ -128,6 +131,38 @@ void applyResolutionProfile(const ResolutionProfile& profile, std::vector<Cloudi
     const auto it = profile.find(f.name);
     if (it != profile.end()) f.resolution = it->second;
     else if (default_resolution && f.type == Cloudini::FieldType::FLOAT32) f.resolution = *default_resolution;
+  }
+}
+
+void applyVizLossyPreprocessing(RosPointCloud2& pc_info) {
+  // the gate of the reference, src/ros_msg_utils.cpp:250-279
+  if (pc_info.fields.size() < 3 || pc_info.point_step == 0) return;
+  const auto& f0 = pc_info.fields[0];
+  const auto& f1 = pc_info.fields[1];
+  const auto& f2 = pc_info.fields[2];
+  const bool has_triple = f0.type == Cloudini::FieldType::FLOAT32 && f1.type == Cloudini::FieldType::FLOAT32 &&
+                          f2.type == Cloudini::FieldType::FLOAT32 && f0.resolution.has_value() &&
+                          f1.resolution.has_value() && f2.resolution.has_value() &&
+                          f0.resolution.value() == f1.resolution.value() &&
+                          f0.resolution.value() == f2.resolution.value() && f1.offset == f0.offset + 4u &&
+                          f2.offset == f0.offset + 8u;
+  if (!has_triple) return;
+  const float xyz_res = f0.resolution.value();
+  if (!(xyz_res > 0.0f) || !std::isfinite(xyz_res)) return;
+  const size_t n_in = pc_info.data.size() == 0 ? 0 : pc_info.data.size() / pc_info.point_step;
+  if (n_in == 0) return;
+
+  std::vector<uint8_t> out(n_in * pc_info.point_step);
+  const uint64_t kept = Cloudini::amd_detail::vizPreprocessOnDevice(pc_info.data.data(), n_in, pc_info.point_step,
+                                                                   f0.offset, xyz_res, out.data(), out.size());
+  out.resize(static_cast<size_t>(kept) * pc_info.point_step);
+  pc_info.owned_data = std::move(out);
+  pc_info.data = Cloudini::ConstBufferView(pc_info.owned_data.data(), pc_info.owned_data.size());
+  pc_info.width = static_cast<uint32_t>(kept);
+  pc_info.height = 1;
+  pc_info.row_step = pc_info.point_step * pc_info.width;
+  for (auto& f : pc_info.fields) {  // :336-340
+    if (f.type == Cloudini::FieldType::FLOAT64 && !f.resolution.has_value()) f.resolution = 1e-6f;
   }
 }
 

@@ -67,4 +67,22 @@ int stage1_configure_kernels();
 int stage1_launch_encode(const EncodeLaunch& L);
 int stage1_launch_decode(const DecodeLaunch& L);
 
+// applyVizLossyPreprocessing (viz_kernels.hip)
+struct VizLaunch {
+  hipStream_t stream;
+  const uint8_t* points;          // device AoS
+  uint64_t n_points;              // < 2^32
+  uint32_t point_step;
+  uint32_t xyz_offset;
+  float inv_res;
+  unsigned long long* keys;       // device [viz_table_capacity(n_points)]
+  uint32_t* first;                // device [capacity]
+  uint32_t* slot_of;              // device [n_points]
+  uint32_t* block_count;          // device [ceil(n_points / 1024)]
+  unsigned long long* total;      // device: surviving points
+  uint8_t* out;                   // device [n_points * point_step]
+};
+uint64_t viz_table_capacity(uint64_t n_points);
+int viz_launch(const VizLaunch& L);
+
 }  // namespace cldn

@@ -81,6 +81,9 @@ def lib() -> C.CDLL:
     L.cldn_hip_codec_enable_timing.restype = C.c_int
     L.cldn_hip_codec_kernel_ms.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float)]
     L.cldn_hip_codec_kernel_ms.restype = C.c_int
+    L.cldn_hip_viz_preprocess.restype = C.c_int
+    L.cldn_hip_viz_preprocess.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, vp, C.c_uint64,
+                                          C.c_int, u64p]
     L.cldn_hip_codec_decode_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.cldn_hip_codec_decode_stats.restype = C.c_int
     L.cldn_hip_codec_force_modes.argtypes = [vp, C.POINTER(C.c_uint8), C.c_uint32]
@@ -166,6 +169,23 @@ class Codec:
 
     def status(self):
         _check(lib().cldn_hip_codec_status(self._h))
+
+    def viz_preprocess_host(self, cloud, point_step: int, xyz_offset: int, resolution: float) -> np.ndarray:
+        """applyVizLossyPreprocessing's data path on host buffers: the surviving points, order preserved."""
+        data = np.ascontiguousarray(cloud).view(np.uint8).reshape(-1)
+        n = data.size // point_step
+        out = np.empty(max(1, data.size), dtype=np.uint8)
+        kept = C.c_uint64(0)
+        _check(lib().cldn_hip_viz_preprocess(self._h, data.ctypes.data_as(C.c_void_p), HOST, n, point_step, xyz_offset,
+                                             resolution, out.ctypes.data_as(C.c_void_p), out.size, HOST, C.byref(kept)))
+        return out[: kept.value * point_step].copy()
+
+    def viz_preprocess_device(self, points_ptr: int, n_points: int, point_step: int, xyz_offset: int, resolution: float,
+                              out_ptr: int, out_capacity: int) -> int:
+        kept = C.c_uint64(0)
+        _check(lib().cldn_hip_viz_preprocess(self._h, C.c_void_p(points_ptr), DEVICE, n_points, point_step, xyz_offset,
+                                             resolution, C.c_void_p(out_ptr), out_capacity, DEVICE, C.byref(kept)))
+        return int(kept.value)
 
     def decode_stats(self):
         """Chunks of the last decode call per kernel: (fast regular, fast sections, serial chunks, serial sections)."""

@@ -55,6 +55,12 @@ int64_t cldn_amd_ros_compress(const uint8_t* dds, uint64_t size, float resolutio
 /* getDeserializedPointCloudMessage + convertCompressedCloudToPointCloud2 */
 int64_t cldn_amd_ros_decompress(const uint8_t* dds, uint64_t size, uint8_t* out, uint64_t capacity);
 
+/* cloudini_ros::applyVizLossyPreprocessing on a bare point buffer (fields / point_step of `info`; width, height are
+ * derived from size): out receives the surviving points (capacity >= size), res_out[i] the resolution of field i
+ * afterwards (NaN = none), *width_out / *height_out the new shape. Returns the surviving byte count. */
+int64_t cldn_amd_viz_preprocess(const cldn_amd_info_t* info, const uint8_t* data, uint64_t size, uint8_t* out,
+                                uint64_t capacity, float* res_out, uint32_t* width_out, uint32_t* height_out);
+
 #ifdef __cplusplus
 }
 #endif

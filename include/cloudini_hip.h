@@ -123,6 +123,17 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* codec, const void* streams, int str
                            const uint64_t* stream_offsets, const uint64_t* cloud_points, uint32_t n_clouds,
                            void* points_out, uint64_t out_capacity, int out_loc);
 
+/* cloudini_ros::applyVizLossyPreprocessing, data path (include/cloudini_lib/ros_msg_utils.hpp:175-221,
+ * src/ros_msg_utils.cpp:249-341) -- the step right in front of the encoder in the rosbag converter
+ * (tools/src/mcap_converter.cpp:195-197): points with a non-finite x, y or z (three float32 at xyz_offset, +4, +8) are
+ * dropped; of the points that fall into the same voxel (lround(v * (1.0f / resolution)) per axis) only the first
+ * one survives; survivors keep their order and all their bytes. `out` must hold n_points * point_step bytes;
+ * *kept_points (HOST) receives the survivor count. The call synchronises the codec's stream. The codec only lends
+ * its device, stream and workspace: its plan is not used. */
+int cldn_hip_viz_preprocess(cldn_hip_codec_t* codec, const void* points, int points_loc, uint64_t n_points,
+                            uint32_t point_step, uint32_t xyz_offset, float resolution, void* out,
+                            uint64_t out_capacity, int out_loc, uint64_t* kept_points);
+
 /* Which kernels the last cldn_hip_decode_stage1 call used, in chunks (synchronises):
  *   stats[0] regular stream by the parallel decoder      stats[1] V5 sections by the parallel decoder
  *   stats[2] whole chunks by the serial decoder          stats[3] only the sections by the serial decoder */

@@ -89,6 +89,14 @@ void applyResolutionProfile(const ResolutionProfile& profile, std::vector<Cloudi
 
 Cloudini::EncodingInfo toEncodingInfo(const RosPointCloud2& pc_info);
 
+// Visualisation-oriented lossy pre-filter that runs in front of the encoder (reference ros_msg_utils.hpp:175-221):
+// if the first three fields are FLOAT32 with one shared resolution and offsets {b, b+4, b+8}, points with a
+// non-finite coordinate are dropped and of all points of one voxel (at that resolution) only the first is kept,
+// order preserved -- on the GPU (cldn_hip_viz_preprocess). pc_info.owned_data receives the surviving points, data
+// views it, width = survivors, height = 1, row_step = point_step * width; FLOAT64 fields without a resolution get
+// 1e-6. No-op without such a triple, with a non-positive / non-finite resolution, or with an empty cloud.
+void applyVizLossyPreprocessing(RosPointCloud2& pc_info);
+
 void writePointCloudHeader(nanocdr::Encoder& encoder, const RosPointCloud2& pc_info);
 
 // sensor_msgs/PointCloud2 or CompressedPointCloud2 (same layout up to `data`) -> RosPointCloud2

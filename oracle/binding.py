@@ -76,6 +76,9 @@ class Oracle:
         L.orc_encode_stage1_continued.restype = C.c_int64
         L.orc_encode_stage1_continued.argtypes = [C.POINTER(_OrcSchema), C.POINTER(C.c_uint8), C.c_uint64,
                                                   C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_uint8), C.c_uint32]
+        L.orc_viz_preprocess.restype = C.c_int64
+        L.orc_viz_preprocess.argtypes = [C.POINTER(C.c_uint8), C.c_uint64, C.c_uint32, C.c_uint32, C.c_float,
+                                         C.POINTER(C.c_uint8)]
         L.orc_decode_stage1.restype = C.c_int64
         L.orc_decode_stage1.argtypes = [C.POINTER(_OrcSchema), C.POINTER(C.c_uint8), C.c_uint64, C.c_uint64,
                                         C.POINTER(C.c_uint8)]
@@ -151,6 +154,17 @@ class Oracle:
             raise OracleError(f"orc_encode_stage1_continued failed: {r}")
         return out[:r].copy()
 
+    def viz_preprocess(self, cloud, point_step: int, xyz_offset: int, resolution: float) -> np.ndarray:
+        """Surviving points of applyVizLossyPreprocessing's data path (orc_viz_preprocess)."""
+        data = _as_u8(cloud)
+        n = data.size // point_step
+        out = np.empty(max(1, data.size), dtype=np.uint8)
+        r = self.lib.orc_viz_preprocess(_ptr(data) if data.size else None, n, point_step, xyz_offset, resolution,
+                                        _ptr(out))
+        if r < 0:
+            raise OracleError(f"orc_viz_preprocess failed: {r}")
+        return out[: r * point_step].copy()
+
     def decode_stage1(self, info, stream, n_points: int, fill: int = 0) -> np.ndarray:
         st = _as_u8(stream)
         s, _keep = self._schema(info)
@@ -207,6 +221,10 @@ class RefLib:
         L.ref_ros_describe.restype = C.c_int64
         L.ref_ros_describe.argtypes = [C.POINTER(C.c_uint8), C.c_uint64, C.c_char_p, C.c_uint64,
                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.ref_viz_preprocess.restype = C.c_int64
+        L.ref_viz_preprocess.argtypes = [C.POINTER(_RefField), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint64,
+                                         C.POINTER(C.c_uint8), C.c_uint64, C.POINTER(C.c_float),
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.ref_bench_encode.restype = C.c_int64
         L.ref_bench_encode.argtypes = common + [C.c_uint8, C.POINTER(C.c_uint8), C.c_uint64, C.c_uint32,
                                                 C.c_uint32, C.POINTER(C.c_double)]
@@ -315,6 +333,19 @@ class RefLib:
         if r < 0:
             self._err("ros_describe")
         return text.value.decode(), int(off.value), int(size.value)
+
+    def viz_preprocess(self, info, cloud):
+        """applyVizLossyPreprocessing of the reference: (surviving bytes, per-field resolution afterwards, width, height)."""
+        data = _as_u8(cloud)
+        arr, keep = self._fields(info)
+        out = np.empty(max(1, data.size), dtype=np.uint8)
+        res = (C.c_float * max(1, len(info.fields)))()
+        w, h = C.c_uint32(0), C.c_uint32(0)
+        r = self.lib.ref_viz_preprocess(arr, len(info.fields), int(info.point_step), _ptr(data) if data.size else None,
+                                        data.size, _ptr(out), out.size, res, C.byref(w), C.byref(h))
+        if r < 0:
+            self._err("ref_viz_preprocess")
+        return out[:r].copy(), [float(x) for x in res][: len(info.fields)], int(w.value), int(h.value)
 
     def bench_encode(self, info, cloud, reps: int = 10, threads: int = 1):
         data = _as_u8(cloud)

@@ -1075,3 +1075,50 @@ out_label:
   free(af);
   return result;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * applyVizLossyPreprocessing -- src/ros_msg_utils.cpp:249-341 (voxel key: packVoxelKey21, :42-49)
+ * ---------------------------------------------------------------------------------------------- */
+static uint64_t viz_key(float fx, float fy, float fz, float inv_res) {
+  /* static_cast<int32_t>(std::lround(f * inv_res)): float product, lround -> long, truncated to 32 bits */
+  const int32_t q[3] = {(int32_t)lroundf(fx * inv_res), (int32_t)lroundf(fy * inv_res), (int32_t)lroundf(fz * inv_res)};
+  uint64_t key = 0;
+  for (int a = 0; a < 3; ++a) {
+    const uint64_t u = (uint64_t)((int64_t)q[a] + ((int64_t)1 << 20)) & (((uint64_t)1 << 21) - 1u);
+    key |= u << (21 * a);
+  }
+  return key;
+}
+
+int64_t orc_viz_preprocess(const uint8_t* data, uint64_t n_points, uint32_t point_step, uint32_t xyz_offset,
+                           float resolution, uint8_t* out) {
+  if (point_step == 0 || xyz_offset + 12u > point_step || (!data && n_points) || (!out && n_points)) return ORC_ERR_ARG;
+  if (!(resolution > 0.0f) || !isfinite(resolution)) return ORC_ERR_ARG;
+  const float inv_res = 1.0f / resolution;
+  /* open addressing, keys + 1 so that 0 marks a free slot (keys have 63 bits) */
+  uint64_t cap = 16;
+  while (cap < 2 * n_points + 2) cap <<= 1;
+  uint64_t* table = (uint64_t*)calloc(cap, sizeof(uint64_t));
+  if (!table) return ORC_ERR_NOMEM;
+  uint64_t kept = 0;
+  for (uint64_t i = 0; i < n_points; ++i) {
+    const uint8_t* p = data + i * point_step;
+    float f[3];
+    memcpy(f, p + xyz_offset, 12);
+    if (!isfinite(f[0]) || !isfinite(f[1]) || !isfinite(f[2])) continue;
+    const uint64_t key = viz_key(f[0], f[1], f[2], inv_res) + 1u;
+    uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> 17;
+    int dup = 0;
+    for (;;) {
+      h &= cap - 1;
+      if (table[h] == 0) { table[h] = key; break; }
+      if (table[h] == key) { dup = 1; break; }
+      ++h;
+    }
+    if (dup) continue;
+    memcpy(out + kept * point_step, p, point_step);
+    ++kept;
+  }
+  free(table);
+  return (int64_t)kept;
+}

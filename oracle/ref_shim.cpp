@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <thread>
 #include <vector>
@@ -231,6 +232,48 @@ REF_API int64_t ref_ros_describe(
     *data_offset = static_cast<uint64_t>(pc.data.data() - dds);
     *data_size = pc.data.size();
     return static_cast<int64_t>(yaml.size());
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return -1;
+  }
+}
+
+// applyVizLossyPreprocessing (ros_msg_utils.hpp:175-221, src/ros_msg_utils.cpp:249-341) on a bare point buffer.
+// out receives the surviving points (capacity >= data_size); res_out[i] = resolution of field i afterwards
+// (NaN = none), so that the FLOAT64 -> 1 us rule is visible. Returns the surviving byte count, or -1.
+REF_API int64_t ref_viz_preprocess(
+    const RefField* fields, uint32_t n_fields, uint32_t point_step, const uint8_t* data, uint64_t data_size,
+    uint8_t* out, uint64_t out_capacity, float* res_out, uint32_t* width_out, uint32_t* height_out) {
+  try {
+    cloudini_ros::RosPointCloud2 pc;
+    for (uint32_t i = 0; i < n_fields; ++i) {
+      Cloudini::PointField f;
+      f.name = fields[i].name ? fields[i].name : "";
+      f.offset = fields[i].offset;
+      f.type = static_cast<Cloudini::FieldType>(fields[i].type);
+      if (fields[i].has_resolution) {
+        f.resolution = fields[i].resolution;
+      }
+      pc.fields.push_back(f);
+    }
+    pc.point_step = point_step;
+    pc.width = point_step ? static_cast<uint32_t>(data_size / point_step) : 0;
+    pc.height = 1;
+    pc.row_step = pc.width * point_step;
+    pc.data = Cloudini::ConstBufferView(data, data_size);
+    cloudini_ros::applyVizLossyPreprocessing(pc);
+    if (pc.data.size() > out_capacity) {
+      g_last_error = "ref_viz_preprocess: output capacity";
+      return -1;
+    }
+    if (pc.data.size()) memcpy(out, pc.data.data(), pc.data.size());
+    for (uint32_t i = 0; i < n_fields; ++i) {
+      res_out[i] = pc.fields[i].resolution.has_value() ? pc.fields[i].resolution.value()
+                                                       : std::numeric_limits<float>::quiet_NaN();
+    }
+    *width_out = pc.width;
+    *height_out = pc.height;
+    return static_cast<int64_t>(pc.data.size());
   } catch (const std::exception& e) {
     g_last_error = e.what();
     return -1;
