@@ -235,3 +235,38 @@ def test_mode_hints_never_change_the_bytes(oracle):
         seen.add(int(want_modes[0]))
     assert seen == {0, 1, 2, 3}
     codec.close()
+
+
+def test_one_codec_many_shapes_interleaved_with_decode(oracle):
+    """Workspace and cached batch shapes: one codec, a random walk over batch shapes, encode and decode interleaved,
+    forced modes toggled in between, every result checked."""
+    from cloudini_amd import native
+    rs = np.random.RandomState(123)
+    info, _ = synth.lidar_xyzi(10, seed=0)
+    pool = {n: synth.lidar_xyzi(n, seed=200 + n % 97)[1] for n in (0, 1, 63, 1000, 4096, 4097, 32768, 33000, 70000, 140000)}
+    codec = native.Codec(native.Plan(info))
+    step = info.point_step
+    last_streams, last_counts = None, None
+    for it in range(40):
+        k = rs.randint(1, 6)
+        sizes = [int(rs.choice(list(pool))) for _ in range(k)]
+        clouds = [pool[n] for n in sizes]
+        action = rs.randint(0, 4)
+        if action == 3 and last_streams is not None:
+            out = np.full(max(1, sum(last_counts) * step), 0x77, dtype=np.uint8)
+            got = codec.decode_host(last_streams, last_counts, out=out)
+            for s, cnt, g in zip(last_streams, last_counts, got):
+                assert np.array_equal(g, oracle.decode_stage1(info, s, cnt, fill=0x77)), f"iteration {it}"
+            continue
+        if action == 2:
+            codec.force_modes([int(rs.randint(0, 4))])
+        streams, _cs, modes = codec.encode_host(clouds)
+        for c, s, m in zip(clouds, streams, modes):
+            if action == 2:
+                want = oracle.encode_stage1_continued(info, c, [int(m[0])])
+            else:
+                want = oracle.encode_stage1(info, c)
+            assert np.array_equal(s, want), f"iteration {it}, sizes {sizes}"
+        codec.force_modes(None)
+        last_streams, last_counts = streams, sizes
+    codec.close()
