@@ -1673,7 +1673,7 @@ int stage1_configure_kernels() {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSecLdsTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_sections)");
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_probe_fast), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)kS2PalLds);
+                          (int)kProbeLds);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_probe_fast)");
   const void* pk[] = {reinterpret_cast<const void*>(&k_section_palette<uint16_t>),
                       reinterpret_cast<const void*>(&k_section_palette<uint32_t>),
@@ -1748,15 +1748,15 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
     if (!L.modes_forced) {
       if (!no_fast) {
-        hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na), dim3(kS2Threads), kS2PalLds, L.stream, *L.plan, L.chunks,
+        hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na), dim3(kS2Threads), kProbeLds, L.stream, *L.plan, L.chunks,
                            L.cloud_first_chunk, L.cols, L.modes);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_fast");
-      } else {
+      } else {  // A/B switch: the general probe decides every mode
         (void)hipMemsetAsync(L.modes, 0xff, (size_t)L.n_clouds * na, L.stream);
+        hipLaunchKernelGGL(k_probe_modes, dim3(L.n_clouds, na), dim3(kSecThreads), kSecLdsTotal, L.stream, *L.plan,
+                           L.chunks, L.cloud_first_chunk, L.cols, L.modes);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_modes");
       }
-      hipLaunchKernelGGL(k_probe_modes, dim3(L.n_clouds, na), dim3(kSecThreads), kSecLdsTotal, L.stream, *L.plan,
-                         L.chunks, L.cloud_first_chunk, L.cols, L.modes);
-      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_modes");
     }
     for (uint32_t a = 0; a < na && !no_fast; ++a) {
       const uint32_t bpv = L.plan->adaptive[a].bpv;

@@ -15,6 +15,8 @@ constexpr int kS2Threads = 1024;
 constexpr uint32_t kS2PalSlots = 4096;
 constexpr uint32_t kS2PalCapacity = 3072;  // load factor 0.75
 constexpr uint32_t kInf = 0xffffffffu;
+constexpr uint32_t kProbeSlots = 8192;                       // mode probe: distinct-value count of <= 4096 values
+constexpr uint32_t kProbeLds = kProbeSlots * 8u + 16u + 256u;  // keys, counters, scan scratch
 
 struct Pal2 {
   unsigned long long* keys;  // [kS2PalSlots]      ~0 = free
@@ -48,6 +50,7 @@ __device__ __forceinline__ void pal2_insert(const Pal2 p, RawT raw, uint32_t ind
     slot = hash_u64(v) & (kS2PalSlots - 1u);
     uint32_t probes = 0u;
     for (;;) {
+      if (p.misc[0] > kS2PalCapacity) return;  // over capacity: the caller gives the chunk up; do not fill the table
       const unsigned long long k = p.keys[slot];
       if (k == v) break;
       if (k == ~0ull) {
@@ -143,8 +146,7 @@ __device__ __forceinline__ uint32_t block_suffix_min_exclusive(uint32_t mine, ui
 template <typename RawT>
 __device__ __forceinline__ uint8_t probe_mode(const RawT* col, uint32_t n, uint32_t type, uint8_t* smem) {
   constexpr int T = kS2Threads;
-  const Pal2 p = pal2_carve(smem);
-  uint32_t* wtot = p.wtot;
+  uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + kProbeSlots * 8u + 16u);  // behind the key table and its counters
   const uint32_t t0 = threadIdx.x * 4u;
   const uint32_t cnt = t0 < n ? min(4u, n - t0) : 0u;
   RawT v[4];
@@ -207,18 +209,39 @@ __device__ __forceinline__ uint8_t probe_mode(const RawT* col, uint32_t n, uint3
   const uint32_t rle_size = run_bytes(hr, false);
   const uint32_t drle_size = run_bytes(hd, true);
 
-  // Palette: distinct values through the LDS hash table
-  for (uint32_t s = threadIdx.x; s < kS2PalSlots; s += T) p.keys[s] = ~0ull;
-  for (uint32_t s = threadIdx.x; s <= kS2PalSlots; s += T) p.first[s] = kInf;
-  if (threadIdx.x < 4u) p.misc[threadIdx.x] = 0u;
+  // Palette: number of distinct values, exact for any window: 8192 key slots for at most 4096 values keep the load
+  // below one half, so probe sequences stay short and the table cannot fill up
+  __syncthreads();
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+  uint32_t* cnt_l = reinterpret_cast<uint32_t*>(smem + kProbeSlots * 8u);  // [0] distinct keys, [1] the value ~0 seen
+  for (uint32_t s = threadIdx.x; s < kProbeSlots; s += T) keys[s] = ~0ull;
+  if (threadIdx.x < 2u) cnt_l[threadIdx.x] = 0u;
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if ((uint32_t)j < cnt) pal2_insert<RawT>(p, v[j], t0 + (uint32_t)j);
+  for (int j = 0; j < 4; ++j) {
+    if ((uint32_t)j < cnt) {
+      const unsigned long long key = (unsigned long long)v[j];
+      if (sizeof(RawT) == 8 && key == ~0ull) {
+        cnt_l[1] = 1u;
+      } else {
+        uint32_t slot = (sizeof(RawT) == 8 ? hash_u64(key) : ((uint32_t)key * 0x9e3779b1u) >> 19) & (kProbeSlots - 1u);
+        for (;;) {
+          unsigned long long k = keys[slot];
+          if (k == ~0ull) {
+            k = atomicCAS(&keys[slot], ~0ull, key);
+            if (k == ~0ull) {
+              atomicAdd(&cnt_l[0], 1u);
+              break;
+            }
+          }
+          if (k == key) break;
+          slot = (slot + 1u) & (kProbeSlots - 1u);
+        }
+      }
+    }
+  }
   __syncthreads();
-  uint32_t U = p.misc[0];
-  if (sizeof(RawT) == 8 && p.first[kS2PalSlots] != kInf) ++U;  // the value ~0 lives outside the key table
-  if (p.misc[1] != 0u || p.misc[0] > kS2PalCapacity) return 0xffu;  // too many distinct values for this table
+  const uint32_t U = cnt_l[0] + cnt_l[1];
   const uint32_t pal_size = 3u + U * (uint32_t)sizeof(RawT) + ((palette_bits(U) * n + 7u) >> 3);
 
   uint32_t mode = 0u, best = delta_size;  // strict '<' in this order
@@ -228,8 +251,7 @@ __device__ __forceinline__ uint8_t probe_mode(const RawT* col, uint32_t n, uint3
   return (uint8_t)mode;
 }
 
-// grid = (n_clouds, n_adaptive). Writes 0xff when the window has more distinct values than the table holds; the
-// general probe kernel then redoes that (cloud, field).
+// grid = (n_clouds, n_adaptive). Exact for every window (the general probe kernel is only the A/B reference).
 __global__ __launch_bounds__(kS2Threads) void k_probe_fast(const DevPlan plan, const ChunkDesc* __restrict__ chunks,
                                                            const uint32_t* __restrict__ cloud_first_chunk,
                                                            const ColumnPtrs cols, uint8_t* __restrict__ modes) {
@@ -437,6 +459,7 @@ struct Pal32 {
     uint32_t slot = home(v);
     uint32_t probes = 0u;
     for (;;) {
+      if (misc[0] > kS2PalCapacity) return;  // over capacity: the chunk is given up anyway; do not fill the table
       if (w == kFree) {
         w = atomicCAS(&tab[slot], kFree, mine);
         if (w == kFree) {
