@@ -511,8 +511,19 @@ __device__ __forceinline__ void ring_flush_n(uint32_t* ring, uint8_t* dst, uint3
 
 constexpr uint32_t kStagedCols = 2;  // adaptive fields (2 or 4 bytes wide) whose SoA copy is staged through LDS
 
-__device__ __forceinline__ bool col_staged(const DevPlan& plan, uint32_t a, bool from_regs) {
-  return from_regs && a < kStagedCols && plan.adaptive[a].bpv <= 4u;
+// adaptive field `a` lies completely inside the `loadw` dwords loaded behind the first float lane. The host picks
+// loadw so that this holds for every field (floatn_loadw) -- except for the padded-fourth-lane layout, whose window
+// is fixed at 8 dwords: CHECK turns the test on for that instantiation only (it costs registers in the others).
+template <bool CHECK>
+__device__ __forceinline__ bool col_in_regs(const DevPlan& plan, uint32_t a, int loadw) {
+  if (!CHECK) return true;
+  const uint32_t off = plan.adaptive[a].offset, off0 = plan.ops[0].offset;
+  return off >= off0 && off - off0 + plan.adaptive[a].bpv <= (uint32_t)loadw * 4u;
+}
+// ... and its SoA copy goes through the LDS staging area
+template <bool CHECK>
+__device__ __forceinline__ bool col_staged(const DevPlan& plan, uint32_t a, int loadw, int lanes) {
+  return loadw > lanes && a < kStagedCols && plan.adaptive[a].bpv <= 4u && col_in_regs<CHECK>(plan, a, loadw);
 }
 
 // bytes [rel, rel + 8) of the dwords loaded for one point (rel + field size <= 4 * LOADW, guaranteed by the host)
@@ -531,7 +542,9 @@ __device__ __forceinline__ uint64_t field_from_regs(const FloatVec<LOADW>& pt, u
 // UNAL: points are not 4-byte aligned (odd point_step / offset / base, e.g. packed 18-byte points): every lane loads
 // LOADW + 1 dwords from the aligned address below its point and realigns them with v_alignbyte; the dwords may reach
 // into the next point, so only the last points of the whole batch need the guarded path (points_end).
-template <int T, int LANES, int PPT, uint32_t RING_BYTES, int LOADW, bool PREFETCH = true, bool UNAL = false>
+// L3: dword (behind the first lane) of the fourth lane -- 3 for x y z w back to back, 4 for the PCL / Ouster layout
+// "x y z <pad> intensity" (the fused encoder takes any four offsets, src/field_encoder.cpp:24-40).
+template <int T, int LANES, int PPT, uint32_t RING_BYTES, int LOADW, bool PREFETCH = true, bool UNAL = false, int L3 = 3>
 __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const uint8_t* __restrict__ points,
                                                      const uint8_t* __restrict__ points_end,
                                                      const ChunkDesc* __restrict__ chunks,
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
         // sides, r - r_prev, 2d + 0.5 and |.| + 0.5 are all exact, and zigzag(d) + 1 == |2d + 0.5| + 0.5. Anything
         // else (NaN, Inf, |r| >= 2^21 ticks) marks the row rare. The neighbour's r travels negated so that the DPP
         // move folds into a commutative add (hipcc's v_subrev_*_dpp returned the operands swapped on gfx950).
-        const float r = rintf(__fmul_rn(cur[j].v[k], mult[k]));
+        const float r = rintf(__fmul_rn(cur[j].v[(LANES == 4 && k == 3) ? L3 : k], mult[k]));
         rare |= !(fabsf(r) < 2097152.0f);
         const float nrp = __uint_as_float(dpp_wave_shr1(__float_as_uint(r) ^ 0x80000000u));
         const float uf = fabsf(__fmaf_rn(__fadd_rn(r, nrp), 2.0f, 0.5f)) + 0.5f;
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
 #pragma unroll
         for (int k = 0; k < LANES; ++k) {
           if (!NAN_TIER) break;
-          const float v = cur[j].v[k];
+          const float v = cur[j].v[(LANES == 4 && k == 3) ? L3 : k];
           const bool isn = is_nan_f32(v);
           const float r = isn ? 0.0f : rintf(__fmul_rn(v, mult[k]));
           hard |= !(fabsf(r) < 2097152.0f);
@@ -678,7 +691,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
           total = 0u;
 #pragma unroll
           for (int k = 0; k < LANES; ++k) {
-            const float v = cur[j].v[k];
+            const float v = cur[j].v[(LANES == 4 && k == 3) ? L3 : k];
             const bool isn = is_nan_f32(v);
             const int32_t q = quant_rne_i32(v, mult[k]);
             const uint32_t nqp = dpp_wave_shr1(isn ? 0u : (0u - (uint32_t)q));  // a NaN resets that lane's reference
@@ -711,7 +724,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
 
     if (plan.n_adaptive && LOADW > LANES && !(ablate & 1u)) {
       for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
-        if (!col_staged(plan, a, true) || (ablate & 16u)) continue;
+        if (!col_staged<L3 == 4>(plan, a, LOADW, LANES) || (ablate & 16u)) continue;
         const uint32_t bpv = plan.adaptive[a].bpv;
         uint8_t* st = colstage + (size_t)a * (TILE * 4u);
 #pragma unroll
@@ -739,7 +752,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
         if (__builtin_expect((rare_rows & (1u << j)) != 0u, 0)) {  // wave-uniform: rebuild the general tokens (all lanes take part in the DPP)
 #pragma unroll
           for (int k = 0; k < LANES; ++k) {
-            const float v = cur[j].v[k];
+            const float v = cur[j].v[(LANES == 4 && k == 3) ? L3 : k];
             const bool isn = is_nan_f32(v);
             const int32_t q = quant_rne_i32(v, mult[k]);
             const uint32_t nqp = dpp_wave_shr1(isn ? 0u : (0u - (uint32_t)q));
@@ -769,7 +782,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
         for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
           const uint32_t bpv = plan.adaptive[a].bpv;
           uint8_t* gcol = cols.p[a] + (first_point + base) * bpv;
-          const bool staged = col_staged(plan, a, LOADW > LANES) && (((uintptr_t)gcol & 15u) == 0u) && !(ablate & 16u);
+          const bool staged = col_staged<L3 == 4>(plan, a, LOADW, LANES) && (((uintptr_t)gcol & 15u) == 0u) && !(ablate & 16u);
           if (staged) {
             const uint8_t* st = colstage + (size_t)a * (TILE * 4u);
             const uint32_t bytes = tile_pts * bpv;
@@ -786,7 +799,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
               const size_t gi = first_point + (size_t)idx;
               uint8_t* col = cols.p[a];
               uint64_t raw;
-              if (LOADW > LANES) {
+              if (LOADW > LANES && col_in_regs<L3 == 4>(plan, a, LOADW)) {
                 raw = field_from_regs<LOADW>(cur[j], plan.adaptive[a].offset - plan.ops[0].offset);
               } else {
                 const uint8_t* fp = points + gi * step + plan.adaptive[a].offset;
@@ -846,7 +859,7 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
 #pragma unroll
     for (int j = 0; j < PPT; ++j)
 #pragma unroll
-      for (int k = 0; k < LANES; ++k) any_nan |= is_nan_f32(cur[j].v[k]);
+      for (int k = 0; k < LANES; ++k) any_nan |= is_nan_f32(cur[j].v[(LANES == 4 && k == 3) ? L3 : k]);
     if (__syncthreads_or(any_nan ? 1 : 0)) run_tiles(std::true_type{});
     else run_tiles(std::false_type{});
   } else {
@@ -1609,11 +1622,18 @@ constexpr uint32_t kFloatnRing = 16384;  // >= one tile of 3-lane points at 5 by
 constexpr uint32_t kFloatnLds = kFloatnRing + 256u + kStagedCols * (4u * 63u * 2u) * 4u + 64u;  // ring, wtot, staged columns (TILE = 504)
 
 // FloatN fast path: the regular stream is exactly one fused 3/4-lane float encoder on a 4-byte aligned layout
-int floatn_lanes(const DevPlan& p, const uint8_t* points) {
+// lanes of the fused FloatN encoder the fast kernel can take (0 = none); *l3 = dword of the fourth lane
+int floatn_lanes(const DevPlan& p, const uint8_t* points, int* l3) {
   const uint32_t lanes = p.n_ops;
+  *l3 = 3;
   if (lanes != 3u && lanes != 4u) return 0;
   for (uint32_t k = 0; k < lanes; ++k) {
-    if (p.ops[k].kind != OP_QF32 || p.ops[k].offset != p.ops[0].offset + 4u * k) return 0;
+    if (p.ops[k].kind != OP_QF32) return 0;
+    if (k < 3u && p.ops[k].offset != p.ops[0].offset + 4u * k) return 0;
+  }
+  if (lanes == 4u) {
+    if (p.ops[3].offset == p.ops[0].offset + 16u) *l3 = 4;
+    else if (p.ops[3].offset != p.ops[0].offset + 12u) return 0;
   }
   return (int)lanes;
 }
@@ -1623,7 +1643,8 @@ bool floatn_unaligned(const DevPlan& p, const uint8_t* points) {
 }
 
 // dwords to load per point so that every adaptive-int field is covered by the point load (0 = not possible)
-int floatn_loadw(const DevPlan& p, int lanes, bool unal) {
+int floatn_loadw(const DevPlan& p, int lanes, bool unal, int l3) {
+  if (l3 == 4) return (!unal && p.ops[0].offset + 32u <= p.point_step) ? 8 : 0;  // one variant: aligned, 8 dwords
   if (p.n_adaptive == 0) return unal && lanes == 3 ? 4 : lanes;
   uint32_t need = (uint32_t)lanes * 4u;
   const uint32_t off0 = p.ops[0].offset;
@@ -1661,7 +1682,8 @@ int stage1_configure_kernels() {
                       reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 2, kFloatnRing, 4, false, true>),
                       reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 2, kFloatnRing, 8, false, true>),
                       reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 2, kFloatnRing, 5, false, true>),
-                      reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 2, kFloatnRing, 8, false, true>)};
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 2, kFloatnRing, 8, false, true>),
+                      reinterpret_cast<const void*>(&k_encode_floatn<256, 4, 2, kFloatnRing, 8, false, false, 4>)};
   for (const void* f : fk) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFloatnLds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_floatn)");
@@ -1716,15 +1738,20 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_gorilla_tokens");
   }
   if (L.n_chunks) {
-    const int lanes = floatn_lanes(*L.plan, L.points);
+    int l3 = 3;
+    const int lanes = floatn_lanes(*L.plan, L.points, &l3);
     static const uint32_t ablate = getenv("CLDN_HIP_ABLATE") ? (uint32_t)atoi(getenv("CLDN_HIP_ABLATE")) : 0u;  // profiling only
     const bool unal = lanes && floatn_unaligned(*L.plan, L.points);
-    const int loadw = lanes ? floatn_loadw(*L.plan, lanes, unal) : 0;
+    const int loadw = lanes ? floatn_loadw(*L.plan, lanes, unal, l3) : 0;
+    // LDS: ring, scan scratch and one staging area per adaptive field that can be staged (at most kStagedCols)
+    const uint32_t floatn_lds = kFloatnRing + 256u + std::min<uint32_t>(L.plan->n_adaptive, kStagedCols) * (4u * 63u * 2u) * 4u + 64u;
 #define LAUNCH_FLOATN(TT, LL, PP, ...)                                                                                          \
-  hipLaunchKernelGGL((k_encode_floatn<TT, LL, PP, kFloatnRing, __VA_ARGS__>), dim3(L.n_chunks * L.subs), dim3(TT), kFloatnLds, \
+  hipLaunchKernelGGL((k_encode_floatn<TT, LL, PP, kFloatnRing, __VA_ARGS__>), dim3(L.n_chunks * L.subs), dim3(TT), floatn_lds, \
                      L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots, L.slot_stride, L.segs,          \
                      L.segs_per_chunk, L.cols, L.subs, L.sub_points, L.sub_stride, ablate)
-    if (unal && lanes == 3 && loadw == 4) LAUNCH_FLOATN(256, 3, 2, 4, false, true);
+    if (l3 == 4 && loadw == 8) LAUNCH_FLOATN(256, 4, 2, 8, false, false, 4);
+    else if (l3 == 4) goto generic_regular;
+    else if (unal && lanes == 3 && loadw == 4) LAUNCH_FLOATN(256, 3, 2, 4, false, true);
     else if (unal && lanes == 3 && loadw == 8) LAUNCH_FLOATN(256, 3, 2, 8, false, true);
     else if (unal && lanes == 4 && loadw == 5) LAUNCH_FLOATN(256, 4, 2, 5, false, true);
     else if (unal && lanes == 4 && loadw == 8) LAUNCH_FLOATN(256, 4, 2, 8, false, true);
@@ -1733,10 +1760,12 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     else if (lanes == 3 && loadw == 8) LAUNCH_FLOATN(256, 3, 2, 8, false);
     else if (lanes == 4 && loadw == 4) LAUNCH_FLOATN(256, 4, 2, 4, false);
     else if (lanes == 4 && loadw == 8) LAUNCH_FLOATN(256, 4, 2, 8, false);
-    else
+    else {
+    generic_regular:
       hipLaunchKernelGGL(k_encode_regular<kRegularThreads>, dim3(L.n_chunks * L.subs), dim3(kRegularThreads),
                          kRegularLds, L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots, L.slot_stride,
                          L.segs, L.segs_per_chunk, L.cols, L.subs, L.sub_points, L.sub_stride, L.pre);
+    }
 #undef LAUNCH_FLOATN
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_regular/floatn");
   }

@@ -230,6 +230,31 @@ def float_domain_boundary(n=30000, seed=53, lanes=3, with_u16=False):
     return info, pack(info, cols, n)
 
 
+def padded_fourth_lane(kind, n=90000, seed=61):
+    """Real-world layouts whose fused FloatN encoder has its 4th lane one dword further: PCL PointXYZI (x y z pad
+    intensity@16, 32-byte points) and an Ouster-style 48-byte point with five integer channels behind the floats."""
+    rs = np.random.RandomState(seed)
+    _, xyz = synth.lidar_xyz(n, seed=seed)
+    p = xyz.view(np.float32).reshape(n, 3).copy()
+    p[rs.randint(0, n, 50)] = np.nan
+    inten = rs.randint(0, 256, n).astype(np.float32)
+    inten[rs.randint(0, n, 30)] = np.nan
+    if kind == "pcl_xyzi":
+        fields = [("x", 0, F.FLOAT32, 0.001), ("y", 4, F.FLOAT32, 0.001), ("z", 8, F.FLOAT32, 0.001),
+                  ("intensity", 16, F.FLOAT32, 0.01)]
+        info = make_info(fields, 32, n)
+        return info, pack(info, {"x": p[:, 0], "y": p[:, 1], "z": p[:, 2], "intensity": inten}, n)
+    fields = [("x", 0, F.FLOAT32, 0.001), ("y", 4, F.FLOAT32, 0.001), ("z", 8, F.FLOAT32, 0.001),
+              ("intensity", 16, F.FLOAT32, 0.001), ("t", 20, F.UINT32, None), ("reflectivity", 24, F.UINT16, None),
+              ("ring", 26, F.UINT16, None), ("ambient", 28, F.UINT16, None), ("range", 32, F.UINT32, None)]
+    info = make_info(fields, 48, n)
+    cols = {"x": p[:, 0], "y": p[:, 1], "z": p[:, 2], "intensity": inten, "t": (np.arange(n) * 97).astype(np.uint32),
+            "reflectivity": rs.randint(0, 256, n).astype(np.uint16), "ring": (np.arange(n) % 64).astype(np.uint16),
+            "ambient": rs.randint(0, 5000, n).astype(np.uint16),
+            "range": (np.nan_to_num(np.linalg.norm(p, axis=1)) * 1000).astype(np.uint32)}
+    return info, pack(info, cols, n)
+
+
 def stride_variants():
     """Same XYZ+u16 content at awkward strides / offsets (unaligned loads, padding untouched)."""
     out = []
@@ -335,6 +360,8 @@ def encode_cases(small=False):
     out.append(("float_boundary3", *float_domain_boundary(lanes=3)))
     out.append(("float_boundary4", *float_domain_boundary(lanes=4, seed=54)))
     out.append(("float_boundary3_u16", *float_domain_boundary(lanes=3, seed=55, with_u16=True)))
+    out.append(("pcl_xyzi_step32", *padded_fourth_lane("pcl_xyzi")))
+    out.append(("ouster_step48", *padded_fourth_lane("ouster")))
     out.extend(stride_variants())
     return out
 
