@@ -1650,14 +1650,17 @@ int floatn_loadw(const DevPlan& p, int lanes, bool unal, int l3) {
   const uint32_t off0 = p.ops[0].offset;
   for (uint32_t a = 0; a < p.n_adaptive; ++a) {
     const DevAdaptive& f = p.adaptive[a];
-    if (f.offset < off0) return lanes;
-    if (f.bpv == 8u && ((f.offset - off0) & 3u)) return lanes;
+    // fields the point load cannot deliver: the aligned kernels then read every field directly (loadw == lanes);
+    // the unaligned instantiations have no such mode -> 0 = generic kernel
+    if (f.offset < off0) return unal ? 0 : lanes;
+    if (f.bpv == 8u && ((f.offset - off0) & 3u)) return unal ? 0 : lanes;
     need = std::max(need, f.offset - off0 + f.bpv);
   }
   const int w = (int)((need + 3u) / 4u);
   if (unal) {  // realigned dword loads may reach into the next point; variants: (3: 4, 8), (4: 5, 8)
-    if (lanes == 3) return w <= 4 ? 4 : (w <= 8 ? 8 : 4);
-    return w <= 5 ? 5 : (w <= 8 ? 8 : 5);
+    if (w > 8) return 0;
+    if (lanes == 3) return w <= 4 ? 4 : 8;
+    return w <= 5 ? 5 : 8;
   }
   const int loadw = w <= lanes ? lanes : (w <= 4 ? 4 : (w <= 8 ? 8 : 0));
   if (loadw == 0 || off0 + (uint32_t)loadw * 4u > p.point_step) return lanes;  // would read past the point
@@ -1750,11 +1753,12 @@ int stage1_launch_encode(const EncodeLaunch& L) {
                      L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots, L.slot_stride, L.segs,          \
                      L.segs_per_chunk, L.cols, L.subs, L.sub_points, L.sub_stride, ablate)
     if (l3 == 4 && loadw == 8) LAUNCH_FLOATN(256, 4, 2, 8, false, false, 4);
-    else if (l3 == 4) goto generic_regular;
+    else if (l3 == 4 || loadw == 0) goto generic_regular;
     else if (unal && lanes == 3 && loadw == 4) LAUNCH_FLOATN(256, 3, 2, 4, false, true);
     else if (unal && lanes == 3 && loadw == 8) LAUNCH_FLOATN(256, 3, 2, 8, false, true);
     else if (unal && lanes == 4 && loadw == 5) LAUNCH_FLOATN(256, 4, 2, 5, false, true);
     else if (unal && lanes == 4 && loadw == 8) LAUNCH_FLOATN(256, 4, 2, 8, false, true);
+    else if (unal) goto generic_regular;
     else if (lanes == 3 && loadw == 3) LAUNCH_FLOATN(256, 3, 2, 3, false);
     else if (lanes == 3 && loadw == 4) LAUNCH_FLOATN(256, 3, 2, 4, false);
     else if (lanes == 3 && loadw == 8) LAUNCH_FLOATN(256, 3, 2, 8, false);
