@@ -94,3 +94,55 @@ def test_random_schema(oracle, seed):
     got = codec.decode_host([want], [n], out=out)[0]
     assert np.array_equal(got, oracle.decode_stage1(info, want, n, fill=0xC3)), seed
     codec.close()
+
+
+_CORRUPT_SEEDS = list(range(3000, 3080 + int(os.environ.get("CLDN_FUZZ_EXTRA", "0"))))
+
+
+@pytest.mark.parametrize("seed", _CORRUPT_SEEDS)
+def test_corrupted_streams_decode_like_the_oracle(oracle, seed):
+    """Random damage (byte flips, truncation, inserted bytes) to valid streams: whenever the oracle's decoder accepts
+    the stream the GPU must return the same bytes, and whenever it rejects it the GPU must report corrupt data."""
+    from cloudini_amd import native, synth
+    rs = np.random.RandomState(seed)
+    pick = rs.randint(0, 5)
+    if pick == 0:
+        info, data = synth.lidar_xyzi(int(rs.choice([500, 5000, 40000])), seed=seed)
+    elif pick == 1:
+        info, data = synth.lidar_xyz(int(rs.choice([300, 33000])), seed=seed)
+    elif pick == 2:
+        info, data = synth.velodyne_xyzir(int(rs.choice([1000, 20000])), seed=seed)
+    elif pick == 3:
+        info, data = synth.depthcam_xyzrgba(64, 48, seed=seed)
+    else:
+        info, data = _random_case(1000 + seed % 100)
+    n = data.size // info.point_step
+    s = oracle.encode_stage1(info, data).copy()
+    if len(s) < 8:
+        pytest.skip("empty stream")
+    kind = rs.randint(0, 4)
+    if kind == 0:
+        for _ in range(int(rs.randint(1, 4))):
+            s[rs.randint(0, len(s))] ^= np.uint8(1 << rs.randint(0, 8))
+    elif kind == 1:
+        s = s[: rs.randint(1, len(s))]
+    elif kind == 2:
+        pos = rs.randint(4, len(s))
+        s = np.concatenate([s[:pos], rs.randint(0, 256, int(rs.randint(1, 4))).astype(np.uint8), s[pos:]])
+    else:
+        pos = rs.randint(4, len(s) - 1)
+        s = np.concatenate([s[:pos], s[pos + 1:]])
+    try:
+        want = oracle.decode_stage1(info, s, n, fill=0xE1)
+    except Exception:
+        want = None
+    codec = native.Codec(native.Plan(info))
+    out = np.full(max(1, data.size), 0xE1, dtype=np.uint8)
+    if want is None:
+        with pytest.raises(native.CloudiniHipError) as e:
+            codec.decode_host([s], [n], out=out)
+        assert e.value.code == -6
+    else:
+        got = codec.decode_host([s], [n], out=out)[0]
+        assert np.array_equal(got, want), seed
+    codec.close()
