@@ -146,3 +146,21 @@ def test_corrupted_streams_decode_like_the_oracle(oracle, seed):
         got = codec.decode_host([s], [n], out=out)[0]
         assert np.array_equal(got, want), seed
     codec.close()
+
+
+@pytest.mark.parametrize("seed", list(range(7000, 7040)))
+def test_host_mirror_full_streams_match_the_reference(reflib, seed):
+    """PointcloudEncoder / PointcloudDecoder of the host mirror (header, chunk framing, NONE / LZ4 / ZSTD, with and
+    without the worker thread) against the compiled reference on random schemas: identical streams, identical decode."""
+    from cloudini_amd import api
+    from cloudini_amd.schema import CompressionOption
+    rs = np.random.RandomState(seed)
+    info, data = _random_case(2000 + seed)
+    info = info.copy(compression_opt=CompressionOption(int(rs.choice([0, 1, 2]))), use_threads=bool(rs.randint(0, 2)))
+    want = reflib.encode(info, data)
+    got = api.PointcloudEncoder(info).encode(data)
+    assert np.array_equal(got, want), (seed, int(info.compression_opt), info.use_threads)
+    n = data.size // info.point_step
+    want_dec, _ = reflib.decode(want, max(1, data.size), fill=0x42)
+    got_dec, got_info = api.PointcloudDecoder().decode_stream(want, fill=0x42)
+    assert np.array_equal(got_dec[: n * info.point_step], want_dec[: n * info.point_step]), seed
