@@ -9,6 +9,11 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <condition_variable>
+#include <functional>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -181,6 +186,80 @@ struct CodecPool {
 
 CodecPool& pool() {
   static CodecPool* p = new CodecPool();
+  return *p;
+}
+
+// Stage-2 workers: a small persistent pool (threads are created once per process, not per encode() call). run(n, fn)
+// calls fn(i) for i in [0, n) on the pool plus the calling thread and returns when all are done; the first exception
+// is rethrown on the caller.
+class WorkerPool {
+ public:
+  explicit WorkerPool(unsigned n_threads) {
+    for (unsigned t = 0; t < n_threads; ++t) threads_.emplace_back([this] { loop(); });
+  }
+  ~WorkerPool() {
+    // process teardown: worker threads are detached on purpose (joining at exit can deadlock in shared libraries)
+    for (auto& t : threads_) t.detach();
+  }
+  template <typename Fn>
+  void run(size_t n, Fn&& fn) {
+    std::unique_lock<std::mutex> run_lock(run_mutex_);  // one job at a time
+    {
+      std::lock_guard<std::mutex> lock(mutex_);
+      job_ = [&fn](size_t i) { fn(i); };
+      n_ = n;
+      next_.store(0);
+      pending_ = n;
+      error_ = nullptr;
+      ++generation_;
+    }
+    wake_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lock(mutex_);
+    done_.wait(lock, [this] { return pending_ == 0; });
+    job_ = nullptr;
+    if (error_) std::rethrow_exception(error_);
+  }
+
+ private:
+  void drain() {
+    for (;;) {
+      const size_t i = next_.fetch_add(1);
+      if (i >= n_) return;
+      try {
+        job_(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lock(mutex_);
+        if (!error_) error_ = std::current_exception();
+      }
+      std::lock_guard<std::mutex> lock(mutex_);
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lock(mutex_);
+        wake_.wait(lock, [&] { return generation_ != seen; });
+        seen = generation_;
+      }
+      drain();
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex mutex_, run_mutex_;
+  std::condition_variable wake_, done_;
+  std::function<void(size_t)> job_;
+  size_t n_ = 0;
+  std::atomic<size_t> next_{0};
+  size_t pending_ = 0;
+  uint64_t generation_ = 0;
+  std::exception_ptr error_;
+};
+
+WorkerPool& stage2Pool() {
+  static WorkerPool* p = new WorkerPool(std::min(31u, std::max(1u, std::thread::hardware_concurrency()) - 1u));
   return *p;
 }
 
@@ -417,7 +496,6 @@ size_t MaxCompressedSize(const EncodingInfo& info, size_t points_count, bool inc
 struct PointcloudEncoder::Impl {
   std::unique_ptr<PlanHandle> plan;
   cldn_hip_codec_t* codec = nullptr;
-  std::vector<uint8_t> stage1;        // framed stage-1 stream of the last cloud
   std::vector<uint32_t> chunk_sizes;  // payload size per chunk
 };
 
@@ -464,10 +542,14 @@ size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output,
   const bool direct = info_.compression_opt == CompressionOption::NONE;  // the framed stream IS the payload
   uint8_t* s1 = dst + written;
   uint64_t s1_cap = output.size() - written;
+  // Staging buffers live per thread, not per encoder: callers like the ROS publisher plugin build a fresh encoder for
+  // every message (cloudini_publisher_plugin.cpp:53-55) and a 20 MB zero-filled vector per message costs more than
+  // the whole encode.
+  static thread_local std::vector<uint8_t> tl_stage1, tl_stage2;
   if (!direct) {
-    if (impl_->stage1.size() < bound) impl_->stage1.resize(bound);
-    s1 = impl_->stage1.data();
-    s1_cap = impl_->stage1.size();
+    if (tl_stage1.size() < bound) tl_stage1.resize(bound);
+    s1 = tl_stage1.data();
+    s1_cap = tl_stage1.size();
   }
   impl_->chunk_sizes.resize(n_chunks);
   uint64_t offsets[2] = {0, 0};
@@ -498,34 +580,28 @@ size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output,
     }
     return written;
   }
-  std::vector<std::vector<uint8_t>> packed(n_chunks);
-  std::atomic<size_t> next{0};
-  std::exception_ptr error;
-  std::mutex error_mutex;
-  auto work = [&] {
-    try {
-      for (size_t c = next.fetch_add(1); c < n_chunks; c = next.fetch_add(1)) {
-        const size_t in = impl_->chunk_sizes[c];
-        const size_t cap = info_.compression_opt == CompressionOption::LZ4 ? size_t(LZ4_compressBound(int(in)))
-                                                                           : ZSTD_compressBound(in);
-        packed[c].resize(cap);
-        packed[c].resize(compressChunk(info_.compression_opt, s1 + src_off[c], in, packed[c].data(), cap));
-      }
-    } catch (...) {
-      std::lock_guard<std::mutex> lock(error_mutex);
-      if (!error) error = std::current_exception();
-    }
-  };
-  std::vector<std::thread> threads;
-  for (unsigned t = 1; t < workers; ++t) threads.emplace_back(work);
-  work();
-  for (auto& t : threads) t.join();
-  if (error) std::rethrow_exception(error);
+  // every chunk into its own worst-case slot of one scratch buffer (reused across calls), then laid out in order
+  const size_t max_in = *std::max_element(impl_->chunk_sizes.begin(), impl_->chunk_sizes.end());
+  if (info_.compression_opt == CompressionOption::LZ4 && max_in > size_t(std::numeric_limits<int>::max()))
+    throw std::runtime_error("Chunk size too large for LZ4");
+  const size_t slot = info_.compression_opt == CompressionOption::LZ4 ? size_t(LZ4_compressBound(int(max_in)))
+                                                                     : ZSTD_compressBound(max_in);
+  if (tl_stage2.size() < slot * n_chunks) tl_stage2.resize(slot * n_chunks);
+  std::vector<uint32_t> packed_size(n_chunks);
+  uint8_t* scratch = tl_stage2.data();
+  static const bool timing = std::getenv("CLDN_HOST_TIMING") != nullptr;  // diagnostics: stage-2 wall time to stderr
+  const auto t0 = std::chrono::steady_clock::now();
+  stage2Pool().run(n_chunks, [&](size_t c) {
+    packed_size[c] = compressChunk(info_.compression_opt, s1 + src_off[c], impl_->chunk_sizes[c], scratch + c * slot, slot);
+  });
+  if (timing)
+    std::fprintf(stderr, "[cloudini_amd] stage 2: %zu chunks, %.3f ms on up to %u threads\n", n_chunks,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), workers);
   for (size_t c = 0; c < n_chunks; ++c) {
-    const uint32_t n = static_cast<uint32_t>(packed[c].size());
+    const uint32_t n = packed_size[c];
     if (output.size() - written < 4u + n) throw std::runtime_error("Output buffer too small for compressed chunk");
     std::memcpy(dst + written, &n, 4);
-    std::memcpy(dst + written + 4, packed[c].data(), n);
+    std::memcpy(dst + written + 4, scratch + c * slot, n);
     written += 4 + n;
   }
   return written;
