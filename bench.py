@@ -76,11 +76,20 @@ def cpu_baseline(info, cloud, budget_s: float):
                "sample": f"{reps} x encode() of one {pts}-pt cloud of the workload, 1 thread, median "
                          f"(best {pts / best / 1e6:.1f} Mpoints/s)"}
         ncores = os.cpu_count() or 1
+        quota = None
+        try:  # containers often grant fewer CPUs than they show (cgroup v2 cpu.max = "<quota> <period>")
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                quota = max(1, int(float(q) / float(per) + 0.5))
+        except (OSError, ValueError):
+            pass
+        if quota is not None:
+            ncores = min(ncores, quota)
         if ncores > 1:
             reps_mt = max(3, reps // 4)
             _size, tm = ref.bench_encode(info, cloud, reps=reps_mt, threads=ncores)
             agg = float(np.sum(pts / np.median(tm, axis=1))) / 1e6
-            out["all_cores"] = {"value": agg, "cores": ncores,
+            out["all_cores"] = {"value": agg, "cores": ncores, "visible_threads": os.cpu_count(), "cgroup_cpu_quota": quota,
                                 "sample": f"{ncores} independent encoders x {reps_mt} reps, sum of per-thread medians"}
         return out
     except (FileNotFoundError, OSError):
