@@ -616,7 +616,6 @@ struct PointcloudDecoder::Impl {
   EncodingInfo info;
   std::unique_ptr<PlanHandle> plan;
   cldn_hip_codec_t* codec = nullptr;
-  std::vector<uint8_t> stage1;  // decompressed, re-framed chunks
 
   void release() {
     if (codec) pool().release(info, codec);
@@ -655,43 +654,63 @@ void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compres
   const bool direct = info.compression_opt == CompressionOption::NONE;
   const uint8_t* s1 = compressed_data.data();
   uint64_t s1_size = compressed_data.size();
+  static thread_local std::vector<uint8_t> tl_stage1;  // per thread, not per decoder (see PointcloudEncoder::encode)
   {
+    struct ChunkRef {
+      const uint8_t* src;
+      uint32_t size;
+      uint64_t in_chunk;
+    };
+    std::vector<ChunkRef> refs;
     ConstBufferView rest = compressed_data;
     uint64_t remaining = points;
-    size_t produced = 0;
-    if (!direct) impl_->stage1.clear();
     while (!rest.empty()) {
       if (remaining == 0) throw std::runtime_error("Encoded data contains more chunks than declared points");
       uint32_t chunk_size = 0;
       Cloudini::decode(rest, chunk_size);
       if (chunk_size > rest.size()) throw std::runtime_error("Invalid chunk size found while decoding");
       const uint64_t in_chunk = std::min<uint64_t>(remaining, kPointsPerChunk);
-      if (!direct) {
-        // the decompressed stage-1 bytes of a chunk are bounded by its worst case
-        const size_t cap = static_cast<size_t>(cldn_hip_stage1_bound(impl_->plan->plan, in_chunk)) + 64;
-        impl_->stage1.resize(produced + 4 + cap);
-        uint8_t* dst = impl_->stage1.data() + produced + 4;
-        size_t got = 0;
-        if (info.compression_opt == CompressionOption::LZ4) {
-          const int n = LZ4_decompress_safe(reinterpret_cast<const char*>(rest.data()), reinterpret_cast<char*>(dst),
-                                            static_cast<int>(chunk_size), static_cast<int>(cap));
-          if (n < 0) throw std::runtime_error("LZ4 decompression failed");
-          got = static_cast<size_t>(n);
-        } else {
-          got = ZSTD_decompress(dst, cap, rest.data(), chunk_size);
-          if (ZSTD_isError(got)) throw std::runtime_error(std::string("ZSTD decompression failed: ") + ZSTD_getErrorName(got));
-        }
-        const uint32_t got32 = static_cast<uint32_t>(got);
-        std::memcpy(impl_->stage1.data() + produced, &got32, 4);
-        produced += 4 + got;
-      }
+      if (!direct) refs.push_back({rest.data(), chunk_size, in_chunk});
       rest.trim_front(chunk_size);
       remaining -= in_chunk;
     }
     if (remaining != 0) throw std::runtime_error("Encoded data ended before all declared points were decoded");
-    if (!direct) {
-      s1 = impl_->stage1.data();
+    if (!direct && !refs.empty()) {
+      // undo stage 2: every chunk into its own worst-case slot (concurrently when use_threads), then packed into the
+      // framed stage-1 stream the device decoder takes
+      const size_t slot = static_cast<size_t>(cldn_hip_stage1_bound(impl_->plan->plan, kPointsPerChunk)) + 64;
+      if (tl_stage1.size() < slot * refs.size()) tl_stage1.resize(slot * refs.size());
+      uint8_t* scratch = tl_stage1.data();
+      std::vector<uint32_t> got(refs.size());
+      auto undo = [&](size_t c) {
+        uint8_t* dst = scratch + c * slot + 4;
+        const size_t cap = slot - 4;
+        if (info.compression_opt == CompressionOption::LZ4) {
+          const int n = LZ4_decompress_safe(reinterpret_cast<const char*>(refs[c].src), reinterpret_cast<char*>(dst),
+                                            static_cast<int>(refs[c].size), static_cast<int>(cap));
+          if (n < 0) throw std::runtime_error("LZ4 decompression failed");
+          got[c] = static_cast<uint32_t>(n);
+        } else {
+          const size_t n = ZSTD_decompress(dst, cap, refs[c].src, refs[c].size);
+          if (ZSTD_isError(n)) throw std::runtime_error(std::string("ZSTD decompression failed: ") + ZSTD_getErrorName(n));
+          got[c] = static_cast<uint32_t>(n);
+        }
+      };
+      if (info.use_threads && refs.size() > 1) {
+        stage2Pool().run(refs.size(), undo);
+      } else {
+        for (size_t c = 0; c < refs.size(); ++c) undo(c);
+      }
+      size_t produced = 0;
+      for (size_t c = 0; c < refs.size(); ++c) {  // slot c starts at or behind `produced`: forward memmove is safe
+        std::memcpy(scratch + c * slot, &got[c], 4);
+        if (produced != c * slot) std::memmove(scratch + produced, scratch + c * slot, 4 + size_t(got[c]));
+        produced += 4 + size_t(got[c]);
+      }
+      s1 = scratch;
       s1_size = produced;
+    } else if (!direct) {
+      s1_size = 0;
     }
   }
   if (points == 0) return;

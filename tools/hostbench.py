@@ -68,3 +68,20 @@ for comp in (CompressionOption.NONE, CompressionOption.LZ4, CompressionOption.ZS
         _size, t = ref.bench_encode(inf, data, reps=5, threads=1)
         line += f"; reference {float(np.median(t))*1e3:.2f} ms"
     print(line)
+
+# d) Cloudini::PointcloudDecoder::decode of the host mirror, full streams
+for comp in (CompressionOption.NONE, CompressionOption.LZ4, CompressionOption.ZSTD):
+    inf = info.copy(compression_opt=comp, use_threads=True)
+    stream = api.PointcloudEncoder(inf).encode(data)
+    dec = api.PointcloudDecoder()
+    for _ in range(2):
+        out, _i = dec.decode_stream(stream)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        out, _i = dec.decode_stream(stream)
+    dt = (time.perf_counter() - t0) / 5
+    line = f"d) PointcloudDecoder::decode {comp.name}: {dt*1e3:.2f} ms per 1M-pt cloud = {1/dt:.0f} Mpoints/s"
+    if ref is not None:
+        _n, t = ref.bench_decode(stream, data.size, reps=5)
+        line += f"; reference {float(np.median(t))*1e3:.2f} ms"
+    print(line)
