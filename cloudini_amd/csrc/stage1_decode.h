@@ -995,6 +995,189 @@ __device__ __forceinline__ void fill_runs(const uint32_t* start, const uint64_t*
   }
 }
 
+// Palette section behind its mode byte (decodeV5AdaptiveIntSection, src/v5_codec.cpp:788-822): u16 count, the
+// palette values, bit-packed indexes; thread t unpacks values [32t, 32t+32). The palette is staged in `pal_l` (LDS)
+// when it has at most `pal_cap` entries. Returns true when something is wrong (block-uniform); `off` moves behind
+// the section. Contains barriers.
+__device__ __forceinline__ bool dec_palette(const uint8_t* __restrict__ src, uint32_t src_size, uint32_t& off, uint32_t n,
+                                            uint8_t* base, uint32_t step, uint32_t field_off, uint32_t bpv,
+                                            uint64_t* pal_l, uint32_t pal_cap, uint32_t* stage, uint32_t* misc) {
+  constexpr int T = kDvThreads;
+  const uint32_t tid = threadIdx.x;
+  if (src_size - off < 2u) return true;
+  const uint32_t count = (uint32_t)src[off] | ((uint32_t)src[off + 1u] << 8);
+  off += 2u;
+  if (count == 0u || (uint64_t)(src_size - off) < (uint64_t)count * bpv) return true;
+  const uint8_t* pal = src + off;
+  off += count * bpv;
+  const uint32_t bits = palette_bits(count);
+  const uint32_t index_bytes = (uint32_t)(((uint64_t)bits * n + 7u) / 8u);
+  if (src_size - off < index_bytes) return true;
+  const uint8_t* ip = src + off;
+  __syncthreads();
+  if (tid == 0) misc[0] = 0u;
+  const bool pal_in_lds = count <= pal_cap;
+  if (pal_in_lds) {
+    for (uint32_t k = tid; k < count; k += T) {
+      uint64_t v = 0;
+      for (uint32_t b = 0; b < bpv; ++b) v |= ((uint64_t)pal[(size_t)k * bpv + b]) << (8u * b);
+      pal_l[k] = v;
+    }
+  }
+  __syncthreads();
+  const uint8_t* ip_end = ip + index_bytes;
+  if (bpv <= 4u && stage != nullptr) {
+    // Rounds of 8192 values: thread t unpacks 8 consecutive indexes (their bits start on a byte boundary: 8 * bits
+    // bits = `bits` bytes), looks the values up and parks them in LDS; after a barrier the same round is written out
+    // with consecutive lanes on consecutive points, so a store instruction touches 8 cache lines instead of 64.
+    const bool st_fast = (bpv == 2u && ((field_off | step) & 1u) == 0u) || (bpv == 4u && ((field_off | step) & 3u) == 0u);
+    for (uint32_t r0 = 0; r0 < n; r0 += 8192u) {
+      const uint32_t i0 = r0 + tid * 8u;
+      if (i0 < n) {
+        const uint32_t cnt = min(8u, n - i0);
+        const uint8_t* ib = ip + (size_t)(i0 >> 3) * bits;
+        const uint32_t mis = (uint32_t)((uintptr_t)ib & 3u);
+        const uint32_t* iq = reinterpret_cast<const uint32_t*>(ib - mis);
+        uint32_t nxt = (reinterpret_cast<const uint8_t*>(iq) < ip_end && bits) ? iq[0] : 0u;
+        uint64_t scratch = 0u;
+        uint32_t held = 0u, k = 0u;
+        for (uint32_t j = 0; j < cnt; ++j) {
+          uint32_t idx = 0u;
+          if (bits) {
+            if (held < bits) {
+              const uint32_t cur_dw = nxt;
+              ++k;
+              nxt = (reinterpret_cast<const uint8_t*>(iq + k) < ip_end) ? iq[k] : 0u;
+              scratch |= (uint64_t)__builtin_amdgcn_alignbyte(nxt, cur_dw, mis) << held;
+              held += 32u;
+            }
+            idx = (uint32_t)(scratch & ((1ull << bits) - 1ull));
+            scratch >>= bits;
+            held -= bits;
+          }
+          if (idx >= count) {
+            misc[0] = 1u;
+            break;
+          }
+          uint32_t v = 0;
+          if (pal_in_lds) {
+            v = (uint32_t)pal_l[idx];
+          } else {
+            for (uint32_t b = 0; b < bpv; ++b) v |= ((uint32_t)pal[(size_t)idx * bpv + b]) << (8u * b);
+          }
+          stage[tid * 8u + j] = v;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t q = k * (uint32_t)T + tid;  // value q of the round
+        if (r0 + q < n) {
+          const uint32_t v = stage[q];
+          uint8_t* o = base + (size_t)(r0 + q) * step + field_off;
+          if (st_fast && bpv == 2u) *reinterpret_cast<uint16_t*>(o) = (uint16_t)v;
+          else if (st_fast && bpv == 4u) *reinterpret_cast<uint32_t*>(o) = v;
+          else st_raw(o, v, bpv);
+        }
+      }
+      __syncthreads();
+    }
+    off += index_bytes;
+    return misc[0] != 0u;
+  }
+  const uint32_t i0 = tid * 32u;
+  if (i0 < n) {
+    const uint32_t cnt = min(32u, n - i0);
+    const uint32_t byte0 = tid * 4u * bits;  // 32 indexes = `bits` dwords
+    // index dwords through aligned loads: the stream position is arbitrary, so fetch the aligned dwords around mine
+    // and realign
+    const uint8_t* ib = ip + byte0;
+    const uint32_t mis = (uint32_t)((uintptr_t)ib & 3u);
+    const uint32_t* iq = reinterpret_cast<const uint32_t*>(ib - mis);
+    const uint8_t* ip_end = ip + index_bytes;
+    uint32_t nxt = (reinterpret_cast<const uint8_t*>(iq) < ip_end && bits) ? iq[0] : 0u;
+    const bool st_fast = (bpv == 2u && ((field_off | step) & 1u) == 0u) || (bpv == 4u && ((field_off | step) & 3u) == 0u);
+    uint64_t scratch = 0u;
+    uint32_t held = 0u, k = 0u;
+    for (uint32_t produced = 0u; produced < cnt; ++produced) {
+      uint32_t idx = 0u;
+      if (bits) {
+        if (held < bits) {
+          const uint32_t cur_dw = nxt;
+          ++k;
+          nxt = (reinterpret_cast<const uint8_t*>(iq + k) < ip_end) ? iq[k] : 0u;
+          const uint32_t dw = __builtin_amdgcn_alignbyte(nxt, cur_dw, mis);
+          scratch |= (uint64_t)dw << held;
+          held += 32u;
+        }
+        idx = (uint32_t)(scratch & ((1ull << bits) - 1ull));
+        scratch >>= bits;
+        held -= bits;
+      }
+      if (idx >= count) {
+        misc[0] = 1u;
+        break;
+      }
+      uint64_t v = 0;
+      if (pal_in_lds) {
+        v = pal_l[idx];
+      } else {
+        for (uint32_t b = 0; b < bpv; ++b) v |= ((uint64_t)pal[(size_t)idx * bpv + b]) << (8u * b);
+      }
+      uint8_t* o = base + (size_t)(i0 + produced) * step + field_off;
+      if (st_fast && bpv == 2u) *reinterpret_cast<uint16_t*>(o) = (uint16_t)v;
+      else if (st_fast && bpv == 4u) *reinterpret_cast<uint32_t*>(o) = (uint32_t)v;
+      else st_raw(o, v, bpv);
+    }
+  }
+  __syncthreads();
+  off += index_bytes;
+  return misc[0] != 0u;
+}
+
+// Chunks whose sections are all Palette with small palettes (the common case: intensity, ring, reflectivity ...) need
+// almost no LDS; this kernel takes them at two workgroups per CU and leaves every other chunk to k_decode_sections,
+// whose 100 KiB of LDS (token tiles, run tables) allow only one.
+constexpr uint32_t kSmallPalEntries = 1024;
+constexpr uint32_t kSmallSecLds = kSmallPalEntries * 8u + 8192u * 4u + 256u;  // palette, transposition buffer, misc
+
+__global__ __launch_bounds__(kDvThreads) void k_decode_sections_small(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                                      const DecChunk* __restrict__ chunks,
+                                                                      uint8_t* __restrict__ out,
+                                                                      const uint32_t* __restrict__ reg_end,
+                                                                      uint8_t* __restrict__ sec_done,
+                                                                      uint32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint64_t* pal_l = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* stage = reinterpret_cast<uint32_t*>(smem + kSmallPalEntries * 8u);
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + kSmallPalEntries * 8u + 8192u * 4u);
+  const uint32_t c = blockIdx.x;
+  const DecChunk dc = chunks[c];
+  if (threadIdx.x == 0) sec_done[c] = 0u;
+  if (!dc.valid) return;
+  uint32_t off = reg_end[c];
+  if (off == kDecRedo || off > dc.src_size) return;
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t src_size = dc.src_size;
+  const uint32_t step = plan.point_step;
+  uint8_t* base = out + (size_t)dc.first_point * step;
+  for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
+    // Palette with at most kSmallPalEntries values, else this chunk is not ours
+    if (src_size - min(src_size, off) < 3u || src[off] != 1u) return;
+    const uint32_t count = (uint32_t)src[off + 1u] | ((uint32_t)src[off + 2u] << 8);
+    if (count > kSmallPalEntries) return;
+    ++off;
+    if (dec_palette(src, src_size, off, dc.n_points, base, step, plan.adaptive[a].offset, plan.adaptive[a].bpv, pal_l,
+                    kSmallPalEntries, stage, misc))
+      return;
+  }
+  if (off != src_size) return;  // trailing bytes: the serial decoder raises the error
+  if (threadIdx.x == 0) {
+    sec_done[c] = 1u;
+    atomicAdd(&status[kStatFastSections], 1u);
+  }
+}
+
 __global__ __launch_bounds__(kDvThreads) void k_decode_sections(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                                 const DecChunk* __restrict__ chunks,
                                                                 uint8_t* __restrict__ out,
@@ -1012,7 +1195,7 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_sections(const DevPlan pl
   const uint32_t c = blockIdx.x;
   const DecChunk dc = chunks[c];
   const uint32_t tid = threadIdx.x;
-  if (tid == 0) sec_done[c] = 0u;
+  if (sec_done[c]) return;  // k_decode_sections_small took this chunk (it also cleared the flag of all others)
   if (!dc.valid) return;
   uint32_t off = reg_end[c];
   if (off == kDecRedo || off > dc.src_size) return;  // the serial decoder owns this chunk
@@ -1038,77 +1221,9 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_sections(const DevPlan pl
       else off = misc[1];
       __syncthreads();
     } else if (mode == 1u) {  // ---- Palette
-      if (src_size - off < 2u) { bad = true; break; }
-      const uint32_t count = (uint32_t)src[off] | ((uint32_t)src[off + 1u] << 8);
-      off += 2u;
-      if (count == 0u || (uint64_t)(src_size - off) < (uint64_t)count * bpv) { bad = true; break; }
-      const uint8_t* pal = src + off;
-      off += count * bpv;
-      const uint32_t bits = palette_bits(count);
-      const uint32_t index_bytes = (uint32_t)(((uint64_t)bits * n + 7u) / 8u);
-      if (src_size - off < index_bytes) { bad = true; break; }
-      const uint8_t* ip = src + off;
-      __syncthreads();
-      if (tid == 0) misc[0] = 0u;
-      // palette -> LDS (the token area is free here) when it fits; values are looked up 32768 times
-      uint64_t* pal_l = raw;
-      const bool pal_in_lds = count <= 8192u;
-      if (pal_in_lds) {
-        for (uint32_t k = tid; k < count; k += T) {
-          uint64_t v = 0;
-          for (uint32_t b = 0; b < bpv; ++b) v |= ((uint64_t)pal[(size_t)k * bpv + b]) << (8u * b);
-          pal_l[k] = v;
-        }
-      }
-      __syncthreads();
-      const uint32_t i0 = tid * 32u;
-      if (i0 < n) {
-        const uint32_t cnt = min(32u, n - i0);
-        const uint32_t byte0 = tid * 4u * bits;  // 32 indexes = `bits` dwords
-        // index dwords through aligned loads: the stream position is arbitrary, so fetch the aligned dwords around
-        // mine and realign
-        const uint8_t* ib = ip + byte0;
-        const uint32_t mis = (uint32_t)((uintptr_t)ib & 3u);
-        const uint32_t* iq = reinterpret_cast<const uint32_t*>(ib - mis);
-        const uint8_t* ip_end = ip + index_bytes;
-        uint32_t nxt = (reinterpret_cast<const uint8_t*>(iq) < ip_end && bits) ? iq[0] : 0u;
-        const bool st_fast = (bpv == 2u && ((field_off | step) & 1u) == 0u) || (bpv == 4u && ((field_off | step) & 3u) == 0u);
-        uint64_t scratch = 0u;
-        uint32_t held = 0u, k = 0u;
-        for (uint32_t produced = 0u; produced < cnt; ++produced) {
-          uint32_t idx = 0u;
-          if (bits) {
-            if (held < bits) {
-              const uint32_t cur_dw = nxt;
-              ++k;
-              nxt = (reinterpret_cast<const uint8_t*>(iq + k) < ip_end) ? iq[k] : 0u;
-              const uint32_t dw = __builtin_amdgcn_alignbyte(nxt, cur_dw, mis);
-              scratch |= (uint64_t)dw << held;
-              held += 32u;
-            }
-            idx = (uint32_t)(scratch & ((1ull << bits) - 1ull));
-            scratch >>= bits;
-            held -= bits;
-          }
-          if (idx >= count) {
-            misc[0] = 1u;
-            break;
-          }
-          uint64_t v = 0;
-          if (pal_in_lds) {
-            v = pal_l[idx];
-          } else {
-            for (uint32_t b = 0; b < bpv; ++b) v |= ((uint64_t)pal[(size_t)idx * bpv + b]) << (8u * b);
-          }
-          uint8_t* o = base + (size_t)(i0 + produced) * step + field_off;
-          if (st_fast && bpv == 2u) *reinterpret_cast<uint16_t*>(o) = (uint16_t)v;
-          else if (st_fast && bpv == 4u) *reinterpret_cast<uint32_t*>(o) = (uint32_t)v;
-          else st_raw(o, v, bpv);
-        }
-      }
-      __syncthreads();
-      if (misc[0]) bad = true;
-      off += index_bytes;
+      // palette in the first 8192 token slots, the 8192-value transposition buffer behind it (both free here)
+      if (dec_palette(src, src_size, off, n, base, step, field_off, bpv, raw, 4096u, reinterpret_cast<uint32_t*>(raw + 4096), misc))
+        bad = true;
     } else if (mode == 2u || mode == 3u) {  // ---- Rle / DeltaRle
       if (src_size - off < 4u) { bad = true; break; }
       const uint32_t runs = (uint32_t)src[off] | ((uint32_t)src[off + 1u] << 8) | ((uint32_t)src[off + 2u] << 16) |

@@ -1871,6 +1871,9 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     }
     const bool fast_sections = fast && L.uses_v5 && P.n_adaptive > 0u;
     if (fast_sections) {
+      hipLaunchKernelGGL(k_decode_sections_small, dim3(L.n_chunks), dim3(kDvThreads), kSmallSecLds, L.stream, P, L.streams,
+                         reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_sections_small");
       hipLaunchKernelGGL(k_decode_sections, dim3(L.n_chunks), dim3(kDvThreads), (DecSecLds::kTotal), L.stream, P, L.streams,
                          reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_sections");
