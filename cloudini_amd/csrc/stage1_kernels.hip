@@ -655,8 +655,10 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
         // move folds into a commutative add (hipcc's v_subrev_*_dpp returned the operands swapped on gfx950).
         const float r = rintf(__fmul_rn(cur[j].v[(LANES == 4 && k == 3) ? L3 : k], mult[k]));
         rare |= !(fabsf(r) < 2097152.0f);
-        const float nrp = __uint_as_float(dpp_wave_shr1(__float_as_uint(r) ^ 0x80000000u));
-        const float uf = fabsf(__fmaf_rn(__fadd_rn(r, nrp), 2.0f, 0.5f)) + 0.5f;
+        // nd = r_prev - r with the DPP value as the first operand (a plain v_sub_f32_dpp; the reversed form is the one
+        // that misbehaved); |2d + 0.5| == |(-2) nd + 0.5|
+        const float nd = __fsub_rn(__uint_as_float(dpp_wave_shr1(__float_as_uint(r))), r);
+        const float uf = fabsf(__fmaf_rn(nd, -2.0f, 0.5f)) + 0.5f;
         const uint32_t u = (uint32_t)uf;
         const uint32_t l = groups7((uint32_t)__builtin_amdgcn_frexp_expf(uf));  // frexp exponent == bit length of u
         tok[j][k] = token4(u, l);
