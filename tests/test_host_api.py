@@ -238,3 +238,40 @@ def test_dds_fixture_layout_roundtrip(reflib):
     assert np.array_equal(got, want)
     back = api.ros_decompress(got, msg.size + 4096)
     assert np.array_equal(back, reflib.ros_decompress(want, msg.size + 4096))
+
+
+@pytest.mark.gpu
+def test_encoders_on_concurrent_threads(reflib):
+    """Distinct encoder / decoder instances are independent (cloudini.hpp contract): four host threads, each with its
+    own schema and compression option, hammer the codec pool, the stage-2 worker pool and the per-thread buffers."""
+    import threading
+    jobs = []
+    for k, (comp, maker) in enumerate(((CompressionOption.LZ4, lambda: synth.lidar_xyzi(90_000, seed=31)),
+                                        (CompressionOption.ZSTD, lambda: synth.velodyne_xyzir(50_000, seed=32)),
+                                        (CompressionOption.NONE, lambda: synth.lidar_xyz(120_000, seed=33)),
+                                        (CompressionOption.ZSTD, lambda: synth.depthcam_xyzrgba(320, 240, seed=34)))):
+        info, data = maker()
+        info = info.copy(compression_opt=comp, use_threads=True)
+        jobs.append((info, data, reflib.encode(info, data)))
+    errors = []
+
+    def worker(info, data, want):
+        try:
+            for _ in range(6):
+                got = api.PointcloudEncoder(info).encode(data)
+                if not np.array_equal(got, want):
+                    errors.append("encode differs")
+                dec, _i = api.PointcloudDecoder().decode_stream(want, fill=0x21)
+                n = data.size
+                ref_dec, _y = reflib.decode(want, n, fill=0x21)
+                if not np.array_equal(dec[:n], ref_dec[:n]):
+                    errors.append("decode differs")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[:3]
