@@ -275,3 +275,35 @@ def test_encoders_on_concurrent_threads(reflib):
     for t in threads:
         t.join(timeout=300)
     assert not errors, errors[:3]
+
+
+@pytest.mark.gpu
+def test_legacy_v3_wire_format_like_the_reference_test(reflib):
+    """test_header.cpp:173-241 (DecodeV3_FromLegacyEncoder): version 3 writes the "CLOUDINI_V03" magic, encodes
+    lossless FLOAT64 with the XOR codec (no Gorilla before v4), and decodes with the current library. Same struct,
+    same generator; additionally the bytes must equal the reference's."""
+    n = 64 * 1024 + 7
+    i = np.arange(n)
+    fields = [("x", 0, FieldType.FLOAT32, 0.001), ("y", 4, FieldType.FLOAT32, 0.001), ("z", 8, FieldType.FLOAT32, 0.001),
+              ("stamp", 16, FieldType.FLOAT64, None)]
+    info = cases.make_info(fields, 24, n, version=3, comp=CompressionOption.ZSTD)
+    cols = {"x": (np.float32(0.01) * i.astype(np.float32)), "y": (np.float32(-0.02) * i.astype(np.float32) + np.float32(0.5)),
+            "z": (np.float32(0.001) * i.astype(np.float32) - np.float32(0.25)), "stamp": 1700000000.0 + 0.000001 * i}
+    data = cases.pack(info, cols, n)
+    got = api.PointcloudEncoder(info).encode(data)
+    assert got[:12].tobytes() == b"CLOUDINI_V03"
+    assert np.array_equal(got, reflib.encode(info, data))
+    dec, dinfo = api.PointcloudDecoder().decode_stream(got, fill=0xA5)
+    assert dinfo.version == 3
+    a = data.reshape(n, 24)
+    b = dec[: n * 24].reshape(n, 24)
+    for k in range(3):
+        x = a[:, 4 * k:4 * k + 4].copy().view(np.float32).reshape(-1)
+        y = b[:, 4 * k:4 * k + 4].copy().view(np.float32).reshape(-1)
+        assert np.all(np.abs(x - y) <= 0.001 * 1.01)
+    assert np.array_equal(a[:, 16:24], b[:, 16:24])  # lossless stamp, bit exact
+    # v4 of the same cloud uses Gorilla for the stamp: a different payload
+    info4 = info.copy(version=4)
+    got4 = api.PointcloudEncoder(info4).encode(data)
+    assert got4[:12].tobytes() == b"CLOUDINI_V04" and not np.array_equal(got4[13:], got[13:])
+    assert np.array_equal(got4, reflib.encode(info4, data))
