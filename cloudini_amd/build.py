@@ -65,7 +65,8 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + _sources(host_dir, (".hpp", ".h")) + _sources(os.path.join(ROOT, "include"), (".h", ".hpp")) + \
         [HIP_SO]
     if force or _newer(HOST_SO, deps):
-        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-fvisibility=hidden",
+        # default visibility: the C++ API of include/cloudini_lib/*.hpp is what callers link against
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall",
                "-I" + os.path.join(ROOT, "include"), "-I" + host_dir] + srcs + \
               [HIP_SO, LZ4_SO, ZSTD_SO, "-lpthread", "-Wl,-rpath,$ORIGIN", "-o", HOST_SO]
         if verbose:
