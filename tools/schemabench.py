@@ -30,6 +30,16 @@ layouts = {
     "xyz_rgb_f32packed_step16 (rgb as FLOAT32 without resolution -> Copy)": (
         [("x", 0, F.FLOAT32, 0.001), ("y", 4, F.FLOAT32, 0.001), ("z", 8, F.FLOAT32, 0.001), ("rgb", 12, F.FLOAT32, None)], 16,
         {"x": p[:, 0], "y": p[:, 1], "z": p[:, 2], "rgb": rs.randint(0, 1 << 24, n).astype(np.uint32).view(np.float32)}),
+    "dds_sample_layout_step26 (XYZI f32 + ring u16 + f64 stamp, Gorilla)": (
+        [("x", 0, F.FLOAT32, 0.001), ("y", 4, F.FLOAT32, 0.001), ("z", 8, F.FLOAT32, 0.001), ("intensity", 12, F.FLOAT32, 0.001),
+         ("ring", 16, F.UINT16, None), ("timestamp", 18, F.FLOAT64, None)], 26,
+        {"x": p[:, 0], "y": p[:, 1], "z": p[:, 2], "intensity": inten, "ring": (np.arange(n) % 64).astype(np.uint16),
+         "timestamp": 1.7e9 + np.arange(n) * 1e-5}),
+    "dds_sample_layout with 1 us stamps (after applyVizLossyPreprocessing)": (
+        [("x", 0, F.FLOAT32, 0.001), ("y", 4, F.FLOAT32, 0.001), ("z", 8, F.FLOAT32, 0.001), ("intensity", 12, F.FLOAT32, 0.001),
+         ("ring", 16, F.UINT16, None), ("timestamp", 18, F.FLOAT64, 1e-6)], 26,
+        {"x": p[:, 0], "y": p[:, 1], "z": p[:, 2], "intensity": inten, "ring": (np.arange(n) % 64).astype(np.uint16),
+         "timestamp": 1.7e9 + np.arange(n) * 1e-5}),
 }
 for name, (fields, step, cols) in layouts.items():
     info = cases.make_info(fields, step, n)
