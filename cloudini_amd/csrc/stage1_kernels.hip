@@ -346,9 +346,21 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
     pr.has_prev = (sub_first + g.p0 + tid) > 0u;
     const size_t gi_point = (size_t)cd.first_point + sub_first + g.p0 + tid;  // index into per-point side buffers
 
-    // pass A: bytes this point contributes to the regular stream
+    // Tokens of this point. Schemas with at most kKeepOps regular ops build every token once and keep it in
+    // registers across the scan; longer ones make a length pass first and rebuild the tokens when they emit.
+    constexpr uint32_t kKeepOps = 8;
+    const bool keep = plan.n_ops <= kKeepOps;  // uniform
+    Tok kept[kKeepOps];
     uint32_t my_len = 0u;
-    if (active) {
+    if (keep) {
+#pragma unroll
+      for (uint32_t k = 0; k < kKeepOps; ++k) {
+        kept[k].w0 = kept[k].w1 = kept[k].w2 = 0u;
+        kept[k].len = 0u;
+        if (active && k < plan.n_ops) kept[k] = eval_op<true>(plan.ops[k], tile, pr, pre, gi_point);
+        my_len += kept[k].len;
+      }
+    } else if (active) {
       for (uint32_t k = 0; k < plan.n_ops; ++k) my_len += eval_op<false>(plan.ops[k], tile, pr, pre, gi_point).len;
     }
     uint32_t tile_total;
@@ -362,10 +374,18 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
       // common case: the whole tile fits the ring
       if (active) {
         uint32_t off = ss.R + excl;
-        for (uint32_t k = 0; k < plan.n_ops; ++k) {
-          const Tok t = eval_op<true>(plan.ops[k], tile, pr, pre, gi_point);
-          ring_put<false>(ring, off, t, 0u);
-          off += t.len;
+        if (keep) {
+#pragma unroll
+          for (uint32_t k = 0; k < kKeepOps; ++k) {
+            if (kept[k].len) ring_put<false>(ring, off, kept[k], 0u);
+            off += kept[k].len;
+          }
+        } else {
+          for (uint32_t k = 0; k < plan.n_ops; ++k) {
+            const Tok t = eval_op<true>(plan.ops[k], tile, pr, pre, gi_point);
+            ring_put<false>(ring, off, t, 0u);
+            off += t.len;
+          }
         }
       }
       __syncthreads();
@@ -377,7 +397,7 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
         if (active) {
           uint32_t off = ss.R + excl;
           for (uint32_t k = 0; k < plan.n_ops; ++k) {
-            const Tok t = eval_op<true>(plan.ops[k], tile, pr, pre, gi_point);
+            const Tok t = eval_op<true>(plan.ops[k], tile, pr, pre, gi_point);  // rebuilt: no dynamic index into `kept`
             ring_put<true>(ring, off, t, ss.F >> 2);
             off += t.len;
           }
