@@ -4,21 +4,35 @@
 A "step" = one cldn_hip_encode_stage1 call over one batch of synthetic clouds that is already resident in
 HBM (inputs and outputs are device buffers; nothing crosses PCIe inside the timed region). The default
 workload is BASELINE.json configs[1]: 1M-point XYZI (float32 XYZ + uint16 intensity) clouds at 1 mm,
-stage 1 only ("pre-ZSTD"), `--clouds` of them per step and per GPU (weak scaling: every rank encodes its
-own batch, no data-path collective -- whole clouds are independent).
+stage 1 only ("pre-ZSTD"), `--clouds` of them per step and per GPU.
+
+Multi-GPU, one process per GPU over RCCL:
+  --shard clouds (default)  weak scaling: every rank encodes its own batch of `--clouds` whole clouds; clouds are
+                            independent, so there is no data-path collective (RCCL carries the barrier, the
+                            per-cloud size all-gather and the max-reduction of the elapsed time).
+  --shard chunks            strong scaling: ONE cloud (`--clouds 1`, e.g. --workload c5) is cut into contiguous ranges
+                            of whole 32768-point chunks; per step rank 0 probes the adaptive-int modes on the
+                            cloud's head, broadcasts those bytes, every rank encodes its range with the modes forced,
+                            and an all-gather of the byte counts gives each rank its offset in the stream.
+`python bench.py --gpus N` launches its own N ranks (torch.distributed.run, 127.0.0.1) when it is not already
+running under a launcher; under a launcher WORLD_SIZE must equal --gpus. A box with fewer than N GPUs fails loudly.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the field meanings):
-  value            whole-job Mpoints/s over all ranks
-  roofline         dominant kernel (k_encode_regular): algorithmic bytes per launch / its average duration
-                   measured with HIP events on the codec's stream inside the timed region
+  value            whole-job Mpoints/s over all ranks (first timed block of --steps steps)
+  repeats          median/min/max ms_per_step over --repeats blocks of --steps steps
+  roofline         dominant kernel: algorithmic bytes per launch / its average duration measured with HIP events on
+                   the codec's stream inside the timed region
   cpu_baseline     the real reference (oracle/_ref, kind "reference") or the C port (kind "port") timed on the
-                   host cores on a bounded sample of the same workload
+                   host cores on a bounded sample of the same workload (rank 0, N=1 only)
+  e2e              PCIe-inclusive and single-cloud figures (never `value`), each next to the reference on the host
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -60,6 +74,19 @@ WORKLOAD_DESC = {
 }
 
 
+def host_cpus():
+    """(usable cores, visible hardware threads, cgroup quota or None): containers often grant fewer CPUs than they show."""
+    ncores = os.cpu_count() or 1
+    quota = None
+    try:  # cgroup v2 cpu.max = "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        pass
+    return (min(ncores, quota) if quota is not None else ncores), ncores, quota
+
+
 def cpu_baseline(info, cloud, budget_s: float):
     """Reference (or port) stage-1 encode of ONE cloud of the workload on the host: single thread, encoder
     constructed outside the timed region, pre-sized output (mcap_codec_benchmark.cpp:447-457 bracket)."""
@@ -75,21 +102,12 @@ def cpu_baseline(info, cloud, budget_s: float):
         out = {"value": pts / med / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "reference",
                "sample": f"{reps} x encode() of one {pts}-pt cloud of the workload, 1 thread, median "
                          f"(best {pts / best / 1e6:.1f} Mpoints/s)"}
-        ncores = os.cpu_count() or 1
-        quota = None
-        try:  # containers often grant fewer CPUs than they show (cgroup v2 cpu.max = "<quota> <period>")
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-            if q != "max":
-                quota = max(1, int(float(q) / float(per) + 0.5))
-        except (OSError, ValueError):
-            pass
-        if quota is not None:
-            ncores = min(ncores, quota)
+        ncores, visible, quota = host_cpus()
         if ncores > 1:
             reps_mt = max(3, reps // 4)
             _size, tm = ref.bench_encode(info, cloud, reps=reps_mt, threads=ncores)
             agg = float(np.sum(pts / np.median(tm, axis=1))) / 1e6
-            out["all_cores"] = {"value": agg, "cores": ncores, "visible_threads": os.cpu_count(), "cgroup_cpu_quota": quota,
+            out["all_cores"] = {"value": agg, "cores": ncores, "visible_threads": visible, "cgroup_cpu_quota": quota,
                                 "sample": f"{ncores} independent encoders x {reps_mt} reps, sum of per-thread medians"}
         return out
     except (FileNotFoundError, OSError):
@@ -104,25 +122,169 @@ def cpu_baseline(info, cloud, budget_s: float):
                 "sample": f"{reps} x orc_encode_stage1 of one {pts}-pt cloud of the workload, 1 thread, mean"}
 
 
+def _stats_ms(times):
+    t = np.asarray(times, dtype=np.float64) * 1e3
+    return {"median_ms": float(np.median(t)), "min_ms": float(t.min()), "max_ms": float(t.max()), "n": int(t.size)}
+
+
+def e2e_figures(info, cloud, dev, budget_s: float):
+    """End-to-end figures for ONE cloud of the workload per call, every call synchronous (never `value`):
+      device_resident   cldn_hip_encode_stage1, input and output in HBM
+      pinned_host       the same call with HOST tags on pinned memory (H2D + kernels + D2H)
+      pageable_host     ... on pageable memory
+      host_mirror_*     Cloudini::PointcloudEncoder (libcloudini_amd.so) constructed fresh for every call, full stream
+                        with header into a pre-sized buffer (mcap_codec_benchmark.cpp:447-457 bracket, construction
+                        included), next to the compiled reference under the same bracket on the host cores."""
+    import ctypes as C
+    import torch
+    from cloudini_amd import api, native
+    from cloudini_amd.schema import CompressionOption
+
+    step = info.point_step
+    pts = len(cloud) // step
+    out = {"points_per_call": pts, "note": "one cloud per call, synchronous; median of the calls that fit the budget"}
+    per_leg = max(0.3, budget_s / 8.0)
+
+    def timed(fn, warm=2):
+        for _ in range(warm):
+            fn()
+        ts = []
+        t_end = time.perf_counter() + per_leg
+        while len(ts) < 5 or (time.perf_counter() < t_end and len(ts) < 200):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        s = _stats_ms(ts)
+        s["Mpoints_per_s"] = pts / (s["median_ms"] * 1e-3) / 1e6
+        return s
+
+    plan = native.Plan(info)
+    codec = native.Codec(plan, device=dev.index)
+    L = native.lib()
+    cap = plan.stage1_bound(pts)
+    cp = np.array([pts], dtype=np.uint64)
+
+    d_in = torch.from_numpy(cloud).to(dev)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def dev_call():
+        codec.encode_device(d_in.data_ptr(), cp, d_out.data_ptr(), cap, d_off.data_ptr())
+        codec.synchronize()
+    out["device_resident"] = timed(dev_call)
+
+    offs = np.zeros(2, dtype=np.uint64)
+    src_pin = torch.from_numpy(cloud).pin_memory()
+    dst_pin = torch.empty(cap, dtype=torch.uint8).pin_memory()
+
+    def pinned_call():
+        rc = L.cldn_hip_encode_stage1(codec._h, C.c_void_p(src_pin.data_ptr()), 0, cp.ctypes.data_as(C.POINTER(C.c_uint64)), 1,
+                                      C.c_void_p(dst_pin.data_ptr()), cap, 0, offs.ctypes.data_as(C.c_void_p), None, None)
+        assert rc == 0
+    out["pinned_host"] = timed(pinned_call)
+
+    dst_pg = np.empty(cap, dtype=np.uint8)
+
+    def pageable_call():
+        rc = L.cldn_hip_encode_stage1(codec._h, cloud.ctypes.data_as(C.c_void_p), 0, cp.ctypes.data_as(C.POINTER(C.c_uint64)), 1,
+                                      dst_pg.ctypes.data_as(C.c_void_p), cap, 0, offs.ctypes.data_as(C.c_void_p), None, None)
+        assert rc == 0
+    out["pageable_host"] = timed(pageable_call)
+    codec.close()
+
+    try:
+        from oracle.binding import RefLib
+        ref = RefLib()
+    except (OSError, FileNotFoundError):
+        ref = None
+    pool_threads = api.stage2_threads() if hasattr(api, "stage2_threads") else None
+    for comp in (CompressionOption.NONE, CompressionOption.LZ4):
+        inf = info.copy(compression_opt=comp, use_threads=True)
+        ci, _keep = api._c_info(inf)
+        hl = api.lib()
+        hcap = api.MaxCompressedSize(inf, pts, True)
+        hout = np.empty(hcap, dtype=np.uint8)
+        size_box = [0]
+
+        def mirror_call():
+            n = hl.cldn_amd_encode(C.byref(ci), api._ptr(cloud), cloud.size, api._ptr(hout), hcap, 1)
+            assert n > 0
+            size_box[0] = n
+        leg = timed(mirror_call)
+        leg["bytes"] = int(size_box[0])
+        leg["stage2_threads"] = pool_threads if comp != CompressionOption.NONE else 0
+        leg["bracket"] = "fresh PointcloudEncoder per call (construction inside the timed region), pre-sized output, host buffers"
+        if ref is not None:
+            reps = int(max(3, min(30, per_leg / 0.03)))
+            _size, t = ref.bench_encode(inf, cloud, reps=reps, threads=1)
+            leg["reference"] = {"median_ms": float(np.median(t)) * 1e3, "min_ms": float(t.min()) * 1e3, "n": reps,
+                                "threads": "1 encode thread + the reference's own stage-2 worker (use_threads=true)",
+                                "bracket": "encoder constructed outside the timed region, pre-sized output"}
+        out["host_mirror_" + comp.name] = leg
+    return out
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start N ranks, one per GPU, and pass their exit code on."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but this box has {have} GPU(s); refusing to report n_gpus={args.gpus} "
+              "from fewer devices", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps (the first one is `value`)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOAD_DESC))
-    ap.add_argument("--clouds", type=int, default=32, help="clouds per step per GPU")
-    ap.add_argument("--points", type=int, default=1_000_000)
+    ap.add_argument("--shard", default="clouds", choices=("clouds", "chunks"))
+    ap.add_argument("--clouds", type=int, default=None, help="clouds per step per GPU (default 32; 1 with --shard chunks)")
+    ap.add_argument("--points", type=int, default=None, help="points per cloud (default 1M; 10M with --shard chunks)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic clouds generated (tiled to --clouds)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--e2e-seconds", type=float, default=6.0, help="budget of the e2e legs (0 = skip; N=1 only)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.clouds is None:
+        args.clouds = 1 if args.shard == "chunks" else 32
+    if args.points is None:
+        args.points = 10_000_000 if args.shard == "chunks" else 1_000_000
+    if args.shard == "chunks" and args.clouds != 1:
+        raise SystemExit("--shard chunks splits ONE cloud over the ranks: use --clouds 1")
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); "
+                         "start one rank per GPU (--nproc-per-node must equal --gpus)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (local rank {local_rank}, {torch.cuda.device_count()} device(s))")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -130,30 +292,17 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == world
 
-    from cloudini_amd import native
+    from cloudini_amd import native, sharding
 
     info, distinct = make_workload(args.workload, args.points, max(1, min(args.distinct, args.clouds)))
     step = info.point_step
     pts_per_cloud = len(distinct[0]) // step
-    n_clouds = args.clouds
-    host = np.concatenate([distinct[(k + rank) % len(distinct)] for k in range(n_clouds)])
-    d_points = torch.from_numpy(host).to(dev)
-    cloud_points = np.full(n_clouds, pts_per_cloud, dtype=np.uint64)
-
     plan = native.Plan(info)
     stream = torch.cuda.current_stream(dev)
     codec = native.Codec(plan, device=local_rank, stream=stream.cuda_stream)
-    cap = plan.stage1_bound(pts_per_cloud) * n_clouds
-    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
-    d_offsets = torch.zeros(n_clouds + 1, dtype=torch.int64, device=dev)
-    n_chunks = n_clouds * ((pts_per_cloud + 32767) // 32768)
-    d_chunk_sizes = torch.zeros(n_chunks, dtype=torch.int32, device=dev)
-    d_modes = torch.zeros(max(1, n_clouds * max(1, plan.adaptive_fields)), dtype=torch.uint8, device=dev)
-
-    def one_step():
-        codec.encode_device(d_points.data_ptr(), cloud_points, d_out.data_ptr(), cap, d_offsets.data_ptr(),
-                            d_chunk_sizes.data_ptr(), d_modes.data_ptr())
+    na = plan.adaptive_fields
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -161,77 +310,160 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if args.shard == "clouds":
+        n_clouds = args.clouds
+        host = np.concatenate([distinct[(k + rank) % len(distinct)] for k in range(n_clouds)])
+        cloud_points = np.full(n_clouds, pts_per_cloud, dtype=np.uint64)
+        points_local = n_clouds * pts_per_cloud
+        points_job = points_local * world
+        scaling = "weak"
+    else:
+        # one cloud, contiguous ranges of whole chunks per rank (sharding.shard_chunks); every rank only uploads its range
+        n_clouds = 1
+        p0, cnt = sharding.shard_chunks(pts_per_cloud, world, rank)
+        host = distinct[0][p0 * step:(p0 + cnt) * step]
+        head = np.ascontiguousarray(distinct[0][: min(pts_per_cloud, sharding.PROBE_POINTS) * step])
+        cloud_points = np.array([cnt], dtype=np.uint64)
+        points_local = cnt
+        points_job = pts_per_cloud
+        scaling = "strong"
+    d_points = torch.from_numpy(np.ascontiguousarray(host)).to(dev) if host.size else torch.empty(1, dtype=torch.uint8, device=dev)
+    cap = max(1, plan.stage1_bound(int(cloud_points[0])) * n_clouds)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_offsets = torch.zeros(n_clouds + 1, dtype=torch.int64, device=dev)
+    n_chunks = int(sum((int(n) + 32767) // 32768 for n in cloud_points))
+    d_chunk_sizes = torch.zeros(max(1, n_chunks), dtype=torch.int32, device=dev)
+    d_modes = torch.zeros(max(1, n_clouds * max(1, na)), dtype=torch.uint8, device=dev)
+
+    exchanged = {}
+    if args.shard == "clouds":
+        def one_step():
+            codec.encode_device(d_points.data_ptr(), cloud_points, d_out.data_ptr(), cap, d_offsets.data_ptr(),
+                                d_chunk_sizes.data_ptr(), d_modes.data_ptr())
+    else:
+        # the full exchange protocol of DESIGN.md section 6 every step: probe on the head (rank 0), broadcast of the
+        # mode bytes, encode of the range with the modes forced, all-gather of the byte counts
+        head_codec = native.Codec(plan, device=local_rank, stream=stream.cuda_stream) if rank == 0 and na else None
+        d_head = torch.from_numpy(head).to(dev) if head_codec is not None else None
+        head_pts = head.size // step
+        head_cap = plan.stage1_bound(head_pts)
+        d_head_out = torch.empty(head_cap, dtype=torch.uint8, device=dev) if head_codec is not None else None
+        d_head_modes = torch.zeros(max(1, na), dtype=torch.uint8, device=dev)
+
+        def one_step():
+            if na:
+                if head_codec is not None:
+                    head_codec.encode_device(d_head.data_ptr(), np.array([head_pts], dtype=np.uint64), d_head_out.data_ptr(),
+                                             head_cap, 0, 0, d_head_modes.data_ptr())
+                if dist is not None and world > 1:
+                    dist.broadcast(d_head_modes, src=0)        # the path's one-to-all exchange (few bytes over RCCL)
+                codec.force_modes(d_head_modes.cpu().numpy()[:na])
+            if cnt:
+                codec.encode_device(d_points.data_ptr(), cloud_points, d_out.data_ptr(), cap, d_offsets.data_ptr(),
+                                    d_chunk_sizes.data_ptr(), d_modes.data_ptr())
+            if dist is not None and world > 1:
+                mine = d_offsets[1:2].clone() if cnt else torch.zeros(1, dtype=torch.int64, device=dev)
+                gathered = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(gathered, mine)                # byte counts -> every rank's offset in the stream
+                exchanged["sizes"] = gathered
+
     for _ in range(args.warmup):
         one_step()
     codec.status()  # raises on device-side errors
     codec.enable_timing(max(1, args.steps))
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+    block_times = []
+    kms = None
+    for rep in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
         torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        block_times.append(elapsed)
+        if rep == 0 and points_local:
+            kms = [codec.kernel_ms(s) for s in range(args.steps)]
     codec.status()
+    elapsed = block_times[0]
 
-    kms = [codec.kernel_ms(s) for s in range(args.steps)]
-    regular_ms = float(np.mean([k["regular"] for k in kms]))
-    sections_ms = float(np.mean([k["sections"] for k in kms]))
-    compact_ms = float(np.mean([k["compact"] for k in kms]))
-    device_ms = float(np.mean([k["total"] for k in kms]))
+    if kms:
+        regular_ms = float(np.mean([k["regular"] for k in kms]))
+        sections_ms = float(np.mean([k["sections"] for k in kms]))
+        compact_ms = float(np.mean([k["compact"] for k in kms]))
+        device_ms = float(np.mean([k["total"] for k in kms]))
+    else:
+        regular_ms = sections_ms = compact_ms = device_ms = float("nan")
 
     offsets = d_offsets.cpu().numpy()
     total_out = int(offsets[-1])
+    out_bpp = total_out / max(1, points_local)
+
+    # job-wide output size through the size exchange of sharding.py (RCCL all-gather; also checks the exchange itself)
+    job_bytes = total_out
+    if dist is not None and world > 1:
+        if args.shard == "clouds":
+            local_sizes = [int(offsets[k + 1] - offsets[k]) for k in range(n_clouds)]
+            t = torch.tensor(local_sizes, dtype=torch.int64, device=dev)
+            gathered = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t)
+            job_bytes = int(sum(int(g.sum().item()) for g in gathered))
+        else:
+            job_bytes = int(sum(int(g.item()) for g in exchanged["sizes"]))
 
     # extra (not `value`): decode of the streams just produced, device resident, same synchronisation bracket
-    d_dec = torch.empty(host.size, dtype=torch.uint8, device=dev)
-    so = offsets.astype(np.uint64)
-    dec_steps = max(1, args.steps // 2)
-    for _ in range(min(2, args.warmup)):
-        codec.decode_device(d_out.data_ptr(), so, cloud_points, d_dec.data_ptr(), host.size)
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(dec_steps):
-        codec.decode_device(d_out.data_ptr(), so, cloud_points, d_dec.data_ptr(), host.size)
-    torch.cuda.synchronize(dev)
-    dec_elapsed = time.perf_counter() - t1
-    codec.status()
-    dec_stats = codec.decode_stats()
-    del d_dec
-    chunk_sizes = d_chunk_sizes.cpu().numpy().astype(np.int64)
-    points_per_step = n_clouds * pts_per_cloud
-    out_bpp = total_out / points_per_step
+    decode = None
+    if rank == 0 and points_local:
+        d_dec = torch.empty(max(1, host.size), dtype=torch.uint8, device=dev)
+        so = offsets.astype(np.uint64)
+        dec_steps = max(1, args.steps // 2)
+        for _ in range(min(2, max(1, args.warmup))):
+            codec.decode_device(d_out.data_ptr(), so, cloud_points, d_dec.data_ptr(), host.size)
+        dec_blocks = []
+        for _rep in range(max(1, min(3, args.repeats))):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(dec_steps):
+                codec.decode_device(d_out.data_ptr(), so, cloud_points, d_dec.data_ptr(), host.size)
+            torch.cuda.synchronize(dev)
+            dec_blocks.append((time.perf_counter() - t1) / dec_steps)
+        codec.status()
+        dec_stats = codec.decode_stats()
+        del d_dec
+        dec_ms = float(np.median(dec_blocks)) * 1e3
+        decode = {"value": points_local / (dec_ms * 1e-3) / 1e6,
+                  "unit": "Mpoints/s (rank 0, stage-1 decode of this rank's streams, device resident)",
+                  "ms_per_step": dec_ms, "ms_per_step_min": float(min(dec_blocks)) * 1e3,
+                  "ms_per_step_max": float(max(dec_blocks)) * 1e3,
+                  "HBM_GBps": (total_out + points_local * step) / (dec_ms * 1e-3) / 1e9,
+                  "chunks_parallel_regular/parallel_sections/serial/serial_sections": list(dec_stats)}
+    if dist is not None:
+        dist.barrier()
 
     if rank == 0:
-        # algorithmic bytes of the dominant kernel (k_encode_regular): every input byte read once + its own output
-        # (the interleaved float stream); the integer column hand-off to the section kernel is not counted.
-        with torch.no_grad():
-            pass
-        total_points_all = points_per_step * world
         ms_per_step = elapsed / args.steps * 1e3
-        mpts = total_points_all * args.steps / elapsed / 1e6
-        # regular-stream bytes per point: payload minus sections. Measured from chunk sizes when there are no
-        # adaptive fields; otherwise derived from the oracle-verified layout: sections are the tail of each chunk.
-        reg_bpp = out_bpp - 4.0 * n_chunks / points_per_step
-        if plan.adaptive_fields:
-            # same buffer, schema restricted to the float fields: the HIP codec's own stream of that schema is the
-            # regular stream of the full one (V5 == V4 bytes for float-only clouds, test_field_encoders.cpp:695-769)
+        mpts = points_job * args.steps / elapsed / 1e6
+        n_ch_cloud = (pts_per_cloud + 32767) // 32768
+        # regular-stream bytes per point: payload minus sections. Measured from the stream size when there are no
+        # adaptive fields; otherwise from the float-only schema of the same buffer (V5 == V4 bytes for float-only
+        # clouds, test_field_encoders.cpp:695-769): the HIP codec's own stream of that schema IS the regular stream.
+        reg_bpp = out_bpp - 4.0 * n_chunks / max(1, points_local)
+        if na:
             float_only = info.copy(fields=[f for f in info.fields if int(f.type) == 7])
             fo_codec = native.Codec(native.Plan(float_only), device=local_rank)
-            fo_stream = fo_codec.encode_host([distinct[rank % len(distinct)]])[0][0]
+            fo_stream = fo_codec.encode_host([distinct[0]])[0][0]
             fo_codec.close()
-            n_ch = (pts_per_cloud + 32767) // 32768
-            reg_bpp = (len(fo_stream) - 4 * n_ch) / pts_per_cloud
-        alg_bytes = points_per_step * (step + reg_bpp)
+            reg_bpp = (len(fo_stream) - 4 * n_ch_cloud) / pts_per_cloud
+        alg_bytes = points_local * (step + reg_bpp)
         achieved = alg_bytes / (regular_ms * 1e-3) / 1e9
-        # the regular-stream kernel of this plan: k_encode_floatn when the stream is exactly one fused FloatN encoder
+        # the regular-stream kernel of this plan: the fused FloatN kernel when the stream is exactly one FloatN encoder
         lead = 0
         for f in info.fields:
             if int(f.type) == 7 and f.resolution is not None:
@@ -243,16 +475,23 @@ def main():
         # HBM bytes per launch of the same kernel from the PMC passes of tools/profile_round.sh (rocprofv3 cannot
         # collect counters from inside this process); only quoted when the committed pass ran this very workload
         traffic, traffic_src = None, None
-        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        pdir = os.path.join(ROOT, "profiles")
+        for name in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
             if name.endswith("_traffic.json"):
                 try:
-                    t = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    t = json.load(open(os.path.join(pdir, name)))
                 except (OSError, ValueError):
                     continue
                 if (t.get("workload") == args.workload and t.get("clouds_per_gpu") == n_clouds
-                        and t.get("points_per_cloud") == pts_per_cloud):
+                        and t.get("points_per_cloud") == pts_per_cloud and args.shard == "clouds"):
                     traffic, traffic_src = float(t["hbm_bytes_per_launch"]), "profiles/" + name
                     break
+        blocks_ms = np.asarray(block_times) / args.steps * 1e3
+        if args.shard == "clouds":
+            par = f"whole clouds sharded over {world} GPU(s), no data-path collective (RCCL: barrier, size all-gather)"
+        else:
+            par = (f"one cloud cut into chunk ranges over {world} GPU(s); per step: mode probe on rank 0, RCCL broadcast of "
+                   f"{na} mode byte(s), encode with forced modes, RCCL all-gather of the byte counts")
         result = {
             "metric": "encode Mpoints/s (stage-1, pre-ZSTD)",
             "value": mpts,
@@ -262,18 +501,21 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32->i32 (u8 varint stream)",
             "data": f"synthetic lidar64 generator (cloudini_amd/synth.py), {len(distinct)} distinct clouds tiled, "
                     "inputs resident in HBM",
-            "config": {"workload": WORKLOAD_DESC[args.workload].format(clouds=n_clouds, points=pts_per_cloud),
-                       "clouds_per_gpu": n_clouds, "points_per_cloud": pts_per_cloud, "point_step": step,
-                       "parallelism": f"whole clouds sharded over {world} GPU(s), no data-path collective"},
-            "input_MBps": total_points_all * step * args.steps / elapsed / 1e6,
-            "decode": {"value": points_per_step * dec_steps / dec_elapsed / 1e6, "unit": "Mpoints/s (rank 0, stage-1 decode, "
-                       "device resident)", "ms_per_step": dec_elapsed / dec_steps * 1e3,
-                       "chunks_parallel_regular/parallel_sections/serial/serial_sections": list(dec_stats)},
+            "config": {"workload": WORKLOAD_DESC[args.workload].format(clouds=args.clouds, points=pts_per_cloud),
+                       "clouds_per_gpu": n_clouds if args.shard == "clouds" else None, "points_per_cloud": pts_per_cloud,
+                       "point_step": step, "shard": args.shard, "parallelism": par},
+            "repeats": {"blocks": int(blocks_ms.size), "steps_per_block": args.steps,
+                        "ms_per_step_median": float(np.median(blocks_ms)), "ms_per_step_min": float(blocks_ms.min()),
+                        "ms_per_step_max": float(blocks_ms.max()),
+                        "value_median": points_job / (float(np.median(blocks_ms)) * 1e-3) / 1e6},
+            "input_MBps": points_job * step * args.steps / elapsed / 1e6,
+            "job_stage1_bytes": job_bytes,
+            "decode": decode,
             "stage1_bytes_per_point": out_bpp,
             "device_ms_per_step": {dominant: regular_ms, "sections": sections_ms,
                                    "offsets+compact": compact_ms, "all_kernels": device_ms},
@@ -281,15 +523,22 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "read_only_GBps": points_per_step * step / (regular_ms * 1e-3) / 1e9,
-                         "whole_stage1_GBps": points_per_step * (step + out_bpp) / (device_ms * 1e-3) / 1e9},
+                         "read_only_GBps": points_local * step / (regular_ms * 1e-3) / 1e9,
+                         "read_only_frac": points_local * step / (regular_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "whole_stage1_GBps": points_local * (step + out_bpp) / (device_ms * 1e-3) / 1e9},
         }
         if args.cpu_baseline_seconds > 0 and world == 1:
             result["cpu_baseline"] = cpu_baseline(info, distinct[0], args.cpu_baseline_seconds)
             result["speedup_vs_cpu_1core"] = mpts / result["cpu_baseline"]["value"]
         else:
             result["cpu_baseline"] = None
+        if args.e2e_seconds > 0 and world == 1 and args.shard == "clouds":
+            try:
+                result["e2e"] = e2e_figures(info, distinct[0], dev, args.e2e_seconds)
+            except Exception as exc:  # the e2e legs must never cost the headline line
+                result["e2e"] = {"error": repr(exc)}
         print(json.dumps(result))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

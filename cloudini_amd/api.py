@@ -61,6 +61,9 @@ def lib() -> C.CDLL:
     L.cldn_amd_viz_preprocess.restype = C.c_int64
     L.cldn_amd_viz_preprocess.argtypes = [C.POINTER(_Info), u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_float),
                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.cldn_amd_stage2_threads.restype = C.c_uint32
+    L.cldn_amd_set_stage2_threads.restype = C.c_uint32
+    L.cldn_amd_set_stage2_threads.argtypes = [C.c_uint32]
     for name in ("cldn_GetHeaderAsYAML", "cldn_GetHeaderAsYAMLFromDDS", "cldn_ConvertCompressedMsgToPointCloud2Msg",
                  "cldn_DecodeCompressedData", "cldn_DecodeCompressedMessage"):
         getattr(L, name).restype = C.c_uint32
@@ -107,6 +110,15 @@ def _check(r: int) -> int:
     if r < 0:
         raise RuntimeError(lib().cldn_amd_last_error().decode(errors="replace"))
     return r
+
+
+def stage2_threads() -> int:
+    """Threads one encode()/decode() call may use for LZ4/ZSTD, the caller included (bounded pool)."""
+    return int(lib().cldn_amd_stage2_threads())
+
+
+def set_stage2_threads(n: int) -> int:
+    return int(lib().cldn_amd_set_stage2_threads(int(n)))
 
 
 def MaxCompressedSize(info, points_count: int, include_header: bool = True) -> int:

@@ -46,6 +46,27 @@ int fail(int code, const char* fmt, ...) {
     }                                                                                               \
   } while (0)
 
+// Selects the codec's device for the duration of an ABI call and gives the calling thread its own device back
+// (callers such as torch or a ROS node with several GPUs keep their own notion of the current device).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t enter(int device) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) return e;
+    if (prev == device) return hipSuccess;
+    e = hipSetDevice(device);
+    switched = (e == hipSuccess);
+    return e;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+#define ENTER_DEVICE(dev) \
+  DeviceGuard _device_guard;  \
+  HIP_TRY(_device_guard.enter(dev))
+
 int size_of_type(uint8_t t) {  // include/cloudini_lib/basic_types.hpp:73-95
   switch (t) {
     case 1: case 2: return 1;
@@ -110,6 +131,12 @@ struct PinnedBuf {
 
 }  // namespace
 
+namespace cldn {
+int launch_fail(hipError_t e, const char* what) {
+  return fail(e == hipErrorNoDevice ? CLDN_HIP_ERR_NO_DEVICE : CLDN_HIP_ERR_DEVICE, "%s failed: %s", what, hipGetErrorString(e));
+}
+}  // namespace cldn
+
 struct cldn_hip_plan {
   DevPlan dev;
   std::vector<cldn_hip_field_t> fields;
@@ -165,6 +192,14 @@ int cldn_hip_device_count(void) {
   if (e == hipErrorNoDevice) return 0;
   if (e != hipSuccess) return fail(CLDN_HIP_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
   return n;
+}
+
+int cldn_hip_current_device(void) {
+  int d = -1;
+  hipError_t e = hipGetDevice(&d);
+  if (e != hipSuccess)
+    return fail(e == hipErrorNoDevice ? CLDN_HIP_ERR_NO_DEVICE : CLDN_HIP_ERR_DEVICE, "hipGetDevice: %s", hipGetErrorString(e));
+  return d;
 }
 
 int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint32_t point_step, uint8_t version,
@@ -381,7 +416,7 @@ int cldn_hip_codec_create(const cldn_hip_plan_t* plan, int device, void* hip_str
                 hipGetErrorString(e));
   if (device < 0) HIP_TRY(hipGetDevice(&device));
   if (device >= n) return fail(CLDN_HIP_ERR_ARG, "device %d out of range (%d devices)", device, n);
-  HIP_TRY(hipSetDevice(device));
+  ENTER_DEVICE(device);
   cldn_hip_codec* c = new (std::nothrow) cldn_hip_codec();
   if (!c) return fail(CLDN_HIP_ERR_NOMEM, "out of memory");
   c->plan = *plan;
@@ -407,7 +442,8 @@ int cldn_hip_codec_create(const cldn_hip_plan_t* plan, int device, void* hip_str
 
 void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);
+  DeviceGuard guard;
+  (void)guard.enter(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_segs,
                     &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_fbflags, &c->d_pre_ptrs,
@@ -436,10 +472,11 @@ int cldn_hip_codec_synchronize(cldn_hip_codec_t* c) {
 }
 
 void* cldn_hip_codec_stream(cldn_hip_codec_t* c) { return c ? (void*)c->stream : nullptr; }
+int cldn_hip_codec_device(const cldn_hip_codec_t* c) { return c ? c->device : CLDN_HIP_ERR_ARG; }
 
 int cldn_hip_codec_enable_timing(cldn_hip_codec_t* c, uint32_t n_slots) {
   if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
-  HIP_TRY(hipSetDevice(c->device));
+  ENTER_DEVICE(c->device);
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (hipEvent_t& ev : c->events)
     if (ev) (void)hipEventDestroy(ev);
@@ -464,7 +501,7 @@ int cldn_hip_codec_kernel_ms(cldn_hip_codec_t* c, uint32_t slot, float ms[4]) {
 
 int cldn_hip_codec_status(cldn_hip_codec_t* c) {
   if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
-  HIP_TRY(hipSetDevice(c->device));
+  ENTER_DEVICE(c->device);
   if (!c->d_status.p) return CLDN_HIP_OK;
   uint32_t st = 0;
   HIP_TRY(hipMemcpyAsync(&st, c->d_status.p, sizeof(st), hipMemcpyDeviceToHost, c->stream));
@@ -536,7 +573,7 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   if ((points_loc != CLDN_HIP_HOST && points_loc != CLDN_HIP_DEVICE) ||
       (out_loc != CLDN_HIP_HOST && out_loc != CLDN_HIP_DEVICE))
     return fail(CLDN_HIP_ERR_ARG, "invalid memory location tag");
-  HIP_TRY(hipSetDevice(c->device));
+  ENTER_DEVICE(c->device);
   const DevPlan& plan = c->plan.dev;
   const uint32_t step = plan.point_step;
 
@@ -763,7 +800,7 @@ int cldn_hip_viz_preprocess(cldn_hip_codec_t* c, const void* points, int points_
   if (out_capacity < bytes)
     return fail(CLDN_HIP_ERR_CAPACITY, "viz_preprocess: output needs room for every input point (%llu < %llu)",
                 (unsigned long long)out_capacity, (unsigned long long)bytes);
-  HIP_TRY(hipSetDevice(c->device));
+  ENTER_DEVICE(c->device);
   int rc;
   const uint8_t* d_points = (const uint8_t*)points;
   if (points_loc == CLDN_HIP_HOST) {
@@ -809,7 +846,7 @@ int cldn_hip_codec_decode_stats(cldn_hip_codec_t* c, uint32_t stats[4]) {
   if (!c || !stats) return fail(CLDN_HIP_ERR_ARG, "decode_stats: NULL argument");
   memset(stats, 0, 4 * sizeof(uint32_t));
   if (!c->d_status.p) return CLDN_HIP_OK;
-  HIP_TRY(hipSetDevice(c->device));
+  ENTER_DEVICE(c->device);
   HIP_TRY(hipMemcpyAsync(stats, (const uint32_t*)c->d_status.p + 8, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost,
                          c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -839,7 +876,7 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams
   if ((streams_loc != CLDN_HIP_HOST && streams_loc != CLDN_HIP_DEVICE) ||
       (out_loc != CLDN_HIP_HOST && out_loc != CLDN_HIP_DEVICE))
     return fail(CLDN_HIP_ERR_ARG, "invalid memory location tag");
-  HIP_TRY(hipSetDevice(c->device));
+  ENTER_DEVICE(c->device);
   const DevPlan& plan = c->plan.dev;
   const uint32_t step = plan.point_step;
   if (n_clouds == 0) return CLDN_HIP_OK;

@@ -8,6 +8,7 @@
 #include "cloudini_lib/cloudini.hpp"
 #include "cloudini_lib/ros_msg_utils.hpp"
 #include "cloudini_lib/wasm_functions.h"
+#include "host_internal.hpp"
 
 #define CLDN_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -87,6 +88,12 @@ CLDN_EXPORT int64_t cldn_amd_encode(const cldn_amd_info_t* info, const uint8_t* 
     Cloudini::BufferView view(out, capacity);
     return (int64_t)encoder.encode(Cloudini::ConstBufferView(data, size), view, write_header != 0);
   });
+}
+
+CLDN_EXPORT uint32_t cldn_amd_stage2_threads(void) { return Cloudini::amd_detail::stage2Threads(); }
+CLDN_EXPORT uint32_t cldn_amd_set_stage2_threads(uint32_t n) {
+  Cloudini::amd_detail::setStage2Threads(n);
+  return Cloudini::amd_detail::stage2Threads();
 }
 
 CLDN_EXPORT int64_t cldn_amd_decode(const uint8_t* stream, uint64_t size, uint8_t* out, uint64_t capacity,
@@ -263,7 +270,8 @@ CLDN_EXPORT uint32_t cldn_EncodePointcloudData(const char* header_as_yaml, const
                                                uintptr_t output_data_ptr) {
   return guarded0([&] {
     const Cloudini::EncodingInfo info = Cloudini::EncodingInfoFromYAML(header_as_yaml);
-    if (pc_data_size != info.width * info.height * info.point_step) throw std::runtime_error("Data size mismatch");
+    const uint64_t cells = (uint64_t)info.width * info.height;  // 64-bit products: the header text is untrusted
+    if (cells > 0xffffffffull || cells * info.point_step != (uint64_t)pc_data_size) throw std::runtime_error("Data size mismatch");
     Cloudini::PointcloudEncoder encoder(info);
     std::vector<uint8_t> encoded;
     const size_t n = encoder.encode(Cloudini::ConstBufferView(reinterpret_cast<const uint8_t*>(pc_data_ptr), pc_data_size), encoded);

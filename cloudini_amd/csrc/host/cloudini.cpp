@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
+#include <deque>
+#include <memory>
 #include <functional>
 #include <cstring>
 #include <limits>
@@ -43,6 +45,7 @@ namespace Cloudini {
 namespace {
 
 constexpr size_t kPointsPerChunk = CLDN_HIP_POINTS_PER_CHUNK;
+constexpr size_t kStagingKeepBytes = size_t(64) << 20;  // per-thread staging buffers larger than this are released after the call
 
 [[noreturn]] void throwHip(const char* what) {
   throw std::runtime_error(std::string(what) + ": " + cldn_hip_last_error());
@@ -152,8 +155,13 @@ struct CodecPool {
     return k.str();
   }
 
+  // a codec is bound to the device it was created on: the caller's current device is part of the key
+  static std::string keyOn(int device, const EncodingInfo& info) { return std::to_string(device) + '@' + keyOf(info); }
+
   cldn_hip_codec_t* acquire(const EncodingInfo& info, const PlanHandle& plan) {
-    const std::string key = keyOf(info);
+    const int device = cldn_hip_current_device();
+    if (device < 0) throwHip("Cloudini (HIP) cannot create a codec");
+    const std::string key = keyOn(device, info);
     {
       std::lock_guard<std::mutex> lock(mutex);
       for (size_t i = 0; i < idle.size(); ++i) {
@@ -165,7 +173,7 @@ struct CodecPool {
       }
     }
     cldn_hip_codec_t* c = nullptr;
-    if (cldn_hip_codec_create(plan.plan, -1, nullptr, &c) != CLDN_HIP_OK) throwHip("Cloudini (HIP) cannot create a codec");
+    if (cldn_hip_codec_create(plan.plan, device, nullptr, &c) != CLDN_HIP_OK) throwHip("Cloudini (HIP) cannot create a codec");
     return c;
   }
 
@@ -176,7 +184,7 @@ struct CodecPool {
       cldn_hip_codec_destroy(idle.front().codec);
       idle.erase(idle.begin());
     }
-    idle.push_back({keyOf(info), c});
+    idle.push_back({keyOn(cldn_hip_codec_device(c), info), c});
   }
 
   ~CodecPool() {
@@ -189,77 +197,125 @@ CodecPool& pool() {
   return *p;
 }
 
-// Stage-2 workers: a small persistent pool (threads are created once per process, not per encode() call). run(n, fn)
-// calls fn(i) for i in [0, n) on the pool plus the calling thread and returns when all are done; the first exception
-// is rethrown on the caller.
+// Stage-2 workers: a small persistent pool (threads are created once per process, not per encode() call).
+// run(n, fn) calls fn(i) for i in [0, n) on the pool plus the calling thread and returns when all are done; the first
+// exception is rethrown on the caller. Every run() owns its Job object: a worker that wakes late still holds the job
+// it was woken for (a shared_ptr), whose tickets are exhausted, so it can never take a ticket of a newer job or touch
+// the caller's stack after run() has returned. Several run() calls may be in flight at once (queue).
+//
+// Size: the reference's `use_threads` means ONE stage-2 worker next to the encoding thread
+// (cloudini_lib/src/cloudini.cpp:453-499). Here chunks are independent after the GPU call, so a few workers pay off,
+// but a process with several publishers must not oversubscribe the host: the pool is bounded, default
+// min(4, hardware threads) including the caller, changed with CLOUDINI_AMD_STAGE2_THREADS (1 = caller only) before
+// the first encode/decode, or with Cloudini::amd_detail::setStage2Threads().
 class WorkerPool {
  public:
-  explicit WorkerPool(unsigned n_threads) {
-    for (unsigned t = 0; t < n_threads; ++t) threads_.emplace_back([this] { loop(); });
-  }
+  explicit WorkerPool(unsigned n_threads) { grow(n_threads); }
   ~WorkerPool() {
     // process teardown: worker threads are detached on purpose (joining at exit can deadlock in shared libraries)
     for (auto& t : threads_) t.detach();
   }
+  unsigned workers() {
+    std::lock_guard<std::mutex> lock(mutex_);
+    return static_cast<unsigned>(threads_.size());
+  }
+  void grow(unsigned n_threads) {  // never shrinks: idle workers cost nothing but a parked thread
+    std::lock_guard<std::mutex> lock(mutex_);
+    while (threads_.size() < n_threads) threads_.emplace_back([this] { loop(); });
+  }
+  // at most `max_helpers` pool threads join the caller
   template <typename Fn>
-  void run(size_t n, Fn&& fn) {
-    std::unique_lock<std::mutex> run_lock(run_mutex_);  // one job at a time
-    {
-      std::lock_guard<std::mutex> lock(mutex_);
-      job_ = [&fn](size_t i) { fn(i); };
-      n_ = n;
-      next_.store(0);
-      pending_ = n;
-      error_ = nullptr;
-      ++generation_;
+  void run(size_t n, unsigned max_helpers, Fn&& fn) {
+    if (n == 0) return;
+    auto job = std::make_shared<Job>();
+    job->fn = [&fn](size_t i) { fn(i); };
+    job->n = n;
+    job->pending = n;
+    const size_t helpers = std::min<size_t>(max_helpers, n > 0 ? n - 1 : 0);
+    if (helpers) {
+      {
+        std::lock_guard<std::mutex> lock(mutex_);
+        for (size_t h = 0; h < helpers; ++h) queue_.push_back(job);
+      }
+      if (helpers == 1) wake_.notify_one();
+      else wake_.notify_all();
     }
-    wake_.notify_all();
-    drain();
-    std::unique_lock<std::mutex> lock(mutex_);
-    done_.wait(lock, [this] { return pending_ == 0; });
-    job_ = nullptr;
-    if (error_) std::rethrow_exception(error_);
+    drain(*job);
+    {
+      std::unique_lock<std::mutex> lock(job->mutex);
+      job->done.wait(lock, [&] { return job->pending == 0; });
+    }
+    {  // helpers that have not started yet must not find the job later: its fn refers to this stack frame
+      std::lock_guard<std::mutex> lock(mutex_);
+      for (auto it = queue_.begin(); it != queue_.end();) it = (*it == job) ? queue_.erase(it) : it + 1;
+    }
+    if (job->error) std::rethrow_exception(job->error);
   }
 
  private:
-  void drain() {
+  struct Job {
+    std::function<void(size_t)> fn;
+    size_t n = 0;
+    std::atomic<size_t> next{0};
+    std::mutex mutex;
+    std::condition_variable done;
+    size_t pending = 0;
+    std::exception_ptr error;
+  };
+  static void drain(Job& job) {
     for (;;) {
-      const size_t i = next_.fetch_add(1);
-      if (i >= n_) return;
+      const size_t i = job.next.fetch_add(1);
+      if (i >= job.n) return;  // tickets exhausted: nothing of the job is touched any more
+      std::exception_ptr err;
       try {
-        job_(i);
+        job.fn(i);
       } catch (...) {
-        std::lock_guard<std::mutex> lock(mutex_);
-        if (!error_) error_ = std::current_exception();
+        err = std::current_exception();
       }
-      std::lock_guard<std::mutex> lock(mutex_);
-      if (--pending_ == 0) done_.notify_all();
+      std::lock_guard<std::mutex> lock(job.mutex);
+      if (err && !job.error) job.error = err;
+      if (--job.pending == 0) job.done.notify_all();
     }
   }
   void loop() {
-    uint64_t seen = 0;
     for (;;) {
+      std::shared_ptr<Job> job;
       {
         std::unique_lock<std::mutex> lock(mutex_);
-        wake_.wait(lock, [&] { return generation_ != seen; });
-        seen = generation_;
+        wake_.wait(lock, [&] { return !queue_.empty(); });
+        job = queue_.front();
+        queue_.pop_front();
       }
-      drain();
+      // A ticket is only valid while pending > 0, and run() cannot return before pending == 0: fn is alive whenever a
+      // ticket below n is drawn.
+      drain(*job);
     }
   }
   std::vector<std::thread> threads_;
-  std::mutex mutex_, run_mutex_;
-  std::condition_variable wake_, done_;
-  std::function<void(size_t)> job_;
-  size_t n_ = 0;
-  std::atomic<size_t> next_{0};
-  size_t pending_ = 0;
-  uint64_t generation_ = 0;
-  std::exception_ptr error_;
+  std::mutex mutex_;
+  std::condition_variable wake_;
+  std::deque<std::shared_ptr<Job>> queue_;
 };
 
+std::atomic<unsigned> g_stage2_threads{0};  // 0 = not decided yet
+
+unsigned stage2Threads() {
+  unsigned n = g_stage2_threads.load();
+  if (n) return n;
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  n = std::min(4u, hw);
+  if (const char* e = std::getenv("CLOUDINI_AMD_STAGE2_THREADS")) {
+    const long v = std::strtol(e, nullptr, 10);
+    if (v >= 1) n = static_cast<unsigned>(std::min<long>(v, 256));
+  }
+  g_stage2_threads.store(n);
+  return n;
+}
+
 WorkerPool& stage2Pool() {
-  static WorkerPool* p = new WorkerPool(std::min(31u, std::max(1u, std::thread::hardware_concurrency()) - 1u));
+  static WorkerPool* p = new WorkerPool(0);
+  const unsigned want = stage2Threads() - 1u;  // the caller is one of the threads
+  if (p->workers() < want) p->grow(want);
   return *p;
 }
 
@@ -353,21 +409,38 @@ std::string EncodingInfoToYAML(const EncodingInfo& info) {
 
 EncodingInfo EncodingInfoFromYAML(std::string_view yaml) {
   const yaml_lite::Document doc = yaml_lite::parse(yaml);
+  // header text is untrusted input: every integer is range-checked before it is narrowed
+  auto ranged = [](long long v, long long hi, const char* what) -> long long {
+    if (v < 0 || v > hi) throw std::runtime_error(std::string("YAML: '") + what + "' out of range: " + std::to_string(v));
+    return v;
+  };
+  constexpr long long kU32 = 0xffffffffll;
   EncodingInfo info;
-  info.version = static_cast<uint8_t>(doc.integer("version"));
-  info.width = static_cast<uint32_t>(doc.integer("width"));
-  info.height = static_cast<uint32_t>(doc.integer("height"));
-  info.point_step = static_cast<uint32_t>(doc.integer("point_step"));
+  info.version = static_cast<uint8_t>(ranged(doc.integer("version"), 255, "version"));
+  info.width = static_cast<uint32_t>(ranged(doc.integer("width"), kU32, "width"));
+  info.height = static_cast<uint32_t>(ranged(doc.integer("height"), kU32, "height"));
+  info.point_step = static_cast<uint32_t>(ranged(doc.integer("point_step"), kU32, "point_step"));
   info.encoding_opt = EncodingOptionsFromString(doc.scalar("encoding_opt"));
   info.compression_opt = CompressionOptionFromString(doc.scalar("compression_opt"));
   if (doc.has("encoding_config")) info.encoding_config = doc.scalar("encoding_config");
   for (const auto& item : doc.items) {
     PointField f;
     f.name = item.scalar("name");
-    f.offset = static_cast<uint32_t>(item.integer("offset"));
+    f.offset = static_cast<uint32_t>(ranged(item.integer("offset"), kU32, "offset"));
     f.type = FieldTypeFromString(item.scalar("type"));
     const std::string res = item.scalar("resolution");
-    if (res != "null") f.resolution = std::stof(res);
+    if (res != "null") {
+      size_t used = 0;
+      float value = 0.0f;
+      try {
+        value = std::stof(res, &used);
+      } catch (const std::exception&) {
+        throw std::runtime_error("YAML: 'resolution' is not a number: " + res);
+      }
+      if (used != res.size() || !(value > 0.0f) || !(value <= std::numeric_limits<float>::max()))
+        throw std::runtime_error("YAML: 'resolution' must be a positive finite number: " + res);
+      f.resolution = value;
+    }
     info.fields.push_back(std::move(f));
   }
   return info;
@@ -546,6 +619,15 @@ size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output,
   // every message (cloudini_publisher_plugin.cpp:53-55) and a 20 MB zero-filled vector per message costs more than
   // the whole encode.
   static thread_local std::vector<uint8_t> tl_stage1, tl_stage2;
+  // ... but one huge cloud must not pin its staging memory to the thread for ever: buffers above the cap are given
+  // back when this call is over
+  struct Trim {
+    std::vector<uint8_t>&a, &b;
+    ~Trim() {
+      if (a.capacity() > kStagingKeepBytes) std::vector<uint8_t>().swap(a);
+      if (b.capacity() > kStagingKeepBytes) std::vector<uint8_t>().swap(b);
+    }
+  } trim{tl_stage1, tl_stage2};
   if (!direct) {
     if (tl_stage1.size() < bound) tl_stage1.resize(bound);
     s1 = tl_stage1.data();
@@ -568,8 +650,7 @@ size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output,
       pos += 4 + impl_->chunk_sizes[c];
     }
   }
-  const unsigned workers =
-      (info_.use_threads && n_chunks > 1) ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), unsigned(n_chunks)) : 1u;
+  const unsigned workers = (info_.use_threads && n_chunks > 1) ? std::min<unsigned>(stage2Threads(), unsigned(n_chunks)) : 1u;
   if (workers <= 1) {
     for (size_t c = 0; c < n_chunks; ++c) {
       uint8_t* size_ptr = dst + written;
@@ -591,7 +672,7 @@ size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output,
   uint8_t* scratch = tl_stage2.data();
   static const bool timing = std::getenv("CLDN_HOST_TIMING") != nullptr;  // diagnostics: stage-2 wall time to stderr
   const auto t0 = std::chrono::steady_clock::now();
-  stage2Pool().run(n_chunks, [&](size_t c) {
+  stage2Pool().run(n_chunks, workers - 1u, [&](size_t c) {
     packed_size[c] = compressChunk(info_.compression_opt, s1 + src_off[c], impl_->chunk_sizes[c], scratch + c * slot, slot);
   });
   if (timing)
@@ -655,6 +736,12 @@ void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compres
   const uint8_t* s1 = compressed_data.data();
   uint64_t s1_size = compressed_data.size();
   static thread_local std::vector<uint8_t> tl_stage1;  // per thread, not per decoder (see PointcloudEncoder::encode)
+  struct Trim {
+    std::vector<uint8_t>& a;
+    ~Trim() {
+      if (a.capacity() > kStagingKeepBytes) std::vector<uint8_t>().swap(a);
+    }
+  } trim{tl_stage1};
   {
     struct ChunkRef {
       const uint8_t* src;
@@ -696,8 +783,8 @@ void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compres
           got[c] = static_cast<uint32_t>(n);
         }
       };
-      if (info.use_threads && refs.size() > 1) {
-        stage2Pool().run(refs.size(), undo);
+      if (info.use_threads && refs.size() > 1 && stage2Threads() > 1u) {
+        stage2Pool().run(refs.size(), stage2Threads() - 1u, undo);
       } else {
         for (size_t c = 0; c < refs.size(); ++c) undo(c);
       }
@@ -722,6 +809,9 @@ void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compres
 }
 
 namespace amd_detail {
+
+unsigned stage2Threads() { return Cloudini::stage2Threads(); }
+void setStage2Threads(unsigned n) { g_stage2_threads.store(std::max(1u, std::min(n, 256u))); }
 
 uint64_t vizPreprocessOnDevice(const uint8_t* points, size_t n_points, uint32_t point_step, uint32_t xyz_offset,
                                float resolution, uint8_t* out, size_t out_capacity) {

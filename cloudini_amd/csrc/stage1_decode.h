@@ -173,7 +173,7 @@ __device__ void decode_section_serial(Rd& r, uint8_t* base, uint32_t step, uint3
       else diff = rd_varint(r);
       const uint64_t run_len = rd_uvarint(r);
       if (r.bad) return;
-      if (out_index + run_len > n) { r.bad = true; return; }
+      if (run_len > (uint64_t)n - out_index) { r.bad = true; return; }  // no addition: run_len may be 2^64-1
       for (uint64_t q = 0; q < run_len; ++q) {
         if (mode == 3u) {
           prev = (int64_t)((uint64_t)prev + (uint64_t)diff);
@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_sections(const DevPlan pl
                 if (shift >= 64u) { fail = true; break; }
               }
               if (fail) break;
-              if ((uint64_t)sidx + len > (uint64_t)n) { fail = true; break; }
+              if (len > (uint64_t)n - (uint64_t)sidx) { fail = true; break; }  // no addition: len may be 2^64-1
               start[r] = sidx;
               raw[2u * r] = v;
               raw[2u * r + 1u] = 0ull;

@@ -1689,10 +1689,7 @@ int floatn_loadw(const DevPlan& p, int lanes, bool unal, int l3) {
   return loadw;
 }
 
-int hip_fail(hipError_t e, const char* what) {
-  fprintf(stderr, "[cloudini_hip] %s: %s\n", what, hipGetErrorString(e));
-  return CLDN_HIP_ERR_DEVICE;
-}
+int hip_fail(hipError_t e, const char* what) { return launch_fail(e, what); }
 }  // namespace
 
 int stage1_configure_kernels() {

@@ -63,6 +63,9 @@ struct DecodeLaunch {
 
 constexpr size_t kDecChunkBytes = 48;
 
+// Launch errors go to the ABI's thread-local error string (cldn_hip_last_error), implemented in hip_abi.hip.
+int launch_fail(hipError_t e, const char* what);
+
 int stage1_configure_kernels();
 int stage1_launch_encode(const EncodeLaunch& L);
 int stage1_launch_decode(const DecodeLaunch& L);

@@ -139,10 +139,7 @@ __global__ __launch_bounds__(kVizBlock) void k_viz_gather(const uint8_t* __restr
   }
 }
 
-int viz_fail(hipError_t e, const char* what) {
-  fprintf(stderr, "[cloudini_hip] %s: %s\n", what, hipGetErrorString(e));
-  return -4;  // CLDN_HIP_ERR_DEVICE
-}
+int viz_fail(hipError_t e, const char* what) { return launch_fail(e, what); }
 }  // namespace
 
 uint64_t viz_table_capacity(uint64_t n_points) {
@@ -154,12 +151,12 @@ uint64_t viz_table_capacity(uint64_t n_points) {
 int viz_launch(const VizLaunch& L) {
   hipError_t e;
   if (L.n_points == 0) {
-    (void)hipMemsetAsync(L.total, 0, sizeof(unsigned long long), L.stream);
+    if ((e = hipMemsetAsync(L.total, 0, sizeof(unsigned long long), L.stream)) != hipSuccess) return viz_fail(e, "hipMemsetAsync(viz total)");
     return 0;
   }
   const uint64_t cap = viz_table_capacity(L.n_points);
-  (void)hipMemsetAsync(L.keys, 0xff, cap * sizeof(unsigned long long), L.stream);
-  (void)hipMemsetAsync(L.first, 0xff, cap * sizeof(uint32_t), L.stream);
+  if ((e = hipMemsetAsync(L.keys, 0xff, cap * sizeof(unsigned long long), L.stream)) != hipSuccess) return viz_fail(e, "hipMemsetAsync(viz keys)");
+  if ((e = hipMemsetAsync(L.first, 0xff, cap * sizeof(uint32_t), L.stream)) != hipSuccess) return viz_fail(e, "hipMemsetAsync(viz first)");
   const uint32_t n_blocks = (uint32_t)((L.n_points + kVizBlock - 1) / kVizBlock);
   hipLaunchKernelGGL(k_viz_insert, dim3((uint32_t)((L.n_points + 255) / 256)), dim3(256), 0, L.stream, L.points, L.n_points,
                      L.point_step, L.xyz_offset, L.inv_res, L.keys, L.first, cap - 1, L.slot_of);

@@ -54,6 +54,9 @@ def lib() -> C.CDLL:
     L.cldn_hip_last_error.restype = C.c_char_p
     L.cldn_hip_abi_version.restype = C.c_int
     L.cldn_hip_device_count.restype = C.c_int
+    L.cldn_hip_current_device.restype = C.c_int
+    L.cldn_hip_codec_device.restype = C.c_int
+    L.cldn_hip_codec_device.argtypes = [vp]
     L.cldn_hip_plan_create.restype = C.c_int
     L.cldn_hip_plan_create.argtypes = [C.POINTER(_Field), C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8,
                                        C.POINTER(vp)]

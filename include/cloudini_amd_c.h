@@ -61,6 +61,13 @@ int64_t cldn_amd_ros_decompress(const uint8_t* dds, uint64_t size, uint8_t* out,
 int64_t cldn_amd_viz_preprocess(const cldn_amd_info_t* info, const uint8_t* data, uint64_t size, uint8_t* out,
                                 uint64_t capacity, float* res_out, uint32_t* width_out, uint32_t* height_out);
 
+/* Stage-2 (LZ4 / ZSTD) threads a single encode()/decode() call with use_threads may occupy, the caller included.
+ * The reference's flag means one extra worker (cloudini_lib/src/cloudini.cpp:453-499); here the pool is bounded:
+ * default min(4, hardware threads), overridden by the environment variable CLOUDINI_AMD_STAGE2_THREADS (read once)
+ * or by this setter (1 = the calling thread only). Returns the value in effect. */
+uint32_t cldn_amd_stage2_threads(void);
+uint32_t cldn_amd_set_stage2_threads(uint32_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,7 @@ typedef struct cldn_hip_codec cldn_hip_codec_t; /* execution context: device, st
 const char* cldn_hip_last_error(void);
 int cldn_hip_abi_version(void);
 int cldn_hip_device_count(void); /* >= 0, or a negative error */
+int cldn_hip_current_device(void); /* the calling thread's current HIP device (>= 0), or a negative error */
 
 /* Plan = the encoder/decoder selection of BuildV4Encoders (src/v4_codec.cpp:26-40), buildV5Plan
  * (src/v5_codec.cpp:719-740) and CreateCompatibleEncoder (src/codec_common.cpp:116-153) for
@@ -81,11 +82,14 @@ uint32_t cldn_hip_plan_max_point_bytes(const cldn_hip_plan_t* plan);    /* detai
  * (src/cloudini.cpp:249-292): the capacity the framed stage-1 stream of one cloud must be given. */
 uint64_t cldn_hip_stage1_bound(const cldn_hip_plan_t* plan, uint64_t n_points);
 
-/* device < 0: current device. hip_stream: a hipStream_t (NULL = the codec creates its own stream). */
+/* device < 0: current device. hip_stream: a hipStream_t (NULL = the codec creates its own stream).
+ * A codec works on its own device whatever the caller's current device is; every entry point restores the calling
+ * thread's current device before it returns. */
 int cldn_hip_codec_create(const cldn_hip_plan_t* plan, int device, void* hip_stream, cldn_hip_codec_t** out);
 void cldn_hip_codec_destroy(cldn_hip_codec_t* codec);
 int cldn_hip_codec_synchronize(cldn_hip_codec_t* codec);
 void* cldn_hip_codec_stream(cldn_hip_codec_t* codec);
+int cldn_hip_codec_device(const cldn_hip_codec_t* codec); /* device the codec was created on */
 
 /* Encode a batch of clouds that share the plan's schema.
  *   points         n_total_points * point_step bytes, clouds back to back (cloud k has cloud_points[k] points)

@@ -1005,7 +1005,9 @@ static int decode_section(const afield_t* f, rd_t* r, uint8_t* base, uint32_t st
           shift += 7;
           if (shift >= 64) return ORC_ERR_CORRUPT;
         }
-        if (oi + run_len > n) return ORC_ERR_CORRUPT;
+        /* :836/:858 test `out_index + run_len > n`; a 10-byte run_len of 2^64-1 wraps that sum and the reference then
+           writes out of bounds. The oracle (like the HIP decoder) compares without the addition and rejects. */
+        if (run_len > n - oi) return ORC_ERR_CORRUPT;
         for (uint64_t q = 0; q < run_len; ++q) {
           if (mode == 2) {
             memcpy(base + oi * step + f->offset, &raw, (size_t)f->bpv);

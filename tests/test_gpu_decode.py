@@ -253,3 +253,34 @@ def test_corrupt_sections_are_rejected(oracle, what):
     with pytest.raises(Exception):
         oracle.decode_stage1(info, s, n)
     codec.close()
+
+
+def _wrapping_run_stream(mode):
+    """One chunk of an integer-only UINT16 cloud whose SECOND run carries run_len = 2^64 - 1 (nine 0xFF bytes and
+    0x01). The reference's bound test `out_index + run_len > n` (v5_codec.cpp:836, :858) wraps on it; a decoder
+    that copies the test fills memory far beyond the output."""
+    huge = bytes([0xFF] * 9 + [0x01])
+    if mode == 2:   # Rle: raw u16 value, uvarint run_len
+        body = bytes([2]) + (2).to_bytes(4, "little") + bytes([7, 0, 1]) + bytes([9, 0]) + huge
+    else:           # DeltaRle: varint diff, uvarint run_len
+        body = bytes([3]) + (2).to_bytes(4, "little") + bytes([0x03, 1]) + bytes([0x03]) + huge
+    return np.frombuffer(len(body).to_bytes(4, "little") + body, dtype=np.uint8).copy()
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+def test_run_length_that_wraps_the_bound_check_is_rejected(oracle, mode):
+    from cloudini_amd import native
+    n = 200
+    info, _data = cases.int_only(np.zeros(n, dtype=np.uint16), cases.F.UINT16)
+    s = _wrapping_run_stream(mode)
+    codec = native.Codec(native.Plan(info))
+    out = np.full(n * info.point_step, 0x5A, dtype=np.uint8)
+    with pytest.raises(native.CloudiniHipError) as e:
+        codec.decode_host([s], [n], out=out)
+    assert e.value.code == -6
+    with pytest.raises(Exception):
+        oracle.decode_stage1(info, s, n)
+    # the codec is still usable afterwards (no fault, no hang)
+    good = oracle.encode_stage1(info, _data)
+    assert np.array_equal(codec.decode_host([good], [n])[0], oracle.decode_stage1(info, good, n))
+    codec.close()
