@@ -158,6 +158,11 @@ struct cldn_hip_codec {
   DevBuf d_cols[kMaxAdaptive];
   DevBuf d_ranks[kMaxAdaptive];
   DevBuf d_dec_meta, d_fbflags, d_pre_ptrs;
+  DevBuf d_pieces, d_fzero, d_prec, d_bitmaps, d_secplace;  // single-pass encoder (stage1_fused.h)
+  uint32_t n_pieces = 0;
+  uint32_t last_piece_pts = 0;
+  int pipeline = 0;           // cldn_hip_codec_pipeline: 0 auto, 1 tile kernel + slots, 2 pieces + slots, 3 single pass
+  bool bitmaps_dirty = true;  // set after an aborted call: the kernel only clears the bitmaps of calls that finish
   DevBuf d_viz_keys, d_viz_first, d_viz_slot, d_viz_blocks, d_viz_total;  // applyVizLossyPreprocessing workspace
   DevBuf d_pre[kMaxGorilla];
   PinnedBuf h_stage;   // chunk table upload
@@ -448,7 +453,8 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_segs,
                     &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_fbflags, &c->d_pre_ptrs,
                     &c->d_pre[0], &c->d_pre[1], &c->d_pre[2], &c->d_pre[3], &c->d_viz_keys, &c->d_viz_first,
-                    &c->d_viz_slot, &c->d_viz_blocks, &c->d_viz_total};
+                    &c->d_viz_slot, &c->d_viz_blocks, &c->d_viz_total, &c->d_pieces, &c->d_fzero, &c->d_prec,
+                    &c->d_bitmaps, &c->d_secplace};
   for (DevBuf* b : bufs) b->release();
   for (int a = 0; a < kMaxAdaptive; ++a) {
     c->d_cols[a].release();
@@ -506,13 +512,19 @@ int cldn_hip_codec_status(cldn_hip_codec_t* c) {
   uint32_t st = 0;
   HIP_TRY(hipMemcpyAsync(&st, c->d_status.p, sizeof(st), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (st & (ST_FUSED_TIMEOUT | ST_FUSED_MISMATCH)) {
+    c->bitmaps_dirty = true;
+    return fail(CLDN_HIP_ERR_DEVICE, "single-pass encoder failed (status 0x%x: %s)", st,
+                (st & ST_FUSED_TIMEOUT) ? "a wave waited too long for its predecessors" : "a section is not the size its statistics promised");
+  }
   if (st & ST_OUT_OVERFLOW) return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for the encoded stream");
   if (st & ST_CORRUPT) return fail(CLDN_HIP_ERR_CORRUPT, "malformed stage-1 stream");
   return CLDN_HIP_OK;
 }
 
 // Build (or reuse) the chunk table of a batch. Returns the number of chunks and total points.
-static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, uint32_t n_clouds,
+// piece_pts != 0: also the piece table of the single-pass encoder (pieces of piece_pts points, per chunk padded to 4)
+static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, uint32_t n_clouds, uint32_t piece_pts,
                               uint32_t* n_chunks_out, uint64_t* n_points_out) {
   uint64_t total_points = 0;
   uint64_t n_chunks64 = 0;
@@ -524,14 +536,27 @@ static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, u
   const uint32_t n_chunks = (uint32_t)n_chunks64;
   *n_chunks_out = n_chunks;
   *n_points_out = total_points;
-  const bool same = c->last_cloud_points.size() == n_clouds && c->last_n_chunks == n_chunks &&
-                    std::equal(c->last_cloud_points.begin(), c->last_cloud_points.end(), cloud_points);
   int rc;
+  const bool same = c->last_cloud_points.size() == n_clouds && c->last_n_chunks == n_chunks &&
+                    c->last_piece_pts == piece_pts &&
+                    std::equal(c->last_cloud_points.begin(), c->last_cloud_points.end(), cloud_points);
+  uint64_t n_pieces64 = 0;
+  if (piece_pts) {
+    for (uint32_t k = 0; k < n_clouds; ++k) {
+      const uint64_t full = cloud_points[k] / kPointsPerChunk, rest = cloud_points[k] % kPointsPerChunk;
+      n_pieces64 += full * ((((uint64_t)kPointsPerChunk + piece_pts - 1) / piece_pts + 3) & ~uint64_t(3));
+      if (rest) n_pieces64 += ((rest + piece_pts - 1) / piece_pts + 3) & ~uint64_t(3);
+    }
+    if (n_pieces64 > 0x7fffffffull) return fail(CLDN_HIP_ERR_ARG, "batch too large");
+  }
+  c->n_pieces = (uint32_t)n_pieces64;
+  if (piece_pts && (rc = c->d_pieces.ensure(std::max<size_t>(1, (size_t)n_pieces64) * sizeof(PieceDesc))) != CLDN_HIP_OK) return rc;
   if ((rc = c->d_chunks.ensure(std::max<size_t>(1, n_chunks) * sizeof(ChunkDesc))) != CLDN_HIP_OK) return rc;
   if ((rc = c->d_cloud_first.ensure((size_t)(n_clouds + 1) * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
   if (same) return CLDN_HIP_OK;
 
-  const size_t bytes = (size_t)n_chunks * sizeof(ChunkDesc) + (size_t)(n_clouds + 1) * sizeof(uint32_t);
+  const size_t head_bytes = ((size_t)n_chunks * sizeof(ChunkDesc) + (size_t)(n_clouds + 1) * sizeof(uint32_t) + 31) & ~size_t(31);
+  const size_t bytes = head_bytes + (size_t)n_pieces64 * sizeof(PieceDesc);
   // the staging buffer may still be in flight from the previous (asynchronous) call
   HIP_TRY(hipStreamSynchronize(c->stream));
   if ((rc = c->h_stage.ensure(bytes)) != CLDN_HIP_OK) return rc;
@@ -556,6 +581,25 @@ static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, u
     }
   }
   hf[n_clouds] = ci;
+  if (piece_pts && n_pieces64) {
+    PieceDesc* hp = (PieceDesc*)((uint8_t*)c->h_stage.p + head_bytes);
+    size_t g = 0;
+    for (uint32_t k = 0; k < n_chunks; ++k) {
+      const uint32_t P = (((hc[k].n_points + piece_pts - 1) / piece_pts) + 3u) & ~3u;
+      for (uint32_t q = 0; q < P; ++q) {
+        hp[g].chunk_first_point = hc[k].first_point;
+        hp[g].chunk = k;
+        hp[g].cloud = hc[k].cloud;
+        hp[g].n_chunk_points = hc[k].n_points;
+        hp[g].p = (uint16_t)q;
+        hp[g].P = (uint16_t)P;
+        hp[g].pad[0] = hp[g].pad[1] = 0;
+        ++g;
+      }
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_pieces.p, hp, g * sizeof(PieceDesc), hipMemcpyHostToDevice, c->stream));
+  }
+  c->last_piece_pts = piece_pts;
   if (n_chunks)
     HIP_TRY(hipMemcpyAsync(c->d_chunks.p, hc, (size_t)n_chunks * sizeof(ChunkDesc), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_cloud_first.p, hf, (size_t)(n_clouds + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
@@ -579,7 +623,11 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
 
   uint32_t n_chunks = 0;
   uint64_t n_points = 0;
-  int rc = upload_batch_shape(c, cloud_points, n_clouds, &n_chunks, &n_points);
+  // device-resident inputs decide the kernel variant by their address; host inputs are staged into an aligned buffer
+  const uint8_t* variant_ptr = points_loc == CLDN_HIP_DEVICE ? (const uint8_t*)points : nullptr;
+  const uint32_t piece_pts = c->pipeline == 1 ? 0u : stage1_piece_points(plan, variant_ptr);
+  const bool want_single_pass = c->pipeline == 3 && piece_pts != 0u && stage1_single_pass_ok(plan, variant_ptr);
+  int rc = upload_batch_shape(c, cloud_points, n_clouds, piece_pts, &n_chunks, &n_points);
   if (rc != CLDN_HIP_OK) return rc;
   if (n_points && !points) return fail(CLDN_HIP_ERR_ARG, "points is NULL");
 
@@ -601,8 +649,14 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
     while (subs < 32u && (uint64_t)n_chunks * subs < 6000u) subs *= 2u;
   }
   if (subs < 1u || subs > 32u || (subs & (subs - 1u))) subs = 1u;
-  const uint32_t sub_points = kPointsPerChunk / subs;
-  const uint32_t sub_stride = (uint32_t)((((uint64_t)sub_points * plan.max_regular_bytes + 64u) + 255u) & ~uint64_t(255));
+  // single-pass encoder: regular bytes go straight to their final place, the slots only hold the sections
+  const bool pieces = piece_pts != 0u && n_chunks != 0u;   // regular stream by the piece kernel
+  const bool fused = pieces && want_single_pass;            // ... placed by the in-kernel protocol
+  if (fused) subs = 0u;
+  else if (pieces) subs = ((((kPointsPerChunk + piece_pts - 1u) / piece_pts) + 3u) & ~3u) / 4u;  // one segment per workgroup (4 pieces)
+  const uint32_t sub_points = fused ? 0u : (pieces ? piece_pts : kPointsPerChunk / subs);
+  const uint32_t sub_stride = fused ? 0u : (pieces ? 4u * stage1_piece_slot_stride(plan, variant_ptr)
+                                                   : (uint32_t)((((uint64_t)sub_points * plan.max_regular_bytes + 64u) + 255u) & ~uint64_t(255)));
   const uint32_t segs_per_chunk = subs + 2u * n_adaptive;
   const uint64_t reg_stride = (uint64_t)subs * sub_stride;
   const uint64_t slot_stride = reg_stride + (uint64_t)n_adaptive * kSectionStride;
@@ -612,14 +666,17 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   if ((rc = c->d_modes.ensure(std::max<size_t>(1, (size_t)n_clouds * std::max(1u, n_adaptive)))) != CLDN_HIP_OK)
     return rc;
   HIP_TRY(hipMemsetAsync(c->d_status.p, 0, 256, c->stream));
+  // a batch without a single point launches no probe: its clouds commit mode 0 (DeltaVarint), like an encode() call of
+  // the reference that never reaches the analysis (src/v5_codec.cpp:934-949)
+  if (n_chunks == 0 && n_clouds && n_adaptive) HIP_TRY(hipMemsetAsync(c->d_modes.p, 0, (size_t)n_clouds * n_adaptive, c->stream));
 
   const uint8_t* d_points = (const uint8_t*)points;
   uint8_t* d_outp = (uint8_t*)out;
   if (n_chunks) {
-    if ((rc = c->d_segs.ensure((size_t)n_chunks * segs_per_chunk * sizeof(Seg))) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_segs.ensure(std::max<size_t>(16, (size_t)n_chunks * segs_per_chunk * sizeof(Seg)))) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_payload.ensure((size_t)n_chunks * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_dst.ensure((size_t)n_chunks * sizeof(uint64_t))) != CLDN_HIP_OK) return rc;
-    if ((rc = c->d_slots.ensure((size_t)n_chunks * slot_stride)) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_slots.ensure(std::max<size_t>(16, (size_t)n_chunks * slot_stride))) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_fbflags.ensure((size_t)n_chunks * std::max(1u, n_adaptive))) != CLDN_HIP_OK) return rc;
     HIP_TRY(hipMemsetAsync(c->d_fbflags.p, 0, (size_t)n_chunks * std::max(1u, n_adaptive), c->stream));
     for (uint32_t a = 0; a < n_adaptive; ++a) {
@@ -645,7 +702,31 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
       if ((rc = c->d_out.ensure((size_t)need)) != CLDN_HIP_OK) return rc;
       d_outp = (uint8_t*)c->d_out.p;
     }
-    HIP_TRY(hipMemsetAsync(c->d_segs.p, 0, (size_t)n_chunks * segs_per_chunk * sizeof(Seg), c->stream));
+    if (segs_per_chunk) HIP_TRY(hipMemsetAsync(c->d_segs.p, 0, (size_t)n_chunks * segs_per_chunk * sizeof(Seg), c->stream));
+  }
+  // workspace of the single-pass encoder: one zero-filled block (control word, per-chunk arrival counters, look-back
+  // records), piece records, per-chunk presence bitmaps (zero between calls: the kernel clears what it sets)
+  const uint32_t n_bm = fused ? stage1_fused_bitmap_fields(plan) : 0u;
+  const size_t fz_arrivals = sizeof(FusedCtrl);
+  const size_t fz_lb = (fz_arrivals + (size_t)n_chunks * 4u + 15u) & ~size_t(15);
+  const size_t fz_lbc = fz_lb + (size_t)c->n_pieces * 8u;
+  const size_t fz_start1 = fz_lbc + (size_t)n_chunks * 8u;
+  const size_t fz_bytes = fz_start1 + (size_t)n_chunks * 8u;
+  const uint32_t prec_stride = 2u + 8u * n_adaptive;
+  if (fused) {
+    if ((rc = c->d_fzero.ensure(fz_bytes)) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_prec.ensure((size_t)c->n_pieces * prec_stride * 4u)) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_secplace.ensure(std::max<size_t>(16, (size_t)n_chunks * n_adaptive * 16u))) != CLDN_HIP_OK) return rc;
+    const size_t bm_bytes = (size_t)n_chunks * n_bm * 8192u;
+    if (bm_bytes) {
+      const void* before = c->d_bitmaps.p;
+      if ((rc = c->d_bitmaps.ensure(bm_bytes)) != CLDN_HIP_OK) return rc;
+      if (c->d_bitmaps.p != before || c->bitmaps_dirty) {
+        HIP_TRY(hipMemsetAsync(c->d_bitmaps.p, 0, c->d_bitmaps.cap, c->stream));
+        c->bitmaps_dirty = false;
+      }
+    }
+    HIP_TRY(hipMemsetAsync(c->d_fzero.p, 0, fz_bytes, c->stream));
   }
 
   EncodeLaunch L;
@@ -701,6 +782,23 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
     L.modes_forced = true;
   }
   L.fallback_flags = (uint8_t*)c->d_fbflags.p;
+  L.fused = fused;
+  if (pieces) {
+    L.pieces = (const PieceDesc*)c->d_pieces.p;
+    L.n_pieces = c->n_pieces;
+  }
+  if (fused) {
+    L.fctrl = (FusedCtrl*)c->d_fzero.p;
+    L.arrivals = (uint32_t*)((uint8_t*)c->d_fzero.p + fz_arrivals);
+    L.lb = (unsigned long long*)((uint8_t*)c->d_fzero.p + fz_lb);
+    L.lbc = (unsigned long long*)((uint8_t*)c->d_fzero.p + fz_lbc);
+    L.start1 = (unsigned long long*)((uint8_t*)c->d_fzero.p + fz_start1);
+    L.prec = (uint32_t*)c->d_prec.p;
+    L.prec_stride = prec_stride;
+    L.bitmaps = (uint32_t*)c->d_bitmaps.p;
+    L.n_bm_fields = n_bm;
+    L.secplace = c->d_secplace.p;
+  }
   L.out = d_outp;
   L.out_capacity = out_capacity;
   L.status = (uint32_t*)c->d_status.p;
@@ -767,6 +865,10 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
                          c->stream));
   HIP_TRY(hipMemcpyAsync(h_status, c->d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (*h_status & (ST_FUSED_TIMEOUT | ST_FUSED_MISMATCH)) {
+    c->bitmaps_dirty = true;
+    return fail(CLDN_HIP_ERR_DEVICE, "single-pass encoder failed (status 0x%x)", *h_status);
+  }
   if (*h_status & ST_OUT_OVERFLOW)
     return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for uncompressed chunk");  // chunk_writer.cpp:34-36
   const uint64_t total = h_off[n_clouds];
@@ -851,6 +953,16 @@ int cldn_hip_codec_decode_stats(cldn_hip_codec_t* c, uint32_t stats[4]) {
                          c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return CLDN_HIP_OK;
+}
+
+int cldn_hip_codec_pipeline(cldn_hip_codec_t* c, int mode, const void* points) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if (mode < 0 || mode > 3) return fail(CLDN_HIP_ERR_ARG, "pipeline mode %d out of range", mode);
+  c->pipeline = mode;
+  const uint8_t* p = (const uint8_t*)points;
+  if (mode == 1 || stage1_piece_points(c->plan.dev, p) == 0u) return 1;
+  if (mode == 3 && stage1_single_pass_ok(c->plan.dev, p)) return 3;
+  return 2;
 }
 
 int cldn_hip_codec_force_modes(cldn_hip_codec_t* c, const uint8_t* modes, uint32_t n_modes) {

@@ -1041,7 +1041,7 @@ __device__ __forceinline__ uint32_t funnel_bytes(uint32_t lo, uint32_t hi, uint3
   return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sb * 8u));
 }
 
-constexpr uint32_t kCompactMaxSegs = 32u + 2u * kMaxAdaptive;
+constexpr uint32_t kCompactMaxSegs = 96u + 2u * kMaxAdaptive;  // sub-chunk or piece segments + two per section
 constexpr uint32_t kCompactItemUnits = 256u;  // 4 KiB per item
 constexpr uint32_t kCompactMaxItems = 1024u;
 
@@ -1151,6 +1151,7 @@ namespace cldn {
 }  // namespace cldn
 
 #include "stage1_sections.h"
+#include "stage1_fused.h"
 
 namespace cldn {
 
@@ -1750,16 +1751,148 @@ int stage1_configure_kernels() {
   return CLDN_HIP_OK;
 }
 
+// ---- single-pass encoder ----
+namespace {
+struct FusedVariant {
+  int lanes, loadw, l3;
+  bool unal;
+};
+// the k_encode_floatn variant table decides whether the point load covers the plan
+bool fused_variant(const DevPlan& p, const uint8_t* points, FusedVariant* v) {
+  int l3 = 3;
+  const int lanes = floatn_lanes(p, points, &l3);
+  if (!lanes) return false;
+  const bool unal = floatn_unaligned(p, points);
+  const int loadw = floatn_loadw(p, lanes, unal, l3);
+  if (loadw == 0) return false;
+  bool ok;
+  if (l3 == 4) ok = (loadw == 8);
+  else if (unal) ok = (lanes == 3 && (loadw == 4 || loadw == 8)) || (lanes == 4 && (loadw == 5 || loadw == 8));
+  else ok = (lanes == 3 && (loadw == 3 || loadw == 4 || loadw == 8)) || (lanes == 4 && (loadw == 4 || loadw == 8));
+  if (!ok) return false;
+  v->lanes = lanes;
+  v->loadw = loadw;
+  v->l3 = l3;
+  v->unal = unal;
+  return true;
+}
+}  // namespace
+
+uint32_t stage1_fused_bitmap_fields(const DevPlan& plan) {
+  uint32_t n = 0;
+  for (uint32_t a = 0; a < plan.n_adaptive; ++a) n += plan.adaptive[a].bpv == 2u ? 1u : 0u;
+  return n;
+}
+
+uint32_t stage1_piece_points(const DevPlan& plan, const uint8_t* points) {
+  FusedVariant v;
+  if (!fused_variant(plan, points, &v)) return 0u;
+  return fused_piece_points(v.lanes);
+}
+
+uint32_t stage1_piece_slot_stride(const DevPlan& plan, const uint8_t* points) {
+  FusedVariant v;
+  if (!fused_variant(plan, points, &v)) return 0u;
+  return (fused_piece_points(v.lanes) * 5u * (uint32_t)v.lanes + 255u) & ~255u;  // worst case, 5 bytes per token
+}
+
+bool stage1_single_pass_ok(const DevPlan& plan, const uint8_t* points) {
+  if (stage1_piece_points(plan, points) == 0u) return false;
+  // Palette sizes come from a presence bitmap, which exists for 2-byte fields only: a wider field could commit
+  // Palette on the device, and the choice of pipeline is made on the host before the modes are known
+  for (uint32_t a = 0; a < plan.n_adaptive; ++a)
+    if (plan.adaptive[a].bpv != 2u) return false;
+  return true;
+}
+
+static int launch_fused(const EncodeLaunch& L) {
+  FusedVariant v;
+  if (!fused_variant(*L.plan, L.points, &v)) return launch_fail(hipErrorInvalidValue, "k_encode_fused (no variant)");
+  FusedArgs A;
+  A.points = L.points;
+  A.points_end = L.points_end;
+  A.chunks = L.chunks;
+  A.pieces = L.pieces;
+  A.n_pieces = L.n_pieces;
+  A.ctrl = L.fctrl;
+  A.arrivals = L.arrivals;
+  A.lb = L.lb;
+  A.lbc = L.lbc;
+  A.start1 = L.start1;
+  A.prec = L.prec;
+  A.prec_stride = L.prec_stride;
+  A.bitmaps = L.bitmaps;
+  A.modes = L.modes;
+  A.cols = L.cols;
+  A.out = L.out;
+  A.out_capacity = L.out_capacity;
+  A.chunk_payload = L.chunk_payload;
+  A.chunk_dst = reinterpret_cast<unsigned long long*>(L.chunk_dst);
+  A.secplace = reinterpret_cast<SecPlace*>(L.secplace);
+  A.status = L.status;
+  static const uint32_t ablate_f = getenv("CLDN_HIP_ABLATE") ? (uint32_t)atoi(getenv("CLDN_HIP_ABLATE")) : 0u;  // profiling only
+  A.ablate = ablate_f;
+  static const uint32_t ticket_f = getenv("CLDN_HIP_FUSED_TICKET") ? 1u : 0u;  // A/B switch: ticket order instead of dispatch order
+  A.use_ticket = L.fused ? ticket_f : 0u;
+  A.slot_mode = L.fused ? 0u : 1u;
+  A.slots = L.slots;
+  A.slot_stride = L.slot_stride;
+  A.piece_stride = L.sub_stride / kFusedWaves;  // sub_stride = one workgroup's range (4 pieces)
+  A.segs = L.segs;
+  A.segs_per_chunk = L.segs_per_chunk;
+  const uint32_t n_bm = L.fused ? L.n_bm_fields : 0u;
+  A.n_bm_fields = n_bm;
+  const uint32_t lds = 16u + kFusedWaves * fused_region_bytes(v.lanes) + (n_bm ? kBitmapWords * 4u : 0u);
+  const dim3 grid(L.n_pieces / kFusedWaves), block(kFusedThreads);
+#define LAUNCH_FUSED(LL, WW, UU, L3)                                                                             \
+  hipLaunchKernelGGL((k_encode_fused<LL, WW, UU, L3>), grid, block, lds, L.stream, *L.plan, A)
+  if (v.l3 == 4) LAUNCH_FUSED(4, 8, false, 4);
+  else if (v.unal && v.lanes == 3 && v.loadw == 4) LAUNCH_FUSED(3, 4, true, 3);
+  else if (v.unal && v.lanes == 3 && v.loadw == 8) LAUNCH_FUSED(3, 8, true, 3);
+  else if (v.unal && v.lanes == 4 && v.loadw == 5) LAUNCH_FUSED(4, 5, true, 3);
+  else if (v.unal && v.lanes == 4 && v.loadw == 8) LAUNCH_FUSED(4, 8, true, 3);
+  else if (v.lanes == 3 && v.loadw == 3) LAUNCH_FUSED(3, 3, false, 3);
+  else if (v.lanes == 3 && v.loadw == 4) LAUNCH_FUSED(3, 4, false, 3);
+  else if (v.lanes == 3 && v.loadw == 8) LAUNCH_FUSED(3, 8, false, 3);
+  else if (v.lanes == 4 && v.loadw == 4) LAUNCH_FUSED(4, 4, false, 3);
+  else LAUNCH_FUSED(4, 8, false, 3);
+#undef LAUNCH_FUSED
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "k_encode_fused");
+  return CLDN_HIP_OK;
+}
+
 int stage1_launch_encode(const EncodeLaunch& L) {
   hipError_t e;
   if (L.events) (void)hipEventRecord(L.events[0], L.stream);
+  const uint32_t na_f = L.plan->n_adaptive;
+  if (L.fused) {
+    // the modes come first: the single-pass kernel needs them for its section statistics
+    if (L.n_chunks && na_f && !L.modes_forced) {
+      hipLaunchKernelGGL(k_probe_extract, dim3(L.n_clouds, na_f), dim3(1024), 0, L.stream, *L.plan, L.points, L.chunks,
+                         L.cloud_first_chunk, L.cols);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_extract");
+      hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na_f), dim3(kS2Threads), kProbeLds, L.stream, *L.plan, L.chunks,
+                         L.cloud_first_chunk, L.cols, L.modes);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_fast");
+    }
+    if (L.events) (void)hipEventRecord(L.events[1], L.stream);
+    if (L.n_chunks) {
+      const int rc = launch_fused(L);
+      if (rc != CLDN_HIP_OK) return rc;
+    }
+    goto regular_done;
+  }
   if (L.events) (void)hipEventRecord(L.events[1], L.stream);
   if (L.n_chunks && L.plan->n_gorilla) {
     hipLaunchKernelGGL(k_gorilla_tokens, dim3(L.n_chunks, L.plan->n_gorilla), dim3(64), 0, L.stream, *L.plan, L.points,
                        L.chunks, L.pre_out);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_gorilla_tokens");
   }
-  if (L.n_chunks) {
+  if (L.n_chunks && L.pieces) {  // slot pipeline, regular stream by the barrier-free piece kernel
+    const int rc = launch_fused(L);
+    if (rc != CLDN_HIP_OK) return rc;
+  } else if (L.n_chunks) {
     int l3 = 3;
     const int lanes = floatn_lanes(*L.plan, L.points, &l3);
     static const uint32_t ablate = getenv("CLDN_HIP_ABLATE") ? (uint32_t)atoi(getenv("CLDN_HIP_ABLATE")) : 0u;  // profiling only
@@ -1792,13 +1925,14 @@ int stage1_launch_encode(const EncodeLaunch& L) {
 #undef LAUNCH_FLOATN
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_regular/floatn");
   }
+regular_done:
   if (L.events) (void)hipEventRecord(L.events[2], L.stream);
   const uint32_t na = L.plan->n_adaptive;
   if (na && L.n_chunks) {
     ColumnPtrs rank_cols;
     for (int a = 0; a < kMaxAdaptive; ++a) rank_cols.p[a] = reinterpret_cast<uint8_t*>(L.ranks[a]);
     static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
-    if (!L.modes_forced) {
+    if (!L.modes_forced && !L.fused) {
       if (!no_fast) {
         hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na), dim3(kS2Threads), kProbeLds, L.stream, *L.plan, L.chunks,
                            L.cloud_first_chunk, L.cols, L.modes);
@@ -1849,6 +1983,16 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_sections");
   }
   if (L.events) (void)hipEventRecord(L.events[3], L.stream);
+  if (L.fused) {
+    hipLaunchKernelGGL(k_place_sections, dim3(std::max(1u, L.n_chunks), std::max(1u, na)), dim3(256), 0, L.stream, L.slots,
+                       L.slot_stride, L.segs, L.segs_per_chunk, L.subs, na, reinterpret_cast<const SecPlace*>(L.secplace),
+                       L.chunk_payload, reinterpret_cast<const unsigned long long*>(L.chunk_dst), L.n_chunks,
+                       L.cloud_first_chunk, L.n_clouds, reinterpret_cast<unsigned long long*>(L.stream_offsets), L.out,
+                       (unsigned long long)L.out_capacity, L.fctrl, L.status);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_place_sections");
+    if (L.events) (void)hipEventRecord(L.events[4], L.stream);
+    return CLDN_HIP_OK;
+  }
   hipLaunchKernelGGL(k_chunk_offsets<1024>, dim3(1), dim3(1024), 0, L.stream, L.segs, L.segs_per_chunk, L.n_chunks,
                      L.cloud_first_chunk, L.n_clouds, L.chunk_payload, L.chunk_dst, L.stream_offsets);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_chunk_offsets");

@@ -41,8 +41,30 @@ struct EncodeLaunch {
   uint8_t* out;               // device, framed streams
   uint64_t out_capacity;
   uint32_t* status;           // device status word
-  hipEvent_t* events;         // 5 events (start, after probe, after regular, after sections, end) or NULL
+  hipEvent_t* events;         // 5 events (start, before regular, after regular, after sections, end) or NULL
+  // piece kernel (stage1_fused.h). pieces != NULL: the regular stream is encoded one wave per piece; fused = true adds
+  // the inter-piece protocol that places every byte at once (single pass), fused = false leaves the pieces in the slots
+  bool fused;
+  const PieceDesc* pieces;    // device [n_pieces] or NULL
+  uint32_t n_pieces;          // multiple of 4
+  FusedCtrl* fctrl;           // device; fctrl, arrivals and lb are one zero-filled block per call
+  uint32_t* arrivals;         // device [n_chunks]
+  unsigned long long* lb;     // device [n_pieces]
+  unsigned long long* lbc;    // device [n_chunks]
+  unsigned long long* start1; // device [n_chunks]
+  uint32_t* prec;             // device [n_pieces * prec_stride]
+  uint32_t prec_stride;
+  uint32_t* bitmaps;          // device [n_chunks * n_bm_fields * 2048], zero between calls
+  uint32_t n_bm_fields;
+  void* secplace;             // device [n_chunks * n_adaptive] SecPlace
 };
+
+// Can the single-pass encoder take this plan (regular stream = one fused FloatN encoder the point load covers, section
+// statistics available for every mode its adaptive fields may commit)? Returns the points per piece, 0 = no.
+uint32_t stage1_piece_points(const DevPlan& plan, const uint8_t* points);        // piece kernel applies: points per piece, else 0
+uint32_t stage1_piece_slot_stride(const DevPlan& plan, const uint8_t* points);   // bytes a piece may produce, 256-aligned
+bool stage1_single_pass_ok(const DevPlan& plan, const uint8_t* points);          // ... and section statistics exist for every field
+uint32_t stage1_fused_bitmap_fields(const DevPlan& plan);
 
 struct DecodeLaunch {
   const DevPlan* plan;

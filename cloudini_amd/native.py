@@ -91,6 +91,8 @@ def lib() -> C.CDLL:
     L.cldn_hip_codec_decode_stats.restype = C.c_int
     L.cldn_hip_codec_force_modes.argtypes = [vp, C.POINTER(C.c_uint8), C.c_uint32]
     L.cldn_hip_codec_force_modes.restype = C.c_int
+    L.cldn_hip_codec_pipeline.argtypes = [vp, C.c_int, vp]
+    L.cldn_hip_codec_pipeline.restype = C.c_int
     L.cldn_hip_encode_stage1.restype = C.c_int
     L.cldn_hip_encode_stage1.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, vp, C.c_uint64, C.c_int, vp, vp, vp]
     L.cldn_hip_decode_stage1.restype = C.c_int
@@ -203,6 +205,13 @@ class Codec:
             return
         m = np.ascontiguousarray(modes, dtype=np.uint8)
         _check(lib().cldn_hip_codec_force_modes(self._h, m.ctypes.data_as(C.POINTER(C.c_uint8)), m.size))
+
+    def pipeline(self, mode: int = 0, points_ptr: int = 0) -> int:
+        """Choose the encoder pipeline (cldn_hip_codec_pipeline: 0 auto, 1 tile kernel + slots, 2 piece kernel + slots,
+        3 single pass); returns the pipeline the next call takes."""
+        r = lib().cldn_hip_codec_pipeline(self._h, int(mode), C.c_void_p(points_ptr))
+        _check(r)
+        return int(r)
 
     def enable_timing(self, n_slots: int):
         _check(lib().cldn_hip_codec_enable_timing(self._h, int(n_slots)))

@@ -15,17 +15,36 @@ def _first_diff(a, b):
 
 
 def check_encode(oracle, info, clouds):
+    """Every encoder pipeline the schema allows (single pass, piece kernel + slots, tile kernel + slots) against the
+    oracle."""
     from cloudini_amd import native
     plan = native.Plan(info)
     codec = native.Codec(plan)
-    streams, chunk_sizes, modes = codec.encode_host(clouds)
-    for k, cloud in enumerate(clouds):
-        want, want_modes = oracle.encode_stage1(info, cloud, return_modes=True)
-        got = streams[k]
-        assert len(got) == len(want), f"cloud {k}: size {len(got)} != {len(want)} (first diff at {_first_diff(got, want)})"
-        assert np.array_equal(got, want), f"cloud {k}: first diff at byte {_first_diff(got, want)}"
-        if plan.adaptive_fields:
-            assert list(modes[k]) == list(want_modes)
+    wants = [oracle.encode_stage1(info, cloud, return_modes=True) for cloud in clouds]
+    streams = None
+    taken_all = set()
+    for mode in (3, 2, 1):
+        taken = codec.pipeline(mode)
+        if taken in taken_all:   # the schema does not allow this pipeline: it falls back to one already checked
+            continue
+        taken_all.add(taken)
+        streams, chunk_sizes, modes = codec.encode_host(clouds)
+        tag = {1: "tile kernel + slots", 2: "piece kernel + slots", 3: "single pass"}[taken]
+        pos = 0
+        for k, cloud in enumerate(clouds):
+            want, want_modes = wants[k]
+            got = streams[k]
+            assert len(got) == len(want), f"{tag} cloud {k}: size {len(got)} != {len(want)} (first diff at {_first_diff(got, want)})"
+            assert np.array_equal(got, want), f"{tag} cloud {k}: first diff at byte {_first_diff(got, want)}"
+            if plan.adaptive_fields:
+                assert list(modes[k]) == list(want_modes), tag
+            # chunk_sizes = the [u32 size] prefixes of the stream
+            o = 0
+            while o < len(want):
+                size = int.from_bytes(bytes(want[o:o + 4]), "little")
+                assert int(chunk_sizes[pos]) == size, f"{tag} cloud {k}: chunk size table"
+                pos += 1
+                o += 4 + size
     codec.close()
     return streams
 

@@ -1,0 +1,188 @@
+"""GPU parity of the single-pass encoder (cloudini_amd/csrc/stage1_fused.h): every byte written once at its final
+position, positions from a look-back scan over pieces, section sizes from per-piece statistics. Compared with the
+oracle and with the slot pipeline on schemas that exercise every section mode, piece / chunk boundaries, padding
+pieces, forced modes, ragged batches and repeated calls on one codec (the per-chunk bitmaps clear themselves)."""
+import numpy as np
+import pytest
+
+import cases
+from cloudini_amd import synth
+from test_gpu_encode import check_encode
+
+pytestmark = pytest.mark.gpu
+F = cases.F
+
+
+def xyz_plus(n, columns, seed=5, step=None, lanes=3):
+    """lidar-like XYZ (or XYZ + f32 intensity) followed by integer columns: [(name, ftype, array)]."""
+    rs = np.random.RandomState(seed)
+    t = np.arange(n, dtype=np.float32)
+    cols = {"x": (20 + 5 * np.sin(t / 97) + rs.normal(0, 0.002, n)).astype(np.float32),
+            "y": (3 * np.cos(t / 61) + rs.normal(0, 0.002, n)).astype(np.float32),
+            "z": (0.001 * t).astype(np.float32)}
+    fields = [("x", 0, F.FLOAT32, 0.001), ("y", 4, F.FLOAT32, 0.001), ("z", 8, F.FLOAT32, 0.001)]
+    off = 12
+    if lanes == 4:
+        cols["i"] = rs.randint(0, 256, n).astype(np.float32)
+        fields.append(("i", 12, F.FLOAT32, 0.001))
+        off = 16
+    for name, ftype, arr in columns:
+        cols[name] = arr
+        fields.append((name, off, ftype, None))
+        off += arr.dtype.itemsize
+    step = step or off
+    info = cases.make_info(fields, step, n)
+    return info, cases.pack(info, cols, n)
+
+
+def mode_columns(n, seed=9):
+    rs = np.random.RandomState(seed)
+    i = np.arange(n, dtype=np.int64)
+    return {
+        "palette": (rs.randint(0, 256, n) * 16).astype(np.uint16),
+        "rle": ((i // 256) % 8).astype(np.uint16),
+        "rle_long": ((i // 20000) % 3 * 1000).astype(np.uint16),
+        "drle": (i % 128).astype(np.uint16),
+        "drle_long": (i * 2).astype(np.uint16),
+        "delta": rs.randint(0, 65536, n).astype(np.uint16),
+        "delta_i16": np.cumsum(rs.randint(-40, 41, n)).astype(np.int16),
+        "const": np.full(n, 77, np.uint16),
+        "runs127": np.repeat(rs.randint(0, 50, n // 127 + 1), 127)[:n].astype(np.uint16),
+        "runs128": np.repeat(rs.randint(0, 50, n // 128 + 1), 128)[:n].astype(np.uint16),
+        "runs130": np.repeat(rs.randint(0, 50, n // 130 + 1), 130)[:n].astype(np.uint16),
+    }
+
+
+@pytest.mark.parametrize("kind", sorted(mode_columns(10).keys()))
+def test_every_section_mode_behind_xyz(oracle, kind):
+    n = 32768 * 2 + 777
+    col = mode_columns(n)[kind]
+    ftype = F.INT16 if col.dtype == np.int16 else F.UINT16
+    info, data = xyz_plus(n, [("v", ftype, col)])
+    from cloudini_amd import native
+    codec = native.Codec(native.Plan(info))
+    assert codec.pipeline(3) == 3 and codec.pipeline(0) == 2  # the single pass is possible, the piece kernel is the default
+    codec.close()
+    check_encode(oracle, info, [data])
+
+
+@pytest.mark.parametrize("n", [1, 2, 62, 63, 64, 503, 504, 505, 1007, 1008, 1009, 2015, 2016, 2017, 4095, 4096, 4097,
+                               32255, 32256, 32257, 32767, 32768, 32769, 33271, 33272, 33273, 65536, 100000])
+def test_piece_and_chunk_boundaries(oracle, n):
+    cols = mode_columns(n, seed=n)
+    info, data = xyz_plus(n, [("a", F.UINT16, cols["palette"]), ("b", F.UINT16, cols["drle"])], seed=n)
+    check_encode(oracle, info, [data])
+
+
+@pytest.mark.parametrize("n", [1, 377, 378, 379, 756, 32768, 32769, 70001])
+def test_four_lane_pieces(oracle, n):
+    cols = mode_columns(n, seed=n + 1)
+    info, data = xyz_plus(n, [("ring", F.UINT16, cols["drle"]), ("lab", F.UINT16, cols["rle"])], seed=n, lanes=4)
+    check_encode(oracle, info, [data])
+
+
+def test_many_fields_all_modes(oracle):
+    n = 70000
+    cols = mode_columns(n, seed=21)
+    info, data = xyz_plus(n, [(k, F.INT16 if v.dtype == np.int16 else F.UINT16, v) for k, v in sorted(cols.items())])
+    check_encode(oracle, info, [data])
+
+
+def test_padded_and_unaligned_layouts(oracle):
+    n = 50000
+    cols = mode_columns(n, seed=4)
+    # 16-byte XYZI (C2), 18-byte packed XYZI+ring (C4), 32-byte stride with the u16 deep in the padding
+    check_encode(oracle, *[(i, [d]) for i, d in [synth.lidar_xyzi(n, seed=8)]][0])
+    check_encode(oracle, *[(i, [d]) for i, d in [synth.velodyne_xyzir(n, seed=8)]][0])
+    info, data = xyz_plus(n, [("v", F.UINT16, cols["palette"])], step=32)
+    check_encode(oracle, info, [data])
+    info, data = xyz_plus(n, [("v", F.UINT16, cols["rle"]), ("w", F.UINT16, cols["delta"])], step=19)
+    check_encode(oracle, info, [data])
+
+
+def test_special_values_and_rare_rows(oracle):
+    n = 40000
+    rs = np.random.RandomState(3)
+    info, data = xyz_plus(n, [("v", F.UINT16, mode_columns(n)["palette"])])
+    pts = data.view(np.uint8).reshape(n, info.point_step)
+    xyz = pts[:, :12].copy().view(np.float32).reshape(n, 3)
+    xyz[rs.randint(0, n, 600), rs.randint(0, 3, 600)] = np.nan
+    xyz[rs.randint(0, n, 60), rs.randint(0, 3, 60)] = np.inf
+    xyz[rs.randint(0, n, 60), rs.randint(0, 3, 60)] = -np.inf
+    xyz[rs.randint(0, n, 60), rs.randint(0, 3, 60)] = 3e9
+    xyz[rs.randint(0, n, 60), rs.randint(0, 3, 60)] = -2.5e6
+    xyz[503:506] = np.nan                       # across a piece boundary
+    xyz[32767:32770, 1] = np.inf                # across a chunk boundary
+    pts[:, :12] = xyz.view(np.uint8).reshape(n, 12)
+    check_encode(oracle, info, [pts.reshape(-1)])
+    # incompressible: every token 4-5 bytes (the LDS region is sized for exactly this)
+    big = rs.uniform(-2e6, 2e6, size=(n, 3)).astype(np.float32)
+    pts[:, :12] = big.view(np.uint8).reshape(n, 12)
+    check_encode(oracle, info, [pts.reshape(-1)])
+    huge = (rs.randint(0, 2, size=(n, 3)) * 4e9 - 2e9).astype(np.float32)   # alternating +-2^31: 5-byte tokens everywhere
+    pts[:, :12] = huge.view(np.uint8).reshape(n, 12)
+    check_encode(oracle, info, [pts.reshape(-1)])
+
+
+def test_ragged_batches_and_empty_clouds(oracle):
+    clouds = []
+    info = None
+    for k, n in enumerate([5, 40000, 0, 32768, 1, 0, 504, 66000]):
+        info, data = synth.lidar_xyzi(n, seed=100 + k)
+        clouds.append(data)
+    check_encode(oracle, info, clouds)
+    check_encode(oracle, info, [clouds[2]])          # a batch of one empty cloud
+    check_encode(oracle, info, [clouds[2], clouds[5]])
+
+
+def test_one_codec_many_calls(oracle):
+    """The per-chunk bitmaps and the control words must be clean for every call, whatever the previous call did."""
+    from cloudini_amd import native
+    info, _ = synth.lidar_xyzi(10)
+    codec = native.Codec(native.Plan(info))
+    assert codec.pipeline(3) == 3
+    rs = np.random.RandomState(11)
+    for it in range(12):
+        clouds = []
+        for _k in range(int(rs.randint(1, 5))):
+            n = int(rs.choice([0, 1, 300, 504, 5000, 32768, 40000, 70000]))
+            _info, data = synth.lidar_xyzi(n, seed=int(rs.randint(0, 1000)))
+            if it % 3 == 1 and n:  # a different value population in the same chunk slots
+                pts = data.reshape(n, 16).copy()
+                pts[:, 12:14] = rs.randint(0, 65536, n).astype(np.uint16).view(np.uint8).reshape(n, 2)
+                data = pts.reshape(-1)
+            clouds.append(data)
+        streams, _cs, modes = codec.encode_host(clouds)
+        for k, cloud in enumerate(clouds):
+            want, want_modes = oracle.encode_stage1(info, cloud, return_modes=True)
+            assert np.array_equal(streams[k], want), (it, k)
+            assert list(modes[k]) == list(want_modes)
+    codec.close()
+
+
+def test_forced_modes_take_the_single_pass(oracle):
+    """Chunk ranges of one cloud with the modes committed elsewhere (cldn_hip_codec_force_modes): concatenation equals
+    the whole cloud's stream."""
+    from cloudini_amd import native
+    info, data = synth.lidar_xyzi(200000, seed=2)
+    want, want_modes = oracle.encode_stage1(info, data, return_modes=True)
+    codec = native.Codec(native.Plan(info))
+    assert codec.pipeline(3) == 3
+    codec.force_modes(want_modes)
+    step = info.point_step
+    parts = []
+    for p0, p1 in ((0, 2 * 32768), (2 * 32768, 5 * 32768), (5 * 32768, 200000)):
+        s, _, _ = codec.encode_host([data[p0 * step:p1 * step]])
+        parts.append(s[0])
+    assert np.array_equal(np.concatenate(parts), want)
+    codec.force_modes(None)
+    codec.close()
+
+
+def test_wide_integer_fields_keep_the_slots(oracle):
+    from cloudini_amd import native
+    info, data = synth.depthcam_xyzrgba(320, 240)
+    codec = native.Codec(native.Plan(info))
+    assert codec.pipeline(3) == 2  # u32 rgba could commit Palette, for which the single pass has no statistics
+    codec.close()
+    check_encode(oracle, info, [data])
