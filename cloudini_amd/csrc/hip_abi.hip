@@ -161,6 +161,14 @@ struct cldn_hip_codec {
   DevBuf d_pieces, d_fzero, d_prec, d_bitmaps, d_secplace;  // single-pass encoder (stage1_fused.h)
   uint32_t n_pieces = 0;
   uint32_t last_piece_pts = 0;
+  // chunk-group pipeline (stage1_launch.h): side stream, events, host copies of the group boundaries
+  hipStream_t side_stream = nullptr;
+  std::vector<hipEvent_t> gev;
+  std::vector<uint32_t> chunk_piece0;   // first piece of every chunk (+ total), host copy of the piece table's layout
+  std::vector<uint32_t> grp_chunk0, grp_piece0;
+  std::vector<hipEvent_t> gtime;        // timing: 16 per slot
+  std::vector<uint32_t> slot_groups;    // groups of the call timed in the slot (0 / 1 = not pipelined)
+  int groups_override = -1;             // CLDN_HIP_GROUPS
   int pipeline = 0;           // cldn_hip_codec_pipeline: 0 auto, 1 tile kernel + slots, 2 pieces + slots, 3 single pass
   bool bitmaps_dirty = true;  // set after an aborted call: the kernel only clears the bitmaps of calls that finish
   DevBuf d_viz_keys, d_viz_first, d_viz_slot, d_viz_blocks, d_viz_total;  // applyVizLossyPreprocessing workspace
@@ -465,6 +473,14 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   c->h_modes.release();
   c->h_last_modes.release();
   if (c->ev_last_modes) (void)hipEventDestroy(c->ev_last_modes);
+  for (hipEvent_t& ev : c->gev)
+    if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t& ev : c->gtime)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->side_stream) {
+    (void)hipStreamSynchronize(c->side_stream);
+    (void)hipStreamDestroy(c->side_stream);
+  }
   for (hipEvent_t& ev : c->events)
     if (ev) (void)hipEventDestroy(ev);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -489,6 +505,11 @@ int cldn_hip_codec_enable_timing(cldn_hip_codec_t* c, uint32_t n_slots) {
   c->events.assign((size_t)n_slots * 5, nullptr);
   c->slot_valid.assign(n_slots, 0);
   for (hipEvent_t& ev : c->events) HIP_TRY(hipEventCreate(&ev));
+  for (hipEvent_t& ev : c->gtime)
+    if (ev) (void)hipEventDestroy(ev);
+  c->gtime.assign((size_t)n_slots * 16, nullptr);
+  for (hipEvent_t& ev : c->gtime) HIP_TRY(hipEventCreate(&ev));
+  c->slot_groups.assign(n_slots, 0u);
   c->call_index = 0;
   return CLDN_HIP_OK;
 }
@@ -498,10 +519,22 @@ int cldn_hip_codec_kernel_ms(cldn_hip_codec_t* c, uint32_t slot, float ms[4]) {
   if (slot >= c->slot_valid.size() || !c->slot_valid[slot]) return fail(CLDN_HIP_ERR_ARG, "no timed call in slot %u", slot);
   hipEvent_t* ev = &c->events[(size_t)slot * 5];
   HIP_TRY(hipEventSynchronize(ev[4]));
+  HIP_TRY(hipEventElapsedTime(&ms[3], ev[0], ev[4]));
+  const uint32_t groups = c->slot_groups[slot];
+  if (groups > 1u) {
+    // pipelined call: the regular kernels of the groups ran next to other kernels; ms[0] = sum of their own durations,
+    // sections and compaction have no separate interval
+    ms[0] = ms[1] = ms[2] = 0.0f;
+    hipEvent_t* gt = &c->gtime[(size_t)slot * 16];
+    for (uint32_t i = 0; i < groups && i < 8u; ++i) {
+      float d = 0.0f;
+      if (hipEventElapsedTime(&d, gt[2u * i], gt[2u * i + 1u]) == hipSuccess) ms[0] += d;
+    }
+    return CLDN_HIP_OK;
+  }
   HIP_TRY(hipEventElapsedTime(&ms[0], ev[1], ev[2]));
   HIP_TRY(hipEventElapsedTime(&ms[1], ev[2], ev[3]));
   HIP_TRY(hipEventElapsedTime(&ms[2], ev[3], ev[4]));
-  HIP_TRY(hipEventElapsedTime(&ms[3], ev[0], ev[4]));
   return CLDN_HIP_OK;
 }
 
@@ -584,7 +617,9 @@ static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, u
   if (piece_pts && n_pieces64) {
     PieceDesc* hp = (PieceDesc*)((uint8_t*)c->h_stage.p + head_bytes);
     size_t g = 0;
+    c->chunk_piece0.assign((size_t)n_chunks + 1, 0u);
     for (uint32_t k = 0; k < n_chunks; ++k) {
+      c->chunk_piece0[k] = (uint32_t)g;
       const uint32_t P = (((hc[k].n_points + piece_pts - 1) / piece_pts) + 3u) & ~3u;
       for (uint32_t q = 0; q < P; ++q) {
         hp[g].chunk_first_point = hc[k].first_point;
@@ -597,6 +632,7 @@ static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, u
         ++g;
       }
     }
+    c->chunk_piece0[n_chunks] = (uint32_t)g;
     HIP_TRY(hipMemcpyAsync(c->d_pieces.p, hp, g * sizeof(PieceDesc), hipMemcpyHostToDevice, c->stream));
   }
   c->last_piece_pts = piece_pts;
@@ -782,6 +818,39 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
     L.modes_forced = true;
   }
   L.fallback_flags = (uint8_t*)c->d_fbflags.p;
+  // chunk groups: compaction and sections of one group next to the regular kernel of the following one
+  uint32_t n_groups = 1;
+  if (pieces && !fused) {
+    if (c->groups_override < 0) {
+      const char* e = getenv("CLDN_HIP_GROUPS");
+      c->groups_override = e ? std::max(0, atoi(e)) : 0;
+    }
+    // Off unless asked for (CLDN_HIP_GROUPS=n): measured on MI355X the two queues do not overlap these kernels -- every
+    // kernel fills the chip on its own -- and the extra launches and event waits cost 18 % (2 groups) to 50 % (8 groups)
+    // of a C2 step (tools/groupbench.sh)
+    n_groups = c->groups_override ? (uint32_t)c->groups_override : 1u;
+    n_groups = std::min<uint32_t>(std::min<uint32_t>(n_groups, 8u), std::max(1u, n_chunks / 16u));
+  }
+  if (n_groups > 1u) {
+    if (!c->side_stream) HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    while (c->gev.size() < 4u + n_groups) {
+      hipEvent_t ev = nullptr;
+      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      c->gev.push_back(ev);
+    }
+    c->grp_chunk0.resize(n_groups + 1u);
+    c->grp_piece0.resize(n_groups + 1u);
+    for (uint32_t i = 0; i <= n_groups; ++i) {
+      c->grp_chunk0[i] = (uint32_t)((uint64_t)n_chunks * i / n_groups);
+      c->grp_piece0[i] = c->chunk_piece0[c->grp_chunk0[i]];
+    }
+    L.n_groups = n_groups;
+    L.group_chunk0 = c->grp_chunk0.data();
+    L.group_piece0 = c->grp_piece0.data();
+    L.side_stream = c->side_stream;
+    L.gev = c->gev.data();
+    L.running = (unsigned long long*)((uint8_t*)c->d_status.p + 64);  // zeroed with the status block
+  }
   L.fused = fused;
   if (pieces) {
     L.pieces = (const PieceDesc*)c->d_pieces.p;
@@ -805,6 +874,8 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   const size_t n_slots = c->slot_valid.size();
   const size_t slot = n_slots ? (size_t)(c->call_index % n_slots) : 0;
   L.events = n_slots ? &c->events[slot * 5] : nullptr;
+  L.gtime = (n_slots && n_groups > 1u) ? &c->gtime[slot * 16] : nullptr;
+  if (n_slots) c->slot_groups[slot] = n_groups;
   rc = stage1_launch_encode(L);
   if (rc != CLDN_HIP_OK) return rc;
   // remember this call's modes for the next call's launch hint (no synchronisation: the copy is only looked at

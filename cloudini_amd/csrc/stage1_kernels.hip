@@ -1029,6 +1029,44 @@ __global__ __launch_bounds__(T) void k_chunk_offsets(const Seg* __restrict__ seg
   }
 }
 
+// k_chunk_offsets_range: the same scan for one chunk group of the pipelined encode; the position where the group
+// starts is the running total the previous group's launch left (launches are ordered by events), chunk tables are
+// passed shifted to the group's first chunk. k_stream_offsets derives the per-cloud offsets once all groups are done.
+template <int T>
+__global__ __launch_bounds__(T) void k_chunk_offsets_range(const Seg* __restrict__ segs, uint32_t segs_per_chunk,
+                                                           uint32_t n_chunks, uint32_t* __restrict__ chunk_payload,
+                                                           uint64_t* __restrict__ chunk_dst, uint64_t* __restrict__ running_total) {
+  __shared__ uint32_t wtot[32];
+  uint64_t running = *running_total;
+  for (uint32_t base = 0; base < n_chunks; base += T) {
+    const uint32_t c = base + threadIdx.x;
+    uint32_t framed = 0u;
+    if (c < n_chunks) {
+      uint32_t payload = 0u;
+      for (uint32_t s = 0; s < segs_per_chunk; ++s) payload += segs[(size_t)c * segs_per_chunk + s].size;
+      chunk_payload[c] = payload;
+      framed = payload + 4u;
+    }
+    uint32_t total;
+    const uint32_t excl = block_exclusive_scan<T>(framed, wtot, &total);
+    if (c < n_chunks) chunk_dst[c] = running + excl;
+    running += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *running_total = running;
+}
+
+__global__ __launch_bounds__(256) void k_stream_offsets(const uint32_t* __restrict__ chunk_payload,
+                                                        const uint64_t* __restrict__ chunk_dst, uint32_t n_chunks,
+                                                        const uint32_t* __restrict__ cloud_first_chunk, uint32_t n_clouds,
+                                                        uint64_t* __restrict__ stream_offsets) {
+  const uint64_t total = n_chunks ? chunk_dst[n_chunks - 1u] + 4ull + chunk_payload[n_chunks - 1u] : 0ull;
+  for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k <= n_clouds; k += gridDim.x * 256u) {
+    const uint32_t fc = (k < n_clouds) ? cloud_first_chunk[k] : n_chunks;
+    stream_offsets[k] = (fc < n_chunks) ? chunk_dst[fc] : total;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // k_compact: final framed stream. grid = (n_chunks, splits). The chunk's segment table is read once into LDS and
 // cut into work items of at most kCompactItemUnits 16-byte units; the waves of the chunk's workgroups take items
@@ -1805,15 +1843,15 @@ bool stage1_single_pass_ok(const DevPlan& plan, const uint8_t* points) {
   return true;
 }
 
-static int launch_fused(const EncodeLaunch& L) {
+static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piece0, uint32_t piece1) {
   FusedVariant v;
   if (!fused_variant(*L.plan, L.points, &v)) return launch_fail(hipErrorInvalidValue, "k_encode_fused (no variant)");
   FusedArgs A;
   A.points = L.points;
   A.points_end = L.points_end;
   A.chunks = L.chunks;
-  A.pieces = L.pieces;
-  A.n_pieces = L.n_pieces;
+  A.pieces = L.pieces + piece0;
+  A.n_pieces = piece1 - piece0;
   A.ctrl = L.fctrl;
   A.arrivals = L.arrivals;
   A.lb = L.lb;
@@ -1843,9 +1881,9 @@ static int launch_fused(const EncodeLaunch& L) {
   const uint32_t n_bm = L.fused ? L.n_bm_fields : 0u;
   A.n_bm_fields = n_bm;
   const uint32_t lds = 16u + kFusedWaves * fused_region_bytes(v.lanes) + (n_bm ? kBitmapWords * 4u : 0u);
-  const dim3 grid(L.n_pieces / kFusedWaves), block(kFusedThreads);
+  const dim3 grid((piece1 - piece0) / kFusedWaves), block(kFusedThreads);
 #define LAUNCH_FUSED(LL, WW, UU, L3)                                                                             \
-  hipLaunchKernelGGL((k_encode_fused<LL, WW, UU, L3>), grid, block, lds, L.stream, *L.plan, A)
+  hipLaunchKernelGGL((k_encode_fused<LL, WW, UU, L3>), grid, block, lds, stream, *L.plan, A)
   if (v.l3 == 4) LAUNCH_FUSED(4, 8, false, 4);
   else if (v.unal && v.lanes == 3 && v.loadw == 4) LAUNCH_FUSED(3, 4, true, 3);
   else if (v.unal && v.lanes == 3 && v.loadw == 8) LAUNCH_FUSED(3, 8, true, 3);
@@ -1862,8 +1900,116 @@ static int launch_fused(const EncodeLaunch& L) {
   return CLDN_HIP_OK;
 }
 
+// section kernels of chunks [c0, c1) on `stream` (per-chunk tables are passed shifted to c0; columns, modes and the
+// chunk descriptors' point indexes are batch-global)
+static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c0, uint32_t c1) {
+  hipError_t e;
+  const uint32_t na = L.plan->n_adaptive;
+  const uint32_t nch = c1 - c0;
+  if (!na || !nch) return CLDN_HIP_OK;
+  const ChunkDesc* chunks = L.chunks + c0;
+  uint8_t* slots = L.slots + (size_t)c0 * L.slot_stride;
+  Seg* segs = L.segs + (size_t)c0 * L.segs_per_chunk;
+  uint8_t* flags = L.fallback_flags + (size_t)c0 * na;
+  ColumnPtrs rank_cols;
+  for (int a = 0; a < kMaxAdaptive; ++a) rank_cols.p[a] = reinterpret_cast<uint8_t*>(L.ranks[a]);
+  static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
+  for (uint32_t a = 0; a < na && !no_fast; ++a) {
+    const uint32_t bpv = L.plan->adaptive[a].bpv;
+    const uint32_t hint = L.mode_hint[a];
+#define SEC_ARGS *L.plan, a, chunks, L.cols, L.modes, slots, L.slot_stride, L.reg_stride, segs, L.segs_per_chunk, L.subs, flags
+    if (hint & 0xDu) {  // DeltaVarint / Rle / DeltaRle expected somewhere
+      if (bpv == 2u) {
+        hipLaunchKernelGGL(k_section_delta32<uint16_t>, dim3(nch), dim3(kS2Threads), kD32Lds, stream, SEC_ARGS);
+        hipLaunchKernelGGL(k_section_runs<uint16_t>, dim3(nch), dim3(kS2Threads), 0, stream, SEC_ARGS);
+      } else if (bpv == 4u) {
+        hipLaunchKernelGGL(k_section_delta32<uint32_t>, dim3(nch), dim3(kS2Threads), kD32Lds, stream, SEC_ARGS);
+        hipLaunchKernelGGL(k_section_runs<uint32_t>, dim3(nch), dim3(kS2Threads), 0, stream, SEC_ARGS);
+      }
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_delta32/runs");
+    if (hint & 0x2u) {
+      if (bpv == 2u) hipLaunchKernelGGL(k_section_palette32<uint16_t>, dim3(nch), dim3(kS2Threads), Pal32<uint16_t>::kLds, stream, SEC_ARGS);
+      else if (bpv == 4u) hipLaunchKernelGGL(k_section_palette32<uint32_t>, dim3(nch), dim3(kS2Threads), Pal32<uint32_t>::kLds, stream, SEC_ARGS);
+      else hipLaunchKernelGGL(k_section_palette<uint64_t>, dim3(nch), dim3(kS2Threads), kS2PalLds, stream, SEC_ARGS);
+    }
+#undef SEC_ARGS
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_palette");
+  }
+  hipLaunchKernelGGL(k_encode_sections, dim3(nch, na), dim3(kSecThreads), kSecLdsTotal, stream, *L.plan, chunks, L.cols,
+                     L.modes, slots, L.slot_stride, L.reg_stride, segs, L.segs_per_chunk, rank_cols, L.subs, flags);
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_sections");
+  return CLDN_HIP_OK;
+}
+
+// Chunk-group pipeline of the piece kernel + slots pipeline (EncodeLaunch::n_groups > 1).
+static int launch_encode_groups(const EncodeLaunch& L) {
+  hipError_t e;
+#define EV_TRY(expr) if ((e = (expr)) != hipSuccess) return hip_fail(e, #expr)
+  const uint32_t na = L.plan->n_adaptive;
+  const uint32_t G = L.n_groups;
+  hipEvent_t ev_setup = L.gev[0], ev_probe = L.gev[1], ev_side = L.gev[2];
+  hipEvent_t* ev_off = L.gev + 4;
+  if (L.events) (void)hipEventRecord(L.events[0], L.stream);
+  // everything enqueued on the main stream so far (uploads, memsets) precedes the side stream's work
+  EV_TRY(hipEventRecord(ev_setup, L.stream));
+  EV_TRY(hipStreamWaitEvent(L.side_stream, ev_setup, 0));
+  const bool probe = na && !L.modes_forced;
+  if (probe) {  // modes from the AoS input, next to the first group's regular kernel
+    hipLaunchKernelGGL(k_probe_extract, dim3(L.n_clouds, na), dim3(1024), 0, L.side_stream, *L.plan, L.points, L.chunks,
+                       L.cloud_first_chunk, L.cols);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_extract");
+    hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na), dim3(kS2Threads), kProbeLds, L.side_stream, *L.plan, L.chunks,
+                       L.cloud_first_chunk, L.cols, L.modes);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_fast");
+    EV_TRY(hipEventRecord(ev_probe, L.side_stream));
+  }
+  if (L.events) (void)hipEventRecord(L.events[1], L.stream);
+  bool main_waited_probe = false;
+  for (uint32_t i = 0; i < G; ++i) {
+    hipStream_t st = (i & 1u) ? L.side_stream : L.stream;
+    const uint32_t c0 = L.group_chunk0[i], c1 = L.group_chunk0[i + 1u];
+    if (c1 == c0) continue;
+    if (L.gtime) (void)hipEventRecord(L.gtime[2u * i], st);
+    int rc = launch_fused(L, st, L.group_piece0[i], L.group_piece0[i + 1u]);
+    if (rc != CLDN_HIP_OK) return rc;
+    if (L.gtime) (void)hipEventRecord(L.gtime[2u * i + 1u], st);
+    if (probe && !(i & 1u) && !main_waited_probe) {  // the side stream is ordered behind the probe by itself
+      EV_TRY(hipStreamWaitEvent(L.stream, ev_probe, 0));
+      main_waited_probe = true;
+    }
+    if ((rc = launch_sections(L, st, c0, c1)) != CLDN_HIP_OK) return rc;
+    if (i > 0u) EV_TRY(hipStreamWaitEvent(st, ev_off[i - 1u], 0));  // the position where this group starts
+    hipLaunchKernelGGL(k_chunk_offsets_range<1024>, dim3(1), dim3(1024), 0, st, L.segs + (size_t)c0 * L.segs_per_chunk,
+                       L.segs_per_chunk, c1 - c0, L.chunk_payload + c0, L.chunk_dst + c0,
+                       reinterpret_cast<uint64_t*>(L.running));
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_chunk_offsets_range");
+    EV_TRY(hipEventRecord(ev_off[i], st));
+    const uint32_t nch = c1 - c0;
+    const uint32_t splits = nch >= 1024u ? 1u : (nch >= 256u ? 4u : 16u);
+    hipLaunchKernelGGL(k_compact<256>, dim3(nch, splits), dim3(256), 0, st, L.slots + (size_t)c0 * L.slot_stride, L.slot_stride,
+                       L.segs + (size_t)c0 * L.segs_per_chunk, L.segs_per_chunk, L.chunk_payload + c0, L.chunk_dst + c0, L.out,
+                       L.out_capacity, L.status);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_compact");
+  }
+  // rejoin: the main stream continues when the side stream is done
+  EV_TRY(hipEventRecord(ev_side, L.side_stream));
+  EV_TRY(hipStreamWaitEvent(L.stream, ev_side, 0));
+  hipLaunchKernelGGL(k_stream_offsets, dim3(std::min(64u, L.n_clouds / 256u + 1u)), dim3(256), 0, L.stream, L.chunk_payload,
+                     L.chunk_dst, L.n_chunks, L.cloud_first_chunk, L.n_clouds, L.stream_offsets);
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_stream_offsets");
+  if (L.events) {
+    (void)hipEventRecord(L.events[2], L.stream);
+    (void)hipEventRecord(L.events[3], L.stream);
+    (void)hipEventRecord(L.events[4], L.stream);
+  }
+#undef EV_TRY
+  return CLDN_HIP_OK;
+}
+
 int stage1_launch_encode(const EncodeLaunch& L) {
   hipError_t e;
+  if (L.n_groups > 1u && L.pieces && !L.fused && L.n_chunks) return launch_encode_groups(L);
   if (L.events) (void)hipEventRecord(L.events[0], L.stream);
   const uint32_t na_f = L.plan->n_adaptive;
   if (L.fused) {
@@ -1878,7 +2024,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     }
     if (L.events) (void)hipEventRecord(L.events[1], L.stream);
     if (L.n_chunks) {
-      const int rc = launch_fused(L);
+      const int rc = launch_fused(L, L.stream, 0u, L.n_pieces);
       if (rc != CLDN_HIP_OK) return rc;
     }
     goto regular_done;
@@ -1890,7 +2036,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_gorilla_tokens");
   }
   if (L.n_chunks && L.pieces) {  // slot pipeline, regular stream by the barrier-free piece kernel
-    const int rc = launch_fused(L);
+    const int rc = launch_fused(L, L.stream, 0u, L.n_pieces);
     if (rc != CLDN_HIP_OK) return rc;
   } else if (L.n_chunks) {
     int l3 = 3;
@@ -1929,8 +2075,6 @@ regular_done:
   if (L.events) (void)hipEventRecord(L.events[2], L.stream);
   const uint32_t na = L.plan->n_adaptive;
   if (na && L.n_chunks) {
-    ColumnPtrs rank_cols;
-    for (int a = 0; a < kMaxAdaptive; ++a) rank_cols.p[a] = reinterpret_cast<uint8_t*>(L.ranks[a]);
     static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
     if (!L.modes_forced && !L.fused) {
       if (!no_fast) {
@@ -1944,43 +2088,8 @@ regular_done:
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_modes");
       }
     }
-    for (uint32_t a = 0; a < na && !no_fast; ++a) {
-      const uint32_t bpv = L.plan->adaptive[a].bpv;
-#define LAUNCH_PAL(RT)                                                                                              \
-  hipLaunchKernelGGL(k_section_palette<RT>, dim3(L.n_chunks), dim3(kS2Threads), kS2PalLds, L.stream, *L.plan, a,      \
-                     L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs, \
-                     L.fallback_flags)
-#define LAUNCH_D32(RT)                                                                                              \
-  hipLaunchKernelGGL(k_section_delta32<RT>, dim3(L.n_chunks), dim3(kS2Threads), kD32Lds, L.stream, *L.plan, a,        \
-                     L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs, \
-                     L.fallback_flags);                                                                             \
-  hipLaunchKernelGGL(k_section_runs<RT>, dim3(L.n_chunks), dim3(kS2Threads), 0, L.stream, *L.plan, a, L.chunks,       \
-                     L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs,        \
-                     L.fallback_flags)
-      const uint32_t hint = L.mode_hint[a];
-      if (hint & 0xDu) {  // DeltaVarint / Rle / DeltaRle expected somewhere
-        if (bpv == 2u) { LAUNCH_D32(uint16_t); }
-        else if (bpv == 4u) { LAUNCH_D32(uint32_t); }
-      }
-#undef LAUNCH_D32
-      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_delta32/runs");
-#define LAUNCH_PAL32(RT)                                                                                            \
-  hipLaunchKernelGGL(k_section_palette32<RT>, dim3(L.n_chunks), dim3(kS2Threads), Pal32<RT>::kLds, L.stream, *L.plan, a, \
-                     L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk, L.subs, \
-                     L.fallback_flags)
-      if (hint & 0x2u) {
-        if (bpv == 2u) LAUNCH_PAL32(uint16_t);
-        else if (bpv == 4u) LAUNCH_PAL32(uint32_t);
-        else LAUNCH_PAL(uint64_t);
-      }
-#undef LAUNCH_PAL32
-#undef LAUNCH_PAL
-      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_palette");
-    }
-    hipLaunchKernelGGL(k_encode_sections, dim3(L.n_chunks, na), dim3(kSecThreads), kSecLdsTotal, L.stream, *L.plan,
-                       L.chunks, L.cols, L.modes, L.slots, L.slot_stride, L.reg_stride, L.segs, L.segs_per_chunk,
-                       rank_cols, L.subs, L.fallback_flags);
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_sections");
+    const int rc_sec = launch_sections(L, L.stream, 0u, L.n_chunks);
+    if (rc_sec != CLDN_HIP_OK) return rc_sec;
   }
   if (L.events) (void)hipEventRecord(L.events[3], L.stream);
   if (L.fused) {

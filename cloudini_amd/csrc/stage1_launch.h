@@ -57,6 +57,17 @@ struct EncodeLaunch {
   uint32_t* bitmaps;          // device [n_chunks * n_bm_fields * 2048], zero between calls
   uint32_t n_bm_fields;
   void* secplace;             // device [n_chunks * n_adaptive] SecPlace
+  // chunk-group pipeline of the piece kernel + slots pipeline (n_groups > 1): group i = chunks [group_chunk0[i],
+  // group_chunk0[i+1]) runs regular -> sections -> offsets -> compaction on stream (i even ? stream : side_stream), so
+  // that the bandwidth-bound compaction and the LDS-bound section kernels of one group overlap the VALU-bound regular
+  // kernel of the next. The only cross-group dependency is the running output position (offsets kernels, in order).
+  uint32_t n_groups;                // 0 / 1: no pipeline
+  const uint32_t* group_chunk0;     // host [n_groups + 1]
+  const uint32_t* group_piece0;     // host [n_groups + 1]
+  hipStream_t side_stream;
+  hipEvent_t* gev;                  // host [4 + n_groups]: setup, probe, side done, main rejoin, offsets of group i
+  unsigned long long* running;      // device: bytes placed so far (zero at launch)
+  hipEvent_t* gtime;                // NULL or host [2 * n_groups]: (start, end) of every group's regular kernel
 };
 
 // Can the single-pass encoder take this plan (regular stream = one fused FloatN encoder the point load covers, section
