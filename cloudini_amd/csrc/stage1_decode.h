@@ -925,13 +925,14 @@ template <int NOPS, bool WIDE>
 __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 : 8, 8))) void k_decode_varint(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                               const DecChunk* __restrict__ chunks,
                                                               uint8_t* __restrict__ out, uint32_t* __restrict__ reg_end,
-                                                              uint32_t* __restrict__ status) {
+                                                              uint32_t* __restrict__ status, uint32_t redo_only) {
   constexpr int BPT = WIDE ? 8 : 16;
   using L = Dv2Lds<NOPS, WIDE, BPT>;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t c = blockIdx.x;
   const DecChunk dc = chunks[c];
   if (!dc.valid) return;
+  if (redo_only && reg_end[c] != kDecRedo) return;  // behind k_decode_points: only the chunks it handed back
   uint8_t* base = out + (size_t)dc.first_point * plan.point_step;
   dv_stream2<NOPS, WIDE, BPT>([&](int o) -> const DevOp& { return plan.ops[o]; }, plan.n_ops, streams + dc.src_off,
                               dc.src_size, 0u, dc.n_points, base, plan.point_step, smem);
@@ -1146,8 +1147,9 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_sections_small(const DevP
                                                                       uint8_t* __restrict__ out,
                                                                       const uint32_t* __restrict__ reg_end,
                                                                       uint8_t* __restrict__ sec_done,
-                                                                      uint32_t* __restrict__ status) {
+                                                                      uint32_t* __restrict__ status, uint32_t honor_folded) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (honor_folded && sec_done[blockIdx.x] == 2u) return;  // k_decode_points wrote this chunk's sections with its points
   uint64_t* pal_l = reinterpret_cast<uint64_t*>(smem);
   uint32_t* stage = reinterpret_cast<uint32_t*>(smem + kSmallPalEntries * 8u);
   uint32_t* misc = reinterpret_cast<uint32_t*>(smem + kSmallPalEntries * 8u + 8192u * 4u);

@@ -1,0 +1,497 @@
+// stage1_decode_fast.h -- k_decode_points: stage-1 decode of chunks whose regular stream is one fused FloatN encoder
+// (3 or 4 int32-delta varint tokens per point; FieldDecoderFloatN_Lossy::decode, src/field_decoder.cpp:43-86), with
+// the chunk's Palette sections (decodeV5AdaptiveIntSection, src/v5_codec.cpp:764-879, mode 1) folded into the same
+// pass. Included by stage1_kernels.hip behind stage1_decode.h.
+//
+// k_decode_varint walks the 16 byte positions of every thread with the full token logic under a predicate (233
+// lane-instructions per token); here the two jobs are separated:
+//   phase A  byte-parallel and cheap: every thread flags the token ends in its 16 bytes, one block scan numbers them,
+//            and the byte position of every token end goes into an LDS list in token order;
+//   phase B  point-parallel, every lane busy: a thread takes 3 consecutive points, reads their 3 * NOPS + 1 end
+//            positions (a token starts behind the previous one's end, so its length needs no flag analysis), pulls
+//            each token out of the LDS copy of the tile with one 8-byte window, sums its deltas, a segmented block
+//            scan (NaN markers reset a lane) turns them into values, and the values leave through an LDS transposition
+//            so that a store instruction covers consecutive points.
+// A tile starts exactly at a point boundary (the next tile begins behind the last token it consumed), so no point is
+// ever cut and nothing but the per-lane running values is carried between tiles.
+//
+// Sections: where the regular stream ends is not written anywhere, so a counting pre-pass over the token-end flags
+// finds it first. If every section of the chunk is a Palette with at most kFastPalEntries entries (intensity, ring,
+// reflectivity ... of real lidars), their tables go to LDS and every point is completed when it is written: x, y, z
+// and its integer fields together, so that each output line is written once by one workgroup (the separate section
+// kernel re-dirtied every 64-byte line: WRITE_SIZE was 1.97x the output). Other sections are left to
+// k_decode_sections / k_decode_general exactly as before, and so is every chunk this kernel finds irregular (tokens of
+// more than 5 bytes, a stream that ends early, an index beyond its palette): reg_end[c] = kDecRedo hands it to
+// k_decode_varint, which keeps the reference's error reporting.
+#pragma once
+
+namespace cldn {
+
+constexpr uint32_t kFpPPT = 3;                          // points per thread and tile
+constexpr uint32_t kFpTileBytes = kDvThreads * 16u;     // 16 KiB of stream per tile
+constexpr uint32_t kFpTilePoints = kDvThreads * kFpPPT; // at most 3072 points leave per tile
+constexpr uint32_t kFastPalEntries = 1024;
+constexpr uint32_t kFastPalFields = 2;
+
+template <int NOPS>
+struct FpLds {
+  static constexpr uint32_t kTileOff = 0;                                   // [16 zero bytes][tile][32 pad]
+  static constexpr uint32_t kPosOff = 16u + kFpTileBytes + 32u;             // u16 [1 + kFpTilePoints * NOPS + 7]
+  static constexpr uint32_t kPosEntries = 1u + kFpTilePoints * NOPS + 7u;
+  static constexpr uint32_t kWorkEnd = (kPosOff + kPosEntries * 2u + 15u) & ~15u;
+  static constexpr uint32_t kStageBytes = kFpTilePoints * NOPS * 4u;        // decoded floats, overlays tile + list
+  static constexpr uint32_t kScanOff = (kWorkEnd > kStageBytes ? kWorkEnd : kStageBytes);
+  static constexpr uint32_t kWaveRec = NOPS * 4u + 8u;                      // per wave: int[NOPS] + flags; [16] = carry
+  static constexpr uint32_t kPalOff = (kScanOff + 17u * kWaveRec + 15u) & ~15u;
+  static constexpr uint32_t kMiscOff = kPalOff + kFastPalFields * kFastPalEntries * 4u;
+  static constexpr uint32_t kTotal = kMiscOff + 512u;
+};
+
+// 16 payload bytes at payload offset `o` (any alignment of the stream); bytes behind the payload read as 0xff
+// (continuation bytes: no token ends there)
+__device__ __forceinline__ void fp_load16(const uint8_t* __restrict__ src, uint32_t src_size, uint32_t o, uint32_t (&b)[4]) {
+  if (o + 16u <= src_size) {
+    const uint8_t* q = src + o;
+    const uint32_t mis = (uint32_t)((uintptr_t)q & 3u);
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(q - mis);
+    // 5 aligned dwords cover the 16 bytes; the fifth is only read when the 16 bytes really reach into it
+    const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3];
+    const uint32_t d4 = mis ? a[4] : 0u;
+    b[0] = __builtin_amdgcn_alignbyte(d1, d0, mis);
+    b[1] = __builtin_amdgcn_alignbyte(d2, d1, mis);
+    b[2] = __builtin_amdgcn_alignbyte(d3, d2, mis);
+    b[3] = __builtin_amdgcn_alignbyte(d4, d3, mis);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t w = 0xffffffffu;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const uint32_t i = o + 4u * k + bb;
+        if (i < src_size) w = (w & ~(0xffu << (8 * bb))) | ((uint32_t)src[i] << (8 * bb));
+      }
+      b[k] = w;
+    }
+  }
+}
+
+// bit j = byte j of the 16 ends a token (MSB clear)
+__device__ __forceinline__ uint32_t fp_ends16(const uint32_t (&b)[4]) {
+  uint32_t ends = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ends |= ((((~b[k] & 0x80808080u) >> 7) * 0x00204081u) >> 21 & 0xfu) << (4 * k);
+  return ends;
+}
+
+struct FpSection {   // a Palette section folded into the point pass
+  uint32_t field_off;  // offset of the field inside the point
+  uint32_t bpv;        // 2 or 4
+  uint32_t count;      // palette entries
+  uint32_t bits;       // bits per index
+  uint32_t index_off;  // payload offset of the packed indexes
+};
+
+template <int NOPS>
+__global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decode_points(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                              const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
+                                                              uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done,
+                                                              uint32_t uses_v5, uint32_t* __restrict__ status) {
+  using L = FpLds<NOPS>;
+  constexpr int T = kDvThreads;
+  constexpr uint32_t CAP_TOK = kFpTilePoints * NOPS;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem + L::kTileOff);             // dwords; byte 16 = first tile byte
+  uint16_t* pos_list = reinterpret_cast<uint16_t*>(smem + L::kPosOff);          // [0] = end of the token before the tile
+  float* stage = reinterpret_cast<float*>(smem);                                // overlays tile and list in phase B
+  uint8_t* scanrec = smem + L::kScanOff;
+  uint32_t* pal = reinterpret_cast<uint32_t*>(smem + L::kPalOff);
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + L::kMiscOff);             // [0] irregular, [2..34) scan scratch,
+                                                                                // [40..) pre-pass, [64..) sections
+  const uint32_t c = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const DecChunk dc = chunks[c];
+  if (!dc.valid) {
+    if (tid == 0) sec_done[c] = 0u;
+    return;
+  }
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t src_size = dc.src_size;
+  const uint32_t n = dc.n_points;
+  const uint32_t step = plan.point_step;
+  uint8_t* base = out + (size_t)dc.first_point * step;
+  const uint32_t target = n * NOPS;
+
+  if (tid < 4u) tile[tid] = 0u;  // the 16 bytes in front of a tile: token ends
+  if (tid == 0) {
+    misc[0] = 0u;
+    misc[1] = 0u;            // a folded Palette index was out of range
+    misc[41] = 0u;
+    misc[40] = 0xffffffffu;  // pre-pass: payload offset behind the regular stream
+    misc[64] = 0u;           // sections folded in
+  }
+  if (tid < (uint32_t)(NOPS + 2)) reinterpret_cast<uint32_t*>(scanrec + 16u * L::kWaveRec)[tid] = 0u;  // carry: values 0
+  __syncthreads();
+
+  // ---------------------------------------------------------------------------------------------------------
+  // pre-pass: the payload offset behind token number `target`. Wave w counts the token ends of its 1/16 of the
+  // payload; the wave that holds the last token walks its part again and finds the byte.
+  // ---------------------------------------------------------------------------------------------------------
+  uint32_t reg_size = 0xffffffffu;
+  if (uses_v5 && plan.n_adaptive != 0u) {
+    const uint32_t part = (((src_size + 15u) / 16u + 15u) / 16u) * 16u;  // bytes per wave, multiple of 16
+    const uint32_t w0 = wave * part, w1 = min(src_size, w0 + part);
+    uint32_t cnt = 0u;
+    for (uint32_t o = w0 + lane * 16u; o < w1; o += 1024u) {
+      uint32_t b[4];
+      fp_load16(src, src_size, o, b);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cnt += (uint32_t)__builtin_popcount(~b[k] & 0x80808080u);  // token ends = bytes with a clear MSB
+    }
+    const uint32_t wsum = wave_sum(cnt);
+    if (lane == 0u) misc[44u + wave] = wsum;
+    __syncthreads();
+    uint32_t before = 0u;
+    for (uint32_t w = 0; w < wave; ++w) before += misc[44u + w];
+    if (target != 0u && before < target && target <= before + wsum) {  // the last token ends in my part (one wave)
+      uint32_t seen = before;
+      for (uint32_t o0 = w0; o0 < w1; o0 += 1024u) {
+        const uint32_t o = o0 + lane * 16u;
+        uint32_t b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        if (o < w1) fp_load16(src, src_size, o, b);
+        const uint32_t ends = fp_ends16(b);
+        const uint32_t cl = (uint32_t)__builtin_popcount(ends);
+        const uint32_t incl = wave_inclusive_scan(cl);
+        const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (seen + row >= target) {
+          const uint32_t my_first = seen + incl - cl;  // tokens before mine
+          if (my_first < target && target <= my_first + cl) {
+            uint32_t m = ends;
+            for (uint32_t k = my_first + 1u; k < target; ++k) m &= m - 1u;  // drop the ends before the wanted one
+            misc[40] = o + (uint32_t)__builtin_ctz(m) + 1u;
+          }
+          break;
+        }
+        seen += row;
+      }
+    }
+    if (target == 0u && tid == 0) misc[40] = 0u;
+    __syncthreads();
+    reg_size = misc[40];
+
+    // section headers (one thread): every section a small Palette of a 2- or 4-byte field -> fold them in
+    if (tid == 0 && reg_size != 0xffffffffu && plan.n_adaptive <= kFastPalFields) {
+      uint32_t off = reg_size;
+      bool ok = true;
+      FpSection* sec = reinterpret_cast<FpSection*>(misc + 72);
+      for (uint32_t a = 0; a < plan.n_adaptive && ok; ++a) {
+        const uint32_t bpv = plan.adaptive[a].bpv;
+        if (bpv > 4u || src_size - min(src_size, off) < 3u || src[off] != 1u) { ok = false; break; }
+        const uint32_t count = (uint32_t)src[off + 1u] | ((uint32_t)src[off + 2u] << 8);
+        off += 3u;
+        if (count == 0u || count > kFastPalEntries || (uint64_t)(src_size - off) < (uint64_t)count * bpv) { ok = false; break; }
+        const uint32_t bits = palette_bits(count);
+        const uint32_t index_bytes = (uint32_t)(((uint64_t)bits * n + 7u) / 8u);
+        const uint32_t table_off = off;
+        off += count * bpv;
+        if (src_size - off < index_bytes) { ok = false; break; }
+        sec[a].field_off = plan.adaptive[a].offset;
+        sec[a].bpv = bpv;
+        sec[a].count = count;
+        sec[a].bits = bits;
+        sec[a].index_off = off;
+        misc[68u + a] = table_off;
+        off += index_bytes;
+      }
+      if (ok && off == src_size) misc[64] = plan.n_adaptive;  // (trailing bytes: the serial decoder raises the error)
+    }
+    __syncthreads();
+    const uint32_t n_fold = misc[64];
+    for (uint32_t a = 0; a < n_fold; ++a) {  // palette tables -> LDS
+      const FpSection s = reinterpret_cast<const FpSection*>(misc + 72)[a];
+      const uint8_t* tp = src + misc[68u + a];
+      for (uint32_t k = tid; k < s.count; k += T) {
+        uint32_t v = 0u;
+        for (uint32_t bb = 0; bb < s.bpv; ++bb) v |= ((uint32_t)tp[(size_t)k * s.bpv + bb]) << (8u * bb);
+        pal[a * kFastPalEntries + k] = v;
+      }
+    }
+    __syncthreads();
+  }
+  const uint32_t n_fold = misc[64];
+
+  // which store forms the layout allows (uniform)
+  bool contig = ((step | plan.ops[0].offset) & 3u) == 0u;
+#pragma unroll
+  for (int o = 1; o < NOPS; ++o) contig = contig && plan.ops[o].offset == plan.ops[0].offset + 4u * (uint32_t)o;
+  float res[NOPS];
+  uint32_t foff[NOPS];
+#pragma unroll
+  for (int o = 0; o < NOPS; ++o) {
+    res[o] = plan.ops[o].res_f;
+    foff[o] = plan.ops[o].offset;
+  }
+
+  // ---------------------------------------------------------------------------------------------------------
+  // tiles
+  // ---------------------------------------------------------------------------------------------------------
+  uint32_t pos = 0u;       // payload offset of the tile (a point boundary)
+  uint32_t pts_done = 0u;
+  bool bad = false;
+  while (pts_done < n) {
+    if (pos >= src_size) { bad = true; break; }
+    // ---- phase A: bytes -> LDS, token ends -> position list
+    uint32_t b[4];
+    fp_load16(src, src_size, pos + tid * 16u, b);
+    *reinterpret_cast<uint4*>(tile + 4u + tid * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
+    const uint32_t ends = fp_ends16(b);
+    uint32_t n_tile;
+    const uint32_t tb = block_exclusive_scan<T>((uint32_t)__builtin_popcount(ends), misc + 2, &n_tile);  // barrier inside
+    const uint32_t want = min(CAP_TOK, (n - pts_done) * NOPS);
+    {
+      uint32_t k = tb + 1u;  // list slot of my first token ([0] is the token before the tile)
+      for (uint32_t m = ends; m != 0u && k <= want; m &= m - 1u, ++k) pos_list[k] = (uint16_t)(tid * 16u + (uint32_t)__builtin_ctz(m));
+      if (tid == 0) pos_list[0] = (uint16_t)0xffffu;  // "ends at -1": the tile's first token starts at byte 0
+    }
+    __syncthreads();
+    const uint32_t npts = min(n_tile, want) / NOPS;  // whole points of this tile
+    if (npts == 0u) { bad = true; break; }           // 16 KiB without NOPS token ends: not a FloatN stream
+
+    // ---- phase B: my points [q0, q0 + kFpPPT)
+    const uint32_t q0 = tid * kFpPPT;
+    int32_t dlt[kFpPPT][NOPS];
+    uint32_t mk = 0u;      // bit (i * NOPS + o): token is the NaN marker
+    bool long_tok = false;
+    {
+      // end positions of tokens q0*NOPS - 1 ... (q0 + PPT)*NOPS - 1: list slots q0*NOPS ... +PPT*NOPS, 2 bytes each
+      const uint32_t s0 = q0 * NOPS;
+      uint32_t e_prev = pos_list[min(s0, CAP_TOK)];
+#pragma unroll
+      for (uint32_t i = 0; i < kFpPPT; ++i) {
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) {
+          const uint32_t slot = s0 + i * NOPS + (uint32_t)o + 1u;
+          const bool have = (q0 + i) < npts;
+          const uint32_t e = pos_list[min(slot, CAP_TOK)];
+          const uint32_t start = (e_prev + 1u) & 0xffffu;  // byte index in the tile
+          const uint32_t len = e - start + 1u;
+          int32_t d = 0;
+          if (have) {
+            if (len > 5u) long_tok = true;
+            const uint32_t byte0 = 16u + start;             // byte index in the LDS copy
+            const uint32_t d0 = tile[byte0 >> 2], d1 = tile[(byte0 >> 2) + 1u];
+            const uint64_t raw = (((((uint64_t)d1) << 32) | d0) >> ((byte0 & 3u) * 8u)) &
+                                 (len >= 8u ? ~0ull : ((1ull << (len * 8u)) - 1ull));
+            const uint32_t lo = (uint32_t)raw & 0x7f7f7f7fu;
+            const uint32_t u28 = (lo & 0x7fu) | ((lo >> 1) & 0x3f80u) | ((lo >> 2) & 0x1fc000u) | ((lo >> 3) & 0xfe00000u);
+            const uint64_t u = (uint64_t)u28 | ((uint64_t)((uint32_t)(raw >> 32) & 0x7fu) << 28);
+            if (u == 0ull) {
+              if (len == 1u) mk |= 1u << (i * NOPS + (uint32_t)o);  // the marker byte 0x00
+              else long_tok = true;                                // an overlong zero: decodeVarint rejects it
+            }
+            const uint64_t u1 = u - 1ull;
+            d = (int32_t)((uint32_t)(u1 >> 1) ^ (0u - ((uint32_t)u1 & 1u)));  // low 32 bits: the decoder narrows to int32
+          }
+          dlt[i][o] = d;
+          e_prev = e;
+        }
+      }
+    }
+    // local sums per lane with NaN resets, then the segmented scan over the threads
+    int32_t acc[NOPS];
+    uint32_t fl = 0u;
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) acc[o] = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kFpPPT; ++i) {
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) {
+        const bool m = (mk >> (i * NOPS + (uint32_t)o)) & 1u;
+        acc[o] = m ? 0 : (int32_t)((uint32_t)acc[o] + (uint32_t)dlt[i][o]);
+        if (m) fl |= 1u << o;
+      }
+    }
+    int32_t inc[NOPS];
+    uint32_t fin = fl;
+    if (__ballot(fl != 0u) == 0ull) {  // no marker in this wave (the rule for lidar data): plain DPP prefix sums
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) inc[o] = (int32_t)wave_inclusive_scan((uint32_t)acc[o]);
+    } else {
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) inc[o] = acc[o];
+#pragma unroll
+      for (int dl = 1; dl < 64; dl <<= 1) {
+        const uint32_t of = (uint32_t)__shfl_up((int)fin, dl);
+        int32_t ov[NOPS];
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) ov[o] = __shfl_up(inc[o], dl);
+        if (lane >= (uint32_t)dl) {
+#pragma unroll
+          for (int o = 0; o < NOPS; ++o)
+            if (!(fin & (1u << o))) inc[o] = (int32_t)((uint32_t)inc[o] + (uint32_t)ov[o]);
+          fin |= of;
+        }
+      }
+    }
+    if (long_tok) misc[0] = 1u;
+    if (lane == 63u) {
+      int32_t* rec = reinterpret_cast<int32_t*>(scanrec + wave * L::kWaveRec);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) rec[o] = inc[o];
+      *reinterpret_cast<uint32_t*>(scanrec + wave * L::kWaveRec + NOPS * 4u) = fin;
+    }
+    __syncthreads();  // also: every thread is done with the tile bytes and the list -> the staging area may overlay them
+    int32_t in[NOPS];
+    {
+      const int32_t* crec = reinterpret_cast<const int32_t*>(scanrec + 16u * L::kWaveRec);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) in[o] = crec[o];
+      {
+        // state behind waves 0..wave-1: lane l < 16 holds wave l's record, a 4-step segmented scan over those 16 lanes
+        // (row-local DPP shifts), lane wave-1 then has the combination of all waves before mine
+        int32_t rv[NOPS];
+        uint32_t rfl = 0u;
+        const uint32_t wl = lane & 15u;
+        {
+          const int32_t* rec = reinterpret_cast<const int32_t*>(scanrec + wl * L::kWaveRec);
+#pragma unroll
+          for (int o = 0; o < NOPS; ++o) rv[o] = rec[o];
+          rfl = *reinterpret_cast<const uint32_t*>(scanrec + wl * L::kWaveRec + NOPS * 4u);
+        }
+#define FP_SEG_STEP(DL)                                                                                         \
+  {                                                                                                            \
+    const uint32_t of = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rfl, 0x110 + DL, 0xf, 0xf, true); /* row_shr */ \
+    int32_t ov[NOPS];                                                                                          \
+    _Pragma("unroll") for (int o = 0; o < NOPS; ++o) ov[o] = __builtin_amdgcn_update_dpp(0, rv[o], 0x110 + DL, 0xf, 0xf, true); \
+    if (wl >= (uint32_t)DL) {                                                                                  \
+      _Pragma("unroll") for (int o = 0; o < NOPS; ++o)                                                         \
+        if (!(rfl & (1u << o))) rv[o] = (int32_t)((uint32_t)rv[o] + (uint32_t)ov[o]);                          \
+      rfl |= of;                                                                                               \
+    }                                                                                                          \
+  }
+        FP_SEG_STEP(1)
+        FP_SEG_STEP(2)
+        FP_SEG_STEP(4)
+        FP_SEG_STEP(8)
+#undef FP_SEG_STEP
+        if (wave > 0u) {
+          const uint32_t pfw = (uint32_t)__builtin_amdgcn_readlane((int)rfl, (int)wave - 1);
+#pragma unroll
+          for (int o = 0; o < NOPS; ++o) {
+            const int32_t pvw = __builtin_amdgcn_readlane(rv[o], (int)wave - 1);
+            in[o] = (pfw & (1u << o)) ? pvw : (int32_t)((uint32_t)in[o] + (uint32_t)pvw);
+          }
+        }
+      }
+      const uint32_t pf = (uint32_t)__shfl_up((int)fin, 1);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) {
+        const int32_t pv = __shfl_up(inc[o], 1);
+        if (lane > 0u) in[o] = (pf & (1u << o)) ? pv : (int32_t)((uint32_t)in[o] + (uint32_t)pv);
+      }
+    }
+    if (misc[0]) { bad = true; break; }  // uniform (read behind the barrier)
+    // final values -> staging (point-major, NOPS floats per point)
+#pragma unroll
+    for (uint32_t i = 0; i < kFpPPT; ++i) {
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) {
+        const bool m = (mk >> (i * NOPS + (uint32_t)o)) & 1u;
+        in[o] = m ? 0 : (int32_t)((uint32_t)in[o] + (uint32_t)dlt[i][o]);
+        const float f = m ? __uint_as_float(0x7fc00000u) : __fmul_rn((float)in[o], res[o]);
+        stage[(q0 + i) * NOPS + (uint32_t)o] = f;  // points >= npts: harmless slots, never read
+      }
+    }
+    if (tid == (npts - 1u) / kFpPPT) {
+      // the thread that owns the tile's last point: its running values (after that point) are the carry; its later
+      // points did not exist (have == false -> delta 0, no marker), so `in` is exactly the state behind point npts - 1
+      int32_t* crec = reinterpret_cast<int32_t*>(scanrec + 16u * L::kWaveRec);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) crec[o] = in[o];
+    }
+    // byte behind the last token this tile consumed = start of the next tile. The list is overlaid by the staging
+    // area now, so the owner of that token recomputes it from its own end flags.
+    {
+      const uint32_t last_tok = npts * NOPS - 1u;  // index in the tile
+      if (tb <= last_tok && last_tok < tb + (uint32_t)__builtin_popcount(ends)) {
+        uint32_t m = ends;
+        for (uint32_t k = tb; k < last_tok; ++k) m &= m - 1u;
+        misc[41] = pos + tid * 16u + (uint32_t)__builtin_ctz(m) + 1u;
+      }
+    }
+    __syncthreads();
+    // ---- read-out: consecutive lanes, consecutive points; folded Palette fields complete the point
+#pragma unroll
+    for (uint32_t r = 0; r < kFpPPT; ++r) {
+      const uint32_t q = r * (uint32_t)T + tid;
+      if (q < npts) {
+        const uint32_t p = pts_done + q;  // point of the chunk
+        uint8_t* pt = base + (size_t)p * step;
+        float f[NOPS];
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) f[o] = stage[q * NOPS + (uint32_t)o];
+        if (contig) {
+          if (NOPS == 3) {
+            FloatVec<3> v;
+            v.v[0] = f[0]; v.v[1] = f[1]; v.v[2] = f[2];
+            *reinterpret_cast<FloatVec<3>*>(pt + foff[0]) = v;
+          } else {
+            FloatVec<4> v;
+#pragma unroll
+            for (int o = 0; o < NOPS; ++o) v.v[o] = f[o];
+            *reinterpret_cast<FloatVec<4>*>(pt + foff[0]) = v;
+          }
+        } else {
+#pragma unroll
+          for (int o = 0; o < NOPS; ++o)
+            if (foff[o] != 0xffffffffu) st_raw(pt + foff[o], __float_as_uint(f[o]), 4);
+        }
+        for (uint32_t a = 0; a < n_fold; ++a) {
+          const FpSection s = reinterpret_cast<const FpSection*>(misc + 72)[a];
+          uint32_t idx = 0u;
+          if (s.bits) {
+            const uint64_t bit = (uint64_t)p * s.bits;
+            const uint8_t* ib = src + s.index_off + (uint32_t)(bit >> 3);
+            // up to 10 + 7 bits: 3 bytes cover it; the section's last bytes are guarded
+            const uint32_t avail = src_size - (s.index_off + (uint32_t)(bit >> 3));
+            uint32_t w;
+            if (avail >= 8u) {  // two aligned dwords cover byte 0..3 of the window wherever it starts
+              const uint32_t mis = (uint32_t)((uintptr_t)ib & 3u);
+              const uint32_t* iq = reinterpret_cast<const uint32_t*>(ib - mis);
+              w = __builtin_amdgcn_alignbyte(iq[1], iq[0], mis);
+            } else {            // the section's last bytes
+              w = ib[0];
+              if (avail > 1u) w |= (uint32_t)ib[1] << 8;
+              if (avail > 2u) w |= (uint32_t)ib[2] << 16;
+            }
+            idx = (w >> ((uint32_t)bit & 7u)) & ((1u << s.bits) - 1u);
+          }
+          if (idx >= s.count) {
+            misc[1] = 1u;  // index beyond the palette: the serial decoder redoes the sections and raises the error
+          } else {
+            const uint32_t v = pal[a * kFastPalEntries + idx];
+            if (s.bpv == 2u && ((s.field_off | step) & 1u) == 0u) *reinterpret_cast<uint16_t*>(pt + s.field_off) = (uint16_t)v;
+            else if (s.bpv == 4u && ((s.field_off | step) & 3u) == 0u) *reinterpret_cast<uint32_t*>(pt + s.field_off) = v;
+            else st_raw(pt + s.field_off, v, s.bpv);
+          }
+        }
+      }
+    }
+    pos = misc[41];
+    pts_done += npts;
+    __syncthreads();  // staging / misc[41] are free again; restore the 16 zero bytes in front of the tile
+    if (tid < 4u) tile[tid] = 0u;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const bool redo = bad || misc[0] != 0u;
+    reg_end[c] = redo ? kDecRedo : pos;
+    const bool folded = !redo && n_fold != 0u && misc[1] == 0u && pos == reg_size;
+    sec_done[c] = folded ? 2u : 0u;
+    if (!redo) atomicAdd(&status[kStatFastRegular], 1u);
+    if (folded) atomicAdd(&status[kStatFastSections], 1u);
+  }
+}
+
+}  // namespace cldn

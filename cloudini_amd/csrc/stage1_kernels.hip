@@ -1667,6 +1667,7 @@ __global__ __launch_bounds__(kSecThreads) void k_encode_sections(const DevPlan p
 }  // namespace cldn
 
 #include "stage1_decode.h"
+#include "stage1_decode_fast.h"
 
 // ------------------------------------------------------------------------------------------------------------
 // launchers
@@ -2132,19 +2133,34 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     bool fast = !no_fast && P.all_varint && P.n_ops <= 8u;  // no regular ops at all (integer-only V5 cloud) is fine too
     bool all_qf32 = true;
     for (uint32_t k = 0; k < P.n_ops; ++k) all_qf32 = all_qf32 && P.ops[k].kind == OP_QF32;
+    // FloatN streams (3 or 4 int32-delta tokens per point): point-parallel kernel with the Palette sections folded in;
+    // it hands irregular chunks back (reg_end = kDecRedo) and k_decode_varint redoes only those
+    static const bool no_points = getenv("CLDN_HIP_NO_POINT_DECODE") != nullptr;  // A/B switch
+    const bool points_kernel = fast && !no_points && all_qf32 && (P.n_ops == 3u || P.n_ops == 4u) && P.n_gorilla == 0u;
+    if (points_kernel) {
+      if (P.n_ops == 3u)
+        hipLaunchKernelGGL((k_decode_points<3>), dim3(L.n_chunks), dim3(kDvThreads), (FpLds<3>::kTotal), L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5, L.status);
+      else
+        hipLaunchKernelGGL((k_decode_points<4>), dim3(L.n_chunks), dim3(kDvThreads), (FpLds<4>::kTotal), L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5, L.status);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_points");
+    }
     if (fast) {
       if (all_qf32 && P.n_ops <= 4u)
         hipLaunchKernelGGL((k_decode_varint<4, false>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<4, false, 16>::kTotal),
-                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status);
+                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status,
+                           points_kernel ? 1u : 0u);
       else
         hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<8, true, 8>::kTotal),
-                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status);
+                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, 0u);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_varint");
     }
     const bool fast_sections = fast && L.uses_v5 && P.n_adaptive > 0u;
     if (fast_sections) {
       hipLaunchKernelGGL(k_decode_sections_small, dim3(L.n_chunks), dim3(kDvThreads), kSmallSecLds, L.stream, P, L.streams,
-                         reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status);
+                         reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status,
+                         points_kernel ? 1u : 0u);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_sections_small");
       hipLaunchKernelGGL(k_decode_sections, dim3(L.n_chunks), dim3(kDvThreads), (DecSecLds::kTotal), L.stream, P, L.streams,
                          reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status);
