@@ -75,9 +75,25 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     return HOST_SO
 
 
+TRANSCODE_BIN = os.path.join(LIBDIR, "cloudini_batch_transcode")
+
+
+def build_tools(force: bool = False, verbose: bool = False) -> str:
+    """Command-line batch transcoder (tools/cloudini_batch_transcode.cpp) next to the libraries."""
+    src = os.path.join(ROOT, "tools", "cloudini_batch_transcode.cpp")
+    if force or _newer(TRANSCODE_BIN, [src, HOST_SO]):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), src, HOST_SO, HIP_SO,
+               "-lpthread", "-Wl,-rpath,$ORIGIN", "-o", TRANSCODE_BIN]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return TRANSCODE_BIN
+
+
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_hip(force, verbose)
     build_host(force, verbose)
+    build_tools(force, verbose)
 
 
 if __name__ == "__main__":

@@ -645,9 +645,12 @@ static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, u
   return CLDN_HIP_OK;
 }
 
-int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_loc, const uint64_t* cloud_points,
-                           uint32_t n_clouds, void* out, uint64_t out_capacity, int out_loc,
-                           uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes) {
+}  // extern "C"
+
+// cloud_ptrs != NULL: the clouds live in separate HOST buffers (`points` is ignored)
+static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int points_loc, const void* const* cloud_ptrs,
+                              const uint64_t* cloud_points, uint32_t n_clouds, void* out, uint64_t out_capacity, int out_loc,
+                              uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes) {
   if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
   if (n_clouds && !cloud_points) return fail(CLDN_HIP_ERR_ARG, "cloud_points is NULL");
   if ((points_loc != CLDN_HIP_HOST && points_loc != CLDN_HIP_DEVICE) ||
@@ -665,7 +668,10 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   const bool want_single_pass = c->pipeline == 3 && piece_pts != 0u && stage1_single_pass_ok(plan, variant_ptr);
   int rc = upload_batch_shape(c, cloud_points, n_clouds, piece_pts, &n_chunks, &n_points);
   if (rc != CLDN_HIP_OK) return rc;
-  if (n_points && !points) return fail(CLDN_HIP_ERR_ARG, "points is NULL");
+  if (n_points && !points && !cloud_ptrs) return fail(CLDN_HIP_ERR_ARG, "points is NULL");
+  if (cloud_ptrs)
+    for (uint32_t k = 0; k < n_clouds; ++k)
+      if (cloud_points[k] && !cloud_ptrs[k]) return fail(CLDN_HIP_ERR_ARG, "cloud %u: NULL buffer", k);
 
   // capacity contract of PointcloudEncoder::encode (cloudini.cpp:531-534)
   uint64_t need = 0;
@@ -731,7 +737,16 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
     }
     if (points_loc == CLDN_HIP_HOST) {
       if ((rc = c->d_in.ensure((size_t)n_points * step)) != CLDN_HIP_OK) return rc;
-      HIP_TRY(hipMemcpyAsync(c->d_in.p, points, (size_t)n_points * step, hipMemcpyHostToDevice, c->stream));
+      if (cloud_ptrs) {  // gather: every cloud straight from its own buffer to its place in the batch
+        size_t at = 0;
+        for (uint32_t k = 0; k < n_clouds; ++k) {
+          const size_t bytes = (size_t)cloud_points[k] * step;
+          if (bytes) HIP_TRY(hipMemcpyAsync((uint8_t*)c->d_in.p + at, cloud_ptrs[k], bytes, hipMemcpyHostToDevice, c->stream));
+          at += bytes;
+        }
+      } else {
+        HIP_TRY(hipMemcpyAsync(c->d_in.p, points, (size_t)n_points * step, hipMemcpyHostToDevice, c->stream));
+      }
       d_points = (const uint8_t*)c->d_in.p;
     }
     if (out_loc == CLDN_HIP_HOST) {
@@ -951,6 +966,23 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_l
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (stream_offsets) memcpy(stream_offsets, h_off, (size_t)(n_clouds + 1) * sizeof(uint64_t));
   return CLDN_HIP_OK;
+}
+
+extern "C" {
+
+int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_loc, const uint64_t* cloud_points,
+                           uint32_t n_clouds, void* out, uint64_t out_capacity, int out_loc,
+                           uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes) {
+  return encode_stage1_impl(c, points, points_loc, nullptr, cloud_points, n_clouds, out, out_capacity, out_loc,
+                            stream_offsets, chunk_sizes, modes);
+}
+
+int cldn_hip_encode_stage1_gather(cldn_hip_codec_t* c, const void* const* cloud_ptrs, const uint64_t* cloud_points,
+                                  uint32_t n_clouds, void* out, uint64_t out_capacity, int out_loc,
+                                  uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes) {
+  if (n_clouds && !cloud_ptrs) return fail(CLDN_HIP_ERR_ARG, "cloud_ptrs is NULL");
+  return encode_stage1_impl(c, nullptr, CLDN_HIP_HOST, cloud_ptrs, cloud_points, n_clouds, out, out_capacity, out_loc,
+                            stream_offsets, chunk_sizes, modes);
 }
 
 int cldn_hip_viz_preprocess(cldn_hip_codec_t* c, const void* points, int points_loc, uint64_t n_points,

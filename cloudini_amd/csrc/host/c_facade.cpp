@@ -8,6 +8,7 @@
 #include "cloudini_lib/cloudini.hpp"
 #include "cloudini_lib/ros_msg_utils.hpp"
 #include "cloudini_lib/wasm_functions.h"
+#include "cloudini_amd/batch_transcoder.hpp"
 #include "host_internal.hpp"
 
 #define CLDN_EXPORT extern "C" __attribute__((visibility("default")))
@@ -87,6 +88,27 @@ CLDN_EXPORT int64_t cldn_amd_encode(const cldn_amd_info_t* info, const uint8_t* 
     Cloudini::PointcloudEncoder encoder(toInfo(info));
     Cloudini::BufferView view(out, capacity);
     return (int64_t)encoder.encode(Cloudini::ConstBufferView(data, size), view, write_header != 0);
+  });
+}
+
+CLDN_EXPORT int64_t cldn_amd_transcode_directory(const char* in_dir, const char* out_dir, float resolution,
+                                                 uint8_t compression_opt, int viz_lossy, uint32_t batch_messages,
+                                                 double* stats_out) {
+  return guarded([&] {
+    cloudini_amd::DirectorySource source(in_dir);
+    cloudini_amd::DirectorySink sink(out_dir);
+    cloudini_amd::TranscodeOptions opt;
+    opt.default_resolution = resolution;
+    opt.compression = static_cast<Cloudini::CompressionOption>(compression_opt);
+    opt.viz_lossy = viz_lossy != 0;
+    if (batch_messages) opt.batch_messages = batch_messages;
+    const cloudini_amd::TranscodeStats st = cloudini_amd::transcodePointClouds(source, sink, opt);
+    if (stats_out) {
+      const double v[8] = {(double)st.messages,    (double)st.points,  (double)st.input_bytes, (double)st.output_bytes,
+                           (double)st.gpu_batches, st.seconds_total, st.seconds_gpu,         st.seconds_stage2};
+      for (int i = 0; i < 8; ++i) stats_out[i] = v[i];
+    }
+    return (int64_t)st.messages;
   });
 }
 

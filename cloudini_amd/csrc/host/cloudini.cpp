@@ -810,6 +810,53 @@ void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compres
 
 namespace amd_detail {
 
+void encodeStage1Batch(const EncodingInfo& info, const uint8_t* const* cloud_ptrs, const uint64_t* cloud_points,
+                       uint32_t n_clouds, std::vector<uint8_t>& stage1, std::vector<uint64_t>& stream_offsets,
+                       std::vector<uint32_t>& chunk_sizes) {
+  PlanHandle plan(info);
+  uint64_t bound = 0, n_chunks = 0;
+  for (uint32_t k = 0; k < n_clouds; ++k) {
+    bound += cldn_hip_stage1_bound(plan.plan, cloud_points[k]);
+    n_chunks += (cloud_points[k] + kPointsPerChunk - 1) / kPointsPerChunk;
+  }
+  if (stage1.size() < bound) stage1.resize(bound);
+  stream_offsets.assign((size_t)n_clouds + 1, 0);
+  chunk_sizes.assign((size_t)std::max<uint64_t>(1, n_chunks), 0);
+  cldn_hip_codec_t* codec = pool().acquire(info, plan);
+  const int rc = cldn_hip_encode_stage1_gather(codec, reinterpret_cast<const void* const*>(cloud_ptrs), cloud_points, n_clouds,
+                                               stage1.data(), stage1.size(), CLDN_HIP_HOST, stream_offsets.data(),
+                                               chunk_sizes.data(), nullptr);
+  const std::string err = rc != CLDN_HIP_OK ? cldn_hip_last_error() : "";
+  pool().release(info, codec);
+  if (rc != CLDN_HIP_OK) throw std::runtime_error(err);
+  chunk_sizes.resize((size_t)n_chunks);
+}
+
+uint32_t compressChunkTo(CompressionOption opt, const uint8_t* src, size_t src_size, uint8_t* dst, size_t dst_cap) {
+  return compressChunk(opt, src, src_size, dst, dst_cap);
+}
+
+size_t compressedChunkBound(CompressionOption opt, size_t stage1_bytes) {
+  switch (opt) {
+    case CompressionOption::LZ4:
+      if (stage1_bytes > size_t(std::numeric_limits<int>::max())) throw std::runtime_error("Chunk size too large for LZ4");
+      return static_cast<size_t>(LZ4_compressBound(static_cast<int>(stage1_bytes)));
+    case CompressionOption::ZSTD:
+      return ZSTD_compressBound(stage1_bytes);
+    default:
+      return stage1_bytes;
+  }
+}
+
+void runOnStage2Pool(size_t n, const std::function<void(size_t)>& fn) {
+  const unsigned threads = Cloudini::stage2Threads();
+  if (n <= 1 || threads <= 1) {
+    for (size_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  stage2Pool().run(n, threads - 1u, fn);
+}
+
 unsigned stage2Threads() { return Cloudini::stage2Threads(); }
 void setStage2Threads(unsigned n) { g_stage2_threads.store(std::max(1u, std::min(n, 256u))); }
 

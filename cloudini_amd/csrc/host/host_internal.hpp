@@ -2,6 +2,10 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
+#include <vector>
+
+#include "cloudini_lib/cloudini.hpp"
 
 namespace Cloudini {
 namespace amd_detail {
@@ -9,6 +13,19 @@ namespace amd_detail {
 // cldn_hip_viz_preprocess on host buffers through a pooled codec; throws std::runtime_error on failure.
 uint64_t vizPreprocessOnDevice(const uint8_t* points, size_t n_points, uint32_t point_step, uint32_t xyz_offset,
                                float resolution, uint8_t* out, size_t out_capacity);
+
+// ---- building blocks of the batch transcoder (batch_transcoder.cpp) ----
+// One batched stage-1 encode of n clouds that share `info`'s schema, each in its own host buffer: the framed streams
+// ([u32 size][payload] per 32768-point chunk) land back to back in `stage1`; stream_offsets has n + 1 entries,
+// chunk_sizes one payload size per chunk in batch order. Throws std::runtime_error.
+void encodeStage1Batch(const Cloudini::EncodingInfo& info, const uint8_t* const* cloud_ptrs, const uint64_t* cloud_points,
+                       uint32_t n_clouds, std::vector<uint8_t>& stage1, std::vector<uint64_t>& stream_offsets,
+                       std::vector<uint32_t>& chunk_sizes);
+// detail::CompressChunk (src/codec_common.cpp:220-258) and its worst-case output size
+uint32_t compressChunkTo(Cloudini::CompressionOption opt, const uint8_t* src, size_t src_size, uint8_t* dst, size_t dst_cap);
+size_t compressedChunkBound(Cloudini::CompressionOption opt, size_t stage1_bytes);
+// fn(i) for i in [0, n) on the bounded stage-2 pool (the caller takes part)
+void runOnStage2Pool(size_t n, const std::function<void(size_t)>& fn);
 
 // Stage-2 (LZ4/ZSTD) threads per encode()/decode() call, the caller included (bounded worker pool, cloudini.cpp).
 unsigned stage2Threads();

@@ -221,6 +221,18 @@ __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(8, 8
   }
   const uint32_t n_fold = misc[64];
 
+  // folded Palette sections: parameters in (uniform) registers for the read-out
+  uint32_t fs_off[kFastPalFields], fs_bpv[kFastPalFields], fs_count[kFastPalFields], fs_bits[kFastPalFields];
+  const uint8_t* fs_idx[kFastPalFields];
+#pragma unroll
+  for (uint32_t a = 0; a < kFastPalFields; ++a) {
+    const FpSection sct = reinterpret_cast<const FpSection*>(misc + 72)[a < n_fold ? a : 0u];
+    fs_off[a] = sct.field_off;
+    fs_bpv[a] = sct.bpv;
+    fs_count[a] = sct.count;
+    fs_bits[a] = a < n_fold ? sct.bits : 0u;
+    fs_idx[a] = src + (a < n_fold ? sct.index_off : 0u);
+  }
   // which store forms the layout allows (uniform)
   bool contig = ((step | plan.ops[0].offset) & 3u) == 0u;
 #pragma unroll
@@ -265,38 +277,39 @@ __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     bool long_tok = false;
     {
       // end positions of tokens q0*NOPS - 1 ... (q0 + PPT)*NOPS - 1: list slots q0*NOPS ... +PPT*NOPS, 2 bytes each
-      const uint32_t s0 = q0 * NOPS;
-      uint32_t e_prev = pos_list[min(s0, CAP_TOK)];
+      const uint32_t s0 = q0 * NOPS;  // slots s0 .. s0 + kFpPPT * NOPS <= CAP_TOK: inside the list whatever it holds
+      uint32_t e_prev = pos_list[s0];
+      uint32_t irregular = 0u;
 #pragma unroll
       for (uint32_t i = 0; i < kFpPPT; ++i) {
+        const bool have = (q0 + i) < npts;  // points behind the tile's last one: same straight-line code, results dropped
 #pragma unroll
         for (int o = 0; o < NOPS; ++o) {
-          const uint32_t slot = s0 + i * NOPS + (uint32_t)o + 1u;
-          const bool have = (q0 + i) < npts;
-          const uint32_t e = pos_list[min(slot, CAP_TOK)];
-          const uint32_t start = (e_prev + 1u) & 0xffffu;  // byte index in the tile
+          const uint32_t e = pos_list[s0 + i * NOPS + (uint32_t)o + 1u];
+          uint32_t start = (e_prev + 1u) & 0xffffu;  // byte index in the tile
           const uint32_t len = e - start + 1u;
-          int32_t d = 0;
-          if (have) {
-            if (len > 5u) long_tok = true;
-            const uint32_t byte0 = 16u + start;             // byte index in the LDS copy
-            const uint32_t d0 = tile[byte0 >> 2], d1 = tile[(byte0 >> 2) + 1u];
-            const uint64_t raw = (((((uint64_t)d1) << 32) | d0) >> ((byte0 & 3u) * 8u)) &
-                                 (len >= 8u ? ~0ull : ((1ull << (len * 8u)) - 1ull));
-            const uint32_t lo = (uint32_t)raw & 0x7f7f7f7fu;
-            const uint32_t u28 = (lo & 0x7fu) | ((lo >> 1) & 0x3f80u) | ((lo >> 2) & 0x1fc000u) | ((lo >> 3) & 0xfe00000u);
-            const uint64_t u = (uint64_t)u28 | ((uint64_t)((uint32_t)(raw >> 32) & 0x7fu) << 28);
-            if (u == 0ull) {
-              if (len == 1u) mk |= 1u << (i * NOPS + (uint32_t)o);  // the marker byte 0x00
-              else long_tok = true;                                // an overlong zero: decodeVarint rejects it
-            }
-            const uint64_t u1 = u - 1ull;
-            d = (int32_t)((uint32_t)(u1 >> 1) ^ (0u - ((uint32_t)u1 & 1u)));  // low 32 bits: the decoder narrows to int32
-          }
-          dlt[i][o] = d;
+          start = have ? start : 0u;
+          // Tokens of up to 4 bytes (|delta| < 2^27 ticks) are decoded here with 32-bit arithmetic; a longer one
+          // (special values, damaged streams) sends the chunk to k_decode_varint.
+          const uint32_t byte0 = 16u + start;  // byte index in the LDS copy
+          const uint32_t d0 = tile[byte0 >> 2], d1 = tile[(byte0 >> 2) + 1u];
+          const uint32_t w = __builtin_amdgcn_alignbit(d1, d0, (byte0 & 3u) * 8u);  // the 4 bytes at the token's start
+          // bytes of the token: up to and including the first byte whose MSB is clear
+          const uint32_t t = ~w & 0x80808080u;
+          const uint32_t keep = ((t & (0u - t)) << 1) - 1u;  // t == 0 (4 continuation bytes) keeps all four
+          const uint32_t lo = w & keep & 0x7f7f7f7fu;
+          const uint32_t u = (lo & 0x7fu) | (((lo >> 8) & 0x7fu) << 7) | (((lo >> 16) & 0x7fu) << 14) | ((lo >> 24) << 21);
+          const bool zero = u == 0u;
+          // the marker byte 0x00; an overlong zero is something decodeVarint rejects
+          mk |= (have && zero && len == 1u) ? (1u << (i * NOPS + (uint32_t)o)) : 0u;
+          irregular |= (have && (len > 4u || (zero && len != 1u))) ? 1u : 0u;
+          const uint32_t u1 = u - 1u;
+          const int32_t d = (int32_t)((u1 >> 1) ^ (0u - (u1 & 1u)));
+          dlt[i][o] = have ? d : 0;
           e_prev = e;
         }
       }
+      long_tok = irregular != 0u;
     }
     // local sums per lane with NaN resets, then the segmented scan over the threads
     int32_t acc[NOPS];
@@ -421,59 +434,87 @@ __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(8, 8
       }
     }
     __syncthreads();
-    // ---- read-out: consecutive lanes, consecutive points; folded Palette fields complete the point
-#pragma unroll
-    for (uint32_t r = 0; r < kFpPPT; ++r) {
-      const uint32_t q = r * (uint32_t)T + tid;
-      if (q < npts) {
-        const uint32_t p = pts_done + q;  // point of the chunk
-        uint8_t* pt = base + (size_t)p * step;
-        float f[NOPS];
-#pragma unroll
-        for (int o = 0; o < NOPS; ++o) f[o] = stage[q * NOPS + (uint32_t)o];
-        if (contig) {
-          if (NOPS == 3) {
-            FloatVec<3> v;
-            v.v[0] = f[0]; v.v[1] = f[1]; v.v[2] = f[2];
-            *reinterpret_cast<FloatVec<3>*>(pt + foff[0]) = v;
-          } else {
-            FloatVec<4> v;
-#pragma unroll
-            for (int o = 0; o < NOPS; ++o) v.v[o] = f[o];
-            *reinterpret_cast<FloatVec<4>*>(pt + foff[0]) = v;
-          }
-        } else {
-#pragma unroll
-          for (int o = 0; o < NOPS; ++o)
-            if (foff[o] != 0xffffffffu) st_raw(pt + foff[o], __float_as_uint(f[o]), 4);
+    // ---- read-out: consecutive lanes, consecutive points; folded Palette fields complete the point. The layout
+    // decisions are uniform: one switch per tile picks a straight-line variant (the common lidar layouts get code
+    // without a branch per point).
+    auto palette_value = [&](uint32_t a, uint32_t p, uint32_t& v) -> bool {  // folded field a of point p
+      uint32_t idx = 0u;
+      if (fs_bits[a]) {
+        const uint32_t bit = p * fs_bits[a];                       // < 32768 * 10
+        const uint8_t* ib = fs_idx[a] + (bit >> 3);
+        const uint32_t avail = (uint32_t)(src + src_size - ib);    // bytes left in the payload
+        uint32_t w;
+        if (avail >= 8u) {  // two aligned dwords cover byte 0..3 of the window wherever it starts
+          const uint32_t mis = (uint32_t)((uintptr_t)ib & 3u);
+          const uint32_t* iq = reinterpret_cast<const uint32_t*>(ib - mis);
+          w = __builtin_amdgcn_alignbyte(iq[1], iq[0], mis);
+        } else {            // the section's last bytes
+          w = ib[0];
+          if (avail > 1u) w |= (uint32_t)ib[1] << 8;
+          if (avail > 2u) w |= (uint32_t)ib[2] << 16;
         }
-        for (uint32_t a = 0; a < n_fold; ++a) {
-          const FpSection s = reinterpret_cast<const FpSection*>(misc + 72)[a];
-          uint32_t idx = 0u;
-          if (s.bits) {
-            const uint64_t bit = (uint64_t)p * s.bits;
-            const uint8_t* ib = src + s.index_off + (uint32_t)(bit >> 3);
-            // up to 10 + 7 bits: 3 bytes cover it; the section's last bytes are guarded
-            const uint32_t avail = src_size - (s.index_off + (uint32_t)(bit >> 3));
-            uint32_t w;
-            if (avail >= 8u) {  // two aligned dwords cover byte 0..3 of the window wherever it starts
-              const uint32_t mis = (uint32_t)((uintptr_t)ib & 3u);
-              const uint32_t* iq = reinterpret_cast<const uint32_t*>(ib - mis);
-              w = __builtin_amdgcn_alignbyte(iq[1], iq[0], mis);
-            } else {            // the section's last bytes
-              w = ib[0];
-              if (avail > 1u) w |= (uint32_t)ib[1] << 8;
-              if (avail > 2u) w |= (uint32_t)ib[2] << 16;
-            }
-            idx = (w >> ((uint32_t)bit & 7u)) & ((1u << s.bits) - 1u);
-          }
-          if (idx >= s.count) {
-            misc[1] = 1u;  // index beyond the palette: the serial decoder redoes the sections and raises the error
+        idx = (w >> (bit & 7u)) & ((1u << fs_bits[a]) - 1u);
+      }
+      if (idx >= fs_count[a]) {
+        misc[1] = 1u;  // index beyond the palette: the serial decoder redoes the sections and raises the error
+        return false;
+      }
+      v = pal[a * kFastPalEntries + idx];
+      return true;
+    };
+    auto store_floats_contig = [&](uint8_t* pt, uint32_t q) {
+      if (NOPS == 3) {
+        FloatVec<3> v;
+        v.v[0] = stage[q * 3u]; v.v[1] = stage[q * 3u + 1u]; v.v[2] = stage[q * 3u + 2u];
+        *reinterpret_cast<FloatVec<3>*>(pt + foff[0]) = v;
+      } else {
+        FloatVec<4> v;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) v.v[o] = stage[q * 4u + (uint32_t)o];
+        *reinterpret_cast<FloatVec<4>*>(pt + foff[0]) = v;
+      }
+    };
+    const bool one_u16 = contig && n_fold == 1u && fs_bpv[0] == 2u && ((fs_off[0] | step) & 1u) == 0u;  // XYZ(I) + one 16-bit field
+    if (contig && n_fold == 0u) {
+#pragma unroll
+      for (uint32_t r = 0; r < kFpPPT; ++r) {
+        const uint32_t q = r * (uint32_t)T + tid;
+        if (q < npts) store_floats_contig(base + (size_t)(pts_done + q) * step, q);
+      }
+    } else if (one_u16) {
+#pragma unroll
+      for (uint32_t r = 0; r < kFpPPT; ++r) {
+        const uint32_t q = r * (uint32_t)T + tid;
+        if (q < npts) {
+          uint8_t* pt = base + (size_t)(pts_done + q) * step;
+          store_floats_contig(pt, q);
+          uint32_t v;
+          if (palette_value(0u, pts_done + q, v)) *reinterpret_cast<uint16_t*>(pt + fs_off[0]) = (uint16_t)v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (uint32_t r = 0; r < kFpPPT; ++r) {
+        const uint32_t q = r * (uint32_t)T + tid;
+        if (q < npts) {
+          const uint32_t p = pts_done + q;  // point of the chunk
+          uint8_t* pt = base + (size_t)p * step;
+          if (contig) {
+            store_floats_contig(pt, q);
           } else {
-            const uint32_t v = pal[a * kFastPalEntries + idx];
-            if (s.bpv == 2u && ((s.field_off | step) & 1u) == 0u) *reinterpret_cast<uint16_t*>(pt + s.field_off) = (uint16_t)v;
-            else if (s.bpv == 4u && ((s.field_off | step) & 3u) == 0u) *reinterpret_cast<uint32_t*>(pt + s.field_off) = v;
-            else st_raw(pt + s.field_off, v, s.bpv);
+#pragma unroll
+            for (int o = 0; o < NOPS; ++o)
+              if (foff[o] != 0xffffffffu) st_raw(pt + foff[o], __float_as_uint(stage[q * NOPS + (uint32_t)o]), 4);
+          }
+#pragma unroll
+          for (uint32_t a = 0; a < kFastPalFields; ++a) {
+            if (a >= n_fold) break;  // uniform
+            uint32_t v;
+            if (palette_value(a, p, v)) {
+              if (fs_bpv[a] == 2u && ((fs_off[a] | step) & 1u) == 0u) *reinterpret_cast<uint16_t*>(pt + fs_off[a]) = (uint16_t)v;
+              else if (fs_bpv[a] == 4u && ((fs_off[a] | step) & 3u) == 0u) *reinterpret_cast<uint32_t*>(pt + fs_off[a]) = v;
+              else st_raw(pt + fs_off[a], v, fs_bpv[a]);
+            }
           }
         }
       }

@@ -95,6 +95,8 @@ def lib() -> C.CDLL:
     L.cldn_hip_codec_pipeline.restype = C.c_int
     L.cldn_hip_encode_stage1.restype = C.c_int
     L.cldn_hip_encode_stage1.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, vp, C.c_uint64, C.c_int, vp, vp, vp]
+    L.cldn_hip_encode_stage1_gather.restype = C.c_int
+    L.cldn_hip_encode_stage1_gather.argtypes = [vp, C.POINTER(vp), u64p, C.c_uint32, vp, C.c_uint64, C.c_int, vp, vp, vp]
     L.cldn_hip_decode_stage1.restype = C.c_int
     L.cldn_hip_decode_stage1.argtypes = [vp, vp, C.c_int, u64p, u64p, C.c_uint32, vp, C.c_uint64, C.c_int]
     _lib = L

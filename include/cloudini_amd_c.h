@@ -61,6 +61,14 @@ int64_t cldn_amd_ros_decompress(const uint8_t* dds, uint64_t size, uint8_t* out,
 int64_t cldn_amd_viz_preprocess(const cldn_amd_info_t* info, const uint8_t* data, uint64_t size, uint8_t* out,
                                 uint64_t capacity, float* res_out, uint32_t* width_out, uint32_t* height_out);
 
+/* Batch transcoder (include/cloudini_amd/batch_transcoder.hpp): every file of in_dir (one CDR sensor_msgs/PointCloud2
+ * per file, lexicographic order) becomes a CompressedPointCloud2 file of the same name in out_dir, byte-identical to
+ * what cloudini_ros::convertPointCloud2ToCompressedCloud writes for it with resolution `resolution` for the FLOAT32
+ * fields and stage 2 `compression_opt`. stats_out (optional, 8 doubles): messages, points, input bytes, output bytes,
+ * GPU batches, seconds total, seconds in GPU calls, seconds in stage 2 + wrapping. Returns the message count or -1. */
+int64_t cldn_amd_transcode_directory(const char* in_dir, const char* out_dir, float resolution, uint8_t compression_opt,
+                                     int viz_lossy, uint32_t batch_messages, double* stats_out);
+
 /* Stage-2 (LZ4 / ZSTD) threads a single encode()/decode() call with use_threads may occupy, the caller included.
  * The reference's flag means one extra worker (cloudini_lib/src/cloudini.cpp:453-499); here the pool is bounded:
  * default min(4, hardware threads), overridden by the environment variable CLOUDINI_AMD_STAGE2_THREADS (read once)

@@ -105,6 +105,13 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* codec, const void* points, int poin
                            const uint64_t* cloud_points, uint32_t n_clouds, void* out, uint64_t out_capacity,
                            int out_loc, uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes);
 
+/* The same for a batch whose clouds sit in SEPARATE host buffers (the messages of a bag): cloud k is read from
+ * cloud_ptrs[k] (HOST array of HOST pointers, cloud_points[k] * point_step bytes each) and copied straight to its place
+ * in the device batch -- no gathering copy on the host. Everything else as in cldn_hip_encode_stage1. */
+int cldn_hip_encode_stage1_gather(cldn_hip_codec_t* codec, const void* const* cloud_ptrs, const uint64_t* cloud_points,
+                                  uint32_t n_clouds, void* out, uint64_t out_capacity, int out_loc,
+                                  uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes);
+
 /* Continuation of one cloud across several calls / devices. The reference commits the adaptive-int modes once per
  * encode() call, on the first <= 4096 points of the cloud (src/v5_codec.cpp:934-949), and resets every other
  * state at each 32768-point chunk (:910-915). A range of whole chunks of a cloud can therefore be encoded on

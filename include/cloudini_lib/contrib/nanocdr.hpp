@@ -130,6 +130,11 @@ class Encoder {
     wide_align_ = header_.version == CdrVersion::XCDRv2 ? 4 : 8;
   }
   explicit Encoder(CdrHeader header) : Encoder(header, own_) {}
+  // continue a message whose first part (encapsulation header included) is already in `storage`
+  Encoder(CdrHeader header, std::vector<uint8_t>& storage, bool append) : header_(header), out_(&storage) {
+    if (!append || storage.size() < 4) throw std::runtime_error("nanocdr::Encoder: nothing to append to");
+    wide_align_ = header_.version == CdrVersion::XCDRv2 ? 4 : 8;
+  }
 
   const CdrHeader& header() const { return header_; }
   ConstBuffer encodedBuffer() const { return ConstBuffer(out_->data(), out_->size()); }

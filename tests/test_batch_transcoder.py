@@ -1,0 +1,86 @@
+"""Batch transcoder (include/cloudini_amd/batch_transcoder.hpp): a directory of CDR PointCloud2 messages through ONE
+batched GPU encode per schema run, stage 2 on the host pool, CDR wrapping -- every output message byte-identical to
+cloudini_ros::convertPointCloud2ToCompressedCloud of the compiled reference (src/ros_msg_utils.cpp:167-213), which is
+what the reference's converter loop (tools/src/mcap_converter.cpp:170-222) writes message by message."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cloudini_amd import api, synth
+from cloudini_amd.schema import CompressionOption
+from test_host_api import _cdr_pointcloud2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_messages(folder, messages):
+    os.makedirs(folder, exist_ok=True)
+    for k, m in enumerate(messages):
+        m.tofile(os.path.join(folder, f"msg_{k:05d}.bin"))
+
+
+def _mixed_messages():
+    msgs = []
+    for k, n in enumerate([40000, 1, 70000, 0, 32768, 5000]):
+        info, data = synth.lidar_xyzi(n, seed=10 + k)
+        msgs.append(_cdr_pointcloud2(info, data, stamp=(1700000000 + k, 1000 * k)))
+    info, data = synth.velodyne_xyzir(130048, seed=3)        # another schema in the middle of the bag
+    msgs.append(_cdr_pointcloud2(info, data, frame_id="velodyne"))
+    for k, n in enumerate([20000, 33000]):
+        info, data = synth.lidar_xyzi(n, seed=50 + k)
+        msgs.append(_cdr_pointcloud2(info, data, is_dense=False))
+    info, data = synth.lidar_xyz(9000, seed=77)
+    msgs.append(_cdr_pointcloud2(info, data))
+    return msgs
+
+
+@pytest.mark.parametrize("comp", [CompressionOption.ZSTD, CompressionOption.LZ4, CompressionOption.NONE])
+def test_every_message_equals_the_reference_converter(tmp_path, reflib, comp):
+    msgs = _mixed_messages()
+    src, dst = str(tmp_path / "in"), str(tmp_path / "out")
+    _write_messages(src, msgs)
+    stats = api.transcode_directory(src, dst, resolution=0.001, compression_opt=int(comp), batch_messages=4)
+    assert int(stats["messages"]) == len(msgs)
+    assert int(stats["gpu_batches"]) >= 3  # 3 batches of 4 at least, more where the schema changes inside a batch
+    for k, m in enumerate(msgs):
+        got = np.fromfile(os.path.join(dst, f"msg_{k:05d}.bin"), dtype=np.uint8)
+        want = reflib.ros_compress(m, 0.001, int(comp))
+        assert got.size == want.size and np.array_equal(got, want), f"message {k}"
+    # and the per-message path of the host mirror writes the same bytes
+    assert np.array_equal(np.fromfile(os.path.join(dst, "msg_00002.bin"), dtype=np.uint8), api.ros_compress(msgs[2], 0.001, int(comp)))
+
+
+def test_c4_shape_in_one_command(tmp_path, reflib):
+    """BASELINE configs[3] end to end with the command-line tool: Velodyne-style XYZI+ring clouds of 130048 points, ZSTD
+    second stage (64 messages here; tools/transcode_c4.py runs all 256)."""
+    distinct = [synth.velodyne_xyzir(130048, seed=42 + k) for k in range(4)]
+    msgs = [_cdr_pointcloud2(distinct[k % 4][0], distinct[k % 4][1], stamp=(1700000000, k)) for k in range(64)]
+    src, dst = str(tmp_path / "in"), str(tmp_path / "out")
+    _write_messages(src, msgs)
+    exe = os.path.join(ROOT, "cloudini_amd", "lib", "cloudini_batch_transcode")
+    r = subprocess.run([exe, src, dst, "--resolution", "0.001", "--compression", "zstd", "--batch", "32"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    st = json.loads(r.stdout.strip().splitlines()[-1])
+    assert st["messages"] == 64 and st["gpu_batches"] == 2 and st["points"] == 64 * 130048
+    for k in (0, 1, 2, 3, 37, 63):
+        got = np.fromfile(os.path.join(dst, f"msg_{k:05d}.bin"), dtype=np.uint8)
+        assert np.array_equal(got, reflib.ros_compress(msgs[k], 0.001, int(CompressionOption.ZSTD))), k
+
+
+def test_viz_prefilter_in_the_batch(tmp_path):
+    info, data = synth.lidar_xyzi(60000, seed=5)
+    pts = data.reshape(-1, 16).copy()
+    pts[::7, 0:4] = np.frombuffer(np.float32(np.nan).tobytes(), dtype=np.uint8)   # NaN x in every 7th point
+    msgs = [_cdr_pointcloud2(info, pts.reshape(-1))] * 3
+    src, dst = str(tmp_path / "in"), str(tmp_path / "out")
+    _write_messages(src, msgs)
+    stats = api.transcode_directory(src, dst, resolution=0.01, compression_opt=int(CompressionOption.ZSTD), viz_lossy=True)
+    assert int(stats["messages"]) == 3 and 0 < stats["points"] < 3 * (60000 - 60000 // 7)
+    out = np.fromfile(os.path.join(dst, "msg_00000.bin"), dtype=np.uint8)
+    back = api.ros_decompress(out, msgs[0].size)
+    assert back.size < msgs[0].size  # fewer points come back than went in

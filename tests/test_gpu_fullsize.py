@@ -71,3 +71,29 @@ def test_c4_batch_of_256_clouds(oracle):
         _roundtrip_tolerance(info, clouds[k], decoded[k])
     assert np.array_equal(decoded[200], decoded[200 % 4])
     codec.close()
+
+
+FULL = {"c1": lambda: synth.lidar_xyz(65536), "c2": lambda: synth.lidar_xyzi(1_000_000),
+        "c3": lambda: synth.depthcam_xyzrgba(1280, 800), "c4": lambda: synth.velodyne_xyzir(130048),
+        "c5": lambda: synth.lidar_xyz(10_000_000)}
+
+
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_full_size_configs_match_the_reference_itself(reflib, name):
+    """BASELINE configs at full size against the compiled reference (oracle/_ref travels with the repository), not via
+    the oracle: the framed stage-1 stream the HIP codec produces must be the bytes PointcloudEncoder::encode writes after
+    its header with CompressionOption::NONE, and the HIP decode of that stream must be the reference's decode."""
+    from cloudini_amd import native
+    info, data = FULL[name]()
+    n = data.size // info.point_step
+    codec = native.Codec(native.Plan(info))
+    want = reflib.encode_stage1(info, data)
+    for mode in (2, 1):  # piece kernel (where the schema allows it) and tile kernel
+        codec.pipeline(mode)
+        got = codec.encode_host([data])[0][0]
+        assert len(got) == len(want) and np.array_equal(got, want), (name, mode)
+    full = reflib.encode(info, data)
+    ref_dec, _yaml = reflib.decode(full, data.size, fill=0x3C)
+    out = np.full(data.size, 0x3C, dtype=np.uint8)
+    assert np.array_equal(codec.decode_host([want], [n], out=out)[0], ref_dec)
+    codec.close()

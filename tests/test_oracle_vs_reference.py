@@ -153,3 +153,19 @@ def test_decoder_hardening_matches_the_reference_on_damaged_streams(oracle, refl
             assert np.array_equal(a, b), seed
         agree += 1
     assert agree == 240
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+def test_full_size_baseline_configs_match_reference(oracle, reflib, name):
+    """The oracle against the reference at BASELINE.json's FULL sizes (the cases above use reduced clouds): C2 1M-pt
+    XYZI, C3 1280x800 XYZRGBA with NaN pixels, C4 130048-pt packed XYZI+ring, C5 10M-pt XYZ. Encode bytes and decoded
+    bytes."""
+    from cloudini_amd import synth
+    info, data = {"c2": lambda: synth.lidar_xyzi(1_000_000), "c3": lambda: synth.depthcam_xyzrgba(1280, 800),
+                  "c4": lambda: synth.velodyne_xyzir(130048), "c5": lambda: synth.lidar_xyz(10_000_000)}[name]()
+    n = len(data) // info.point_step
+    want = reflib.encode_stage1(info, data)
+    got = oracle.encode_stage1(info, data)
+    assert len(got) == len(want) and np.array_equal(got, want)
+    ref_dec, _yaml = reflib.decode(reflib.encode(info, data), len(data), fill=0x5A)
+    assert np.array_equal(oracle.decode_stage1(info, want, n, fill=0x5A), ref_dec)

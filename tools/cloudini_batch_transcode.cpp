@@ -1,0 +1,45 @@
+// cloudini_batch_transcode: directory of CDR sensor_msgs/PointCloud2 messages -> directory of CompressedPointCloud2
+// messages, through the batched HIP encoder (include/cloudini_amd/batch_transcoder.hpp). The batched counterpart of the
+// reference's cloudini_rosbag_converter encode loop (tools/src/mcap_converter.cpp:140-222) for containers that are
+// plain directories.
+//   cloudini_batch_transcode <in_dir> <out_dir> [--resolution 0.001] [--compression none|lz4|zstd] [--viz] [--batch 64]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "cloudini_amd/batch_transcoder.hpp"
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    std::fprintf(stderr, "usage: %s <in_dir> <out_dir> [--resolution r] [--compression none|lz4|zstd] [--viz] [--batch n]\n", argv[0]);
+    return 2;
+  }
+  cloudini_amd::TranscodeOptions opt;
+  for (int i = 3; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a == "--resolution" && i + 1 < argc) opt.default_resolution = std::strtof(argv[++i], nullptr);
+    else if (a == "--compression" && i + 1 < argc) opt.compression = Cloudini::CompressionOptionFromString(
+        std::string(argv[i + 1]) == "none" ? "NONE" : (std::string(argv[i + 1]) == "lz4" ? "LZ4" : "ZSTD")), ++i;
+    else if (a == "--viz") opt.viz_lossy = true;
+    else if (a == "--batch" && i + 1 < argc) opt.batch_messages = (size_t)std::strtoul(argv[++i], nullptr, 10);
+    else {
+      std::fprintf(stderr, "unknown argument %s\n", a.c_str());
+      return 2;
+    }
+  }
+  try {
+    cloudini_amd::DirectorySource source(argv[1]);
+    cloudini_amd::DirectorySink sink(argv[2]);
+    const cloudini_amd::TranscodeStats st = cloudini_amd::transcodePointClouds(source, sink, opt);
+    std::printf("{\"messages\": %llu, \"points\": %llu, \"input_bytes\": %llu, \"output_bytes\": %llu, \"gpu_batches\": %llu, "
+                "\"seconds_total\": %.6f, \"seconds_gpu\": %.6f, \"seconds_stage2\": %.6f, \"Mpoints_per_s\": %.1f}\n",
+                (unsigned long long)st.messages, (unsigned long long)st.points, (unsigned long long)st.input_bytes,
+                (unsigned long long)st.output_bytes, (unsigned long long)st.gpu_batches, st.seconds_total, st.seconds_gpu,
+                st.seconds_stage2, st.seconds_total > 0 ? st.points / st.seconds_total / 1e6 : 0.0);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "cloudini_batch_transcode: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -8,7 +8,12 @@ import torch
 from cloudini_amd import native, synth
 
 dev = torch.device("cuda", 0)
-for name, (info, data), n_clouds in (("c5 xyz 10M", synth.lidar_xyz(10_000_000), 1), ("c2 xyzi 32x1M", synth.lidar_xyzi(1_000_000), 32)):
+only = sys.argv[1] if len(sys.argv) > 1 else ""
+cases = (("c5 xyz 10M", lambda: synth.lidar_xyz(10_000_000), 1), ("c2 xyzi 32x1M", lambda: synth.lidar_xyzi(1_000_000), 32))
+for name, make, n_clouds in cases:
+    if only and not name.startswith(only):
+        continue
+    info, data = make()
     plan = native.Plan(info)
     codec = native.Codec(plan, device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
     step = info.point_step
@@ -23,15 +28,18 @@ for name, (info, data), n_clouds in (("c5 xyz 10M", synth.lidar_xyz(10_000_000),
     torch.cuda.synchronize()
     offs = d_off.cpu().numpy().astype(np.uint64)
     d_dec = torch.zeros(host.size, dtype=torch.uint8, device=dev)
-    for it in range(3):
+    for it in range(5):
         codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    reps = 5
-    for it in range(reps):
-        codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    ts = []
+    for blk in range(7):
+        t0 = time.perf_counter()
+        reps = 10
+        for it in range(reps):
+            codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / reps)
+    dt = float(np.median(ts))
     codec.status()
-    print(f"{name}: decode {dt*1e3:.3f} ms -> {n*n_clouds/dt/1e6:.0f} Mpoints/s, stream {int(offs[-1])/1e6:.1f} MB")
+    print(f"{name}: decode median {dt*1e3:.3f} ms (min {min(ts)*1e3:.3f}, max {max(ts)*1e3:.3f}) -> {n*n_clouds/dt/1e6:.0f} Mpoints/s, stream {int(offs[-1])/1e6:.1f} MB, stats {codec.decode_stats()}")
     codec.close()
