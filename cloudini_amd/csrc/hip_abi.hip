@@ -169,6 +169,7 @@ struct cldn_hip_codec {
   std::vector<hipEvent_t> gtime;        // timing: 16 per slot
   std::vector<uint32_t> slot_groups;    // groups of the call timed in the slot (0 / 1 = not pipelined)
   int groups_override = -1;             // CLDN_HIP_GROUPS
+  uint64_t pending_total = 0;  // bytes of a deferred host output waiting in d_out (cldn_hip_codec_fetch_output)
   int pipeline = 0;           // cldn_hip_codec_pipeline: 0 auto, 1 tile kernel + slots, 2 pieces + slots, 3 single pass
   bool bitmaps_dirty = true;  // set after an aborted call: the kernel only clears the bitmaps of calls that finish
   DevBuf d_viz_keys, d_viz_first, d_viz_slot, d_viz_blocks, d_viz_total;  // applyVizLossyPreprocessing workspace
@@ -205,6 +206,18 @@ int cldn_hip_device_count(void) {
   if (e == hipErrorNoDevice) return 0;
   if (e != hipSuccess) return fail(CLDN_HIP_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
   return n;
+}
+
+void* cldn_hip_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void cldn_hip_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int cldn_hip_current_device(void) {
@@ -676,10 +689,14 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   // capacity contract of PointcloudEncoder::encode (cloudini.cpp:531-534)
   uint64_t need = 0;
   for (uint32_t k = 0; k < n_clouds; ++k) need += cldn_hip_stage1_bound(&c->plan, cloud_points[k]);
+  // two-step host output (cldn_hip_codec_fetch_output): no caller buffer yet, the codec's own device buffer takes the bound
+  const bool deferred = out == nullptr && out_loc == CLDN_HIP_HOST;
+  if (deferred) out_capacity = need;
   if (out_capacity < need)
     return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for worst-case compressed size (%llu < %llu)",
                 (unsigned long long)out_capacity, (unsigned long long)need);
-  if (need && !out) return fail(CLDN_HIP_ERR_ARG, "out is NULL");
+  if (need && !out && !deferred) return fail(CLDN_HIP_ERR_ARG, "out is NULL");
+  c->pending_total = 0;
 
   const uint32_t n_adaptive = plan.n_adaptive;
   // Sub-chunks: the regular stream of a chunk is produced as `subs` independent sub-streams (one workgroup each)
@@ -958,7 +975,8 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   if (*h_status & ST_OUT_OVERFLOW)
     return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for uncompressed chunk");  // chunk_writer.cpp:34-36
   const uint64_t total = h_off[n_clouds];
-  if (total) HIP_TRY(hipMemcpyAsync(out, d_outp, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+  if (deferred) c->pending_total = total;
+  else if (total) HIP_TRY(hipMemcpyAsync(out, d_outp, (size_t)total, hipMemcpyDeviceToHost, c->stream));
   if (chunk_sizes && n_chunks)
     HIP_TRY(hipMemcpyAsync(chunk_sizes, c->d_payload.p, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost,
                            c->stream));
@@ -1055,6 +1073,20 @@ int cldn_hip_codec_decode_stats(cldn_hip_codec_t* c, uint32_t stats[4]) {
   HIP_TRY(hipMemcpyAsync(stats, (const uint32_t*)c->d_status.p + 8, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost,
                          c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return CLDN_HIP_OK;
+}
+
+int cldn_hip_codec_fetch_output(cldn_hip_codec_t* c, void* out, uint64_t out_capacity) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if (out_capacity < c->pending_total)
+    return fail(CLDN_HIP_ERR_CAPACITY, "fetch_output: %llu bytes are waiting, the buffer holds %llu",
+                (unsigned long long)c->pending_total, (unsigned long long)out_capacity);
+  if (c->pending_total == 0) return CLDN_HIP_OK;
+  if (!out) return fail(CLDN_HIP_ERR_ARG, "out is NULL");
+  ENTER_DEVICE(c->device);
+  HIP_TRY(hipMemcpyAsync(out, c->d_out.p, (size_t)c->pending_total, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->pending_total = 0;
   return CLDN_HIP_OK;
 }
 

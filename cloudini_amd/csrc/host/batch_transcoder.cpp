@@ -10,6 +10,7 @@
 #include <deque>
 #include <dirent.h>
 #include <fstream>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <stdexcept>
@@ -123,16 +124,33 @@ void DirectorySink::write(const std::string& name, const uint8_t* data, size_t s
     throw std::runtime_error("cannot write " + dir_ + "/" + name);
 }
 
-// ---- one batch ------------------------------------------------------------------------------------------------
+// ---- one batch: GPU phase, then stage-2 phase ---------------------------------------------------------------------
 
-void transcodeBatch(const std::vector<Message>& in, const TranscodeOptions& opt, std::vector<std::vector<uint8_t>>& out,
-                    TranscodeStats* stats) {
-  const size_t n = in.size();
-  out.assign(n, {});
-  std::vector<Parsed> parsed(n);
-  for (size_t i = 0; i < n; ++i) {  // the front of the reference's loop, message by message (mcap_converter.cpp:187-203)
-    Parsed& p = parsed[i];
-    p.pc = cloudini_ros::getDeserializedPointCloudMessage(Cloudini::ConstBufferView(in[i].bytes.data(), in[i].bytes.size()));
+namespace {
+
+struct Run {                       // messages [first, first + count) share a schema: one GPU call
+  size_t first = 0;
+  uint32_t count = 0;
+  PinnedBytes stage1;              // framed stage-1 streams of the run, page-locked (the GPU copies into it)
+  std::vector<uint64_t> offsets;   // count + 1
+  std::vector<uint32_t> chunk_sizes;
+};
+
+struct Batch {
+  std::vector<Message> in;
+  std::vector<Parsed> parsed;
+  std::vector<Run> runs;
+  std::vector<std::vector<uint8_t>> out;
+};
+
+// the front of the reference's loop message by message (mcap_converter.cpp:187-203), then one GPU call per schema run
+void gpuPhase(Batch& b, const TranscodeOptions& opt, TranscodeStats* stats) {
+  const size_t n = b.in.size();
+  b.parsed.assign(n, Parsed());
+  b.out.assign(n, {});
+  for (size_t i = 0; i < n; ++i) {
+    Parsed& p = b.parsed[i];
+    p.pc = cloudini_ros::getDeserializedPointCloudMessage(Cloudini::ConstBufferView(b.in[i].bytes.data(), b.in[i].bytes.size()));
     cloudini_ros::applyResolutionProfile(opt.profile, p.pc.fields, opt.default_resolution);
     if (opt.viz_lossy) cloudini_ros::applyVizLossyPreprocessing(p.pc);
     p.info = cloudini_ros::toEncodingInfo(p.pc);
@@ -142,67 +160,78 @@ void transcodeBatch(const std::vector<Message>& in, const TranscodeOptions& opt,
     if (stats) {
       stats->messages += 1;
       stats->points += p.points;
-      stats->input_bytes += in[i].bytes.size();
+      stats->input_bytes += b.in[i].bytes.size();
     }
   }
-
-  std::vector<uint8_t> stage1;
-  std::vector<uint64_t> offsets;
-  std::vector<uint32_t> chunk_sizes;
-  for (size_t r0 = 0; r0 < n;) {  // runs of messages that share a schema: one GPU call each
+  size_t n_runs = 0;
+  for (size_t r0 = 0; r0 < n;) {
     size_t r1 = r0 + 1;
-    while (r1 < n && parsed[r1].key == parsed[r0].key) ++r1;
-    const uint32_t m = static_cast<uint32_t>(r1 - r0);
-    const Cloudini::EncodingInfo& info0 = parsed[r0].info;
+    while (r1 < n && b.parsed[r1].key == b.parsed[r0].key) ++r1;
+    if (b.runs.size() <= n_runs) b.runs.emplace_back();  // recycled batches keep their page-locked staging
+    Run& run = b.runs[n_runs++];
+    run.first = r0;
+    run.count = static_cast<uint32_t>(r1 - r0);
+    const Cloudini::EncodingInfo& info0 = b.parsed[r0].info;
     if (info0.point_step == 0) throw std::runtime_error("convertPointCloud2ToCompressedCloud: point_step cannot be 0");
-
-    std::vector<const uint8_t*> ptrs(m);
-    std::vector<uint64_t> pts(m);
-    for (uint32_t k = 0; k < m; ++k) {
-      ptrs[k] = parsed[r0 + k].pc.data.data();
-      pts[k] = parsed[r0 + k].points;
+    std::vector<const uint8_t*> ptrs(run.count);
+    std::vector<uint64_t> pts(run.count);
+    for (uint32_t k = 0; k < run.count; ++k) {
+      ptrs[k] = b.parsed[r0 + k].pc.data.data();
+      pts[k] = b.parsed[r0 + k].points;
     }
     const auto t_gpu = Clock::now();
-    Cloudini::amd_detail::encodeStage1Batch(info0, ptrs.data(), pts.data(), m, stage1, offsets, chunk_sizes);
+    Cloudini::amd_detail::encodeStage1Batch(
+        info0, ptrs.data(), pts.data(), run.count,
+        [&](uint64_t bytes) {  // the exact size, not the 50-bytes-per-point bound; recycled batches keep the capacity
+          if (run.stage1.size() < bytes) run.stage1.resize(bytes + bytes / 8);
+          return run.stage1.data();
+        },
+        run.offsets, run.chunk_sizes);
     if (stats) {
       stats->seconds_gpu += since(t_gpu);
       stats->gpu_batches += 1;
     }
+    r0 = r1;
+  }
+  b.runs.resize(n_runs);
+}
 
-    // stage 2: every chunk of the run is an independent job; each message owns a worst-case slot range of its own
-    // output vector, so the jobs write in place and only a compaction inside the message remains
-    const auto t_s2 = Clock::now();
-    struct Job {
-      uint32_t msg;        // index in the run
-      const uint8_t* src;  // stage-1 payload
-      uint32_t src_size;
-      size_t slot;         // offset of the job's worst-case slot inside the message's scratch area
-      uint32_t packed = 0;
-    };
-    std::vector<Job> jobs;
-    std::vector<size_t> first_job(m + 1, 0), scratch_at(m), payload_at(m), length_at(m);
-    std::vector<std::vector<uint8_t>> header(m);
-    const bool direct = opt.compression == Cloudini::CompressionOption::NONE;
+// stage 2 of every chunk of the batch on the host pool + CDR wrapping (src/ros_msg_utils.cpp:167-213)
+void stage2Phase(Batch& b, const TranscodeOptions& opt, TranscodeStats* stats) {
+  const auto t_s2 = Clock::now();
+  const bool direct = opt.compression == Cloudini::CompressionOption::NONE;
+  struct Job {
+    size_t msg;          // index in the batch
+    const uint8_t* src;  // stage-1 payload
+    uint32_t src_size;
+    size_t slot;         // offset of the job's worst-case slot inside the message's scratch area
+    uint32_t packed = 0;
+  };
+  const size_t n = b.in.size();
+  std::vector<Job> jobs;
+  std::vector<size_t> first_job(n + 1, 0), scratch_at(n, 0), payload_at(n, 0), length_at(n, 0);
+  std::vector<uint8_t> header;
+  for (const Run& run : b.runs) {
     size_t chunk_index = 0;
-    for (uint32_t k = 0; k < m; ++k) {
-      const Parsed& p = parsed[r0 + k];
-      std::vector<uint8_t>& msg = out[r0 + k];
+    for (uint32_t k = 0; k < run.count; ++k) {
+      const size_t i = run.first + k;
+      const Parsed& p = b.parsed[i];
+      std::vector<uint8_t>& msg = b.out[i];
       nanocdr::Encoder enc(p.pc.cdr_header, msg);
       cloudini_ros::writePointCloudHeader(enc, p.pc);
-      length_at[k] = msg.size();
+      length_at[i] = msg.size();  // patched once the encoded size is known
       enc.encode(static_cast<uint32_t>(0));
-      payload_at[k] = msg.size();
-      first_job[k] = jobs.size();
+      payload_at[i] = msg.size();
+      first_job[i] = jobs.size();
       if (p.pc.data.size() == 0) continue;  // empty cloud: no Cloudini header either (ros_msg_utils.cpp:178-183)
-      Cloudini::EncodeHeader(p.info, header[k]);
-      size_t need = header[k].size();
+      Cloudini::EncodeHeader(p.info, header);
       const uint64_t n_chunks = (p.points + 32767) / 32768;
-      const uint8_t* s = stage1.data() + offsets[k];
+      const uint8_t* s = run.stage1.data() + run.offsets[k];
       size_t slot = 0;
       for (uint64_t c = 0; c < n_chunks; ++c) {
-        const uint32_t size = chunk_sizes[chunk_index + c];
+        const uint32_t size = run.chunk_sizes[chunk_index + c];
         Job j;
-        j.msg = k;
+        j.msg = i;
         j.src = s + 4;
         j.src_size = size;
         j.slot = slot;
@@ -211,111 +240,157 @@ void transcodeBatch(const std::vector<Message>& in, const TranscodeOptions& opt,
         s += 4 + size;
       }
       chunk_index += n_chunks;
-      need += slot;
-      scratch_at[k] = payload_at[k] + header[k].size();
-      msg.resize(payload_at[k] + need);
-      std::memcpy(msg.data() + payload_at[k], header[k].data(), header[k].size());
+      scratch_at[i] = payload_at[i] + header.size();
+      msg.resize(scratch_at[i] + slot);
+      std::memcpy(msg.data() + payload_at[i], header.data(), header.size());
     }
-    first_job[m] = jobs.size();
-    Cloudini::amd_detail::runOnStage2Pool(jobs.size(), [&](size_t ji) {
-      Job& j = jobs[ji];
-      uint8_t* dst = out[r0 + j.msg].data() + scratch_at[j.msg] + j.slot;
-      if (direct) {
-        std::memcpy(dst + 4, j.src, j.src_size);
-        j.packed = j.src_size;
-      } else {
-        j.packed = Cloudini::amd_detail::compressChunkTo(opt.compression, j.src, j.src_size, dst + 4,
-                                                         Cloudini::amd_detail::compressedChunkBound(opt.compression, j.src_size));
-      }
-      std::memcpy(dst, &j.packed, 4);
-    });
-    // close the gaps between a message's chunks, patch the length, finish the CDR message
-    for (uint32_t k = 0; k < m; ++k) {
-      const Parsed& p = parsed[r0 + k];
-      std::vector<uint8_t>& msg = out[r0 + k];
-      size_t end = payload_at[k];
-      if (p.pc.data.size() != 0) {
-        end = scratch_at[k];
-        for (size_t ji = first_job[k]; ji < first_job[k + 1]; ++ji) {
-          const Job& j = jobs[ji];
-          uint8_t* from = msg.data() + scratch_at[k] + j.slot;
-          if (from != msg.data() + end) std::memmove(msg.data() + end, from, 4u + j.packed);
-          end += 4u + j.packed;
-        }
-      }
-      const uint32_t encoded32 = static_cast<uint32_t>(end - payload_at[k]);
-      std::memcpy(msg.data() + length_at[k], &encoded32, 4);
-      msg.resize(end);
-      nanocdr::Encoder tail(p.pc.cdr_header, msg, /*append=*/true);
-      tail.encode(p.pc.is_dense);
-      tail.encode(std::string("cloudini"));  // CompressedPointCloud2::format
-      if (stats) stats->output_bytes += msg.size();
-    }
-    if (stats) stats->seconds_stage2 += since(t_s2);
-    r0 = r1;
   }
+  first_job[n] = jobs.size();  // messages were visited in batch order (runs are consecutive ranges): the table is monotone
+  Cloudini::amd_detail::runOnStage2Pool(jobs.size(), [&](size_t ji) {
+    Job& j = jobs[ji];
+    uint8_t* dst = b.out[j.msg].data() + scratch_at[j.msg] + j.slot;
+    if (direct) {
+      std::memcpy(dst + 4, j.src, j.src_size);
+      j.packed = j.src_size;
+    } else {
+      j.packed = Cloudini::amd_detail::compressChunkTo(opt.compression, j.src, j.src_size, dst + 4,
+                                                       Cloudini::amd_detail::compressedChunkBound(opt.compression, j.src_size));
+    }
+    std::memcpy(dst, &j.packed, 4);
+  });
+  // close the gaps between a message's chunks, patch the length, finish the CDR message
+  for (size_t i = 0; i < n; ++i) {
+    const Parsed& p = b.parsed[i];
+    std::vector<uint8_t>& msg = b.out[i];
+    size_t end = payload_at[i];
+    if (p.pc.data.size() != 0) {
+      end = scratch_at[i];
+      for (size_t ji = first_job[i]; ji < first_job[i + 1]; ++ji) {
+        const Job& j = jobs[ji];
+        uint8_t* from = msg.data() + scratch_at[i] + j.slot;
+        if (from != msg.data() + end) std::memmove(msg.data() + end, from, 4u + j.packed);
+        end += 4u + j.packed;
+      }
+    }
+    const uint32_t encoded32 = static_cast<uint32_t>(end - payload_at[i]);
+    std::memcpy(msg.data() + length_at[i], &encoded32, 4);
+    msg.resize(end);
+    nanocdr::Encoder tail(p.pc.cdr_header, msg, /*append=*/true);
+    tail.encode(p.pc.is_dense);
+    tail.encode(std::string("cloudini"));  // CompressedPointCloud2::format
+    if (stats) stats->output_bytes += msg.size();
+  }
+  if (stats) stats->seconds_stage2 += since(t_s2);
 }
 
-// ---- the pipeline ---------------------------------------------------------------------------------------------
+}  // namespace
+
+void transcodeBatch(const std::vector<Message>& in, const TranscodeOptions& opt, std::vector<std::vector<uint8_t>>& out,
+                    TranscodeStats* stats) {
+  Batch b;
+  b.in.resize(in.size());
+  for (size_t i = 0; i < in.size(); ++i) {
+    b.in[i].name = in[i].name;
+    b.in[i].bytes.assign(in[i].bytes.begin(), in[i].bytes.end());
+  }
+  gpuPhase(b, opt, stats);
+  stage2Phase(b, opt, stats);
+  out = std::move(b.out);
+}
+
+// ---- the pipeline: reader -> GPU (this thread) -> stage 2 -> writer; batches circulate (page-locked buffers are reused) ---
 
 TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, const TranscodeOptions& opt) {
-  TranscodeStats stats;
+  TranscodeStats stats, stats2;
   const auto t0 = Clock::now();
-  struct Batch {
-    std::vector<Message> in;
-    std::vector<std::vector<uint8_t>> out;
-  };
-  BoundedQueue<Batch> to_encode(2), to_write(2);
-  std::exception_ptr reader_error, writer_error;
+  constexpr size_t kBatchesInFlight = 3;
+  std::vector<std::unique_ptr<Batch>> storage;
+  for (size_t i = 0; i < kBatchesInFlight; ++i) storage.emplace_back(new Batch());
+  BoundedQueue<Batch*> free_q(kBatchesInFlight), to_gpu(kBatchesInFlight), to_stage2(kBatchesInFlight), to_write(kBatchesInFlight);
+  for (auto& b : storage) free_q.push(b.get());
+  std::exception_ptr reader_error, stage2_error, writer_error, gpu_error;
   const size_t batch = std::max<size_t>(1, opt.batch_messages);
 
   std::thread reader([&] {
     try {
-      Batch b;
-      Message msg;
-      while (source.next(msg)) {
-        b.in.push_back(std::move(msg));
-        if (b.in.size() == batch) {
-          to_encode.push(std::move(b));
-          b = Batch();
+      Batch* b = nullptr;
+      size_t used = 0;
+      for (;;) {
+        if (!b) {
+          if (!free_q.pop(b)) break;
+          used = 0;
+        }
+        if (b->in.size() <= used) b->in.emplace_back();
+        if (!source.next(b->in[used])) break;  // the source refills the Message (and reuses its page-locked capacity)
+        if (++used == batch) {
+          b->in.resize(used);
+          to_gpu.push(b);
+          b = nullptr;
         }
       }
-      if (!b.in.empty()) to_encode.push(std::move(b));
+      if (b && used) {
+        b->in.resize(used);
+        to_gpu.push(b);
+      }
     } catch (...) {
       reader_error = std::current_exception();
     }
-    to_encode.close();
+    to_gpu.close();
+  });
+  std::thread stage2([&] {
+    Batch* b = nullptr;
+    while (to_stage2.pop(b)) {
+      if (!stage2_error) {
+        try {
+          stage2Phase(*b, opt, &stats2);
+        } catch (...) {
+          stage2_error = std::current_exception();
+        }
+      }
+      to_write.push(b);
+    }
+    to_write.close();
   });
   std::thread writer([&] {
-    Batch b;
+    Batch* b = nullptr;
     while (to_write.pop(b)) {
-      if (writer_error) continue;  // keep draining so the encoder never blocks
-      try {
-        for (size_t i = 0; i < b.in.size(); ++i) sink.write(b.in[i].name, b.out[i].data(), b.out[i].size());
-      } catch (...) {
-        writer_error = std::current_exception();
+      if (!writer_error && !stage2_error) {
+        try {
+          for (size_t i = 0; i < b->in.size(); ++i) sink.write(b->in[i].name, b->out[i].data(), b->out[i].size());
+        } catch (...) {
+          writer_error = std::current_exception();
+        }
       }
+      free_q.push(b);  // back to the reader
     }
   });
 
-  std::exception_ptr encode_error;
-  Batch b;
-  while (to_encode.pop(b)) {
-    if (encode_error) continue;
-    try {
-      transcodeBatch(b.in, opt, b.out, &stats);
-      to_write.push(std::move(b));
-      b = Batch();
-    } catch (...) {
-      encode_error = std::current_exception();
+  Batch* b = nullptr;
+  while (to_gpu.pop(b)) {
+    if (!gpu_error) {
+      try {
+        gpuPhase(*b, opt, &stats);
+      } catch (...) {
+        gpu_error = std::current_exception();
+      }
     }
+    if (gpu_error) {
+      free_q.push(b);
+      continue;
+    }
+    to_stage2.push(b);
   }
-  to_write.close();
-  reader.join();
+  to_stage2.close();
+  stage2.join();
   writer.join();
-  if (encode_error) std::rethrow_exception(encode_error);
+  free_q.close();
+  reader.join();
+  if (gpu_error) std::rethrow_exception(gpu_error);
+  if (stage2_error) std::rethrow_exception(stage2_error);
   if (reader_error) std::rethrow_exception(reader_error);
   if (writer_error) std::rethrow_exception(writer_error);
+  stats.output_bytes = stats2.output_bytes;
+  stats.seconds_stage2 = stats2.seconds_stage2;
   stats.seconds_total = since(t0);
   return stats;
 }

@@ -811,21 +811,21 @@ void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compres
 namespace amd_detail {
 
 void encodeStage1Batch(const EncodingInfo& info, const uint8_t* const* cloud_ptrs, const uint64_t* cloud_points,
-                       uint32_t n_clouds, std::vector<uint8_t>& stage1, std::vector<uint64_t>& stream_offsets,
+                       uint32_t n_clouds, const std::function<uint8_t*(uint64_t)>& grow, std::vector<uint64_t>& stream_offsets,
                        std::vector<uint32_t>& chunk_sizes) {
   PlanHandle plan(info);
-  uint64_t bound = 0, n_chunks = 0;
-  for (uint32_t k = 0; k < n_clouds; ++k) {
-    bound += cldn_hip_stage1_bound(plan.plan, cloud_points[k]);
-    n_chunks += (cloud_points[k] + kPointsPerChunk - 1) / kPointsPerChunk;
-  }
-  if (stage1.size() < bound) stage1.resize(bound);
+  uint64_t n_chunks = 0;
+  for (uint32_t k = 0; k < n_clouds; ++k) n_chunks += (cloud_points[k] + kPointsPerChunk - 1) / kPointsPerChunk;
   stream_offsets.assign((size_t)n_clouds + 1, 0);
   chunk_sizes.assign((size_t)std::max<uint64_t>(1, n_chunks), 0);
   cldn_hip_codec_t* codec = pool().acquire(info, plan);
-  const int rc = cldn_hip_encode_stage1_gather(codec, reinterpret_cast<const void* const*>(cloud_ptrs), cloud_points, n_clouds,
-                                               stage1.data(), stage1.size(), CLDN_HIP_HOST, stream_offsets.data(),
-                                               chunk_sizes.data(), nullptr);
+  // two-step host output: sizes first, then exactly the bytes that were produced
+  int rc = cldn_hip_encode_stage1_gather(codec, reinterpret_cast<const void* const*>(cloud_ptrs), cloud_points, n_clouds, nullptr,
+                                         0, CLDN_HIP_HOST, stream_offsets.data(), chunk_sizes.data(), nullptr);
+  if (rc == CLDN_HIP_OK) {
+    const uint64_t total = stream_offsets[n_clouds];
+    rc = cldn_hip_codec_fetch_output(codec, total ? grow(total) : nullptr, total);
+  }
   const std::string err = rc != CLDN_HIP_OK ? cldn_hip_last_error() : "";
   pool().release(info, codec);
   if (rc != CLDN_HIP_OK) throw std::runtime_error(err);

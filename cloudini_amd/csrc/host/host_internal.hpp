@@ -18,8 +18,10 @@ uint64_t vizPreprocessOnDevice(const uint8_t* points, size_t n_points, uint32_t 
 // One batched stage-1 encode of n clouds that share `info`'s schema, each in its own host buffer: the framed streams
 // ([u32 size][payload] per 32768-point chunk) land back to back in `stage1`; stream_offsets has n + 1 entries,
 // chunk_sizes one payload size per chunk in batch order. Throws std::runtime_error.
+// `grow(bytes)` is called once with the exact size of the batch's streams and returns where they go (page-locked memory
+// makes the copy back fast).
 void encodeStage1Batch(const Cloudini::EncodingInfo& info, const uint8_t* const* cloud_ptrs, const uint64_t* cloud_points,
-                       uint32_t n_clouds, std::vector<uint8_t>& stage1, std::vector<uint64_t>& stream_offsets,
+                       uint32_t n_clouds, const std::function<uint8_t*(uint64_t)>& grow, std::vector<uint64_t>& stream_offsets,
                        std::vector<uint32_t>& chunk_sizes);
 // detail::CompressChunk (src/codec_common.cpp:220-258) and its worst-case output size
 uint32_t compressChunkTo(Cloudini::CompressionOption opt, const uint8_t* src, size_t src_size, uint8_t* dst, size_t dst_cap);

@@ -57,6 +57,10 @@ def lib() -> C.CDLL:
     L.cldn_hip_current_device.restype = C.c_int
     L.cldn_hip_codec_device.restype = C.c_int
     L.cldn_hip_codec_device.argtypes = [vp]
+    L.cldn_hip_host_alloc.restype = vp
+    L.cldn_hip_host_alloc.argtypes = [C.c_size_t]
+    L.cldn_hip_host_free.restype = None
+    L.cldn_hip_host_free.argtypes = [vp]
     L.cldn_hip_plan_create.restype = C.c_int
     L.cldn_hip_plan_create.argtypes = [C.POINTER(_Field), C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8,
                                        C.POINTER(vp)]
@@ -97,6 +101,8 @@ def lib() -> C.CDLL:
     L.cldn_hip_encode_stage1.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, vp, C.c_uint64, C.c_int, vp, vp, vp]
     L.cldn_hip_encode_stage1_gather.restype = C.c_int
     L.cldn_hip_encode_stage1_gather.argtypes = [vp, C.POINTER(vp), u64p, C.c_uint32, vp, C.c_uint64, C.c_int, vp, vp, vp]
+    L.cldn_hip_codec_fetch_output.restype = C.c_int
+    L.cldn_hip_codec_fetch_output.argtypes = [vp, vp, C.c_uint64]
     L.cldn_hip_decode_stage1.restype = C.c_int
     L.cldn_hip_decode_stage1.argtypes = [vp, vp, C.c_int, u64p, u64p, C.c_uint32, vp, C.c_uint64, C.c_int]
     _lib = L

@@ -6,10 +6,10 @@
 // bytes are exactly what cloudini_ros::convertPointCloud2ToCompressedCloud (src/ros_msg_utils.cpp:167-213) produces; the
 // difference is how the work is arranged:
 //
-//   reader thread   pulls messages from a MessageSource into batches
-//   encode          one cldn_hip_encode_stage1_gather call per run of messages that share a schema (the clouds go from
-//                   their message buffers straight to the device), stage 2 (LZ4 / ZSTD per 32768-point chunk) of ALL
-//                   chunks of the batch on the bounded host pool, CDR wrapping
+//   reader thread   pulls messages from a MessageSource into batches (page-locked buffers, recycled)
+//   GPU stage       one cldn_hip_encode_stage1_gather call per run of messages that share a schema: the clouds go from
+//                   their message buffers straight to the device, the stage-1 streams come back into page-locked memory
+//   stage-2 thread  LZ4 / ZSTD of ALL chunks of the batch on the bounded host pool, CDR wrapping
 //   writer thread   hands the messages to a MessageSink in input order
 // so the GPU works on batch k+1 while the host cores compress batch k and the sink writes batch k-1.
 //
@@ -19,18 +19,36 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <new>
 #include <optional>
 #include <string>
 #include <vector>
 
+#include "cloudini_hip.h"
 #include "cloudini_lib/cloudini.hpp"
 #include "cloudini_lib/ros_msg_utils.hpp"
 
 namespace cloudini_amd {
 
+// Page-locked host memory (cldn_hip_host_alloc): message buffers and staging areas the GPU copies from / to directly.
+template <typename T>
+struct PinnedAllocator {
+  using value_type = T;
+  PinnedAllocator() = default;
+  template <typename U>
+  PinnedAllocator(const PinnedAllocator<U>&) {}
+  T* allocate(size_t n);
+  void deallocate(T* p, size_t) noexcept;
+  template <typename U>
+  bool operator==(const PinnedAllocator<U>&) const { return true; }
+  template <typename U>
+  bool operator!=(const PinnedAllocator<U>&) const { return false; }
+};
+using PinnedBytes = std::vector<uint8_t, PinnedAllocator<uint8_t>>;
+
 struct Message {
-  std::string name;            // file name / channel + sequence: whatever identifies the message for the sink
-  std::vector<uint8_t> bytes;  // CDR (DDS) bytes of a sensor_msgs/PointCloud2
+  std::string name;   // file name / channel + sequence: whatever identifies the message for the sink
+  PinnedBytes bytes;  // CDR (DDS) bytes of a sensor_msgs/PointCloud2; sources reuse the capacity of the Message they are given
 };
 
 class MessageSource {
@@ -71,13 +89,24 @@ struct TranscodeOptions {
   std::optional<float> default_resolution = 0.001f;             // for FLOAT32 fields the profile does not name
   bool viz_lossy = false;                                       // applyVizLossyPreprocessing in front of the encoder
   Cloudini::CompressionOption compression = Cloudini::CompressionOption::ZSTD;  // toEncodingInfo's default
-  size_t batch_messages = 64;                                   // messages per GPU batch
+  size_t batch_messages = 32;                                   // messages per GPU batch
 };
 
 struct TranscodeStats {
   uint64_t messages = 0, points = 0, input_bytes = 0, output_bytes = 0, gpu_batches = 0;
   double seconds_total = 0, seconds_gpu = 0, seconds_stage2 = 0;
 };
+
+template <typename T>
+T* PinnedAllocator<T>::allocate(size_t n) {
+  void* p = cldn_hip_host_alloc(n * sizeof(T));
+  if (!p) throw std::bad_alloc();
+  return static_cast<T*>(p);
+}
+template <typename T>
+void PinnedAllocator<T>::deallocate(T* p, size_t) noexcept {
+  cldn_hip_host_free(p);
+}
 
 // One batch, in memory (also the unit the pipeline below runs): out[i] = CompressedPointCloud2 of in[i].
 void transcodeBatch(const std::vector<Message>& in, const TranscodeOptions& options, std::vector<std::vector<uint8_t>>& out,

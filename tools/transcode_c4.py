@@ -24,7 +24,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
         env["CLOUDINI_AMD_STAGE2_THREADS"] = threads
     for rep in range(2):  # the second run has warm files and a warm GPU context
         t0 = time.perf_counter()
-        r = subprocess.run([exe, src, dst, "--resolution", "0.001", "--compression", "zstd", "--batch", "64"], capture_output=True, text=True, env=env)
+        r = subprocess.run([exe, src, dst, "--resolution", "0.001", "--compression", "zstd", "--batch", "32"], capture_output=True, text=True, env=env)
         wall = time.perf_counter() - t0
         assert r.returncode == 0, r.stderr
         st = json.loads(r.stdout.strip().splitlines()[-1])
