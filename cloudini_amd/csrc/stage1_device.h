@@ -9,9 +9,12 @@ namespace cldn {
 
 constexpr uint32_t kPointsPerChunk = 32768;  // detail::kPointsPerChunk, src/codec_common.hpp:28
 constexpr uint32_t kProbePoints = 4096;      // kAdaptiveModeProbePoints, src/v5_codec.cpp:76
-constexpr int kMaxOps = 32;                  // regular tokens per point this build supports
-constexpr int kMaxAdaptive = 16;             // V5 adaptive-int fields per schema this build supports
-constexpr uint32_t kMaxPointStep = 256;         // 64-point tiles of a 1024-thread workgroup still fit the LDS tile
+// Schema limits of this build. The plan travels to the kernels by value: 64 ops * 40 B + 32 adaptive fields * 8 B plus
+// the column pointer table (32 * 8 B, twice in the general section kernel) stay below the 4 KB a launch may carry.
+constexpr int kMaxOps = 64;                  // regular tokens per point
+constexpr int kMaxAdaptive = 32;             // V5 adaptive-int fields per schema
+constexpr uint32_t kMaxPointStep = 1024;     // generic kernel: points wider than 256 bytes go in 64-point tiles (2 x 64 KiB of LDS)
+constexpr uint32_t kWidePointStep = 256;     // up to here a 1024-thread tile of 16 KiB holds at least 64 points
 
 // One regular token per point. A FieldEncoderFloatN_Lossy (3 or 4 fused floats) is flattened into 3-4 OP_QF32
 // ops: its lanes are independent (src/field_encoder.cpp:42-91) and emit in lane order.

@@ -681,7 +681,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
           size = 5u + keys + heads + l128 + l16k;  // v5_codec.cpp:269-296, run lengths <= 32768: 1..3 bytes
         }
       }
-      if (lane == a) {  // lane a keeps section a's place (na <= kMaxAdaptive = 16 lanes), written once the chunk start is known
+      if (lane == a) {  // lane a keeps section a's place (na <= kMaxAdaptive <= 64 lanes), written once the chunk start is known
         sec_rel = sec_total;
         sec_size = size;
       }

@@ -272,7 +272,14 @@ __device__ __forceinline__ uint4 load_unit_guarded(const uint8_t* addr, const ui
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int T>
+// LDS bytes of one staged tile: 16 KiB (one unit per thread) for points up to 256 bytes, 64 points for wider ones
+__host__ __device__ inline uint32_t regular_tile_lds(uint32_t T, uint32_t step) {
+  const uint32_t body = step <= kWidePointStep ? T * 16u : 64u * step;
+  return ((body + step + 48u) + 15u) & ~15u;
+}
+
+// WIDE: point_step > 256 (tiles of 64 points, up to 5 staged units per thread)
+template <int T, bool WIDE = false>
 __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const uint8_t* __restrict__ points,
                                                       const uint8_t* points_end,
                                                       const ChunkDesc* __restrict__ chunks,
@@ -280,7 +287,8 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
                                                       Seg* __restrict__ segs, uint32_t segs_per_chunk,
                                                       const ColumnPtrs cols, uint32_t subs, uint32_t sub_points,
                                                       uint32_t sub_stride, const PreTokenPtrs pre) {
-  constexpr uint32_t kTileLds = T * 16u + kMaxPointStep + 48u;  // multiple of 16
+  constexpr int UPT = WIDE ? 5 : 2;  // 16-byte units a thread stages per tile
+  const uint32_t kTileLds = regular_tile_lds(T, plan.point_step);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* ring = reinterpret_cast<uint32_t*>(smem + 2u * kTileLds);
   uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + 2u * kTileLds + kRingBytes);
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
   // points of this sub-chunk; written with a saturating subtraction (hipcc 7.2 folded the guarded form
   // "n_points > sub_first ? min(sub_points, n_points - sub_first) : 0" into an unguarded unsigned min)
   const uint32_t n = min(sub_points, cd.n_points - min(cd.n_points, sub_first));
-  const uint32_t P = min((uint32_t)T, ((T * 16u) / step) & ~63u);  // points per tile (multiple of 64)
+  const uint32_t P = WIDE ? 64u : min((uint32_t)T, ((T * 16u) / step) & ~63u);  // points per tile (multiple of 64)
   const uint32_t n_tiles = (n + P - 1u) / P;
   const uint8_t* gchunk = points + ((size_t)cd.first_point + sub_first) * step;
   uint8_t* slot = slots + (size_t)chunk_id * slot_stride + (size_t)sub_id * sub_stride;
@@ -332,11 +340,14 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
     // issue the global loads of the next tile now; they land in LDS at the end of this iteration
     TileGeom gn;
     gn.units = 0u;
-    uint4 pre0 = make_uint4(0u, 0u, 0u, 0u), pre1 = pre0;
+    uint4 staged[UPT];
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) staged[k] = make_uint4(0u, 0u, 0u, 0u);
     if (it + 1u < n_tiles) {
       gn = tile_geom(gchunk, step, P, n, it + 1u, sub_has_prev);
-      if (tid < gn.units) pre0 = load_unit_guarded(gn.a0 + (size_t)tid * 16u, points, points_end);
-      if (tid + T < gn.units) pre1 = load_unit_guarded(gn.a0 + (size_t)(tid + T) * 16u, points, points_end);
+#pragma unroll
+      for (int k = 0; k < UPT; ++k)
+        if (tid + (uint32_t)k * T < gn.units) staged[k] = load_unit_guarded(gn.a0 + (size_t)(tid + (uint32_t)k * T) * 16u, points, points_end);
     }
 
     const bool active = tid < g.npts;
@@ -428,8 +439,9 @@ __global__ __launch_bounds__(T) void k_encode_regular(const DevPlan plan, const 
 
     // land the prefetched tile
     if (it + 1u < n_tiles) {
-      if (tid < gn.units) reinterpret_cast<uint4*>(tile_next)[tid] = pre0;
-      if (tid + T < gn.units) reinterpret_cast<uint4*>(tile_next)[tid + T] = pre1;
+#pragma unroll
+      for (int k = 0; k < UPT; ++k)
+        if (tid + (uint32_t)k * T < gn.units) reinterpret_cast<uint4*>(tile_next)[tid + (uint32_t)k * T] = staged[k];
       g = gn;
     }
     __syncthreads();
@@ -1095,6 +1107,9 @@ __global__ __launch_bounds__(T) void k_compact(const uint8_t* __restrict__ slots
   __shared__ uint32_t n_items_l;
   const uint32_t c = blockIdx.x;
   const uint32_t payload = chunk_payload[c];
+  // work items of 4 KiB, larger when the chunk is so big (wide raw-copied points: up to 32768 * 1024 bytes) that 4 KiB
+  // items would not fit the table
+  const uint32_t item_units = max(kCompactItemUnits, (payload >> 4) / (kCompactMaxItems - kCompactMaxSegs - 8u) + 1u);
   const uint64_t dst0 = chunk_dst[c];
   if (dst0 + 4u + payload > out_capacity) {
     if (threadIdx.x == 0 && blockIdx.y == 0) atomicOr(status, (uint32_t)ST_OUT_OVERFLOW);
@@ -1119,7 +1134,7 @@ __global__ __launch_bounds__(T) void k_compact(const uint8_t* __restrict__ slots
             item_u0[n_items] = u0;
             ++n_items;
           }
-          u0 += kCompactItemUnits;
+          u0 += item_units;
         } while (u0 < units);
       }
       d += size;
@@ -1154,7 +1169,7 @@ __global__ __launch_bounds__(T) void k_compact(const uint8_t* __restrict__ slots
     const uint32_t sdw = head >> 2, sb = head & 3u;
     const uint4* src4 = reinterpret_cast<const uint4*>(src);
     uint4* dst4 = reinterpret_cast<uint4*>(dst + head);
-    const uint32_t u1 = min(body_units, u0 + kCompactItemUnits);
+    const uint32_t u1 = min(body_units, u0 + item_units);
     for (uint32_t j = u0 + lane; j < u1; j += 64u) {
       const uint4 a = src4[j];
       uint4 b = make_uint4(0u, 0u, 0u, 0u);
@@ -1679,7 +1694,8 @@ namespace cldn {
 
 namespace {
 constexpr int kRegularThreads = 1024;
-constexpr uint32_t kRegularLds = 2u * (kRegularThreads * 16u + kMaxPointStep + 48u) + kRingBytes + 128u;
+inline uint32_t regular_lds(uint32_t step) { return 2u * regular_tile_lds(kRegularThreads, step) + kRingBytes + 128u; }
+constexpr uint32_t kRegularLdsMax = 2u * (((64u * kMaxPointStep + kMaxPointStep + 48u) + 15u) & ~15u) + kRingBytes + 128u;
 constexpr uint32_t kFloatnRing = 16384;  // >= one tile of 3-lane points at 5 bytes per token (1008 * 15 B); wider tiles use windows
 constexpr uint32_t kFloatnLds = kFloatnRing + 256u + kStagedCols * (4u * 63u * 2u) * 4u + 64u;  // ring, wtot, staged columns (TILE = 504)
 
@@ -1733,9 +1749,12 @@ int hip_fail(hipError_t e, const char* what) { return launch_fail(e, what); }
 }  // namespace
 
 int stage1_configure_kernels() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_regular<kRegularThreads>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRegularLds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_regular<kRegularThreads, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)regular_lds(kWidePointStep));
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_regular)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encode_regular<kRegularThreads, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRegularLdsMax);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_encode_regular wide)");
   const void* fk[] = {reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 2, kFloatnRing, 3, false>),
                       reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 2, kFloatnRing, 4, false>),
                       reinterpret_cast<const void*>(&k_encode_floatn<256, 3, 2, kFloatnRing, 8, false>),
@@ -2065,9 +2084,14 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     else if (lanes == 4 && loadw == 8) LAUNCH_FLOATN(256, 4, 2, 8, false);
     else {
     generic_regular:
-      hipLaunchKernelGGL(k_encode_regular<kRegularThreads>, dim3(L.n_chunks * L.subs), dim3(kRegularThreads),
-                         kRegularLds, L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots, L.slot_stride,
-                         L.segs, L.segs_per_chunk, L.cols, L.subs, L.sub_points, L.sub_stride, L.pre);
+      if (L.plan->point_step <= kWidePointStep)
+        hipLaunchKernelGGL((k_encode_regular<kRegularThreads, false>), dim3(L.n_chunks * L.subs), dim3(kRegularThreads),
+                           regular_lds(L.plan->point_step), L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots,
+                           L.slot_stride, L.segs, L.segs_per_chunk, L.cols, L.subs, L.sub_points, L.sub_stride, L.pre);
+      else
+        hipLaunchKernelGGL((k_encode_regular<kRegularThreads, true>), dim3(L.n_chunks * L.subs), dim3(kRegularThreads),
+                           regular_lds(L.plan->point_step), L.stream, *L.plan, L.points, L.points_end, L.chunks, L.slots,
+                           L.slot_stride, L.segs, L.segs_per_chunk, L.cols, L.subs, L.sub_points, L.sub_stride, L.pre);
     }
 #undef LAUNCH_FLOATN
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_regular/floatn");

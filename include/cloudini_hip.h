@@ -36,6 +36,12 @@ extern "C" {
 #define CLDN_HIP_POINTS_PER_CHUNK 32768u /* detail::kPointsPerChunk, src/codec_common.hpp:28 */
 #define CLDN_HIP_PROBE_POINTS 4096u      /* kAdaptiveModeProbePoints, src/v5_codec.cpp:76 */
 
+/* Schema limits of this build (cldn_hip_plan_create answers CLDN_HIP_ERR_UNSUPPORTED beyond them; there is no CPU
+ * fallback): point_step <= 1024 bytes; <= 64 per-point tokens (fields of the regular stream: a fused FloatN group
+ * counts 3 or 4); <= 32 adaptive integer fields (16/32/64-bit integers of a V5 lossy schema); <= 4 Gorilla-coded FLOAT64
+ * fields (FLOAT64 without resolution, version >= 4). The reference has no such limits (src/codec_common.cpp:116-153,
+ * src/v5_codec.cpp:719-740). Points wider than 256 bytes take the generic kernel in 64-point tiles. */
+
 /* Return codes. */
 enum {
   CLDN_HIP_OK = 0,

@@ -140,7 +140,7 @@ def test_batch_mixed_clouds_v5(oracle):
 def test_unsupported_schemas_fail_loudly():
     """No CPU fallback: what the kernels cannot do is refused with CLDN_HIP_ERR_UNSUPPORTED."""
     from cloudini_amd import native
-    info = cases.make_info([("x", 0, FieldType.FLOAT32, 0.001)], 300, 10)  # point_step beyond the tile staging
+    info = cases.make_info([("x", 0, FieldType.FLOAT32, 0.001)], 1025, 10)  # point_step beyond kMaxPointStep
     with pytest.raises(native.CloudiniHipError) as e:
         native.Plan(info)
     assert e.value.code == -3

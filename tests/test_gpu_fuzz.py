@@ -15,10 +15,11 @@ _NP = {F.INT8: np.int8, F.UINT8: np.uint8, F.INT16: np.int16, F.UINT16: np.uint1
        F.FLOAT32: np.float32, F.FLOAT64: np.float64, F.INT64: np.int64, F.UINT64: np.uint64}
 
 
-def _random_case(seed):
+def _random_case(seed, wide=False):
+    """wide: up to 64 fields and points of up to 1024 bytes (the limits the library states in include/cloudini_hip.h)."""
     rs = np.random.RandomState(seed)
-    n = int(rs.choice([1, 100, 4095, 4097, 33000, 70001]))
-    n_fields = int(rs.randint(1, 9))
+    n = int(rs.choice([1, 100, 4095, 4097, 33000, 70001])) if not wide else int(rs.choice([1, 100, 4097, 33000]))
+    n_fields = int(rs.randint(1, 9)) if not wide else int(rs.choice([9, 16, 33, 40, 64]))
     lead_floats = int(rs.choice([0, 1, 2, 3, 3, 4, 4, 5]))
     types = []
     for i in range(n_fields):
@@ -62,6 +63,8 @@ def _random_case(seed):
         cols[name] = v
         off += _SIZE[t] + int(rs.choice([0, 0, 0, 1, 2, 4]))
     step = off + int(rs.choice([0, 0, 3, 8]))
+    if wide:
+        step = max(step, int(rs.choice([257, 300, 512, 777, 1024])))
     enc = EncodingOptions(int(rs.choice([0, 1, 1, 1, 2])))
     version = int(rs.choice([4, 5, 5, 5]))
     info = cases.make_info(fields, step, n, enc=enc, version=version)
@@ -88,6 +91,30 @@ def test_random_schema(oracle, seed):
     streams, _sizes, modes = codec.encode_host([data])
     assert np.array_equal(streams[0], want), (seed, [(f.name, int(f.type), f.offset, f.resolution) for f in info.fields],
                                               info.point_step, int(info.encoding_opt), info.version)
+    if plan.adaptive_fields:
+        assert list(modes[0]) == list(want_modes)
+    out = np.full(max(1, data.size), 0xC3, dtype=np.uint8)
+    got = codec.decode_host([want], [n], out=out)[0]
+    assert np.array_equal(got, oracle.decode_stage1(info, want, n, fill=0xC3)), seed
+    codec.close()
+
+
+@pytest.mark.parametrize("seed", list(range(5000, 5040)))
+def test_random_wide_schema(oracle, seed):
+    """Up to 64 fields, points of up to 1024 bytes: either byte-exact or refused with UNSUPPORTED for one of the limits
+    include/cloudini_hip.h lists (more than 64 per-point tokens, 32 adaptive fields, 4 Gorilla fields)."""
+    from cloudini_amd import native
+    info, data = _random_case(seed, wide=True)
+    n = data.size // info.point_step
+    want, want_modes = oracle.encode_stage1(info, data, return_modes=True)
+    try:
+        plan = native.Plan(info)
+    except native.CloudiniHipError as e:
+        assert e.code == -3, e
+        pytest.skip(f"schema refused: {e}")
+    codec = native.Codec(plan)
+    streams, _sizes, modes = codec.encode_host([data])
+    assert np.array_equal(streams[0], want), (seed, len(info.fields), info.point_step, int(info.encoding_opt), info.version)
     if plan.adaptive_fields:
         assert list(modes[0]) == list(want_modes)
     out = np.full(max(1, data.size), 0xC3, dtype=np.uint8)
