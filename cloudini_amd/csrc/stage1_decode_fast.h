@@ -6,12 +6,12 @@
 // k_decode_varint walks the 16 byte positions of every thread with the full token logic under a predicate (233
 // lane-instructions per token); here the two jobs are separated:
 //   phase A  byte-parallel and cheap: every thread flags the token ends in its 16 bytes, one block scan numbers them,
-//            and the byte position of every token end goes into an LDS list in token order;
-//   phase B  point-parallel, every lane busy: a thread takes 3 consecutive points, reads their 3 * NOPS + 1 end
-//            positions (a token starts behind the previous one's end, so its length needs no flag analysis), pulls
-//            each token out of the LDS copy of the tile with one 8-byte window, sums its deltas, a segmented block
-//            scan (NaN markers reset a lane) turns them into values, and the values leave through an LDS transposition
-//            so that a store instruction covers consecutive points.
+//            and the byte behind every NOPS-th end -- where a point starts -- goes into an LDS list in point order;
+//   phase B  point-parallel, every lane busy: a thread takes 3 consecutive points; for each it reads the 4 * (NOPS + 1)
+//            bytes behind the point's start from the LDS copy of the tile and walks the NOPS tokens in registers (a
+//            token's length is the position of its first byte with a clear MSB; the window is shifted by it), sums
+//            the deltas, a segmented block scan (NaN markers reset a lane) turns them into values, and the values leave
+//            through an LDS transposition so that a store instruction covers consecutive points.
 // A tile starts exactly at a point boundary (the next tile begins behind the last token it consumed), so no point is
 // ever cut and nothing but the per-lane running values is carried between tiles.
 //
@@ -36,13 +36,13 @@ constexpr uint32_t kFastPalFields = 2;
 template <int NOPS>
 struct FpLds {
   static constexpr uint32_t kTileOff = 0;                                   // [16 zero bytes][tile][32 pad]
-  static constexpr uint32_t kPosOff = 16u + kFpTileBytes + 32u;             // u16 [1 + kFpTilePoints * NOPS + 7]
-  static constexpr uint32_t kPosEntries = 1u + kFpTilePoints * NOPS + 7u;
+  static constexpr uint32_t kPosOff = 16u + kFpTileBytes + 32u;             // u16 [kFpTilePoints + 1 + 7]: where point q starts
+  static constexpr uint32_t kPosEntries = 1u + kFpTilePoints + 7u;
   static constexpr uint32_t kWorkEnd = (kPosOff + kPosEntries * 2u + 15u) & ~15u;
   static constexpr uint32_t kStageBytes = kFpTilePoints * NOPS * 4u;        // decoded floats, overlays tile + list
   static constexpr uint32_t kScanOff = (kWorkEnd > kStageBytes ? kWorkEnd : kStageBytes);
-  static constexpr uint32_t kWaveRec = NOPS * 4u + 8u;                      // per wave: int[NOPS] + flags; [16] = carry
-  static constexpr uint32_t kPalOff = (kScanOff + 17u * kWaveRec + 15u) & ~15u;
+  static constexpr uint32_t kWaveRec = NOPS * 4u + 8u;                      // per wave: int[NOPS] + flags; [16], [17] = carry
+  static constexpr uint32_t kPalOff = (kScanOff + 18u * kWaveRec + 15u) & ~15u;     // (read and written in turns)
   static constexpr uint32_t kMiscOff = kPalOff + kFastPalFields * kFastPalEntries * 4u;
   static constexpr uint32_t kTotal = kMiscOff + 512u;
 };
@@ -98,7 +98,6 @@ __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(8, 8
                                                               uint32_t uses_v5, uint32_t* __restrict__ status) {
   using L = FpLds<NOPS>;
   constexpr int T = kDvThreads;
-  constexpr uint32_t CAP_TOK = kFpTilePoints * NOPS;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* tile = reinterpret_cast<uint32_t*>(smem + L::kTileOff);             // dwords; byte 16 = first tile byte
   uint16_t* pos_list = reinterpret_cast<uint16_t*>(smem + L::kPosOff);          // [0] = end of the token before the tile
@@ -127,11 +126,10 @@ __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(8, 8
   if (tid == 0) {
     misc[0] = 0u;
     misc[1] = 0u;            // a folded Palette index was out of range
-    misc[41] = 0u;
     misc[40] = 0xffffffffu;  // pre-pass: payload offset behind the regular stream
     misc[64] = 0u;           // sections folded in
   }
-  if (tid < (uint32_t)(NOPS + 2)) reinterpret_cast<uint32_t*>(scanrec + 16u * L::kWaveRec)[tid] = 0u;  // carry: values 0
+  if (tid < (uint32_t)(NOPS + 2)) reinterpret_cast<uint32_t*>(scanrec + 16u * L::kWaveRec)[tid] = 0u;  // carry of tile 0: values 0
   __syncthreads();
 
   // ---------------------------------------------------------------------------------------------------------
@@ -250,87 +248,110 @@ __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(8, 8
   // ---------------------------------------------------------------------------------------------------------
   uint32_t pos = 0u;       // payload offset of the tile (a point boundary)
   uint32_t pts_done = 0u;
+  uint32_t par = 0u;       // which carry record this tile reads (it writes the other one)
   bool bad = false;
   while (pts_done < n) {
     if (pos >= src_size) { bad = true; break; }
-    // ---- phase A: bytes -> LDS, token ends -> position list
+    // ---- phase A: bytes -> LDS; the byte where every point starts -> list
     uint32_t b[4];
     fp_load16(src, src_size, pos + tid * 16u, b);
     *reinterpret_cast<uint4*>(tile + 4u + tid * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
     const uint32_t ends = fp_ends16(b);
     uint32_t n_tile;
     const uint32_t tb = block_exclusive_scan<T>((uint32_t)__builtin_popcount(ends), misc + 2, &n_tile);  // barrier inside
-    const uint32_t want = min(CAP_TOK, (n - pts_done) * NOPS);
+    const uint32_t want_pts = min(kFpTilePoints, n - pts_done);
     {
-      uint32_t k = tb + 1u;  // list slot of my first token ([0] is the token before the tile)
-      for (uint32_t m = ends; m != 0u && k <= want; m &= m - 1u, ++k) pos_list[k] = (uint16_t)(tid * 16u + (uint32_t)__builtin_ctz(m));
-      if (tid == 0) pos_list[0] = (uint16_t)0xffffu;  // "ends at -1": the tile's first token starts at byte 0
+      // my token ends are tokens tb, tb + 1, ... of the tile; point q starts behind the end of token q * NOPS - 1.
+      // Only those ends are listed: the tokens inside a point are found by walking its bytes in phase B.
+      const uint32_t tq = tb / (uint32_t)NOPS;
+      const uint32_t rank0 = (uint32_t)(NOPS - 1) - (tb - tq * (uint32_t)NOPS);  // ends of mine to skip first
+      uint32_t m = ends;
+#pragma unroll
+      for (uint32_t i = 0; i + 1u < (uint32_t)NOPS; ++i) {
+        const uint32_t mm = m & (m - 1u);
+        m = (i < rank0) ? mm : m;
+      }
+      uint32_t q = tq + 1u;
+      while (m != 0u && q <= want_pts) {
+        pos_list[q] = (uint16_t)(tid * 16u + (uint32_t)__builtin_ctz(m) + 1u);
+        ++q;
+#pragma unroll
+        for (int i = 0; i < NOPS; ++i) m &= m - 1u;
+      }
+      if (tid == 0) pos_list[0] = (uint16_t)0u;
     }
     __syncthreads();
-    const uint32_t npts = min(n_tile, want) / NOPS;  // whole points of this tile
+    const uint32_t npts = min(n_tile / (uint32_t)NOPS, want_pts);  // whole points of this tile
     if (npts == 0u) { bad = true; break; }           // 16 KiB without NOPS token ends: not a FloatN stream
+    const uint32_t next_pos = pos + (uint32_t)pos_list[npts];  // behind the last token this tile consumes
 
     // ---- phase B: my points [q0, q0 + kFpPPT)
     const uint32_t q0 = tid * kFpPPT;
-    int32_t dlt[kFpPPT][NOPS];
-    uint32_t mk = 0u;      // bit (i * NOPS + o): token is the NaN marker
+    int32_t dlt[kFpPPT][NOPS];   // 0x80000000 = the NaN marker (no token of at most 4 bytes decodes to it)
     bool long_tok = false;
-    {
-      // end positions of tokens q0*NOPS - 1 ... (q0 + PPT)*NOPS - 1: list slots q0*NOPS ... +PPT*NOPS, 2 bytes each
-      const uint32_t s0 = q0 * NOPS;  // slots s0 .. s0 + kFpPPT * NOPS <= CAP_TOK: inside the list whatever it holds
-      uint32_t e_prev = pos_list[s0];
-      uint32_t irregular = 0u;
+    bool any_marker = false;
 #pragma unroll
-      for (uint32_t i = 0; i < kFpPPT; ++i) {
-        const bool have = (q0 + i) < npts;  // points behind the tile's last one: same straight-line code, results dropped
+    for (uint32_t i = 0; i < kFpPPT; ++i) {
+      // points behind the tile's last one run the same straight-line code on whatever the list holds (masked into the
+      // tile); nothing of theirs is used: they come after every real point in scan order
+      const bool have = (q0 + i) < npts;
+      const uint32_t byte0 = 16u + ((uint32_t)pos_list[q0 + i] & (kFpTileBytes - 1u));  // byte index in the LDS copy
+      const uint32_t di = byte0 >> 2, sh = (byte0 & 3u) * 8u;
+      uint32_t d[NOPS + 1];
 #pragma unroll
-        for (int o = 0; o < NOPS; ++o) {
-          const uint32_t e = pos_list[s0 + i * NOPS + (uint32_t)o + 1u];
-          uint32_t start = (e_prev + 1u) & 0xffffu;  // byte index in the tile
-          const uint32_t len = e - start + 1u;
-          start = have ? start : 0u;
-          // Tokens of up to 4 bytes (|delta| < 2^27 ticks) are decoded here with 32-bit arithmetic; a longer one
-          // (special values, damaged streams) sends the chunk to k_decode_varint.
-          const uint32_t byte0 = 16u + start;  // byte index in the LDS copy
-          const uint32_t d0 = tile[byte0 >> 2], d1 = tile[(byte0 >> 2) + 1u];
-          const uint32_t w = __builtin_amdgcn_alignbit(d1, d0, (byte0 & 3u) * 8u);  // the 4 bytes at the token's start
-          // bytes of the token: up to and including the first byte whose MSB is clear
-          const uint32_t t = ~w & 0x80808080u;
-          const uint32_t keep = ((t & (0u - t)) << 1) - 1u;  // t == 0 (4 continuation bytes) keeps all four
-          const uint32_t lo = w & keep & 0x7f7f7f7fu;
-          const uint32_t u = (lo & 0x7fu) | (((lo >> 8) & 0x7fu) << 7) | (((lo >> 16) & 0x7fu) << 14) | ((lo >> 24) << 21);
-          const bool zero = u == 0u;
-          // the marker byte 0x00; an overlong zero is something decodeVarint rejects
-          mk |= (have && zero && len == 1u) ? (1u << (i * NOPS + (uint32_t)o)) : 0u;
-          irregular |= (have && (len > 4u || (zero && len != 1u))) ? 1u : 0u;
-          const uint32_t u1 = u - 1u;
-          const int32_t d = (int32_t)((u1 >> 1) ^ (0u - (u1 & 1u)));
-          dlt[i][o] = have ? d : 0;
-          e_prev = e;
+      for (int k = 0; k <= NOPS; ++k) d[k] = tile[di + (uint32_t)k];
+      uint32_t W[NOPS];  // W[k] = bytes [4k, 4k + 4) behind the current token's start
+#pragma unroll
+      for (int k = 0; k < NOPS; ++k) W[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) {
+        // Tokens of up to 4 bytes (|delta| < 2^27 ticks) are decoded here with 32-bit arithmetic; a longer one
+        // (special values, damaged streams) sends the chunk to k_decode_varint.
+        const uint32_t w = W[0];
+        const uint32_t t = ~w & 0x80808080u;     // the bytes that can end the token
+        const uint32_t keep = t ^ (t - 1u);      // everything up to and including the first of them
+        const uint32_t wk = w & keep;            // == 0: the marker byte 0x00
+        const uint32_t lo = wk & 0x7f7f7f7fu;
+        const uint32_t u = (lo & 0x7fu) | (((lo >> 8) & 0x7fu) << 7) | (((lo >> 16) & 0x7fu) << 14) | ((lo >> 24) << 21);
+        // no end in 4 bytes; or an overlong zero, which decodeVarint rejects
+        long_tok = long_tok || (have && (t == 0u || (lo == 0u && wk != 0u)));
+        any_marker = any_marker || wk == 0u;
+        const uint32_t u1 = u - 1u;
+        dlt[i][o] = (int32_t)((u1 >> 1) ^ (0u - (u1 & 1u)));   // u == 0 -> 0x80000000
+        if (o + 1 < NOPS) {
+          const uint32_t adv = (uint32_t)__ffs((int)t);  // bits of this token: 8, 16, 24, 32
+#pragma unroll
+          for (int k = 0; k + 1 < NOPS - o; ++k) W[k] = (uint32_t)(((((uint64_t)W[k + 1]) << 32) | W[k]) >> adv);
         }
       }
-      long_tok = irregular != 0u;
     }
     // local sums per lane with NaN resets, then the segmented scan over the threads
     int32_t acc[NOPS];
     uint32_t fl = 0u;
+    const bool wave_marker = __ballot(any_marker) != 0ull;  // (markers of points that do not exist only cost time)
 #pragma unroll
     for (int o = 0; o < NOPS; ++o) acc[o] = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < kFpPPT; ++i) {
-#pragma unroll
-      for (int o = 0; o < NOPS; ++o) {
-        const bool m = (mk >> (i * NOPS + (uint32_t)o)) & 1u;
-        acc[o] = m ? 0 : (int32_t)((uint32_t)acc[o] + (uint32_t)dlt[i][o]);
-        if (m) fl |= 1u << o;
-      }
-    }
     int32_t inc[NOPS];
-    uint32_t fin = fl;
-    if (__ballot(fl != 0u) == 0ull) {  // no marker in this wave (the rule for lidar data): plain DPP prefix sums
+    uint32_t fin = 0u;
+    if (!wave_marker) {  // no marker in this wave (the rule for lidar data): plain sums, DPP prefix sums
+#pragma unroll
+      for (uint32_t i = 0; i < kFpPPT; ++i) {
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) acc[o] = (int32_t)((uint32_t)acc[o] + (uint32_t)dlt[i][o]);
+      }
 #pragma unroll
       for (int o = 0; o < NOPS; ++o) inc[o] = (int32_t)wave_inclusive_scan((uint32_t)acc[o]);
     } else {
+#pragma unroll
+      for (uint32_t i = 0; i < kFpPPT; ++i) {
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) {
+          const bool m = dlt[i][o] == (int32_t)0x80000000;
+          acc[o] = m ? 0 : (int32_t)((uint32_t)acc[o] + (uint32_t)dlt[i][o]);
+          if (m) fl |= 1u << o;
+        }
+      }
+      fin = fl;
 #pragma unroll
       for (int o = 0; o < NOPS; ++o) inc[o] = acc[o];
 #pragma unroll
@@ -357,7 +378,7 @@ __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     __syncthreads();  // also: every thread is done with the tile bytes and the list -> the staging area may overlay them
     int32_t in[NOPS];
     {
-      const int32_t* crec = reinterpret_cast<const int32_t*>(scanrec + 16u * L::kWaveRec);
+      const int32_t* crec = reinterpret_cast<const int32_t*>(scanrec + (16u + par) * L::kWaveRec);
 #pragma unroll
       for (int o = 0; o < NOPS; ++o) in[o] = crec[o];
       {
@@ -405,34 +426,39 @@ __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(8, 8
       }
     }
     if (misc[0]) { bad = true; break; }  // uniform (read behind the barrier)
-    // final values -> staging (point-major, NOPS floats per point)
+    // final values -> staging (point-major, NOPS floats per point); the values behind the tile's last point are the
+    // next tile's carry (the record this tile did not read)
+    int32_t* crec_next = reinterpret_cast<int32_t*>(scanrec + (17u - par) * L::kWaveRec);
+    if (!wave_marker) {
 #pragma unroll
-    for (uint32_t i = 0; i < kFpPPT; ++i) {
+      for (uint32_t i = 0; i < kFpPPT; ++i) {
 #pragma unroll
-      for (int o = 0; o < NOPS; ++o) {
-        const bool m = (mk >> (i * NOPS + (uint32_t)o)) & 1u;
-        in[o] = m ? 0 : (int32_t)((uint32_t)in[o] + (uint32_t)dlt[i][o]);
-        const float f = m ? __uint_as_float(0x7fc00000u) : __fmul_rn((float)in[o], res[o]);
-        stage[(q0 + i) * NOPS + (uint32_t)o] = f;  // points >= npts: harmless slots, never read
+        for (int o = 0; o < NOPS; ++o) {
+          in[o] = (int32_t)((uint32_t)in[o] + (uint32_t)dlt[i][o]);
+          stage[(q0 + i) * NOPS + (uint32_t)o] = __fmul_rn((float)in[o], res[o]);  // points >= npts: harmless slots, never read
+        }
+        if (q0 + i + 1u == npts) {
+#pragma unroll
+          for (int o = 0; o < NOPS; ++o) crec_next[o] = in[o];
+        }
+      }
+    } else {
+#pragma unroll
+      for (uint32_t i = 0; i < kFpPPT; ++i) {
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) {
+          const bool m = dlt[i][o] == (int32_t)0x80000000;
+          in[o] = m ? 0 : (int32_t)((uint32_t)in[o] + (uint32_t)dlt[i][o]);
+          const float f = m ? __uint_as_float(0x7fc00000u) : __fmul_rn((float)in[o], res[o]);
+          stage[(q0 + i) * NOPS + (uint32_t)o] = f;
+        }
+        if (q0 + i + 1u == npts) {
+#pragma unroll
+          for (int o = 0; o < NOPS; ++o) crec_next[o] = in[o];
+        }
       }
     }
-    if (tid == (npts - 1u) / kFpPPT) {
-      // the thread that owns the tile's last point: its running values (after that point) are the carry; its later
-      // points did not exist (have == false -> delta 0, no marker), so `in` is exactly the state behind point npts - 1
-      int32_t* crec = reinterpret_cast<int32_t*>(scanrec + 16u * L::kWaveRec);
-#pragma unroll
-      for (int o = 0; o < NOPS; ++o) crec[o] = in[o];
-    }
-    // byte behind the last token this tile consumed = start of the next tile. The list is overlaid by the staging
-    // area now, so the owner of that token recomputes it from its own end flags.
-    {
-      const uint32_t last_tok = npts * NOPS - 1u;  // index in the tile
-      if (tb <= last_tok && last_tok < tb + (uint32_t)__builtin_popcount(ends)) {
-        uint32_t m = ends;
-        for (uint32_t k = tb; k < last_tok; ++k) m &= m - 1u;
-        misc[41] = pos + tid * 16u + (uint32_t)__builtin_ctz(m) + 1u;
-      }
-    }
+    par ^= 1u;
     __syncthreads();
     // ---- read-out: consecutive lanes, consecutive points; folded Palette fields complete the point. The layout
     // decisions are uniform: one switch per tile picks a straight-line variant (the common lidar layouts get code
@@ -519,10 +545,9 @@ __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(8, 8
         }
       }
     }
-    pos = misc[41];
+    pos = next_pos;
     pts_done += npts;
-    __syncthreads();  // staging / misc[41] are free again; restore the 16 zero bytes in front of the tile
-    if (tid < 4u) tile[tid] = 0u;
+    __syncthreads();  // the staging area is free again
   }
   __syncthreads();
   if (tid == 0) {
