@@ -28,8 +28,9 @@
 namespace cldn {
 
 constexpr uint32_t kFpPPT = 3;                          // points per thread and tile
-constexpr uint32_t kFpTileBytes = kDvThreads * 16u;     // 16 KiB of stream per tile
-constexpr uint32_t kFpTilePoints = kDvThreads * kFpPPT; // at most 3072 points leave per tile
+constexpr uint32_t kFpThreads = 512;                    // 8 waves; four workgroups share a CU
+constexpr uint32_t kFpTileBytes = kFpThreads * 16u;     // 8 KiB of stream per tile
+constexpr uint32_t kFpTilePoints = kFpThreads * kFpPPT; // at most 1536 points leave per tile
 constexpr uint32_t kFastPalEntries = 1024;
 constexpr uint32_t kFastPalFields = 2;
 
@@ -92,12 +93,13 @@ struct FpSection {   // a Palette section folded into the point pass
 };
 
 template <int NOPS>
-__global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decode_points(const DevPlan plan, const uint8_t* __restrict__ streams,
+__global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decode_points(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                               const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
                                                               uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done,
                                                               uint32_t uses_v5, uint32_t* __restrict__ status) {
   using L = FpLds<NOPS>;
-  constexpr int T = kDvThreads;
+  constexpr int T = kFpThreads;
+  constexpr uint32_t NW = kFpThreads / 64u;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* tile = reinterpret_cast<uint32_t*>(smem + L::kTileOff);             // dwords; byte 16 = first tile byte
   uint16_t* pos_list = reinterpret_cast<uint16_t*>(smem + L::kPosOff);          // [0] = end of the token before the tile
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(8, 8
   // ---------------------------------------------------------------------------------------------------------
   uint32_t reg_size = 0xffffffffu;
   if (uses_v5 && plan.n_adaptive != 0u) {
-    const uint32_t part = (((src_size + 15u) / 16u + 15u) / 16u) * 16u;  // bytes per wave, multiple of 16
+    const uint32_t part = (((src_size + 15u) / 16u + NW - 1u) / NW) * 16u;  // bytes per wave, multiple of 16
     const uint32_t w0 = wave * part, w1 = min(src_size, w0 + part);
     uint32_t cnt = 0u;
     for (uint32_t o = w0 + lane * 16u; o < w1; o += 1024u) {

@@ -2163,10 +2163,10 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     const bool points_kernel = fast && !no_points && all_qf32 && (P.n_ops == 3u || P.n_ops == 4u) && P.n_gorilla == 0u;
     if (points_kernel) {
       if (P.n_ops == 3u)
-        hipLaunchKernelGGL((k_decode_points<3>), dim3(L.n_chunks), dim3(kDvThreads), (FpLds<3>::kTotal), L.stream, P, L.streams,
+        hipLaunchKernelGGL((k_decode_points<3>), dim3(L.n_chunks), dim3(kFpThreads), (FpLds<3>::kTotal), L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5, L.status);
       else
-        hipLaunchKernelGGL((k_decode_points<4>), dim3(L.n_chunks), dim3(kDvThreads), (FpLds<4>::kTotal), L.stream, P, L.streams,
+        hipLaunchKernelGGL((k_decode_points<4>), dim3(L.n_chunks), dim3(kFpThreads), (FpLds<4>::kTotal), L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5, L.status);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_points");
     }
