@@ -175,6 +175,12 @@ struct cldn_hip_codec {
   DevBuf d_viz_keys, d_viz_first, d_viz_slot, d_viz_blocks, d_viz_total;  // applyVizLossyPreprocessing workspace
   DevBuf d_pre[kMaxGorilla];
   PinnedBuf h_stage;   // chunk table upload
+  // decode table upload: a ring of staging buffers, each guarded by the event recorded behind its copy, so that a call
+  // does not have to drain the stream before it fills the next one
+  static constexpr int kDecStageRing = 4;
+  PinnedBuf h_dec_stage[kDecStageRing];
+  hipEvent_t dec_stage_ev[kDecStageRing] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t dec_stage_next = 0;
   PinnedBuf h_result;  // offsets / status readback
   PinnedBuf h_modes;   // forced modes upload
   // modes of the previous encode call, copied back asynchronously: launch hint for the section kernels
@@ -482,6 +488,10 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
     c->d_ranks[a].release();
   }
   c->h_stage.release();
+  for (int k = 0; k < cldn_hip_codec::kDecStageRing; ++k) {
+    c->h_dec_stage[k].release();
+    if (c->dec_stage_ev[k]) (void)hipEventDestroy(c->dec_stage_ev[k]);
+  }
   c->h_result.release();
   c->h_modes.release();
   c->h_last_modes.release();
@@ -1148,9 +1158,12 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams
   // tables: [stream_offsets u64 | cloud_first_point u64 | cloud_first_chunk u32] (n_clouds + 1 entries each)
   const size_t ne = (size_t)n_clouds + 1;
   const size_t table_bytes = ne * 8 + ne * 8 + ne * 4;
-  HIP_TRY(hipStreamSynchronize(c->stream));  // staging buffer reuse
-  if ((rc = c->h_stage.ensure(table_bytes)) != CLDN_HIP_OK) return rc;
-  uint64_t* h_so = (uint64_t*)c->h_stage.p;
+  const uint32_t slot = c->dec_stage_next++ % (uint32_t)cldn_hip_codec::kDecStageRing;
+  PinnedBuf& stage = c->h_dec_stage[slot];
+  if (c->dec_stage_ev[slot]) HIP_TRY(hipEventSynchronize(c->dec_stage_ev[slot]));  // its last upload has left the buffer
+  else HIP_TRY(hipEventCreateWithFlags(&c->dec_stage_ev[slot], hipEventDisableTiming));
+  if ((rc = stage.ensure(table_bytes)) != CLDN_HIP_OK) return rc;
+  uint64_t* h_so = (uint64_t*)stage.p;
   uint64_t* h_fp = h_so + ne;
   uint32_t* h_fc = (uint32_t*)(h_fp + ne);
   const uint64_t base_off = stream_offsets[0];
@@ -1169,10 +1182,9 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams
   const size_t chunk_table_bytes = ((size_t)std::max(1u, n_chunks) * kDecChunkBytes + 63) & ~size_t(63);
   if ((rc = c->d_dec_meta.ensure(((table_bytes + 63) & ~size_t(63)) + chunk_table_bytes + (size_t)std::max(1u, n_chunks) * 5u)) != CLDN_HIP_OK)
     return rc;
-  c->last_cloud_points.clear();  // the staging buffer no longer holds the encode chunk table
   uint8_t* meta = (uint8_t*)c->d_dec_meta.p;
-  HIP_TRY(hipMemcpyAsync(meta, c->h_stage.p, table_bytes, hipMemcpyHostToDevice, c->stream));
-  // the upload invalidates the cached encode batch shape (same staging buffer, different tables on device are fine)
+  HIP_TRY(hipMemcpyAsync(meta, stage.p, table_bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->dec_stage_ev[slot], c->stream));
 
   const uint8_t* d_streams = (const uint8_t*)streams + base_off;
   if (streams_loc == CLDN_HIP_HOST) {

@@ -40,7 +40,8 @@ struct FpLds {
   static constexpr uint32_t kPosOff = 16u + kFpTileBytes + 32u;             // u16 [kFpTilePoints + 1 + 7]: where point q starts
   static constexpr uint32_t kPosEntries = 1u + kFpTilePoints + 7u;
   static constexpr uint32_t kWorkEnd = (kPosOff + kPosEntries * 2u + 15u) & ~15u;
-  static constexpr uint32_t kStageBytes = kFpTilePoints * NOPS * 4u;        // decoded floats, overlays tile + list
+  static constexpr uint32_t kStageBytes = kFpTilePoints * (NOPS + kFastPalFields) * 4u;  // decoded points (floats + folded
+                                                                                         // fields), overlays tile + list
   static constexpr uint32_t kScanOff = (kWorkEnd > kStageBytes ? kWorkEnd : kStageBytes);
   static constexpr uint32_t kWaveRec = NOPS * 4u + 8u;                      // per wave: int[NOPS] + flags; [16], [17] = carry
   static constexpr uint32_t kPalOff = (kScanOff + 18u * kWaveRec + 15u) & ~15u;     // (read and written in turns)
@@ -327,6 +328,39 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
         }
       }
     }
+    // folded Palette fields of my points: their indexes are consecutive bits, one 8-byte window holds all kFpPPT
+    uint32_t pv[kFastPalFields][kFpPPT];
+    const uint32_t SP = (uint32_t)NOPS + n_fold;  // dwords per staged point
+    if (n_fold != 0u) {
+#pragma unroll
+      for (uint32_t a = 0; a < kFastPalFields; ++a) {
+        if (a >= n_fold) break;  // uniform
+        const uint32_t bits = fs_bits[a];
+        uint64_t w64 = 0u;
+        if (bits != 0u && q0 < npts) {
+          const uint32_t bit0 = (pts_done + q0) * bits;                 // < 32768 * 10
+          const uint8_t* ib = fs_idx[a] + (bit0 >> 3);
+          const uint32_t mis = (uint32_t)((uintptr_t)ib & 3u);
+          const uint8_t* al = ib - mis;                                 // index_off >= 3: still inside the payload
+          if (al + 8u <= src + src_size) {  // kFpPPT * 10 + 7 bits <= 5 bytes: two aligned dwords cover them
+            const uint32_t* iq = reinterpret_cast<const uint32_t*>(al);
+            w64 = ((((uint64_t)iq[1]) << 32) | iq[0]) >> (mis * 8u + (bit0 & 7u));
+          } else {                          // the section's last bytes
+            const uint32_t avail = (uint32_t)(src + src_size - ib);
+            for (uint32_t k = 0; k < 5u && k < avail; ++k) w64 |= ((uint64_t)ib[k]) << (8u * k);
+            w64 >>= (bit0 & 7u);
+          }
+        }
+        bool beyond = false;
+#pragma unroll
+        for (uint32_t i = 0; i < kFpPPT; ++i) {
+          const uint32_t idx = (uint32_t)(w64 >> (i * bits)) & ((1u << bits) - 1u);  // < kFastPalEntries
+          beyond = beyond || ((q0 + i) < npts && idx >= fs_count[a]);
+          pv[a][i] = pal[a * kFastPalEntries + idx];
+        }
+        if (beyond) misc[1] = 1u;  // index beyond the palette: the serial decoder redoes the sections and raises the error
+      }
+    }
     // local sums per lane with NaN resets, then the segmented scan over the threads
     int32_t acc[NOPS];
     uint32_t fl = 0u;
@@ -437,8 +471,11 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
 #pragma unroll
         for (int o = 0; o < NOPS; ++o) {
           in[o] = (int32_t)((uint32_t)in[o] + (uint32_t)dlt[i][o]);
-          stage[(q0 + i) * NOPS + (uint32_t)o] = __fmul_rn((float)in[o], res[o]);  // points >= npts: harmless slots, never read
+          stage[(q0 + i) * SP + (uint32_t)o] = __fmul_rn((float)in[o], res[o]);  // points >= npts: harmless slots, never read
         }
+#pragma unroll
+        for (uint32_t a = 0; a < kFastPalFields; ++a)
+          if (a < n_fold) stage[(q0 + i) * SP + (uint32_t)NOPS + a] = __uint_as_float(pv[a][i]);
         if (q0 + i + 1u == npts) {
 #pragma unroll
           for (int o = 0; o < NOPS; ++o) crec_next[o] = in[o];
@@ -452,8 +489,11 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
           const bool m = dlt[i][o] == (int32_t)0x80000000;
           in[o] = m ? 0 : (int32_t)((uint32_t)in[o] + (uint32_t)dlt[i][o]);
           const float f = m ? __uint_as_float(0x7fc00000u) : __fmul_rn((float)in[o], res[o]);
-          stage[(q0 + i) * NOPS + (uint32_t)o] = f;
+          stage[(q0 + i) * SP + (uint32_t)o] = f;
         }
+#pragma unroll
+        for (uint32_t a = 0; a < kFastPalFields; ++a)
+          if (a < n_fold) stage[(q0 + i) * SP + (uint32_t)NOPS + a] = __uint_as_float(pv[a][i]);
         if (q0 + i + 1u == npts) {
 #pragma unroll
           for (int o = 0; o < NOPS; ++o) crec_next[o] = in[o];
@@ -465,44 +505,19 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     // ---- read-out: consecutive lanes, consecutive points; folded Palette fields complete the point. The layout
     // decisions are uniform: one switch per tile picks a straight-line variant (the common lidar layouts get code
     // without a branch per point).
-    auto palette_value = [&](uint32_t a, uint32_t p, uint32_t& v) -> bool {  // folded field a of point p
-      uint32_t idx = 0u;
-      if (fs_bits[a]) {
-        const uint32_t bit = p * fs_bits[a];                       // < 32768 * 10
-        const uint8_t* ib = fs_idx[a] + (bit >> 3);
-        const uint32_t avail = (uint32_t)(src + src_size - ib);    // bytes left in the payload
-        uint32_t w;
-        if (avail >= 8u) {  // two aligned dwords cover byte 0..3 of the window wherever it starts
-          const uint32_t mis = (uint32_t)((uintptr_t)ib & 3u);
-          const uint32_t* iq = reinterpret_cast<const uint32_t*>(ib - mis);
-          w = __builtin_amdgcn_alignbyte(iq[1], iq[0], mis);
-        } else {            // the section's last bytes
-          w = ib[0];
-          if (avail > 1u) w |= (uint32_t)ib[1] << 8;
-          if (avail > 2u) w |= (uint32_t)ib[2] << 16;
-        }
-        idx = (w >> (bit & 7u)) & ((1u << fs_bits[a]) - 1u);
-      }
-      if (idx >= fs_count[a]) {
-        misc[1] = 1u;  // index beyond the palette: the serial decoder redoes the sections and raises the error
-        return false;
-      }
-      v = pal[a * kFastPalEntries + idx];
-      return true;
-    };
     auto store_floats_contig = [&](uint8_t* pt, uint32_t q) {
       if (NOPS == 3) {
         FloatVec<3> v;
-        v.v[0] = stage[q * 3u]; v.v[1] = stage[q * 3u + 1u]; v.v[2] = stage[q * 3u + 2u];
+        v.v[0] = stage[q * SP]; v.v[1] = stage[q * SP + 1u]; v.v[2] = stage[q * SP + 2u];
         *reinterpret_cast<FloatVec<3>*>(pt + foff[0]) = v;
       } else {
         FloatVec<4> v;
 #pragma unroll
-        for (int o = 0; o < 4; ++o) v.v[o] = stage[q * 4u + (uint32_t)o];
+        for (int o = 0; o < 4; ++o) v.v[o] = stage[q * SP + (uint32_t)o];
         *reinterpret_cast<FloatVec<4>*>(pt + foff[0]) = v;
       }
     };
-    const bool one_u16 = contig && n_fold == 1u && fs_bpv[0] == 2u && ((fs_off[0] | step) & 1u) == 0u;  // XYZ(I) + one 16-bit field
+    const bool one_u16 = NOPS == 3 && contig && n_fold == 1u && fs_bpv[0] == 2u && ((fs_off[0] | step) & 1u) == 0u;  // XYZ + one 16-bit field
     if (contig && n_fold == 0u) {
 #pragma unroll
       for (uint32_t r = 0; r < kFpPPT; ++r) {
@@ -515,9 +530,11 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
         const uint32_t q = r * (uint32_t)T + tid;
         if (q < npts) {
           uint8_t* pt = base + (size_t)(pts_done + q) * step;
-          store_floats_contig(pt, q);
-          uint32_t v;
-          if (palette_value(0u, pts_done + q, v)) *reinterpret_cast<uint16_t*>(pt + fs_off[0]) = (uint16_t)v;
+          const float4 sv = *reinterpret_cast<const float4*>(stage + q * 4u);  // x, y, z, field
+          FloatVec<3> v;
+          v.v[0] = sv.x; v.v[1] = sv.y; v.v[2] = sv.z;
+          *reinterpret_cast<FloatVec<3>*>(pt + foff[0]) = v;
+          *reinterpret_cast<uint16_t*>(pt + fs_off[0]) = (uint16_t)__float_as_uint(sv.w);
         }
       }
     } else {
@@ -525,24 +542,21 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
       for (uint32_t r = 0; r < kFpPPT; ++r) {
         const uint32_t q = r * (uint32_t)T + tid;
         if (q < npts) {
-          const uint32_t p = pts_done + q;  // point of the chunk
-          uint8_t* pt = base + (size_t)p * step;
+          uint8_t* pt = base + (size_t)(pts_done + q) * step;
           if (contig) {
             store_floats_contig(pt, q);
           } else {
 #pragma unroll
             for (int o = 0; o < NOPS; ++o)
-              if (foff[o] != 0xffffffffu) st_raw(pt + foff[o], __float_as_uint(stage[q * NOPS + (uint32_t)o]), 4);
+              if (foff[o] != 0xffffffffu) st_raw(pt + foff[o], __float_as_uint(stage[q * SP + (uint32_t)o]), 4);
           }
 #pragma unroll
           for (uint32_t a = 0; a < kFastPalFields; ++a) {
             if (a >= n_fold) break;  // uniform
-            uint32_t v;
-            if (palette_value(a, p, v)) {
-              if (fs_bpv[a] == 2u && ((fs_off[a] | step) & 1u) == 0u) *reinterpret_cast<uint16_t*>(pt + fs_off[a]) = (uint16_t)v;
-              else if (fs_bpv[a] == 4u && ((fs_off[a] | step) & 3u) == 0u) *reinterpret_cast<uint32_t*>(pt + fs_off[a]) = v;
-              else st_raw(pt + fs_off[a], v, fs_bpv[a]);
-            }
+            const uint32_t v = __float_as_uint(stage[q * SP + (uint32_t)NOPS + a]);
+            if (fs_bpv[a] == 2u && ((fs_off[a] | step) & 1u) == 0u) *reinterpret_cast<uint16_t*>(pt + fs_off[a]) = (uint16_t)v;
+            else if (fs_bpv[a] == 4u && ((fs_off[a] | step) & 3u) == 0u) *reinterpret_cast<uint32_t*>(pt + fs_off[a]) = v;
+            else st_raw(pt + fs_off[a], v, fs_bpv[a]);
           }
         }
       }
