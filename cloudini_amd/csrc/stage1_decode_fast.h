@@ -15,8 +15,9 @@
 // A tile starts exactly at a point boundary (the next tile begins behind the last token it consumed), so no point is
 // ever cut and nothing but the per-lane running values is carried between tiles.
 //
-// Sections: where the regular stream ends is not written anywhere, so a counting pre-pass over the token-end flags
-// finds it first. If every section of the chunk is a Palette with at most kFastPalEntries entries (intensity, ring,
+// Sections: where the regular stream ends is not written anywhere. With one adaptive field the place is guessed from
+// the end of the payload (a Palette section's size is a function of its entry count: all counts are tried, the guess is
+// checked against where the tiles really end); with two, a counting pre-pass over the token-end flags finds it. If every section of the chunk is a Palette with at most kFastPalEntries entries (intensity, ring,
 // reflectivity ... of real lidars), their tables go to LDS and every point is completed when it is written: x, y, z
 // and its integer fields together, so that each output line is written once by one workgroup (the separate section
 // kernel re-dirtied every 64-byte line: WRITE_SIZE was 1.97x the output). Other sections are left to
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     misc[0] = 0u;
     misc[1] = 0u;            // a folded Palette index was out of range
     misc[40] = 0xffffffffu;  // pre-pass: payload offset behind the regular stream
+    misc[42] = 0xffffffffu;  // entries of the Palette section found by its size (smallest hit)
     misc[64] = 0u;           // sections folded in
   }
   if (tid < (uint32_t)(NOPS + 2)) reinterpret_cast<uint32_t*>(scanrec + 16u * L::kWaveRec)[tid] = 0u;  // carry of tile 0: values 0
@@ -140,7 +142,28 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
   // payload; the wave that holds the last token walks its part again and finds the byte.
   // ---------------------------------------------------------------------------------------------------------
   uint32_t reg_size = 0xffffffffu;
-  if (uses_v5 && plan.n_adaptive != 0u) {
+  const bool v5_sections = uses_v5 && plan.n_adaptive != 0u;
+  bool located = false;
+  if (v5_sections && plan.n_adaptive == 1u && plan.adaptive[0].bpv <= 4u) {
+    // One section behind the regular stream. If it is a Palette of U entries its size follows from U alone
+    // (3 + U * bpv + ceil(bits(U) * n / 8)), so every U has one place where its header would have to be: the threads
+    // try them all. A hit that is no header (3 bytes of a token stream that look like one) is found out when the
+    // tiles end somewhere else: the chunk's sections are then left to the section kernels, like any chunk without a
+    // hit. This spares the counting pass over the whole payload.
+    const uint32_t bpv = plan.adaptive[0].bpv;
+    for (uint32_t U = tid + 1u; U <= kFastPalEntries; U += (uint32_t)T) {
+      const uint64_t S = 3ull + (uint64_t)U * bpv + ((uint64_t)palette_bits(U) * n + 7u) / 8u;
+      if (S <= src_size) {
+        const uint8_t* h = src + (src_size - (uint32_t)S);
+        if (h[0] == 1u && ((uint32_t)h[1] | ((uint32_t)h[2] << 8)) == U) atomicMin(&misc[42], U);
+      }
+    }
+    __syncthreads();
+    const uint32_t U = misc[42];
+    if (U != 0xffffffffu) reg_size = src_size - (uint32_t)(3ull + (uint64_t)U * bpv + ((uint64_t)palette_bits(U) * n + 7u) / 8u);
+    located = true;
+  }
+  if (v5_sections && !located) {
     const uint32_t part = (((src_size + 15u) / 16u + NW - 1u) / NW) * 16u;  // bytes per wave, multiple of 16
     const uint32_t w0 = wave * part, w1 = min(src_size, w0 + part);
     uint32_t cnt = 0u;
@@ -180,6 +203,8 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     if (target == 0u && tid == 0) misc[40] = 0u;
     __syncthreads();
     reg_size = misc[40];
+  }
+  if (v5_sections) {
 
     // section headers (one thread): every section a small Palette of a 2- or 4-byte field -> fold them in
     if (tid == 0 && reg_size != 0xffffffffu && plan.n_adaptive <= kFastPalFields) {
@@ -253,11 +278,11 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
   uint32_t pts_done = 0u;
   uint32_t par = 0u;       // which carry record this tile reads (it writes the other one)
   bool bad = false;
+  uint32_t b[4];           // my 16 bytes of the tile (those of the next tile are fetched while this one is decoded)
+  fp_load16(src, src_size, tid * 16u, b);
   while (pts_done < n) {
     if (pos >= src_size) { bad = true; break; }
     // ---- phase A: bytes -> LDS; the byte where every point starts -> list
-    uint32_t b[4];
-    fp_load16(src, src_size, pos + tid * 16u, b);
     *reinterpret_cast<uint4*>(tile + 4u + tid * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
     const uint32_t ends = fp_ends16(b);
     uint32_t n_tile;
@@ -287,6 +312,7 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     const uint32_t npts = min(n_tile / (uint32_t)NOPS, want_pts);  // whole points of this tile
     if (npts == 0u) { bad = true; break; }           // 16 KiB without NOPS token ends: not a FloatN stream
     const uint32_t next_pos = pos + (uint32_t)pos_list[npts];  // behind the last token this tile consumes
+    if (pts_done + npts < n) fp_load16(src, src_size, next_pos + tid * 16u, b);  // (`ends` is all this tile still needs of b)
 
     // ---- phase B: my points [q0, q0 + kFpPPT)
     const uint32_t q0 = tid * kFpPPT;

@@ -284,3 +284,29 @@ def test_run_length_that_wraps_the_bound_check_is_rejected(oracle, mode):
     good = oracle.encode_stage1(info, _data)
     assert np.array_equal(codec.decode_host([good], [n])[0], oracle.decode_stage1(info, good, n))
     codec.close()
+
+
+@pytest.mark.parametrize("field", ["palette3", "growing"])
+def test_section_guess_with_a_false_hit_in_the_token_stream(oracle, field):
+    """k_decode_points finds the one section of a chunk by trying every Palette size from the end of the payload. A
+    cloud that stands still has a regular stream of 0x01 bytes: the three bytes 01 01 01 read as a Palette header of
+    257 entries wherever the 257-entry guess lands. With a real 3-entry Palette behind the stream the smaller (real)
+    hit must win and the section is folded; with a section in another mode the false hit is all there is, and the kernel
+    must notice that its tiles end elsewhere and leave the section to the section kernels. Either way the bytes are
+    the oracle's (decodeV5AdaptiveIntSection, src/v5_codec.cpp:764-879)."""
+    from cloudini_amd.schema import FieldType as F
+    n = 20000
+    fields = [("x", 0, F.FLOAT32, 0.001), ("y", 4, F.FLOAT32, 0.001), ("z", 8, F.FLOAT32, 0.001), ("i", 12, F.UINT16, None)]
+    info = cases.make_info(fields, 16, n)
+    rs = np.random.RandomState(5)
+    vals = (rs.randint(0, 3, n) * 11).astype(np.uint16) if field == "palette3" else (np.arange(n) * 3 % 60000).astype(np.uint16)
+    data = cases.pack(info, {"x": np.full(n, 1.5, np.float32), "y": np.full(n, -2.25, np.float32),
+                             "z": np.full(n, 0.75, np.float32), "i": vals}, n)
+    stream, modes = oracle.encode_stage1(info, data, return_modes=True)
+    payload = _split_chunks(stream)[0]
+    assert (modes.tolist() == [1]) == (field == "palette3")   # "growing": a run-length mode, anything but Palette
+    # the 257-entry guess really lands on 01 01 01 inside the token stream
+    guess = len(payload) - (3 + 257 * 2 + (9 * n + 7) // 8)
+    assert 3 < guess < 3 * n - 3 and bytes(payload[guess:guess + 3]) == b"\x01\x01\x01"
+    stats, _modes, n_chunks = _stats_after_decode(oracle, info, data)
+    assert stats == (n_chunks, n_chunks, 0, 0)
