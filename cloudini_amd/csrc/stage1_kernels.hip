@@ -910,14 +910,37 @@ __global__ __launch_bounds__(T) void k_encode_floatn(const DevPlan plan, const u
 
 // ------------------------------------------------------------------------------------------------------------
 // k_gorilla_tokens: FieldEncoderFloat_Gorilla<double> (include/cloudini_lib/field_encoder.hpp:156-312). The codec
-// keeps a (leading, trailing) bit window that only changes at "new window" points, so one wave per chunk walks
-// 64 points at a time: every lane XORs with its predecessor and assumes the current window; the lowest lane that
-// would open a new window is resolved, the window is updated, and only the lanes behind it re-check. The bytes of
-// every point (the reference flushes to a byte boundary per point) are stored as a 16-byte token for
-// k_encode_regular to place. grid = (n_chunks, n_gorilla), block = 64.
+// keeps a (leading, trailing) bit window that only changes at "new window" points; everything else about a point
+// (its XOR with the predecessor, the bits it writes once the window is known) is independent of the other points.
+// One workgroup per chunk works in passes of kGorPass points:
+//   1. all threads load their points and the predecessors, XOR, count leading / trailing zero bits -> LDS (2 bytes);
+//   2. wave 0 alone walks the pass 64 points at a time: every lane assumes the current window, the lowest lane that
+//      would open a new one is resolved, the window is updated, and only the lanes behind it re-check; each point's
+//      window (and whether it opened it) goes back to LDS;
+//   3. all threads build the bytes of their points (the reference flushes to a byte boundary per point) and store
+//      them as 16-byte tokens for k_encode_regular to place.
+// Only step 2 is serial, and it touches nothing but LDS. grid = (n_chunks, n_gorilla), block = kGorThreads.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_gorilla_tokens(const DevPlan plan, const uint8_t* __restrict__ points,
-                                                       const ChunkDesc* __restrict__ chunks, uint4* const* out_tokens) {
+constexpr uint32_t kGorThreads = 512;
+constexpr uint32_t kGorPPT = 16;
+constexpr uint32_t kGorPass = kGorThreads * kGorPPT;  // 8192 points per pass
+
+// the 8 bytes at p (any alignment); `end` = first byte that must not be read
+__device__ __forceinline__ uint64_t gor_load64(const uint8_t* p, const uint8_t* end) {
+  const uint32_t mis = (uint32_t)((uintptr_t)p & 3u);
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p - mis);
+  const uint32_t d0 = q[0], d1 = q[1];
+  const uint32_t d2 = (mis != 0u && reinterpret_cast<const uint8_t*>(q + 2) < end) ? q[2] : 0u;
+  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, mis);
+  const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, mis);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(kGorThreads) void k_gorilla_tokens(const DevPlan plan, const uint8_t* __restrict__ points,
+                                                                const uint8_t* __restrict__ points_end,
+                                                                const ChunkDesc* __restrict__ chunks,
+                                                                uint4* const* out_tokens) {
+  __shared__ uint16_t lt[kGorPass];  // in: lead | trail << 8 (lead 64 = no difference); out: window + bit 15 "opens"
   // find the blockIdx.y-th Gorilla op
   uint32_t opi = 0, seen = 0;
   for (; opi < plan.n_ops; ++opi) {
@@ -926,82 +949,106 @@ __global__ __launch_bounds__(64) void k_gorilla_tokens(const DevPlan plan, const
       ++seen;
     }
   }
-  const DevOp& op = plan.ops[opi];
+  const uint32_t field_off = plan.ops[opi].offset;
   const ChunkDesc cd = chunks[blockIdx.x];
   const uint32_t n = cd.n_points;
   const uint32_t step = plan.point_step;
-  const uint32_t lane = threadIdx.x;
-  const uint8_t* base = points + (size_t)cd.first_point * step + op.offset;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint8_t* base = points + (size_t)cd.first_point * step + field_off;
   uint4* out = out_tokens[blockIdx.y] + cd.first_point;
 
-  uint32_t win_lead = 255u, win_trail = 0u;  // kLeadingSentinel: no window yet
-  uint64_t carry = 0u;                       // bits of the last point of the previous batch
-  for (uint32_t b0 = 0; b0 < n; b0 += 64u) {
-    const uint32_t i = b0 + lane;
-    const bool valid = i < n;
-    uint64_t cur = 0u;
-    if (valid) {
-      const uint8_t* q = base + (size_t)i * step;
-      for (int b = 0; b < 8; ++b) cur |= ((uint64_t)q[b]) << (8 * b);
+  uint32_t win_lead = 255u, win_trail = 0u;  // kLeadingSentinel: no window yet (wave 0 keeps the state)
+  for (uint32_t p0 = 0; p0 < n; p0 += kGorPass) {
+    // ---- 1: XOR with the predecessor (point 0 of the chunk has none: written raw)
+    uint64_t cur[kGorPPT], x[kGorPPT];
+#pragma unroll
+    for (uint32_t k = 0; k < kGorPPT; ++k) {
+      const uint32_t i = p0 + k * kGorThreads + tid;
+      cur[k] = 0u;
+      x[k] = 0u;
+      if (i < n) {
+        const uint8_t* q = base + (size_t)i * step;
+        cur[k] = gor_load64(q, points_end);
+        const uint64_t prev = i ? gor_load64(q - step, points_end) : 0u;
+        x[k] = cur[k] ^ prev;
+      }
+      const uint32_t lead = x[k] ? (uint32_t)__builtin_clzll(x[k]) : 64u;
+      const uint32_t trail = x[k] ? (uint32_t)__builtin_ctzll(x[k]) : 0u;
+      lt[k * kGorThreads + tid] = (uint16_t)(lead | (trail << 8));
     }
-    uint64_t prev = __shfl_up((unsigned long long)cur, 1);
-    if (lane == 0u) prev = carry;
-    carry = __shfl((unsigned long long)cur, 63);
-    const uint64_t x = cur ^ prev;
-    const uint32_t lead = x ? (uint32_t)__builtin_clzll(x) : 64u;
-    const uint32_t trail = x ? (uint32_t)__builtin_ctzll(x) : 64u;
-
-    // window in effect before my point, and whether my point opens a new one
-    bool pending = valid && i > 0u && x != 0u;
-    bool opens = false;
-    uint32_t my_lead = win_lead, my_trail = win_trail;
-    for (;;) {
-      const bool would_open = pending && (win_lead == 255u || lead < win_lead || trail < win_trail);
-      const uint64_t ev = __ballot(would_open);
-      if (ev == 0ull) {
-        if (pending) {
-          my_lead = win_lead;
-          my_trail = win_trail;
+    __syncthreads();
+    // ---- 2: the windows (wave 0)
+    if (tid < 64u) {
+      const uint32_t np = min(kGorPass, n - p0);
+      for (uint32_t b0 = 0; b0 < np; b0 += 64u) {
+        const uint32_t j = b0 + lane;
+        const uint32_t e16 = lt[j];
+        const uint32_t lead = e16 & 0xffu, trail = e16 >> 8;
+        bool pending = j < np && (p0 + j) > 0u && lead != 64u;
+        bool opens = false;
+        uint32_t my_lead = win_lead, my_trail = win_trail;
+        for (;;) {
+          const bool would_open = pending && (win_lead == 255u || lead < win_lead || trail < win_trail);
+          const uint64_t ev = __ballot(would_open);
+          if (ev == 0ull) {
+            if (pending) {
+              my_lead = win_lead;
+              my_trail = win_trail;
+            }
+            break;
+          }
+          const uint32_t e = (uint32_t)__builtin_ctzll(ev);
+          if (pending && lane <= e) {
+            my_lead = win_lead;
+            my_trail = win_trail;
+            opens = (lane == e);
+            pending = false;
+          }
+          const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)lead, (int)e);
+          const uint32_t te = (uint32_t)__builtin_amdgcn_readlane((int)trail, (int)e);
+          win_lead = le > 31u ? 31u : le;
+          win_trail = te;
         }
-        break;
+        // a point that does not open one writes inside (my_lead <= 31, my_trail <= 63); an opener uses its own counts
+        lt[j] = (uint16_t)((my_lead & 0x3fu) | ((my_trail & 0x7fu) << 6) | (opens ? 0x8000u : 0u));
       }
-      const uint32_t e = (uint32_t)__builtin_ctzll(ev);
-      if (pending && lane <= e) {
-        my_lead = win_lead;
-        my_trail = win_trail;
-        opens = (lane == e);
-        pending = false;
-      }
-      const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)lead, (int)e);
-      const uint32_t te = (uint32_t)__builtin_amdgcn_readlane((int)trail, (int)e);
-      win_lead = le > 31u ? 31u : le;
-      win_trail = te;
     }
-
-    if (valid) {
-      uint64_t lo = 0u, hi = 0u;
-      uint32_t nbits;
-      if (i == 0u) {  // first value of the chunk: raw 64 bits
-        lo = cur;
-        nbits = 64u;
-      } else if (x == 0u) {
-        nbits = 1u;  // single '0' bit
-      } else if (!opens) {
-        const uint32_t m = 64u - my_lead - my_trail;  // '1','0', m bits of (x >> trailing)
-        const uint64_t payload = x >> my_trail;
-        lo = 1u | (payload << 2);
-        hi = payload >> 62;
-        nbits = 2u + m;
-      } else {
-        const uint32_t sl = lead > 31u ? 31u : lead;  // '1','1', leading(5), m-1 (6), m bits of (x >> trailing)
-        const uint32_t m = 64u - sl - trail;
-        const uint64_t payload = x >> trail;
-        lo = 3u | ((uint64_t)sl << 2) | ((uint64_t)(m - 1u) << 7) | (payload << 13);
-        hi = payload >> 51;
-        nbits = 13u + m;
+    __syncthreads();
+    // ---- 3: the bytes of every point
+#pragma unroll
+    for (uint32_t k = 0; k < kGorPPT; ++k) {
+      const uint32_t i = p0 + k * kGorThreads + tid;
+      if (i < n) {
+        const uint32_t w16 = lt[k * kGorThreads + tid];
+        const uint64_t xx = x[k];
+        uint64_t lo = 0u, hi = 0u;
+        uint32_t nbits;
+        if (i == 0u) {  // first value of the chunk: raw 64 bits
+          lo = cur[k];
+          nbits = 64u;
+        } else if (xx == 0u) {
+          nbits = 1u;  // single '0' bit
+        } else if (!(w16 & 0x8000u)) {
+          const uint32_t my_lead = w16 & 0x3fu, my_trail = (w16 >> 6) & 0x7fu;
+          const uint32_t m = 64u - my_lead - my_trail;  // '1','0', m bits of (x >> trailing)
+          const uint64_t payload = xx >> my_trail;
+          lo = 1u | (payload << 2);
+          hi = payload >> 62;
+          nbits = 2u + m;
+        } else {
+          const uint32_t lead = (uint32_t)__builtin_clzll(xx), trail = (uint32_t)__builtin_ctzll(xx);
+          const uint32_t sl = lead > 31u ? 31u : lead;  // '1','1', leading(5), m-1 (6), m bits of (x >> trailing)
+          const uint32_t m = 64u - sl - trail;
+          const uint64_t payload = xx >> trail;
+          lo = 3u | ((uint64_t)sl << 2) | ((uint64_t)(m - 1u) << 7) | (payload << 13);
+          hi = payload >> 51;
+          nbits = 13u + m;
+        }
+        out[i] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (nbits + 7u) >> 3);
       }
-      out[i] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (nbits + 7u) >> 3);
     }
+    __syncthreads();  // lt is rewritten by the next pass
   }
 }
 
@@ -2051,8 +2098,8 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   }
   if (L.events) (void)hipEventRecord(L.events[1], L.stream);
   if (L.n_chunks && L.plan->n_gorilla) {
-    hipLaunchKernelGGL(k_gorilla_tokens, dim3(L.n_chunks, L.plan->n_gorilla), dim3(64), 0, L.stream, *L.plan, L.points,
-                       L.chunks, L.pre_out);
+    hipLaunchKernelGGL(k_gorilla_tokens, dim3(L.n_chunks, L.plan->n_gorilla), dim3(kGorThreads), 0, L.stream, *L.plan,
+                       L.points, L.points_end, L.chunks, L.pre_out);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_gorilla_tokens");
   }
   if (L.n_chunks && L.pieces) {  // slot pipeline, regular stream by the barrier-free piece kernel
