@@ -471,7 +471,11 @@ def main():
             else:
                 break
         rest_adaptive = all(int(f.type) in (3, 4, 5, 6, 9, 10) for f in info.fields[lead:])
-        dominant = "k_encode_floatn" if lead in (3, 4) and rest_adaptive and int(info.version) >= 5 else "k_encode_regular"
+        floatn = lead in (3, 4) and rest_adaptive and int(info.version) >= 5
+        # which kernel that is follows the codec's pipeline for this buffer (cldn_hip_codec_pipeline): the piece kernel
+        # k_encode_fused (slot mode) by default, the tile kernel k_encode_floatn with pipeline 1
+        pipeline = codec.pipeline(0, d_points.data_ptr())
+        dominant = ("k_encode_fused" if pipeline >= 2 else "k_encode_floatn") if floatn else "k_encode_regular"
         # HBM bytes per launch of the same kernel from the PMC passes of tools/profile_round.sh (rocprofv3 cannot
         # collect counters from inside this process); only quoted when the committed pass ran this very workload
         traffic, traffic_src = None, None
