@@ -11,7 +11,7 @@ run() {  # name, rocprofv3 args...
   local name=$1; shift
   rm -rf /tmp/prof_$name
   rocprofv3 "$@" -d /tmp/prof_$name -o trace -- $BENCH > /tmp/prof_$name.log 2>&1
-  tail -1 /tmp/prof_$name.log > $OUT/prof_${TAG}_${name}_bench.json
+  grep "^{\"metric\"" /tmp/prof_$name.log | tail -1 > $OUT/prof_${TAG}_${name}_bench.json
   local db=$(find /tmp/prof_$name -name "*.db" | head -1)
   { echo "# rocprofv3 $* -- $BENCH"; python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $db --filter cldn; } > $OUT/prof_${TAG}_${name}.txt
 }
