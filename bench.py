@@ -221,6 +221,18 @@ def e2e_figures(info, cloud, dev, budget_s: float):
                                 "threads": "1 encode thread + the reference's own stage-2 worker (use_threads=true)",
                                 "bracket": "encoder constructed outside the timed region, pre-sized output"}
         out["host_mirror_" + comp.name] = leg
+        if comp == CompressionOption.LZ4 and hasattr(api, "set_stage2_threads"):
+            # the same call with the stage-2 knob at 16 threads (the box grants 16 CPUs): from 8 threads on encode() cuts
+            # the cloud into two chunk groups and compresses the first while the GPU encodes the second
+            api.set_stage2_threads(16)
+            try:
+                leg16 = timed(mirror_call)
+            finally:
+                api.set_stage2_threads(pool_threads or 4)
+            leg16["bytes"] = int(size_box[0])
+            leg16["stage2_threads"] = 16
+            leg16["bracket"] = leg["bracket"] + "; CLOUDINI_AMD_STAGE2_THREADS=16, chunk-group pipeline (2 groups)"
+            out["host_mirror_LZ4_16_threads"] = leg16
     return out
 
 

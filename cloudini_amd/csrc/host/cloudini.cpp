@@ -252,7 +252,39 @@ class WorkerPool {
     if (job->error) std::rethrow_exception(job->error);
   }
 
- private:
+  struct Job;
+  // Asynchronous form of run(): at most `helpers` pool threads start on the job right away, the caller goes on with
+  // something else (the next chunk group's GPU call) and joins in finish(). `fn` is copied into the job; whatever it
+  // refers to must stay alive until finish() has returned.
+  std::shared_ptr<Job> submit(size_t n, unsigned helpers, std::function<void(size_t)> fn) {
+    auto job = std::make_shared<Job>();
+    job->fn = std::move(fn);
+    job->n = n;
+    job->pending = n;
+    const size_t h = std::min<size_t>(helpers, n);
+    if (h) {
+      {
+        std::lock_guard<std::mutex> lock(mutex_);
+        for (size_t k = 0; k < h; ++k) queue_.push_back(job);
+      }
+      if (h == 1) wake_.notify_one();
+      else wake_.notify_all();
+    }
+    return job;
+  }
+  // the caller takes part in what is left of the job, waits for the rest, and gets the first error (if any) back
+  std::exception_ptr finish(const std::shared_ptr<Job>& job) {
+    if (job->n) {
+      drain(*job);
+      std::unique_lock<std::mutex> lock(job->mutex);
+      job->done.wait(lock, [&] { return job->pending == 0; });
+    }
+    std::lock_guard<std::mutex> lock(mutex_);
+    for (auto it = queue_.begin(); it != queue_.end();) it = (*it == job) ? queue_.erase(it) : it + 1;
+    return job->error;
+  }
+
+ public:
   struct Job {
     std::function<void(size_t)> fn;
     size_t n = 0;
@@ -262,6 +294,8 @@ class WorkerPool {
     size_t pending = 0;
     std::exception_ptr error;
   };
+
+ private:
   static void drain(Job& job) {
     for (;;) {
       const size_t i = job.next.fetch_add(1);
@@ -582,6 +616,123 @@ PointcloudEncoder::~PointcloudEncoder() {
   if (impl_ && impl_->codec) pool().release(info_, impl_->codec);
 }
 
+// Chunk-group pipeline of one encode() call (the reference double-buffers chunk k's compression against chunk k+1's
+// encoding, src/cloudini.cpp:453-499, :572-588): the cloud is cut into groups of whole chunks; while the stage-2 pool
+// compresses the chunks of group g, the calling thread runs group g+1 through the GPU (H2D, kernels, D2H). The
+// adaptive-int modes are a property of the cloud's first <= 4096 points (src/v5_codec.cpp:934-949): group 0 decides
+// them, the later groups are encoded with those modes forced (cldn_hip_codec_force_modes), which yields exactly the
+// chunks of a whole-cloud call.
+// [u32 size][compressed chunk] in chunk order (src/chunk_writer.cpp:41-47) from the per-chunk scratch slots; the copies
+// run on the stage-2 threads (6 MB through one core is 0.3-0.5 ms of a 1.2 ms call)
+static size_t layOutChunks(const std::vector<uint32_t>& packed_size, const uint8_t* scratch, size_t slot, uint8_t* dst,
+                           size_t dst_cap, unsigned workers) {
+  const size_t n_chunks = packed_size.size();
+  std::vector<size_t> at(n_chunks + 1, 0);
+  for (size_t c = 0; c < n_chunks; ++c) at[c + 1] = at[c] + 4u + packed_size[c];
+  if (at[n_chunks] > dst_cap) throw std::runtime_error("Output buffer too small for compressed chunk");
+  auto place = [&](size_t c) {
+    const uint32_t n = packed_size[c];
+    std::memcpy(dst + at[c], &n, 4);
+    std::memcpy(dst + at[c] + 4, scratch + c * slot, n);
+  };
+  if (workers > 1u && at[n_chunks] > (size_t(1) << 20)) stage2Pool().run(n_chunks, workers - 1u, place);
+  else
+    for (size_t c = 0; c < n_chunks; ++c) place(c);
+  return at[n_chunks];
+}
+
+constexpr size_t kPipelineMinChunks = 8;
+constexpr size_t kPipelineMaxGroups = 8;
+
+// Number of chunk groups: CLOUDINI_AMD_PIPELINE=n (2..8; 0 or 1 = never); without it, 2 groups when the call has at
+// least 8 stage-2 threads and none below. Measured on MI355X (one 1 M-point XYZI cloud, LZ4, median ms per encode()):
+//   stage-2 threads   off    2 groups   3 groups   4 groups
+//          4          2.46     2.67       2.50       2.93
+//         16          1.40     1.17       1.27       1.63
+// Stage 1 is 0.5 ms of a call that stage 2 dominates, and every extra synchronous GPU call costs 0.1-0.15 ms (launch-bound
+// kernels, another round of copies): the earlier start of stage 2 only pays when there are threads to use it.
+static size_t pipelineGroups(unsigned workers) {
+  static const long env = [] {
+    const char* e = std::getenv("CLOUDINI_AMD_PIPELINE");
+    return e ? std::strtol(e, nullptr, 10) : -1L;
+  }();
+  if (env >= 0) return size_t(env < 2 ? 0 : std::min<long>(env, long(kPipelineMaxGroups)));
+  return workers >= 8u ? 2u : 0u;
+}
+
+size_t PointcloudEncoder::encodePipelined(ConstBufferView cloud_data, uint64_t points, size_t n_chunks, unsigned workers,
+                                          uint8_t* dst, size_t dst_cap, std::vector<uint8_t>& stage1,
+                                          std::vector<uint8_t>& stage2) {
+  const size_t n_groups = std::min(pipelineGroups(workers), n_chunks / (kPipelineMinChunks / 2));
+  const uint32_t na = cldn_hip_plan_adaptive_fields(impl_->plan->plan);
+  const size_t step = info_.point_step;
+  // staging: every group's framed stream behind the previous one; a worst-case slot per chunk for stage 2
+  std::vector<size_t> g_chunk0(n_groups + 1);
+  uint64_t s1_need = 0;
+  for (size_t g = 0; g <= n_groups; ++g) g_chunk0[g] = n_chunks * g / n_groups;
+  for (size_t g = 0; g < n_groups; ++g) {
+    const uint64_t p0 = uint64_t(g_chunk0[g]) * kPointsPerChunk, p1 = std::min<uint64_t>(points, uint64_t(g_chunk0[g + 1]) * kPointsPerChunk);
+    s1_need += cldn_hip_stage1_bound(impl_->plan->plan, p1 - p0);
+  }
+  if (stage1.size() < s1_need) stage1.resize(s1_need);
+  const size_t chunk_bound = size_t(cldn_hip_stage1_bound(impl_->plan->plan, kPointsPerChunk));
+  const size_t slot = amd_detail::compressedChunkBound(info_.compression_opt, chunk_bound);
+  if (stage2.size() < slot * n_chunks) stage2.resize(slot * n_chunks);
+  uint8_t* s1 = stage1.data();
+  uint8_t* scratch = stage2.data();
+  std::vector<uint32_t> packed_size(n_chunks);
+  std::vector<size_t> src_off(n_chunks);
+  std::vector<uint8_t> modes(std::max<uint32_t>(1u, na));
+
+  struct Guard {  // whatever happens: no job refers to this frame afterwards, and the codec probes again next time
+    WorkerPool& pool;
+    cldn_hip_codec_t* codec;
+    std::vector<std::shared_ptr<WorkerPool::Job>> jobs;
+    std::exception_ptr finishAll() {
+      std::exception_ptr first;
+      for (auto& j : jobs) {
+        std::exception_ptr e = pool.finish(j);
+        if (e && !first) first = e;
+      }
+      jobs.clear();
+      return first;
+    }
+    ~Guard() {
+      (void)finishAll();
+      (void)cldn_hip_codec_force_modes(codec, nullptr, 0);
+    }
+  } guard{stage2Pool(), impl_->codec, {}};
+
+  const CompressionOption opt = info_.compression_opt;
+  const uint32_t* chunk_sizes = impl_->chunk_sizes.data();
+  size_t s1_pos = 0;
+  for (size_t g = 0; g < n_groups; ++g) {
+    const size_t c0 = g_chunk0[g], c1 = g_chunk0[g + 1];
+    const uint64_t p0 = uint64_t(c0) * kPointsPerChunk, p1 = std::min<uint64_t>(points, uint64_t(c1) * kPointsPerChunk);
+    const uint64_t gp = p1 - p0;
+    if (g == 1 && na && cldn_hip_codec_force_modes(impl_->codec, modes.data(), na) != CLDN_HIP_OK)
+      throw std::runtime_error(cldn_hip_last_error());
+    uint64_t offsets[2] = {0, 0};
+    if (cldn_hip_encode_stage1(impl_->codec, cloud_data.data() + p0 * step, CLDN_HIP_HOST, &gp, 1, s1 + s1_pos,
+                               stage1.size() - s1_pos, CLDN_HIP_HOST, offsets, impl_->chunk_sizes.data() + c0,
+                               g == 0 ? modes.data() : nullptr) != CLDN_HIP_OK)
+      throw std::runtime_error(cldn_hip_last_error());
+    size_t pos = s1_pos;
+    for (size_t c = c0; c < c1; ++c) {
+      src_off[c] = pos + 4;
+      pos += 4 + chunk_sizes[c];
+    }
+    s1_pos += size_t(offsets[1]);
+    // stage 2 of this group starts now; the last group is taken up by this thread as well (finish below)
+    guard.jobs.push_back(guard.pool.submit(c1 - c0, workers - 1u, [=, &packed_size, &src_off](size_t i) {
+      const size_t c = c0 + i;
+      packed_size[c] = compressChunk(opt, s1 + src_off[c], chunk_sizes[c], scratch + c * slot, slot);
+    }));
+  }
+  if (std::exception_ptr e = guard.finishAll()) std::rethrow_exception(e);
+  return layOutChunks(packed_size, scratch, slot, dst, dst_cap, workers);
+}
+
 size_t PointcloudEncoder::encode(ConstBufferView cloud_data, std::vector<uint8_t>& output) {
   if (info_.point_step == 0) throw std::runtime_error("point_step cannot be 0");
   if (cloud_data.size() % info_.point_step != 0)
@@ -634,6 +785,10 @@ size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output,
     s1_cap = tl_stage1.size();
   }
   impl_->chunk_sizes.resize(n_chunks);
+  const unsigned workers = (info_.use_threads && n_chunks > 1) ? std::min<unsigned>(stage2Threads(), unsigned(n_chunks)) : 1u;
+  if (!direct && workers > 1u && n_chunks >= kPipelineMinChunks && pipelineGroups(workers) >= 2u)
+    return written + encodePipelined(cloud_data, points, n_chunks, workers, dst + written, output.size() - written,
+                                     tl_stage1, tl_stage2);
   uint64_t offsets[2] = {0, 0};
   if (cldn_hip_encode_stage1(impl_->codec, cloud_data.data(), CLDN_HIP_HOST, &points, 1, s1, s1_cap, CLDN_HIP_HOST,
                              offsets, impl_->chunk_sizes.data(), nullptr) != CLDN_HIP_OK)
@@ -650,7 +805,6 @@ size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output,
       pos += 4 + impl_->chunk_sizes[c];
     }
   }
-  const unsigned workers = (info_.use_threads && n_chunks > 1) ? std::min<unsigned>(stage2Threads(), unsigned(n_chunks)) : 1u;
   if (workers <= 1) {
     for (size_t c = 0; c < n_chunks; ++c) {
       uint8_t* size_ptr = dst + written;
@@ -678,14 +832,7 @@ size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output,
   if (timing)
     std::fprintf(stderr, "[cloudini_amd] stage 2: %zu chunks, %.3f ms on up to %u threads\n", n_chunks,
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), workers);
-  for (size_t c = 0; c < n_chunks; ++c) {
-    const uint32_t n = packed_size[c];
-    if (output.size() - written < 4u + n) throw std::runtime_error("Output buffer too small for compressed chunk");
-    std::memcpy(dst + written, &n, 4);
-    std::memcpy(dst + written + 4, scratch + c * slot, n);
-    written += 4 + n;
-  }
-  return written;
+  return written + layOutChunks(packed_size, scratch, slot, dst + written, output.size() - written, workers);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -86,6 +86,9 @@ class PointcloudEncoder {
 
  private:
   struct Impl;
+  // chunk-group pipeline of encode(): stage 2 of group g next to the GPU's work on group g + 1 (host/cloudini.cpp)
+  size_t encodePipelined(ConstBufferView cloud_data, uint64_t points, size_t n_chunks, unsigned workers, uint8_t* dst,
+                         size_t dst_cap, std::vector<uint8_t>& stage1, std::vector<uint8_t>& stage2);
   EncodingInfo info_;
   std::vector<uint8_t> header_;
   std::unique_ptr<Impl> impl_;

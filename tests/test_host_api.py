@@ -120,6 +120,37 @@ def test_full_stream_none_equals_reference(reflib, name, info, data):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("comp", [CompressionOption.LZ4, CompressionOption.ZSTD])
+def test_chunk_group_pipeline_equals_reference(reflib, comp):
+    """Clouds of 8 chunks and more go through the chunk-group pipeline of PointcloudEncoder::encode (stage 2 of group g
+    next to the GPU's work on group g + 1, later groups with the modes of the cloud's head forced): 2, 3 and 4 groups,
+    with and without adaptive fields, a ragged last chunk, the generic kernel -- the stream must still be the
+    reference's (src/cloudini.cpp:572-588)."""
+    before = api.stage2_threads()
+    api.set_stage2_threads(8)  # the pipeline is taken from 8 stage-2 threads on (CLOUDINI_AMD_PIPELINE=n forces n groups)
+    try:
+        _pipeline_cases(reflib, comp)
+    finally:
+        api.set_stage2_threads(before)
+
+
+def _pipeline_cases(reflib, comp):
+    for info, data in (synth.lidar_xyzi(300_001), synth.velodyne_xyzir(600_000, seed=9), synth.lidar_xyz(1_000_000),
+                       synth.depthcam_xyzrgba(640, 480), cases.mixed_schema(280_000, 5)):
+        info = info.copy(compression_opt=comp, use_threads=True)
+        enc = api.PointcloudEncoder(info)
+        want = reflib.encode(info, data)
+        for _ in range(2):  # the second call reuses the codec: the forced modes must not leak into it
+            got = enc.encode(data)
+            assert np.array_equal(got, want)
+        # a short cloud through the same encoder's schema afterwards: probes its own modes again
+        n_small = 5000
+        small = data[: n_small * info.point_step]
+        info_s = info.copy(width=n_small, height=1)
+        assert np.array_equal(api.PointcloudEncoder(info_s).encode(small), reflib.encode(info_s, small))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("comp", [CompressionOption.LZ4, CompressionOption.ZSTD])
 @pytest.mark.parametrize("threads", [False, True])
 def test_stage2_streams_equal_reference(reflib, comp, threads):
     """Both sides link the same liblz4 / libzstd here, so even the compressed bytes must agree."""
