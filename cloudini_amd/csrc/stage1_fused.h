@@ -42,6 +42,11 @@ __host__ __device__ constexpr uint32_t fused_piece_points(int lanes) { return fu
 __host__ __device__ constexpr uint32_t fused_region_bytes(int lanes) {
   return ((fused_piece_points(lanes) * 5u * (uint32_t)lanes + 15u) & ~15u) + 32u;
 }
+// ... with one more token of up to kTailMaxBytes behind the FloatN tokens of every point (TAIL instantiations)
+constexpr uint32_t kTailMaxBytes = 10;  // varint of an int64 delta, Gorilla token (13 + 64 bits), raw 8 bytes
+__host__ __device__ constexpr uint32_t fused_region_bytes_tail(int lanes) {
+  return ((fused_piece_points(lanes) * (5u * (uint32_t)lanes + kTailMaxBytes) + 15u) & ~15u) + 32u;
+}
 
 // look-back record: [63:62] state, [61:0] value
 constexpr unsigned long long kLbAggregate = 1ull << 62;
@@ -143,6 +148,37 @@ __device__ __forceinline__ void lds_or5(uint8_t* region, uint32_t off, uint32_t 
   }
 }
 
+// token of <= 12 bytes (Tok::w0..w2) OR-ed in at byte address `off`
+__device__ __forceinline__ void lds_or12(uint8_t* region, uint32_t off, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t len) {
+  const uint32_t sh = (off & 3u) * 8u;
+  uint32_t* w = reinterpret_cast<uint32_t*>(region + (off & ~3u));
+  const uint32_t o0 = w0 << sh;
+  const uint32_t o1 = (uint32_t)((((uint64_t)w1 << 32) | w0) << sh >> 32);
+  const uint32_t o2 = (uint32_t)((((uint64_t)w2 << 32) | w1) << sh >> 32);
+  const uint32_t o3 = (uint32_t)(((uint64_t)w2 << sh) >> 32);
+  const uint32_t span = (off & 3u) + len;  // bytes from the first dword's start to the token's end
+  if (o0) atomicOr(w, o0);
+  if (span > 4u && o1) atomicOr(w + 1, o1);
+  if (span > 8u && o2) atomicOr(w + 2, o2);
+  if (span > 12u && o3) atomicOr(w + 3, o3);
+}
+
+// bytes [rel, rel + 8) of the dwords loaded for one point, any rel (three dwords)
+template <int LOADW>
+__device__ __forceinline__ uint64_t field64_from_regs(const FloatVec<LOADW>& pt, uint32_t rel) {
+  const uint32_t di = rel >> 2;
+  uint32_t d0 = 0u, d1 = 0u, d2 = 0u;
+#pragma unroll
+  for (int k = 0; k < LOADW; ++k) {
+    if ((uint32_t)k == di) d0 = __float_as_uint(pt.v[k]);
+    if ((uint32_t)k == di + 1u) d1 = __float_as_uint(pt.v[k]);
+    if ((uint32_t)k == di + 2u) d2 = __float_as_uint(pt.v[k]);
+  }
+  const uint32_t mis = rel & 3u;
+  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, mis), hi = __builtin_amdgcn_alignbyte(d2, d1, mis);
+  return (((uint64_t)hi) << 32) | lo;
+}
+
 // One wave copies R bytes from its LDS region (16-byte aligned, 32 bytes of slack behind it) to dst (any alignment):
 // byte stores up to the first aligned unit and behind the last one, in between 16-byte units assembled from two
 // aligned LDS reads with a wave-uniform byte funnel.
@@ -214,6 +250,11 @@ struct FusedArgs {
   uint32_t piece_stride;
   Seg* segs;
   uint32_t segs_per_chunk;
+  // TAIL instantiations: one more regular op behind the FloatN lanes (raw copy, scalar lossy float, Gorilla token)
+  uint32_t tail_kind;            // OP_* of plan.ops[LANES]
+  uint32_t tail_rel;             // its offset behind plan.ops[0].offset (inside the LOADW dwords loaded per point)
+  uint32_t tail_size;            // field bytes
+  const uint4* tail_tokens;      // OP_GORILLA64: the tokens k_gorilla_tokens left, one per point of the batch
   uint32_t ablate;               // profiling only (CLDN_HIP_ABLATE): 1 no statistics pass, 2 no inter-piece protocol (fake positions), 4 no column stores
 };
 
@@ -224,11 +265,11 @@ struct FusedArgs {
 // that the compiler's s_waitcnt counting stays exact -- a conditional load inside a loop made it fall back to
 // vmcnt(0) before every row, which serialised the whole kernel on memory latency. The rows are unrolled for the same
 // reason.
-template <int LANES, int LOADW, bool UNAL, int L3>
+template <int LANES, int LOADW, bool UNAL, int L3, bool TAIL = false>
 __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan plan, const FusedArgs A) {
   constexpr uint32_t ROWS = fused_piece_rows(LANES);
   constexpr uint32_t PIECE = fused_piece_points(LANES);
-  constexpr uint32_t REGION = fused_region_bytes(LANES);
+  constexpr uint32_t REGION = TAIL ? fused_region_bytes_tail(LANES) : fused_region_bytes(LANES);
   constexpr uint32_t ROWS_B = (PIECE + 63u) / 64u;  // 64-wide rows of the statistics pass
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* wg_misc = reinterpret_cast<uint32_t*>(smem);                       // [0] ticket
@@ -290,6 +331,22 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
         }
 #pragma unroll
         for (int k = 0; k < LOADW; ++k) rows[r].v[k] = __uint_as_float(__builtin_amdgcn_alignbyte(d[k + 1], d[k], mis));
+      }
+    }
+  }
+
+  // TAIL, Gorilla: the ready-made token of every point of mine, requested with the rows (same reason: no load inside
+  // the row loop)
+  uint4 gtok[TAIL ? ROWS : 1];
+  if (TAIL) {
+#pragma unroll
+    for (uint32_t r = 0; r < (TAIL ? ROWS : 1u); ++r) gtok[r] = make_uint4(0u, 0u, 0u, 0u);
+    if (n && A.tail_kind == (uint32_t)OP_GORILLA64) {
+      const uint4* tq = A.tail_tokens + first_point;
+#pragma unroll
+      for (uint32_t r = 0; r < (TAIL ? ROWS : 1u); ++r) {
+        const int32_t idx = (int32_t)(r * kRowPts + lane) - 1;
+        gtok[r] = tq[(idx >= 0 && idx < (int32_t)n) ? (uint32_t)idx : 0u];
       }
     }
   }
@@ -372,6 +429,39 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
           }
         }
       }
+      // TAIL: the op behind the FloatN lanes (include/cloudini_lib/field_encoder.hpp:56-60, :342-370, :156-312), from
+      // the dwords already loaded for the point; lane l-1 holds the previous point (zeros in front of a chunk)
+      Tok tt;
+      tt.w0 = tt.w1 = tt.w2 = 0u;
+      tt.len = 0u;
+      if (TAIL) {
+        const uint32_t kind = A.tail_kind;  // uniform
+        const uint64_t raw = field64_from_regs<LOADW>(cur, A.tail_rel);
+        if (kind == (uint32_t)OP_COPY) {
+          tt = raw_tok(A.tail_size >= 8u ? raw : (raw & ((1ull << (8u * A.tail_size)) - 1ull)), A.tail_size);
+        } else if (kind == (uint32_t)OP_LOSSY_F64) {
+          const double v = __longlong_as_double((long long)raw);
+          const bool isn = is_nan_f64(v);
+          const int64_t q = isn ? 0 : quant_away_i64_f64(v, plan.ops[LANES].mult_d);  // a NaN resets the reference to 0
+          const int64_t pq = (int64_t)shr1_carry64((uint64_t)q, 0u);
+          if (isn) tt.len = 1u;  // marker byte 0x00
+          else tt = varint64_tok((int64_t)((uint64_t)q - (uint64_t)pq));
+        } else if (kind == (uint32_t)OP_LOSSY_F32) {
+          const float v = __uint_as_float((uint32_t)raw);
+          const bool isn = is_nan_f32(v);
+          const int64_t q = isn ? 0 : quant_away_i64_f32(v, plan.ops[LANES].mult_f);
+          const int64_t pq = (int64_t)shr1_carry64((uint64_t)q, 0u);
+          if (isn) tt.len = 1u;
+          else tt = varint64_tok((int64_t)((uint64_t)q - (uint64_t)pq));
+        } else {  // OP_GORILLA64
+          const uint4 g = gtok[TAIL ? r : 0u];
+          tt.w0 = g.x;
+          tt.w1 = g.y;
+          tt.w2 = g.z;
+          tt.len = g.w;
+        }
+        total += tt.len;
+      }
       const uint32_t plen = emits ? total : 0u;
       const uint32_t incl = wave_inclusive_scan(plen);
       uint32_t off = R + incl - plen;
@@ -394,6 +484,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
           off += (lens >> (8 * k)) & 0xffu;
         }
       }
+      if (TAIL && plen) lds_or12(region, off, tt.w0, tt.w1, tt.w2, tt.len);
       R += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 
       // AoS -> SoA split of the adaptive-int fields (uniform loop: the plan is read with scalar loads)

@@ -1748,12 +1748,23 @@ constexpr uint32_t kFloatnLds = kFloatnRing + 256u + kStagedCols * (4u * 63u * 2
 
 // FloatN fast path: the regular stream is exactly one fused 3/4-lane float encoder on a 4-byte aligned layout
 // lanes of the fused FloatN encoder the fast kernel can take (0 = none); *l3 = dword of the fourth lane
-int floatn_lanes(const DevPlan& p, const uint8_t* points, int* l3) {
-  const uint32_t lanes = p.n_ops;
+// `tail` (may be NULL): index of ONE more regular op behind the lanes that the piece kernel can append to every point
+// (raw copy, scalar lossy float, Gorilla token), -1 if there is none. Callers that pass NULL get 0 for such plans.
+int floatn_lanes(const DevPlan& p, const uint8_t* points, int* l3, int* tail = nullptr) {
   *l3 = 3;
+  if (tail) *tail = -1;
+  uint32_t lanes = 0;
+  while (lanes < p.n_ops && lanes < 4u && p.ops[lanes].kind == OP_QF32) ++lanes;
   if (lanes != 3u && lanes != 4u) return 0;
+  if (p.n_ops != lanes) {
+    if (!tail || p.n_ops != lanes + 1u) return 0;
+    const uint32_t k = p.ops[lanes].kind;
+    // (XOR fields only exist in lossless schemas, which have no FloatN lanes)
+    if (k != OP_COPY && k != OP_LOSSY_F32 && k != OP_LOSSY_F64 && k != OP_GORILLA64) return 0;
+    if (p.ops[lanes].size > 8u || p.ops[lanes].offset < p.ops[0].offset) return 0;
+    *tail = (int)lanes;
+  }
   for (uint32_t k = 0; k < lanes; ++k) {
-    if (p.ops[k].kind != OP_QF32) return 0;
     if (k < 3u && p.ops[k].offset != p.ops[0].offset + 4u * k) return 0;
   }
   if (lanes == 4u) {
@@ -1767,21 +1778,32 @@ bool floatn_unaligned(const DevPlan& p, const uint8_t* points) {
   return (p.point_step & 3u) || (p.ops[0].offset & 3u) || ((uintptr_t)points & 3u);
 }
 
-// dwords to load per point so that every adaptive-int field is covered by the point load (0 = not possible)
-int floatn_loadw(const DevPlan& p, int lanes, bool unal, int l3) {
-  if (l3 == 4) return (!unal && p.ops[0].offset + 32u <= p.point_step) ? 8 : 0;  // one variant: aligned, 8 dwords
-  if (p.n_adaptive == 0) return unal && lanes == 3 ? 4 : lanes;
-  uint32_t need = (uint32_t)lanes * 4u;
+// dwords to load per point so that every adaptive-int field (and the tail op's field) is covered by the point load
+// (0 = not possible)
+int floatn_loadw(const DevPlan& p, int lanes, bool unal, int l3, int tail = -1) {
   const uint32_t off0 = p.ops[0].offset;
+  // bytes behind off0 the tail needs; an unaligned 8-byte field is read from three dwords
+  uint32_t tail_need = 0;
+  if (tail >= 0) {
+    const uint32_t rel = p.ops[tail].offset - off0;
+    tail_need = ((rel >> 2) + (p.ops[tail].size > 4u || (rel & 3u) + p.ops[tail].size > 4u ? ((rel & 3u) ? 3u : 2u) : 1u)) * 4u;
+  }
+  if (l3 == 4) return (!unal && off0 + 32u <= p.point_step && tail_need <= 32u) ? 8 : 0;  // one variant: aligned, 8 dwords
+  if (p.n_adaptive == 0 && tail < 0) return unal && lanes == 3 ? 4 : lanes;
+  uint32_t need = std::max((uint32_t)lanes * 4u, tail_need);
   for (uint32_t a = 0; a < p.n_adaptive; ++a) {
     const DevAdaptive& f = p.adaptive[a];
     // fields the point load cannot deliver: the aligned kernels then read every field directly (loadw == lanes);
     // the unaligned instantiations have no such mode -> 0 = generic kernel
-    if (f.offset < off0) return unal ? 0 : lanes;
-    if (f.bpv == 8u && ((f.offset - off0) & 3u)) return unal ? 0 : lanes;
+    if (f.offset < off0) return (unal || tail >= 0) ? 0 : lanes;
+    if (f.bpv == 8u && ((f.offset - off0) & 3u)) return (unal || tail >= 0) ? 0 : lanes;
     need = std::max(need, f.offset - off0 + f.bpv);
   }
   const int w = (int)((need + 3u) / 4u);
+  if (tail >= 0) {  // TAIL instantiations: (3: 4, 8), (4: 8), aligned and unaligned
+    if (w > 8) return 0;
+    return (lanes == 3 && w <= 4) ? 4 : 8;  // (an aligned layout whose point is shorter takes the guarded UNAL variant)
+  }
   if (unal) {  // realigned dword loads may reach into the next point; variants: (3: 4, 8), (4: 5, 8)
     if (w > 8) return 0;
     if (lanes == 3) return w <= 4 ? 4 : 8;
@@ -1861,17 +1883,22 @@ namespace {
 struct FusedVariant {
   int lanes, loadw, l3;
   bool unal;
+  int tail;  // index of the op appended behind the lanes, -1 = none
 };
 // the k_encode_floatn variant table decides whether the point load covers the plan
 bool fused_variant(const DevPlan& p, const uint8_t* points, FusedVariant* v) {
-  int l3 = 3;
-  const int lanes = floatn_lanes(p, points, &l3);
+  int l3 = 3, tail = -1;
+  const int lanes = floatn_lanes(p, points, &l3, &tail);
   if (!lanes) return false;
-  const bool unal = floatn_unaligned(p, points);
-  const int loadw = floatn_loadw(p, lanes, unal, l3);
+  bool unal = floatn_unaligned(p, points);
+  const int loadw = floatn_loadw(p, lanes, unal, l3, tail);
   if (loadw == 0) return false;
+  // TAIL on an aligned layout whose loaded dwords reach into the next point: the UNAL instantiation (aligned dwords +
+  // realignment, here by 0 bytes) has the guard for the last points of the batch
+  if (tail >= 0 && !unal && l3 != 4 && p.ops[0].offset + (uint32_t)loadw * 4u > p.point_step) unal = true;
   bool ok;
-  if (l3 == 4) ok = (loadw == 8);
+  if (tail >= 0) ok = l3 == 4 ? loadw == 8 : ((lanes == 3 && (loadw == 4 || loadw == 8)) || (lanes == 4 && loadw == 8));
+  else if (l3 == 4) ok = (loadw == 8);
   else if (unal) ok = (lanes == 3 && (loadw == 4 || loadw == 8)) || (lanes == 4 && (loadw == 5 || loadw == 8));
   else ok = (lanes == 3 && (loadw == 3 || loadw == 4 || loadw == 8)) || (lanes == 4 && (loadw == 4 || loadw == 8));
   if (!ok) return false;
@@ -1879,6 +1906,7 @@ bool fused_variant(const DevPlan& p, const uint8_t* points, FusedVariant* v) {
   v->loadw = loadw;
   v->l3 = l3;
   v->unal = unal;
+  v->tail = tail;
   return true;
 }
 }  // namespace
@@ -1898,11 +1926,13 @@ uint32_t stage1_piece_points(const DevPlan& plan, const uint8_t* points) {
 uint32_t stage1_piece_slot_stride(const DevPlan& plan, const uint8_t* points) {
   FusedVariant v;
   if (!fused_variant(plan, points, &v)) return 0u;
-  return (fused_piece_points(v.lanes) * 5u * (uint32_t)v.lanes + 255u) & ~255u;  // worst case, 5 bytes per token
+  const uint32_t per_point = 5u * (uint32_t)v.lanes + (v.tail >= 0 ? kTailMaxBytes : 0u);  // worst case, 5 bytes per token
+  return (fused_piece_points(v.lanes) * per_point + 255u) & ~255u;
 }
 
 bool stage1_single_pass_ok(const DevPlan& plan, const uint8_t* points) {
-  if (stage1_piece_points(plan, points) == 0u) return false;
+  FusedVariant fv;
+  if (!fused_variant(plan, points, &fv) || fv.tail >= 0) return false;
   // Palette sizes come from a presence bitmap, which exists for 2-byte fields only: a wider field could commit
   // Palette on the device, and the choice of pipeline is made on the host before the modes are known
   for (uint32_t a = 0; a < plan.n_adaptive; ++a)
@@ -1947,11 +1977,33 @@ static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piec
   A.segs_per_chunk = L.segs_per_chunk;
   const uint32_t n_bm = L.fused ? L.n_bm_fields : 0u;
   A.n_bm_fields = n_bm;
-  const uint32_t lds = 16u + kFusedWaves * fused_region_bytes(v.lanes) + (n_bm ? kBitmapWords * 4u : 0u);
+  A.tail_kind = 0u;
+  A.tail_rel = 0u;
+  A.tail_size = 0u;
+  A.tail_tokens = nullptr;
+  if (v.tail >= 0) {
+    const DevOp& top = L.plan->ops[v.tail];
+    A.tail_kind = top.kind;
+    A.tail_rel = top.offset - L.plan->ops[0].offset;
+    A.tail_size = top.size;
+    if (top.kind == OP_GORILLA64) A.tail_tokens = L.pre.p[top.type];
+  }
+  const uint32_t region = v.tail >= 0 ? fused_region_bytes_tail(v.lanes) : fused_region_bytes(v.lanes);
+  const uint32_t lds = 16u + kFusedWaves * region + (n_bm ? kBitmapWords * 4u : 0u);
   const dim3 grid((piece1 - piece0) / kFusedWaves), block(kFusedThreads);
 #define LAUNCH_FUSED(LL, WW, UU, L3)                                                                             \
   hipLaunchKernelGGL((k_encode_fused<LL, WW, UU, L3>), grid, block, lds, stream, *L.plan, A)
-  if (v.l3 == 4) LAUNCH_FUSED(4, 8, false, 4);
+#define LAUNCH_FUSED_TAIL(LL, WW, UU, L3)                                                                        \
+  hipLaunchKernelGGL((k_encode_fused<LL, WW, UU, L3, true>), grid, block, lds, stream, *L.plan, A)
+  if (v.tail >= 0) {
+    if (v.l3 == 4) LAUNCH_FUSED_TAIL(4, 8, false, 4);
+    else if (v.unal && v.lanes == 3 && v.loadw == 4) LAUNCH_FUSED_TAIL(3, 4, true, 3);
+    else if (v.unal && v.lanes == 3) LAUNCH_FUSED_TAIL(3, 8, true, 3);
+    else if (v.unal) LAUNCH_FUSED_TAIL(4, 8, true, 3);
+    else if (v.lanes == 3 && v.loadw == 4) LAUNCH_FUSED_TAIL(3, 4, false, 3);
+    else if (v.lanes == 3) LAUNCH_FUSED_TAIL(3, 8, false, 3);
+    else LAUNCH_FUSED_TAIL(4, 8, false, 3);
+  } else if (v.l3 == 4) LAUNCH_FUSED(4, 8, false, 4);
   else if (v.unal && v.lanes == 3 && v.loadw == 4) LAUNCH_FUSED(3, 4, true, 3);
   else if (v.unal && v.lanes == 3 && v.loadw == 8) LAUNCH_FUSED(3, 8, true, 3);
   else if (v.unal && v.lanes == 4 && v.loadw == 5) LAUNCH_FUSED(4, 5, true, 3);
@@ -1962,6 +2014,7 @@ static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piec
   else if (v.lanes == 4 && v.loadw == 4) LAUNCH_FUSED(4, 4, false, 3);
   else LAUNCH_FUSED(4, 8, false, 3);
 #undef LAUNCH_FUSED
+#undef LAUNCH_FUSED_TAIL
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "k_encode_fused");
   return CLDN_HIP_OK;

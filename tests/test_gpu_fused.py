@@ -186,3 +186,72 @@ def test_wide_integer_fields_keep_the_slots(oracle):
     assert codec.pipeline(3) == 2  # u32 rgba could commit Palette, for which the single pass has no statistics
     codec.close()
     check_encode(oracle, info, [data])
+
+
+# ---- one more regular op behind the FloatN lanes (TAIL instantiations of the piece kernel) ------------------------
+
+def _tail_layout(kind, n, seed=3):
+    rs = np.random.RandomState(seed)
+    t = np.arange(n, dtype=np.float32)
+    cols = {"x": (20 + 5 * np.sin(t / 97) + rs.normal(0, 0.002, n)).astype(np.float32),
+            "y": (3 * np.cos(t / 61) + rs.normal(0, 0.002, n)).astype(np.float32),
+            "z": (0.001 * t).astype(np.float32),
+            "i": rs.randint(0, 256, n).astype(np.float32)}
+    xyz = [("x", 0, F.FLOAT32, 0.001), ("y", 4, F.FLOAT32, 0.001), ("z", 8, F.FLOAT32, 0.001)]
+    stamp = 1.7e9 + np.arange(n) * 1e-5 + rs.normal(0, 1e-7, n)
+    if kind == "xyz_rgb_copy_step16":          # PCL PointXYZRGB: packed rgb as a FLOAT32 without resolution
+        fields, step = xyz + [("rgb", 12, F.FLOAT32, None)], 16
+        cols["rgb"] = rs.randint(0, 1 << 24, n).astype(np.uint32).view(np.float32)
+    elif kind == "xyz_u8_copy_step13":          # packed, unaligned points, 1-byte tail
+        fields, step = xyz + [("flag", 12, F.UINT8, None)], 13
+        cols["flag"] = rs.randint(0, 256, n).astype(np.uint8)
+    elif kind in ("dds_gorilla_step26", "dds_stamp_1us_step26"):   # the reference's samples/dds_message.bin layout
+        res = None if kind == "dds_gorilla_step26" else 1e-6
+        fields = xyz + [("i", 12, F.FLOAT32, 0.001), ("ring", 16, F.UINT16, None), ("timestamp", 18, F.FLOAT64, res)]
+        step = 26
+        cols["ring"] = (np.arange(n) % 64).astype(np.uint16)
+        cols["timestamp"] = stamp.copy()
+        cols["timestamp"][::5003] = np.nan
+        cols["timestamp"][7::9001] = 1e300      # beyond int64 after scaling: the reference's cvttsd2si result
+    elif kind == "xyz_f64_1us_step24":          # aligned, 8 dwords
+        fields, step = xyz + [("timestamp", 16, F.FLOAT64, 1e-6)], 24
+        cols["timestamp"] = stamp
+    elif kind == "xyz_gorilla_step20":          # f64 directly behind the lanes, unaligned step
+        fields, step = xyz + [("timestamp", 12, F.FLOAT64, None)], 20
+        cols["timestamp"] = np.where(np.arange(n) % 100 < 50, stamp, np.round(stamp))  # repeats -> '0' bits, new windows
+    elif kind == "xyz_pad_i_u8_step32":         # PCL layout x y z <pad> intensity, then a 1-byte copy field
+        fields = xyz + [("i", 16, F.FLOAT32, 0.001), ("flag", 20, F.UINT8, None)]
+        step = 32
+        cols["flag"] = rs.randint(0, 256, n).astype(np.uint8)
+    elif kind == "xyzi_ring_scalar_f32_step22":  # a lossy float behind an integer field is not fused: Float_Lossy<float>
+        fields = xyz + [("i", 12, F.FLOAT32, 0.001), ("ring", 16, F.UINT16, None), ("temp", 18, F.FLOAT32, 0.01)]
+        step = 22
+        cols["ring"] = (np.arange(n) % 32).astype(np.uint16)
+        cols["temp"] = (rs.normal(30, 5, n)).astype(np.float32)
+        cols["temp"][::777] = np.nan
+    else:
+        raise KeyError(kind)
+    cols = {k: v for k, v in cols.items() if k in [f[0] for f in fields]}
+    info = cases.make_info(fields, step, n)
+    return info, cases.pack(info, cols, n)
+
+
+TAIL_KINDS = ["xyz_rgb_copy_step16", "xyz_u8_copy_step13", "dds_gorilla_step26", "dds_stamp_1us_step26",
+              "xyz_f64_1us_step24", "xyz_gorilla_step20", "xyz_pad_i_u8_step32", "xyzi_ring_scalar_f32_step22"]
+
+
+@pytest.mark.parametrize("kind", TAIL_KINDS)
+def test_tail_op_behind_the_floatn_lanes(oracle, kind):
+    """Layouts whose regular stream is the fused FloatN encoder plus ONE more per-point encoder (FieldEncoderCopy,
+    Float_Lossy<float/double>, Float_Gorilla<double>: include/cloudini_lib/field_encoder.hpp:56-60, :342-357, :156-312)
+    take the piece kernel with the tail token appended to every point; the tile/generic pipeline must agree."""
+    from cloudini_amd import native
+    info, data = _tail_layout(kind, 32768 * 2 + 777)
+    codec = native.Codec(native.Plan(info))
+    assert codec.pipeline(2) == 2, "the piece kernel must take this layout"
+    codec.close()
+    check_encode(oracle, info, [data])
+    # ragged batch: chunk starts inside the batch, a cloud shorter than a piece, an empty one
+    step = info.point_step
+    parts = [data[: 40000 * step], data[40000 * step: 40100 * step], data[:0], data[40100 * step:]]
+    check_encode(oracle, info, parts)
