@@ -2034,28 +2034,42 @@ static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c
   ColumnPtrs rank_cols;
   for (int a = 0; a < kMaxAdaptive; ++a) rank_cols.p[a] = reinterpret_cast<uint8_t*>(L.ranks[a]);
   static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
+  // One launch per kernel type covers all the fields of that type (grid.y): the fields are independent and every one of
+  // these kernels is latency-bound at one workgroup per chunk, so a schema with five integer channels gets five times
+  // the workgroups in flight instead of five launches in a row.
+  SectionFields run16, run32, pal16, pal32, pal64;
+  run16.n = run32.n = pal16.n = pal32.n = pal64.n = 0u;
   for (uint32_t a = 0; a < na && !no_fast; ++a) {
     const uint32_t bpv = L.plan->adaptive[a].bpv;
     const uint32_t hint = L.mode_hint[a];
-#define SEC_ARGS *L.plan, a, chunks, L.cols, L.modes, slots, L.slot_stride, L.reg_stride, segs, L.segs_per_chunk, L.subs, flags
     if (hint & 0xDu) {  // DeltaVarint / Rle / DeltaRle expected somewhere
-      if (bpv == 2u) {
-        hipLaunchKernelGGL(k_section_delta32<uint16_t>, dim3(nch), dim3(kS2Threads), kD32Lds, stream, SEC_ARGS);
-        hipLaunchKernelGGL(k_section_runs<uint16_t>, dim3(nch), dim3(kS2Threads), 0, stream, SEC_ARGS);
-      } else if (bpv == 4u) {
-        hipLaunchKernelGGL(k_section_delta32<uint32_t>, dim3(nch), dim3(kS2Threads), kD32Lds, stream, SEC_ARGS);
-        hipLaunchKernelGGL(k_section_runs<uint32_t>, dim3(nch), dim3(kS2Threads), 0, stream, SEC_ARGS);
-      }
+      if (bpv == 2u) run16.a[run16.n++] = (uint8_t)a;
+      else if (bpv == 4u) run32.a[run32.n++] = (uint8_t)a;
     }
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_delta32/runs");
     if (hint & 0x2u) {
-      if (bpv == 2u) hipLaunchKernelGGL(k_section_palette32<uint16_t>, dim3(nch), dim3(kS2Threads), Pal32<uint16_t>::kLds, stream, SEC_ARGS);
-      else if (bpv == 4u) hipLaunchKernelGGL(k_section_palette32<uint32_t>, dim3(nch), dim3(kS2Threads), Pal32<uint32_t>::kLds, stream, SEC_ARGS);
-      else hipLaunchKernelGGL(k_section_palette<uint64_t>, dim3(nch), dim3(kS2Threads), kS2PalLds, stream, SEC_ARGS);
+      if (bpv == 2u) pal16.a[pal16.n++] = (uint8_t)a;
+      else if (bpv == 4u) pal32.a[pal32.n++] = (uint8_t)a;
+      else pal64.a[pal64.n++] = (uint8_t)a;
     }
-#undef SEC_ARGS
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_palette");
   }
+#define SEC_ARGS(FL) *L.plan, FL, chunks, L.cols, L.modes, slots, L.slot_stride, L.reg_stride, segs, L.segs_per_chunk, L.subs, flags
+  if (run16.n) {
+    hipLaunchKernelGGL(k_section_delta32<uint16_t>, dim3(nch, run16.n), dim3(kS2Threads), kD32Lds, stream, SEC_ARGS(run16));
+    hipLaunchKernelGGL(k_section_runs<uint16_t>, dim3(nch, run16.n), dim3(kS2Threads), 0, stream, SEC_ARGS(run16));
+  }
+  if (run32.n) {
+    hipLaunchKernelGGL(k_section_delta32<uint32_t>, dim3(nch, run32.n), dim3(kS2Threads), kD32Lds, stream, SEC_ARGS(run32));
+    hipLaunchKernelGGL(k_section_runs<uint32_t>, dim3(nch, run32.n), dim3(kS2Threads), 0, stream, SEC_ARGS(run32));
+  }
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_delta32/runs");
+  if (pal16.n)
+    hipLaunchKernelGGL(k_section_palette32<uint16_t>, dim3(nch, pal16.n), dim3(kS2Threads), Pal32<uint16_t>::kLds, stream, SEC_ARGS(pal16));
+  if (pal32.n)
+    hipLaunchKernelGGL(k_section_palette32<uint32_t>, dim3(nch, pal32.n), dim3(kS2Threads), Pal32<uint32_t>::kLds, stream, SEC_ARGS(pal32));
+  if (pal64.n)
+    hipLaunchKernelGGL(k_section_palette<uint64_t>, dim3(nch, pal64.n), dim3(kS2Threads), kS2PalLds, stream, SEC_ARGS(pal64));
+#undef SEC_ARGS
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_palette");
   hipLaunchKernelGGL(k_encode_sections, dim3(nch, na), dim3(kSecThreads), kSecLdsTotal, stream, *L.plan, chunks, L.cols,
                      L.modes, slots, L.slot_stride, L.reg_stride, segs, L.segs_per_chunk, rank_cols, L.subs, flags);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_sections");

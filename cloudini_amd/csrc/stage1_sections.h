@@ -11,6 +11,12 @@
 
 namespace cldn {
 
+// the adaptive fields one section-kernel launch covers: blockIdx.y indexes the list
+struct SectionFields {
+  uint32_t n;
+  uint8_t a[kMaxAdaptive];
+};
+
 constexpr int kS2Threads = 1024;
 constexpr uint32_t kS2PalSlots = 4096;
 constexpr uint32_t kS2PalCapacity = 3072;  // load factor 0.75
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(kS2Threads) void k_probe_fast(const DevPlan plan, c
 // grid = n_chunks (one launch per adaptive field). Chunks whose mode is not Palette exit at once; chunks whose
 // table overflows exit without setting handled_flags[c * n_adaptive + a] and are encoded by the general kernel.
 template <typename RawT>
-__global__ __launch_bounds__(kS2Threads) void k_section_palette(const DevPlan plan, uint32_t a,
+__global__ __launch_bounds__(kS2Threads) void k_section_palette(const DevPlan plan, const SectionFields fl,
                                                                 const ChunkDesc* __restrict__ chunks,
                                                                 const ColumnPtrs cols, const uint8_t* __restrict__ modes,
                                                                 uint8_t* __restrict__ slots, uint64_t slot_stride,
@@ -289,6 +295,7 @@ __global__ __launch_bounds__(kS2Threads) void k_section_palette(const DevPlan pl
   constexpr uint32_t ROUND = T * 8u;  // values per round
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t c = blockIdx.x;
+  const uint32_t a = fl.a[blockIdx.y];  // one launch covers every field of this kernel's type (grid.y)
   const ChunkDesc cd = chunks[c];
   if (modes[cd.cloud * plan.n_adaptive + a] != 1u) return;
   const uint32_t n = cd.n_points;
@@ -534,7 +541,7 @@ __device__ __forceinline__ void pal32_pack(const Pal32<RawT>& p, const RawT* col
 
 template <typename RawT>
 __global__ __launch_bounds__(kS2Threads) void k_section_palette32(
-    const DevPlan plan, uint32_t a, const ChunkDesc* __restrict__ chunks, const ColumnPtrs cols,
+    const DevPlan plan, const SectionFields fl, const ChunkDesc* __restrict__ chunks, const ColumnPtrs cols,
     const uint8_t* __restrict__ modes, uint8_t* __restrict__ slots, uint64_t slot_stride, uint64_t reg_stride,
     Seg* __restrict__ segs, uint32_t segs_per_chunk, uint32_t subs, uint8_t* __restrict__ handled_flags) {
   static_assert(sizeof(RawT) == 2 || sizeof(RawT) == 4, "16- or 32-bit keys");
@@ -544,6 +551,7 @@ __global__ __launch_bounds__(kS2Threads) void k_section_palette32(
   constexpr int T = kS2Threads;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t c = blockIdx.x;
+  const uint32_t a = fl.a[blockIdx.y];  // one launch covers every field of this kernel's type (grid.y)
   const ChunkDesc cd = chunks[c];
   if (modes[cd.cloud * plan.n_adaptive + a] != 1u) return;
   const uint32_t n = cd.n_points;
@@ -663,7 +671,7 @@ constexpr uint32_t kD32Ring = 65536;  // >= 8192 values * 5 bytes + 16
 constexpr uint32_t kD32Lds = kD32Ring + 256u;
 
 template <typename RawT>
-__global__ __launch_bounds__(kS2Threads) void k_section_delta32(const DevPlan plan, uint32_t a,
+__global__ __launch_bounds__(kS2Threads) void k_section_delta32(const DevPlan plan, const SectionFields fl,
                                                                 const ChunkDesc* __restrict__ chunks,
                                                                 const ColumnPtrs cols, const uint8_t* __restrict__ modes,
                                                                 uint8_t* __restrict__ slots, uint64_t slot_stride,
@@ -676,6 +684,7 @@ __global__ __launch_bounds__(kS2Threads) void k_section_delta32(const DevPlan pl
   uint32_t* ring = reinterpret_cast<uint32_t*>(smem);
   uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + kD32Ring);
   const uint32_t c = blockIdx.x;
+  const uint32_t a = fl.a[blockIdx.y];  // one launch covers every field of this kernel's type (grid.y)
   const ChunkDesc cd = chunks[c];
   if (modes[cd.cloud * plan.n_adaptive + a] != 0u) return;
   const uint32_t n = cd.n_points;
@@ -748,7 +757,7 @@ __global__ __launch_bounds__(kS2Threads) void k_section_delta32(const DevPlan pl
 // the records are written straight to the slot.
 // ---------------------------------------------------------------------------------------------------------
 template <typename RawT>
-__global__ __launch_bounds__(kS2Threads) void k_section_runs(const DevPlan plan, uint32_t a,
+__global__ __launch_bounds__(kS2Threads) void k_section_runs(const DevPlan plan, const SectionFields fl,
                                                              const ChunkDesc* __restrict__ chunks, const ColumnPtrs cols,
                                                              const uint8_t* __restrict__ modes,
                                                              uint8_t* __restrict__ slots, uint64_t slot_stride,
@@ -759,6 +768,7 @@ __global__ __launch_bounds__(kS2Threads) void k_section_runs(const DevPlan plan,
   constexpr int T = kS2Threads;
   __shared__ uint32_t wtot[64];
   const uint32_t c = blockIdx.x;
+  const uint32_t a = fl.a[blockIdx.y];  // one launch covers every field of this kernel's type (grid.y)
   const ChunkDesc cd = chunks[c];
   const uint32_t mode = modes[cd.cloud * plan.n_adaptive + a];
   if (mode != 2u && mode != 3u) return;
