@@ -35,18 +35,21 @@ constexpr uint32_t kFpTilePoints = kFpThreads * kFpPPT; // at most 1536 points l
 constexpr uint32_t kFastPalEntries = 1024;
 constexpr uint32_t kFastPalFields = 2;
 
-template <int NOPS>
+// NF = Palette sections the instantiation can fold (0, 1, 2 = min(adaptive fields of the plan, kFastPalFields)): the
+// staging area and the palette tables are sized for it, so that XYZ(I) clouds with one integer field keep four
+// workgroups per CU (the 4-lane layout with room for two folded fields needs 46 KB and gets three)
+template <int NOPS, int NF = 2>
 struct FpLds {
   static constexpr uint32_t kTileOff = 0;                                   // [16 zero bytes][tile][32 pad]
   static constexpr uint32_t kPosOff = 16u + kFpTileBytes + 32u;             // u16 [kFpTilePoints + 1 + 7]: where point q starts
   static constexpr uint32_t kPosEntries = 1u + kFpTilePoints + 7u;
   static constexpr uint32_t kWorkEnd = (kPosOff + kPosEntries * 2u + 15u) & ~15u;
-  static constexpr uint32_t kStageBytes = kFpTilePoints * (NOPS + kFastPalFields) * 4u;  // decoded points (floats + folded
+  static constexpr uint32_t kStageBytes = kFpTilePoints * (NOPS + NF) * 4u;  // decoded points (floats + folded
                                                                                          // fields), overlays tile + list
   static constexpr uint32_t kScanOff = (kWorkEnd > kStageBytes ? kWorkEnd : kStageBytes);
   static constexpr uint32_t kWaveRec = NOPS * 4u + 8u;                      // per wave: int[NOPS] + flags; [16], [17] = carry
   static constexpr uint32_t kPalOff = (kScanOff + 18u * kWaveRec + 15u) & ~15u;     // (read and written in turns)
-  static constexpr uint32_t kMiscOff = kPalOff + kFastPalFields * kFastPalEntries * 4u;
+  static constexpr uint32_t kMiscOff = kPalOff + (uint32_t)NF * kFastPalEntries * 4u;
   static constexpr uint32_t kTotal = kMiscOff + 512u;
 };
 
@@ -94,12 +97,13 @@ struct FpSection {   // a Palette section folded into the point pass
   uint32_t index_off;  // payload offset of the packed indexes
 };
 
-template <int NOPS>
+template <int NOPS, int NF>
 __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decode_points(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                               const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
                                                               uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done,
                                                               uint32_t uses_v5, uint32_t* __restrict__ status) {
-  using L = FpLds<NOPS>;
+  using L = FpLds<NOPS, NF>;
+  constexpr uint32_t NFA = NF ? NF : 1;  // array extents (NF == 0: nothing is ever folded)
   constexpr int T = kFpThreads;
   constexpr uint32_t NW = kFpThreads / 64u;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
   if (v5_sections) {
 
     // section headers (one thread): every section a small Palette of a 2- or 4-byte field -> fold them in
-    if (tid == 0 && reg_size != 0xffffffffu && plan.n_adaptive <= kFastPalFields) {
+    if (tid == 0 && reg_size != 0xffffffffu && plan.n_adaptive <= (uint32_t)NF) {
       uint32_t off = reg_size;
       bool ok = true;
       FpSection* sec = reinterpret_cast<FpSection*>(misc + 72);
@@ -248,10 +252,10 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
   const uint32_t n_fold = misc[64];
 
   // folded Palette sections: parameters in (uniform) registers for the read-out
-  uint32_t fs_off[kFastPalFields], fs_bpv[kFastPalFields], fs_count[kFastPalFields], fs_bits[kFastPalFields];
-  const uint8_t* fs_idx[kFastPalFields];
+  uint32_t fs_off[NFA], fs_bpv[NFA], fs_count[NFA], fs_bits[NFA];
+  const uint8_t* fs_idx[NFA];
 #pragma unroll
-  for (uint32_t a = 0; a < kFastPalFields; ++a) {
+  for (uint32_t a = 0; a < NFA; ++a) {
     const FpSection sct = reinterpret_cast<const FpSection*>(misc + 72)[a < n_fold ? a : 0u];
     fs_off[a] = sct.field_off;
     fs_bpv[a] = sct.bpv;
@@ -355,11 +359,11 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
       }
     }
     // folded Palette fields of my points: their indexes are consecutive bits, one 8-byte window holds all kFpPPT
-    uint32_t pv[kFastPalFields][kFpPPT];
+    uint32_t pv[NFA][kFpPPT];
     const uint32_t SP = (uint32_t)NOPS + n_fold;  // dwords per staged point
     if (n_fold != 0u) {
 #pragma unroll
-      for (uint32_t a = 0; a < kFastPalFields; ++a) {
+      for (uint32_t a = 0; a < NFA; ++a) {
         if (a >= n_fold) break;  // uniform
         const uint32_t bits = fs_bits[a];
         uint64_t w64 = 0u;
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
           stage[(q0 + i) * SP + (uint32_t)o] = __fmul_rn((float)in[o], res[o]);  // points >= npts: harmless slots, never read
         }
 #pragma unroll
-        for (uint32_t a = 0; a < kFastPalFields; ++a)
+        for (uint32_t a = 0; a < NFA; ++a)
           if (a < n_fold) stage[(q0 + i) * SP + (uint32_t)NOPS + a] = __uint_as_float(pv[a][i]);
         if (q0 + i + 1u == npts) {
 #pragma unroll
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
           stage[(q0 + i) * SP + (uint32_t)o] = f;
         }
 #pragma unroll
-        for (uint32_t a = 0; a < kFastPalFields; ++a)
+        for (uint32_t a = 0; a < NFA; ++a)
           if (a < n_fold) stage[(q0 + i) * SP + (uint32_t)NOPS + a] = __uint_as_float(pv[a][i]);
         if (q0 + i + 1u == npts) {
 #pragma unroll
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
               if (foff[o] != 0xffffffffu) st_raw(pt + foff[o], __float_as_uint(stage[q * SP + (uint32_t)o]), 4);
           }
 #pragma unroll
-          for (uint32_t a = 0; a < kFastPalFields; ++a) {
+          for (uint32_t a = 0; a < NFA; ++a) {
             if (a >= n_fold) break;  // uniform
             const uint32_t v = __float_as_uint(stage[q * SP + (uint32_t)NOPS + a]);
             if (fs_bpv[a] == 2u && ((fs_off[a] | step) & 1u) == 0u) *reinterpret_cast<uint16_t*>(pt + fs_off[a]) = (uint16_t)v;

@@ -2276,12 +2276,22 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     static const bool no_points = getenv("CLDN_HIP_NO_POINT_DECODE") != nullptr;  // A/B switch
     const bool points_kernel = fast && !no_points && all_qf32 && (P.n_ops == 3u || P.n_ops == 4u) && P.n_gorilla == 0u;
     if (points_kernel) {
-      if (P.n_ops == 3u)
-        hipLaunchKernelGGL((k_decode_points<3>), dim3(L.n_chunks), dim3(kFpThreads), (FpLds<3>::kTotal), L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5, L.status);
-      else
-        hipLaunchKernelGGL((k_decode_points<4>), dim3(L.n_chunks), dim3(kFpThreads), (FpLds<4>::kTotal), L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5, L.status);
+      // NF: Palette sections the launch can fold into the point pass (sizes its LDS)
+      const uint32_t nf = (L.uses_v5 && P.n_adaptive <= kFastPalFields) ? P.n_adaptive : 0u;
+#define LAUNCH_POINTS(NOPS_, NF_)                                                                                         \
+  hipLaunchKernelGGL((k_decode_points<NOPS_, NF_>), dim3(L.n_chunks), dim3(kFpThreads), (FpLds<NOPS_, NF_>::kTotal), L.stream, \
+                     P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5,  \
+                     L.status)
+      if (P.n_ops == 3u) {
+        if (nf == 0u) LAUNCH_POINTS(3, 0);
+        else if (nf == 1u) LAUNCH_POINTS(3, 1);
+        else LAUNCH_POINTS(3, 2);
+      } else {
+        if (nf == 0u) LAUNCH_POINTS(4, 0);
+        else if (nf == 1u) LAUNCH_POINTS(4, 1);
+        else LAUNCH_POINTS(4, 2);
+      }
+#undef LAUNCH_POINTS
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_points");
     }
     if (fast) {
