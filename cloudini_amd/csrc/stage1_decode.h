@@ -189,7 +189,7 @@ __device__ void decode_section_serial(Rd& r, uint8_t* base, uint32_t step, uint3
 
 // grid = n_chunks, 64 threads, lane 0 works. `only_sections`: the regular stream was decoded by the fast kernel, which
 // left the offset of the first section byte in reg_end[c].
-__global__ __launch_bounds__(64) void k_decode_general(const DevPlan plan, const uint8_t* __restrict__ streams,
+__device__ __forceinline__ void decode_general_body(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                        const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
                                                        uint32_t uses_v5, uint32_t only_sections,
                                                        const uint32_t* __restrict__ reg_end,
@@ -362,6 +362,15 @@ __global__ __launch_bounds__(64) void k_decode_general(const DevPlan plan, const
   }
   if (r.bad) atomicOr(status, (uint32_t)ST_CORRUPT);
 }
+
+__global__ __launch_bounds__(64) void k_decode_general(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                       const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
+                                                       uint32_t uses_v5, uint32_t only_sections,
+                                                       const uint32_t* __restrict__ reg_end,
+                                                       const uint8_t* __restrict__ sec_done, uint32_t* __restrict__ status) {
+  decode_general_body(plan, streams, chunks, out, uses_v5, only_sections, reg_end, sec_done, status);
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // Parallel decode of varint token streams.
@@ -922,7 +931,7 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
 }
 
 template <int NOPS, bool WIDE>
-__global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 : 8, 8))) void k_decode_varint(const DevPlan plan, const uint8_t* __restrict__ streams,
+__device__ __forceinline__ void decode_varint_body(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                               const DecChunk* __restrict__ chunks,
                                                               uint8_t* __restrict__ out, uint32_t* __restrict__ reg_end,
                                                               uint32_t* __restrict__ status, uint32_t redo_only) {
@@ -943,6 +952,15 @@ __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(WIDE
     if (!redo) atomicAdd(&status[kStatFastRegular], 1u);
   }
 }
+
+template <int NOPS, bool WIDE>
+__global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 : 8, 8))) void k_decode_varint(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                              const DecChunk* __restrict__ chunks,
+                                                              uint8_t* __restrict__ out, uint32_t* __restrict__ reg_end,
+                                                              uint32_t* __restrict__ status, uint32_t redo_only) {
+  decode_varint_body<NOPS, WIDE>(plan, streams, chunks, out, reg_end, status, redo_only);
+}
+
 
 // ---- sections -------------------------------------------------------------------------------------------------
 constexpr uint32_t kRunTile = 4096;     // DeltaRle: runs per table tile (8192 tokens)
@@ -1142,7 +1160,7 @@ __device__ __forceinline__ bool dec_palette(const uint8_t* __restrict__ src, uin
 constexpr uint32_t kSmallPalEntries = 1024;
 constexpr uint32_t kSmallSecLds = kSmallPalEntries * 8u + 8192u * 4u + 256u;  // palette, transposition buffer, misc
 
-__global__ __launch_bounds__(kDvThreads) void k_decode_sections_small(const DevPlan plan, const uint8_t* __restrict__ streams,
+__device__ __forceinline__ void decode_sections_small_body(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                                       const DecChunk* __restrict__ chunks,
                                                                       uint8_t* __restrict__ out,
                                                                       const uint32_t* __restrict__ reg_end,
@@ -1180,7 +1198,17 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_sections_small(const DevP
   }
 }
 
-__global__ __launch_bounds__(kDvThreads) void k_decode_sections(const DevPlan plan, const uint8_t* __restrict__ streams,
+__global__ __launch_bounds__(kDvThreads) void k_decode_sections_small(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                                      const DecChunk* __restrict__ chunks,
+                                                                      uint8_t* __restrict__ out,
+                                                                      const uint32_t* __restrict__ reg_end,
+                                                                      uint8_t* __restrict__ sec_done,
+                                                                      uint32_t* __restrict__ status, uint32_t honor_folded) {
+  decode_sections_small_body(plan, streams, chunks, out, reg_end, sec_done, status, honor_folded);
+}
+
+
+__device__ __forceinline__ void decode_sections_body(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                                 const DecChunk* __restrict__ chunks,
                                                                 uint8_t* __restrict__ out,
                                                                 const uint32_t* __restrict__ reg_end,
@@ -1374,5 +1402,36 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_sections(const DevPlan pl
     atomicAdd(&status[kStatFastSections], 1u);
   }
 }
+
+__global__ __launch_bounds__(kDvThreads) void k_decode_sections(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                                const DecChunk* __restrict__ chunks,
+                                                                uint8_t* __restrict__ out,
+                                                                const uint32_t* __restrict__ reg_end,
+                                                                uint8_t* __restrict__ sec_done,
+                                                                uint32_t* __restrict__ status) {
+  decode_sections_body(plan, streams, chunks, out, reg_end, sec_done, status);
+}
+
+// k_decode_tail: everything that may be left behind k_decode_points, in ONE launch (four mostly idle launches cost
+// ~5 us each): chunks it handed back -> the varint decoder; sections it did not fold -> the two section decoders;
+// whatever those stepped away from -> the serial decoder on thread 0. The bodies are the kernels above; a barrier
+// between them orders what one leaves in reg_end / sec_done for the next. All early exits of the bodies are uniform
+// over the workgroup (they depend on the chunk table, reg_end, sec_done and LDS words read behind barriers).
+__global__ __launch_bounds__(kDvThreads) void k_decode_tail(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                            const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
+                                                            uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done,
+                                                            uint32_t* __restrict__ status, uint32_t uses_v5,
+                                                            uint32_t with_sections) {
+  decode_varint_body<4, false>(plan, streams, chunks, out, reg_end, status, 1u);
+  __syncthreads();
+  if (with_sections) {
+    decode_sections_small_body(plan, streams, chunks, out, reg_end, sec_done, status, 1u);
+    __syncthreads();
+    decode_sections_body(plan, streams, chunks, out, reg_end, sec_done, status);
+    __syncthreads();
+  }
+  decode_general_body(plan, streams, chunks, out, uses_v5, 1u, reg_end, with_sections ? sec_done : nullptr, status);
+}
+
 
 }  // namespace cldn

@@ -1860,6 +1860,9 @@ int stage1_configure_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_varint<8, true>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Dv2Lds<8, true, 8>::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_varint<8>)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)std::max<uint32_t>(std::max<uint32_t>((uint32_t)Dv2Lds<4, false, 16>::kTotal, kSmallSecLds), (uint32_t)DecSecLds::kTotal));
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_tail)");
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sections),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecSecLds::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_sections)");
@@ -2293,6 +2296,20 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       }
 #undef LAUNCH_POINTS
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_points");
+    }
+    // Behind k_decode_points, for plans whose sections it can fold, the rest is normally idle: one launch covers it
+    // (plans with more adaptive fields keep the separate kernels: their Palette chunks really run k_decode_sections_small,
+    // which wants its own, smaller LDS footprint)
+    static const bool no_tail = getenv("CLDN_HIP_NO_DECODE_TAIL") != nullptr;  // A/B switch
+    const bool sections_any = L.uses_v5 && P.n_adaptive > 0u;
+    if (points_kernel && !no_tail && (!sections_any || P.n_adaptive <= kFastPalFields)) {
+      const uint32_t lds = sections_any ? std::max<uint32_t>(std::max<uint32_t>((uint32_t)Dv2Lds<4, false, 16>::kTotal, kSmallSecLds), (uint32_t)DecSecLds::kTotal)
+                                        : (uint32_t)Dv2Lds<4, false, 16>::kTotal;
+      hipLaunchKernelGGL(k_decode_tail, dim3(L.n_chunks), dim3(kDvThreads), lds, L.stream, P, L.streams,
+                         reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.status, L.uses_v5,
+                         sections_any ? 1u : 0u);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_tail");
+      return CLDN_HIP_OK;
     }
     if (fast) {
       if (all_qf32 && P.n_ops <= 4u)
