@@ -132,6 +132,8 @@ def e2e_figures(info, cloud, dev, budget_s: float):
       device_resident   cldn_hip_encode_stage1, input and output in HBM
       pinned_host       the same call with HOST tags on pinned memory (H2D + kernels + D2H)
       pageable_host     ... on pageable memory
+      host_mirror_decode_*  Cloudini::PointcloudDecoder::decode of the stream the encoder leg produced, next to the
+                        reference's decoder
       host_mirror_*     Cloudini::PointcloudEncoder (libcloudini_amd.so) constructed fresh for every call, full stream
                         with header into a pre-sized buffer (mcap_codec_benchmark.cpp:447-457 bracket, construction
                         included), next to the compiled reference under the same bracket on the host cores."""
@@ -143,7 +145,7 @@ def e2e_figures(info, cloud, dev, budget_s: float):
     step = info.point_step
     pts = len(cloud) // step
     out = {"points_per_call": pts, "note": "one cloud per call, synchronous; median of the calls that fit the budget"}
-    per_leg = max(0.3, budget_s / 8.0)
+    per_leg = max(0.3, budget_s / 10.0)
 
     def timed(fn, warm=2):
         for _ in range(warm):
@@ -221,6 +223,25 @@ def e2e_figures(info, cloud, dev, budget_s: float):
                                 "threads": "1 encode thread + the reference's own stage-2 worker (use_threads=true)",
                                 "bracket": "encoder constructed outside the timed region, pre-sized output"}
         out["host_mirror_" + comp.name] = leg
+        # the way back: PointcloudDecoder::decode of that very stream (header parsed once outside, like the subscriber
+        # plugin does), host buffers, next to the reference's decoder
+        stream = hout[: size_box[0]].copy()
+        hdr_len = int(np.nonzero(stream == 0)[0][0]) + 1
+        body = stream[hdr_len:]
+        dec_out = np.empty(cloud.size, dtype=np.uint8)
+
+        def mirror_decode():
+            n = hl.cldn_amd_decode_noheader(C.byref(ci), api._ptr(body), body.size, api._ptr(dec_out), dec_out.size)
+            assert n == cloud.size
+        dleg = timed(mirror_decode)
+        dleg["stage2_threads"] = pool_threads if comp != CompressionOption.NONE else 0
+        dleg["bracket"] = "fresh PointcloudDecoder per call, header parsed outside, pre-sized output, host buffers"
+        if ref is not None:
+            reps = int(max(3, min(30, per_leg / 0.03)))
+            _dec, t = ref.bench_decode(stream, cloud.size, reps=reps)
+            dleg["reference"] = {"median_ms": float(np.median(t)) * 1e3, "min_ms": float(t.min()) * 1e3, "n": reps,
+                                 "threads": "1 decode thread (the reference's decoder is single-threaded)"}
+        out["host_mirror_decode_" + comp.name] = dleg
         if comp == CompressionOption.LZ4 and hasattr(api, "set_stage2_threads"):
             # the same call with the stage-2 knob at 16 threads (the box grants 16 CPUs): from 8 threads on encode() cuts
             # the cloud into two chunk groups and compresses the first while the GPU encodes the second
