@@ -755,7 +755,8 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
     if (plan.n_gorilla) {
       void* ptrs[kMaxGorilla] = {nullptr, nullptr, nullptr, nullptr};
       for (uint32_t g = 0; g < plan.n_gorilla; ++g) {
-        if ((rc = c->d_pre[g].ensure((size_t)n_points * 16 + 64)) != CLDN_HIP_OK) return rc;
+        // 16-byte tokens per point (generic kernel) or one window word per piece (piece kernel, kGorWinStride per chunk)
+        if ((rc = c->d_pre[g].ensure(std::max((size_t)n_points * 16, (size_t)n_chunks * 256) + 64)) != CLDN_HIP_OK) return rc;
         ptrs[g] = c->d_pre[g].p;
       }
       if ((rc = c->d_pre_ptrs.ensure(sizeof(ptrs))) != CLDN_HIP_OK) return rc;

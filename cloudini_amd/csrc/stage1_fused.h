@@ -254,7 +254,7 @@ struct FusedArgs {
   uint32_t tail_kind;            // OP_* of plan.ops[LANES]
   uint32_t tail_rel;             // its offset behind plan.ops[0].offset (inside the LOADW dwords loaded per point)
   uint32_t tail_size;            // field bytes
-  const uint4* tail_tokens;      // OP_GORILLA64: the tokens k_gorilla_tokens left, one per point of the batch
+  const uint16_t* tail_windows;  // OP_GORILLA64: k_gorilla_windows' window in front of every piece, [chunk * 128 + piece]
   uint32_t ablate;               // profiling only (CLDN_HIP_ABLATE): 1 no statistics pass, 2 no inter-piece protocol (fake positions), 4 no column stores
 };
 
@@ -335,20 +335,13 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
     }
   }
 
-  // TAIL, Gorilla: the ready-made token of every point of mine, requested with the rows (same reason: no load inside
-  // the row loop)
-  uint4 gtok[TAIL ? ROWS : 1];
-  if (TAIL) {
-#pragma unroll
-    for (uint32_t r = 0; r < (TAIL ? ROWS : 1u); ++r) gtok[r] = make_uint4(0u, 0u, 0u, 0u);
-    if (n && A.tail_kind == (uint32_t)OP_GORILLA64) {
-      const uint4* tq = A.tail_tokens + first_point;
-#pragma unroll
-      for (uint32_t r = 0; r < (TAIL ? ROWS : 1u); ++r) {
-        const int32_t idx = (int32_t)(r * kRowPts + lane) - 1;
-        gtok[r] = tq[(idx >= 0 && idx < (int32_t)n) ? (uint32_t)idx : 0u];
-      }
-    }
+  // TAIL, Gorilla (FieldEncoderFloat_Gorilla<double>, include/cloudini_lib/field_encoder.hpp:156-312): the (leading,
+  // trailing) window in front of my piece comes from k_gorilla_windows; from there the wave carries it row by row
+  uint32_t gw_lead = 255u, gw_trail = 0u;
+  if (TAIL && n && A.tail_kind == (uint32_t)OP_GORILLA64) {
+    const uint32_t w16 = A.tail_windows[(size_t)pd.chunk * 128u + p];
+    gw_lead = w16 & 0xffu;
+    gw_trail = w16 >> 8;
   }
 
   // zero my stream region (tokens are OR-ed in) and, together, the bitmap -- while the loads fly
@@ -454,11 +447,61 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
           if (isn) tt.len = 1u;
           else tt = varint64_tok((int64_t)((uint64_t)q - (uint64_t)pq));
         } else {  // OP_GORILLA64
-          const uint4 g = gtok[TAIL ? r : 0u];
-          tt.w0 = g.x;
-          tt.w1 = g.y;
-          tt.w2 = g.z;
-          tt.len = g.w;
+          const bool chunk_first = first == 0u && idx == 0;          // the chunk's first value is written raw
+          const uint64_t x = raw ^ shr1_carry64(raw, 0u);
+          const uint32_t lead = x ? (uint32_t)__builtin_clzll(x) : 64u;
+          const uint32_t trail = x ? (uint32_t)__builtin_ctzll(x) : 0u;
+          // every lane assumes the current window; the lowest lane that would open a new one is resolved, the window is
+          // updated, and only the lanes behind it re-check (lanes = points in order; lane 0 is the point before the row)
+          bool pending = emits && !chunk_first && x != 0u;
+          bool opens = false;
+          uint32_t my_lead = gw_lead, my_trail = gw_trail;
+          for (;;) {
+            const bool would_open = pending && (gw_lead == 255u || lead < gw_lead || trail < gw_trail);
+            const uint64_t ev = __ballot(would_open);
+            if (ev == 0ull) {
+              if (pending) {
+                my_lead = gw_lead;
+                my_trail = gw_trail;
+              }
+              break;
+            }
+            const uint32_t e = (uint32_t)__builtin_ctzll(ev);
+            if (pending && lane <= e) {
+              my_lead = gw_lead;
+              my_trail = gw_trail;
+              opens = (lane == e);
+              pending = false;
+            }
+            const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)lead, (int)e);
+            gw_lead = le > 31u ? 31u : le;
+            gw_trail = (uint32_t)__builtin_amdgcn_readlane((int)trail, (int)e);
+          }
+          uint64_t lo = 0u, hi = 0u;
+          uint32_t nbits;
+          if (chunk_first) {
+            lo = raw;
+            nbits = 64u;
+          } else if (x == 0u) {
+            nbits = 1u;  // single '0' bit
+          } else if (!opens) {
+            const uint32_t m = 64u - my_lead - my_trail;  // '1','0', m bits of (x >> trailing)
+            const uint64_t payload = x >> my_trail;
+            lo = 1u | (payload << 2);
+            hi = payload >> 62;
+            nbits = 2u + m;
+          } else {
+            const uint32_t sl = lead > 31u ? 31u : lead;  // '1','1', leading(5), m-1 (6), m bits of (x >> trailing)
+            const uint32_t m = 64u - sl - trail;
+            const uint64_t payload = x >> trail;
+            lo = 3u | ((uint64_t)sl << 2) | ((uint64_t)(m - 1u) << 7) | (payload << 13);
+            hi = payload >> 51;
+            nbits = 13u + m;
+          }
+          tt.w0 = (uint32_t)lo;
+          tt.w1 = (uint32_t)(lo >> 32);
+          tt.w2 = (uint32_t)hi;
+          tt.len = (nbits + 7u) >> 3;
         }
         total += tt.len;
       }

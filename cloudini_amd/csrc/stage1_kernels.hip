@@ -1052,6 +1052,119 @@ __global__ __launch_bounds__(kGorThreads) void k_gorilla_tokens(const DevPlan pl
   }
 }
 
+// k_gorilla_windows: steps 1 and 2 of k_gorilla_tokens for layouts whose Gorilla field the piece kernel encodes itself
+// (TAIL instantiations of k_encode_fused): all it leaves behind is the window in effect in front of every piece of
+// `piece_pts` points -- out[chunk * kGorWinStride + piece] = lead | trail << 8 (lead 255 = no window yet) -- instead of
+// a 16-byte token per point written here and read back there. grid = (n_chunks), block = kGorThreads.
+constexpr uint32_t kGorWinStride = 128;  // >= pieces per chunk (32768 / 378 = 87)
+
+// min over the wave, valid in lane 63 (DPP row shifts and row broadcasts; lanes without a source keep their own value)
+__device__ __forceinline__ uint32_t gor_wave_min(uint32_t x) {
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x111, 0xf, 0xf, false));  // row_shr:1
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x112, 0xf, 0xf, false));  // row_shr:2
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x114, 0xf, 0xf, false));  // row_shr:4
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x118, 0xf, 0xf, false));  // row_shr:8
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x142, 0xa, 0xf, false));  // row_bcast:15
+  x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x143, 0xc, 0xf, false));  // row_bcast:31
+  return x;
+}
+
+__global__ __launch_bounds__(kGorThreads) void k_gorilla_windows(const DevPlan plan, uint32_t opi, uint32_t piece_pts,
+                                                                 const uint8_t* __restrict__ points,
+                                                                 const uint8_t* __restrict__ points_end,
+                                                                 const ChunkDesc* __restrict__ chunks,
+                                                                 uint16_t* __restrict__ win_out) {
+  constexpr uint32_t NB = kGorPass / 64u;  // batches of 64 points per pass: one per (k, wave)
+  static_assert(NB <= 128u, "two batch summaries per lane of wave 0");
+  __shared__ uint16_t lt[kGorPass];
+  __shared__ uint32_t bmin[NB];  // per batch: min lead | min trail << 8 over its points that differ from their predecessor
+  const uint32_t field_off = plan.ops[opi].offset;
+  const ChunkDesc cd = chunks[blockIdx.x];
+  const uint32_t n = cd.n_points;
+  const uint32_t step = plan.point_step;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = tid >> 6;
+  const uint8_t* base = points + (size_t)cd.first_point * step + field_off;
+  uint16_t* out = win_out + (size_t)blockIdx.x * kGorWinStride;
+
+  uint32_t win_lead = 255u, win_trail = 0u;
+  for (uint32_t p0 = 0; p0 < n; p0 += kGorPass) {
+#pragma unroll
+    for (uint32_t k = 0; k < kGorPPT; ++k) {
+      const uint32_t i = p0 + k * kGorThreads + tid;
+      uint64_t x = 0u;
+      if (i < n) {
+        const uint8_t* q = base + (size_t)i * step;
+        const uint64_t cur = gor_load64(q, points_end);
+        const uint64_t prev = i ? gor_load64(q - step, points_end) : 0u;
+        x = i ? (cur ^ prev) : 0u;
+      }
+      const bool counts = x != 0u;  // may open a window
+      const uint32_t lead = x ? (uint32_t)__builtin_clzll(x) : 64u;
+      const uint32_t trail = x ? (uint32_t)__builtin_ctzll(x) : 0u;
+      lt[k * kGorThreads + tid] = (uint16_t)(lead | (trail << 8));
+      // the batch of this (k, wave): the smallest counts any of its points brings -- a window at least that wide on both
+      // sides is left alone by the whole batch, and the serial walk below skips it
+      uint32_t ml = counts ? lead : 255u, mt = counts ? trail : 255u;
+      ml = gor_wave_min(ml);
+      mt = gor_wave_min(mt);
+      if (lane == 63u) bmin[k * (kGorThreads / 64u) + wave] = ml | (mt << 8);
+    }
+    __syncthreads();
+    if (tid < 64u) {
+      const uint32_t np = min(kGorPass, n - p0);
+      const uint32_t my_bmin0 = lane < NB ? bmin[lane] : 0xffffu;
+      const uint32_t my_bmin1 = lane + 64u < NB ? bmin[lane + 64u] : 0xffffu;
+      for (uint32_t b = 0; b * 64u < np; ++b) {
+        const uint32_t b0 = b * 64u;
+        const uint32_t bm = (uint32_t)__builtin_amdgcn_readlane((int)(b < 64u ? my_bmin0 : my_bmin1), (int)(b & 63u));  // uniform
+        const uint32_t entry_lead = win_lead, entry_trail = win_trail;
+        const bool quiet = (bm & 0xffu) == 255u || (win_lead != 255u && (bm & 0xffu) >= win_lead && (bm >> 8) >= win_trail);
+        uint64_t opened = 0ull;
+        uint32_t lead = 0u, trail = 0u;
+        if (!quiet) {
+          const uint32_t j = b0 + lane;
+          const uint32_t e16 = lt[j];
+          lead = e16 & 0xffu;
+          trail = e16 >> 8;
+          bool pending = j < np && (p0 + j) > 0u && lead != 64u;
+          for (;;) {
+            const bool would_open = pending && (win_lead == 255u || lead < win_lead || trail < win_trail);
+            const uint64_t ev = __ballot(would_open);
+            if (ev == 0ull) break;
+            const uint32_t e = (uint32_t)__builtin_ctzll(ev);
+            opened |= 1ull << e;
+            if (lane <= e) pending = false;
+            const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)lead, (int)e);
+            const uint32_t te = (uint32_t)__builtin_amdgcn_readlane((int)trail, (int)e);
+            win_lead = le > 31u ? 31u : le;
+            win_trail = te;
+          }
+        }
+        // a piece that starts inside this batch: the window in front of its first point is the one the last opener
+        // below that lane set, or the one the batch was entered with
+        const uint32_t i0 = p0 + b0;                                   // chunk index of lane 0's point
+        const uint32_t pc = (i0 + piece_pts - 1u) / piece_pts;         // first piece starting at or behind i0
+        const uint32_t bnd = pc * piece_pts;
+        if (bnd < i0 + 64u && bnd < n) {                               // uniform
+          const uint32_t lb = bnd - i0;
+          const uint64_t below = opened & ((1ull << lb) - 1ull);
+          uint32_t wl = entry_lead, wt = entry_trail;
+          if (below != 0ull) {
+            const int e = 63 - (int)__builtin_clzll(below);
+            const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)lead, e);
+            wl = le > 31u ? 31u : le;
+            wt = (uint32_t)__builtin_amdgcn_readlane((int)trail, e);
+          }
+          if (lane == 0u) out[pc] = (uint16_t)(wl | (wt << 8));
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // k_chunk_offsets: payload size of every chunk, exclusive scan of the framed sizes (4 + payload), per-cloud
 // stream offsets. One workgroup.
@@ -1926,6 +2039,13 @@ uint32_t stage1_piece_points(const DevPlan& plan, const uint8_t* points) {
   return fused_piece_points(v.lanes);
 }
 
+// the piece kernel takes this plan and its tail op is the Gorilla field: points per piece, else 0
+uint32_t stage1_gorilla_inline_piece_points(const DevPlan& plan, const uint8_t* points) {
+  FusedVariant v;
+  if (!fused_variant(plan, points, &v) || v.tail < 0 || plan.ops[v.tail].kind != OP_GORILLA64) return 0u;
+  return fused_piece_points(v.lanes);
+}
+
 uint32_t stage1_piece_slot_stride(const DevPlan& plan, const uint8_t* points) {
   FusedVariant v;
   if (!fused_variant(plan, points, &v)) return 0u;
@@ -1983,13 +2103,13 @@ static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piec
   A.tail_kind = 0u;
   A.tail_rel = 0u;
   A.tail_size = 0u;
-  A.tail_tokens = nullptr;
+  A.tail_windows = nullptr;
   if (v.tail >= 0) {
     const DevOp& top = L.plan->ops[v.tail];
     A.tail_kind = top.kind;
     A.tail_rel = top.offset - L.plan->ops[0].offset;
     A.tail_size = top.size;
-    if (top.kind == OP_GORILLA64) A.tail_tokens = L.pre.p[top.type];
+    if (top.kind == OP_GORILLA64) A.tail_windows = reinterpret_cast<const uint16_t*>(L.pre.p[top.type]);
   }
   const uint32_t region = v.tail >= 0 ? fused_region_bytes_tail(v.lanes) : fused_region_bytes(v.lanes);
   const uint32_t lds = 16u + kFusedWaves * region + (n_bm ? kBitmapWords * 4u : 0u);
@@ -2146,9 +2266,10 @@ static int launch_encode_groups(const EncodeLaunch& L) {
 
 int stage1_launch_encode(const EncodeLaunch& L) {
   hipError_t e;
-  if (L.n_groups > 1u && L.pieces && !L.fused && L.n_chunks) return launch_encode_groups(L);
+  if (L.n_groups > 1u && L.pieces && !L.fused && L.n_chunks && !L.plan->n_gorilla) return launch_encode_groups(L);
   if (L.events) (void)hipEventRecord(L.events[0], L.stream);
   const uint32_t na_f = L.plan->n_adaptive;
+  uint32_t gor_piece_pts = 0u;  // the piece kernel encodes the Gorilla field itself: points per piece
   if (L.fused) {
     // the modes come first: the single-pass kernel needs them for its section statistics
     if (L.n_chunks && na_f && !L.modes_forced) {
@@ -2167,7 +2288,14 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     goto regular_done;
   }
   if (L.events) (void)hipEventRecord(L.events[1], L.stream);
-  if (L.n_chunks && L.plan->n_gorilla) {
+  gor_piece_pts = (L.n_chunks && L.pieces && !L.fused) ? stage1_gorilla_inline_piece_points(*L.plan, L.points) : 0u;
+  if (gor_piece_pts) {
+    const uint32_t opi = L.plan->n_ops - 1u;  // the tail op
+    hipLaunchKernelGGL(k_gorilla_windows, dim3(L.n_chunks), dim3(kGorThreads), 0, L.stream, *L.plan, opi, gor_piece_pts,
+                       L.points, L.points_end, L.chunks,
+                       reinterpret_cast<uint16_t*>(const_cast<uint4*>(L.pre.p[L.plan->ops[opi].type])));
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_gorilla_windows");
+  } else if (L.n_chunks && L.plan->n_gorilla) {
     hipLaunchKernelGGL(k_gorilla_tokens, dim3(L.n_chunks, L.plan->n_gorilla), dim3(kGorThreads), 0, L.stream, *L.plan,
                        L.points, L.points_end, L.chunks, L.pre_out);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_gorilla_tokens");
