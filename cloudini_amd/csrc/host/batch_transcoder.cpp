@@ -3,6 +3,7 @@
 #include "cloudini_amd/batch_transcoder.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -107,6 +108,7 @@ bool DirectorySource::next(Message& out) {
   std::ifstream f(dir_ + "/" + out.name, std::ios::binary | std::ios::ate);
   if (!f) throw std::runtime_error("cannot read " + dir_ + "/" + out.name);
   const std::streamsize size = f.tellg();
+  if (size < 0) throw std::runtime_error("cannot size " + dir_ + "/" + out.name);
   f.seekg(0);
   out.bytes.resize(static_cast<size_t>(size));
   if (size && !f.read(reinterpret_cast<char*>(out.bytes.data()), size)) throw std::runtime_error("short read: " + out.name);
@@ -308,7 +310,9 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
   for (size_t i = 0; i < kBatchesInFlight; ++i) storage.emplace_back(new Batch());
   BoundedQueue<Batch*> free_q(kBatchesInFlight), to_gpu(kBatchesInFlight), to_stage2(kBatchesInFlight), to_write(kBatchesInFlight);
   for (auto& b : storage) free_q.push(b.get());
+  // every error is written by one thread and rethrown behind the joins; the flags are what the other threads look at
   std::exception_ptr reader_error, stage2_error, writer_error, gpu_error;
+  std::atomic<bool> stage2_failed{false};
   const size_t batch = std::max<size_t>(1, opt.batch_messages);
 
   std::thread reader([&] {
@@ -340,11 +344,12 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
   std::thread stage2([&] {
     Batch* b = nullptr;
     while (to_stage2.pop(b)) {
-      if (!stage2_error) {
+      if (!stage2_failed.load()) {
         try {
           stage2Phase(*b, opt, &stats2);
         } catch (...) {
           stage2_error = std::current_exception();
+          stage2_failed.store(true);
         }
       }
       to_write.push(b);
@@ -354,7 +359,7 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
   std::thread writer([&] {
     Batch* b = nullptr;
     while (to_write.pop(b)) {
-      if (!writer_error && !stage2_error) {
+      if (!writer_error && !stage2_failed.load()) {
         try {
           for (size_t i = 0; i < b->in.size(); ++i) sink.write(b->in[i].name, b->out[i].data(), b->out[i].size());
         } catch (...) {
