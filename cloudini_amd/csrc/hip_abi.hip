@@ -1197,6 +1197,7 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams
   }
   uint8_t* d_outp = (uint8_t*)points_out;
   if (out_loc == CLDN_HIP_HOST) {
+    c->pending_total = 0;  // the device output buffer is reused: a deferred encode output waiting in it is gone
     if ((rc = c->d_out.ensure((size_t)std::max<uint64_t>(1, need))) != CLDN_HIP_OK) return rc;
     d_outp = (uint8_t*)c->d_out.p;
     // bytes of a point that no field covers keep the caller's content (src/field_decoder.cpp:72-76): bring it along
