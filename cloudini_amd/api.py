@@ -63,6 +63,8 @@ def lib() -> C.CDLL:
                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.cldn_amd_transcode_directory.restype = C.c_int64
     L.cldn_amd_transcode_directory.argtypes = [C.c_char_p, C.c_char_p, C.c_float, C.c_uint8, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
+    L.cldn_amd_decode_directory.restype = C.c_int64
+    L.cldn_amd_decode_directory.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_double)]
     L.cldn_amd_stage2_threads.restype = C.c_uint32
     L.cldn_amd_set_stage2_threads.restype = C.c_uint32
     L.cldn_amd_set_stage2_threads.argtypes = [C.c_uint32]
@@ -130,6 +132,15 @@ def transcode_directory(in_dir: str, out_dir: str, resolution: float = 0.001, co
     st = (C.c_double * 8)()
     _check(lib().cldn_amd_transcode_directory(in_dir.encode(), out_dir.encode(), resolution, compression_opt,
                                               1 if viz_lossy else 0, batch_messages, st))
+    keys = ("messages", "points", "input_bytes", "output_bytes", "gpu_batches", "seconds_total", "seconds_gpu", "seconds_stage2")
+    return dict(zip(keys, [float(x) for x in st]))
+
+
+def decode_directory(in_dir: str, out_dir: str, batch_messages: int = 64) -> dict:
+    """The way back: every CDR CompressedPointCloud2 file of in_dir -> PointCloud2 file of the same name in out_dir
+    (batched GPU decode). Returns the statistics."""
+    st = (C.c_double * 8)()
+    _check(lib().cldn_amd_decode_directory(in_dir.encode(), out_dir.encode(), batch_messages, st))
     keys = ("messages", "points", "input_bytes", "output_bytes", "gpu_batches", "seconds_total", "seconds_gpu", "seconds_stage2")
     return dict(zip(keys, [float(x) for x in st]))
 

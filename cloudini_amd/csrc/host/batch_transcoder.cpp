@@ -136,6 +136,8 @@ struct Run {                       // messages [first, first + count) share a sc
   PinnedBytes stage1;              // framed stage-1 streams of the run, page-locked (the GPU copies into it)
   std::vector<uint64_t> offsets;   // count + 1
   std::vector<uint32_t> chunk_sizes;
+  PinnedBytes decoded;             // decode direction: the points of the run's clouds, back to back
+  std::vector<uint64_t> out_at;    // decode direction: where every message's points start in `decoded`
 };
 
 struct Batch {
@@ -285,6 +287,131 @@ void stage2Phase(Batch& b, const TranscodeOptions& opt, TranscodeStats* stats) {
   if (stats) stats->seconds_stage2 += since(t_s2);
 }
 
+// ---- the way back: CompressedPointCloud2 -> PointCloud2 ---------------------------------------------------------------
+
+// per message: CDR parse + Cloudini header; per schema run: stage 2 undone on the host pool, ONE batched GPU decode
+void decodeGpuPhase(Batch& b, TranscodeStats* stats) {
+  const size_t n = b.in.size();
+  b.parsed.assign(n, Parsed());
+  b.out.assign(n, {});
+  std::vector<Cloudini::ConstBufferView> body(n);  // the chunks of every message, behind the Cloudini header
+  for (size_t i = 0; i < n; ++i) {
+    Parsed& p = b.parsed[i];
+    p.pc = cloudini_ros::getDeserializedPointCloudMessage(Cloudini::ConstBufferView(b.in[i].bytes.data(), b.in[i].bytes.size()));
+    const uint64_t cloud_bytes = uint64_t(p.pc.width) * p.pc.height * p.pc.point_step;
+    p.points = 0;
+    p.key.clear();
+    if (cloud_bytes != 0) {
+      body[i] = p.pc.data;
+      p.info = Cloudini::DecodeHeader(body[i]);
+      const uint64_t pts = uint64_t(p.info.width) * p.info.height;
+      // what the decoder would check (src/cloudini.cpp:632-635), against the size the message announces
+      if (pts * p.info.point_step > cloud_bytes) throw std::runtime_error("Output buffer is too small to hold the decoded data");
+      p.points = pts;
+      // batchable only when the message's own geometry is the header's (always, for streams this library or the
+      // reference wrote); anything else takes the single-message path in the wrap phase
+      if (pts * p.info.point_step == cloud_bytes && pts != 0) p.key = schemaKey(p.info);
+    }
+    if (stats) {
+      stats->messages += 1;
+      stats->points += p.points;
+      stats->input_bytes += b.in[i].bytes.size();
+    }
+  }
+  size_t n_runs = 0;
+  std::vector<Cloudini::amd_detail::ChunkRef> refs, all_refs;
+  for (size_t r0 = 0; r0 < n;) {
+    if (b.parsed[r0].key.empty()) {  // empty or odd message: no GPU work here
+      ++r0;
+      continue;
+    }
+    size_t r1 = r0 + 1;
+    while (r1 < n && b.parsed[r1].key == b.parsed[r0].key) ++r1;
+    if (b.runs.size() <= n_runs) b.runs.emplace_back();
+    Run& run = b.runs[n_runs++];
+    run.first = r0;
+    run.count = static_cast<uint32_t>(r1 - r0);
+    const Cloudini::EncodingInfo& info0 = b.parsed[r0].info;
+    const auto t_gpu = Clock::now();
+    // stage 2 undone chunk by chunk into worst-case slots, then packed into the framed stage-1 streams of the run
+    const size_t slot = 4u + Cloudini::amd_detail::stage1ChunkBound(info0) + 64u;
+    all_refs.clear();
+    std::vector<size_t> first_ref(run.count + 1, 0);
+    for (uint32_t k = 0; k < run.count; ++k) {
+      Cloudini::amd_detail::walkCompressedChunks(body[r0 + k], b.parsed[r0 + k].points, refs);
+      first_ref[k] = all_refs.size();
+      all_refs.insert(all_refs.end(), refs.begin(), refs.end());
+    }
+    first_ref[run.count] = all_refs.size();
+    if (run.stage1.size() < slot * all_refs.size()) run.stage1.resize(slot * all_refs.size());
+    uint8_t* scratch = run.stage1.data();
+    std::vector<uint32_t> got(all_refs.size());
+    const Cloudini::CompressionOption comp = info0.compression_opt;  // part of the schema key: the same for the whole run
+    Cloudini::amd_detail::runOnStage2Pool(all_refs.size(), [&](size_t c) {
+      got[c] = Cloudini::amd_detail::decompressChunkTo(comp, all_refs[c].src, all_refs[c].size, scratch + c * slot + 4, slot - 4);
+    });
+    run.offsets.assign(run.count + 1, 0);
+    run.out_at.assign(run.count + 1, 0);
+    std::vector<uint64_t> pts(run.count);
+    size_t produced = 0;
+    for (uint32_t k = 0; k < run.count; ++k) {
+      run.offsets[k] = produced;
+      for (size_t c = first_ref[k]; c < first_ref[k + 1]; ++c) {  // slot c starts at or behind `produced`
+        std::memcpy(scratch + c * slot, &got[c], 4);
+        if (produced != c * slot) std::memmove(scratch + produced, scratch + c * slot, 4u + size_t(got[c]));
+        produced += 4u + size_t(got[c]);
+      }
+      pts[k] = b.parsed[r0 + k].points;
+      run.out_at[k + 1] = run.out_at[k] + pts[k] * info0.point_step;
+    }
+    run.offsets[run.count] = produced;
+    const uint64_t out_bytes = run.out_at[run.count];
+    if (run.decoded.size() < out_bytes) run.decoded.resize(out_bytes);
+    // bytes of a point that no field covers stay what they are: zero, like the freshly resized vector the reference
+    // decodes into (src/ros_msg_utils.cpp:150-153)
+    std::memset(run.decoded.data(), 0, out_bytes);
+    Cloudini::amd_detail::decodeStage1Batch(info0, scratch, run.offsets.data(), pts.data(), run.count, run.decoded.data(),
+                                            out_bytes);
+    if (stats) {
+      stats->seconds_gpu += since(t_gpu);
+      stats->gpu_batches += 1;
+    }
+    r0 = r1;
+  }
+  b.runs.resize(n_runs);
+}
+
+// CDR wrapping of the decoded clouds (convertCompressedCloudToPointCloud2, src/ros_msg_utils.cpp:135-165)
+void decodeWrapPhase(Batch& b, TranscodeStats* stats) {
+  const auto t0 = Clock::now();
+  const size_t n = b.in.size();
+  std::vector<const uint8_t*> data_of(n, nullptr);
+  for (const Run& run : b.runs)
+    for (uint32_t k = 0; k < run.count; ++k) data_of[run.first + k] = run.decoded.data() + run.out_at[k];
+  for (size_t i = 0; i < n; ++i) {
+    const Parsed& p = b.parsed[i];
+    std::vector<uint8_t>& msg = b.out[i];
+    const size_t cloud_bytes = size_t(p.pc.width) * p.pc.height * p.pc.point_step;
+    if (cloud_bytes != 0 && !data_of[i]) {  // geometry of the message and of its Cloudini header differ: one by one
+      cloudini_ros::convertCompressedCloudToPointCloud2(p.pc, msg);
+    } else {
+      msg.clear();
+      nanocdr::Encoder enc(p.pc.cdr_header, msg);
+      cloudini_ros::writePointCloudHeader(enc, p.pc);
+      enc.encode(static_cast<uint32_t>(cloud_bytes));
+      if (cloud_bytes != 0) {
+        const size_t at = msg.size();
+        msg.resize(at + cloud_bytes);
+        std::memcpy(msg.data() + at, data_of[i], cloud_bytes);
+      }
+      nanocdr::Encoder tail(p.pc.cdr_header, msg, /*append=*/true);
+      tail.encode(p.pc.is_dense);
+    }
+    if (stats) stats->output_bytes += msg.size();
+  }
+  if (stats) stats->seconds_stage2 += since(t0);
+}
+
 }  // namespace
 
 void transcodeBatch(const std::vector<Message>& in, const TranscodeOptions& opt, std::vector<std::vector<uint8_t>>& out,
@@ -295,8 +422,13 @@ void transcodeBatch(const std::vector<Message>& in, const TranscodeOptions& opt,
     b.in[i].name = in[i].name;
     b.in[i].bytes.assign(in[i].bytes.begin(), in[i].bytes.end());
   }
-  gpuPhase(b, opt, stats);
-  stage2Phase(b, opt, stats);
+  if (opt.decode) {
+    decodeGpuPhase(b, stats);
+    decodeWrapPhase(b, stats);
+  } else {
+    gpuPhase(b, opt, stats);
+    stage2Phase(b, opt, stats);
+  }
   out = std::move(b.out);
 }
 
@@ -346,7 +478,8 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
     while (to_stage2.pop(b)) {
       if (!stage2_failed.load()) {
         try {
-          stage2Phase(*b, opt, &stats2);
+          if (opt.decode) decodeWrapPhase(*b, &stats2);
+          else stage2Phase(*b, opt, &stats2);
         } catch (...) {
           stage2_error = std::current_exception();
           stage2_failed.store(true);
@@ -374,7 +507,8 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
   while (to_gpu.pop(b)) {
     if (!gpu_error) {
       try {
-        gpuPhase(*b, opt, &stats);
+        if (opt.decode) decodeGpuPhase(*b, &stats);
+        else gpuPhase(*b, opt, &stats);
       } catch (...) {
         gpu_error = std::current_exception();
       }

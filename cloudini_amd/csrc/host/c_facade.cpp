@@ -112,6 +112,24 @@ CLDN_EXPORT int64_t cldn_amd_transcode_directory(const char* in_dir, const char*
   });
 }
 
+CLDN_EXPORT int64_t cldn_amd_decode_directory(const char* in_dir, const char* out_dir, uint32_t batch_messages,
+                                              double* stats_out) {
+  return guarded([&] {
+    cloudini_amd::DirectorySource source(in_dir);
+    cloudini_amd::DirectorySink sink(out_dir);
+    cloudini_amd::TranscodeOptions opt;
+    opt.decode = true;
+    if (batch_messages) opt.batch_messages = batch_messages;
+    const cloudini_amd::TranscodeStats st = cloudini_amd::transcodePointClouds(source, sink, opt);
+    if (stats_out) {
+      const double v[8] = {(double)st.messages,    (double)st.points,  (double)st.input_bytes, (double)st.output_bytes,
+                           (double)st.gpu_batches, st.seconds_total, st.seconds_gpu,         st.seconds_stage2};
+      for (int i = 0; i < 8; ++i) stats_out[i] = v[i];
+    }
+    return (int64_t)st.messages;
+  });
+}
+
 CLDN_EXPORT uint32_t cldn_amd_stage2_threads(void) { return Cloudini::amd_detail::stage2Threads(); }
 CLDN_EXPORT uint32_t cldn_amd_set_stage2_threads(uint32_t n) {
   Cloudini::amd_detail::setStage2Threads(n);

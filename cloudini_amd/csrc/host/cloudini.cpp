@@ -995,6 +995,63 @@ size_t compressedChunkBound(CompressionOption opt, size_t stage1_bytes) {
   }
 }
 
+void walkCompressedChunks(ConstBufferView data, uint64_t points, std::vector<ChunkRef>& refs) {
+  refs.clear();
+  ConstBufferView rest = data;
+  uint64_t remaining = points;
+  while (!rest.empty()) {
+    if (remaining == 0) throw std::runtime_error("Encoded data contains more chunks than declared points");
+    uint32_t chunk_size = 0;
+    Cloudini::decode(rest, chunk_size);
+    if (chunk_size > rest.size()) throw std::runtime_error("Invalid chunk size found while decoding");
+    refs.push_back({rest.data(), chunk_size});
+    rest.trim_front(chunk_size);
+    remaining -= std::min<uint64_t>(remaining, kPointsPerChunk);
+  }
+  if (remaining != 0) throw std::runtime_error("Encoded data ended before all declared points were decoded");
+}
+
+uint32_t decompressChunkTo(CompressionOption opt, const uint8_t* src, size_t size, uint8_t* dst, size_t dst_cap) {
+  switch (opt) {
+    case CompressionOption::LZ4: {
+      if (size > size_t(std::numeric_limits<int>::max()) || dst_cap > size_t(std::numeric_limits<int>::max()))
+        throw std::runtime_error("Chunk size too large for LZ4");
+      const int n = LZ4_decompress_safe(reinterpret_cast<const char*>(src), reinterpret_cast<char*>(dst), static_cast<int>(size),
+                                        static_cast<int>(dst_cap));
+      if (n < 0) throw std::runtime_error("LZ4 decompression failed");
+      return static_cast<uint32_t>(n);
+    }
+    case CompressionOption::ZSTD: {
+      const size_t n = ZSTD_decompress(dst, dst_cap, src, size);
+      if (ZSTD_isError(n)) throw std::runtime_error(std::string("ZSTD decompression failed: ") + ZSTD_getErrorName(n));
+      return static_cast<uint32_t>(n);
+    }
+    default:
+      if (size > dst_cap) throw std::runtime_error("Invalid chunk size found while decoding");
+      std::memcpy(dst, src, size);
+      return static_cast<uint32_t>(size);
+  }
+}
+
+size_t stage1ChunkBound(const EncodingInfo& info) {
+  PlanHandle plan(info);
+  return static_cast<size_t>(cldn_hip_stage1_bound(plan.plan, kPointsPerChunk));
+}
+
+void decodeStage1Batch(const EncodingInfo& info, const uint8_t* streams, const uint64_t* offsets, const uint64_t* cloud_points,
+                       uint32_t n_clouds, uint8_t* out, uint64_t out_capacity) {
+  if (info.version < 3)
+    throw std::runtime_error("Cloudini (HIP): streams older than wire version 3 (unchunked) are not supported");
+  if (info.point_step == 0) throw std::runtime_error("point_step cannot be 0");
+  PlanHandle plan(info);
+  cldn_hip_codec_t* codec = pool().acquire(info, plan);
+  const int rc = cldn_hip_decode_stage1(codec, streams, CLDN_HIP_HOST, offsets, cloud_points, n_clouds, out, out_capacity,
+                                        CLDN_HIP_HOST);
+  const std::string err = rc != CLDN_HIP_OK ? cldn_hip_last_error() : "";
+  pool().release(info, codec);
+  if (rc != CLDN_HIP_OK) throw std::runtime_error(err);
+}
+
 void runOnStage2Pool(size_t n, const std::function<void(size_t)>& fn) {
   const unsigned threads = Cloudini::stage2Threads();
   if (n <= 1 || threads <= 1) {

@@ -26,6 +26,23 @@ void encodeStage1Batch(const Cloudini::EncodingInfo& info, const uint8_t* const*
 // detail::CompressChunk (src/codec_common.cpp:220-258) and its worst-case output size
 uint32_t compressChunkTo(Cloudini::CompressionOption opt, const uint8_t* src, size_t src_size, uint8_t* dst, size_t dst_cap);
 size_t compressedChunkBound(Cloudini::CompressionOption opt, size_t stage1_bytes);
+// ---- the way back (decode direction of the batch transcoder) ----
+struct ChunkRef {
+  const uint8_t* src;  // stage-2 payload of the chunk (behind its [u32 size])
+  uint32_t size;
+};
+// The chunk chain of one compressed cloud (header already removed), validated like PointcloudDecoder::decode does
+// (src/cloudini.cpp:645-664; same error strings). `points` = width * height of the header.
+void walkCompressedChunks(Cloudini::ConstBufferView data, uint64_t points, std::vector<ChunkRef>& refs);
+// detail::DecompressChunk (src/codec_common.cpp:260-300): LZ4 block / ZSTD frame / plain copy -> stage-1 bytes
+uint32_t decompressChunkTo(Cloudini::CompressionOption opt, const uint8_t* src, size_t size, uint8_t* dst, size_t dst_cap);
+// worst-case stage-1 bytes of one 32768-point chunk of this schema (without its [u32 size])
+size_t stage1ChunkBound(const Cloudini::EncodingInfo& info);
+// One batched stage-1 decode: n clouds of the same schema, framed stage-1 streams back to back in `streams` (offsets has
+// n + 1 entries), decoded points back to back in `out` (cloud k: cloud_points[k] * point_step bytes). Bytes of a point that
+// no field covers keep the content of `out`. Throws std::runtime_error.
+void decodeStage1Batch(const Cloudini::EncodingInfo& info, const uint8_t* streams, const uint64_t* offsets,
+                       const uint64_t* cloud_points, uint32_t n_clouds, uint8_t* out, uint64_t out_capacity);
 // fn(i) for i in [0, n) on the bounded stage-2 pool (the caller takes part)
 void runOnStage2Pool(size_t n, const std::function<void(size_t)>& fn);
 

@@ -90,6 +90,10 @@ struct TranscodeOptions {
   bool viz_lossy = false;                                       // applyVizLossyPreprocessing in front of the encoder
   Cloudini::CompressionOption compression = Cloudini::CompressionOption::ZSTD;  // toEncodingInfo's default
   size_t batch_messages = 32;                                   // messages per GPU batch
+  // The way back (McapConverter::decodePointClouds, tools/src/mcap_converter.cpp:240-300): the messages are
+  // CompressedPointCloud2, every output is the sensor_msgs/PointCloud2 that convertCompressedCloudToPointCloud2
+  // (src/ros_msg_utils.cpp:135-165) writes. profile / default_resolution / viz_lossy / compression are not used.
+  bool decode = false;
 };
 
 struct TranscodeStats {

@@ -69,6 +69,12 @@ int64_t cldn_amd_viz_preprocess(const cldn_amd_info_t* info, const uint8_t* data
 int64_t cldn_amd_transcode_directory(const char* in_dir, const char* out_dir, float resolution, uint8_t compression_opt,
                                      int viz_lossy, uint32_t batch_messages, double* stats_out);
 
+/* The way back (McapConverter::decodePointClouds, cloudini_lib/tools/src/mcap_converter.cpp:240-300): every file of
+ * in_dir is a CDR CompressedPointCloud2, the file of the same name in out_dir the sensor_msgs/PointCloud2 that
+ * cloudini_ros::convertCompressedCloudToPointCloud2 writes for it -- stage 2 undone on the host pool, one batched GPU
+ * decode per run of messages with the same schema. stats_out as above. Returns the message count or -1. */
+int64_t cldn_amd_decode_directory(const char* in_dir, const char* out_dir, uint32_t batch_messages, double* stats_out);
+
 /* Stage-2 (LZ4 / ZSTD) threads a single encode()/decode() call with use_threads may occupy, the caller included.
  * The reference's flag means one extra worker (cloudini_lib/src/cloudini.cpp:453-499); here the pool is bounded:
  * default min(4, hardware threads), overridden by the environment variable CLOUDINI_AMD_STAGE2_THREADS (read once)

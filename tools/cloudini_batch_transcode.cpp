@@ -3,6 +3,7 @@
 // reference's cloudini_rosbag_converter encode loop (tools/src/mcap_converter.cpp:140-222) for containers that are
 // plain directories.
 //   cloudini_batch_transcode <in_dir> <out_dir> [--resolution 0.001] [--compression none|lz4|zstd] [--viz] [--batch 64]
+//   cloudini_batch_transcode <in_dir> <out_dir> --decode [--batch 64]      (CompressedPointCloud2 -> PointCloud2)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,7 +13,7 @@
 
 int main(int argc, char** argv) {
   if (argc < 3) {
-    std::fprintf(stderr, "usage: %s <in_dir> <out_dir> [--resolution r] [--compression none|lz4|zstd] [--viz] [--batch n]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <in_dir> <out_dir> [--resolution r] [--compression none|lz4|zstd] [--viz] [--batch n] | --decode [--batch n]\n", argv[0]);
     return 2;
   }
   cloudini_amd::TranscodeOptions opt;
@@ -22,6 +23,7 @@ int main(int argc, char** argv) {
     else if (a == "--compression" && i + 1 < argc) opt.compression = Cloudini::CompressionOptionFromString(
         std::string(argv[i + 1]) == "none" ? "NONE" : (std::string(argv[i + 1]) == "lz4" ? "LZ4" : "ZSTD")), ++i;
     else if (a == "--viz") opt.viz_lossy = true;
+    else if (a == "--decode") opt.decode = true;
     else if (a == "--batch" && i + 1 < argc) opt.batch_messages = (size_t)std::strtoul(argv[++i], nullptr, 10);
     else {
       std::fprintf(stderr, "unknown argument %s\n", a.c_str());

@@ -31,6 +31,31 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
         st["process_wall_s"] = round(wall, 3)
         st["stage2_threads"] = threads or "default (4)"
         print(json.dumps(st))
+    # the way back: the compressed files through the decode direction
+    back = os.path.join(tmp, "back")
+    for rep in range(2):
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, dst, back, "--decode", "--batch", "32"], capture_output=True, text=True, env=env)
+        wall = time.perf_counter() - t0
+        assert r.returncode == 0, r.stderr
+        st = json.loads(r.stdout.strip().splitlines()[-1])
+        st["process_wall_s"] = round(wall, 3)
+        st["direction"] = "decode"
+        print(json.dumps(st))
+    try:
+        from oracle.binding import RefLib
+        ref = RefLib()
+        t0 = time.perf_counter()
+        for k in range(4):
+            packed = np.fromfile(os.path.join(dst, f"msg_{k:05d}.bin"), dtype=np.uint8)
+            want = ref.ros_decompress(packed, msgs[k].size + 4096)
+            got = np.fromfile(os.path.join(back, f"msg_{k:05d}.bin"), dtype=np.uint8)
+            assert np.array_equal(got, want), k
+        per = (time.perf_counter() - t0) / 4
+        print(json.dumps({"reference_decode_per_message_ms": round(per * 1e3, 2),
+                          "reference_decode_Mpoints_per_s_1_thread": round(130048 / per / 1e6, 1)}))
+    except (OSError, FileNotFoundError):
+        pass
     try:
         from oracle.binding import RefLib
         ref = RefLib()
