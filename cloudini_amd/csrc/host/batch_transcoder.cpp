@@ -325,16 +325,22 @@ void decodeGpuPhase(Batch& b, TranscodeStats* stats) {
       ++r0;
       continue;
     }
-    size_t r1 = r0 + 1;
-    while (r1 < n && b.parsed[r1].key == b.parsed[r0].key) ++r1;
+    const Cloudini::EncodingInfo& info0 = b.parsed[r0].info;
+    // stage 2 is undone chunk by chunk into worst-case slots, then packed into the framed stage-1 streams of the run; a run
+    // ends where its slots would pass kDecodeScratchBytes (wide points: one chunk can be tens of megabytes)
+    const size_t slot = 4u + Cloudini::amd_detail::stage1ChunkBound(info0) + 64u;
+    constexpr size_t kDecodeScratchBytes = size_t(256) << 20;
+    auto chunks_of = [&](size_t i) { return size_t((b.parsed[i].points + 32767) / 32768); };
+    size_t r1 = r0 + 1, run_chunks = chunks_of(r0);
+    while (r1 < n && b.parsed[r1].key == b.parsed[r0].key && (run_chunks + chunks_of(r1)) * slot <= kDecodeScratchBytes) {
+      run_chunks += chunks_of(r1);
+      ++r1;
+    }
     if (b.runs.size() <= n_runs) b.runs.emplace_back();
     Run& run = b.runs[n_runs++];
     run.first = r0;
     run.count = static_cast<uint32_t>(r1 - r0);
-    const Cloudini::EncodingInfo& info0 = b.parsed[r0].info;
     const auto t_gpu = Clock::now();
-    // stage 2 undone chunk by chunk into worst-case slots, then packed into the framed stage-1 streams of the run
-    const size_t slot = 4u + Cloudini::amd_detail::stage1ChunkBound(info0) + 64u;
     all_refs.clear();
     std::vector<size_t> first_ref(run.count + 1, 0);
     for (uint32_t k = 0; k < run.count; ++k) {
