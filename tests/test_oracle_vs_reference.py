@@ -169,3 +169,23 @@ def test_full_size_baseline_configs_match_reference(oracle, reflib, name):
     assert len(got) == len(want) and np.array_equal(got, want)
     ref_dec, _yaml = reflib.decode(reflib.encode(info, data), len(data), fill=0x5A)
     assert np.array_equal(oracle.decode_stage1(info, want, n, fill=0x5A), ref_dec)
+
+
+def _tail_kinds():
+    import test_gpu_fused
+    return test_gpu_fused.TAIL_KINDS
+
+
+@pytest.mark.parametrize("kind", _tail_kinds())
+def test_tail_layouts_match_reference(oracle, reflib, kind):
+    """The layouts the TAIL instantiations of the piece kernel take (FloatN lanes + one more per-point encoder: raw copy,
+    Float_Lossy<float/double>, Gorilla) are checked on the GPU against the oracle only: here the oracle itself is pinned
+    to the reference on exactly those inputs, encode and decode."""
+    import test_gpu_fused
+    info, data = test_gpu_fused._tail_layout(kind, 32768 * 2 + 777)
+    n = len(data) // info.point_step
+    want = reflib.encode_stage1(info, data)
+    assert np.array_equal(oracle.encode_stage1(info, data), want)
+    full = reflib.encode(info, data)
+    ref_dec, _yaml = reflib.decode(full, len(data), fill=0x5A)
+    assert np.array_equal(oracle.decode_stage1(info, want, n, fill=0x5A), ref_dec)
