@@ -250,8 +250,16 @@ def test_tail_op_behind_the_floatn_lanes(oracle, kind):
     codec = native.Codec(native.Plan(info))
     assert codec.pipeline(2) == 2, "the piece kernel must take this layout"
     codec.close()
-    check_encode(oracle, info, [data])
+    streams = check_encode(oracle, info, [data])
     # ragged batch: chunk starts inside the batch, a cloud shorter than a piece, an empty one
     step = info.point_step
     parts = [data[: 40000 * step], data[40000 * step: 40100 * step], data[:0], data[40100 * step:]]
     check_encode(oracle, info, parts)
+    # and the way back (these layouts decode through k_decode_varint<8> or, with raw / Gorilla bytes in the point stream,
+    # through the serial decoder): bit for bit the oracle's decode, untouched bytes included
+    n = data.size // step
+    codec = native.Codec(native.Plan(info))
+    out = np.full(data.size, 0x5D, dtype=np.uint8)
+    got = codec.decode_host([streams[0]], [n], out=out)[0]
+    assert np.array_equal(got, oracle.decode_stage1(info, streams[0], n, fill=0x5D))
+    codec.close()
