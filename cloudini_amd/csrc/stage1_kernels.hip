@@ -1985,8 +1985,9 @@ int stage1_configure_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_section_delta32<uint32_t>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD32Lds);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_delta32<u32>)");
-  const void* pk32[] = {reinterpret_cast<const void*>(&k_section_palette32<uint16_t>),
-                        reinterpret_cast<const void*>(&k_section_palette32<uint32_t>)};
+  const void* pk32[] = {reinterpret_cast<const void*>(&k_section_palette32<uint16_t, kS2Threads>),
+                        reinterpret_cast<const void*>(&k_section_palette32<uint16_t, 512>),
+                        reinterpret_cast<const void*>(&k_section_palette32<uint32_t, 512>)};
   for (const void* f : pk32) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Pal32<uint32_t>::kLds);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_palette32)");
@@ -2186,9 +2187,17 @@ static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c
   }
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_delta32/runs");
   if (pal16.n)
-    hipLaunchKernelGGL(k_section_palette32<uint16_t>, dim3(nch, pal16.n), dim3(kS2Threads), Pal32<uint16_t>::kLds, stream, SEC_ARGS(pal16));
+  {
+    // 512-thread workgroups (two bitmap words and two groups of 32 values per thread): four of them fit a CU, so a batch
+    // of up to 1024 chunks is one generation (C2: sections 0.066 -> 0.062 ms); CLDN_HIP_PAL32_THREADS=1024 is the A/B switch
+    static const bool pal1024 = getenv("CLDN_HIP_PAL32_THREADS") && atoi(getenv("CLDN_HIP_PAL32_THREADS")) == 1024;
+    if (pal1024)
+      hipLaunchKernelGGL((k_section_palette32<uint16_t, kS2Threads>), dim3(nch, pal16.n), dim3(kS2Threads), Pal32<uint16_t>::kLds, stream, SEC_ARGS(pal16));
+    else
+      hipLaunchKernelGGL((k_section_palette32<uint16_t, 512>), dim3(nch, pal16.n), dim3(512), Pal32<uint16_t>::kLds, stream, SEC_ARGS(pal16));
+  }
   if (pal32.n)
-    hipLaunchKernelGGL(k_section_palette32<uint32_t>, dim3(nch, pal32.n), dim3(kS2Threads), Pal32<uint32_t>::kLds, stream, SEC_ARGS(pal32));
+    hipLaunchKernelGGL((k_section_palette32<uint32_t, 512>), dim3(nch, pal32.n), dim3(512), Pal32<uint32_t>::kLds, stream, SEC_ARGS(pal32));
   if (pal64.n)
     hipLaunchKernelGGL(k_section_palette<uint64_t>, dim3(nch, pal64.n), dim3(kS2Threads), kS2PalLds, stream, SEC_ARGS(pal64));
 #undef SEC_ARGS

@@ -539,16 +539,18 @@ __device__ __forceinline__ void pal32_pack(const Pal32<RawT>& p, const RawT* col
   }
 }
 
-template <typename RawT>
-__global__ __launch_bounds__(kS2Threads) void k_section_palette32(
+// T threads: 1024 (one bitmap word and 32 values per thread) or 512 (two of each: four workgroups fit a CU, so that
+// up to 1024 chunks are in flight at once instead of 512)
+template <typename RawT, int T = kS2Threads>
+__global__ __launch_bounds__(T) void k_section_palette32(
     const DevPlan plan, const SectionFields fl, const ChunkDesc* __restrict__ chunks, const ColumnPtrs cols,
     const uint8_t* __restrict__ modes, uint8_t* __restrict__ slots, uint64_t slot_stride, uint64_t reg_stride,
     Seg* __restrict__ segs, uint32_t segs_per_chunk, uint32_t subs, uint8_t* __restrict__ handled_flags) {
   static_assert(sizeof(RawT) == 2 || sizeof(RawT) == 4, "16- or 32-bit keys");
-  static_assert(kS2Threads * 32u == 32768u, "one bitmap word per thread covers a chunk");
+  static_assert(kS2Threads * 32u == 32768u && (T == kS2Threads || 2 * T == kS2Threads), "bitmap words per thread: 1 or 2");
+  constexpr uint32_t WPT = kS2Threads / T;  // bitmap words (and groups of 32 values) per thread
   using P = Pal32<RawT>;
   using Word = typename P::Word;
-  constexpr int T = kS2Threads;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t c = blockIdx.x;
   const uint32_t a = fl.a[blockIdx.y];  // one launch covers every field of this kernel's type (grid.y)
@@ -562,13 +564,14 @@ __global__ __launch_bounds__(kS2Threads) void k_section_palette32(
   const uint32_t tid = threadIdx.x;
 
   for (uint32_t s = tid; s < kS2PalSlots; s += T) p.tab[s] = P::kFree;
-  p.bitmap[tid] = 0u;
+#pragma unroll
+  for (uint32_t w = 0; w < WPT; ++w) p.bitmap[w * T + tid] = 0u;
   if (tid < 4u) p.misc[tid] = 0u;
   __syncthreads();
 
   // seed
 #pragma unroll
-  for (uint32_t r = 0; r < 4u; ++r) {
+  for (uint32_t r = 0; r < 4096u / T; ++r) {
     const uint32_t i = r * T + tid;
     if (i < n) {
       const uint32_t v = (uint32_t)col[i];
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(kS2Threads) void k_section_palette32(
   __syncthreads();
 
   // pass 1
-  for (uint32_t s = 0; s < 4u; ++s) {
+  for (uint32_t s = 0; s < 4096u / T; ++s) {
     const uint32_t i0 = (s * T + tid) * 8u;
     if (i0 >= n) break;
     RawT v[8];
@@ -604,7 +607,21 @@ __global__ __launch_bounds__(kS2Threads) void k_section_palette32(
   }
   __syncthreads();
   uint32_t U;
-  p.prefix[tid] = block_exclusive_scan<T>((uint32_t)__builtin_popcount(p.bitmap[tid]), p.wtot, &U);
+  {
+    // thread t owns bitmap words WPT * t ... (consecutive, so that the scan order is the index order)
+    uint32_t pc[WPT], mine = 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < WPT; ++w) {
+      pc[w] = (uint32_t)__builtin_popcount(p.bitmap[WPT * tid + w]);
+      mine += pc[w];
+    }
+    uint32_t run = block_exclusive_scan<T>(mine, p.wtot, &U);
+#pragma unroll
+    for (uint32_t w = 0; w < WPT; ++w) {
+      p.prefix[WPT * tid + w] = run;
+      run += pc[w];
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (uint32_t q = 0; q < kS2PalSlots / T; ++q) {
@@ -628,23 +645,27 @@ __global__ __launch_bounds__(kS2Threads) void k_section_palette32(
 
   // pass 3
   const uint32_t bits = palette_bits(U);
-  const uint32_t i0 = tid * 32u;
-  const uint32_t cnt = i0 < n ? min(32u, n - i0) : 0u;
-  if (bits != 0u && cnt != 0u) {
-    uint32_t* idx_out = reinterpret_cast<uint32_t*>(dst + kPaletteIndexOffset) + (size_t)tid * bits;
-    switch (bits) {  // block-uniform
-      case 1: pal32_pack<RawT, 1>(p, col, i0, n, cnt, idx_out); break;
-      case 2: pal32_pack<RawT, 2>(p, col, i0, n, cnt, idx_out); break;
-      case 3: pal32_pack<RawT, 3>(p, col, i0, n, cnt, idx_out); break;
-      case 4: pal32_pack<RawT, 4>(p, col, i0, n, cnt, idx_out); break;
-      case 5: pal32_pack<RawT, 5>(p, col, i0, n, cnt, idx_out); break;
-      case 6: pal32_pack<RawT, 6>(p, col, i0, n, cnt, idx_out); break;
-      case 7: pal32_pack<RawT, 7>(p, col, i0, n, cnt, idx_out); break;
-      case 8: pal32_pack<RawT, 8>(p, col, i0, n, cnt, idx_out); break;
-      case 9: pal32_pack<RawT, 9>(p, col, i0, n, cnt, idx_out); break;
-      case 10: pal32_pack<RawT, 10>(p, col, i0, n, cnt, idx_out); break;
-      case 11: pal32_pack<RawT, 11>(p, col, i0, n, cnt, idx_out); break;
-      default: pal32_pack<RawT, 12>(p, col, i0, n, cnt, idx_out); break;  // U <= kS2PalCapacity = 3072: <= 12 bits
+#pragma unroll
+  for (uint32_t g = 0; g < WPT; ++g) {
+    const uint32_t grp = g * T + tid;  // group of 32 values
+    const uint32_t i0 = grp * 32u;
+    const uint32_t cnt = i0 < n ? min(32u, n - i0) : 0u;
+    if (bits != 0u && cnt != 0u) {
+      uint32_t* idx_out = reinterpret_cast<uint32_t*>(dst + kPaletteIndexOffset) + (size_t)grp * bits;
+      switch (bits) {  // block-uniform
+        case 1: pal32_pack<RawT, 1>(p, col, i0, n, cnt, idx_out); break;
+        case 2: pal32_pack<RawT, 2>(p, col, i0, n, cnt, idx_out); break;
+        case 3: pal32_pack<RawT, 3>(p, col, i0, n, cnt, idx_out); break;
+        case 4: pal32_pack<RawT, 4>(p, col, i0, n, cnt, idx_out); break;
+        case 5: pal32_pack<RawT, 5>(p, col, i0, n, cnt, idx_out); break;
+        case 6: pal32_pack<RawT, 6>(p, col, i0, n, cnt, idx_out); break;
+        case 7: pal32_pack<RawT, 7>(p, col, i0, n, cnt, idx_out); break;
+        case 8: pal32_pack<RawT, 8>(p, col, i0, n, cnt, idx_out); break;
+        case 9: pal32_pack<RawT, 9>(p, col, i0, n, cnt, idx_out); break;
+        case 10: pal32_pack<RawT, 10>(p, col, i0, n, cnt, idx_out); break;
+        case 11: pal32_pack<RawT, 11>(p, col, i0, n, cnt, idx_out); break;
+        default: pal32_pack<RawT, 12>(p, col, i0, n, cnt, idx_out); break;  // U <= kS2PalCapacity = 3072: <= 12 bits
+      }
     }
   }
   if (tid == 0) {
