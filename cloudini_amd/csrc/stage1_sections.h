@@ -645,7 +645,6 @@ __global__ __launch_bounds__(T) void k_section_palette32(
 
   // pass 3
   const uint32_t bits = palette_bits(U);
-#pragma unroll
   for (uint32_t g = 0; g < WPT; ++g) {
     const uint32_t grp = g * T + tid;  // group of 32 values
     const uint32_t i0 = grp * 32u;
