@@ -158,20 +158,11 @@ struct cldn_hip_codec {
   DevBuf d_cols[kMaxAdaptive];
   DevBuf d_ranks[kMaxAdaptive];
   DevBuf d_dec_meta, d_fbflags, d_pre_ptrs;
-  DevBuf d_pieces, d_fzero, d_prec, d_bitmaps, d_secplace;  // single-pass encoder (stage1_fused.h)
+  DevBuf d_pieces;  // piece table of the piece kernel (stage1_fused.h)
   uint32_t n_pieces = 0;
   uint32_t last_piece_pts = 0;
-  // chunk-group pipeline (stage1_launch.h): side stream, events, host copies of the group boundaries
-  hipStream_t side_stream = nullptr;
-  std::vector<hipEvent_t> gev;
-  std::vector<uint32_t> chunk_piece0;   // first piece of every chunk (+ total), host copy of the piece table's layout
-  std::vector<uint32_t> grp_chunk0, grp_piece0;
-  std::vector<hipEvent_t> gtime;        // timing: 16 per slot
-  std::vector<uint32_t> slot_groups;    // groups of the call timed in the slot (0 / 1 = not pipelined)
-  int groups_override = -1;             // CLDN_HIP_GROUPS
   uint64_t pending_total = 0;  // bytes of a deferred host output waiting in d_out (cldn_hip_codec_fetch_output)
-  int pipeline = 0;           // cldn_hip_codec_pipeline: 0 auto, 1 tile kernel + slots, 2 pieces + slots, 3 single pass
-  bool bitmaps_dirty = true;  // set after an aborted call: the kernel only clears the bitmaps of calls that finish
+  int pipeline = 0;           // cldn_hip_codec_pipeline: 0 auto, 1 tile kernel + slots, 2 piece kernel + slots
   DevBuf d_viz_keys, d_viz_first, d_viz_slot, d_viz_blocks, d_viz_total;  // applyVizLossyPreprocessing workspace
   DevBuf d_pre[kMaxGorilla];
   PinnedBuf h_stage;   // chunk table upload
@@ -480,8 +471,7 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_segs,
                     &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_fbflags, &c->d_pre_ptrs,
                     &c->d_pre[0], &c->d_pre[1], &c->d_pre[2], &c->d_pre[3], &c->d_viz_keys, &c->d_viz_first,
-                    &c->d_viz_slot, &c->d_viz_blocks, &c->d_viz_total, &c->d_pieces, &c->d_fzero, &c->d_prec,
-                    &c->d_bitmaps, &c->d_secplace};
+                    &c->d_viz_slot, &c->d_viz_blocks, &c->d_viz_total, &c->d_pieces};
   for (DevBuf* b : bufs) b->release();
   for (int a = 0; a < kMaxAdaptive; ++a) {
     c->d_cols[a].release();
@@ -496,14 +486,6 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   c->h_modes.release();
   c->h_last_modes.release();
   if (c->ev_last_modes) (void)hipEventDestroy(c->ev_last_modes);
-  for (hipEvent_t& ev : c->gev)
-    if (ev) (void)hipEventDestroy(ev);
-  for (hipEvent_t& ev : c->gtime)
-    if (ev) (void)hipEventDestroy(ev);
-  if (c->side_stream) {
-    (void)hipStreamSynchronize(c->side_stream);
-    (void)hipStreamDestroy(c->side_stream);
-  }
   for (hipEvent_t& ev : c->events)
     if (ev) (void)hipEventDestroy(ev);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -528,11 +510,6 @@ int cldn_hip_codec_enable_timing(cldn_hip_codec_t* c, uint32_t n_slots) {
   c->events.assign((size_t)n_slots * 5, nullptr);
   c->slot_valid.assign(n_slots, 0);
   for (hipEvent_t& ev : c->events) HIP_TRY(hipEventCreate(&ev));
-  for (hipEvent_t& ev : c->gtime)
-    if (ev) (void)hipEventDestroy(ev);
-  c->gtime.assign((size_t)n_slots * 16, nullptr);
-  for (hipEvent_t& ev : c->gtime) HIP_TRY(hipEventCreate(&ev));
-  c->slot_groups.assign(n_slots, 0u);
   c->call_index = 0;
   return CLDN_HIP_OK;
 }
@@ -543,18 +520,6 @@ int cldn_hip_codec_kernel_ms(cldn_hip_codec_t* c, uint32_t slot, float ms[4]) {
   hipEvent_t* ev = &c->events[(size_t)slot * 5];
   HIP_TRY(hipEventSynchronize(ev[4]));
   HIP_TRY(hipEventElapsedTime(&ms[3], ev[0], ev[4]));
-  const uint32_t groups = c->slot_groups[slot];
-  if (groups > 1u) {
-    // pipelined call: the regular kernels of the groups ran next to other kernels; ms[0] = sum of their own durations,
-    // sections and compaction have no separate interval
-    ms[0] = ms[1] = ms[2] = 0.0f;
-    hipEvent_t* gt = &c->gtime[(size_t)slot * 16];
-    for (uint32_t i = 0; i < groups && i < 8u; ++i) {
-      float d = 0.0f;
-      if (hipEventElapsedTime(&d, gt[2u * i], gt[2u * i + 1u]) == hipSuccess) ms[0] += d;
-    }
-    return CLDN_HIP_OK;
-  }
   HIP_TRY(hipEventElapsedTime(&ms[0], ev[1], ev[2]));
   HIP_TRY(hipEventElapsedTime(&ms[1], ev[2], ev[3]));
   HIP_TRY(hipEventElapsedTime(&ms[2], ev[3], ev[4]));
@@ -568,11 +533,7 @@ int cldn_hip_codec_status(cldn_hip_codec_t* c) {
   uint32_t st = 0;
   HIP_TRY(hipMemcpyAsync(&st, c->d_status.p, sizeof(st), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (st & (ST_FUSED_TIMEOUT | ST_FUSED_MISMATCH)) {
-    c->bitmaps_dirty = true;
-    return fail(CLDN_HIP_ERR_DEVICE, "single-pass encoder failed (status 0x%x: %s)", st,
-                (st & ST_FUSED_TIMEOUT) ? "a wave waited too long for its predecessors" : "a section is not the size its statistics promised");
-  }
+  if (st & ST_FINISH_TIMEOUT) return fail(CLDN_HIP_ERR_DEVICE, "k_finish: a workgroup waited too long for the sizes of the chunks before it (status 0x%x)", st);
   if (st & ST_OUT_OVERFLOW) return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for the encoded stream");
   if (st & ST_CORRUPT) return fail(CLDN_HIP_ERR_CORRUPT, "malformed stage-1 stream");
   return CLDN_HIP_OK;
@@ -640,9 +601,7 @@ static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, u
   if (piece_pts && n_pieces64) {
     PieceDesc* hp = (PieceDesc*)((uint8_t*)c->h_stage.p + head_bytes);
     size_t g = 0;
-    c->chunk_piece0.assign((size_t)n_chunks + 1, 0u);
     for (uint32_t k = 0; k < n_chunks; ++k) {
-      c->chunk_piece0[k] = (uint32_t)g;
       const uint32_t P = (((hc[k].n_points + piece_pts - 1) / piece_pts) + 3u) & ~3u;
       for (uint32_t q = 0; q < P; ++q) {
         hp[g].chunk_first_point = hc[k].first_point;
@@ -655,7 +614,6 @@ static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, u
         ++g;
       }
     }
-    c->chunk_piece0[n_chunks] = (uint32_t)g;
     HIP_TRY(hipMemcpyAsync(c->d_pieces.p, hp, g * sizeof(PieceDesc), hipMemcpyHostToDevice, c->stream));
   }
   c->last_piece_pts = piece_pts;
@@ -688,7 +646,6 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   // device-resident inputs decide the kernel variant by their address; host inputs are staged into an aligned buffer
   const uint8_t* variant_ptr = points_loc == CLDN_HIP_DEVICE ? (const uint8_t*)points : nullptr;
   const uint32_t piece_pts = c->pipeline == 1 ? 0u : stage1_piece_points(plan, variant_ptr);
-  const bool want_single_pass = c->pipeline == 3 && piece_pts != 0u && stage1_single_pass_ok(plan, variant_ptr);
   int rc = upload_batch_shape(c, cloud_points, n_clouds, piece_pts, &n_chunks, &n_points);
   if (rc != CLDN_HIP_OK) return rc;
   if (n_points && !points && !cloud_ptrs) return fail(CLDN_HIP_ERR_ARG, "points is NULL");
@@ -718,14 +675,11 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
     while (subs < 32u && (uint64_t)n_chunks * subs < 6000u) subs *= 2u;
   }
   if (subs < 1u || subs > 32u || (subs & (subs - 1u))) subs = 1u;
-  // single-pass encoder: regular bytes go straight to their final place, the slots only hold the sections
   const bool pieces = piece_pts != 0u && n_chunks != 0u;   // regular stream by the piece kernel
-  const bool fused = pieces && want_single_pass;            // ... placed by the in-kernel protocol
-  if (fused) subs = 0u;
-  else if (pieces) subs = ((((kPointsPerChunk + piece_pts - 1u) / piece_pts) + 3u) & ~3u) / 4u;  // one segment per workgroup (4 pieces)
-  const uint32_t sub_points = fused ? 0u : (pieces ? piece_pts : kPointsPerChunk / subs);
-  const uint32_t sub_stride = fused ? 0u : (pieces ? 4u * stage1_piece_slot_stride(plan, variant_ptr)
-                                                   : (uint32_t)((((uint64_t)sub_points * plan.max_regular_bytes + 64u) + 255u) & ~uint64_t(255)));
+  if (pieces) subs = ((((kPointsPerChunk + piece_pts - 1u) / piece_pts) + 3u) & ~3u) / 4u;  // one segment per workgroup (4 pieces)
+  const uint32_t sub_points = pieces ? piece_pts : kPointsPerChunk / subs;
+  const uint32_t sub_stride = pieces ? 4u * stage1_piece_slot_stride(plan, variant_ptr)
+                                     : (uint32_t)((((uint64_t)sub_points * plan.max_regular_bytes + 64u) + 255u) & ~uint64_t(255));
   const uint32_t segs_per_chunk = subs + 2u * n_adaptive;
   const uint64_t reg_stride = (uint64_t)subs * sub_stride;
   const uint64_t slot_stride = reg_stride + (uint64_t)n_adaptive * kSectionStride;
@@ -783,31 +737,6 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
     }
     if (segs_per_chunk) HIP_TRY(hipMemsetAsync(c->d_segs.p, 0, (size_t)n_chunks * segs_per_chunk * sizeof(Seg), c->stream));
   }
-  // workspace of the single-pass encoder: one zero-filled block (control word, per-chunk arrival counters, look-back
-  // records), piece records, per-chunk presence bitmaps (zero between calls: the kernel clears what it sets)
-  const uint32_t n_bm = fused ? stage1_fused_bitmap_fields(plan) : 0u;
-  const size_t fz_arrivals = sizeof(FusedCtrl);
-  const size_t fz_lb = (fz_arrivals + (size_t)n_chunks * 4u + 15u) & ~size_t(15);
-  const size_t fz_lbc = fz_lb + (size_t)c->n_pieces * 8u;
-  const size_t fz_start1 = fz_lbc + (size_t)n_chunks * 8u;
-  const size_t fz_bytes = fz_start1 + (size_t)n_chunks * 8u;
-  const uint32_t prec_stride = 2u + 8u * n_adaptive;
-  if (fused) {
-    if ((rc = c->d_fzero.ensure(fz_bytes)) != CLDN_HIP_OK) return rc;
-    if ((rc = c->d_prec.ensure((size_t)c->n_pieces * prec_stride * 4u)) != CLDN_HIP_OK) return rc;
-    if ((rc = c->d_secplace.ensure(std::max<size_t>(16, (size_t)n_chunks * n_adaptive * 16u))) != CLDN_HIP_OK) return rc;
-    const size_t bm_bytes = (size_t)n_chunks * n_bm * 8192u;
-    if (bm_bytes) {
-      const void* before = c->d_bitmaps.p;
-      if ((rc = c->d_bitmaps.ensure(bm_bytes)) != CLDN_HIP_OK) return rc;
-      if (c->d_bitmaps.p != before || c->bitmaps_dirty) {
-        HIP_TRY(hipMemsetAsync(c->d_bitmaps.p, 0, c->d_bitmaps.cap, c->stream));
-        c->bitmaps_dirty = false;
-      }
-    }
-    HIP_TRY(hipMemsetAsync(c->d_fzero.p, 0, fz_bytes, c->stream));
-  }
-
   EncodeLaunch L;
   memset(&L, 0, sizeof(L));
   L.plan = &plan;
@@ -861,55 +790,9 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
     L.modes_forced = true;
   }
   L.fallback_flags = (uint8_t*)c->d_fbflags.p;
-  // chunk groups: compaction and sections of one group next to the regular kernel of the following one
-  uint32_t n_groups = 1;
-  if (pieces && !fused) {
-    if (c->groups_override < 0) {
-      const char* e = getenv("CLDN_HIP_GROUPS");
-      c->groups_override = e ? std::max(0, atoi(e)) : 0;
-    }
-    // Off unless asked for (CLDN_HIP_GROUPS=n): measured on MI355X the two queues do not overlap these kernels -- every
-    // kernel fills the chip on its own -- and the extra launches and event waits cost 18 % (2 groups) to 50 % (8 groups)
-    // of a C2 step (tools/groupbench.sh)
-    n_groups = c->groups_override ? (uint32_t)c->groups_override : 1u;
-    n_groups = std::min<uint32_t>(std::min<uint32_t>(n_groups, 8u), std::max(1u, n_chunks / 16u));
-  }
-  if (n_groups > 1u) {
-    if (!c->side_stream) HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-    while (c->gev.size() < 4u + n_groups) {
-      hipEvent_t ev = nullptr;
-      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      c->gev.push_back(ev);
-    }
-    c->grp_chunk0.resize(n_groups + 1u);
-    c->grp_piece0.resize(n_groups + 1u);
-    for (uint32_t i = 0; i <= n_groups; ++i) {
-      c->grp_chunk0[i] = (uint32_t)((uint64_t)n_chunks * i / n_groups);
-      c->grp_piece0[i] = c->chunk_piece0[c->grp_chunk0[i]];
-    }
-    L.n_groups = n_groups;
-    L.group_chunk0 = c->grp_chunk0.data();
-    L.group_piece0 = c->grp_piece0.data();
-    L.side_stream = c->side_stream;
-    L.gev = c->gev.data();
-    L.running = (unsigned long long*)((uint8_t*)c->d_status.p + 64);  // zeroed with the status block
-  }
-  L.fused = fused;
   if (pieces) {
     L.pieces = (const PieceDesc*)c->d_pieces.p;
     L.n_pieces = c->n_pieces;
-  }
-  if (fused) {
-    L.fctrl = (FusedCtrl*)c->d_fzero.p;
-    L.arrivals = (uint32_t*)((uint8_t*)c->d_fzero.p + fz_arrivals);
-    L.lb = (unsigned long long*)((uint8_t*)c->d_fzero.p + fz_lb);
-    L.lbc = (unsigned long long*)((uint8_t*)c->d_fzero.p + fz_lbc);
-    L.start1 = (unsigned long long*)((uint8_t*)c->d_fzero.p + fz_start1);
-    L.prec = (uint32_t*)c->d_prec.p;
-    L.prec_stride = prec_stride;
-    L.bitmaps = (uint32_t*)c->d_bitmaps.p;
-    L.n_bm_fields = n_bm;
-    L.secplace = c->d_secplace.p;
   }
   L.out = d_outp;
   L.out_capacity = out_capacity;
@@ -917,8 +800,6 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   const size_t n_slots = c->slot_valid.size();
   const size_t slot = n_slots ? (size_t)(c->call_index % n_slots) : 0;
   L.events = n_slots ? &c->events[slot * 5] : nullptr;
-  L.gtime = (n_slots && n_groups > 1u) ? &c->gtime[slot * 16] : nullptr;
-  if (n_slots) c->slot_groups[slot] = n_groups;
   rc = stage1_launch_encode(L);
   if (rc != CLDN_HIP_OK) return rc;
   // remember this call's modes for the next call's launch hint (no synchronisation: the copy is only looked at
@@ -979,10 +860,7 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
                          c->stream));
   HIP_TRY(hipMemcpyAsync(h_status, c->d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (*h_status & (ST_FUSED_TIMEOUT | ST_FUSED_MISMATCH)) {
-    c->bitmaps_dirty = true;
-    return fail(CLDN_HIP_ERR_DEVICE, "single-pass encoder failed (status 0x%x)", *h_status);
-  }
+  if (*h_status & ST_FINISH_TIMEOUT) return fail(CLDN_HIP_ERR_DEVICE, "k_finish: a workgroup waited too long for the sizes of the chunks before it (status 0x%x)", *h_status);
   if (*h_status & ST_OUT_OVERFLOW)
     return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for uncompressed chunk");  // chunk_writer.cpp:34-36
   const uint64_t total = h_off[n_clouds];
@@ -1103,11 +981,10 @@ int cldn_hip_codec_fetch_output(cldn_hip_codec_t* c, void* out, uint64_t out_cap
 
 int cldn_hip_codec_pipeline(cldn_hip_codec_t* c, int mode, const void* points) {
   if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
-  if (mode < 0 || mode > 3) return fail(CLDN_HIP_ERR_ARG, "pipeline mode %d out of range", mode);
+  if (mode < 0 || mode > 2) return fail(CLDN_HIP_ERR_ARG, "pipeline mode %d out of range", mode);
   c->pipeline = mode;
   const uint8_t* p = (const uint8_t*)points;
   if (mode == 1 || stage1_piece_points(c->plan.dev, p) == 0u) return 1;
-  if (mode == 3 && stage1_single_pass_ok(c->plan.dev, p)) return 3;
   return 2;
 }
 

@@ -99,11 +99,10 @@ enum : uint32_t {
   ST_OUT_OVERFLOW = 1u,    // compacted stream did not fit the output capacity
   ST_CORRUPT = 2u,         // decode: malformed input
   ST_PALETTE_FULL = 4u,    // internal: LDS palette table overflowed (handled by the global-table path)
-  ST_FUSED_TIMEOUT = 8u,   // internal: a wave of the single-pass encoder waited too long for a predecessor
-  ST_FUSED_MISMATCH = 16u  // internal: a section is not the size its statistics promised
+  ST_FINISH_TIMEOUT = 8u   // internal: a workgroup of k_finish waited too long for a predecessor's chunk size
 };
 
-// ---- single-pass encoder (stage1_fused.h) ----
+// ---- piece kernel (stage1_fused.h) ----
 // One piece = the points one wave encodes: kPieceRows rows of 63 points of ONE chunk. Piece counts per chunk are
 // padded to a multiple of 4 (one workgroup = 4 pieces of the same chunk); padding pieces have no points.
 struct PieceDesc {
@@ -116,12 +115,5 @@ struct PieceDesc {
   uint32_t pad[2];
 };
 static_assert(sizeof(PieceDesc) == 32, "one aligned 32-byte load per piece");
-
-struct FusedCtrl {
-  uint32_t ticket;         // next workgroup ticket (pieces are handed out in ticket order)
-  uint32_t need_fallback;  // a committed mode has no statistics in the single-pass kernel: the slot pipeline encodes
-  uint32_t timeout;        // a bounded spin ran out
-  uint32_t pad[13];
-};
 
 }  // namespace cldn

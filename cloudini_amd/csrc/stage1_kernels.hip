@@ -1201,44 +1201,6 @@ __global__ __launch_bounds__(T) void k_chunk_offsets(const Seg* __restrict__ seg
   }
 }
 
-// k_chunk_offsets_range: the same scan for one chunk group of the pipelined encode; the position where the group
-// starts is the running total the previous group's launch left (launches are ordered by events), chunk tables are
-// passed shifted to the group's first chunk. k_stream_offsets derives the per-cloud offsets once all groups are done.
-template <int T>
-__global__ __launch_bounds__(T) void k_chunk_offsets_range(const Seg* __restrict__ segs, uint32_t segs_per_chunk,
-                                                           uint32_t n_chunks, uint32_t* __restrict__ chunk_payload,
-                                                           uint64_t* __restrict__ chunk_dst, uint64_t* __restrict__ running_total) {
-  __shared__ uint32_t wtot[32];
-  uint64_t running = *running_total;
-  for (uint32_t base = 0; base < n_chunks; base += T) {
-    const uint32_t c = base + threadIdx.x;
-    uint32_t framed = 0u;
-    if (c < n_chunks) {
-      uint32_t payload = 0u;
-      for (uint32_t s = 0; s < segs_per_chunk; ++s) payload += segs[(size_t)c * segs_per_chunk + s].size;
-      chunk_payload[c] = payload;
-      framed = payload + 4u;
-    }
-    uint32_t total;
-    const uint32_t excl = block_exclusive_scan<T>(framed, wtot, &total);
-    if (c < n_chunks) chunk_dst[c] = running + excl;
-    running += total;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *running_total = running;
-}
-
-__global__ __launch_bounds__(256) void k_stream_offsets(const uint32_t* __restrict__ chunk_payload,
-                                                        const uint64_t* __restrict__ chunk_dst, uint32_t n_chunks,
-                                                        const uint32_t* __restrict__ cloud_first_chunk, uint32_t n_clouds,
-                                                        uint64_t* __restrict__ stream_offsets) {
-  const uint64_t total = n_chunks ? chunk_dst[n_chunks - 1u] + 4ull + chunk_payload[n_chunks - 1u] : 0ull;
-  for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k <= n_clouds; k += gridDim.x * 256u) {
-    const uint32_t fc = (k < n_clouds) ? cloud_first_chunk[k] : n_chunks;
-    stream_offsets[k] = (fc < n_chunks) ? chunk_dst[fc] : total;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // k_compact: final framed stream. grid = (n_chunks, splits). The chunk's segment table is read once into LDS and
 // cut into work items of at most kCompactItemUnits 16-byte units; the waves of the chunk's workgroups take items
@@ -2028,12 +1990,6 @@ bool fused_variant(const DevPlan& p, const uint8_t* points, FusedVariant* v) {
 }
 }  // namespace
 
-uint32_t stage1_fused_bitmap_fields(const DevPlan& plan) {
-  uint32_t n = 0;
-  for (uint32_t a = 0; a < plan.n_adaptive; ++a) n += plan.adaptive[a].bpv == 2u ? 1u : 0u;
-  return n;
-}
-
 uint32_t stage1_piece_points(const DevPlan& plan, const uint8_t* points) {
   FusedVariant v;
   if (!fused_variant(plan, points, &v)) return 0u;
@@ -2054,53 +2010,21 @@ uint32_t stage1_piece_slot_stride(const DevPlan& plan, const uint8_t* points) {
   return (fused_piece_points(v.lanes) * per_point + 255u) & ~255u;
 }
 
-bool stage1_single_pass_ok(const DevPlan& plan, const uint8_t* points) {
-  FusedVariant fv;
-  if (!fused_variant(plan, points, &fv) || fv.tail >= 0) return false;
-  // Palette sizes come from a presence bitmap, which exists for 2-byte fields only: a wider field could commit
-  // Palette on the device, and the choice of pipeline is made on the host before the modes are known
-  for (uint32_t a = 0; a < plan.n_adaptive; ++a)
-    if (plan.adaptive[a].bpv != 2u) return false;
-  return true;
-}
-
 static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piece0, uint32_t piece1) {
   FusedVariant v;
   if (!fused_variant(*L.plan, L.points, &v)) return launch_fail(hipErrorInvalidValue, "k_encode_fused (no variant)");
   FusedArgs A;
   A.points = L.points;
   A.points_end = L.points_end;
-  A.chunks = L.chunks;
   A.pieces = L.pieces + piece0;
-  A.n_pieces = piece1 - piece0;
-  A.ctrl = L.fctrl;
-  A.arrivals = L.arrivals;
-  A.lb = L.lb;
-  A.lbc = L.lbc;
-  A.start1 = L.start1;
-  A.prec = L.prec;
-  A.prec_stride = L.prec_stride;
-  A.bitmaps = L.bitmaps;
-  A.modes = L.modes;
   A.cols = L.cols;
-  A.out = L.out;
-  A.out_capacity = L.out_capacity;
-  A.chunk_payload = L.chunk_payload;
-  A.chunk_dst = reinterpret_cast<unsigned long long*>(L.chunk_dst);
-  A.secplace = reinterpret_cast<SecPlace*>(L.secplace);
-  A.status = L.status;
   static const uint32_t ablate_f = getenv("CLDN_HIP_ABLATE") ? (uint32_t)atoi(getenv("CLDN_HIP_ABLATE")) : 0u;  // profiling only
   A.ablate = ablate_f;
-  static const uint32_t ticket_f = getenv("CLDN_HIP_FUSED_TICKET") ? 1u : 0u;  // A/B switch: ticket order instead of dispatch order
-  A.use_ticket = L.fused ? ticket_f : 0u;
-  A.slot_mode = L.fused ? 0u : 1u;
   A.slots = L.slots;
   A.slot_stride = L.slot_stride;
   A.piece_stride = L.sub_stride / kFusedWaves;  // sub_stride = one workgroup's range (4 pieces)
   A.segs = L.segs;
   A.segs_per_chunk = L.segs_per_chunk;
-  const uint32_t n_bm = L.fused ? L.n_bm_fields : 0u;
-  A.n_bm_fields = n_bm;
   A.tail_kind = 0u;
   A.tail_rel = 0u;
   A.tail_size = 0u;
@@ -2113,7 +2037,7 @@ static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piec
     if (top.kind == OP_GORILLA64) A.tail_windows = reinterpret_cast<const uint16_t*>(L.pre.p[top.type]);
   }
   const uint32_t region = v.tail >= 0 ? fused_region_bytes_tail(v.lanes) : fused_region_bytes(v.lanes);
-  const uint32_t lds = 16u + kFusedWaves * region + (n_bm ? kBitmapWords * 4u : 0u);
+  const uint32_t lds = 16u + kFusedWaves * region;
   const dim3 grid((piece1 - piece0) / kFusedWaves), block(kFusedThreads);
 #define LAUNCH_FUSED(LL, WW, UU, L3)                                                                             \
   hipLaunchKernelGGL((k_encode_fused<LL, WW, UU, L3>), grid, block, lds, stream, *L.plan, A)
@@ -2208,96 +2132,12 @@ static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c
   return CLDN_HIP_OK;
 }
 
-// Chunk-group pipeline of the piece kernel + slots pipeline (EncodeLaunch::n_groups > 1).
-static int launch_encode_groups(const EncodeLaunch& L) {
-  hipError_t e;
-#define EV_TRY(expr) if ((e = (expr)) != hipSuccess) return hip_fail(e, #expr)
-  const uint32_t na = L.plan->n_adaptive;
-  const uint32_t G = L.n_groups;
-  hipEvent_t ev_setup = L.gev[0], ev_probe = L.gev[1], ev_side = L.gev[2];
-  hipEvent_t* ev_off = L.gev + 4;
-  if (L.events) (void)hipEventRecord(L.events[0], L.stream);
-  // everything enqueued on the main stream so far (uploads, memsets) precedes the side stream's work
-  EV_TRY(hipEventRecord(ev_setup, L.stream));
-  EV_TRY(hipStreamWaitEvent(L.side_stream, ev_setup, 0));
-  const bool probe = na && !L.modes_forced;
-  if (probe) {  // modes from the AoS input, next to the first group's regular kernel
-    hipLaunchKernelGGL(k_probe_extract, dim3(L.n_clouds, na), dim3(1024), 0, L.side_stream, *L.plan, L.points, L.chunks,
-                       L.cloud_first_chunk, L.cols);
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_extract");
-    hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na), dim3(kS2Threads), kProbeLds, L.side_stream, *L.plan, L.chunks,
-                       L.cloud_first_chunk, L.cols, L.modes);
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_fast");
-    EV_TRY(hipEventRecord(ev_probe, L.side_stream));
-  }
-  if (L.events) (void)hipEventRecord(L.events[1], L.stream);
-  bool main_waited_probe = false;
-  for (uint32_t i = 0; i < G; ++i) {
-    hipStream_t st = (i & 1u) ? L.side_stream : L.stream;
-    const uint32_t c0 = L.group_chunk0[i], c1 = L.group_chunk0[i + 1u];
-    if (c1 == c0) continue;
-    if (L.gtime) (void)hipEventRecord(L.gtime[2u * i], st);
-    int rc = launch_fused(L, st, L.group_piece0[i], L.group_piece0[i + 1u]);
-    if (rc != CLDN_HIP_OK) return rc;
-    if (L.gtime) (void)hipEventRecord(L.gtime[2u * i + 1u], st);
-    if (probe && !(i & 1u) && !main_waited_probe) {  // the side stream is ordered behind the probe by itself
-      EV_TRY(hipStreamWaitEvent(L.stream, ev_probe, 0));
-      main_waited_probe = true;
-    }
-    if ((rc = launch_sections(L, st, c0, c1)) != CLDN_HIP_OK) return rc;
-    if (i > 0u) EV_TRY(hipStreamWaitEvent(st, ev_off[i - 1u], 0));  // the position where this group starts
-    hipLaunchKernelGGL(k_chunk_offsets_range<1024>, dim3(1), dim3(1024), 0, st, L.segs + (size_t)c0 * L.segs_per_chunk,
-                       L.segs_per_chunk, c1 - c0, L.chunk_payload + c0, L.chunk_dst + c0,
-                       reinterpret_cast<uint64_t*>(L.running));
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_chunk_offsets_range");
-    EV_TRY(hipEventRecord(ev_off[i], st));
-    const uint32_t nch = c1 - c0;
-    const uint32_t splits = nch >= 1024u ? 1u : (nch >= 256u ? 4u : 16u);
-    hipLaunchKernelGGL(k_compact<256>, dim3(nch, splits), dim3(256), 0, st, L.slots + (size_t)c0 * L.slot_stride, L.slot_stride,
-                       L.segs + (size_t)c0 * L.segs_per_chunk, L.segs_per_chunk, L.chunk_payload + c0, L.chunk_dst + c0, L.out,
-                       L.out_capacity, L.status);
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_compact");
-  }
-  // rejoin: the main stream continues when the side stream is done
-  EV_TRY(hipEventRecord(ev_side, L.side_stream));
-  EV_TRY(hipStreamWaitEvent(L.stream, ev_side, 0));
-  hipLaunchKernelGGL(k_stream_offsets, dim3(std::min(64u, L.n_clouds / 256u + 1u)), dim3(256), 0, L.stream, L.chunk_payload,
-                     L.chunk_dst, L.n_chunks, L.cloud_first_chunk, L.n_clouds, L.stream_offsets);
-  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_stream_offsets");
-  if (L.events) {
-    (void)hipEventRecord(L.events[2], L.stream);
-    (void)hipEventRecord(L.events[3], L.stream);
-    (void)hipEventRecord(L.events[4], L.stream);
-  }
-#undef EV_TRY
-  return CLDN_HIP_OK;
-}
-
 int stage1_launch_encode(const EncodeLaunch& L) {
   hipError_t e;
-  if (L.n_groups > 1u && L.pieces && !L.fused && L.n_chunks && !L.plan->n_gorilla) return launch_encode_groups(L);
   if (L.events) (void)hipEventRecord(L.events[0], L.stream);
-  const uint32_t na_f = L.plan->n_adaptive;
   uint32_t gor_piece_pts = 0u;  // the piece kernel encodes the Gorilla field itself: points per piece
-  if (L.fused) {
-    // the modes come first: the single-pass kernel needs them for its section statistics
-    if (L.n_chunks && na_f && !L.modes_forced) {
-      hipLaunchKernelGGL(k_probe_extract, dim3(L.n_clouds, na_f), dim3(1024), 0, L.stream, *L.plan, L.points, L.chunks,
-                         L.cloud_first_chunk, L.cols);
-      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_extract");
-      hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na_f), dim3(kS2Threads), kProbeLds, L.stream, *L.plan, L.chunks,
-                         L.cloud_first_chunk, L.cols, L.modes);
-      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_fast");
-    }
-    if (L.events) (void)hipEventRecord(L.events[1], L.stream);
-    if (L.n_chunks) {
-      const int rc = launch_fused(L, L.stream, 0u, L.n_pieces);
-      if (rc != CLDN_HIP_OK) return rc;
-    }
-    goto regular_done;
-  }
   if (L.events) (void)hipEventRecord(L.events[1], L.stream);
-  gor_piece_pts = (L.n_chunks && L.pieces && !L.fused) ? stage1_gorilla_inline_piece_points(*L.plan, L.points) : 0u;
+  gor_piece_pts = (L.n_chunks && L.pieces) ? stage1_gorilla_inline_piece_points(*L.plan, L.points) : 0u;
   if (gor_piece_pts) {
     const uint32_t opi = L.plan->n_ops - 1u;  // the tail op
     hipLaunchKernelGGL(k_gorilla_windows, dim3(L.n_chunks), dim3(kGorThreads), 0, L.stream, *L.plan, opi, gor_piece_pts,
@@ -2350,12 +2190,11 @@ int stage1_launch_encode(const EncodeLaunch& L) {
 #undef LAUNCH_FLOATN
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_regular/floatn");
   }
-regular_done:
   if (L.events) (void)hipEventRecord(L.events[2], L.stream);
   const uint32_t na = L.plan->n_adaptive;
   if (na && L.n_chunks) {
     static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
-    if (!L.modes_forced && !L.fused) {
+    if (!L.modes_forced) {
       if (!no_fast) {
         hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na), dim3(kS2Threads), kProbeLds, L.stream, *L.plan, L.chunks,
                            L.cloud_first_chunk, L.cols, L.modes);
@@ -2371,16 +2210,6 @@ regular_done:
     if (rc_sec != CLDN_HIP_OK) return rc_sec;
   }
   if (L.events) (void)hipEventRecord(L.events[3], L.stream);
-  if (L.fused) {
-    hipLaunchKernelGGL(k_place_sections, dim3(std::max(1u, L.n_chunks), std::max(1u, na)), dim3(256), 0, L.stream, L.slots,
-                       L.slot_stride, L.segs, L.segs_per_chunk, L.subs, na, reinterpret_cast<const SecPlace*>(L.secplace),
-                       L.chunk_payload, reinterpret_cast<const unsigned long long*>(L.chunk_dst), L.n_chunks,
-                       L.cloud_first_chunk, L.n_clouds, reinterpret_cast<unsigned long long*>(L.stream_offsets), L.out,
-                       (unsigned long long)L.out_capacity, L.fctrl, L.status);
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_place_sections");
-    if (L.events) (void)hipEventRecord(L.events[4], L.stream);
-    return CLDN_HIP_OK;
-  }
   hipLaunchKernelGGL(k_chunk_offsets<1024>, dim3(1), dim3(1024), 0, L.stream, L.segs, L.segs_per_chunk, L.n_chunks,
                      L.cloud_first_chunk, L.n_clouds, L.chunk_payload, L.chunk_dst, L.stream_offsets);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_chunk_offsets");

@@ -42,40 +42,14 @@ struct EncodeLaunch {
   uint64_t out_capacity;
   uint32_t* status;           // device status word
   hipEvent_t* events;         // 5 events (start, before regular, after regular, after sections, end) or NULL
-  // piece kernel (stage1_fused.h). pieces != NULL: the regular stream is encoded one wave per piece; fused = true adds
-  // the inter-piece protocol that places every byte at once (single pass), fused = false leaves the pieces in the slots
-  bool fused;
+  // piece kernel (stage1_fused.h). pieces != NULL: the regular stream is encoded one wave per piece, every workgroup
+  // leaves one segment in the chunk's slot
   const PieceDesc* pieces;    // device [n_pieces] or NULL
   uint32_t n_pieces;          // multiple of 4
-  FusedCtrl* fctrl;           // device; fctrl, arrivals and lb are one zero-filled block per call
-  uint32_t* arrivals;         // device [n_chunks]
-  unsigned long long* lb;     // device [n_pieces]
-  unsigned long long* lbc;    // device [n_chunks]
-  unsigned long long* start1; // device [n_chunks]
-  uint32_t* prec;             // device [n_pieces * prec_stride]
-  uint32_t prec_stride;
-  uint32_t* bitmaps;          // device [n_chunks * n_bm_fields * 2048], zero between calls
-  uint32_t n_bm_fields;
-  void* secplace;             // device [n_chunks * n_adaptive] SecPlace
-  // chunk-group pipeline of the piece kernel + slots pipeline (n_groups > 1): group i = chunks [group_chunk0[i],
-  // group_chunk0[i+1]) runs regular -> sections -> offsets -> compaction on stream (i even ? stream : side_stream), so
-  // that the bandwidth-bound compaction and the LDS-bound section kernels of one group overlap the VALU-bound regular
-  // kernel of the next. The only cross-group dependency is the running output position (offsets kernels, in order).
-  uint32_t n_groups;                // 0 / 1: no pipeline
-  const uint32_t* group_chunk0;     // host [n_groups + 1]
-  const uint32_t* group_piece0;     // host [n_groups + 1]
-  hipStream_t side_stream;
-  hipEvent_t* gev;                  // host [4 + n_groups]: setup, probe, side done, main rejoin, offsets of group i
-  unsigned long long* running;      // device: bytes placed so far (zero at launch)
-  hipEvent_t* gtime;                // NULL or host [2 * n_groups]: (start, end) of every group's regular kernel
 };
 
-// Can the single-pass encoder take this plan (regular stream = one fused FloatN encoder the point load covers, section
-// statistics available for every mode its adaptive fields may commit)? Returns the points per piece, 0 = no.
 uint32_t stage1_piece_points(const DevPlan& plan, const uint8_t* points);        // piece kernel applies: points per piece, else 0
 uint32_t stage1_piece_slot_stride(const DevPlan& plan, const uint8_t* points);   // bytes a piece may produce, 256-aligned
-bool stage1_single_pass_ok(const DevPlan& plan, const uint8_t* points);          // ... and section statistics exist for every field
-uint32_t stage1_fused_bitmap_fields(const DevPlan& plan);
 
 struct DecodeLaunch {
   const DevPlan* plan;

@@ -215,8 +215,8 @@ class Codec:
         _check(lib().cldn_hip_codec_force_modes(self._h, m.ctypes.data_as(C.POINTER(C.c_uint8)), m.size))
 
     def pipeline(self, mode: int = 0, points_ptr: int = 0) -> int:
-        """Choose the encoder pipeline (cldn_hip_codec_pipeline: 0 auto, 1 tile kernel + slots, 2 piece kernel + slots,
-        3 single pass); returns the pipeline the next call takes."""
+        """Choose the encoder pipeline (cldn_hip_codec_pipeline: 0 auto, 1 tile kernel + slots, 2 piece kernel + slots);
+        returns the pipeline the next call takes."""
         r = lib().cldn_hip_codec_pipeline(self._h, int(mode), C.c_void_p(points_ptr))
         _check(r)
         return int(r)

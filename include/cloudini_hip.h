@@ -140,15 +140,13 @@ int cldn_hip_encode_stage1_gather(cldn_hip_codec_t* codec, const void* const* cl
  * The setting stays until changed and applies to every cloud of the following encode calls. */
 int cldn_hip_codec_force_modes(cldn_hip_codec_t* codec, const uint8_t* modes, uint32_t n_modes);
 
-/* Encoder pipelines (all produce identical bytes; for A/B runs and tests):
- *   1  tile kernel + slots   every schema: workgroup tiles with barriers (k_encode_floatn / k_encode_regular), streams
- *                            left in per-chunk slots, k_chunk_offsets + k_compact pack them
+/* Encoder pipelines (both produce identical bytes; for A/B runs and tests):
+ *   1  tile kernel + slots   every schema: workgroup tiles with barriers (k_encode_floatn / k_encode_regular)
  *   2  piece kernel + slots  schemas whose per-point stream is one fused FloatN encoder (3 or 4 leading lossy FLOAT32
- *                            fields): one wave per 504/378-point piece, barrier-free (cloudini_amd/csrc/stage1_fused.h)
- *   3  single pass           the piece kernel places every byte itself (look-back over pieces, section sizes from
- *                            per-piece statistics); needs 16-bit adaptive fields only. Experimental: correct, but on
- *                            MI355X the inter-workgroup hops cost more than the compaction pass they replace
+ *                            fields), optionally followed by one more per-point encoder: one wave per 504/378-point
+ *                            piece, barrier-free (cloudini_amd/csrc/stage1_fused.h)
  *   0  automatic (default)   2 where the schema allows it, else 1
+ * Either way the streams are left in per-chunk slots and k_finish (sections, chunk sizes, placement) packs them.
  * Returns the pipeline the next encode call of this codec takes for inputs at `points` (device pointer, or NULL for
  * host inputs), or a negative error. */
 int cldn_hip_codec_pipeline(cldn_hip_codec_t* codec, int mode, const void* points);

@@ -15,21 +15,20 @@ def _first_diff(a, b):
 
 
 def check_encode(oracle, info, clouds):
-    """Every encoder pipeline the schema allows (single pass, piece kernel + slots, tile kernel + slots) against the
-    oracle."""
+    """Every encoder pipeline the schema allows (piece kernel + slots, tile kernel + slots) against the oracle."""
     from cloudini_amd import native
     plan = native.Plan(info)
     codec = native.Codec(plan)
     wants = [oracle.encode_stage1(info, cloud, return_modes=True) for cloud in clouds]
     streams = None
     taken_all = set()
-    for mode in (3, 2, 1):
+    for mode in (2, 1):
         taken = codec.pipeline(mode)
         if taken in taken_all:   # the schema does not allow this pipeline: it falls back to one already checked
             continue
         taken_all.add(taken)
         streams, chunk_sizes, modes = codec.encode_host(clouds)
-        tag = {1: "tile kernel + slots", 2: "piece kernel + slots", 3: "single pass"}[taken]
+        tag = {1: "tile kernel + slots", 2: "piece kernel + slots"}[taken]
         pos = 0
         for k, cloud in enumerate(clouds):
             want, want_modes = wants[k]

@@ -1,7 +1,7 @@
-"""GPU parity of the single-pass encoder (cloudini_amd/csrc/stage1_fused.h): every byte written once at its final
-position, positions from a look-back scan over pieces, section sizes from per-piece statistics. Compared with the
-oracle and with the slot pipeline on schemas that exercise every section mode, piece / chunk boundaries, padding
-pieces, forced modes, ragged batches and repeated calls on one codec (the per-chunk bitmaps clear themselves)."""
+"""GPU parity of the piece kernel (cloudini_amd/csrc/stage1_fused.h: one wave per 504/378-point piece) and of k_finish
+(stage1_finish.h: sections, chunk sizes and placement in one launch) against the oracle and against the tile-kernel
+pipeline, on schemas that exercise every section mode, piece / chunk boundaries, padding pieces, forced modes, ragged
+batches and repeated calls on one codec."""
 import numpy as np
 import pytest
 
@@ -61,7 +61,7 @@ def test_every_section_mode_behind_xyz(oracle, kind):
     info, data = xyz_plus(n, [("v", ftype, col)])
     from cloudini_amd import native
     codec = native.Codec(native.Plan(info))
-    assert codec.pipeline(3) == 3 and codec.pipeline(0) == 2  # the single pass is possible, the piece kernel is the default
+    assert codec.pipeline(0) == 2  # the piece kernel is the default
     codec.close()
     check_encode(oracle, info, [data])
 
@@ -136,11 +136,11 @@ def test_ragged_batches_and_empty_clouds(oracle):
 
 
 def test_one_codec_many_calls(oracle):
-    """The per-chunk bitmaps and the control words must be clean for every call, whatever the previous call did."""
+    """The look-back records and control words must be clean for every call, whatever the previous call did."""
     from cloudini_amd import native
     info, _ = synth.lidar_xyzi(10)
     codec = native.Codec(native.Plan(info))
-    assert codec.pipeline(3) == 3
+    assert codec.pipeline(2) == 2
     rs = np.random.RandomState(11)
     for it in range(12):
         clouds = []
@@ -160,14 +160,14 @@ def test_one_codec_many_calls(oracle):
     codec.close()
 
 
-def test_forced_modes_take_the_single_pass(oracle):
+def test_forced_modes_chunk_ranges(oracle):
     """Chunk ranges of one cloud with the modes committed elsewhere (cldn_hip_codec_force_modes): concatenation equals
     the whole cloud's stream."""
     from cloudini_amd import native
     info, data = synth.lidar_xyzi(200000, seed=2)
     want, want_modes = oracle.encode_stage1(info, data, return_modes=True)
     codec = native.Codec(native.Plan(info))
-    assert codec.pipeline(3) == 3
+    assert codec.pipeline(2) == 2
     codec.force_modes(want_modes)
     step = info.point_step
     parts = []
@@ -179,12 +179,8 @@ def test_forced_modes_take_the_single_pass(oracle):
     codec.close()
 
 
-def test_wide_integer_fields_keep_the_slots(oracle):
-    from cloudini_amd import native
+def test_wide_integer_fields(oracle):
     info, data = synth.depthcam_xyzrgba(320, 240)
-    codec = native.Codec(native.Plan(info))
-    assert codec.pipeline(3) == 2  # u32 rgba could commit Palette, for which the single pass has no statistics
-    codec.close()
     check_encode(oracle, info, [data])
 
 
