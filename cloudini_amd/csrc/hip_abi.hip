@@ -154,13 +154,18 @@ struct cldn_hip_codec {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   // workspace (grow-only)
-  DevBuf d_in, d_out, d_slots, d_chunks, d_cloud_first, d_segs, d_payload, d_dst, d_offsets, d_modes, d_status;
+  DevBuf d_in, d_out, d_slots, d_chunks, d_cloud_first, d_payload, d_dst, d_offsets, d_modes;
+  // zeroed once per encode call: [status block 256 B | k_finish anchors | section-handled flags | segment table]
+  DevBuf d_status;
   DevBuf d_cols[kMaxAdaptive];
   DevBuf d_ranks[kMaxAdaptive];
-  DevBuf d_dec_meta, d_fbflags, d_pre_ptrs;
+  DevBuf d_dec_meta, d_pre_ptrs;
+  DevBuf d_finrec;            // k_finish look-back records (rec, rec2), cleared only when (re)allocated
+  uint32_t finish_epoch = 0;  // tag of this call's records
   DevBuf d_pieces;  // piece table of the piece kernel (stage1_fused.h)
   uint32_t n_pieces = 0;
   uint32_t last_piece_pts = 0;
+  bool last_quad_major = false;
   uint64_t pending_total = 0;  // bytes of a deferred host output waiting in d_out (cldn_hip_codec_fetch_output)
   int pipeline = 0;           // cldn_hip_codec_pipeline: 0 auto, 1 tile kernel + slots, 2 piece kernel + slots
   DevBuf d_viz_keys, d_viz_first, d_viz_slot, d_viz_blocks, d_viz_total;  // applyVizLossyPreprocessing workspace
@@ -468,8 +473,8 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   DeviceGuard guard;
   (void)guard.enter(c->device);
   (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_segs,
-                    &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_fbflags, &c->d_pre_ptrs,
+  DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec,
+                    &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_pre_ptrs,
                     &c->d_pre[0], &c->d_pre[1], &c->d_pre[2], &c->d_pre[3], &c->d_viz_keys, &c->d_viz_first,
                     &c->d_viz_slot, &c->d_viz_blocks, &c->d_viz_total, &c->d_pieces};
   for (DevBuf* b : bufs) b->release();
@@ -541,8 +546,10 @@ int cldn_hip_codec_status(cldn_hip_codec_t* c) {
 
 // Build (or reuse) the chunk table of a batch. Returns the number of chunks and total points.
 // piece_pts != 0: also the piece table of the single-pass encoder (pieces of piece_pts points, per chunk padded to 4)
+// quad_major: the piece table lists workgroup 0 (pieces 0..3) of every chunk, then workgroup 1 of every chunk, ... so
+// that the workgroups of ONE chunk start far apart in time (intra-chunk placement of the piece kernel)
 static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, uint32_t n_clouds, uint32_t piece_pts,
-                              uint32_t* n_chunks_out, uint64_t* n_points_out) {
+                              bool quad_major, uint32_t* n_chunks_out, uint64_t* n_points_out) {
   uint64_t total_points = 0;
   uint64_t n_chunks64 = 0;
   for (uint32_t k = 0; k < n_clouds; ++k) {
@@ -555,7 +562,7 @@ static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, u
   *n_points_out = total_points;
   int rc;
   const bool same = c->last_cloud_points.size() == n_clouds && c->last_n_chunks == n_chunks &&
-                    c->last_piece_pts == piece_pts &&
+                    c->last_piece_pts == piece_pts && c->last_quad_major == quad_major &&
                     std::equal(c->last_cloud_points.begin(), c->last_cloud_points.end(), cloud_points);
   uint64_t n_pieces64 = 0;
   if (piece_pts) {
@@ -601,22 +608,34 @@ static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, u
   if (piece_pts && n_pieces64) {
     PieceDesc* hp = (PieceDesc*)((uint8_t*)c->h_stage.p + head_bytes);
     size_t g = 0;
-    for (uint32_t k = 0; k < n_chunks; ++k) {
-      const uint32_t P = (((hc[k].n_points + piece_pts - 1) / piece_pts) + 3u) & ~3u;
-      for (uint32_t q = 0; q < P; ++q) {
-        hp[g].chunk_first_point = hc[k].first_point;
-        hp[g].chunk = k;
-        hp[g].cloud = hc[k].cloud;
-        hp[g].n_chunk_points = hc[k].n_points;
-        hp[g].p = (uint16_t)q;
-        hp[g].P = (uint16_t)P;
-        hp[g].pad[0] = hp[g].pad[1] = 0;
-        ++g;
+    auto put = [&](uint32_t k, uint32_t q, uint32_t P) {
+      hp[g].chunk_first_point = hc[k].first_point;
+      hp[g].chunk = k;
+      hp[g].cloud = hc[k].cloud;
+      hp[g].n_chunk_points = hc[k].n_points;
+      hp[g].p = (uint16_t)q;
+      hp[g].P = (uint16_t)P;
+      hp[g].pad[0] = hp[g].pad[1] = 0;
+      ++g;
+    };
+    const uint32_t max_p = (((kPointsPerChunk + piece_pts - 1) / piece_pts) + 3u) & ~3u;
+    if (!quad_major) {
+      for (uint32_t k = 0; k < n_chunks; ++k) {
+        const uint32_t P = (((hc[k].n_points + piece_pts - 1) / piece_pts) + 3u) & ~3u;
+        for (uint32_t q = 0; q < P; ++q) put(k, q, P);
       }
+    } else {
+      for (uint32_t q0 = 0; q0 < max_p; q0 += 4u)
+        for (uint32_t k = 0; k < n_chunks; ++k) {
+          const uint32_t P = (((hc[k].n_points + piece_pts - 1) / piece_pts) + 3u) & ~3u;
+          if (q0 < P)
+            for (uint32_t q = q0; q < q0 + 4u; ++q) put(k, q, P);
+        }
     }
     HIP_TRY(hipMemcpyAsync(c->d_pieces.p, hp, g * sizeof(PieceDesc), hipMemcpyHostToDevice, c->stream));
   }
   c->last_piece_pts = piece_pts;
+  c->last_quad_major = quad_major;
   if (n_chunks)
     HIP_TRY(hipMemcpyAsync(c->d_chunks.p, hc, (size_t)n_chunks * sizeof(ChunkDesc), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_cloud_first.p, hf, (size_t)(n_clouds + 1) * sizeof(uint32_t), hipMemcpyHostToDevice,
@@ -646,7 +665,9 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   // device-resident inputs decide the kernel variant by their address; host inputs are staged into an aligned buffer
   const uint8_t* variant_ptr = points_loc == CLDN_HIP_DEVICE ? (const uint8_t*)points : nullptr;
   const uint32_t piece_pts = c->pipeline == 1 ? 0u : stage1_piece_points(plan, variant_ptr);
-  int rc = upload_batch_shape(c, cloud_points, n_clouds, piece_pts, &n_chunks, &n_points);
+  static const bool intra_env = getenv("CLDN_HIP_INTRA") && atoi(getenv("CLDN_HIP_INTRA")) != 0;  // A/B switch
+  static const bool quad_major_env = !(getenv("CLDN_HIP_QUAD_MAJOR") && atoi(getenv("CLDN_HIP_QUAD_MAJOR")) == 0);
+  int rc = upload_batch_shape(c, cloud_points, n_clouds, piece_pts, piece_pts != 0u && intra_env && quad_major_env, &n_chunks, &n_points);
   if (rc != CLDN_HIP_OK) return rc;
   if (n_points && !points && !cloud_ptrs) return fail(CLDN_HIP_ERR_ARG, "points is NULL");
   if (cloud_ptrs)
@@ -676,19 +697,27 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   }
   if (subs < 1u || subs > 32u || (subs & (subs - 1u))) subs = 1u;
   const bool pieces = piece_pts != 0u && n_chunks != 0u;   // regular stream by the piece kernel
-  if (pieces) subs = ((((kPointsPerChunk + piece_pts - 1u) / piece_pts) + 3u) & ~3u) / 4u;  // one segment per workgroup (4 pieces)
+  const bool intra = pieces && intra_env;
+  const uint32_t piece_wgs = ((((kPointsPerChunk + piece_pts - 1u) / std::max(1u, piece_pts)) + 3u) & ~3u) / 4u;  // workgroups (4 pieces) per full chunk
+  if (pieces) subs = intra ? 1u : piece_wgs;  // one segment per workgroup, or one per chunk
   const uint32_t sub_points = pieces ? piece_pts : kPointsPerChunk / subs;
-  const uint32_t sub_stride = pieces ? 4u * stage1_piece_slot_stride(plan, variant_ptr)
+  // (intra: the slot still reserves the worst case of every workgroup, the streams are packed at its start)
+  const uint32_t sub_stride = pieces ? 4u * stage1_piece_slot_stride(plan, variant_ptr) * (intra ? piece_wgs : 1u)
                                      : (uint32_t)((((uint64_t)sub_points * plan.max_regular_bytes + 64u) + 255u) & ~uint64_t(255));
   const uint32_t segs_per_chunk = subs + 2u * n_adaptive;
   const uint64_t reg_stride = (uint64_t)subs * sub_stride;
   const uint64_t slot_stride = reg_stride + (uint64_t)n_adaptive * kSectionStride;
 
-  if ((rc = c->d_status.ensure(256)) != CLDN_HIP_OK) return rc;
+  // one zero-filled block per call (one memset launch instead of three)
+  const size_t z_anchor = 256;
+  const size_t z_flags = z_anchor + (((size_t)(n_chunks / 1024u + 1u) * 8u + 63u) & ~size_t(63));
+  const size_t z_segs = (z_flags + (size_t)n_chunks * std::max(1u, n_adaptive) + 63u) & ~size_t(63);
+  const size_t z_bytes = z_segs + std::max<size_t>(16, (size_t)n_chunks * segs_per_chunk * sizeof(Seg));
+  if ((rc = c->d_status.ensure(z_bytes)) != CLDN_HIP_OK) return rc;
   if ((rc = c->d_offsets.ensure((size_t)(n_clouds + 1) * sizeof(uint64_t))) != CLDN_HIP_OK) return rc;
   if ((rc = c->d_modes.ensure(std::max<size_t>(1, (size_t)n_clouds * std::max(1u, n_adaptive)))) != CLDN_HIP_OK)
     return rc;
-  HIP_TRY(hipMemsetAsync(c->d_status.p, 0, 256, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_status.p, 0, z_bytes, c->stream));
   // a batch without a single point launches no probe: its clouds commit mode 0 (DeltaVarint), like an encode() call of
   // the reference that never reaches the analysis (src/v5_codec.cpp:934-949)
   if (n_chunks == 0 && n_clouds && n_adaptive) HIP_TRY(hipMemsetAsync(c->d_modes.p, 0, (size_t)n_clouds * n_adaptive, c->stream));
@@ -696,12 +725,21 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   const uint8_t* d_points = (const uint8_t*)points;
   uint8_t* d_outp = (uint8_t*)out;
   if (n_chunks) {
-    if ((rc = c->d_segs.ensure(std::max<size_t>(16, (size_t)n_chunks * segs_per_chunk * sizeof(Seg)))) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_payload.ensure((size_t)n_chunks * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_dst.ensure((size_t)n_chunks * sizeof(uint64_t))) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_slots.ensure(std::max<size_t>(16, (size_t)n_chunks * slot_stride))) != CLDN_HIP_OK) return rc;
-    if ((rc = c->d_fbflags.ensure((size_t)n_chunks * std::max(1u, n_adaptive))) != CLDN_HIP_OK) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_fbflags.p, 0, (size_t)n_chunks * std::max(1u, n_adaptive), c->stream));
+    {  // look-back records of k_finish: tagged with the call's epoch, so only a fresh allocation is cleared
+      const void* before = c->d_finrec.p;
+      if ((rc = c->d_finrec.ensure((size_t)n_chunks * 16u + (size_t)n_chunks * 32u * 8u)) != CLDN_HIP_OK) return rc;  // rec, rec2, 32 workgroup records per chunk
+      if (c->d_finrec.p != before) {
+        HIP_TRY(hipMemsetAsync(c->d_finrec.p, 0, c->d_finrec.cap, c->stream));
+        c->finish_epoch = 0;
+      }
+      if (++c->finish_epoch == 0u) {  // wrapped: old records could carry the new tags
+        HIP_TRY(hipMemsetAsync(c->d_finrec.p, 0, c->d_finrec.cap, c->stream));
+        c->finish_epoch = 1u;
+      }
+    }
     for (uint32_t a = 0; a < n_adaptive; ++a) {
       if ((rc = c->d_cols[a].ensure((size_t)n_points * plan.adaptive[a].bpv + 64)) != CLDN_HIP_OK) return rc;
       if ((rc = c->d_ranks[a].ensure((size_t)n_points * 2 + 64)) != CLDN_HIP_OK) return rc;
@@ -735,7 +773,6 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
       if ((rc = c->d_out.ensure((size_t)need)) != CLDN_HIP_OK) return rc;
       d_outp = (uint8_t*)c->d_out.p;
     }
-    if (segs_per_chunk) HIP_TRY(hipMemsetAsync(c->d_segs.p, 0, (size_t)n_chunks * segs_per_chunk * sizeof(Seg), c->stream));
   }
   EncodeLaunch L;
   memset(&L, 0, sizeof(L));
@@ -753,7 +790,7 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   L.subs = subs;
   L.sub_points = sub_points;
   L.sub_stride = sub_stride;
-  L.segs = (Seg*)c->d_segs.p;
+  L.segs = (Seg*)((uint8_t*)c->d_status.p + z_segs);
   L.segs_per_chunk = segs_per_chunk;
   for (uint32_t a = 0; a < n_adaptive; ++a) {
     L.cols.p[a] = (uint8_t*)c->d_cols[a].p;
@@ -789,10 +826,17 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
                            c->stream));
     L.modes_forced = true;
   }
-  L.fallback_flags = (uint8_t*)c->d_fbflags.p;
+  L.fallback_flags = (uint8_t*)c->d_status.p + z_flags;
+  L.fin_rec = (unsigned long long*)c->d_finrec.p;
+  L.fin_rec2 = L.fin_rec + n_chunks;
+  L.fin_anchor = (unsigned long long*)((uint8_t*)c->d_status.p + z_anchor);
+  L.fin_epoch = c->finish_epoch;
+  L.fin_ticket = (uint32_t*)c->d_status.p + 40;
   if (pieces) {
     L.pieces = (const PieceDesc*)c->d_pieces.p;
     L.n_pieces = c->n_pieces;
+    L.intra = intra;
+    L.wgrec = L.fin_rec2 + n_chunks;
   }
   L.out = d_outp;
   L.out_capacity = out_capacity;
@@ -822,7 +866,7 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
     std::vector<Seg> hs((size_t)n_chunks * segs_per_chunk);
     std::vector<ChunkDesc> hc(n_chunks);
     if (n_chunks) {
-      HIP_TRY(hipMemcpy(hs.data(), c->d_segs.p, hs.size() * sizeof(Seg), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(hs.data(), (uint8_t*)c->d_status.p + z_segs, hs.size() * sizeof(Seg), hipMemcpyDeviceToHost));
       HIP_TRY(hipMemcpy(hc.data(), c->d_chunks.p, hc.size() * sizeof(ChunkDesc), hipMemcpyDeviceToHost));
     }
     if (FILE* f = fopen(dump, "w")) {

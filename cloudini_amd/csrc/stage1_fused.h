@@ -178,6 +178,13 @@ struct FusedArgs {
   uint32_t tail_size;            // field bytes
   const uint16_t* tail_windows;  // OP_GORILLA64: k_gorilla_windows' window in front of every piece, [chunk * 128 + piece]
   uint32_t ablate;               // profiling only (CLDN_HIP_ABLATE): 4 no column stores
+  // intra != 0: the workgroups of a chunk place their streams back to back at the start of the chunk's slot (ONE
+  // regular segment per chunk): every workgroup publishes its byte count as {epoch, bytes} and adds up the records of
+  // its chunk's workgroups before it (at most 16, one load per lane; agent-scope store / loads, bounded spin)
+  uint32_t intra;
+  uint32_t epoch;
+  unsigned long long* wgrec;     // [n_chunks * 32]
+  uint32_t* status;
 };
 
 // UNAL / L3 / LOADW as in k_encode_floatn.
@@ -487,6 +494,35 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
     total += rw;
   }
   const uint32_t quad = p >> 2;
+  if (A.intra) {
+    // The piece table lists the chunk's workgroups in ascending order, and the hardware hands out a grid's workgroups
+    // in index order: the records this workgroup waits for belong to workgroups that have started -- with the
+    // quad-major table of a large batch, a whole generation of workgroups earlier. The spin is bounded all the same.
+    unsigned long long* rec = A.wgrec + (size_t)pd.chunk * 32u;  // my chunk's records (<= 22 workgroups per chunk)
+    if (wave == 0u && lane == 0u)
+      __hip_atomic_store(rec + quad, ((unsigned long long)A.epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t mine = 0u;
+    for (uint32_t spins = 0;; ++spins) {
+      const unsigned long long x = lane < quad ? __hip_atomic_load(rec + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                               : ((unsigned long long)A.epoch << 32);
+      mine = (uint32_t)x;
+      if (__ballot((uint32_t)(x >> 32) != A.epoch) == 0ull) break;
+      if (spins >= (1u << 22)) {
+        if (lane == 0u) atomicOr(A.status, (uint32_t)ST_FINISH_TIMEOUT);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const uint32_t wg_off = wave_sum(mine);  // bytes of the chunk's workgroups before mine
+    if (R) copy_region_out(region, R, A.slots + (size_t)pd.chunk * A.slot_stride + wg_off + before, lane);
+    if (wave == 0u && lane == 0u && quad + 1u == (pd.P >> 2)) {  // the chunk's last workgroup: the regular stream is complete
+      Seg sg;
+      sg.off = 0u;
+      sg.size = wg_off + total;
+      A.segs[(size_t)pd.chunk * A.segs_per_chunk] = sg;
+    }
+    return;
+  }
   const uint32_t seg_off = quad * kFusedWaves * A.piece_stride;
   if (R) copy_region_out(region, R, A.slots + (size_t)pd.chunk * A.slot_stride + seg_off + before, lane);
   if (wave == 0u && lane == 0u) {

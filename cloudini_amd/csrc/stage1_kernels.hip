@@ -1327,6 +1327,7 @@ namespace cldn {
 
 #include "stage1_sections.h"
 #include "stage1_fused.h"
+#include "stage1_finish.h"
 
 namespace cldn {
 
@@ -1762,13 +1763,16 @@ __global__ __launch_bounds__(kSecThreads) void k_encode_sections(const DevPlan p
                                                                  uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                                  uint64_t reg_stride, Seg* __restrict__ segs,
                                                                  uint32_t segs_per_chunk, const ColumnPtrs rank_cols,
-                                                                 uint32_t subs, const uint8_t* __restrict__ handled_flags) {
+                                                                 uint32_t subs, const uint8_t* __restrict__ handled_flags,
+                                                                 uint32_t fused_field) {
   constexpr int T = kSecThreads;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const SecLds l = sec_lds_carve(smem);
   const uint32_t c = blockIdx.x, a = blockIdx.y;
   if (handled_flags[(size_t)c * plan.n_adaptive + a]) return;  // a fast-path kernel already wrote this section
   const ChunkDesc cd = chunks[c];
+  // k_finish builds the Palette sections of this field itself (any number of distinct values)
+  if (a == fused_field && modes[cd.cloud * plan.n_adaptive + a] == 1u) return;
   const uint32_t n = cd.n_points;
   const uint32_t bpv = plan.adaptive[a].bpv, type = plan.adaptive[a].type;
   const uint8_t* col = cols.p[a] + (size_t)cd.first_point * bpv;
@@ -2025,6 +2029,10 @@ static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piec
   A.piece_stride = L.sub_stride / kFusedWaves;  // sub_stride = one workgroup's range (4 pieces)
   A.segs = L.segs;
   A.segs_per_chunk = L.segs_per_chunk;
+  A.intra = L.intra ? 1u : 0u;
+  A.epoch = L.fin_epoch;
+  A.wgrec = L.wgrec;
+  A.status = L.status;
   A.tail_kind = 0u;
   A.tail_rel = 0u;
   A.tail_size = 0u;
@@ -2070,7 +2078,7 @@ static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piec
 
 // section kernels of chunks [c0, c1) on `stream` (per-chunk tables are passed shifted to c0; columns, modes and the
 // chunk descriptors' point indexes are batch-global)
-static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c0, uint32_t c1) {
+static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c0, uint32_t c1, uint32_t fused_field) {
   hipError_t e;
   const uint32_t na = L.plan->n_adaptive;
   const uint32_t nch = c1 - c0;
@@ -2094,7 +2102,7 @@ static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c
       if (bpv == 2u) run16.a[run16.n++] = (uint8_t)a;
       else if (bpv == 4u) run32.a[run32.n++] = (uint8_t)a;
     }
-    if (hint & 0x2u) {
+    if ((hint & 0x2u) && a != fused_field) {
       if (bpv == 2u) pal16.a[pal16.n++] = (uint8_t)a;
       else if (bpv == 4u) pal32.a[pal32.n++] = (uint8_t)a;
       else pal64.a[pal64.n++] = (uint8_t)a;
@@ -2116,24 +2124,35 @@ static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c
     // of up to 1024 chunks is one generation (C2: sections 0.066 -> 0.062 ms); CLDN_HIP_PAL32_THREADS=1024 is the A/B switch
     static const bool pal1024 = getenv("CLDN_HIP_PAL32_THREADS") && atoi(getenv("CLDN_HIP_PAL32_THREADS")) == 1024;
     if (pal1024)
-      hipLaunchKernelGGL((k_section_palette32<uint16_t, kS2Threads>), dim3(nch, pal16.n), dim3(kS2Threads), Pal32<uint16_t>::kLds, stream, SEC_ARGS(pal16));
+      hipLaunchKernelGGL((k_section_palette32<uint16_t, kS2Threads>), dim3(nch, pal16.n), dim3(kS2Threads), Pal32<uint16_t>::kLds, stream, SEC_ARGS(pal16), rank_cols, L.status);
     else
-      hipLaunchKernelGGL((k_section_palette32<uint16_t, 512>), dim3(nch, pal16.n), dim3(512), Pal32<uint16_t>::kLds, stream, SEC_ARGS(pal16));
+      hipLaunchKernelGGL((k_section_palette32<uint16_t, 512>), dim3(nch, pal16.n), dim3(512), Pal32<uint16_t>::kLds, stream, SEC_ARGS(pal16), rank_cols, L.status);
   }
   if (pal32.n)
-    hipLaunchKernelGGL((k_section_palette32<uint32_t, 512>), dim3(nch, pal32.n), dim3(512), Pal32<uint32_t>::kLds, stream, SEC_ARGS(pal32));
+    hipLaunchKernelGGL((k_section_palette32<uint32_t, 512>), dim3(nch, pal32.n), dim3(512), Pal32<uint32_t>::kLds, stream, SEC_ARGS(pal32), rank_cols, L.status);
   if (pal64.n)
     hipLaunchKernelGGL(k_section_palette<uint64_t>, dim3(nch, pal64.n), dim3(kS2Threads), kS2PalLds, stream, SEC_ARGS(pal64));
 #undef SEC_ARGS
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_palette");
   hipLaunchKernelGGL(k_encode_sections, dim3(nch, na), dim3(kSecThreads), kSecLdsTotal, stream, *L.plan, chunks, L.cols,
-                     L.modes, slots, L.slot_stride, L.reg_stride, segs, L.segs_per_chunk, rank_cols, L.subs, flags);
+                     L.modes, slots, L.slot_stride, L.reg_stride, segs, L.segs_per_chunk, rank_cols, L.subs, flags, fused_field);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_sections");
   return CLDN_HIP_OK;
 }
 
+constexpr uint32_t kNoFusedField = 0xffffffffu;
+
 int stage1_launch_encode(const EncodeLaunch& L) {
   hipError_t e;
+  // CLDN_HIP_FINISH (A/B switch): 0 = the round-2 kernels (k_chunk_offsets + k_compact), 1 = k_finish without the fused
+  // Palette section, 2 (default) = k_finish with it where the schema allows
+  static const int finish_mode = getenv("CLDN_HIP_FINISH") ? atoi(getenv("CLDN_HIP_FINISH")) : 2;
+  // the field whose Palette sections k_finish builds itself: the first 2- or 4-byte adaptive field that may commit Palette
+  uint32_t fused_field = kNoFusedField;
+  if (finish_mode >= 2 && L.n_chunks) {
+    for (uint32_t a = 0; a < L.plan->n_adaptive && fused_field == kNoFusedField; ++a)
+      if ((L.plan->adaptive[a].bpv == 2u || L.plan->adaptive[a].bpv == 4u) && (L.mode_hint[a] & 0x2u)) fused_field = a;
+  }
   if (L.events) (void)hipEventRecord(L.events[0], L.stream);
   uint32_t gor_piece_pts = 0u;  // the piece kernel encodes the Gorilla field itself: points per piece
   if (L.events) (void)hipEventRecord(L.events[1], L.stream);
@@ -2206,10 +2225,65 @@ int stage1_launch_encode(const EncodeLaunch& L) {
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_probe_modes");
       }
     }
-    const int rc_sec = launch_sections(L, L.stream, 0u, L.n_chunks);
+    const int rc_sec = launch_sections(L, L.stream, 0u, L.n_chunks, fused_field);
     if (rc_sec != CLDN_HIP_OK) return rc_sec;
   }
   if (L.events) (void)hipEventRecord(L.events[3], L.stream);
+  if (finish_mode != 0) {
+    if (L.n_chunks == 0u) {  // no chunk, no workgroup: every cloud's stream is empty
+      if ((e = hipMemsetAsync(L.stream_offsets, 0, (size_t)(L.n_clouds + 1u) * sizeof(uint64_t), L.stream)) != hipSuccess)
+        return hip_fail(e, "hipMemsetAsync(stream_offsets)");
+    } else {
+      FinishArgs F;
+      F.chunks = L.chunks;
+      F.n_chunks = L.n_chunks;
+      F.cloud_first_chunk = L.cloud_first_chunk;
+      F.n_clouds = L.n_clouds;
+      F.slots = L.slots;
+      F.slot_stride = L.slot_stride;
+      F.segs = L.segs;
+      F.segs_per_chunk = L.segs_per_chunk;
+      F.subs = L.subs;
+      F.rec = L.fin_rec;
+      F.rec2 = L.fin_rec2;
+      F.anchor = L.fin_anchor;
+      F.epoch = L.fin_epoch;
+      F.ticket = L.fin_ticket;
+      static const uint32_t use_ticket = getenv("CLDN_HIP_FINISH_TICKET") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_TICKET")) : 0u;
+      static const uint32_t order = getenv("CLDN_HIP_FINISH_ORDER") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_ORDER")) : 0u;  // A/B switch
+      F.use_ticket = use_ticket;
+      F.order = order;
+      F.chunk_payload = L.chunk_payload;
+      F.chunk_dst = L.chunk_dst;
+      F.stream_offsets = L.stream_offsets;
+      F.out = L.out;
+      F.out_capacity = L.out_capacity;
+      F.status = L.status;
+      F.modes = L.modes;
+      F.n_adaptive = na;
+      F.fuse_field = fused_field;
+      F.fuse_col = nullptr;
+      F.fuse_first = nullptr;
+      if (fused_field != kNoFusedField) {
+        F.fuse_col = L.cols.p[fused_field];
+        F.fuse_first = L.ranks[fused_field];
+        const uint32_t splits = L.n_chunks >= 512u ? 1u : (L.n_chunks >= 128u ? 2u : 8u);
+        F.splits = splits;
+        if (L.plan->adaptive[fused_field].bpv == 2u)
+          hipLaunchKernelGGL((k_finish<512, 2>), dim3(L.n_chunks * splits), dim3(512), Pal32<uint16_t>::kLds, L.stream, F);
+        else
+          hipLaunchKernelGGL((k_finish<512, 4>), dim3(L.n_chunks * splits), dim3(512), Pal32<uint32_t>::kLds, L.stream, F);
+      } else {
+        const uint32_t splits = L.n_chunks >= 1024u ? 1u : (L.n_chunks >= 256u ? 4u : 16u);
+        F.splits = splits;
+        static const uint32_t ldspad = getenv("CLDN_HIP_FINISH_LDSPAD") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_LDSPAD")) : 0u;  // experiment: occupancy
+        hipLaunchKernelGGL((k_finish<256, 0>), dim3(L.n_chunks * splits), dim3(256), ldspad, L.stream, F);
+      }
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_finish");
+    }
+    if (L.events) (void)hipEventRecord(L.events[4], L.stream);
+    return CLDN_HIP_OK;
+  }
   hipLaunchKernelGGL(k_chunk_offsets<1024>, dim3(1), dim3(1024), 0, L.stream, L.segs, L.segs_per_chunk, L.n_chunks,
                      L.cloud_first_chunk, L.n_clouds, L.chunk_payload, L.chunk_dst, L.stream_offsets);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_chunk_offsets");

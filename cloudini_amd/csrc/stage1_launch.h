@@ -38,6 +38,12 @@ struct EncodeLaunch {
   // Only a launch hint: a fast section kernel that is not launched leaves its chunks to k_encode_sections.
   uint8_t mode_hint[kMaxAdaptive];
   uint8_t* fallback_flags;    // device [n_chunks * n_adaptive], zeroed per call: 1 = section written by a fast path
+  // k_finish (stage1_finish.h)
+  unsigned long long* fin_rec;     // device [n_chunks]: look-back records, tagged with fin_epoch
+  unsigned long long* fin_rec2;    // device [n_chunks]
+  unsigned long long* fin_anchor;  // device [n_chunks / 1024 + 1], zero at launch
+  uint32_t fin_epoch;              // != 0, changes with every call
+  uint32_t* fin_ticket;            // device, zero at launch
   uint8_t* out;               // device, framed streams
   uint64_t out_capacity;
   uint32_t* status;           // device status word
@@ -46,6 +52,8 @@ struct EncodeLaunch {
   // leaves one segment in the chunk's slot
   const PieceDesc* pieces;    // device [n_pieces] or NULL
   uint32_t n_pieces;          // multiple of 4
+  bool intra;                 // the piece kernel's workgroups place a chunk's regular stream contiguously (subs == 1)
+  unsigned long long* wgrec;  // device [n_chunks * 32]: their look-back records, tagged with fin_epoch
 };
 
 uint32_t stage1_piece_points(const DevPlan& plan, const uint8_t* points);        // piece kernel applies: points per piece, else 0

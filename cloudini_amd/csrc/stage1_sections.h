@@ -497,10 +497,11 @@ struct Pal32 {
   }
 };
 
-// ranks of values [i0, i0 + cnt) (cnt <= 32) packed BITS bits each into BITS dwords
+// ranks of values [i0, i0 + cnt) (cnt <= 32) packed BITS bits each into BITS dwords at `out` (any byte alignment: the
+// stores are unaligned dword / dwordx4 stores, which gfx950 performs natively)
 template <typename RawT, uint32_t BITS>
 __device__ __forceinline__ void pal32_pack(const Pal32<RawT>& p, const RawT* col, uint32_t i0, uint32_t n, uint32_t cnt,
-                                           uint32_t* out) {
+                                           uint8_t* out) {
   using P = Pal32<RawT>;
   uint32_t w[BITS];
 #pragma unroll
@@ -527,48 +528,44 @@ __device__ __forceinline__ void pal32_pack(const Pal32<RawT>& p, const RawT* col
       if ((bit & 31u) + BITS > 32u) w[(bit >> 5) + 1u] |= x >> (32u - (bit & 31u));
     }
   }
-  const uint32_t n_dw = (cnt * BITS + 31u) >> 5;  // a short tail thread stops at its last partial dword
+  // byte-exact: the chunk's last (short) group ends with the section's last byte -- in the final stream the next byte
+  // belongs to the following chunk
+  const uint32_t n_bytes = (cnt * BITS + 7u) >> 3;
+  const uint32_t n_dw = n_bytes >> 2;
   if (n_dw == BITS && BITS % 4u == 0u) {
 #pragma unroll
-    for (uint32_t k = 0; k < BITS; k += 4u)
-      *reinterpret_cast<uint4*>(out + k) = make_uint4(w[k], w[k + 1u], w[k + 2u], w[k + 3u]);
+    for (uint32_t k = 0; k < BITS; k += 4u) {
+      const uint4 q = make_uint4(w[k], w[k + 1u], w[k + 2u], w[k + 3u]);
+      __builtin_memcpy(out + 4u * k, &q, 16);
+    }
   } else {
 #pragma unroll
-    for (uint32_t k = 0; k < BITS; ++k)
-      if (k < n_dw) out[k] = w[k];
+    for (uint32_t k = 0; k < BITS; ++k) {
+      if (k < n_dw) __builtin_memcpy(out + 4u * k, &w[k], 4);
+      else if (k == n_dw) {
+        for (uint32_t b = 0; b < (n_bytes & 3u); ++b) out[4u * k + b] = (uint8_t)(w[k] >> (8u * b));
+      }
+    }
   }
 }
 
-// T threads: 1024 (one bitmap word and 32 values per thread) or 512 (two of each: four workgroups fit a CU, so that
-// up to 1024 chunks are in flight at once instead of 512)
-template <typename RawT, int T = kS2Threads>
-__global__ __launch_bounds__(T) void k_section_palette32(
-    const DevPlan plan, const SectionFields fl, const ChunkDesc* __restrict__ chunks, const ColumnPtrs cols,
-    const uint8_t* __restrict__ modes, uint8_t* __restrict__ slots, uint64_t slot_stride, uint64_t reg_stride,
-    Seg* __restrict__ segs, uint32_t segs_per_chunk, uint32_t subs, uint8_t* __restrict__ handled_flags) {
-  static_assert(sizeof(RawT) == 2 || sizeof(RawT) == 4, "16- or 32-bit keys");
-  static_assert(kS2Threads * 32u == 32768u && (T == kS2Threads || 2 * T == kS2Threads), "bitmap words per thread: 1 or 2");
-  constexpr uint32_t WPT = kS2Threads / T;  // bitmap words (and groups of 32 values) per thread
+// ---- the steps of the palette section, shared by k_section_palette32 (section into the chunk's slot) and k_finish
+// (stage1_finish.h: section straight to its final place). T threads: 1024 (one bitmap word and 32 values per thread) or
+// 512 (two of each: four workgroups fit a CU, so that up to 1024 chunks are in flight at once instead of 512).
+
+// clear + seed + pass 1: afterwards the table holds every distinct value with its first index and misc[0] = their
+// number -- unless it returns false (more than kS2PalCapacity distinct values: pal32_slow_* take over)
+template <typename RawT, int T>
+__device__ __forceinline__ bool pal32_build(const Pal32<RawT>& p, const RawT* col, uint32_t n) {
   using P = Pal32<RawT>;
   using Word = typename P::Word;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const uint32_t c = blockIdx.x;
-  const uint32_t a = fl.a[blockIdx.y];  // one launch covers every field of this kernel's type (grid.y)
-  const ChunkDesc cd = chunks[c];
-  if (modes[cd.cloud * plan.n_adaptive + a] != 1u) return;
-  const uint32_t n = cd.n_points;
-  const RawT* col = reinterpret_cast<const RawT*>(cols.p[a]) + cd.first_point;
-  const uint32_t sec_off = (uint32_t)reg_stride + a * kSectionStride;
-  uint8_t* dst = slots + (size_t)c * slot_stride + sec_off;
-  const P p(smem);
+  constexpr uint32_t WPT = kS2Threads / T;
   const uint32_t tid = threadIdx.x;
-
   for (uint32_t s = tid; s < kS2PalSlots; s += T) p.tab[s] = P::kFree;
 #pragma unroll
   for (uint32_t w = 0; w < WPT; ++w) p.bitmap[w * T + tid] = 0u;
   if (tid < 4u) p.misc[tid] = 0u;
   __syncthreads();
-
   // seed
 #pragma unroll
   for (uint32_t r = 0; r < 4096u / T; ++r) {
@@ -579,7 +576,6 @@ __global__ __launch_bounds__(T) void k_section_palette32(
     }
   }
   __syncthreads();
-
   // pass 1
   for (uint32_t s = 0; s < 4096u / T; ++s) {
     const uint32_t i0 = (s * T + tid) * 8u;
@@ -597,9 +593,17 @@ __global__ __launch_bounds__(T) void k_section_palette32(
     }
   }
   __syncthreads();
-  if (p.misc[1] != 0u || p.misc[0] > kS2PalCapacity) return;  // uniform: the general kernel encodes this chunk
+  return p.misc[1] == 0u && p.misc[0] <= kS2PalCapacity;  // uniform
+}
 
-  // ranks in first-occurrence order
+// first occurrences -> bitmap, prefix; ranks into the table words; palette values to vals_out (any alignment).
+// Returns the number of distinct values.
+template <typename RawT, int T>
+__device__ __forceinline__ uint32_t pal32_rank(const Pal32<RawT>& p, uint8_t* vals_out) {
+  using P = Pal32<RawT>;
+  using Word = typename P::Word;
+  constexpr uint32_t WPT = kS2Threads / T;
+  const uint32_t tid = threadIdx.x;
 #pragma unroll
   for (uint32_t q = 0; q < kS2PalSlots / T; ++q) {
     const Word w = p.tab[q * T + tid];
@@ -631,49 +635,222 @@ __global__ __launch_bounds__(T) void k_section_palette32(
       const uint32_t rk = p.prefix[f >> 5] + (uint32_t)__builtin_popcount(p.bitmap[f >> 5] & ((1u << (f & 31u)) - 1u));
       p.tab[q * T + tid] = (w & ~(Word)0xffffu) | rk;
       const uint32_t val = P::key_of(w);
-      uint8_t* out = dst + 3u + (size_t)rk * sizeof(RawT);  // palette value rk behind the 3-byte header
+      uint8_t* out = vals_out + (size_t)rk * sizeof(RawT);  // palette value rk
 #pragma unroll
       for (uint32_t b = 0; b < sizeof(RawT); ++b) out[b] = (uint8_t)(val >> (8u * b));
     }
   }
-  if (tid == 0) {
-    dst[0] = 1u;
-    dst[1] = (uint8_t)(U & 0xffu);
-    dst[2] = (uint8_t)((U >> 8) & 0xffu);  // static_cast<uint16_t>(palette.size()), v5_codec.cpp:464
-  }
   __syncthreads();
+  return U;
+}
 
-  // pass 3
-  const uint32_t bits = palette_bits(U);
+// pass 3: thread t packs the ranks of its groups of 32 values into `bits` dwords each (appendBitpackedIndexes,
+// v5_codec.cpp:209-227); idx_out = where the packed indexes begin (any alignment)
+template <typename RawT, int T>
+__device__ __forceinline__ void pal32_pack_chunk(const Pal32<RawT>& p, const RawT* col, uint32_t n, uint32_t bits,
+                                                 uint8_t* idx_out) {
+  constexpr uint32_t WPT = kS2Threads / T;
+  const uint32_t tid = threadIdx.x;
   for (uint32_t g = 0; g < WPT; ++g) {
     const uint32_t grp = g * T + tid;  // group of 32 values
     const uint32_t i0 = grp * 32u;
     const uint32_t cnt = i0 < n ? min(32u, n - i0) : 0u;
     if (bits != 0u && cnt != 0u) {
-      uint32_t* idx_out = reinterpret_cast<uint32_t*>(dst + kPaletteIndexOffset) + (size_t)grp * bits;
+      uint8_t* o = idx_out + (size_t)grp * bits * 4u;
       switch (bits) {  // block-uniform
-        case 1: pal32_pack<RawT, 1>(p, col, i0, n, cnt, idx_out); break;
-        case 2: pal32_pack<RawT, 2>(p, col, i0, n, cnt, idx_out); break;
-        case 3: pal32_pack<RawT, 3>(p, col, i0, n, cnt, idx_out); break;
-        case 4: pal32_pack<RawT, 4>(p, col, i0, n, cnt, idx_out); break;
-        case 5: pal32_pack<RawT, 5>(p, col, i0, n, cnt, idx_out); break;
-        case 6: pal32_pack<RawT, 6>(p, col, i0, n, cnt, idx_out); break;
-        case 7: pal32_pack<RawT, 7>(p, col, i0, n, cnt, idx_out); break;
-        case 8: pal32_pack<RawT, 8>(p, col, i0, n, cnt, idx_out); break;
-        case 9: pal32_pack<RawT, 9>(p, col, i0, n, cnt, idx_out); break;
-        case 10: pal32_pack<RawT, 10>(p, col, i0, n, cnt, idx_out); break;
-        case 11: pal32_pack<RawT, 11>(p, col, i0, n, cnt, idx_out); break;
-        default: pal32_pack<RawT, 12>(p, col, i0, n, cnt, idx_out); break;  // U <= kS2PalCapacity = 3072: <= 12 bits
+        case 1: pal32_pack<RawT, 1>(p, col, i0, n, cnt, o); break;
+        case 2: pal32_pack<RawT, 2>(p, col, i0, n, cnt, o); break;
+        case 3: pal32_pack<RawT, 3>(p, col, i0, n, cnt, o); break;
+        case 4: pal32_pack<RawT, 4>(p, col, i0, n, cnt, o); break;
+        case 5: pal32_pack<RawT, 5>(p, col, i0, n, cnt, o); break;
+        case 6: pal32_pack<RawT, 6>(p, col, i0, n, cnt, o); break;
+        case 7: pal32_pack<RawT, 7>(p, col, i0, n, cnt, o); break;
+        case 8: pal32_pack<RawT, 8>(p, col, i0, n, cnt, o); break;
+        case 9: pal32_pack<RawT, 9>(p, col, i0, n, cnt, o); break;
+        case 10: pal32_pack<RawT, 10>(p, col, i0, n, cnt, o); break;
+        case 11: pal32_pack<RawT, 11>(p, col, i0, n, cnt, o); break;
+        default: pal32_pack<RawT, 12>(p, col, i0, n, cnt, o); break;  // U <= kS2PalCapacity = 3072: <= 12 bits
       }
     }
   }
+}
+
+// ---- chunks with more than kS2PalCapacity distinct values (up to 32768): the values are split into P partitions, one
+// table pass per partition finds the first occurrence of every value of that partition, and the first-occurrence index
+// of EVERY value goes to a scratch column in global memory (`first`, n entries). Ranks then come from the bitmap of
+// first occurrences alone: rank(i) = first occurrences below first[i]. Slow (P + 2 sweeps over the chunk), exact.
+// 16-bit keys are partitioned by key range (32 ranges of 2048 keys can never overflow a table); 32-bit keys by a hash,
+// P grows until every partition fits (kPalSlowMaxParts: beyond it the call fails loudly with ST_PALETTE_FULL).
+constexpr uint32_t kPalSlowMaxParts = 4096;
+
+template <typename RawT>
+__device__ __forceinline__ uint32_t pal32_part(uint32_t v, uint32_t parts) {
+  if (sizeof(RawT) == 2) return (v * parts) >> 16;
+  uint32_t h = v * 0x85ebca6bu;
+  h ^= h >> 15;
+  h *= 0xc2b2ae35u;
+  return (uint32_t)(((uint64_t)h * parts) >> 32);
+}
+
+// fills first[0..n); returns false (status raised) if the values could not be partitioned
+template <typename RawT, int T>
+__device__ __forceinline__ bool pal32_slow_first(const Pal32<RawT> p, const RawT* col, uint32_t n, uint16_t* first, uint32_t* status) {
+  using P = Pal32<RawT>;
+  const uint32_t tid = threadIdx.x;
+  uint32_t parts = 32u;
+  for (;;) {
+    bool ok = true;
+    for (uint32_t part = 0; part < parts && ok; ++part) {
+      __syncthreads();
+      for (uint32_t s = tid; s < kS2PalSlots; s += T) p.tab[s] = P::kFree;
+      if (tid < 4u) p.misc[tid] = 0u;
+      __syncthreads();
+      for (uint32_t i = tid; i < n; i += T) {
+        const uint32_t v = (uint32_t)col[i];
+        if (pal32_part<RawT>(v, parts) == part) p.insert(v, i, p.tab[P::home(v)]);
+      }
+      __syncthreads();
+      ok = p.misc[1] == 0u && p.misc[0] <= kS2PalCapacity;  // uniform
+      if (!ok) break;
+      for (uint32_t i = tid; i < n; i += T) {
+        const uint32_t v = (uint32_t)col[i];
+        if (pal32_part<RawT>(v, parts) == part) {
+          uint32_t slot = P::home(v);
+          typename P::Word w = p.tab[slot];
+          while (w == P::kFree || P::key_of(w) != v) {
+            slot = (slot + 1u) & (kS2PalSlots - 1u);
+            w = p.tab[slot];
+          }
+          first[i] = (uint16_t)P::low_of(w);
+        }
+      }
+    }
+    if (ok) break;
+    if (sizeof(RawT) == 2 || parts >= kPalSlowMaxParts) {  // (16-bit keys cannot get here)
+      if (tid == 0) atomicOr(status, (uint32_t)ST_PALETTE_FULL);
+      return false;
+    }
+    parts *= 4u;
+  }
+  __threadfence_block();
+  __syncthreads();
+  return true;
+}
+
+// bitmap / prefix from first[]; returns U
+template <typename RawT, int T>
+__device__ __forceinline__ uint32_t pal32_slow_rank(const Pal32<RawT> p, const RawT* col, uint32_t n, const uint16_t* first,
+                                    uint8_t* vals_out) {
+  constexpr uint32_t WPT = kS2Threads / T;
+  const uint32_t tid = threadIdx.x;
+  uint32_t U;
+  uint32_t pc[WPT], bm[WPT], mine = 0u;
+#pragma unroll
+  for (uint32_t w = 0; w < WPT; ++w) {
+    const uint32_t word = WPT * tid + w;
+    uint32_t m = 0u;
+    for (uint32_t b = 0; b < 32u; ++b) {
+      const uint32_t i = word * 32u + b;
+      if (i < n && first[i] == (uint16_t)i) m |= 1u << b;
+    }
+    bm[w] = m;
+    p.bitmap[word] = m;
+    pc[w] = (uint32_t)__builtin_popcount(m);
+    mine += pc[w];
+  }
+  uint32_t run = block_exclusive_scan<T>(mine, p.wtot, &U);
+#pragma unroll
+  for (uint32_t w = 0; w < WPT; ++w) {
+    const uint32_t word = WPT * tid + w;
+    p.prefix[word] = run;
+    uint32_t m = bm[w];
+    uint32_t rk = run;
+    while (m) {
+      const uint32_t b = (uint32_t)__builtin_ctz(m);
+      m &= m - 1u;
+      const uint64_t val = (uint64_t)col[word * 32u + b];
+      uint8_t* out = vals_out + (size_t)rk * sizeof(RawT);
+#pragma unroll
+      for (uint32_t k = 0; k < sizeof(RawT); ++k) out[k] = (uint8_t)(val >> (8u * k));
+      ++rk;
+    }
+    run += pc[w];
+  }
+  __syncthreads();
+  return U;
+}
+
+template <typename RawT, int T>
+__device__ __forceinline__ void pal32_slow_pack(const Pal32<RawT> p, uint32_t n, uint32_t bits, const uint16_t* first, uint8_t* idx_out) {
+  constexpr uint32_t WPT = kS2Threads / T;
+  const uint32_t tid = threadIdx.x;
+  if (bits == 0u) return;
+  for (uint32_t g = 0; g < WPT; ++g) {
+    const uint32_t grp = g * T + tid;
+    const uint32_t i0 = grp * 32u;
+    if (i0 >= n) continue;
+    const uint32_t cnt = min(32u, n - i0);
+    uint8_t* o = idx_out + (size_t)grp * bits * 4u;
+    uint64_t scratch = 0u;
+    uint32_t held = 0u, w = 0u;
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t f = first[i0 + j];
+      const uint32_t rk = p.prefix[f >> 5] + (uint32_t)__builtin_popcount(p.bitmap[f >> 5] & ((1u << (f & 31u)) - 1u));
+      scratch |= ((uint64_t)rk) << held;
+      held += bits;
+      if (held >= 32u) {
+        const uint32_t d = (uint32_t)scratch;
+        __builtin_memcpy(o + 4u * w, &d, 4);
+        ++w;
+        scratch >>= 32;
+        held -= 32u;
+      }
+    }
+    for (uint32_t b = 0; b < ((held + 7u) >> 3); ++b) o[4u * w + b] = (uint8_t)(scratch >> (8u * b));  // byte-exact end
+  }
+}
+
+template <typename RawT, int T = kS2Threads>
+__global__ __launch_bounds__(T, (T == 512 ? 8 : 4)) __attribute__((amdgpu_num_sgpr(80))) void k_section_palette32(
+    const DevPlan plan, const SectionFields fl, const ChunkDesc* __restrict__ chunks, const ColumnPtrs cols,
+    const uint8_t* __restrict__ modes, uint8_t* __restrict__ slots, uint64_t slot_stride, uint64_t reg_stride,
+    Seg* __restrict__ segs, uint32_t segs_per_chunk, uint32_t subs, uint8_t* __restrict__ handled_flags,
+    const ColumnPtrs first_cols, uint32_t* __restrict__ status) {
+  static_assert(sizeof(RawT) == 2 || sizeof(RawT) == 4, "16- or 32-bit keys");
+  static_assert(kS2Threads * 32u == 32768u && (T == kS2Threads || 2 * T == kS2Threads), "bitmap words per thread: 1 or 2");
+  using P = Pal32<RawT>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t c = blockIdx.x;
+  const uint32_t a = fl.a[blockIdx.y];  // one launch covers every field of this kernel's type (grid.y)
+  const ChunkDesc cd = chunks[c];
+  if (modes[cd.cloud * plan.n_adaptive + a] != 1u) return;
+  const uint32_t n = cd.n_points;
+  const RawT* col = reinterpret_cast<const RawT*>(cols.p[a]) + cd.first_point;
+  const uint32_t sec_off = (uint32_t)reg_stride + a * kSectionStride;
+  uint8_t* dst = slots + (size_t)c * slot_stride + sec_off;
+  const P p(smem);
+  const uint32_t tid = threadIdx.x;
+
+  uint32_t U;
+  if (pal32_build<RawT, T>(p, col, n)) {
+    U = pal32_rank<RawT, T>(p, dst + 3u);
+    pal32_pack_chunk<RawT, T>(p, col, n, palette_bits(U), dst + kPaletteIndexOffset);
+  } else {
+    uint16_t* first = reinterpret_cast<uint16_t*>(first_cols.p[a]) + cd.first_point;
+    if (!pal32_slow_first<RawT, T>(p, col, n, first, status)) return;
+    U = pal32_slow_rank<RawT, T>(p, col, n, first, dst + 3u);
+    pal32_slow_pack<RawT, T>(p, n, palette_bits(U), first, dst + kPaletteIndexOffset);
+  }
   if (tid == 0) {
+    dst[0] = 1u;
+    dst[1] = (uint8_t)(U & 0xffu);
+    dst[2] = (uint8_t)((U >> 8) & 0xffu);  // static_cast<uint16_t>(palette.size()), v5_codec.cpp:464
     Seg s;
     s.off = sec_off;
     s.size = 3u + U * (uint32_t)sizeof(RawT);
     segs[(size_t)c * segs_per_chunk + subs + 2u * a] = s;
     s.off = sec_off + kPaletteIndexOffset;
-    s.size = (bits * n + 7u) >> 3;
+    s.size = (palette_bits(U) * n + 7u) >> 3;
     segs[(size_t)c * segs_per_chunk + subs + 1u + 2u * a] = s;
     handled_flags[(size_t)c * plan.n_adaptive + a] = 1u;
   }
