@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0 (see README/DESIGN.md for the field meanings):
   cpu_baseline     the real reference (oracle/_ref, kind "reference") or the C port (kind "port") timed on the
                    host cores on a bounded sample of the same workload (rank 0, N=1 only)
   e2e              PCIe-inclusive and single-cloud figures (never `value`), each next to the reference on the host
+  bit_exact        the streams of the timed batch equal the checker's (compiled reference, else the C port), byte for byte
 """
 from __future__ import annotations
 
@@ -293,6 +294,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic clouds generated (tiled to --clouds)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--e2e-seconds", type=float, default=6.0, help="budget of the e2e legs (0 = skip; N=1 only)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false",
+                    help="skip the bit-exactness check of the timed batch's streams (outside the timed region)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -477,6 +480,29 @@ def main():
                   "ms_per_step_max": float(max(dec_blocks)) * 1e3,
                   "HBM_GBps": (total_out + points_local * step) / (dec_ms * 1e-3) / 1e9,
                   "chunks_parallel_regular/parallel_sections/serial/serial_sections": list(dec_stats)}
+    # "plus bit-exactness flag vs oracle" -- the streams the TIMED batch left in HBM, compared
+    # outside the timed region with the compiled reference (oracle/_ref) or, where that is absent, the C port: every
+    # distinct cloud against the checker, every tiled copy against its first occurrence
+    bit_exact = None
+    if rank == 0 and points_local and args.shard == "clouds" and args.verify:
+        from oracle import binding
+        try:
+            checker, checker_kind = binding.RefLib(), "reference"
+        except (OSError, FileNotFoundError):
+            checker, checker_kind = binding.Oracle(), "port"
+        ok, compared = True, 0
+        first_of = {}
+        for k in range(n_clouds):
+            j = (k + rank) % len(distinct)
+            got = d_out[int(offsets[k]):int(offsets[k + 1])]
+            if j not in first_of:
+                first_of[j] = got
+                want = checker.encode_stage1(info, distinct[j])
+                ok = ok and got.numel() == len(want) and bool(np.array_equal(got.cpu().numpy(), want))
+                compared += 1
+            else:
+                ok = ok and got.numel() == first_of[j].numel() and bool(torch.equal(got, first_of[j]))
+        bit_exact = {"ok": bool(ok), "checker": checker_kind, "clouds_vs_checker": compared, "clouds_vs_first_copy": n_clouds - compared}
     if dist is not None:
         dist.barrier()
 
@@ -552,13 +578,15 @@ def main():
                         "value_median": points_job / (float(np.median(blocks_ms)) * 1e-3) / 1e6},
             "input_MBps": points_job * step * args.steps / elapsed / 1e6,
             "job_stage1_bytes": job_bytes,
+            "bit_exact": bit_exact["ok"] if bit_exact else None,
+            "bit_exact_detail": bit_exact,
             "decode": decode,
             "stage1_bytes_per_point": out_bpp,
             "device_ms_per_step": {dominant: regular_ms, "sections": sections_ms,
                                    "offsets+compact": compact_ms, "all_kernels": device_ms},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "traffic_measured_in_run": False,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "read_only_GBps": points_local * step / (regular_ms * 1e-3) / 1e9,
                          "read_only_frac": points_local * step / (regular_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,

@@ -61,6 +61,12 @@ def lib() -> C.CDLL:
     L.cldn_amd_viz_preprocess.restype = C.c_int64
     L.cldn_amd_viz_preprocess.argtypes = [C.POINTER(_Info), u8p, C.c_uint64, u8p, C.c_uint64, C.POINTER(C.c_float),
                                           C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.cldn_amd_transcode_directory_on.restype = C.c_int64
+    L.cldn_amd_transcode_directory_on.argtypes = [C.c_char_p, C.c_char_p, C.c_float, C.c_uint8, C.c_int, C.c_uint32,
+                                                  C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_double)]
+    L.cldn_amd_decode_directory_on.restype = C.c_int64
+    L.cldn_amd_decode_directory_on.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.c_uint32,
+                                               C.POINTER(C.c_double)]
     L.cldn_amd_transcode_directory.restype = C.c_int64
     L.cldn_amd_transcode_directory.argtypes = [C.c_char_p, C.c_char_p, C.c_float, C.c_uint8, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
     L.cldn_amd_decode_directory.restype = C.c_int64
@@ -125,22 +131,32 @@ def set_stage2_threads(n: int) -> int:
     return int(lib().cldn_amd_set_stage2_threads(int(n)))
 
 
+def _device_list(devices):
+    if not devices:
+        return None, 0
+    arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+    return arr, len(devices)
+
+
 def transcode_directory(in_dir: str, out_dir: str, resolution: float = 0.001, compression_opt: int = 2,
-                        viz_lossy: bool = False, batch_messages: int = 64) -> dict:
+                        viz_lossy: bool = False, batch_messages: int = 64, devices=None) -> dict:
     """Batch transcoder (include/cloudini_amd/batch_transcoder.hpp): every CDR PointCloud2 file of in_dir ->
-    CompressedPointCloud2 file of the same name in out_dir. Returns the statistics."""
+    CompressedPointCloud2 file of the same name in out_dir. `devices`: GPUs to spread the batches over (one GPU stage per
+    entry; None = the current device). Returns the statistics."""
     st = (C.c_double * 8)()
-    _check(lib().cldn_amd_transcode_directory(in_dir.encode(), out_dir.encode(), resolution, compression_opt,
-                                              1 if viz_lossy else 0, batch_messages, st))
+    dv, nd = _device_list(devices)
+    _check(lib().cldn_amd_transcode_directory_on(in_dir.encode(), out_dir.encode(), resolution, compression_opt,
+                                                 1 if viz_lossy else 0, batch_messages, dv, nd, st))
     keys = ("messages", "points", "input_bytes", "output_bytes", "gpu_batches", "seconds_total", "seconds_gpu", "seconds_stage2")
     return dict(zip(keys, [float(x) for x in st]))
 
 
-def decode_directory(in_dir: str, out_dir: str, batch_messages: int = 64) -> dict:
+def decode_directory(in_dir: str, out_dir: str, batch_messages: int = 64, devices=None) -> dict:
     """The way back: every CDR CompressedPointCloud2 file of in_dir -> PointCloud2 file of the same name in out_dir
     (batched GPU decode). Returns the statistics."""
     st = (C.c_double * 8)()
-    _check(lib().cldn_amd_decode_directory(in_dir.encode(), out_dir.encode(), batch_messages, st))
+    dv, nd = _device_list(devices)
+    _check(lib().cldn_amd_decode_directory_on(in_dir.encode(), out_dir.encode(), batch_messages, dv, nd, st))
     keys = ("messages", "points", "input_bytes", "output_bytes", "gpu_batches", "seconds_total", "seconds_gpu", "seconds_stage2")
     return dict(zip(keys, [float(x) for x in st]))
 

@@ -212,7 +212,7 @@ int cldn_hip_device_count(void) {
 
 void* cldn_hip_host_alloc(size_t bytes) {
   void* p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {  // page-locked for every device
     (void)hipGetLastError();
     return nullptr;
   }
@@ -228,6 +228,13 @@ int cldn_hip_current_device(void) {
   if (e != hipSuccess)
     return fail(e == hipErrorNoDevice ? CLDN_HIP_ERR_NO_DEVICE : CLDN_HIP_ERR_DEVICE, "hipGetDevice: %s", hipGetErrorString(e));
   return d;
+}
+
+int cldn_hip_set_current_device(int device) {
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess)
+    return fail(e == hipErrorNoDevice ? CLDN_HIP_ERR_NO_DEVICE : CLDN_HIP_ERR_DEVICE, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+  return CLDN_HIP_OK;
 }
 
 int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint32_t point_step, uint8_t version,
@@ -966,6 +973,7 @@ int cldn_hip_viz_preprocess(cldn_hip_codec_t* c, const void* points, int points_
   }
   uint8_t* d_out = (uint8_t*)out;
   if (out_loc == CLDN_HIP_HOST) {
+    c->pending_total = 0;  // the device output buffer is reused: a deferred encode output waiting in it is gone
     if ((rc = c->d_out.ensure((size_t)bytes)) != CLDN_HIP_OK) return rc;
     d_out = (uint8_t*)c->d_out.p;
   }
@@ -1150,6 +1158,50 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (st & ST_CORRUPT) return fail(CLDN_HIP_ERR_CORRUPT, "malformed stage-1 stream (truncated, bad chunk size, bad mode or trailing bytes)");
   if (need) HIP_TRY(hipMemcpy(points_out, d_outp, (size_t)need, hipMemcpyDeviceToHost));
+  return CLDN_HIP_OK;
+}
+
+int cldn_hip_decode_stage1_unframed(cldn_hip_codec_t* c, const void* payload, uint64_t size, int payload_loc,
+                                    void* points_out, uint64_t out_capacity, int out_loc) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if ((payload_loc != CLDN_HIP_HOST && payload_loc != CLDN_HIP_DEVICE) || (out_loc != CLDN_HIP_HOST && out_loc != CLDN_HIP_DEVICE))
+    return fail(CLDN_HIP_ERR_ARG, "invalid memory location tag");
+  if (c->plan.uses_v5) return fail(CLDN_HIP_ERR_ARG, "unframed streams (wire version 2) never use the V5 codec");
+  if (size == 0) return CLDN_HIP_OK;
+  if (!payload) return fail(CLDN_HIP_ERR_ARG, "payload is NULL");
+  if (size > 0xffffffffull) return fail(CLDN_HIP_ERR_UNSUPPORTED, "unframed payload of more than 4 GiB");
+  ENTER_DEVICE(c->device);
+  const uint32_t step = c->plan.dev.point_step;
+  const uint64_t cap_points = std::min<uint64_t>(out_capacity / step, 0xffffffffull);
+  int rc;
+  if ((rc = c->d_status.ensure(256)) != CLDN_HIP_OK) return rc;
+  HIP_TRY(hipMemsetAsync(c->d_status.p, 0, 256, c->stream));
+  if ((rc = c->d_dec_meta.ensure(256)) != CLDN_HIP_OK) return rc;
+  const uint8_t* d_payload = (const uint8_t*)payload;
+  if (payload_loc == CLDN_HIP_HOST) {
+    if ((rc = c->d_in.ensure((size_t)size)) != CLDN_HIP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_in.p, payload, (size_t)size, hipMemcpyHostToDevice, c->stream));
+    d_payload = (const uint8_t*)c->d_in.p;
+  }
+  uint8_t* d_outp = (uint8_t*)points_out;
+  const uint64_t out_bytes = cap_points * step;
+  if (out_loc == CLDN_HIP_HOST) {
+    c->pending_total = 0;
+    if ((rc = c->d_out.ensure((size_t)std::max<uint64_t>(1, out_bytes))) != CLDN_HIP_OK) return rc;
+    d_outp = (uint8_t*)c->d_out.p;
+    // how many points the stream holds is not known beforehand: every byte the decoder does not write keeps the caller's
+    // content (uncovered bytes of a point, and all points behind the last decoded one)
+    if (out_bytes) HIP_TRY(hipMemcpyAsync(d_outp, points_out, (size_t)out_bytes, hipMemcpyHostToDevice, c->stream));
+  }
+  if ((rc = stage1_launch_decode_unframed(c->plan.dev, c->stream, d_payload, (uint32_t)size, (uint32_t)cap_points, c->d_dec_meta.p,
+                                          d_outp, (uint32_t*)c->d_status.p)) != CLDN_HIP_OK)
+    return rc;
+  if (out_loc == CLDN_HIP_DEVICE) return CLDN_HIP_OK;
+  uint32_t st = 0;
+  HIP_TRY(hipMemcpyAsync(&st, c->d_status.p, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (st & ST_CORRUPT) return fail(CLDN_HIP_ERR_CORRUPT, "malformed stage-1 stream (truncated point, or more points than the output holds)");
+  if (out_bytes) HIP_TRY(hipMemcpy(points_out, d_outp, (size_t)out_bytes, hipMemcpyDeviceToHost));
   return CLDN_HIP_OK;
 }
 

@@ -141,6 +141,7 @@ struct Run {                       // messages [first, first + count) share a sc
 };
 
 struct Batch {
+  uint64_t seq = 0;                // position in the input (the writer restores this order)
   std::vector<Message> in;
   std::vector<Parsed> parsed;
   std::vector<Run> runs;
@@ -159,8 +160,17 @@ void gpuPhase(Batch& b, const TranscodeOptions& opt, TranscodeStats* stats) {
     if (opt.viz_lossy) cloudini_ros::applyVizLossyPreprocessing(p.pc);
     p.info = cloudini_ros::toEncodingInfo(p.pc);
     p.info.compression_opt = opt.compression;
-    p.points = p.info.point_step ? p.pc.data.size() / p.info.point_step : 0;
-    p.key = schemaKey(p.info);
+    // the reference's order, message by message (src/ros_msg_utils.cpp:178-190, src/cloudini.cpp:525-531): an empty
+    // cloud becomes an empty message whatever its schema says; otherwise point_step 0 and a data size that is not a
+    // multiple of point_step are errors (never a silently shortened cloud)
+    p.points = 0;
+    if (!p.pc.data.empty()) {
+      if (p.info.point_step == 0) throw std::runtime_error("convertPointCloud2ToCompressedCloud: point_step cannot be 0");
+      if (p.pc.data.size() % p.info.point_step != 0)
+        throw std::runtime_error("Input cloud_data size is not a multiple of point_step");
+      p.points = p.pc.data.size() / p.info.point_step;
+    }
+    p.key = p.pc.data.empty() ? std::string() : schemaKey(p.info);  // empty clouds: a run of their own, no GPU call
     if (stats) {
       stats->messages += 1;
       stats->points += p.points;
@@ -176,7 +186,12 @@ void gpuPhase(Batch& b, const TranscodeOptions& opt, TranscodeStats* stats) {
     run.first = r0;
     run.count = static_cast<uint32_t>(r1 - r0);
     const Cloudini::EncodingInfo& info0 = b.parsed[r0].info;
-    if (info0.point_step == 0) throw std::runtime_error("convertPointCloud2ToCompressedCloud: point_step cannot be 0");
+    if (b.parsed[r0].key.empty()) {  // a run of empty clouds: nothing to encode (their schema may not even be one)
+      run.offsets.assign(run.count + 1, 0);
+      run.chunk_sizes.clear();
+      r0 = r1;
+      continue;
+    }
     std::vector<const uint8_t*> ptrs(run.count);
     std::vector<uint64_t> pts(run.count);
     for (uint32_t k = 0; k < run.count; ++k) {
@@ -287,6 +302,15 @@ void stage2Phase(Batch& b, const TranscodeOptions& opt, TranscodeStats* stats) {
   if (stats) stats->seconds_stage2 += since(t_s2);
 }
 
+// width * height * point_step of a message, checked: a product that wraps, or a cloud beyond the u32 length field of
+// the CDR byte sequence, is an error (the reference would try to allocate it, src/ros_msg_utils.cpp:150-153)
+uint64_t messageCloudBytes(uint32_t width, uint32_t height, uint32_t point_step) {
+  uint64_t bytes = 0;
+  if (__builtin_mul_overflow(uint64_t(width) * height, uint64_t(point_step), &bytes) || bytes > 0xffffffffull)
+    throw std::runtime_error("CompressedPointCloud2: width * height * point_step does not fit a PointCloud2 message");
+  return bytes;
+}
+
 // ---- the way back: CompressedPointCloud2 -> PointCloud2 ---------------------------------------------------------------
 
 // per message: CDR parse + Cloudini header; per schema run: stage 2 undone on the host pool, ONE batched GPU decode
@@ -298,15 +322,19 @@ void decodeGpuPhase(Batch& b, TranscodeStats* stats) {
   for (size_t i = 0; i < n; ++i) {
     Parsed& p = b.parsed[i];
     p.pc = cloudini_ros::getDeserializedPointCloudMessage(Cloudini::ConstBufferView(b.in[i].bytes.data(), b.in[i].bytes.size()));
-    const uint64_t cloud_bytes = uint64_t(p.pc.width) * p.pc.height * p.pc.point_step;
+    // header values are not trusted: width * height * point_step must not wrap 64 bits, and the decoded cloud has to fit
+    // the u32 length of the CDR byte sequence it goes into
+    const uint64_t cloud_bytes = messageCloudBytes(p.pc.width, p.pc.height, p.pc.point_step);
     p.points = 0;
     p.key.clear();
     if (cloud_bytes != 0) {
       body[i] = p.pc.data;
       p.info = Cloudini::DecodeHeader(body[i]);
       const uint64_t pts = uint64_t(p.info.width) * p.info.height;
+      uint64_t need = 0;
       // what the decoder would check (src/cloudini.cpp:632-635), against the size the message announces
-      if (pts * p.info.point_step > cloud_bytes) throw std::runtime_error("Output buffer is too small to hold the decoded data");
+      if (__builtin_mul_overflow(pts, uint64_t(p.info.point_step), &need) || need > cloud_bytes)
+        throw std::runtime_error("Output buffer is too small to hold the decoded data");
       p.points = pts;
       // batchable only when the message's own geometry is the header's (always, for streams this library or the
       // reference wrote); anything else takes the single-message path in the wrap phase
@@ -397,7 +425,7 @@ void decodeWrapPhase(Batch& b, TranscodeStats* stats) {
   for (size_t i = 0; i < n; ++i) {
     const Parsed& p = b.parsed[i];
     std::vector<uint8_t>& msg = b.out[i];
-    const size_t cloud_bytes = size_t(p.pc.width) * p.pc.height * p.pc.point_step;
+    const size_t cloud_bytes = messageCloudBytes(p.pc.width, p.pc.height, p.pc.point_step);
     if (cloud_bytes != 0 && !data_of[i]) {  // geometry of the message and of its Cloudini header differ: one by one
       cloudini_ros::convertCompressedCloudToPointCloud2(p.pc, msg);
     } else {
@@ -443,52 +471,107 @@ void transcodeBatch(const std::vector<Message>& in, const TranscodeOptions& opt,
 TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, const TranscodeOptions& opt) {
   TranscodeStats stats, stats2;
   const auto t0 = Clock::now();
-  constexpr size_t kBatchesInFlight = 3;
+  // GPU workers: one thread per entry of options.devices (the same device may appear more than once), each with its own
+  // pooled codecs (the pool key carries the device, host/cloudini.cpp); batches go to whichever worker is free and are put
+  // back into input order in front of the writer
+  std::vector<int> devices = opt.devices;
+  if (devices.empty()) devices.push_back(-1);  // -1: the calling thread's current device
+  const int caller_device = cldn_hip_current_device();
+  for (int& d : devices)
+    if (d < 0) d = caller_device;
+  const int n_devices = cldn_hip_device_count();
+  for (int d : devices)
+    if (d < 0 || d >= n_devices) throw std::runtime_error("transcodePointClouds: device " + std::to_string(d) + " does not exist");
+  const size_t n_workers = devices.size();
+  const size_t batches_in_flight = 2 * n_workers + 1;
   std::vector<std::unique_ptr<Batch>> storage;
-  for (size_t i = 0; i < kBatchesInFlight; ++i) storage.emplace_back(new Batch());
-  BoundedQueue<Batch*> free_q(kBatchesInFlight), to_gpu(kBatchesInFlight), to_stage2(kBatchesInFlight), to_write(kBatchesInFlight);
+  for (size_t i = 0; i < batches_in_flight; ++i) storage.emplace_back(new Batch());
+  BoundedQueue<Batch*> free_q(batches_in_flight), to_gpu(batches_in_flight), to_stage2(batches_in_flight), to_write(batches_in_flight);
   for (auto& b : storage) free_q.push(b.get());
-  // every error is written by one thread and rethrown behind the joins; the flags are what the other threads look at
-  std::exception_ptr reader_error, stage2_error, writer_error, gpu_error;
-  std::atomic<bool> stage2_failed{false};
+  // every error is written by one thread and rethrown behind the joins; `failed` is what the other threads look at: after
+  // the first error nothing more is read, encoded or written (messages already written stay in the sink: the output of
+  // a failed run is a prefix of the input)
+  std::exception_ptr reader_error, stage2_error, writer_error;
+  std::vector<std::exception_ptr> gpu_error(n_workers);
+  std::atomic<bool> failed{false};
   const size_t batch = std::max<size_t>(1, opt.batch_messages);
 
   std::thread reader([&] {
     try {
       Batch* b = nullptr;
       size_t used = 0;
+      uint64_t seq = 0;
       for (;;) {
         if (!b) {
           if (!free_q.pop(b)) break;
           used = 0;
         }
+        if (failed.load()) break;
         if (b->in.size() <= used) b->in.emplace_back();
         if (!source.next(b->in[used])) break;  // the source refills the Message (and reuses its page-locked capacity)
         if (++used == batch) {
           b->in.resize(used);
+          b->seq = seq++;
           to_gpu.push(b);
           b = nullptr;
         }
       }
-      if (b && used) {
+      if (b && used && !failed.load()) {
         b->in.resize(used);
+        b->seq = seq++;
         to_gpu.push(b);
       }
     } catch (...) {
       reader_error = std::current_exception();
+      failed.store(true);
     }
     to_gpu.close();
   });
+  std::mutex stats_mutex;
+  std::atomic<size_t> gpu_workers_left{n_workers};
+  std::vector<std::thread> gpu_workers;
+  for (size_t w = 0; w < n_workers; ++w) {
+    gpu_workers.emplace_back([&, w] {
+      TranscodeStats mine;
+      Batch* b = nullptr;
+      bool device_set = false;
+      while (to_gpu.pop(b)) {
+        if (!failed.load()) {
+          try {
+            if (!device_set) {
+              if (cldn_hip_set_current_device(devices[w]) != CLDN_HIP_OK) throw std::runtime_error(cldn_hip_last_error());
+              device_set = true;
+            }
+            if (opt.decode) decodeGpuPhase(*b, &mine);
+            else gpuPhase(*b, opt, &mine);
+          } catch (...) {
+            gpu_error[w] = std::current_exception();
+            failed.store(true);
+          }
+        }
+        to_stage2.push(b);  // failed batches travel on (nobody touches them) so that they return to the reader
+      }
+      {
+        std::lock_guard<std::mutex> lock(stats_mutex);
+        stats.messages += mine.messages;
+        stats.points += mine.points;
+        stats.input_bytes += mine.input_bytes;
+        stats.gpu_batches += mine.gpu_batches;
+        stats.seconds_gpu += mine.seconds_gpu;
+      }
+      if (gpu_workers_left.fetch_sub(1) == 1) to_stage2.close();
+    });
+  }
   std::thread stage2([&] {
     Batch* b = nullptr;
     while (to_stage2.pop(b)) {
-      if (!stage2_failed.load()) {
+      if (!failed.load()) {
         try {
           if (opt.decode) decodeWrapPhase(*b, &stats2);
           else stage2Phase(*b, opt, &stats2);
         } catch (...) {
           stage2_error = std::current_exception();
-          stage2_failed.store(true);
+          failed.store(true);
         }
       }
       to_write.push(b);
@@ -497,46 +580,58 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
   });
   std::thread writer([&] {
     Batch* b = nullptr;
-    while (to_write.pop(b)) {
-      if (!writer_error && !stage2_failed.load()) {
+    uint64_t next_seq = 0;
+    std::vector<Batch*> parked;  // batches that overtook an earlier one on another GPU worker
+    auto write_one = [&](Batch* x) {
+      if (!failed.load()) {
         try {
-          for (size_t i = 0; i < b->in.size(); ++i) sink.write(b->in[i].name, b->out[i].data(), b->out[i].size());
+          for (size_t i = 0; i < x->in.size(); ++i) sink.write(x->in[i].name, x->out[i].data(), x->out[i].size());
         } catch (...) {
           writer_error = std::current_exception();
+          failed.store(true);
         }
       }
-      free_q.push(b);  // back to the reader
-    }
-  });
-
-  Batch* b = nullptr;
-  while (to_gpu.pop(b)) {
-    if (!gpu_error) {
-      try {
-        if (opt.decode) decodeGpuPhase(*b, &stats);
-        else gpuPhase(*b, opt, &stats);
-      } catch (...) {
-        gpu_error = std::current_exception();
+      ++next_seq;
+      free_q.push(x);  // back to the reader
+    };
+    while (to_write.pop(b)) {
+      if (failed.load()) {  // nothing more is written: hand everything back
+        free_q.push(b);
+        for (Batch* x : parked) free_q.push(x);
+        parked.clear();
+        continue;
+      }
+      parked.push_back(b);
+      for (bool progress = true; progress;) {
+        progress = false;
+        for (size_t i = 0; i < parked.size(); ++i) {
+          if (parked[i]->seq == next_seq) {
+            Batch* x = parked[i];
+            parked.erase(parked.begin() + i);
+            write_one(x);
+            progress = true;
+            break;
+          }
+        }
       }
     }
-    if (gpu_error) {
-      free_q.push(b);
-      continue;
-    }
-    to_stage2.push(b);
-  }
-  to_stage2.close();
+    for (Batch* x : parked) free_q.push(x);
+  });
+
+  for (std::thread& t : gpu_workers) t.join();
   stage2.join();
   writer.join();
   free_q.close();
   reader.join();
-  if (gpu_error) std::rethrow_exception(gpu_error);
+  for (const std::exception_ptr& e : gpu_error)
+    if (e) std::rethrow_exception(e);
   if (stage2_error) std::rethrow_exception(stage2_error);
   if (reader_error) std::rethrow_exception(reader_error);
   if (writer_error) std::rethrow_exception(writer_error);
   stats.output_bytes = stats2.output_bytes;
   stats.seconds_stage2 = stats2.seconds_stage2;
   stats.seconds_total = since(t0);
+  stats.gpu_workers = n_workers;
   return stats;
 }
 

@@ -91,9 +91,9 @@ CLDN_EXPORT int64_t cldn_amd_encode(const cldn_amd_info_t* info, const uint8_t* 
   });
 }
 
-CLDN_EXPORT int64_t cldn_amd_transcode_directory(const char* in_dir, const char* out_dir, float resolution,
-                                                 uint8_t compression_opt, int viz_lossy, uint32_t batch_messages,
-                                                 double* stats_out) {
+CLDN_EXPORT int64_t cldn_amd_transcode_directory_on(const char* in_dir, const char* out_dir, float resolution,
+                                                    uint8_t compression_opt, int viz_lossy, uint32_t batch_messages,
+                                                    const int32_t* devices, uint32_t n_devices, double* stats_out) {
   return guarded([&] {
     cloudini_amd::DirectorySource source(in_dir);
     cloudini_amd::DirectorySink sink(out_dir);
@@ -102,6 +102,33 @@ CLDN_EXPORT int64_t cldn_amd_transcode_directory(const char* in_dir, const char*
     opt.compression = static_cast<Cloudini::CompressionOption>(compression_opt);
     opt.viz_lossy = viz_lossy != 0;
     if (batch_messages) opt.batch_messages = batch_messages;
+    if (devices) opt.devices.assign(devices, devices + n_devices);
+    const cloudini_amd::TranscodeStats st = cloudini_amd::transcodePointClouds(source, sink, opt);
+    if (stats_out) {
+      const double v[8] = {(double)st.messages,    (double)st.points,  (double)st.input_bytes, (double)st.output_bytes,
+                           (double)st.gpu_batches, st.seconds_total, st.seconds_gpu,         st.seconds_stage2};
+      for (int i = 0; i < 8; ++i) stats_out[i] = v[i];
+    }
+    return (int64_t)st.messages;
+  });
+}
+
+CLDN_EXPORT int64_t cldn_amd_transcode_directory(const char* in_dir, const char* out_dir, float resolution,
+                                                 uint8_t compression_opt, int viz_lossy, uint32_t batch_messages,
+                                                 double* stats_out) {
+  return cldn_amd_transcode_directory_on(in_dir, out_dir, resolution, compression_opt, viz_lossy, batch_messages, nullptr, 0,
+                                         stats_out);
+}
+
+CLDN_EXPORT int64_t cldn_amd_decode_directory_on(const char* in_dir, const char* out_dir, uint32_t batch_messages,
+                                                 const int32_t* devices, uint32_t n_devices, double* stats_out) {
+  return guarded([&] {
+    cloudini_amd::DirectorySource source(in_dir);
+    cloudini_amd::DirectorySink sink(out_dir);
+    cloudini_amd::TranscodeOptions opt;
+    opt.decode = true;
+    if (batch_messages) opt.batch_messages = batch_messages;
+    if (devices) opt.devices.assign(devices, devices + n_devices);
     const cloudini_amd::TranscodeStats st = cloudini_amd::transcodePointClouds(source, sink, opt);
     if (stats_out) {
       const double v[8] = {(double)st.messages,    (double)st.points,  (double)st.input_bytes, (double)st.output_bytes,
@@ -114,20 +141,7 @@ CLDN_EXPORT int64_t cldn_amd_transcode_directory(const char* in_dir, const char*
 
 CLDN_EXPORT int64_t cldn_amd_decode_directory(const char* in_dir, const char* out_dir, uint32_t batch_messages,
                                               double* stats_out) {
-  return guarded([&] {
-    cloudini_amd::DirectorySource source(in_dir);
-    cloudini_amd::DirectorySink sink(out_dir);
-    cloudini_amd::TranscodeOptions opt;
-    opt.decode = true;
-    if (batch_messages) opt.batch_messages = batch_messages;
-    const cloudini_amd::TranscodeStats st = cloudini_amd::transcodePointClouds(source, sink, opt);
-    if (stats_out) {
-      const double v[8] = {(double)st.messages,    (double)st.points,  (double)st.input_bytes, (double)st.output_bytes,
-                           (double)st.gpu_batches, st.seconds_total, st.seconds_gpu,         st.seconds_stage2};
-      for (int i = 0; i < 8; ++i) stats_out[i] = v[i];
-    }
-    return (int64_t)st.messages;
-  });
+  return cldn_amd_decode_directory_on(in_dir, out_dir, batch_messages, nullptr, 0, stats_out);
 }
 
 CLDN_EXPORT uint32_t cldn_amd_stage2_threads(void) { return Cloudini::amd_detail::stage2Threads(); }

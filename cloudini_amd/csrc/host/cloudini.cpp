@@ -861,8 +861,6 @@ void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compres
   if (compressed_data.size() >= size_t(kMagicHeaderLength) &&
       std::memcmp(compressed_data.data(), kMagicHeader, kMagicHeaderLength) == 0)
     throw std::runtime_error("compressed_data contains the header. You should use DecodeHeader first");
-  if (info.version < 3)
-    throw std::runtime_error("Cloudini (HIP): streams older than wire version 3 (unchunked) are not supported");
   if (info.point_step == 0) throw std::runtime_error("point_step cannot be 0");
 
   const std::string key = CodecPool::keyOf(info);
@@ -876,6 +874,26 @@ void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compres
 
   const uint64_t points = static_cast<uint64_t>(info.width) * info.height;
   const uint64_t out_bytes = points * info.point_step;
+  if (info.version < 3) {
+    // wire version 2 (src/cloudini.cpp:665-667): the whole payload is one chunk -- stage 2 undone in one piece with
+    // width * height * point_step as its bound (:672-675), then points until the payload is empty (src/v4_codec.cpp:108-115)
+    const uint8_t* s1 = compressed_data.data();
+    size_t s1_size = compressed_data.size();
+    std::vector<uint8_t> plain;
+    if (info.compression_opt != CompressionOption::NONE) {
+      if (info.compression_opt == CompressionOption::LZ4 &&
+          (compressed_data.size() > size_t(std::numeric_limits<int>::max()) || out_bytes > uint64_t(std::numeric_limits<int>::max())))
+        throw std::runtime_error("Chunk size too large for LZ4");
+      plain.resize(static_cast<size_t>(out_bytes));
+      s1_size = amd_detail::decompressChunkTo(info.compression_opt, compressed_data.data(), compressed_data.size(), plain.data(),
+                                              plain.size());
+      s1 = plain.data();
+    }
+    if (cldn_hip_decode_stage1_unframed(impl_->codec, s1, s1_size, CLDN_HIP_HOST, output.data(), output.size(), CLDN_HIP_HOST) !=
+        CLDN_HIP_OK)
+      throw std::runtime_error(cldn_hip_last_error());
+    return;
+  }
   if (output.size() < out_bytes) throw std::runtime_error("Output buffer is too small to hold the decoded data");
 
   // validate the chunk chain the way the reference does (src/cloudini.cpp:645-664) and undo stage 2
@@ -1040,8 +1058,6 @@ size_t stage1ChunkBound(const EncodingInfo& info) {
 
 void decodeStage1Batch(const EncodingInfo& info, const uint8_t* streams, const uint64_t* offsets, const uint64_t* cloud_points,
                        uint32_t n_clouds, uint8_t* out, uint64_t out_capacity) {
-  if (info.version < 3)
-    throw std::runtime_error("Cloudini (HIP): streams older than wire version 3 (unchunked) are not supported");
   if (info.point_step == 0) throw std::runtime_error("point_step cannot be 0");
   PlanHandle plan(info);
   cldn_hip_codec_t* codec = pool().acquire(info, plan);

@@ -26,7 +26,8 @@ struct DecChunk {
   uint32_t n_points;
   uint64_t first_point;
   uint32_t cloud;
-  uint32_t valid;
+  uint32_t valid;     // 0 = do not touch; 1 = chunk of n_points points; 2 = unframed payload of a wire-version-2 stream:
+                      // points until the payload is empty, n_points = the points the output buffer has room for
 };
 
 // grid = ceil(n_clouds / 64), one thread per cloud
@@ -224,7 +225,11 @@ __device__ __forceinline__ void decode_general_body(const DevPlan plan, const ui
       gor_lead[k] = 255;  // kLeadingSentinel
       gor_trail[k] = 0;
     }
-    for (uint32_t i = 0; i < n && !r.bad; ++i) {
+    // wire version 2 (src/cloudini.cpp:665-667, src/v4_codec.cpp:108-115): no chunks, no point count -- points until the
+    // payload is empty; one more point than the output holds is "Output buffer is too small to hold the decoded data"
+    const bool unframed = dc.valid == 2u;
+    for (uint32_t i = 0; (unframed ? r.p < r.end : i < n) && !r.bad; ++i) {
+      if (unframed && i >= n) { r.bad = true; break; }
       uint8_t* pt = base + (size_t)i * step;
       // "Truncated encoded data: not enough bytes for a complete point" (v4_codec.cpp:103-105)
       if (!uses_v5 && (size_t)(r.end - r.p) < plan.min_regular_bytes) { r.bad = true; break; }

@@ -2299,6 +2299,25 @@ int stage1_launch_encode(const EncodeLaunch& L) {
 
 static_assert(sizeof(DecChunk) <= kDecChunkBytes, "DecodeLaunch::chunks entries must hold a DecChunk");
 
+// wire version 2: one unframed payload, decoded by the serial restatement of DecodeV4Stage1Chunk (one lane)
+int stage1_launch_decode_unframed(const DevPlan& plan, hipStream_t stream, const uint8_t* payload, uint32_t size,
+                                  uint32_t capacity_points, void* chunk_slot, uint8_t* out, uint32_t* status) {
+  DecChunk dc;
+  dc.src_off = 0;
+  dc.src_size = size;
+  dc.n_points = capacity_points;
+  dc.first_point = 0;
+  dc.cloud = 0;
+  dc.valid = 2u;
+  hipError_t e = hipMemcpyAsync(chunk_slot, &dc, sizeof(dc), hipMemcpyHostToDevice, stream);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(DecChunk)");
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return hip_fail(e, "hipStreamSynchronize");  // `dc` lives on this frame
+  hipLaunchKernelGGL(k_decode_general, dim3(1), dim3(64), 0, stream, plan, payload, reinterpret_cast<const DecChunk*>(chunk_slot),
+                     out, 0u, 0u, (const uint32_t*)nullptr, (const uint8_t*)nullptr, status);
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_general");
+  return CLDN_HIP_OK;
+}
+
 int stage1_launch_decode(const DecodeLaunch& L) {
   hipError_t e;
   if (L.n_clouds == 0) return CLDN_HIP_OK;

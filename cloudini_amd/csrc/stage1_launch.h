@@ -84,6 +84,8 @@ int launch_fail(hipError_t e, const char* what);
 int stage1_configure_kernels();
 int stage1_launch_encode(const EncodeLaunch& L);
 int stage1_launch_decode(const DecodeLaunch& L);
+int stage1_launch_decode_unframed(const DevPlan& plan, hipStream_t stream, const uint8_t* payload, uint32_t size,
+                                  uint32_t capacity_points, void* chunk_slot, uint8_t* out, uint32_t* status);
 
 // applyVizLossyPreprocessing (viz_kernels.hip)
 struct VizLaunch {

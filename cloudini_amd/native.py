@@ -55,6 +55,8 @@ def lib() -> C.CDLL:
     L.cldn_hip_abi_version.restype = C.c_int
     L.cldn_hip_device_count.restype = C.c_int
     L.cldn_hip_current_device.restype = C.c_int
+    L.cldn_hip_set_current_device.restype = C.c_int
+    L.cldn_hip_set_current_device.argtypes = [C.c_int]
     L.cldn_hip_codec_device.restype = C.c_int
     L.cldn_hip_codec_device.argtypes = [vp]
     L.cldn_hip_host_alloc.restype = vp

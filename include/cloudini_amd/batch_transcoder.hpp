@@ -94,11 +94,16 @@ struct TranscodeOptions {
   // CompressedPointCloud2, every output is the sensor_msgs/PointCloud2 that convertCompressedCloudToPointCloud2
   // (src/ros_msg_utils.cpp:135-165) writes. profile / default_resolution / viz_lossy / compression are not used.
   bool decode = false;
+  // GPUs the batches are spread over: one GPU stage (thread + pooled codecs) per entry, shared reader, stage-2 pool and
+  // ordered writer; batches go to whichever GPU stage is free. Empty = the calling thread's current device. The same
+  // device may be listed more than once (two batches in flight on one GPU).
+  std::vector<int> devices;
 };
 
 struct TranscodeStats {
   uint64_t messages = 0, points = 0, input_bytes = 0, output_bytes = 0, gpu_batches = 0;
-  double seconds_total = 0, seconds_gpu = 0, seconds_stage2 = 0;
+  double seconds_total = 0, seconds_gpu = 0, seconds_stage2 = 0;  // seconds_gpu: summed over the GPU stages
+  uint64_t gpu_workers = 0;
 };
 
 template <typename T>

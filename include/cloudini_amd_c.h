@@ -75,6 +75,15 @@ int64_t cldn_amd_transcode_directory(const char* in_dir, const char* out_dir, fl
  * decode per run of messages with the same schema. stats_out as above. Returns the message count or -1. */
 int64_t cldn_amd_decode_directory(const char* in_dir, const char* out_dir, uint32_t batch_messages, double* stats_out);
 
+/* The same two with a device list (cloudini_amd::TranscodeOptions::devices): the batches are spread over one GPU stage
+ * per entry (a device may be listed twice), the output order and bytes are those of the single-device run.
+ * devices == NULL: the calling thread's current device. */
+int64_t cldn_amd_transcode_directory_on(const char* in_dir, const char* out_dir, float resolution, uint8_t compression_opt,
+                                        int viz_lossy, uint32_t batch_messages, const int32_t* devices, uint32_t n_devices,
+                                        double* stats_out);
+int64_t cldn_amd_decode_directory_on(const char* in_dir, const char* out_dir, uint32_t batch_messages, const int32_t* devices,
+                                     uint32_t n_devices, double* stats_out);
+
 /* Stage-2 (LZ4 / ZSTD) threads a single encode()/decode() call with use_threads may occupy, the caller included.
  * The reference's flag means one extra worker (cloudini_lib/src/cloudini.cpp:453-499); here the pool is bounded:
  * default min(4, hardware threads), overridden by the environment variable CLOUDINI_AMD_STAGE2_THREADS (read once)

@@ -74,6 +74,7 @@ const char* cldn_hip_last_error(void);
 int cldn_hip_abi_version(void);
 int cldn_hip_device_count(void); /* >= 0, or a negative error */
 int cldn_hip_current_device(void); /* the calling thread's current HIP device (>= 0), or a negative error */
+int cldn_hip_set_current_device(int device); /* hipSetDevice for the calling thread (a worker thread per GPU) */
 
 /* Page-locked host memory for buffers handed to the HOST-tagged entry points: copies from / to it run at PCIe speed and
  * asynchronously, pageable memory goes through the driver's bounce buffers (measured 1.4 GB/s against 25 GB/s for the
@@ -162,6 +163,14 @@ int cldn_hip_codec_pipeline(cldn_hip_codec_t* codec, int mode, const void* point
 int cldn_hip_decode_stage1(cldn_hip_codec_t* codec, const void* streams, int streams_loc,
                            const uint64_t* stream_offsets, const uint64_t* cloud_points, uint32_t n_clouds,
                            void* points_out, uint64_t out_capacity, int out_loc);
+
+/* Wire version 2 (streams written before the chunked format; the reference still reads them, src/cloudini.cpp:665-667):
+ * the whole stage-1 payload is ONE unframed run of points without [u32 size] prefixes and without state resets, decoded
+ * until it is empty (DecodeV4Stage1Chunk with expected_points = 0, src/v4_codec.cpp:108-115). The output capacity bounds
+ * the point count ("Output buffer is too small to hold the decoded data" = CLDN_HIP_ERR_CORRUPT here); points behind the
+ * last decoded one keep their content. One lane decodes: this is a compatibility path, not a fast one. */
+int cldn_hip_decode_stage1_unframed(cldn_hip_codec_t* codec, const void* payload, uint64_t size, int payload_loc,
+                                    void* points_out, uint64_t out_capacity, int out_loc);
 
 /* cloudini_ros::applyVizLossyPreprocessing, data path (include/cloudini_lib/ros_msg_utils.hpp:175-221,
  * src/ros_msg_utils.cpp:249-341) -- the step right in front of the encoder in the rosbag converter

@@ -71,7 +71,7 @@ size_t MaxCompressedSize(const EncodingInfo& info, size_t points_count, bool inc
 
 class PointcloudEncoder {
  public:
-  explicit PointcloudEncoder(const EncodingInfo& info);
+  PointcloudEncoder(const EncodingInfo& info);  // (not explicit: the reference's is not, include/cloudini_lib/cloudini.hpp:156)
   ~PointcloudEncoder();
   PointcloudEncoder(const PointcloudEncoder&) = delete;
   PointcloudEncoder& operator=(const PointcloudEncoder&) = delete;

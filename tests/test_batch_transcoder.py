@@ -123,3 +123,91 @@ def test_round_trip_through_both_directions_with_the_tool(tmp_path):
     assert back.size == msgs[3].size                      # same CDR layout, points within half a tick
     n = 130048 * info.point_step
     assert np.array_equal(back[: msgs[3].size - n - 1], msgs[3][: msgs[3].size - n - 1])  # header part unchanged
+
+
+def test_two_gpu_stages_keep_order_and_bytes(tmp_path, reflib):
+    """TranscodeOptions::devices: one GPU stage per entry, shared reader / stage-2 pool / ordered writer. Two stages on
+    device 0 (what a 1-GPU box can run) must write the files the single-stage run writes, in the same order; the
+    command-line tool takes the list as --devices."""
+    msgs = _mixed_messages() * 3
+    src, one, two, three = str(tmp_path / "in"), str(tmp_path / "one"), str(tmp_path / "two"), str(tmp_path / "three")
+    _write_messages(src, msgs)
+    api.transcode_directory(src, one, resolution=0.001, compression_opt=int(CompressionOption.ZSTD), batch_messages=3)
+    st = api.transcode_directory(src, two, resolution=0.001, compression_opt=int(CompressionOption.ZSTD), batch_messages=3,
+                                 devices=[0, 0])
+    assert int(st["messages"]) == len(msgs)
+    exe = os.path.join(ROOT, "cloudini_amd", "lib", "cloudini_batch_transcode")
+    r = subprocess.run([exe, src, three, "--resolution", "0.001", "--compression", "zstd", "--batch", "3", "--devices", "0,0,0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["gpu_stages"] == 3
+    for k, m in enumerate(msgs):
+        a = np.fromfile(os.path.join(one, f"msg_{k:05d}.bin"), dtype=np.uint8)
+        for other in (two, three):
+            b = np.fromfile(os.path.join(other, f"msg_{k:05d}.bin"), dtype=np.uint8)
+            assert a.size == b.size and np.array_equal(a, b), (other, k)
+    assert np.array_equal(np.fromfile(os.path.join(two, "msg_00006.bin"), dtype=np.uint8),
+                          reflib.ros_compress(msgs[6], 0.001, int(CompressionOption.ZSTD)))
+    # the way back over two stages
+    back1, back2 = str(tmp_path / "b1"), str(tmp_path / "b2")
+    api.decode_directory(one, back1, batch_messages=3)
+    api.decode_directory(one, back2, batch_messages=3, devices=[0, 0])
+    for k in range(len(msgs)):
+        assert np.array_equal(np.fromfile(os.path.join(back1, f"msg_{k:05d}.bin"), dtype=np.uint8),
+                              np.fromfile(os.path.join(back2, f"msg_{k:05d}.bin"), dtype=np.uint8)), k
+    with pytest.raises(RuntimeError):
+        api.transcode_directory(src, str(tmp_path / "bad"), devices=[99])
+
+
+@pytest.mark.skipif("__import__('torch').cuda.device_count() < 2")
+def test_two_real_gpus_write_the_single_gpu_bytes(tmp_path):
+    msgs = _mixed_messages() * 2
+    src, one, two = str(tmp_path / "in"), str(tmp_path / "one"), str(tmp_path / "two")
+    _write_messages(src, msgs)
+    api.transcode_directory(src, one, batch_messages=2)
+    api.transcode_directory(src, two, batch_messages=2, devices=[0, 1])
+    for k in range(len(msgs)):
+        assert np.array_equal(np.fromfile(os.path.join(one, f"msg_{k:05d}.bin"), dtype=np.uint8),
+                              np.fromfile(os.path.join(two, f"msg_{k:05d}.bin"), dtype=np.uint8)), k
+
+
+def test_truncated_and_degenerate_messages_fail_like_the_reference(tmp_path, reflib):
+    """The reference's order, message by message (src/ros_msg_utils.cpp:178-190, src/cloudini.cpp:525-531): an empty cloud
+    is an empty message whatever its schema says; a data blob that is not a multiple of point_step is an error, never a
+    silently shortened cloud."""
+    info, data = synth.lidar_xyzi(1000, seed=1)
+    good = _cdr_pointcloud2(info, data)
+    cut = _cdr_pointcloud2(info, data[:-5])            # 995 whole points + 11 bytes
+    tiny = _cdr_pointcloud2(info, data[:7])            # less than one point
+    for bad in (cut, tiny):
+        with pytest.raises(RuntimeError, match="not a multiple of point_step"):
+            reflib.ros_compress(bad, 0.001, int(CompressionOption.ZSTD))
+        src = str(tmp_path / f"in{bad.size}")
+        _write_messages(src, [good, bad, good])
+        with pytest.raises(RuntimeError, match="not a multiple of point_step"):
+            api.transcode_directory(src, str(tmp_path / f"out{bad.size}"), batch_messages=4)
+    # an empty cloud with point_step 0 in its schema: an empty message in the reference, and here
+    empty0 = _cdr_pointcloud2(info.copy(point_step=0, width=0), data[:0])
+    src, dst = str(tmp_path / "in_e"), str(tmp_path / "out_e")
+    _write_messages(src, [good, empty0, good])
+    st = api.transcode_directory(src, dst, batch_messages=4)
+    assert int(st["messages"]) == 3
+    assert np.array_equal(np.fromfile(os.path.join(dst, "msg_00001.bin"), dtype=np.uint8),
+                          reflib.ros_compress(empty0, 0.001, int(CompressionOption.ZSTD)))
+
+
+def test_wrapping_geometry_is_refused_on_the_way_back(tmp_path):
+    """width * height * point_step of a CompressedPointCloud2 must not wrap 64 bits into a small (or zero) cloud size."""
+    info, data = synth.lidar_xyzi(100, seed=1)
+    packed = api.ros_compress(_cdr_pointcloud2(info, data), 0.001, int(CompressionOption.NONE))
+    msg = bytearray(packed.tobytes())
+    # height and width sit behind stamp (8) + frame_id string; patch both to 2^31 -> 2^62 points * 16 bytes wraps to 0
+    at = 4 + 8 + 4 + len(b"lidar_top\0")
+    at += (-(at - 4)) % 4
+    assert int.from_bytes(msg[at:at + 4], "little") == info.height and int.from_bytes(msg[at + 4:at + 8], "little") == info.width
+    msg[at:at + 4] = (1 << 31).to_bytes(4, "little")
+    msg[at + 4:at + 8] = (1 << 31).to_bytes(4, "little")
+    src = str(tmp_path / "in")
+    _write_messages(src, [np.frombuffer(bytes(msg), dtype=np.uint8)])
+    with pytest.raises(RuntimeError):
+        api.decode_directory(src, str(tmp_path / "out"))

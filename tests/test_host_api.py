@@ -338,3 +338,61 @@ def test_legacy_v3_wire_format_like_the_reference_test(reflib):
     got4 = api.PointcloudEncoder(info4).encode(data)
     assert got4[:12].tobytes() == b"CLOUDINI_V04" and not np.array_equal(got4[13:], got[13:])
     assert np.array_equal(got4, reflib.encode(info4, data))
+
+
+def _stage2(comp, payload: bytes) -> bytes:
+    """LZ4 block / ZSTD frame of `payload` through the system libraries (what CompressChunk calls, codec_common.cpp:220-258)."""
+    if comp == CompressionOption.NONE:
+        return payload
+    if comp == CompressionOption.LZ4:
+        lz4 = C.CDLL("/usr/lib/x86_64-linux-gnu/liblz4.so.1")
+        cap = lz4.LZ4_compressBound(len(payload))
+        out = C.create_string_buffer(cap)
+        n = lz4.LZ4_compress_default(payload, out, len(payload), cap)
+        assert n > 0
+        return out.raw[:n]
+    zstd = C.CDLL("/usr/lib/x86_64-linux-gnu/libzstd.so.1")
+    zstd.ZSTD_compressBound.restype = C.c_size_t
+    zstd.ZSTD_compressBound.argtypes = [C.c_size_t]
+    zstd.ZSTD_compress.restype = C.c_size_t
+    zstd.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+    cap = zstd.ZSTD_compressBound(len(payload))
+    out = C.create_string_buffer(cap)
+    n = zstd.ZSTD_compress(out, cap, payload, len(payload), 1)
+    return out.raw[:n]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("comp", [CompressionOption.NONE, CompressionOption.LZ4, CompressionOption.ZSTD])
+def test_wire_version_2_streams_decode_like_the_reference(reflib, comp):
+    """Streams of wire version 2 (no chunks: the whole payload is one run of points, decoded until it is empty) are still
+    read by the reference (src/cloudini.cpp:665-667, src/v4_codec.cpp:108-115), and by the host mirror."""
+    n = 20000
+    info3, data = synth.lidar_xyzi(n, seed=4)
+    info3 = info3.copy(version=3, compression_opt=CompressionOption.NONE)
+    framed = reflib.encode_stage1(info3, data)               # one chunk: [u32 size][payload]
+    size = int.from_bytes(framed[:4].tobytes(), "little")
+    assert size + 4 == framed.size
+    payload = framed[4:].tobytes()
+    for declared, keep in ((n, n), (n + 500, n), (n - 1, n)):
+        info2 = info3.copy(version=2, compression_opt=comp, width=declared, height=1)
+        stream = np.frombuffer(reflib.header(info2) + _stage2(comp, payload), dtype=np.uint8)
+        assert stream[:12].tobytes() == b"CLOUDINI_V02"
+        out_size = declared * info2.point_step
+        if declared < keep:   # one point more than the output holds
+            with pytest.raises(RuntimeError):
+                reflib.decode(stream, out_size, fill=0x5A)
+            with pytest.raises(RuntimeError):
+                api.PointcloudDecoder().decode_stream(stream, fill=0x5A)
+            continue
+        want, _yaml = reflib.decode(stream, out_size, fill=0x5A)
+        got, got_info = api.PointcloudDecoder().decode_stream(stream, fill=0x5A)
+        assert int(got_info.version) == 2
+        assert got.size == want.size and np.array_equal(got, want), (comp, declared)
+    # a payload cut inside a point is "Truncated encoded data"
+    info2 = info3.copy(version=2, compression_opt=comp, width=n, height=1)
+    stream = np.frombuffer(reflib.header(info2) + _stage2(comp, payload[:-1]), dtype=np.uint8)
+    with pytest.raises(RuntimeError):
+        reflib.decode(stream, n * info2.point_step)
+    with pytest.raises(RuntimeError):
+        api.PointcloudDecoder().decode_stream(stream)

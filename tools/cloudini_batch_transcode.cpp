@@ -4,6 +4,7 @@
 // plain directories.
 //   cloudini_batch_transcode <in_dir> <out_dir> [--resolution 0.001] [--compression none|lz4|zstd] [--viz] [--batch 64]
 //   cloudini_batch_transcode <in_dir> <out_dir> --decode [--batch 64]      (CompressedPointCloud2 -> PointCloud2)
+//   ... --devices 0,1,2,3   spreads the batches over these GPUs (one GPU stage per entry; "0,0" = two stages on GPU 0)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,7 +14,7 @@
 
 int main(int argc, char** argv) {
   if (argc < 3) {
-    std::fprintf(stderr, "usage: %s <in_dir> <out_dir> [--resolution r] [--compression none|lz4|zstd] [--viz] [--batch n] | --decode [--batch n]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <in_dir> <out_dir> [--resolution r] [--compression none|lz4|zstd] [--viz] [--batch n] [--devices 0,1,...] | --decode [--batch n] [--devices ...]\n", argv[0]);
     return 2;
   }
   cloudini_amd::TranscodeOptions opt;
@@ -25,6 +26,17 @@ int main(int argc, char** argv) {
     else if (a == "--viz") opt.viz_lossy = true;
     else if (a == "--decode") opt.decode = true;
     else if (a == "--batch" && i + 1 < argc) opt.batch_messages = (size_t)std::strtoul(argv[++i], nullptr, 10);
+    else if (a == "--devices" && i + 1 < argc) {
+      for (const char* p = argv[++i]; *p;) {
+        char* end = nullptr;
+        opt.devices.push_back((int)std::strtol(p, &end, 10));
+        if (end == p) {
+          std::fprintf(stderr, "--devices wants a comma-separated list of device numbers\n");
+          return 2;
+        }
+        p = *end == ',' ? end + 1 : end;
+      }
+    }
     else {
       std::fprintf(stderr, "unknown argument %s\n", a.c_str());
       return 2;
@@ -35,10 +47,10 @@ int main(int argc, char** argv) {
     cloudini_amd::DirectorySink sink(argv[2]);
     const cloudini_amd::TranscodeStats st = cloudini_amd::transcodePointClouds(source, sink, opt);
     std::printf("{\"messages\": %llu, \"points\": %llu, \"input_bytes\": %llu, \"output_bytes\": %llu, \"gpu_batches\": %llu, "
-                "\"seconds_total\": %.6f, \"seconds_gpu\": %.6f, \"seconds_stage2\": %.6f, \"Mpoints_per_s\": %.1f}\n",
+                "\"seconds_total\": %.6f, \"seconds_gpu\": %.6f, \"seconds_stage2\": %.6f, \"gpu_stages\": %llu, \"Mpoints_per_s\": %.1f}\n",
                 (unsigned long long)st.messages, (unsigned long long)st.points, (unsigned long long)st.input_bytes,
                 (unsigned long long)st.output_bytes, (unsigned long long)st.gpu_batches, st.seconds_total, st.seconds_gpu,
-                st.seconds_stage2, st.seconds_total > 0 ? st.points / st.seconds_total / 1e6 : 0.0);
+                st.seconds_stage2, (unsigned long long)st.gpu_workers, st.seconds_total > 0 ? st.points / st.seconds_total / 1e6 : 0.0);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "cloudini_batch_transcode: %s\n", e.what());
     return 1;

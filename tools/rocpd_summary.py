@@ -8,6 +8,23 @@ import sqlite3
 import statistics
 
 
+def short_name(name: str) -> str:
+    """Kernel name without its argument list. Names such as `cldn::(anonymous namespace)::k_viz_insert(...)` or
+    `void cldn::k_x<(anonymous namespace)::T>(...)` contain parentheses of their own: cut at the LAST top-level '('."""
+    name = name.replace("void ", "")
+    if not name.endswith(")"):
+        return name
+    depth = 0
+    for i in range(len(name) - 1, -1, -1):
+        if name[i] == ")":
+            depth += 1
+        elif name[i] == "(":
+            depth -= 1
+            if depth == 0:
+                return name[:i]
+    return name
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("db")
@@ -22,7 +39,7 @@ def main():
     for name, dur, gx, gy, wx, lds, vg, sg in rows:
         if args.filter and args.filter not in name:
             continue
-        short = name.split("(")[0].replace("void ", "")
+        short = short_name(name)
         by.setdefault(short, []).append((dur, gx, gy, wx, lds, vg, sg))
     if by:
         total = sum(sum(d[0] for d in v) for v in by.values())
@@ -31,7 +48,7 @@ def main():
         for k, v in sorted(by.items(), key=lambda kv: -sum(d[0] for d in kv[1])):
             ds = [d[0] / 1e3 for d in v]
             g = v[-1]
-            print(f"{k[:46]:46s} {len(ds):6d} {sum(ds):11.1f} {statistics.mean(ds):9.2f} {min(ds):9.2f} {max(ds):9.2f} "
+            print(f"{k[-46:]:46s} {len(ds):6d} {sum(ds):11.1f} {statistics.mean(ds):9.2f} {min(ds):9.2f} {max(ds):9.2f} "
                   f"{100 * sum(ds) * 1e3 / total:6.2f}  {g[1]}x{g[2]} x {g[3]}, {g[4]}, {g[5]}, {g[6]}")
 
     try:
@@ -43,7 +60,7 @@ def main():
         for name, cname, val, disp in pm:
             if args.filter and args.filter not in name:
                 continue
-            short = name.split("(")[0].replace("void ", "")
+            short = short_name(name)
             acc.setdefault(short, {}).setdefault(cname, {}).setdefault(disp, 0.0)
             acc[short][cname][disp] += val
         print("\n== PMC counters (sum over SEs/XCDs per dispatch, then mean over dispatches) ==")
