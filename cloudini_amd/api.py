@@ -131,6 +131,15 @@ def set_stage2_threads(n: int) -> int:
     return int(lib().cldn_amd_set_stage2_threads(int(n)))
 
 
+def device_lz4() -> bool:
+    return bool(lib().cldn_amd_device_lz4())
+
+
+def set_device_lz4(on: bool) -> bool:
+    """LZ4 streams with stage 2 on the GPU (valid LZ4 blocks, not lz4's own bytes). Returns the value in effect."""
+    return bool(lib().cldn_amd_set_device_lz4(1 if on else 0))
+
+
 def _device_list(devices):
     if not devices:
         return None, 0

@@ -45,7 +45,7 @@ def _sources(folder: str, exts) -> list:
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, "stage1_kernels.hip"), os.path.join(CSRC, "viz_kernels.hip"),
-            os.path.join(CSRC, "hip_abi.hip")]
+            os.path.join(CSRC, "lz4_kernels.hip"), os.path.join(CSRC, "hip_abi.hip")]
     deps = _sources(CSRC, (".hip", ".h")) + _sources(os.path.join(ROOT, "include"), (".h",))
     deps = [d for d in deps if os.sep + "host" + os.sep not in d]
     if force or _newer(HIP_SO, deps):

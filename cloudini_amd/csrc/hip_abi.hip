@@ -160,6 +160,9 @@ struct cldn_hip_codec {
   DevBuf d_cols[kMaxAdaptive];
   DevBuf d_ranks[kMaxAdaptive];
   DevBuf d_dec_meta, d_pre_ptrs;
+  // stage 2 on the device (cldn_hip_codec_set_stage2): the stage-1 streams stay in d_s1, LZ4 blocks go to d_lz_slots
+  int stage2 = 0;
+  DevBuf d_s1, d_s1_offsets, d_lz_matches, d_lz_counts, d_lz_slots, d_lz_segs, d_payload2, d_dst2;
   DevBuf d_finrec;            // k_finish look-back records (rec, rec2), cleared only when (re)allocated
   uint32_t finish_epoch = 0;  // tag of this call's records
   DevBuf d_pieces;  // piece table of the piece kernel (stage1_fused.h)
@@ -441,6 +444,29 @@ uint64_t cldn_hip_stage1_bound(const cldn_hip_plan_t* plan, uint64_t n_points) {
   return total;
 }
 
+static uint64_t lz4_block_bound(uint64_t n) { return n + n / 255u + 16u; }  // LZ4_COMPRESSBOUND, lz4.h
+
+uint64_t cldn_hip_stage2_bound(const cldn_hip_plan_t* plan, uint64_t n_points, int stage2) {  // cloudini.cpp:249-292
+  if (!plan) return 0;
+  if (stage2 == CLDN_HIP_STAGE2_NONE) return cldn_hip_stage1_bound(plan, n_points);
+  uint64_t total = 0, left = n_points;
+  while (left > 0) {
+    const uint64_t in_chunk = std::min<uint64_t>(left, kPointsPerChunk);
+    left -= in_chunk;
+    uint64_t chunk = in_chunk * plan->ref_max_point_bytes;
+    if (plan->uses_v5) chunk += (uint64_t)plan->fields.size() * 32u + 1024u;
+    total += 4 + lz4_block_bound(chunk);
+  }
+  return total;
+}
+
+int cldn_hip_codec_set_stage2(cldn_hip_codec_t* c, int stage2) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if (stage2 != CLDN_HIP_STAGE2_NONE && stage2 != CLDN_HIP_STAGE2_LZ4) return fail(CLDN_HIP_ERR_ARG, "invalid stage-2 mode %d", stage2);
+  c->stage2 = stage2;
+  return CLDN_HIP_OK;
+}
+
 int cldn_hip_codec_create(const cldn_hip_plan_t* plan, int device, void* hip_stream, cldn_hip_codec_t** out) {
   if (!plan || !out) return fail(CLDN_HIP_ERR_ARG, "codec_create: NULL argument");
   *out = nullptr;
@@ -480,7 +506,8 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   DeviceGuard guard;
   (void)guard.enter(c->device);
   (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec,
+  DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec, &c->d_s1, &c->d_s1_offsets,
+                    &c->d_lz_matches, &c->d_lz_counts, &c->d_lz_slots, &c->d_lz_segs, &c->d_payload2, &c->d_dst2,
                     &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_pre_ptrs,
                     &c->d_pre[0], &c->d_pre[1], &c->d_pre[2], &c->d_pre[3], &c->d_viz_keys, &c->d_viz_first,
                     &c->d_viz_slot, &c->d_viz_blocks, &c->d_viz_total, &c->d_pieces};
@@ -682,8 +709,12 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
       if (cloud_points[k] && !cloud_ptrs[k]) return fail(CLDN_HIP_ERR_ARG, "cloud %u: NULL buffer", k);
 
   // capacity contract of PointcloudEncoder::encode (cloudini.cpp:531-534)
-  uint64_t need = 0;
-  for (uint32_t k = 0; k < n_clouds; ++k) need += cldn_hip_stage1_bound(&c->plan, cloud_points[k]);
+  uint64_t need = 0, need_s1 = 0;
+  for (uint32_t k = 0; k < n_clouds; ++k) {
+    need_s1 += cldn_hip_stage1_bound(&c->plan, cloud_points[k]);
+    need += cldn_hip_stage2_bound(&c->plan, cloud_points[k], c->stage2);
+  }
+  const bool lz4 = c->stage2 == CLDN_HIP_STAGE2_LZ4;
   // two-step host output (cldn_hip_codec_fetch_output): no caller buffer yet, the codec's own device buffer takes the bound
   const bool deferred = out == nullptr && out_loc == CLDN_HIP_HOST;
   if (deferred) out_capacity = need;
@@ -717,7 +748,8 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
 
   // one zero-filled block per call (one memset launch instead of three)
   const size_t z_anchor = 256;
-  const size_t z_flags = z_anchor + (((size_t)(n_chunks / 1024u + 1u) * 8u + 63u) & ~size_t(63));
+  const size_t z_anchor2 = z_anchor + (((size_t)(n_chunks / 1024u + 1u) * 8u + 63u) & ~size_t(63));  // framing of the LZ4 blocks
+  const size_t z_flags = z_anchor2 + (((size_t)(n_chunks / 1024u + 1u) * 8u + 63u) & ~size_t(63));
   const size_t z_segs = (z_flags + (size_t)n_chunks * std::max(1u, n_adaptive) + 63u) & ~size_t(63);
   const size_t z_bytes = z_segs + std::max<size_t>(16, (size_t)n_chunks * segs_per_chunk * sizeof(Seg));
   if ((rc = c->d_status.ensure(z_bytes)) != CLDN_HIP_OK) return rc;
@@ -780,6 +812,12 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
       if ((rc = c->d_out.ensure((size_t)need)) != CLDN_HIP_OK) return rc;
       d_outp = (uint8_t*)c->d_out.p;
     }
+    if (lz4) {
+      if ((rc = c->d_s1.ensure((size_t)need_s1)) != CLDN_HIP_OK) return rc;
+      if ((rc = c->d_s1_offsets.ensure((size_t)(n_clouds + 1) * sizeof(uint64_t))) != CLDN_HIP_OK) return rc;
+      if ((rc = c->d_payload2.ensure((size_t)n_chunks * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
+      if ((rc = c->d_dst2.ensure((size_t)n_chunks * sizeof(uint64_t))) != CLDN_HIP_OK) return rc;
+    }
   }
   EncodeLaunch L;
   memset(&L, 0, sizeof(L));
@@ -807,7 +845,7 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   L.pre_out = (uint4* const*)c->d_pre_ptrs.p;
   L.chunk_payload = (uint32_t*)c->d_payload.p;
   L.chunk_dst = (uint64_t*)c->d_dst.p;
-  L.stream_offsets = (uint64_t*)c->d_offsets.p;
+  L.stream_offsets = lz4 ? (uint64_t*)c->d_s1_offsets.p : (uint64_t*)c->d_offsets.p;
   L.modes = (uint8_t*)c->d_modes.p;
   L.modes_forced = false;
   if (c->last_modes_count && c->ev_last_modes && hipEventQuery(c->ev_last_modes) == hipSuccess) {
@@ -845,14 +883,67 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
     L.intra = intra;
     L.wgrec = L.fin_rec2 + n_chunks;
   }
-  L.out = d_outp;
-  L.out_capacity = out_capacity;
+  L.out = lz4 ? (uint8_t*)c->d_s1.p : d_outp;
+  L.out_capacity = lz4 ? need_s1 : out_capacity;
   L.status = (uint32_t*)c->d_status.p;
   const size_t n_slots = c->slot_valid.size();
   const size_t slot = n_slots ? (size_t)(c->call_index % n_slots) : 0;
   L.events = n_slots ? &c->events[slot * 5] : nullptr;
   rc = stage1_launch_encode(L);
   if (rc != CLDN_HIP_OK) return rc;
+  const void* d_sizes = c->d_payload.p;  // what chunk_sizes reports
+  if (lz4 && n_chunks) {
+    // stage 2 on the device: an LZ4 block per chunk payload (lz4_kernels.hip), framed by k_finish like the payloads were
+    uint64_t chunk_bound = (uint64_t)kPointsPerChunk * c->plan.ref_max_point_bytes;
+    if (c->plan.uses_v5) chunk_bound += (uint64_t)c->plan.fields.size() * 32u + 1024u;
+    const uint32_t spc = (uint32_t)((chunk_bound + kLzSubBytes - 1u) / kLzSubBytes);
+    const uint64_t out_stride = (lz4_block_bound(chunk_bound) + 255u) & ~uint64_t(255);
+    if ((rc = c->d_lz_matches.ensure((size_t)n_chunks * spc * kLzMaxMatches * sizeof(LzMatch))) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_lz_counts.ensure((size_t)n_chunks * spc * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_lz_slots.ensure((size_t)n_chunks * out_stride)) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_lz_segs.ensure((size_t)n_chunks * sizeof(Seg))) != CLDN_HIP_OK) return rc;
+    Lz4Launch Z;
+    Z.stream = c->stream;
+    Z.stage1 = (const uint8_t*)c->d_s1.p;
+    Z.chunk_dst = (const uint64_t*)c->d_dst.p;
+    Z.chunk_payload = (const uint32_t*)c->d_payload.p;
+    Z.n_chunks = n_chunks;
+    Z.subs_per_chunk = spc;
+    Z.matches = (LzMatch*)c->d_lz_matches.p;
+    Z.counts = (uint32_t*)c->d_lz_counts.p;
+    Z.out_slots = (uint8_t*)c->d_lz_slots.p;
+    Z.out_stride = out_stride;
+    Z.out_segs = (Seg*)c->d_lz_segs.p;
+    if ((rc = lz4_launch(Z)) != CLDN_HIP_OK) return rc;
+    if (++c->finish_epoch == 0u) {  // wrapped: old records could carry the new tags
+      HIP_TRY(hipMemsetAsync(c->d_finrec.p, 0, c->d_finrec.cap, c->stream));
+      c->finish_epoch = 1u;
+    }
+    FrameLaunch F;
+    F.stream = c->stream;
+    F.chunks = (const ChunkDesc*)c->d_chunks.p;
+    F.n_chunks = n_chunks;
+    F.cloud_first_chunk = (const uint32_t*)c->d_cloud_first.p;
+    F.n_clouds = n_clouds;
+    F.slots = (const uint8_t*)c->d_lz_slots.p;
+    F.slot_stride = out_stride;
+    F.segs = (const Seg*)c->d_lz_segs.p;
+    F.segs_per_chunk = 1u;
+    F.rec = (unsigned long long*)c->d_finrec.p;
+    F.anchor = (unsigned long long*)((uint8_t*)c->d_status.p + z_anchor2);
+    F.epoch = c->finish_epoch;
+    F.ticket = (uint32_t*)c->d_status.p + 41;
+    F.chunk_payload = (uint32_t*)c->d_payload2.p;
+    F.chunk_dst = (uint64_t*)c->d_dst2.p;
+    F.stream_offsets = (uint64_t*)c->d_offsets.p;
+    F.out = d_outp;
+    F.out_capacity = out_capacity;
+    F.status = (uint32_t*)c->d_status.p;
+    if ((rc = stage1_launch_frame(F)) != CLDN_HIP_OK) return rc;
+    d_sizes = c->d_payload2.p;
+  } else if (lz4) {
+    HIP_TRY(hipMemsetAsync(c->d_offsets.p, 0, (size_t)(n_clouds + 1) * sizeof(uint64_t), c->stream));
+  }
   // remember this call's modes for the next call's launch hint (no synchronisation: the copy is only looked at
   // once its event has fired)
   if (n_adaptive && n_clouds && (size_t)n_clouds * n_adaptive <= 65536u && c->last_modes_count == 0) {
@@ -896,7 +987,7 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
       HIP_TRY(hipMemcpyAsync(stream_offsets, c->d_offsets.p, (size_t)(n_clouds + 1) * sizeof(uint64_t),
                              hipMemcpyDeviceToDevice, c->stream));
     if (chunk_sizes && n_chunks)
-      HIP_TRY(hipMemcpyAsync(chunk_sizes, c->d_payload.p, (size_t)n_chunks * sizeof(uint32_t),
+      HIP_TRY(hipMemcpyAsync(chunk_sizes, d_sizes, (size_t)n_chunks * sizeof(uint32_t),
                              hipMemcpyDeviceToDevice, c->stream));
     if (modes && modes_bytes)
       HIP_TRY(hipMemcpyAsync(modes, c->d_modes.p, modes_bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -918,7 +1009,7 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   if (deferred) c->pending_total = total;
   else if (total) HIP_TRY(hipMemcpyAsync(out, d_outp, (size_t)total, hipMemcpyDeviceToHost, c->stream));
   if (chunk_sizes && n_chunks)
-    HIP_TRY(hipMemcpyAsync(chunk_sizes, c->d_payload.p, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost,
+    HIP_TRY(hipMemcpyAsync(chunk_sizes, d_sizes, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost,
                            c->stream));
   if (modes && modes_bytes) HIP_TRY(hipMemcpyAsync(modes, c->d_modes.p, modes_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -785,6 +785,20 @@ size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output,
     s1_cap = tl_stage1.size();
   }
   impl_->chunk_sizes.resize(n_chunks);
+  if (info_.compression_opt == CompressionOption::LZ4 && amd_detail::deviceLz4()) {
+    // stage 2 on the device as well: the codec writes [u32 size][LZ4 block] per chunk straight
+    // into the caller's buffer. Valid LZ4 blocks (the reference's decoder reads them), not lz4's own bytes.
+    struct Reset {
+      cldn_hip_codec_t* codec;
+      ~Reset() { (void)cldn_hip_codec_set_stage2(codec, CLDN_HIP_STAGE2_NONE); }  // the codec goes back to the pool
+    } reset{impl_->codec};
+    if (cldn_hip_codec_set_stage2(impl_->codec, CLDN_HIP_STAGE2_LZ4) != CLDN_HIP_OK) throw std::runtime_error(cldn_hip_last_error());
+    uint64_t offsets[2] = {0, 0};
+    if (cldn_hip_encode_stage1(impl_->codec, cloud_data.data(), CLDN_HIP_HOST, &points, 1, dst + written, output.size() - written,
+                               CLDN_HIP_HOST, offsets, impl_->chunk_sizes.data(), nullptr) != CLDN_HIP_OK)
+      throw std::runtime_error(cldn_hip_last_error());
+    return written + static_cast<size_t>(offsets[1]);
+  }
   const unsigned workers = (info_.use_threads && n_chunks > 1) ? std::min<unsigned>(stage2Threads(), unsigned(n_chunks)) : 1u;
   if (!direct && workers > 1u && n_chunks >= kPipelineMinChunks && pipelineGroups(workers) >= 2u)
     return written + encodePipelined(cloud_data, points, n_chunks, workers, dst + written, output.size() - written,
@@ -974,6 +988,20 @@ void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compres
 }
 
 namespace amd_detail {
+
+namespace {
+std::atomic<int> g_device_lz4{-1};  // -1: not decided yet (environment)
+}
+bool deviceLz4() {
+  int v = g_device_lz4.load();
+  if (v < 0) {
+    const char* e = std::getenv("CLOUDINI_AMD_DEVICE_LZ4");
+    v = (e && std::atoi(e) != 0) ? 1 : 0;
+    g_device_lz4.store(v);
+  }
+  return v != 0;
+}
+void setDeviceLz4(bool on) { g_device_lz4.store(on ? 1 : 0); }
 
 void encodeStage1Batch(const EncodingInfo& info, const uint8_t* const* cloud_ptrs, const uint64_t* cloud_points,
                        uint32_t n_clouds, const std::function<uint8_t*(uint64_t)>& grow, std::vector<uint64_t>& stream_offsets,

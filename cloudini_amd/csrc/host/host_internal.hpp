@@ -35,6 +35,10 @@ struct ChunkRef {
 // (src/cloudini.cpp:645-664; same error strings). `points` = width * height of the header.
 void walkCompressedChunks(Cloudini::ConstBufferView data, uint64_t points, std::vector<ChunkRef>& refs);
 // detail::DecompressChunk (src/codec_common.cpp:260-300): LZ4 block / ZSTD frame / plain copy -> stage-1 bytes
+// LZ4 streams with stage 2 on the device (cldn_hip_codec_set_stage2): off unless CLOUDINI_AMD_DEVICE_LZ4=1 or the setter
+bool deviceLz4();
+void setDeviceLz4(bool on);
+
 uint32_t decompressChunkTo(Cloudini::CompressionOption opt, const uint8_t* src, size_t size, uint8_t* dst, size_t dst_cap);
 // worst-case stage-1 bytes of one 32768-point chunk of this schema (without its [u32 size])
 size_t stage1ChunkBound(const Cloudini::EncodingInfo& info);

@@ -2297,6 +2297,43 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   return CLDN_HIP_OK;
 }
 
+int stage1_launch_frame(const FrameLaunch& L) {
+  hipError_t e;
+  if (L.n_chunks == 0u) {
+    if ((e = hipMemsetAsync(L.stream_offsets, 0, (size_t)(L.n_clouds + 1u) * sizeof(uint64_t), L.stream)) != hipSuccess)
+      return hip_fail(e, "hipMemsetAsync(stream_offsets)");
+    return CLDN_HIP_OK;
+  }
+  FinishArgs F;
+  F = FinishArgs{};
+  F.chunks = L.chunks;
+  F.n_chunks = L.n_chunks;
+  F.cloud_first_chunk = L.cloud_first_chunk;
+  F.n_clouds = L.n_clouds;
+  F.slots = L.slots;
+  F.slot_stride = L.slot_stride;
+  F.segs = L.segs;
+  F.segs_per_chunk = L.segs_per_chunk;
+  F.subs = L.segs_per_chunk;
+  F.rec = L.rec;
+  F.rec2 = nullptr;
+  F.anchor = L.anchor;
+  F.epoch = L.epoch;
+  F.ticket = L.ticket;
+  F.use_ticket = 0u;
+  F.chunk_payload = L.chunk_payload;
+  F.chunk_dst = L.chunk_dst;
+  F.stream_offsets = L.stream_offsets;
+  F.out = L.out;
+  F.out_capacity = L.out_capacity;
+  F.status = L.status;
+  F.fuse_field = kNoFusedField;
+  F.splits = L.n_chunks >= 1024u ? 1u : (L.n_chunks >= 256u ? 4u : 16u);
+  hipLaunchKernelGGL((k_finish<256, 0>), dim3(L.n_chunks * F.splits), dim3(256), 0, L.stream, F);
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_finish (frame)");
+  return CLDN_HIP_OK;
+}
+
 static_assert(sizeof(DecChunk) <= kDecChunkBytes, "DecodeLaunch::chunks entries must hold a DecChunk");
 
 // wire version 2: one unframed payload, decoded by the serial restatement of DecodeV4Stage1Chunk (one lane)

@@ -87,6 +87,56 @@ int stage1_launch_decode(const DecodeLaunch& L);
 int stage1_launch_decode_unframed(const DevPlan& plan, hipStream_t stream, const uint8_t* payload, uint32_t size,
                                   uint32_t capacity_points, void* chunk_slot, uint8_t* out, uint32_t* status);
 
+// k_finish alone (no section work): frames the chunks of a batch -- one or more segments per chunk in per-chunk slots --
+// as [u32 size][bytes] streams. Used for the chunks the device-side stage 2 leaves (lz4_kernels.hip).
+struct FrameLaunch {
+  hipStream_t stream;
+  const ChunkDesc* chunks;
+  uint32_t n_chunks;
+  const uint32_t* cloud_first_chunk;
+  uint32_t n_clouds;
+  const uint8_t* slots;
+  uint64_t slot_stride;
+  const Seg* segs;
+  uint32_t segs_per_chunk;
+  unsigned long long* rec;     // [n_chunks], tagged with epoch
+  unsigned long long* anchor;  // [n_chunks / 1024 + 1], zero at launch
+  uint32_t epoch;
+  uint32_t* ticket;            // zero at launch
+  uint32_t* chunk_payload;     // out
+  uint64_t* chunk_dst;         // out
+  uint64_t* stream_offsets;    // out
+  uint8_t* out;
+  uint64_t out_capacity;
+  uint32_t* status;
+};
+int stage1_launch_frame(const FrameLaunch& F);
+
+// ---- stage 2 on the device: LZ4 block per chunk (lz4_kernels.hip; parameters shared with oracle/lz4_model.c) ----
+constexpr uint32_t kLzSubBytes = 16384;   // a wave parses this much of a payload with its own hash table
+constexpr uint32_t kLzHashBits = 12;
+constexpr uint32_t kLzMaxMatches = 2048;  // per sub-range (the rest of it leaves as literals)
+constexpr uint32_t kLzMaxSubs = 1024;     // sub-ranges per chunk the emitter can index (16 MiB payloads); beyond: literals only
+struct LzMatch {
+  uint32_t pos;  // in the chunk's payload
+  uint16_t len;  // 4 .. kLzSubBytes
+  uint16_t off;  // 1 .. kLzSubBytes - 1
+};
+struct Lz4Launch {
+  hipStream_t stream;
+  const uint8_t* stage1;          // framed stage-1 streams (the payload of chunk c starts at chunk_dst[c] + 4)
+  const uint64_t* chunk_dst;
+  const uint32_t* chunk_payload;
+  uint32_t n_chunks;
+  uint32_t subs_per_chunk;        // ceil(largest possible payload / kLzSubBytes)
+  LzMatch* matches;               // [n_chunks * subs_per_chunk * kLzMaxMatches]
+  uint32_t* counts;               // [n_chunks * subs_per_chunk]
+  uint8_t* out_slots;             // [n_chunks * out_stride]: the blocks
+  uint64_t out_stride;
+  Seg* out_segs;                  // [n_chunks]: {0, block size}
+};
+int lz4_launch(const Lz4Launch& L);
+
 // applyVizLossyPreprocessing (viz_kernels.hip)
 struct VizLaunch {
   hipStream_t stream;

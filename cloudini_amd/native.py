@@ -97,6 +97,10 @@ def lib() -> C.CDLL:
     L.cldn_hip_codec_decode_stats.restype = C.c_int
     L.cldn_hip_codec_force_modes.argtypes = [vp, C.POINTER(C.c_uint8), C.c_uint32]
     L.cldn_hip_codec_force_modes.restype = C.c_int
+    L.cldn_hip_codec_set_stage2.argtypes = [vp, C.c_int]
+    L.cldn_hip_codec_set_stage2.restype = C.c_int
+    L.cldn_hip_stage2_bound.argtypes = [vp, C.c_uint64, C.c_int]
+    L.cldn_hip_stage2_bound.restype = C.c_uint64
     L.cldn_hip_codec_pipeline.argtypes = [vp, C.c_int, vp]
     L.cldn_hip_codec_pipeline.restype = C.c_int
     L.cldn_hip_encode_stage1.restype = C.c_int
@@ -162,6 +166,9 @@ class Plan:
     def stage1_bound(self, n_points: int) -> int:
         return int(lib().cldn_hip_stage1_bound(self._h, int(n_points)))
 
+    def stage2_bound(self, n_points: int, stage2: int) -> int:
+        return int(lib().cldn_hip_stage2_bound(self._h, int(n_points), int(stage2)))
+
 
 class Codec:
     """cldn_hip_codec_t: device, stream and workspace. `stream` is a raw hipStream_t value (int) or None."""
@@ -216,6 +223,11 @@ class Codec:
         m = np.ascontiguousarray(modes, dtype=np.uint8)
         _check(lib().cldn_hip_codec_force_modes(self._h, m.ctypes.data_as(C.POINTER(C.c_uint8)), m.size))
 
+    def set_stage2(self, stage2: int):
+        """0 = stage-1 streams (default), 1 = [u32 size][LZ4 block] per chunk, compressed on the device."""
+        _check(lib().cldn_hip_codec_set_stage2(self._h, int(stage2)))
+        self._stage2 = int(stage2)
+
     def pipeline(self, mode: int = 0, points_ptr: int = 0) -> int:
         """Choose the encoder pipeline (cldn_hip_codec_pipeline: 0 auto, 1 tile kernel + slots, 2 piece kernel + slots);
         returns the pipeline the next call takes."""
@@ -241,7 +253,7 @@ class Codec:
             if a.size % step:
                 raise ValueError("Input cloud_data size is not a multiple of point_step")
         data = np.concatenate(arrs) if arrs else np.zeros(0, np.uint8)
-        cap = int(sum(self.plan.stage1_bound(int(n)) for n in npts))
+        cap = int(sum(self.plan.stage2_bound(int(n), getattr(self, "_stage2", 0)) for n in npts))
         out = np.empty(max(cap, 1), dtype=np.uint8)
         offs = np.zeros(len(arrs) + 1, dtype=np.uint64)
         n_chunks = int(sum((int(n) + 32767) // 32768 for n in npts))

@@ -131,6 +131,19 @@ int cldn_hip_encode_stage1_gather(cldn_hip_codec_t* codec, const void* const* cl
                                   uint32_t n_clouds, void* out, uint64_t out_capacity, int out_loc,
                                   uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes);
 
+/* Stage 2 on the device (what it replaces: CompressChunk with LZ4_compress_default,
+ * src/codec_common.cpp:220-258, fed by WriteStage1Chunk, src/chunk_writer.cpp:27-48). With CLDN_HIP_STAGE2_LZ4 the encode
+ * calls of this codec write, for every chunk, [u32 LE block size][LZ4 block of the chunk's stage-1 payload] -- the bytes
+ * a stream with compression_opt == LZ4 holds behind its header; chunk_sizes then reports the block sizes and the
+ * capacity `out` must offer is sum_k cldn_hip_stage2_bound(plan, cloud_points[k], CLDN_HIP_STAGE2_LZ4)
+ * (= MaxCompressedSize for LZ4, src/cloudini.cpp:249-292). The blocks are valid LZ4 blocks that LZ4_decompress_safe
+ * (the reference's DecompressChunk, src/codec_common.cpp:260-299) turns back into the exact stage-1 payloads; they are
+ * NOT the bytes lz4's own compressor would write (a different, data-parallel parse: cloudini_amd/csrc/lz4_kernels.hip,
+ * restated serially in oracle/lz4_model.c). The setting stays until changed. Default: CLDN_HIP_STAGE2_NONE. */
+enum { CLDN_HIP_STAGE2_NONE = 0, CLDN_HIP_STAGE2_LZ4 = 1 };
+int cldn_hip_codec_set_stage2(cldn_hip_codec_t* codec, int stage2);
+uint64_t cldn_hip_stage2_bound(const cldn_hip_plan_t* plan, uint64_t n_points, int stage2);
+
 /* Continuation of one cloud across several calls / devices. The reference commits the adaptive-int modes once per
  * encode() call, on the first <= 4096 points of the cloud (src/v5_codec.cpp:934-949), and resets every other
  * state at each 32768-point chunk (:910-915). A range of whole chunks of a cloud can therefore be encoded on

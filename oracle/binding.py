@@ -174,6 +174,19 @@ class Oracle:
             raise OracleError(f"orc_decode_stage1 failed: {r}")
         return out
 
+    def lz4_model(self, payload, sub_bytes: int = 16384, hash_bits: int = 12, max_matches: int = 2048) -> np.ndarray:
+        """Serial model of the device-side LZ4 block compressor (oracle/lz4_model.c): the block for `payload`."""
+        a = _as_u8(payload)
+        self.lib.orc_lz4_bound.restype = C.c_uint32
+        self.lib.orc_lz4_compress.restype = C.c_int64
+        self.lib.orc_lz4_compress.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        cap = int(self.lib.orc_lz4_bound(C.c_uint32(a.size)))
+        out = np.empty(max(1, cap), dtype=np.uint8)
+        n = self.lib.orc_lz4_compress(a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap, sub_bytes, hash_bits, max_matches)
+        if n < 0:
+            raise RuntimeError("orc_lz4_compress failed")
+        return out[:n].copy()
+
     def encode_varint64(self, v: int) -> bytes:
         buf = (C.c_uint8 * 16)()
         n = self.lib.orc_encode_varint64(v, buf)
