@@ -255,6 +255,23 @@ def e2e_figures(info, cloud, dev, budget_s: float):
             leg16["stage2_threads"] = 16
             leg16["bracket"] = leg["bracket"] + "; CLOUDINI_AMD_STAGE2_THREADS=16, chunk-group pipeline (2 groups)"
             out["host_mirror_LZ4_16_threads"] = leg16
+        if comp == CompressionOption.LZ4 and hasattr(api, "set_device_lz4"):
+            # stage 2 on the GPU as well (valid LZ4 blocks, not lz4's own bytes); the stream is
+            # checked through the reference's decoder once, outside the timed calls
+            api.set_device_lz4(True)
+            try:
+                legd = timed(mirror_call)
+                dev_stream = hout[: size_box[0]].copy()
+            finally:
+                api.set_device_lz4(False)
+            legd["bytes"] = int(size_box[0])
+            legd["stage2_threads"] = 0
+            legd["bracket"] = leg["bracket"] + "; CLOUDINI_AMD_DEVICE_LZ4=1: LZ4 blocks written by the GPU (lz4_kernels.hip)"
+            if ref is not None:
+                back, _y = ref.decode(dev_stream, cloud.size)
+                want, _y = ref.decode(stream, cloud.size)
+                legd["decodes_through_reference_to_the_same_points"] = bool(np.array_equal(back, want))
+            out["host_mirror_LZ4_device"] = legd
     return out
 
 

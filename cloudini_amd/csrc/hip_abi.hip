@@ -896,10 +896,11 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
     // stage 2 on the device: an LZ4 block per chunk payload (lz4_kernels.hip), framed by k_finish like the payloads were
     uint64_t chunk_bound = (uint64_t)kPointsPerChunk * c->plan.ref_max_point_bytes;
     if (c->plan.uses_v5) chunk_bound += (uint64_t)c->plan.fields.size() * 32u + 1024u;
-    const uint32_t spc = (uint32_t)((chunk_bound + kLzSubBytes - 1u) / kLzSubBytes);
+    // every chunk has ceil(payload / 16 KiB) sub-ranges; the payloads of the batch are bounded by need_s1
+    const uint64_t max_subs = need_s1 / kLzSubBytes + n_chunks;
     const uint64_t out_stride = (lz4_block_bound(chunk_bound) + 255u) & ~uint64_t(255);
-    if ((rc = c->d_lz_matches.ensure((size_t)n_chunks * spc * kLzMaxMatches * sizeof(LzMatch))) != CLDN_HIP_OK) return rc;
-    if ((rc = c->d_lz_counts.ensure((size_t)n_chunks * spc * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_lz_matches.ensure((size_t)max_subs * kLzMaxMatches * sizeof(LzMatch))) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_lz_counts.ensure((size_t)(max_subs * 4u + n_chunks + 1u) * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_lz_slots.ensure((size_t)n_chunks * out_stride)) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_lz_segs.ensure((size_t)n_chunks * sizeof(Seg))) != CLDN_HIP_OK) return rc;
     Lz4Launch Z;
@@ -908,9 +909,13 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
     Z.chunk_dst = (const uint64_t*)c->d_dst.p;
     Z.chunk_payload = (const uint32_t*)c->d_payload.p;
     Z.n_chunks = n_chunks;
-    Z.subs_per_chunk = spc;
+    Z.max_subs = max_subs;
     Z.matches = (LzMatch*)c->d_lz_matches.p;
     Z.counts = (uint32_t*)c->d_lz_counts.p;
+    Z.last_end = Z.counts + max_subs;
+    Z.anchor_in = Z.last_end + max_subs;
+    Z.sub_size = Z.anchor_in + max_subs;
+    Z.sub_first = Z.sub_size + max_subs;
     Z.out_slots = (uint8_t*)c->d_lz_slots.p;
     Z.out_stride = out_stride;
     Z.out_segs = (Seg*)c->d_lz_segs.p;

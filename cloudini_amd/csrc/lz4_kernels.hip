@@ -8,19 +8,24 @@
 // only, the last 5 bytes literals, no match starting within the last 12 bytes.
 //
 // The algorithm is deterministic and restated serially in oracle/lz4_model.c (the GPU tests ask for byte equality):
-//   k_lz4_match   one wave per 16 KiB sub-range of a chunk's payload: the sub-range is staged in LDS next to a hash table
+//   k_lz4_plan    sub-ranges per chunk -> compact numbering (one scan).
+//   k_lz4_match   one wave per 8 KiB sub-range of a chunk's payload: the sub-range is staged in LDS next to a hash table
 //                 of its own positions (4096 entries, atomicMax = the most recent position wins), so every byte the
-//                 parser touches is an LDS access. Per step the 64 lanes look at 64 consecutive positions, the first
-//                 lane with a verified 4-byte match wins, the wave extends it cooperatively (64 bytes per compare),
-//                 enters the positions up to the match start and jumps behind the match. Matches never leave their
-//                 sub-range; output = the ordered list of (position, length, offset) per sub-range.
-//   k_lz4_emit    one workgroup per chunk: sequence sizes from the match lists (a sequence's literals start where the
-//                 previous match ended, whichever sub-range that was in), their prefix sum, then headers by lanes and
-//                 literals by whole waves, the trailing literals by the whole workgroup.
+//                 parser touches is an LDS access. Per step the 64 lanes look at 64 consecutive positions: every lane
+//                 with a verified 4-byte hit extends its own match (4 bytes per round; the whole wave finishes what is
+//                 still open after 3 rounds), all 64 positions enter the table, and the step's matches are taken greedily
+//                 in position order. Matches never leave their sub-range; output = the ordered list of (position,
+//                 length, offset) per sub-range.
+//   k_lz4_sizes   per sub-range: bytes of its sequences (a sequence's literals start where the previous match ended,
+//                 whichever sub-range that was in).
+//   k_lz4_emit    per sub-range: headers and match fields by lanes; every literal byte is copied by the wave of the
+//                 sub-range it lies in, so no wave ever moves more than 8 KiB however long a literal run is.
 // The compressed chunks are left in per-chunk slots of their worst-case size; k_finish (stage1_finish.h) frames them as
 // [u32 size][block] exactly as it frames stage-1 payloads.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <algorithm>
 
 #include "cloudini_hip.h"
 #include "stage1_device.h"
@@ -32,7 +37,6 @@ namespace {
 
 constexpr uint32_t kLzHashMul = 2654435761u;
 constexpr uint32_t kLzTableSize = 1u << kLzHashBits;
-constexpr uint32_t kLzEmitThreads = 256;
 
 __device__ __forceinline__ uint32_t lz_wave_excl_scan(uint32_t x, uint32_t lane, uint32_t* total) {
   uint32_t incl = x;
@@ -66,182 +70,276 @@ __device__ __forceinline__ uint32_t lz_lds_u32(const uint32_t* base, uint32_t by
   return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> ((byte_off & 3u) * 8u));
 }
 
-// n bytes, any alignment on both sides, by `nthreads` threads (this thread = t): dwords through unaligned accesses
-__device__ __forceinline__ void lz_copy(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t n, uint32_t t,
-                                        uint32_t nthreads) {
-  const uint32_t n4 = n >> 2;
-  for (uint32_t i = t; i < n4; i += nthreads) {
-    uint32_t w;
-    __builtin_memcpy(&w, src + 4u * i, 4);
-    __builtin_memcpy(dst + 4u * i, &w, 4);
-  }
-  const uint32_t done = n4 << 2;
-  if (t < (n & 3u)) dst[done + t] = src[done + t];
-}
-
 }  // namespace
 
-// grid = n_chunks * subs_per_chunk workgroups of one wave
-__global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ stream, const uint64_t* __restrict__ chunk_dst,
-                                                  const uint32_t* __restrict__ chunk_payload, uint32_t subs_per_chunk,
-                                                  LzMatch* __restrict__ matches, uint32_t* __restrict__ counts) {
-  __shared__ uint32_t data[kLzSubBytes / 4u + 4u];  // the sub-range (+ slack for the straddling dword reads)
-  __shared__ uint32_t table[kLzTableSize];          // position inside the sub-range + 1; 0 = free
-  const uint32_t lane = threadIdx.x;
-  const uint32_t c = blockIdx.x / subs_per_chunk, k = blockIdx.x % subs_per_chunk;
-  const uint32_t n = chunk_payload[c];
-  const uint32_t s = k * kLzSubBytes;
-  if (s >= n) return;  // (k_lz4_emit only looks at the sub-ranges the payload has)
-  const uint32_t e = n - s < kLzSubBytes ? n : s + kLzSubBytes;
-  const uint8_t* in = stream + chunk_dst[c] + 4u;
-  LzMatch* out = matches + (size_t)blockIdx.x * kLzMaxMatches;
-  uint32_t count = 0u;
-
-  if (n >= 13u && e - s >= 4u) {
-    {  // stage [s, e) in LDS: unaligned dword loads, aligned LDS stores; bytes behind e read as 0
-      const uint32_t bytes = e - s;
-      const uint8_t* src = in + s;
-      for (uint32_t i = lane; i < kLzSubBytes / 4u + 4u; i += 64u) {
-        uint32_t w = 0u;
-        if (4u * i + 4u <= bytes) {
-          __builtin_memcpy(&w, src + 4u * i, 4);
-        } else if (4u * i < bytes) {
-          for (uint32_t b = 0; 4u * i + b < bytes; ++b) w |= (uint32_t)src[4u * i + b] << (8u * b);
-        }
-        data[i] = w;
-      }
-      for (uint32_t i = lane; i < kLzTableSize; i += 64u) table[i] = 0u;
-    }
-    __syncthreads();
-    // positions below are relative to s
-    const int32_t last_start = min((int32_t)(e - s) - 4, (int32_t)n - 12 - (int32_t)s);  // last position a match may start at
-    const uint32_t end_limit = min(e, n - 5u) - s;                                        // where a match ends at the latest
-    const uint8_t* bytes = reinterpret_cast<const uint8_t*>(data);
-    int32_t i = 0;
-    while (i <= last_start && count < kLzMaxMatches) {
-      const int32_t p = i + (int32_t)lane;
-      const bool active = p <= last_start;
-      const uint32_t seq = lz_lds_u32(data, active ? (uint32_t)p : 0u);
-      const uint32_t h = (seq * kLzHashMul) >> (32u - kLzHashBits);
-      const uint32_t cand = active ? table[h] : 0u;
-      const bool ok = cand != 0u && lz_lds_u32(data, cand - 1u) == seq;
-      const uint64_t m = __ballot(ok);
-      const uint32_t f = m ? (uint32_t)__builtin_ctzll(m) : 63u;
-      // (the lanes have read the table: the LDS operations of a wave are performed in order)
-      if (active && lane <= f) atomicMax(&table[h], (uint32_t)p + 1u);
-      if (m == 0ull) {
-        i += 64;
-        continue;
-      }
-      const uint32_t pm = (uint32_t)i + f;
-      const uint32_t cf = (uint32_t)__shfl((int)cand, (int)f) - 1u;
-      uint32_t len = 4u;
-      const uint32_t maxlen = end_limit - pm;
-      while (len < maxlen) {  // 64 bytes per compare
-        const uint32_t q = len + lane;
-        const bool differ = q >= maxlen || bytes[pm + q] != bytes[cf + q];
-        const uint64_t d = __ballot(differ);
-        const uint32_t same = d ? (uint32_t)__builtin_ctzll(d) : 64u;
-        len += same;
-        if (same < 64u) break;
-      }
-      if (lane == 0u) {
-        LzMatch rec;
-        rec.pos = s + pm;
-        rec.len = (uint16_t)len;  // <= kLzSubBytes = 16384
-        rec.off = (uint16_t)(pm - cf);
-        out[count] = rec;
-      }
-      ++count;
-      i = (int32_t)(pm + len);
-    }
+// n bytes, any alignment, by one wave: 16 bytes per lane and step through unaligned accesses
+__device__ __forceinline__ void lz_copy_wave(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint32_t n, uint32_t lane) {
+  const uint32_t n16 = n >> 4;
+  for (uint32_t i = lane; i < n16; i += 64u) {
+    uint4 w;
+    __builtin_memcpy(&w, src + 16u * i, 16);
+    __builtin_memcpy(dst + 16u * i, &w, 16);
   }
-  if (lane == 0u) counts[blockIdx.x] = count;
+  const uint32_t done = n16 << 4;
+  if (lane < (n & 15u)) dst[done + lane] = src[done + lane];
 }
 
-// grid = n_chunks
-__global__ __launch_bounds__(kLzEmitThreads) void k_lz4_emit(const uint8_t* __restrict__ stream, const uint64_t* __restrict__ chunk_dst,
-                                                             const uint32_t* __restrict__ chunk_payload, uint32_t subs_per_chunk,
-                                                             const LzMatch* __restrict__ matches, const uint32_t* __restrict__ counts,
-                                                             uint8_t* __restrict__ out_slots, uint64_t out_stride,
-                                                             Seg* __restrict__ out_segs) {
-  __shared__ uint32_t cnt[kLzMaxSubs], anchor_in[kLzMaxSubs], sub_size[kLzMaxSubs], out_base[kLzMaxSubs];
-  __shared__ uint32_t tail_anchor, tail_at;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr uint32_t NW = kLzEmitThreads / 64u;
-  const uint32_t c = blockIdx.x;
-  const uint32_t n = chunk_payload[c];
-  const uint8_t* in = stream + chunk_dst[c] + 4u;
-  uint8_t* out = out_slots + (size_t)c * out_stride;
-  uint32_t nsub = (n + kLzSubBytes - 1u) / kLzSubBytes;
-  const LzMatch* mbase = matches + (size_t)c * subs_per_chunk * kLzMaxMatches;
-  // (a payload with more sub-ranges than the tables hold -- beyond 16 MiB -- leaves as literals only: valid, not smaller)
-  const bool use_matches = nsub <= kLzMaxSubs;
-  if (!use_matches) nsub = 0u;
+// chunk of compact sub-range index `idx`: the last c with sub_first[c] <= idx
+__device__ __forceinline__ uint32_t lz_chunk_of(const uint32_t* __restrict__ sub_first, uint32_t n_chunks, uint32_t idx) {
+  uint32_t lo = 0u, hi = n_chunks;  // invariant: sub_first[lo] <= idx < sub_first[hi]
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (sub_first[mid] <= idx) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
 
-  // A: matches per sub-range, and where the last one ends
-  for (uint32_t k = tid; k < nsub; k += kLzEmitThreads) {
-    const uint32_t m = counts[(size_t)c * subs_per_chunk + k];
-    cnt[k] = m;
-    uint32_t last_end = 0u;
-    if (m) {
-      const LzMatch r = mbase[(size_t)k * kLzMaxMatches + m - 1u];
-      last_end = r.pos + r.len;
-    }
-    sub_size[k] = last_end;  // (parked here until step B has read it)
-  }
+// one workgroup: sub_first[c] = sub-ranges of the chunks before c (sub_first[n_chunks] = all of them)
+// (a chunk without a byte of payload has no sub-range and no wave below: its block, the single token 0x00, is written here)
+__global__ __launch_bounds__(1024) void k_lz4_plan(const uint32_t* __restrict__ chunk_payload, uint32_t n_chunks,
+                                                   uint32_t* __restrict__ sub_first, uint8_t* __restrict__ out_slots,
+                                                   uint64_t out_stride, Seg* __restrict__ out_segs) {
+  __shared__ uint32_t wtot[16];
+  __shared__ uint32_t carry;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0u) carry = 0u;
   __syncthreads();
-  // B: a sub-range's first sequence takes its literals from the end of the last match before it
-  if (tid == 0u) {
+  for (uint32_t base = 0; base < n_chunks; base += 1024u) {
+    const uint32_t c = base + tid;
+    const uint32_t mine = c < n_chunks ? (chunk_payload[c] + kLzSubBytes - 1u) / kLzSubBytes : 0u;
+    if (c < n_chunks && mine == 0u) {
+      out_slots[(size_t)c * out_stride] = 0u;
+      Seg sg;
+      sg.off = 0u;
+      sg.size = 1u;
+      out_segs[c] = sg;
+    }
+    uint32_t wsum;
+    const uint32_t excl = lz_wave_excl_scan(mine, lane, &wsum);
+    if (lane == 0u) wtot[wave] = wsum;
+    __syncthreads();
+    uint32_t before = carry;
+    for (uint32_t w = 0; w < wave; ++w) before += wtot[w];
+    if (c < n_chunks) sub_first[c] = before + excl;
+    __syncthreads();
+    if (tid == 1023u) carry = before + excl + mine;
+    __syncthreads();
+  }
+  if (tid == 0u) sub_first[n_chunks] = carry;
+}
+
+// workgroups of one wave; every workgroup takes the sub-ranges blockIdx.x, blockIdx.x + gridDim.x, ...
+__global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ stream, const uint64_t* __restrict__ chunk_dst,
+                                                  const uint32_t* __restrict__ chunk_payload, uint32_t n_chunks,
+                                                  const uint32_t* __restrict__ sub_first, LzMatch* __restrict__ matches,
+                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ last_end) {
+  __shared__ __attribute__((aligned(16))) uint32_t data[kLzSubBytes / 4u + 8u];  // the sub-range (+ slack for the straddling dword reads)
+  __shared__ uint32_t table[kLzTableSize];          // position inside the sub-range + 1; 0 = free
+  const uint32_t lane = threadIdx.x;
+  const uint32_t total = sub_first[n_chunks];
+  for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
+    const uint32_t c = lz_chunk_of(sub_first, n_chunks, idx);
+    const uint32_t k = idx - sub_first[c];
+    const uint32_t n = chunk_payload[c];
+    const uint32_t s = k * kLzSubBytes;
+    const uint32_t e = n - s < kLzSubBytes ? n : s + kLzSubBytes;
+    const uint8_t* in = stream + chunk_dst[c] + 4u;
+    LzMatch* out = matches + (size_t)idx * kLzMaxMatches;
+    uint32_t count = 0u, lend = 0u;
+    __syncthreads();  // the previous sub-range's LDS contents are done with
+    if (n >= 13u && e - s >= 4u) {
+      {  // stage [s, e) in LDS: unaligned dword loads, aligned LDS stores; bytes behind e read as 0
+        const uint32_t bytes = e - s;
+        const uint8_t* src = in + s;
+        const uint32_t full = bytes >> 4;  // 16 bytes per lane and load (unaligned dwordx4), all loads before the stores
+        constexpr uint32_t kRounds = kLzSubBytes / 16u / 64u;
+        uint4 w[kRounds];
+#pragma unroll
+        for (uint32_t r = 0; r < kRounds; ++r) {
+          const uint32_t i = r * 64u + lane;
+          w[r] = make_uint4(0u, 0u, 0u, 0u);
+          if (i < full) __builtin_memcpy(&w[r], src + 16u * i, 16);
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < kRounds; ++r) reinterpret_cast<uint4*>(data)[r * 64u + lane] = w[r];
+        if (lane < 2u) reinterpret_cast<uint4*>(data)[kLzSubBytes / 16u + lane] = make_uint4(0u, 0u, 0u, 0u);  // the slack
+        __syncthreads();
+        if (lane < (bytes & 15u)) reinterpret_cast<uint8_t*>(data)[(full << 4) + lane] = src[(full << 4) + lane];  // last partial unit
+        for (uint32_t i = lane; i < kLzTableSize; i += 64u) table[i] = 0u;
+      }
+      __syncthreads();
+      // positions below are relative to s
+      const int32_t last_start = min((int32_t)(e - s) - 4, (int32_t)n - 12 - (int32_t)s);  // last position a match may start at
+      const uint32_t end_limit = min(e, n - 5u) - s;                                        // where a match ends at the latest
+      const uint8_t* bytes = reinterpret_cast<const uint8_t*>(data);
+      int32_t i = 0;
+      while (i <= last_start && count < kLzMaxMatches) {
+        const int32_t p = i + (int32_t)lane;
+        const bool active = p <= last_start;
+        const uint32_t seq = lz_lds_u32(data, active ? (uint32_t)p : 0u);
+        const uint32_t h = (seq * kLzHashMul) >> (32u - kLzHashBits);
+        const uint32_t cand = active ? table[h] : 0u;
+        const bool ok = cand != 0u && lz_lds_u32(data, cand - 1u) == seq;
+        // every hit extends its own match, 4 bytes per round, up to kLaneRounds rounds; what is still open then is
+        // finished by the whole wave when (and if) the match is taken
+        constexpr uint32_t kLaneRounds = 3u;
+        const uint32_t maxlen = ok ? end_limit - (uint32_t)p : 0u;
+        uint32_t len = ok ? 4u : 0u;
+        bool going = ok && len < maxlen;
+        for (uint32_t r = 0; r < kLaneRounds; ++r) {
+          if (__ballot(going) == 0ull) break;
+          if (going) {
+            const uint32_t x = lz_lds_u32(data, (uint32_t)p + len) ^ lz_lds_u32(data, cand - 1u + len);
+            if (x) {
+              len += (uint32_t)__builtin_ctz(x) >> 3;
+              going = false;
+            } else {
+              len += 4u;
+            }
+            if (len >= maxlen) {
+              len = maxlen;
+              going = false;
+            }
+          }
+        }
+        // (the lanes have read the table: the LDS operations of a wave are performed in order)
+        if (active) atomicMax(&table[h], (uint32_t)p + 1u);
+        const uint64_t okmask = __ballot(ok);
+        const uint64_t openmask = __ballot(going);
+        uint32_t cur = 0u;
+        while (count < kLzMaxMatches && cur < 64u) {
+          const uint64_t mask = okmask & (~0ull << cur);
+          if (mask == 0ull) break;
+          const uint32_t f = (uint32_t)__builtin_ctzll(mask);
+          uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f);
+          const uint32_t cf = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)f) - 1u;
+          const uint32_t pm = (uint32_t)i + f;
+          if ((openmask >> f) & 1ull) {  // 64 bytes per compare
+            const uint32_t ml = end_limit - pm;
+            while (L < ml) {
+              const uint32_t q = L + lane;
+              const bool differ = q >= ml || bytes[pm + q] != bytes[cf + q];
+              const uint64_t d = __ballot(differ);
+              const uint32_t same = d ? (uint32_t)__builtin_ctzll(d) : 64u;
+              L += same;
+              if (same < 64u) break;
+            }
+          }
+          if (lane == 0u) {
+            LzMatch rec;
+            rec.pos = s + pm;
+            rec.len = (uint16_t)L;  // <= kLzSubBytes
+            rec.off = (uint16_t)(pm - cf);
+            out[count] = rec;
+          }
+          ++count;
+          lend = s + pm + L;
+          cur = f + L;
+        }
+        i += (int32_t)max(64u, cur);
+      }
+    }
+    if (lane == 0u) {
+      counts[idx] = count;
+      last_end[idx] = lend;  // 0 = no match (a match never ends at 0)
+    }
+  }
+}
+
+namespace {
+// fields of sequence j of sub-range idx (anchor_in = where the literals of its first sequence start)
+__device__ __forceinline__ void lz_seq_fields(const LzMatch* __restrict__ list, uint32_t j, uint32_t anchor_in, uint32_t& lit,
+                                              uint32_t& ml, uint32_t& anchor, LzMatch& r) {
+  r = list[j];
+  if (j) {
+    const LzMatch q = list[j - 1u];
+    anchor = q.pos + q.len;
+  } else {
+    anchor = anchor_in;
+  }
+  lit = r.pos - anchor;
+  ml = (uint32_t)r.len - 4u;
+}
+}  // namespace
+
+// per sub-range: where the literals of its first sequence start (the end of the last match before it in the chunk) and
+// the bytes its sequences take
+__global__ __launch_bounds__(64) void k_lz4_sizes(uint32_t n_chunks, const uint32_t* __restrict__ sub_first,
+                                                  const LzMatch* __restrict__ matches, const uint32_t* __restrict__ counts,
+                                                  const uint32_t* __restrict__ last_end, uint32_t* __restrict__ anchor_in,
+                                                  uint32_t* __restrict__ sub_size) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t total = sub_first[n_chunks];
+  for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
+    const uint32_t c = lz_chunk_of(sub_first, n_chunks, idx);
+    const uint32_t first = sub_first[c];
     uint32_t a = 0u;
-    for (uint32_t k = 0; k < nsub; ++k) {
-      anchor_in[k] = a;
-      if (cnt[k]) a = sub_size[k];
+    for (uint32_t j = idx; j > first;) {  // (uniform; usually one step)
+      --j;
+      const uint32_t le = last_end[j];
+      if (le) {
+        a = le;
+        break;
+      }
     }
-    tail_anchor = a;
-  }
-  __syncthreads();
-  // C: bytes of the sequences of every sub-range
-  auto seq_fields = [&](uint32_t k, uint32_t j, uint32_t& lit, uint32_t& ml, uint32_t& anchor, LzMatch& r) {
-    const LzMatch* list = mbase + (size_t)k * kLzMaxMatches;
-    r = list[j];
-    if (j) {
-      const LzMatch q = list[j - 1u];
-      anchor = q.pos + q.len;
-    } else {
-      anchor = anchor_in[k];
-    }
-    lit = r.pos - anchor;
-    ml = (uint32_t)r.len - 4u;
-  };
-  for (uint32_t k = wave; k < nsub; k += NW) {
+    const LzMatch* list = matches + (size_t)idx * kLzMaxMatches;
+    const uint32_t m = counts[idx];
     uint32_t acc = 0u;
-    for (uint32_t j = lane; j < cnt[k]; j += 64u) {
+    for (uint32_t j = lane; j < m; j += 64u) {
       uint32_t lit, ml, anchor;
       LzMatch r;
-      seq_fields(k, j, lit, ml, anchor, r);
+      lz_seq_fields(list, j, a, lit, ml, anchor, r);
       acc += 1u + lz_ext_bytes(lit) + lit + 2u + lz_ext_bytes(ml);
     }
-    uint32_t total;
-    (void)lz_wave_excl_scan(acc, lane, &total);
-    if (lane == 0u) sub_size[k] = total;
-  }
-  __syncthreads();
-  // D: where every sub-range's sequences go
-  if (tid == 0u) {
-    uint32_t o = 0u;
-    for (uint32_t k = 0; k < nsub; ++k) {
-      out_base[k] = o;
-      o += sub_size[k];
+    uint32_t sum;
+    (void)lz_wave_excl_scan(acc, lane, &sum);
+    if (lane == 0u) {
+      anchor_in[idx] = a;
+      sub_size[idx] = sum;
     }
-    tail_at = o;
   }
-  __syncthreads();
-  // E: the sequences. Headers and match fields by their lanes, literals by the whole wave
-  for (uint32_t k = wave; k < nsub; k += NW) {
-    uint32_t run = out_base[k];
-    const uint32_t m = cnt[k];
+}
+
+// per sub-range: its sequences (headers and match fields by their lanes) and every LITERAL byte that lies inside the
+// sub-range, whichever sequence it belongs to -- its own, or the next one of the chunk (the bytes behind the sub-range's
+// last match; that sequence may be the block's last, literals-only one). All copies are local: 8 KiB per wave at most.
+__global__ __launch_bounds__(64) void k_lz4_emit(const uint8_t* __restrict__ stream, const uint64_t* __restrict__ chunk_dst,
+                                                 const uint32_t* __restrict__ chunk_payload, uint32_t n_chunks,
+                                                 const uint32_t* __restrict__ sub_first, const LzMatch* __restrict__ matches,
+                                                 const uint32_t* __restrict__ counts, const uint32_t* __restrict__ last_end,
+                                                 const uint32_t* __restrict__ anchor_in, const uint32_t* __restrict__ sub_size,
+                                                 uint8_t* __restrict__ out_slots, uint64_t out_stride, Seg* __restrict__ out_segs) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t total = sub_first[n_chunks];
+  for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
+    const uint32_t c = lz_chunk_of(sub_first, n_chunks, idx);
+    const uint32_t first = sub_first[c], end = sub_first[c + 1u];
+    const uint32_t n = chunk_payload[c];
+    const uint32_t s = (idx - first) * kLzSubBytes;
+    const uint32_t e = n - s < kLzSubBytes ? n : s + kLzSubBytes;
+    const uint8_t* in = stream + chunk_dst[c] + 4u;
+    uint8_t* out = out_slots + (size_t)c * out_stride;
+    // bytes of the sequences before mine / of all sequences; where the last match of the chunk ends
+    uint32_t before = 0u, all = 0u, tail_anchor = 0u;
+    for (uint32_t j = first + lane; j < end; j += 64u) {
+      const uint32_t sz = sub_size[j];
+      all += sz;
+      before += j < idx ? sz : 0u;
+      tail_anchor = max(tail_anchor, last_end[j]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      before += (uint32_t)__shfl_xor((int)before, d);
+      all += (uint32_t)__shfl_xor((int)all, d);
+      tail_anchor = max(tail_anchor, (uint32_t)__shfl_xor((int)tail_anchor, d));
+    }
+    const LzMatch* list = matches + (size_t)idx * kLzMaxMatches;
+    const uint32_t m = counts[idx];
+    const uint32_t a_in = anchor_in[idx];
+
+    // ---- my sequences
+    uint32_t run = before;
     for (uint32_t j0 = 0; j0 < m; j0 += 64u) {
       const uint32_t j = j0 + lane;
       uint32_t lit = 0u, ml = 0u, anchor = 0u, size = 0u;
@@ -250,7 +348,7 @@ __global__ __launch_bounds__(kLzEmitThreads) void k_lz4_emit(const uint8_t* __re
       r.len = 4u;
       r.off = 0u;
       if (j < m) {
-        seq_fields(k, j, lit, ml, anchor, r);
+        lz_seq_fields(list, j, a_in, lit, ml, anchor, r);
         size = 1u + lz_ext_bytes(lit) + lit + 2u + lz_ext_bytes(ml);
       }
       uint32_t tile_total;
@@ -266,41 +364,94 @@ __global__ __launch_bounds__(kLzEmitThreads) void k_lz4_emit(const uint8_t* __re
         *o++ = (uint8_t)(r.off >> 8);
         if (ml >= 15u) (void)lz_put_ext(o, ml);
       }
-      const uint32_t in_tile = min(64u, m - j0);
-      for (uint32_t q = 0; q < in_tile; ++q) {
-        const uint32_t ql = (uint32_t)__shfl((int)lit, (int)q);
-        if (ql == 0u) continue;  // uniform
-        const uint32_t qa = (uint32_t)__shfl((int)anchor, (int)q), qo = (uint32_t)__shfl((int)lit_at, (int)q);
-        lz_copy(in + qa, out + qo, ql, lane, 64u);
+      // literals of these sequences that lie inside my sub-range (the first sequence's may begin before it: those bytes
+      // are copied by the sub-ranges they lie in). Runs of up to kLaneLit bytes by their own lane (all lanes at once,
+      // dwords through unaligned accesses, the last 1-3 bytes singly), longer ones by the whole wave one after the other
+      constexpr uint32_t kLaneLit = 128u;
+      const uint32_t skip = (j < m && anchor < s) ? min(lit, s - anchor) : 0u;  // (only sequence 0 can start before s)
+      const uint32_t clit = lit - skip;
+      const uint8_t* src = in + anchor + skip;
+      uint8_t* dst = out + lit_at + skip;
+      {
+        const bool mine = j < m && clit <= kLaneLit;
+        const uint32_t words = mine ? (clit >> 2) : 0u;
+        uint32_t wmax = words;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d));
+        for (uint32_t i = 0; i < wmax; ++i) {
+          if (i < words) {
+            uint32_t w;
+            __builtin_memcpy(&w, src + 4u * i, 4);
+            __builtin_memcpy(dst + 4u * i, &w, 4);
+          }
+        }
+        if (mine)
+          for (uint32_t b = words << 2; b < clit; ++b) dst[b] = src[b];
+      }
+      uint64_t long_runs = __ballot(j < m && clit > kLaneLit);
+      while (long_runs) {
+        const int q = __builtin_ctzll(long_runs);
+        long_runs &= long_runs - 1ull;
+        const uint32_t ql = (uint32_t)__builtin_amdgcn_readlane((int)clit, q);
+        const uint32_t qa = (uint32_t)__builtin_amdgcn_readlane((int)(anchor + skip), q);
+        const uint32_t qo = (uint32_t)__builtin_amdgcn_readlane((int)(lit_at + skip), q);
+        lz_copy_wave(in + qa, out + qo, ql, lane);
       }
       run += tile_total;
     }
-  }
-  // F: the last sequence, literals only
-  {
-    const uint32_t a = tail_anchor, lit = n - a;
-    uint8_t* o = out + tail_at;
-    const uint32_t hdr = 1u + lz_ext_bytes(lit);
-    if (tid == 0u) {
+
+    // ---- the bytes behind my last match (all of my bytes if I have none): literals of the chunk's NEXT sequence
+    const uint32_t t0 = m ? last_end[idx] : s;
+    if (t0 < e) {
+      // the next sub-range with a match (uniform search; usually the neighbour)
+      uint32_t nxt = end;
+      for (uint32_t j0 = idx + 1u; j0 < end && nxt == end; j0 += 64u) {
+        const uint32_t j = j0 + lane;
+        const uint64_t has = __ballot(j < end && counts[j] != 0u);
+        if (has) nxt = j0 + (uint32_t)__builtin_ctzll(has);
+      }
+      uint32_t a2, dst0;
+      if (nxt < end) {  // first sequence of sub-range nxt: everything between has no sequences, so it starts where mine end
+        a2 = anchor_in[nxt];
+        const LzMatch r0 = matches[(size_t)nxt * kLzMaxMatches];
+        dst0 = before + sub_size[idx] + 1u + lz_ext_bytes(r0.pos - a2);
+      } else {  // the block's last sequence
+        a2 = tail_anchor;
+        dst0 = all + 1u + lz_ext_bytes(n - a2);
+      }
+      lz_copy_wave(in + t0, out + dst0 + (t0 - a2), e - t0, lane);
+    }
+
+    // ---- the last sub-range of the chunk also writes the header of the last sequence and the block's size
+    if (idx + 1u == end && lane == 0u) {
+      const uint32_t lit = n - tail_anchor;
+      uint8_t* o = out + all;
       *o = (uint8_t)((lit < 15u ? lit : 15u) << 4);
       if (lit >= 15u) (void)lz_put_ext(o + 1u, lit);
       Seg sg;
       sg.off = 0u;
-      sg.size = tail_at + hdr + lit;
+      sg.size = all + 1u + lz_ext_bytes(lit) + lit;
       out_segs[c] = sg;
     }
-    lz_copy(in + a, o + hdr, lit, tid, kLzEmitThreads);
   }
 }
 
 int lz4_launch(const Lz4Launch& L) {
   if (L.n_chunks == 0u) return CLDN_HIP_OK;
-  hipLaunchKernelGGL(k_lz4_match, dim3(L.n_chunks * L.subs_per_chunk), dim3(64), 0, L.stream, L.stage1, L.chunk_dst, L.chunk_payload,
-                     L.subs_per_chunk, L.matches, L.counts);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return launch_fail(e, "k_lz4_match");
-  hipLaunchKernelGGL(k_lz4_emit, dim3(L.n_chunks), dim3(kLzEmitThreads), 0, L.stream, L.stage1, L.chunk_dst, L.chunk_payload,
-                     L.subs_per_chunk, L.matches, L.counts, L.out_slots, L.out_stride, L.out_segs);
+  hipError_t e;
+  hipLaunchKernelGGL(k_lz4_plan, dim3(1), dim3(1024), 0, L.stream, L.chunk_payload, L.n_chunks, L.sub_first, L.out_slots, L.out_stride,
+                     L.out_segs);
+  if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_plan");
+  // one wave per sub-range, at most `max_subs` of them: workgroups beyond the real number find nothing to do
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(L.max_subs, 256u * 16u);
+  hipLaunchKernelGGL(k_lz4_match, dim3(grid), dim3(64), 0, L.stream, L.stage1, L.chunk_dst, L.chunk_payload, L.n_chunks, L.sub_first,
+                     L.matches, L.counts, L.last_end);
+  if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_match");
+  hipLaunchKernelGGL(k_lz4_sizes, dim3(grid), dim3(64), 0, L.stream, L.n_chunks, L.sub_first, L.matches, L.counts, L.last_end,
+                     L.anchor_in, L.sub_size);
+  if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_sizes");
+  hipLaunchKernelGGL(k_lz4_emit, dim3(grid), dim3(64), 0, L.stream, L.stage1, L.chunk_dst, L.chunk_payload, L.n_chunks, L.sub_first,
+                     L.matches, L.counts, L.last_end, L.anchor_in, L.sub_size, L.out_slots, L.out_stride, L.out_segs);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_emit");
   return CLDN_HIP_OK;
 }

@@ -113,10 +113,9 @@ struct FrameLaunch {
 int stage1_launch_frame(const FrameLaunch& F);
 
 // ---- stage 2 on the device: LZ4 block per chunk (lz4_kernels.hip; parameters shared with oracle/lz4_model.c) ----
-constexpr uint32_t kLzSubBytes = 16384;   // a wave parses this much of a payload with its own hash table
+constexpr uint32_t kLzSubBytes = 8192;    // a wave parses this much of a payload with its own hash table
 constexpr uint32_t kLzHashBits = 12;
-constexpr uint32_t kLzMaxMatches = 2048;  // per sub-range (the rest of it leaves as literals)
-constexpr uint32_t kLzMaxSubs = 1024;     // sub-ranges per chunk the emitter can index (16 MiB payloads); beyond: literals only
+constexpr uint32_t kLzMaxMatches = 1024;  // per sub-range (the rest of it leaves as literals)
 struct LzMatch {
   uint32_t pos;  // in the chunk's payload
   uint16_t len;  // 4 .. kLzSubBytes
@@ -128,9 +127,13 @@ struct Lz4Launch {
   const uint64_t* chunk_dst;
   const uint32_t* chunk_payload;
   uint32_t n_chunks;
-  uint32_t subs_per_chunk;        // ceil(largest possible payload / kLzSubBytes)
-  LzMatch* matches;               // [n_chunks * subs_per_chunk * kLzMaxMatches]
-  uint32_t* counts;               // [n_chunks * subs_per_chunk]
+  uint64_t max_subs;              // upper bound of the sub-ranges of the batch (payload bound / kLzSubBytes + n_chunks)
+  uint32_t* sub_first;            // [n_chunks + 1]: compact sub-range numbering
+  LzMatch* matches;               // [max_subs * kLzMaxMatches]
+  uint32_t* counts;               // [max_subs] and the three arrays behind it: last_end, anchor_in, sub_size
+  uint32_t* last_end;
+  uint32_t* anchor_in;
+  uint32_t* sub_size;
   uint8_t* out_slots;             // [n_chunks * out_stride]: the blocks
   uint64_t out_stride;
   Seg* out_segs;                  // [n_chunks]: {0, block size}

@@ -9,13 +9,13 @@
  *
  * The device algorithm is deterministic, and this file restates it serially so that the GPU tests can ask for
  * byte equality (and the CPU tests for validity against the system's liblz4):
- *   - the payload is cut into sub-ranges of `sub_bytes`; a sub-range is parsed by one wave with its own hash table
+ *   - the payload is cut into sub-ranges of `sub_bytes` (8192 on the device, 4096-entry table, 1024 matches); a sub-range is parsed by one wave with its own hash table
  *     (2^hash_bits entries, position inside the sub-range + 1), so matches never leave their sub-range;
- *   - the wave looks at 64 consecutive positions per step: every lane hashes the 4 bytes at its position and checks the
- *     table's candidate; the FIRST lane with a match wins, the match is extended (up to the sub-range end and the
- *     block's end rules), the positions up to and including the match start are entered into the table (within a
- *     step the highest position wins a slot), and the cursor moves behind the match; without a match all 64
- *     positions are entered and the cursor moves by 64;
+ *   - the wave looks at 64 consecutive positions per step: every lane hashes the 4 bytes at its position, checks the
+ *     table's candidate (the table as it was before the step) and, on a hit, extends its match as far as it goes (up to
+ *     the sub-range end and the block's end rules). All 64 positions are then entered into the table (the highest
+ *     position wins a slot). The step's matches are taken greedily in position order: the first hit, then the first hit
+ *     at or behind its end, and so on. The cursor moves by 64, or behind the last match taken if that reaches further;
  *   - at most `max_matches` matches per sub-range (the rest of the sub-range is literals);
  *   - sequences are then emitted over the whole block from the ordered list of matches.
  */
@@ -55,40 +55,38 @@ static uint32_t lz4m_parse(const uint8_t* in, uint32_t n, uint32_t s, uint32_t e
   uint32_t count = 0u;
   int64_t i = s;
   while (i <= last_start && count < max_matches) {
-    int found = -1;
-    uint32_t cf = 0u;
+    uint32_t len[64], cf[64];
     for (int l = 0; l < 64; ++l) { /* every lane looks at the table as it was BEFORE the step */
       const int64_t p = i + l;
-      if (p > last_start) break;
+      len[l] = 0u;
+      if (p > last_start) continue;
       const uint32_t seq = rd32(in + p);
       const uint32_t h = (seq * 2654435761u) >> (32u - hash_bits);
       const uint32_t cand = table[h];
       if (cand != 0u && rd32(in + s + cand - 1u) == seq) {
-        found = l;
-        cf = s + cand - 1u;
-        break;
+        const uint32_t c = s + cand - 1u, maxlen = end_limit - (uint32_t)p;
+        uint32_t k = 4u;
+        while (k < maxlen && in[p + k] == in[c + k]) ++k;
+        len[l] = k;
+        cf[l] = c;
       }
     }
-    const int upto = found >= 0 ? found : 63;
-    for (int l = 0; l <= upto; ++l) { /* ascending positions: within a step the highest position wins a slot */
+    for (int l = 0; l < 64; ++l) { /* ascending positions: within a step the highest position wins a slot */
       const int64_t p = i + l;
       if (p > last_start) break;
       const uint32_t h = (rd32(in + p) * 2654435761u) >> (32u - hash_bits);
       table[h] = (uint16_t)(p - s + 1);
     }
-    if (found < 0) {
-      i += 64;
-      continue;
+    uint32_t cur = 0u;
+    for (uint32_t l = 0; l < 64u && count < max_matches; ++l) {
+      if (l < cur || len[l] == 0u) continue;
+      m[count].pos = (uint32_t)(i + l);
+      m[count].len = len[l];
+      m[count].off = (uint32_t)(i + l) - cf[l];
+      ++count;
+      cur = l + len[l];
     }
-    const uint32_t pm = (uint32_t)(i + found);
-    uint32_t len = 4u;
-    const uint32_t maxlen = end_limit - pm;
-    while (len < maxlen && in[pm + len] == in[cf + len]) ++len;
-    m[count].pos = pm;
-    m[count].len = len;
-    m[count].off = pm - cf;
-    ++count;
-    i = (int64_t)pm + len;
+    i += cur > 64u ? cur : 64u;
   }
   return count;
 }

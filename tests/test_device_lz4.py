@@ -34,12 +34,12 @@ def _payload_kinds(rs, n):
     yield "sparse_matches", bytes(b if (i // 5) % 2 else (i * 37) & 0xff for i, b in enumerate(rs.randint(0, 3, n).astype(np.uint8)))
 
 
-@pytest.mark.parametrize("n", list(range(0, 24)) + [63, 64, 65, 255, 256, 270, 1000, 4096, 16383, 16384, 16385, 16396, 16400,
+@pytest.mark.parametrize("n", list(range(0, 24)) + [63, 64, 65, 255, 256, 270, 1000, 4096, 8191, 8192, 8193, 8204, 8208, 16383, 16384, 16385,
                                                     32768 + 11, 70001])
 def test_model_blocks_are_valid_lz4(oracle, n):
     rs = np.random.RandomState(n)
     for kind, payload in _payload_kinds(rs, n):
-        for sub, hb, mm in ((16384, 12, 2048), (64, 4, 3), (100, 6, 1 << 20), (16384, 12, 5)):
+        for sub, hb, mm in ((8192, 12, 1024), (16384, 12, 2048), (64, 4, 3), (100, 6, 1 << 20), (8192, 12, 5)):
             block = oracle.lz4_model(payload, sub, hb, mm)
             assert _lz4_decompress(block, n) == payload, (kind, sub, hb, mm)
             assert block.size <= n + n // 255 + 16
@@ -47,8 +47,8 @@ def test_model_blocks_are_valid_lz4(oracle, n):
 
 def test_model_compresses_what_is_compressible(oracle):
     rs = np.random.RandomState(3)
-    assert oracle.lz4_model(bytes(100000)).size < 1000                      # one long match per 16 KiB sub-range
-    assert oracle.lz4_model((bytes(range(7)) * 20000)[:100000]).size < 1100
+    assert oracle.lz4_model(bytes(100000)).size < 1600                      # one long match per 8 KiB sub-range
+    assert oracle.lz4_model((bytes(range(7)) * 20000)[:100000]).size < 1700
     noise = rs.randint(0, 256, 100000).astype(np.uint8).tobytes()
     assert oracle.lz4_model(noise).size <= 100000 + 100000 // 255 + 16
     info, data = synth.depthcam_xyzrgba(320, 240, seed=1)
