@@ -160,6 +160,7 @@ struct cldn_hip_codec {
   DevBuf d_cols[kMaxAdaptive];
   DevBuf d_ranks[kMaxAdaptive];
   DevBuf d_dec_meta, d_pre_ptrs;
+  DevBuf d_dec_cols[2];       // decode: dense columns of the adaptive fields that k_decode_points takes its integer fields from
   // stage 2 on the device (cldn_hip_codec_set_stage2): the stage-1 streams stay in d_s1, LZ4 blocks go to d_lz_slots
   int stage2 = 0;
   DevBuf d_s1, d_s1_offsets, d_lz_matches, d_lz_counts, d_lz_slots, d_lz_segs, d_payload2, d_dst2;
@@ -508,7 +509,7 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec, &c->d_s1, &c->d_s1_offsets,
                     &c->d_lz_matches, &c->d_lz_counts, &c->d_lz_slots, &c->d_lz_segs, &c->d_payload2, &c->d_dst2,
-                    &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_pre_ptrs,
+                    &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_pre_ptrs, &c->d_dec_cols[0], &c->d_dec_cols[1],
                     &c->d_pre[0], &c->d_pre[1], &c->d_pre[2], &c->d_pre[3], &c->d_viz_keys, &c->d_viz_first,
                     &c->d_viz_slot, &c->d_viz_blocks, &c->d_viz_total, &c->d_pieces};
   for (DevBuf* b : bufs) b->release();
@@ -1154,7 +1155,16 @@ int cldn_hip_codec_force_modes(cldn_hip_codec_t* c, const uint8_t* modes, uint32
 int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams_loc, const uint64_t* stream_offsets,
                            const uint64_t* cloud_points, uint32_t n_clouds, void* points_out, uint64_t out_capacity,
                            int out_loc) {
+  return cldn_hip_decode_stage1_sized(c, streams, streams_loc, stream_offsets, cloud_points, n_clouds, nullptr, CLDN_HIP_HOST,
+                                      points_out, out_capacity, out_loc);
+}
+
+int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int streams_loc, const uint64_t* stream_offsets,
+                                 const uint64_t* cloud_points, uint32_t n_clouds, const uint32_t* chunk_sizes, int chunk_sizes_loc,
+                                 void* points_out, uint64_t out_capacity, int out_loc) {
   if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if (chunk_sizes && chunk_sizes_loc != CLDN_HIP_HOST && chunk_sizes_loc != CLDN_HIP_DEVICE)
+    return fail(CLDN_HIP_ERR_ARG, "invalid memory location tag");
   if (n_clouds && (!cloud_points || !stream_offsets)) return fail(CLDN_HIP_ERR_ARG, "NULL offsets / cloud_points");
   if ((streams_loc != CLDN_HIP_HOST && streams_loc != CLDN_HIP_DEVICE) ||
       (out_loc != CLDN_HIP_HOST && out_loc != CLDN_HIP_DEVICE))
@@ -1206,8 +1216,13 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams
   h_fp[n_clouds] = fp;
   h_fc[n_clouds] = fc;
   const size_t chunk_table_bytes = ((size_t)std::max(1u, n_chunks) * kDecChunkBytes + 63) & ~size_t(63);
-  if ((rc = c->d_dec_meta.ensure(((table_bytes + 63) & ~size_t(63)) + chunk_table_bytes + (size_t)std::max(1u, n_chunks) * 5u)) != CLDN_HIP_OK)
+  if ((rc = c->d_dec_meta.ensure(((table_bytes + 63) & ~size_t(63)) + chunk_table_bytes + (size_t)std::max(1u, n_chunks) * 14u + 64u)) != CLDN_HIP_OK)
     return rc;
+  const bool dec_cols = c->plan.uses_v5 && plan.n_adaptive >= 1u && plan.n_adaptive <= 2u;
+  for (uint32_t a = 0; a < 2u; ++a)
+    if (dec_cols && a < plan.n_adaptive && plan.adaptive[a].bpv <= 4u &&
+        (rc = c->d_dec_cols[a].ensure((size_t)n_points * plan.adaptive[a].bpv + 64)) != CLDN_HIP_OK)
+      return rc;
   uint8_t* meta = (uint8_t*)c->d_dec_meta.p;
   HIP_TRY(hipMemcpyAsync(meta, stage.p, table_bytes, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipEventRecord(c->dec_stage_ev[slot], c->stream));
@@ -1243,7 +1258,21 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* c, const void* streams, int streams
   L.n_chunks = n_chunks;
   L.chunks = meta + ((table_bytes + 63) & ~size_t(63));
   L.reg_end = (uint32_t*)(meta + ((table_bytes + 63) & ~size_t(63)) + chunk_table_bytes);
-  L.sec_done = (uint8_t*)(L.reg_end + std::max(1u, n_chunks));
+  L.reg_end_pre = L.reg_end + std::max(1u, n_chunks);
+  L.sec_done = (uint8_t*)(L.reg_end_pre + std::max(1u, n_chunks));
+  L.sec_cols = L.sec_done + std::max(1u, n_chunks);
+  L.chunk_sizes = nullptr;
+  if (chunk_sizes && n_chunks) {
+    if (chunk_sizes_loc == CLDN_HIP_DEVICE) {
+      L.chunk_sizes = chunk_sizes;
+    } else {  // (pageable source: the copy is over when the call returns)
+      uint32_t* d_sizes = (uint32_t*)(((uintptr_t)(L.sec_cols + std::max(1u, n_chunks)) + 3u) & ~uintptr_t(3));
+      HIP_TRY(hipMemcpyAsync(d_sizes, chunk_sizes, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      L.chunk_sizes = d_sizes;
+    }
+  }
+  for (uint32_t a = 0; a < 2u; ++a)
+    L.cols[a] = (dec_cols && a < plan.n_adaptive && plan.adaptive[a].bpv <= 4u) ? (uint8_t*)c->d_dec_cols[a].p : nullptr;
   L.out = d_outp;
   L.status = (uint32_t*)c->d_status.p;
   if ((rc = stage1_launch_decode(L)) != CLDN_HIP_OK) return rc;

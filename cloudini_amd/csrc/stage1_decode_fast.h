@@ -81,6 +81,17 @@ __device__ __forceinline__ void fp_load16(const uint8_t* __restrict__ src, uint3
   }
 }
 
+// the same through ONE unaligned 16-byte load (gfx950 performs it natively): for streaming passes that only count
+__device__ __forceinline__ void fp_load16u(const uint8_t* __restrict__ src, uint32_t src_size, uint32_t o, uint32_t (&b)[4]) {
+  if (o + 16u <= src_size) {
+    uint4 w;
+    __builtin_memcpy(&w, src + o, 16);
+    b[0] = w.x; b[1] = w.y; b[2] = w.z; b[3] = w.w;
+  } else {
+    fp_load16(src, src_size, o, b);
+  }
+}
+
 // bit j = byte j of the 16 ends a token (MSB clear)
 __device__ __forceinline__ uint32_t fp_ends16(const uint32_t (&b)[4]) {
   uint32_t ends = 0u;
@@ -97,11 +108,146 @@ struct FpSection {   // a Palette section folded into the point pass
   uint32_t index_off;  // payload offset of the packed indexes
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_locate_sections: where a chunk's sections begin = behind token number n_points * n_ops of its payload. The token
+// ends (bytes with a clear MSB) are counted by four waves, each over a quarter of the payload, 64 bytes per lane and
+// step; the wave that holds the last token walks its quarter again and finds the byte. A light kernel (no LDS to speak
+// of, eight workgroups per CU): the count is a plain streaming read of the regular stream.
+// reg_end_pre[c] = the offset, 0xffffffff = not found / not looked for (one-field plans whose section looks like a small
+// Palette from the end of the payload are left to k_decode_points' own guess). grid = n_chunks, 256 threads.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_locate_sections(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                         const DecChunk* __restrict__ chunks, uint32_t n_ops,
+                                                         uint32_t* __restrict__ reg_end_pre) {
+  __shared__ uint32_t wcnt[4];
+  __shared__ uint32_t found, pal_hit;
+  const uint32_t c = blockIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const DecChunk dc = chunks[c];
+  if (tid == 0) {
+    reg_end_pre[c] = 0xffffffffu;
+    found = 0xffffffffu;
+    pal_hit = 0u;
+  }
+  if (!dc.valid || plan.n_adaptive == 0u || plan.n_adaptive > kFastPalFields) return;
+  for (uint32_t a = 0; a < plan.n_adaptive; ++a)
+    if (plan.adaptive[a].bpv > 4u) return;
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t src_size = dc.src_size;
+  const uint32_t n = dc.n_points;
+  const uint32_t target = n * n_ops;
+  __syncthreads();
+  if (plan.n_adaptive == 1u) {
+    const uint32_t bpv = plan.adaptive[0].bpv;
+    for (uint32_t U = tid + 1u; U <= kFastPalEntries; U += 256u) {
+      const uint64_t S = 3ull + (uint64_t)U * bpv + ((uint64_t)palette_bits(U) * n + 7u) / 8u;
+      if (S <= src_size) {
+        const uint8_t* h = src + (src_size - (uint32_t)S);
+        if (h[0] == 1u && ((uint32_t)h[1] | ((uint32_t)h[2] << 8)) == U) pal_hit = 1u;
+      }
+    }
+    __syncthreads();
+    if (pal_hit) return;  // uniform
+  }
+  const uint32_t part = (((src_size + 15u) / 16u + 3u) / 4u) * 16u;  // bytes per wave, multiple of 16
+  const uint32_t w0 = min(src_size, wave * part), w1 = min(src_size, w0 + part);
+  uint32_t cnt = 0u;
+  for (uint32_t o0 = w0; o0 < w1; o0 += 4096u) {  // four 16-byte units per lane, all loads before the first use
+    uint32_t b[4][4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) {
+      const uint32_t o = o0 + u * 1024u + lane * 16u;
+      b[u][0] = b[u][1] = b[u][2] = b[u][3] = 0xffffffffu;
+      if (o < w1) fp_load16u(src, src_size, o, b[u]);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cnt += (uint32_t)__builtin_popcount(~b[u][k] & 0x80808080u);
+  }
+  const uint32_t wsum = wave_sum(cnt);
+  if (lane == 0u) wcnt[wave] = wsum;
+  __syncthreads();
+  uint32_t before = 0u;
+  for (uint32_t w = 0; w < wave; ++w) before += wcnt[w];
+  if (target != 0u && before < target && target <= before + wsum) {  // the last token ends in my part (one wave)
+    uint32_t seen = before;
+    for (uint32_t o0 = w0; o0 < w1; o0 += 1024u) {
+      const uint32_t o = o0 + lane * 16u;
+      uint32_t b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      if (o < w1) fp_load16u(src, src_size, o, b);
+      const uint32_t ends = fp_ends16(b);
+      const uint32_t cl = (uint32_t)__builtin_popcount(ends);
+      const uint32_t incl = wave_inclusive_scan(cl);
+      const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      if (seen + row >= target) {
+        const uint32_t my_first = seen + incl - cl;  // tokens before mine
+        if (my_first < target && target <= my_first + cl) {
+          uint32_t m = ends;
+          for (uint32_t k = my_first + 1u; k < target; ++k) m &= m - 1u;  // drop the ends before the wanted one
+          found = o + (uint32_t)__builtin_ctz(m) + 1u;
+        }
+        break;
+      }
+      seen += row;
+    }
+  }
+  if (target == 0u && tid == 0) found = 0u;
+  __syncthreads();
+  if (tid == 0) reg_end_pre[c] = found;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_decode_sections_cols: in front of k_decode_points, for chunks whose sections it cannot fold from a palette table
+// (DeltaVarint / Rle / DeltaRle sections, large palettes). The sections are decoded into DENSE COLUMNS (value i of
+// the chunk at col[a] + (first_point + i) * bpv) with the parallel section decoder (decode_sections_core); the point
+// kernel then reads a point's integer fields next to its floats and writes every point ONCE -- round 2 decoded these
+// sections behind the point kernel straight into the AoS cloud, which dirtied every output line a second time
+// (C3 / C4: 0.26 ms of a 0.57 / 0.74 ms decode).
+// Where the sections begin comes from k_locate_sections (reg_end_pre). sec_cols[c] = 1: the columns hold this chunk's
+// fields. Chunks k_locate_sections did not look at (a small Palette seen from the end) are left alone.
+// grid = n_chunks, kDvThreads threads, DecSecLds::kTotal bytes of LDS.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kDvThreads) void k_decode_sections_cols(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                                     const DecChunk* __restrict__ chunks, uint32_t n_ops,
+                                                                     uint8_t* __restrict__ col0, uint8_t* __restrict__ col1,
+                                                                     const uint32_t* __restrict__ reg_end_pre,
+                                                                     uint8_t* __restrict__ sec_cols) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t c = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const DecChunk dc = chunks[c];
+  if (tid == 0) sec_cols[c] = 0u;
+  if (!dc.valid || plan.n_adaptive == 0u || plan.n_adaptive > kFastPalFields) return;
+  for (uint32_t a = 0; a < plan.n_adaptive; ++a)
+    if (plan.adaptive[a].bpv > 4u) return;
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t src_size = dc.src_size;
+  const uint32_t n = dc.n_points;
+  const uint32_t reg_size = reg_end_pre[c];  // k_locate_sections
+  if (reg_size == 0xffffffffu || reg_size > src_size) return;  // not looked for / fewer tokens than the points need
+  const bool ok = decode_sections_core(plan, src, src_size, reg_size, n,
+                                       [&](uint32_t a) {
+                                         SecFieldOut fo;
+                                         const uint32_t bpv = plan.adaptive[a].bpv;
+                                         fo.base = (a == 0u ? col0 : col1) + (size_t)dc.first_point * bpv;
+                                         fo.step = bpv;
+                                         fo.off = 0u;
+                                         return fo;
+                                       },
+                                       smem);
+  if (ok && tid == 0) sec_cols[c] = 1u;
+}
+
 template <int NOPS, int NF>
 __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decode_points(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                               const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
                                                               uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done,
-                                                              uint32_t uses_v5, uint32_t* __restrict__ status) {
+                                                              uint32_t uses_v5, uint32_t* __restrict__ status,
+                                                              const uint8_t* __restrict__ col0, const uint8_t* __restrict__ col1,
+                                                              const uint32_t* __restrict__ reg_end_pre,
+                                                              const uint8_t* __restrict__ sec_cols) {
   using L = FpLds<NOPS, NF>;
   constexpr uint32_t NFA = NF ? NF : 1;  // array extents (NF == 0: nothing is ever folded)
   constexpr int T = kFpThreads;
@@ -148,7 +294,25 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
   uint32_t reg_size = 0xffffffffu;
   const bool v5_sections = uses_v5 && plan.n_adaptive != 0u;
   bool located = false;
-  if (v5_sections && plan.n_adaptive == 1u && plan.adaptive[0].bpv <= 4u) {
+  // k_decode_sections_cols has decoded this chunk's sections into columns: every point takes its integer fields from there
+  const bool from_cols = NF != 0 && v5_sections && sec_cols != nullptr && sec_cols[c] != 0u && plan.n_adaptive <= (uint32_t)NF;
+  if (from_cols) {
+    reg_size = reg_end_pre[c];
+    located = true;
+    if (tid == 0) {
+      FpSection* sec = reinterpret_cast<FpSection*>(misc + 72);
+      for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
+        sec[a].field_off = plan.adaptive[a].offset;
+        sec[a].bpv = plan.adaptive[a].bpv;
+        sec[a].count = 0u;
+        sec[a].bits = 0u;
+        sec[a].index_off = 0u;
+      }
+      misc[64] = plan.n_adaptive;
+    }
+    __syncthreads();
+  }
+  if (!from_cols && v5_sections && plan.n_adaptive == 1u && plan.adaptive[0].bpv <= 4u) {
     // One section behind the regular stream. If it is a Palette of U entries its size follows from U alone
     // (3 + U * bpv + ceil(bits(U) * n / 8)), so every U has one place where its header would have to be: the threads
     // try them all. A hit that is no header (3 bytes of a token stream that look like one) is found out when the
@@ -208,7 +372,7 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     __syncthreads();
     reg_size = misc[40];
   }
-  if (v5_sections) {
+  if (v5_sections && !from_cols) {
 
     // section headers (one thread): every section a small Palette of a 2- or 4-byte field -> fold them in
     if (tid == 0 && reg_size != 0xffffffffu && plan.n_adaptive <= (uint32_t)NF) {
@@ -361,7 +525,18 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     // folded Palette fields of my points: their indexes are consecutive bits, one 8-byte window holds all kFpPPT
     uint32_t pv[NFA][kFpPPT];
     const uint32_t SP = (uint32_t)NOPS + n_fold;  // dwords per staged point
-    if (n_fold != 0u) {
+    if (from_cols) {
+#pragma unroll
+      for (uint32_t a = 0; a < NFA; ++a) {
+        if (a >= n_fold) break;  // uniform
+        const uint8_t* colp = (a == 0u ? col0 : col1) + ((size_t)dc.first_point + pts_done) * fs_bpv[a];
+#pragma unroll
+        for (uint32_t i = 0; i < kFpPPT; ++i) {
+          const uint32_t q = min(q0 + i, npts - 1u);  // (points behind the tile's last one read a valid slot; unused)
+          pv[a][i] = fs_bpv[a] == 2u ? (uint32_t)reinterpret_cast<const uint16_t*>(colp)[q] : reinterpret_cast<const uint32_t*>(colp)[q];
+        }
+      }
+    } else if (n_fold != 0u) {
 #pragma unroll
       for (uint32_t a = 0; a < NFA; ++a) {
         if (a >= n_fold) break;  // uniform

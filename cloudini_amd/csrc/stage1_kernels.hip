@@ -1945,6 +1945,9 @@ int stage1_configure_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sections),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecSecLds::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_sections)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sections_cols),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecSecLds::kTotal);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_sections_cols)");
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_section_delta32<uint16_t>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD32Lds);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_delta32<u16>)");
@@ -2358,10 +2361,16 @@ int stage1_launch_decode_unframed(const DevPlan& plan, hipStream_t stream, const
 int stage1_launch_decode(const DecodeLaunch& L) {
   hipError_t e;
   if (L.n_clouds == 0) return CLDN_HIP_OK;
-  hipLaunchKernelGGL(k_walk_chunks, dim3((L.n_clouds + 63u) / 64u), dim3(64), 0, L.stream, L.streams, L.stream_offsets,
-                     L.cloud_first_point, L.cloud_first_chunk, L.n_clouds, reinterpret_cast<DecChunk*>(L.chunks),
-                     L.status);
-  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_walk_chunks");
+  if (L.chunk_sizes) {
+    hipLaunchKernelGGL(k_build_chunks, dim3(L.n_clouds), dim3(256), 0, L.stream, L.streams, L.stream_offsets, L.cloud_first_point,
+                       L.cloud_first_chunk, L.chunk_sizes, reinterpret_cast<DecChunk*>(L.chunks), L.status);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_build_chunks");
+  } else {
+    hipLaunchKernelGGL(k_walk_chunks, dim3((L.n_clouds + 63u) / 64u), dim3(64), 0, L.stream, L.streams, L.stream_offsets,
+                       L.cloud_first_point, L.cloud_first_chunk, L.n_clouds, reinterpret_cast<DecChunk*>(L.chunks),
+                       L.status);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_walk_chunks");
+  }
   if (L.n_chunks) {
     // regular streams made of varint tokens only go through the parallel kernel; the general kernel then decodes
     // the V5 sections (and whole chunks the fast kernel handed back)
@@ -2377,10 +2386,25 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     if (points_kernel) {
       // NF: Palette sections the launch can fold into the point pass (sizes its LDS)
       const uint32_t nf = (L.uses_v5 && P.n_adaptive <= kFastPalFields) ? P.n_adaptive : 0u;
+      // sections that are no small palettes go to dense columns first (every point is then written once)
+      static const bool no_cols = getenv("CLDN_HIP_NO_DECODE_COLS") != nullptr;  // A/B switch
+      bool cols = !no_cols && nf != 0u && L.cols[0] != nullptr && L.sec_cols != nullptr;
+      for (uint32_t a = 0; a < P.n_adaptive && cols; ++a) cols = P.adaptive[a].bpv <= 4u && L.cols[a] != nullptr;
+      if (cols) {
+        hipLaunchKernelGGL(k_locate_sections, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
+        hipLaunchKernelGGL(k_decode_sections_cols, dim3(L.n_chunks), dim3(kDvThreads), (DecSecLds::kTotal), L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.cols[0], L.cols[1], L.reg_end_pre, L.sec_cols);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_sections_cols");
+      }
+      const uint8_t* c0 = cols ? L.cols[0] : nullptr;
+      const uint8_t* c1 = cols ? L.cols[1] : nullptr;
+      const uint8_t* sc = cols ? L.sec_cols : nullptr;
 #define LAUNCH_POINTS(NOPS_, NF_)                                                                                         \
   hipLaunchKernelGGL((k_decode_points<NOPS_, NF_>), dim3(L.n_chunks), dim3(kFpThreads), (FpLds<NOPS_, NF_>::kTotal), L.stream, \
                      P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5,  \
-                     L.status)
+                     L.status, c0, c1, L.reg_end_pre, sc)
       if (P.n_ops == 3u) {
         if (nf == 0u) LAUNCH_POINTS(3, 0);
         else if (nf == 1u) LAUNCH_POINTS(3, 1);

@@ -72,6 +72,10 @@ struct DecodeLaunch {
   void* chunks;                       // device [n_chunks] DecChunk (48 bytes each)
   uint32_t* reg_end;                  // device [n_chunks]: end of the regular stream per chunk (fast path)
   uint8_t* sec_done;                  // device [n_chunks]: 1 = sections decoded by k_decode_sections
+  uint8_t* cols[2];                   // device: dense columns of the first two adaptive fields (n_points * bpv each), or NULL
+  uint32_t* reg_end_pre;              // device [n_chunks]: k_decode_sections_cols: where the regular stream ends
+  uint8_t* sec_cols;                  // device [n_chunks]: 1 = the columns hold the chunk's integer fields
+  const uint32_t* chunk_sizes;        // device [n_chunks] or NULL: the payload sizes, if the caller knows them (no serial walk)
   uint8_t* out;                       // device: decoded AoS points
   uint32_t* status;
 };

@@ -111,6 +111,10 @@ def lib() -> C.CDLL:
     L.cldn_hip_codec_fetch_output.argtypes = [vp, vp, C.c_uint64]
     L.cldn_hip_decode_stage1.restype = C.c_int
     L.cldn_hip_decode_stage1.argtypes = [vp, vp, C.c_int, u64p, u64p, C.c_uint32, vp, C.c_uint64, C.c_int]
+    L.cldn_hip_decode_stage1_sized.restype = C.c_int
+    L.cldn_hip_decode_stage1_sized.argtypes = [vp, vp, C.c_int, u64p, u64p, C.c_uint32, vp, C.c_int, vp, C.c_uint64, C.c_int]
+    L.cldn_hip_decode_stage1_unframed.restype = C.c_int
+    L.cldn_hip_decode_stage1_unframed.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, C.c_int]
     _lib = L
     return L
 
@@ -277,7 +281,7 @@ class Codec:
             C.c_void_p(chunk_sizes_ptr), C.c_void_p(modes_ptr)))
 
     def decode_host(self, streams: Sequence[np.ndarray], cloud_points: Sequence[int],
-                    out: Optional[np.ndarray] = None) -> List[np.ndarray]:
+                    out: Optional[np.ndarray] = None, chunk_sizes=None) -> List[np.ndarray]:
         step = self.plan.point_step
         arrs = [np.ascontiguousarray(s).view(np.uint8).reshape(-1) for s in streams]
         offs = np.zeros(len(arrs) + 1, dtype=np.uint64)
@@ -289,9 +293,11 @@ class Codec:
         total = int(npts.sum()) * step
         if out is None:
             out = np.zeros(max(1, total), dtype=np.uint8)
-        _check(lib().cldn_hip_decode_stage1(
+        cs = None if chunk_sizes is None else np.ascontiguousarray(chunk_sizes, dtype=np.uint32)
+        _check(lib().cldn_hip_decode_stage1_sized(
             self._h, data.ctypes.data_as(C.c_void_p), HOST, offs.ctypes.data_as(C.POINTER(C.c_uint64)),
-            npts.ctypes.data_as(C.POINTER(C.c_uint64)), len(arrs), out.ctypes.data_as(C.c_void_p), total, HOST))
+            npts.ctypes.data_as(C.POINTER(C.c_uint64)), len(arrs), None if cs is None else cs.ctypes.data_as(C.c_void_p), HOST,
+            out.ctypes.data_as(C.c_void_p), total, HOST))
         res, pos = [], 0
         for n in npts:
             res.append(out[pos:pos + int(n) * step])
@@ -299,9 +305,12 @@ class Codec:
         return res
 
     def decode_device(self, streams_ptr: int, stream_offsets: np.ndarray, cloud_points: np.ndarray, out_ptr: int,
-                      out_capacity: int):
+                      out_capacity: int, chunk_sizes_ptr: int = 0):
+        """chunk_sizes_ptr: device array of the chunks' payload sizes (what encode_device reported): the chunk table is then
+        built in parallel (cldn_hip_decode_stage1_sized)."""
         so = np.ascontiguousarray(stream_offsets, dtype=np.uint64)
         cp = np.ascontiguousarray(cloud_points, dtype=np.uint64)
-        _check(lib().cldn_hip_decode_stage1(
+        _check(lib().cldn_hip_decode_stage1_sized(
             self._h, C.c_void_p(streams_ptr), DEVICE, so.ctypes.data_as(C.POINTER(C.c_uint64)),
-            cp.ctypes.data_as(C.POINTER(C.c_uint64)), cp.size, C.c_void_p(out_ptr), int(out_capacity), DEVICE))
+            cp.ctypes.data_as(C.POINTER(C.c_uint64)), cp.size, C.c_void_p(chunk_sizes_ptr), DEVICE, C.c_void_p(out_ptr),
+            int(out_capacity), DEVICE))

@@ -177,6 +177,16 @@ int cldn_hip_decode_stage1(cldn_hip_codec_t* codec, const void* streams, int str
                            const uint64_t* stream_offsets, const uint64_t* cloud_points, uint32_t n_clouds,
                            void* points_out, uint64_t out_capacity, int out_loc);
 
+/* The same with the payload sizes of the chunks given (chunk_sizes: [total chunks], batch order, HOST or DEVICE per
+ * chunk_sizes_loc; e.g. what cldn_hip_encode_stage1 reported, or the [u32] prefixes a host caller has read anyway): the
+ * chunk table is then built in parallel instead of following the prefixes one dependent read after the other (one
+ * 10 M-point cloud has 306 of them). Every size is still checked against its prefix; a mismatch is
+ * CLDN_HIP_ERR_CORRUPT. chunk_sizes == NULL: exactly cldn_hip_decode_stage1. */
+int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* codec, const void* streams, int streams_loc,
+                                 const uint64_t* stream_offsets, const uint64_t* cloud_points, uint32_t n_clouds,
+                                 const uint32_t* chunk_sizes, int chunk_sizes_loc, void* points_out, uint64_t out_capacity,
+                                 int out_loc);
+
 /* Wire version 2 (streams written before the chunked format; the reference still reads them, src/cloudini.cpp:665-667):
  * the whole stage-1 payload is ONE unframed run of points without [u32 size] prefixes and without state resets, decoded
  * until it is empty (DecodeV4Stage1Chunk with expected_points = 0, src/v4_codec.cpp:108-115). The output capacity bounds

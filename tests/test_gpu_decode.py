@@ -310,3 +310,46 @@ def test_section_guess_with_a_false_hit_in_the_token_stream(oracle, field):
     assert 3 < guess < 3 * n - 3 and bytes(payload[guess:guess + 3]) == b"\x01\x01\x01"
     stats, _modes, n_chunks = _stats_after_decode(oracle, info, data)
     assert stats == (n_chunks, n_chunks, 0, 0)
+
+
+def test_decode_with_the_chunk_sizes_given(oracle):
+    """cldn_hip_decode_stage1_sized: the caller's payload sizes replace the serial walk over the [u32] prefixes; every size
+    is still checked against its prefix."""
+    from cloudini_amd import native
+    info, _ = synth.lidar_xyzi(10)
+    clouds = [synth.lidar_xyzi(n, seed=60 + k)[1] for k, n in enumerate([100000, 0, 5, 32768, 70001])]
+    codec = native.Codec(native.Plan(info))
+    streams, chunk_sizes, _ = codec.encode_host(clouds)
+    npts = [c.size // info.point_step for c in clouds]
+    want = codec.decode_host(streams, npts)
+    got = codec.decode_host(streams, npts, chunk_sizes=chunk_sizes)
+    for a, b, cloud in zip(want, got, clouds):
+        assert np.array_equal(a, b)
+        assert np.array_equal(a, oracle.decode_stage1(info, oracle.encode_stage1(info, cloud), cloud.size // info.point_step))
+    assert codec.decode_stats()[0] == len(chunk_sizes)
+    for k in (0, len(chunk_sizes) - 1):
+        wrong = np.array(chunk_sizes, dtype=np.uint32)
+        wrong[k] += 1
+        with pytest.raises(native.CloudiniHipError):
+            codec.decode_host(streams, npts, chunk_sizes=wrong)
+    # a 10-chunk cloud through the device-resident entry point
+    import torch
+    dev = torch.device("cuda", 0)
+    info5, data = synth.lidar_xyz(320000, seed=2)
+    c5 = native.Codec(native.Plan(info5))
+    d_in = torch.from_numpy(data).to(dev)
+    cap = c5.plan.stage1_bound(320000)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_sizes = torch.zeros(10, dtype=torch.int32, device=dev)
+    c5.encode_device(d_in.data_ptr(), np.array([320000], dtype=np.uint64), d_out.data_ptr(), cap, d_off.data_ptr(), d_sizes.data_ptr())
+    c5.synchronize()
+    offs = d_off.cpu().numpy().astype(np.uint64)
+    d_dec = torch.zeros(data.size, dtype=torch.uint8, device=dev)
+    c5.decode_device(d_out.data_ptr(), offs, np.array([320000], dtype=np.uint64), d_dec.data_ptr(), data.size, d_sizes.data_ptr())
+    c5.synchronize()
+    c5.status()
+    stream = d_out[: int(offs[1])].cpu().numpy()
+    assert np.array_equal(d_dec.cpu().numpy(), oracle.decode_stage1(info5, stream, 320000))
+    c5.close()
+    codec.close()

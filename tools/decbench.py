@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Decode timing (device resident): C5-like 10M-pt XYZ cloud and 32 x 1M-pt XYZI batch."""
+"""Decode timing (device resident): BASELINE configs C2-C5 (argument: prefix of the case name, e.g. c3)."""
 import sys, os, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,8 @@ from cloudini_amd import native, synth
 
 dev = torch.device("cuda", 0)
 only = sys.argv[1] if len(sys.argv) > 1 else ""
-cases = (("c5 xyz 10M", lambda: synth.lidar_xyz(10_000_000), 1), ("c2 xyzi 32x1M", lambda: synth.lidar_xyzi(1_000_000), 32))
+cases = (("c5 xyz 10M", lambda: synth.lidar_xyz(10_000_000), 1), ("c2 xyzi 32x1M", lambda: synth.lidar_xyzi(1_000_000), 32),
+         ("c3 xyzrgba 16x1M", lambda: synth.depthcam_xyzrgba(1280, 800), 16), ("c4 velodyne 256x130k", lambda: synth.velodyne_xyzir(130048), 256))
 for name, make, n_clouds in cases:
     if only and not name.startswith(only):
         continue
@@ -24,19 +25,22 @@ for name, make, n_clouds in cases:
     cap = plan.stage1_bound(n) * n_clouds
     d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
     d_off = torch.zeros(n_clouds + 1, dtype=torch.int64, device=dev)
-    codec.encode_device(d_points.data_ptr(), cloud_points, d_out.data_ptr(), cap, d_off.data_ptr(), 0, 0)
+    n_chunks = int(sum((int(x) + 32767) // 32768 for x in cloud_points))
+    d_sizes = torch.zeros(n_chunks, dtype=torch.int32, device=dev)
+    codec.encode_device(d_points.data_ptr(), cloud_points, d_out.data_ptr(), cap, d_off.data_ptr(), d_sizes.data_ptr(), 0)
+    sized = d_sizes.data_ptr() if os.environ.get("DECBENCH_SIZED", "1") != "0" else 0
     torch.cuda.synchronize()
     offs = d_off.cpu().numpy().astype(np.uint64)
     d_dec = torch.zeros(host.size, dtype=torch.uint8, device=dev)
     for it in range(5):
-        codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size)
+        codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size, sized)
     torch.cuda.synchronize()
     ts = []
     for blk in range(7):
         t0 = time.perf_counter()
         reps = 10
         for it in range(reps):
-            codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size)
+            codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size, sized)
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) / reps)
     dt = float(np.median(ts))
