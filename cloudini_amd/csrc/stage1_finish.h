@@ -175,9 +175,10 @@ __device__ __forceinline__ void fin_copy(const FinishLds& L, const uint8_t* __re
   }
 }
 
-// T threads; FUSE_BPV = 0 (no section work), 2 or 4 (Palette section of A.fuse_field in-kernel; T = 512)
+// T threads; FUSE_BPV = 0 (no section work), 2 or 4 (Palette section of A.fuse_field in-kernel; T = 512, or 1024 for small
+// batches: a chunk's section then has twice the threads)
 template <int T, int FUSE_BPV>
-__global__ __launch_bounds__(T, 8) __attribute__((amdgpu_num_sgpr(80))) void k_finish(const FinishArgs A) {
+__global__ __launch_bounds__(T, (T == 1024 ? 4 : 8)) __attribute__((amdgpu_num_sgpr(80))) void k_finish(const FinishArgs A) {
   using RawT = typename std::conditional<FUSE_BPV == 4, uint32_t, uint16_t>::type;
   using P = Pal32<RawT>;
   __shared__ FinishLds L;

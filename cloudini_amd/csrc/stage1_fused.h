@@ -178,6 +178,15 @@ struct FusedArgs {
   uint32_t tail_size;            // field bytes
   const uint16_t* tail_windows;  // OP_GORILLA64: k_gorilla_windows' window in front of every piece, [chunk * 128 + piece]
   uint32_t ablate;               // profiling only (CLDN_HIP_ABLATE): 4 no column stores
+  // n_probe != 0: the first n_probe workgroups of the grid are not pieces: workgroup b decides the adaptive-int mode of
+  // (cloud b / n_adaptive, field b % n_adaptive) on the first <= 4096 values of the cloud, read from the AoS input
+  // (analyzeAdaptiveIntField + selectBestAdaptiveIntMode, src/v5_codec.cpp:387-412, :934-949) -- next to the pieces
+  // instead of in a launch of its own behind them (10 us + a launch boundary per call)
+  uint32_t n_probe;
+  uint32_t probe_lds;            // bytes of dynamic LDS the launch has
+  const ChunkDesc* chunks;
+  const uint32_t* cloud_first_chunk;
+  uint8_t* modes;
   // intra != 0: the workgroups of a chunk place their streams back to back at the start of the chunk's slot (ONE
   // regular segment per chunk): every workgroup publishes its byte count as {epoch, bytes} and adds up the records of
   // its chunk's workgroups before it (at most 16, one load per lane; agent-scope store / loads, bounded spin)
@@ -207,7 +216,33 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t na = plan.n_adaptive;
 
-  const uint32_t g = blockIdx.x * kFusedWaves + wave;  // my piece
+  if (blockIdx.x < A.n_probe) {  // uniform: a mode-probe workgroup
+    const uint32_t cloud = blockIdx.x / na, a = blockIdx.x - cloud * na;
+    uint8_t* mode_out = A.modes + (size_t)cloud * na + a;
+    const uint32_t fc = A.cloud_first_chunk[cloud];
+    if (fc == A.cloud_first_chunk[cloud + 1u]) {  // empty cloud
+      if (tid == 0u) *mode_out = 0u;
+      return;
+    }
+    const ChunkDesc cd = A.chunks[fc];
+    const uint32_t n = cd.n_points > kProbePoints ? kProbePoints : cd.n_points;
+    uint32_t f_off, f_type, bpv;
+    adaptive_field(plan, a, f_off, f_type, bpv);
+    const uint8_t* fp = A.points + (size_t)cd.first_point * plan.point_step + f_off;
+    const uint32_t pstep = plan.point_step;
+    uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + ((A.probe_lds - 256u) & ~15u));
+    const uint32_t slots = (A.probe_lds - 272u) / 4u;  // 32-bit keys: >= 6144 slots for <= 4096 values
+    uint8_t mode;
+    if (bpv == 2u)
+      mode = probe_mode_t<uint16_t, (int)kFusedThreads>([&](uint32_t i) { return (uint16_t)aos_field(fp + (size_t)i * pstep, 2u); }, n, f_type,
+                                                        smem, 0u, wtot);
+    else
+      mode = probe_mode_t<uint32_t, (int)kFusedThreads>([&](uint32_t i) { return (uint32_t)aos_field(fp + (size_t)i * pstep, 4u); }, n, f_type,
+                                                        smem, slots, wtot);
+    if (tid == 0u) *mode_out = mode;
+    return;
+  }
+  const uint32_t g = (blockIdx.x - A.n_probe) * kFusedWaves + wave;  // my piece
   const PieceDesc pd = A.pieces[g];           // one 32-byte record: no dependent second load
   const uint32_t p = pd.p;
   const uint32_t first = p * PIECE;           // chunk-relative index of my first point

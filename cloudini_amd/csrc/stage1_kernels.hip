@@ -2017,7 +2017,7 @@ uint32_t stage1_piece_slot_stride(const DevPlan& plan, const uint8_t* points) {
   return (fused_piece_points(v.lanes) * per_point + 255u) & ~255u;
 }
 
-static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piece0, uint32_t piece1) {
+static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piece0, uint32_t piece1, bool* probed) {
   FusedVariant v;
   if (!fused_variant(*L.plan, L.points, &v)) return launch_fail(hipErrorInvalidValue, "k_encode_fused (no variant)");
   FusedArgs A;
@@ -2032,6 +2032,15 @@ static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piec
   A.piece_stride = L.sub_stride / kFusedWaves;  // sub_stride = one workgroup's range (4 pieces)
   A.segs = L.segs;
   A.segs_per_chunk = L.segs_per_chunk;
+  // mode probe next to the pieces: fields of 2 and 4 bytes (the distinct-value structure has to fit the launch's LDS)
+  static const bool probe_in_piece_env = !(getenv("CLDN_HIP_PROBE_IN_PIECE") && atoi(getenv("CLDN_HIP_PROBE_IN_PIECE")) == 0);  // A/B switch
+  bool probe_here = probe_in_piece_env && piece0 == 0u && L.plan->n_adaptive != 0u && !L.modes_forced && L.n_clouds != 0u &&
+                    (uint64_t)L.n_clouds * L.plan->n_adaptive < (1u << 20);
+  for (uint32_t a = 0; a < L.plan->n_adaptive && probe_here; ++a) probe_here = L.plan->adaptive[a].bpv <= 4u;
+  A.n_probe = probe_here ? L.n_clouds * L.plan->n_adaptive : 0u;
+  A.chunks = L.chunks;
+  A.cloud_first_chunk = L.cloud_first_chunk;
+  A.modes = L.modes;
   A.intra = L.intra ? 1u : 0u;
   A.epoch = L.fin_epoch;
   A.wgrec = L.wgrec;
@@ -2049,7 +2058,10 @@ static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piec
   }
   const uint32_t region = v.tail >= 0 ? fused_region_bytes_tail(v.lanes) : fused_region_bytes(v.lanes);
   const uint32_t lds = 16u + kFusedWaves * region;
-  const dim3 grid((piece1 - piece0) / kFusedWaves), block(kFusedThreads);
+  if (lds < 6144u * 4u + 272u) A.n_probe = 0u;  // (never: four regions are 30 KB and more)
+  A.probe_lds = lds;
+  if (probed) *probed = A.n_probe != 0u;
+  const dim3 grid(A.n_probe + (piece1 - piece0) / kFusedWaves), block(kFusedThreads);
 #define LAUNCH_FUSED(LL, WW, UU, L3)                                                                             \
   hipLaunchKernelGGL((k_encode_fused<LL, WW, UU, L3>), grid, block, lds, stream, *L.plan, A)
 #define LAUNCH_FUSED_TAIL(LL, WW, UU, L3)                                                                        \
@@ -2158,6 +2170,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   }
   if (L.events) (void)hipEventRecord(L.events[0], L.stream);
   uint32_t gor_piece_pts = 0u;  // the piece kernel encodes the Gorilla field itself: points per piece
+  bool modes_probed = false;    // the piece kernel's launch decided the adaptive-int modes
   if (L.events) (void)hipEventRecord(L.events[1], L.stream);
   gor_piece_pts = (L.n_chunks && L.pieces) ? stage1_gorilla_inline_piece_points(*L.plan, L.points) : 0u;
   if (gor_piece_pts) {
@@ -2172,7 +2185,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_gorilla_tokens");
   }
   if (L.n_chunks && L.pieces) {  // slot pipeline, regular stream by the barrier-free piece kernel
-    const int rc = launch_fused(L, L.stream, 0u, L.n_pieces);
+    const int rc = launch_fused(L, L.stream, 0u, L.n_pieces, &modes_probed);
     if (rc != CLDN_HIP_OK) return rc;
   } else if (L.n_chunks) {
     int l3 = 3;
@@ -2216,7 +2229,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   const uint32_t na = L.plan->n_adaptive;
   if (na && L.n_chunks) {
     static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
-    if (!L.modes_forced) {
+    if (!L.modes_forced && !modes_probed) {
       if (!no_fast) {
         hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na), dim3(kS2Threads), kProbeLds, L.stream, *L.plan, L.chunks,
                            L.cloud_first_chunk, L.cols, L.modes);
@@ -2270,9 +2283,17 @@ int stage1_launch_encode(const EncodeLaunch& L) {
       if (fused_field != kNoFusedField) {
         F.fuse_col = L.cols.p[fused_field];
         F.fuse_first = L.ranks[fused_field];
-        const uint32_t splits = L.n_chunks >= 512u ? 1u : (L.n_chunks >= 128u ? 2u : 8u);
+        // small batches: 1024-thread workgroups (a chunk's Palette section is latency-bound: twice the threads, 0.6x the time)
+        static const uint32_t big_at = getenv("CLDN_HIP_FINISH_1024_BELOW") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_1024_BELOW")) : 200u;  // A/B switch
+        const bool big = L.n_chunks < big_at;
+        const uint32_t splits = big ? 4u : (L.n_chunks >= 512u ? 1u : 2u);
         F.splits = splits;
-        if (L.plan->adaptive[fused_field].bpv == 2u)
+        const bool u16 = L.plan->adaptive[fused_field].bpv == 2u;
+        if (big && u16)
+          hipLaunchKernelGGL((k_finish<1024, 2>), dim3(L.n_chunks * splits), dim3(1024), Pal32<uint16_t>::kLds, L.stream, F);
+        else if (big)
+          hipLaunchKernelGGL((k_finish<1024, 4>), dim3(L.n_chunks * splits), dim3(1024), Pal32<uint32_t>::kLds, L.stream, F);
+        else if (u16)
           hipLaunchKernelGGL((k_finish<512, 2>), dim3(L.n_chunks * splits), dim3(512), Pal32<uint16_t>::kLds, L.stream, F);
         else
           hipLaunchKernelGGL((k_finish<512, 4>), dim3(L.n_chunks * splits), dim3(512), Pal32<uint32_t>::kLds, L.stream, F);

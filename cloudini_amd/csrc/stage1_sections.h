@@ -22,7 +22,7 @@ constexpr uint32_t kS2PalSlots = 4096;
 constexpr uint32_t kS2PalCapacity = 3072;  // load factor 0.75
 constexpr uint32_t kInf = 0xffffffffu;
 constexpr uint32_t kProbeSlots = 8192;                       // mode probe: distinct-value count of <= 4096 values
-constexpr uint32_t kProbeLds = kProbeSlots * 8u + 16u + 256u;  // keys, counters, scan scratch
+constexpr uint32_t kProbeLds = kProbeSlots * 8u + 16u + 256u;  // keys, scan scratch (+ counters at word 40 of the scratch)
 
 struct Pal2 {
   unsigned long long* keys;  // [kS2PalSlots]      ~0 = free
@@ -149,37 +149,33 @@ __device__ __forceinline__ uint32_t block_suffix_min_exclusive(uint32_t mine, ui
   return min(excl, cross);
 }
 
-template <typename RawT>
-__device__ __forceinline__ uint8_t probe_mode(const RawT* col, uint32_t n, uint32_t type, uint8_t* smem) {
-  constexpr int T = kS2Threads;
-  uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + kProbeSlots * 8u + 16u);  // behind the key table and its counters
-  const uint32_t t0 = threadIdx.x * 4u;
-  const uint32_t cnt = t0 < n ? min(4u, n - t0) : 0u;
-  RawT v[4];
+// T threads, VPT = 4096 / T consecutive values per thread. `at(i)` = value i of the window (a column, or the AoS input).
+// LDS: `smem` = distinct-value structure (16-bit keys: presence bitmap of 8 KiB; wider keys: hash table of `slots` keys),
+// `wtot` = 64 words of scan scratch behind it.
+template <typename RawT, int T, typename At>
+__device__ __forceinline__ uint8_t probe_mode_t(At at, uint32_t n, uint32_t type, uint8_t* smem, uint32_t slots, uint32_t* wtot) {
+  constexpr uint32_t VPT = 4096u / (uint32_t)T;
+  const uint32_t t0 = threadIdx.x * VPT;
+  const uint32_t cnt = t0 < n ? min(VPT, n - t0) : 0u;
+  RawT v[VPT];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = ((uint32_t)j < cnt) ? col[t0 + j] : (RawT)0;
-  const RawT pm1 = (cnt && t0 >= 1u) ? col[t0 - 1u] : (RawT)0;
-  const RawT pm2 = (cnt && t0 >= 2u) ? col[t0 - 2u] : (RawT)0;
+  for (uint32_t j = 0; j < VPT; ++j) v[j] = (j < cnt) ? at(t0 + j) : (RawT)0;
+  const RawT pm1 = (cnt && t0 >= 1u) ? at(t0 - 1u) : (RawT)0;
+  const RawT pm2 = (cnt && t0 >= 2u) ? at(t0 - 2u) : (RawT)0;
   auto as64 = [&](RawT r) { return int_field_as_i64((uint64_t)r, type); };
-
-  // keys: raw values (Rle) and first differences (DeltaVarint / DeltaRle), values[-1] = 0
-  uint64_t diff[4];
-  {
-    int64_t prev = t0 >= 1u ? as64(pm1) : 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t cur = as64(v[j]);
-      diff[j] = (uint64_t)cur - (uint64_t)prev;
-      prev = cur;
-    }
-  }
+  // first differences (DeltaVarint / DeltaRle keys), values[-1] = 0: recomputed where needed (registers)
+  auto diff_of = [&](uint32_t j) -> uint64_t {
+    const int64_t cur = as64(v[j]);
+    const int64_t prev = j ? as64(v[j - 1u]) : (t0 >= 1u ? as64(pm1) : 0);
+    return (uint64_t)cur - (uint64_t)prev;
+  };
   const uint64_t diff_before = (uint64_t)(t0 >= 1u ? as64(pm1) : 0) - (uint64_t)(t0 >= 2u ? as64(pm2) : 0);
 
   // DeltaVarint: 1 + sum of token lengths
   uint32_t dv = 0u;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if ((uint32_t)j < cnt) dv += varint64_len((int64_t)diff[j]);
+  for (uint32_t j = 0; j < VPT; ++j)
+    if (j < cnt) dv += varint64_len((int64_t)diff_of(j));
   const uint32_t delta_size = 1u + block_sum<T>(dv, wtot);
 
   // run heads of both run codings
@@ -187,13 +183,14 @@ __device__ __forceinline__ uint8_t probe_mode(const RawT* col, uint32_t n, uint3
   {
     uint64_t kr = (uint64_t)pm1, kd = diff_before;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if ((uint32_t)j < cnt) {
-        const bool first = (t0 + (uint32_t)j) == 0u;
+    for (uint32_t j = 0; j < VPT; ++j) {
+      if (j < cnt) {
+        const bool first = (t0 + j) == 0u;
+        const uint64_t d = diff_of(j);
         if (first || (uint64_t)v[j] != kr) hr |= 1u << j;
-        if (first || diff[j] != kd) hd |= 1u << j;
+        if (first || d != kd) hd |= 1u << j;
         kr = (uint64_t)v[j];
-        kd = diff[j];
+        kd = d;
       }
     }
   }
@@ -203,11 +200,11 @@ __device__ __forceinline__ uint8_t probe_mode(const RawT* col, uint32_t n, uint3
     if (next_after == kInf) next_after = n;
     uint32_t bytes = 0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (uint32_t j = 0; j < VPT; ++j) {
       if (heads & (1u << j)) {
         const uint32_t above = heads & ~((2u << j) - 1u);
         const uint32_t nxt = above ? (t0 + (uint32_t)__builtin_ctz(above)) : next_after;
-        bytes += (delta ? varint64_len((int64_t)diff[j]) : (uint32_t)sizeof(RawT)) + uvarint32_len(nxt - (t0 + (uint32_t)j));
+        bytes += (delta ? varint64_len((int64_t)diff_of(j)) : (uint32_t)sizeof(RawT)) + uvarint32_len(nxt - (t0 + j));
       }
     }
     return 5u + block_sum<T>(bytes, wtot);
@@ -215,39 +212,58 @@ __device__ __forceinline__ uint8_t probe_mode(const RawT* col, uint32_t n, uint3
   const uint32_t rle_size = run_bytes(hr, false);
   const uint32_t drle_size = run_bytes(hd, true);
 
-  // Palette: number of distinct values, exact for any window: 8192 key slots for at most 4096 values keep the load
-  // below one half, so probe sequences stay short and the table cannot fill up
+  // Palette: number of distinct values, exact for any window
   __syncthreads();
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
-  uint32_t* cnt_l = reinterpret_cast<uint32_t*>(smem + kProbeSlots * 8u);  // [0] distinct keys, [1] the value ~0 seen
-  for (uint32_t s = threadIdx.x; s < kProbeSlots; s += T) keys[s] = ~0ull;
-  if (threadIdx.x < 2u) cnt_l[threadIdx.x] = 0u;
-  __syncthreads();
+  uint32_t U;
+  if (sizeof(RawT) == 2) {  // presence bitmap of the 65536 possible keys
+    uint32_t* bm = reinterpret_cast<uint32_t*>(smem);
+    for (uint32_t w = threadIdx.x; w < 2048u; w += T) bm[w] = 0u;
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if ((uint32_t)j < cnt) {
-      const unsigned long long key = (unsigned long long)v[j];
-      if (sizeof(RawT) == 8 && key == ~0ull) {
-        cnt_l[1] = 1u;
-      } else {
-        uint32_t slot = (sizeof(RawT) == 8 ? hash_u64(key) : ((uint32_t)key * 0x9e3779b1u) >> 19) & (kProbeSlots - 1u);
-        for (;;) {
-          unsigned long long k = keys[slot];
-          if (k == ~0ull) {
-            k = atomicCAS(&keys[slot], ~0ull, key);
-            if (k == ~0ull) {
-              atomicAdd(&cnt_l[0], 1u);
-              break;
+    for (uint32_t j = 0; j < VPT; ++j)
+      if (j < cnt) atomicOr(&bm[(uint32_t)v[j] >> 5], 1u << ((uint32_t)v[j] & 31u));
+    __syncthreads();
+    uint32_t pc = 0u;
+    for (uint32_t w = threadIdx.x; w < 2048u; w += T) pc += (uint32_t)__builtin_popcount(bm[w]);
+    U = block_sum<T>(pc, wtot);
+  } else {
+    // hash table of `slots` keys for at most 4096 values: the load stays below 0.7, so probe sequences stay short and the
+    // table cannot fill up (`slots` need not be a power of two: multiply-shift range reduction, probing modulo `slots`)
+    using Key = typename std::conditional<sizeof(RawT) == 8, unsigned long long, uint32_t>::type;
+    constexpr Key kFreeKey = ~(Key)0;
+    Key* keys = reinterpret_cast<Key*>(smem);
+    uint32_t* cnt_l = wtot + 40;  // [0] distinct keys, [1] the all-ones value seen
+    for (uint32_t sidx = threadIdx.x; sidx < slots; sidx += T) keys[sidx] = kFreeKey;
+    if (threadIdx.x < 2u) cnt_l[threadIdx.x] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < VPT; ++j) {
+      if (j < cnt) {
+        const Key key = (Key)v[j];
+        if (key == kFreeKey) {
+          cnt_l[1] = 1u;
+        } else {
+          const uint32_t h32 = sizeof(RawT) == 8 ? hash_u64((uint64_t)key) * 0x9e3779b1u : (uint32_t)key * 0x9e3779b1u;
+          uint32_t slot = (uint32_t)(((uint64_t)h32 * slots) >> 32);
+          for (;;) {
+            Key k = keys[slot];
+            if (k == kFreeKey) {
+              k = atomicCAS(&keys[slot], kFreeKey, key);
+              if (k == kFreeKey) {
+                atomicAdd(&cnt_l[0], 1u);
+                break;
+              }
             }
+            if (k == key) break;
+            slot = slot + 1u == slots ? 0u : slot + 1u;
           }
-          if (k == key) break;
-          slot = (slot + 1u) & (kProbeSlots - 1u);
         }
       }
     }
+    __syncthreads();
+    U = cnt_l[0] + cnt_l[1];
+    __syncthreads();
   }
-  __syncthreads();
-  const uint32_t U = cnt_l[0] + cnt_l[1];
   const uint32_t pal_size = 3u + U * (uint32_t)sizeof(RawT) + ((palette_bits(U) * n + 7u) >> 3);
 
   uint32_t mode = 0u, best = delta_size;  // strict '<' in this order
@@ -255,6 +271,13 @@ __device__ __forceinline__ uint8_t probe_mode(const RawT* col, uint32_t n, uint3
   if (rle_size < best) { best = rle_size; mode = 2u; }
   if (drle_size < best) { mode = 3u; }
   return (uint8_t)mode;
+}
+
+template <typename RawT>
+__device__ __forceinline__ uint8_t probe_mode(const RawT* col, uint32_t n, uint32_t type, uint8_t* smem) {
+  // 8192 key slots of 8 bytes (k_probe_fast's LDS), scan scratch behind them
+  uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + kProbeSlots * 8u + 16u);
+  return probe_mode_t<RawT, kS2Threads>([&](uint32_t i) { return col[i]; }, n, type, smem, kProbeSlots, wtot);
 }
 
 // grid = (n_clouds, n_adaptive). Exact for every window (the general probe kernel is only the A/B reference).
