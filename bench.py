@@ -497,6 +497,51 @@ def main():
                   "ms_per_step_max": float(max(dec_blocks)) * 1e3,
                   "HBM_GBps": (total_out + points_local * step) / (dec_ms * 1e-3) / 1e9,
                   "chunks_parallel_regular/parallel_sections/serial/serial_sections": list(dec_stats)}
+    # extra (not `value`): stage 1 WITHOUT the framing -- cldn_hip_encode_stage1_chunks leaves every chunk's payload as one
+    # run of its slot (the reference's own stage-1 / stage-2 boundary is a buffer per chunk, src/cloudini.cpp:590-614);
+    # a device-side stage 2 or any other consumer on the GPU starts from there. Same steps, same bracket; the table is
+    # framed afterwards (outside the timed region) and compared with the streams of the timed batch.
+    chunk_table = None
+    if rank == 0 and points_local and args.shard == "clouds":
+        try:
+            ct_codec = native.Codec(plan, device=local_rank, stream=stream.cuda_stream)
+            for _ in range(max(1, args.warmup)):
+                ct_codec.encode_chunks_device(d_points.data_ptr(), cloud_points)
+            ct_codec.status()
+            ct_codec.enable_timing(max(1, args.steps))
+            ct_blocks = []
+            for _rep in range(max(1, min(3, args.repeats))):
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    table = ct_codec.encode_chunks_device(d_points.data_ptr(), cloud_points)
+                torch.cuda.synchronize(dev)
+                ct_blocks.append((time.perf_counter() - t1) / args.steps)
+            ct_codec.status()
+            ct_k = [ct_codec.kernel_ms(s_) for s_ in range(args.steps)]
+            d_out2 = torch.empty(cap, dtype=torch.uint8, device=dev)
+            d_off2 = torch.zeros(n_clouds + 1, dtype=torch.int64, device=dev)
+            ct_codec.frame_chunks_device(d_out2.data_ptr(), cap, d_off2.data_ptr())
+            torch.cuda.synchronize(dev)
+            ct_codec.status()
+            same = bool(torch.equal(d_off2, d_offsets)) and bool(torch.equal(d_out2[:total_out], d_out[:total_out]))
+            import ctypes as _C
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            _C.CDLL("libamdhip64.so").hipMemcpy(_C.c_void_p(flag.data_ptr()), _C.c_void_p(table.not_contiguous), _C.c_size_t(4), 3)
+            ct_ms = float(np.median(ct_blocks)) * 1e3
+            ct_dev = float(np.mean([k["total"] for k in ct_k]))
+            chunk_table = {"value": points_local / (ct_ms * 1e-3) / 1e6, "unit": "Mpoints/s (rank 0, stage 1 to the chunk table: no framing)",
+                           "ms_per_step": ct_ms, "ms_per_step_min": float(min(ct_blocks)) * 1e3,
+                           "device_ms_per_step": {"regular": float(np.mean([k["regular"] for k in ct_k])),
+                                                  "sections": float(np.mean([k["sections"] for k in ct_k])), "all_kernels": ct_dev},
+                           "whole_stage1_GBps": points_local * (step + out_bpp) / (ct_dev * 1e-3) / 1e9,
+                           "payloads_contiguous": int(flag.item()) == 0,
+                           "framed_afterwards_equals_the_timed_batch": same}
+            del d_out2
+            ct_codec.close()
+        except Exception as exc:  # never costs the headline line
+            chunk_table = {"error": repr(exc)}
+
     # "plus bit-exactness flag vs oracle" -- the streams the TIMED batch left in HBM, compared
     # outside the timed region with the compiled reference (oracle/_ref) or, where that is absent, the C port: every
     # distinct cloud against the checker, every tiled copy against its first occurrence
@@ -598,6 +643,7 @@ def main():
             "bit_exact": bit_exact["ok"] if bit_exact else None,
             "bit_exact_detail": bit_exact,
             "decode": decode,
+            "chunk_table": chunk_table,
             "stage1_bytes_per_point": out_bpp,
             "device_ms_per_step": {dominant: regular_ms, "sections": sections_ms,
                                    "offsets+compact": compact_ms, "all_kernels": device_ms},

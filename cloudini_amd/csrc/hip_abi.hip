@@ -162,6 +162,11 @@ struct cldn_hip_codec {
   DevBuf d_dec_meta, d_pre_ptrs;
   DevBuf d_dec_cols[2];       // decode: dense columns of the adaptive fields that k_decode_points takes its integer fields from
   // stage 2 on the device (cldn_hip_codec_set_stage2): the stage-1 streams stay in d_s1, LZ4 blocks go to d_lz_slots
+  // chunk table of the last cldn_hip_encode_stage1_chunks call (cldn_hip_frame_chunks frames it)
+  bool ct_valid = false;
+  uint32_t ct_n_chunks = 0, ct_n_clouds = 0, ct_segs_per_chunk = 0;
+  uint64_t ct_slot_stride = 0, ct_need = 0;
+  size_t ct_segs_off = 0, ct_anchor_off = 0;
   int stage2 = 0;
   DevBuf d_s1, d_s1_offsets, d_lz_matches, d_lz_counts, d_lz_slots, d_lz_segs, d_payload2, d_dst2;
   DevBuf d_finrec;            // k_finish look-back records (rec, rec2), cleared only when (re)allocated
@@ -683,15 +688,23 @@ static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, u
 }  // extern "C"
 
 // cloud_ptrs != NULL: the clouds live in separate HOST buffers (`points` is ignored)
+// table != NULL: chunk-table output (cldn_hip_encode_stage1_chunks): no framing, `out` is not used
 static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int points_loc, const void* const* cloud_ptrs,
                               const uint64_t* cloud_points, uint32_t n_clouds, void* out, uint64_t out_capacity, int out_loc,
-                              uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes) {
+                              uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes,
+                              cldn_hip_chunk_table_t* table = nullptr) {
   if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if (table) {
+    memset(table, 0, sizeof(*table));
+    c->ct_valid = false;
+    if (c->stage2 != CLDN_HIP_STAGE2_NONE) return fail(CLDN_HIP_ERR_ARG, "chunk-table output and stage 2 on the device exclude each other");
+  }
   if (n_clouds && !cloud_points) return fail(CLDN_HIP_ERR_ARG, "cloud_points is NULL");
   if ((points_loc != CLDN_HIP_HOST && points_loc != CLDN_HIP_DEVICE) ||
       (out_loc != CLDN_HIP_HOST && out_loc != CLDN_HIP_DEVICE))
     return fail(CLDN_HIP_ERR_ARG, "invalid memory location tag");
   ENTER_DEVICE(c->device);
+  c->ct_valid = false;  // (the workspace is about to be rewritten)
   const DevPlan& plan = c->plan.dev;
   const uint32_t step = plan.point_step;
 
@@ -700,7 +713,8 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   // device-resident inputs decide the kernel variant by their address; host inputs are staged into an aligned buffer
   const uint8_t* variant_ptr = points_loc == CLDN_HIP_DEVICE ? (const uint8_t*)points : nullptr;
   const uint32_t piece_pts = c->pipeline == 1 ? 0u : stage1_piece_points(plan, variant_ptr);
-  static const bool intra_env = getenv("CLDN_HIP_INTRA") && atoi(getenv("CLDN_HIP_INTRA")) != 0;  // A/B switch
+  static const bool intra_env0 = getenv("CLDN_HIP_INTRA") && atoi(getenv("CLDN_HIP_INTRA")) != 0;  // A/B switch
+  const bool intra_env = intra_env0 || table != nullptr;  // chunk tables want one regular segment per chunk
   static const bool quad_major_env = !(getenv("CLDN_HIP_QUAD_MAJOR") && atoi(getenv("CLDN_HIP_QUAD_MAJOR")) == 0);
   int rc = upload_batch_shape(c, cloud_points, n_clouds, piece_pts, piece_pts != 0u && intra_env && quad_major_env, &n_chunks, &n_points);
   if (rc != CLDN_HIP_OK) return rc;
@@ -717,12 +731,12 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   }
   const bool lz4 = c->stage2 == CLDN_HIP_STAGE2_LZ4;
   // two-step host output (cldn_hip_codec_fetch_output): no caller buffer yet, the codec's own device buffer takes the bound
-  const bool deferred = out == nullptr && out_loc == CLDN_HIP_HOST;
-  if (deferred) out_capacity = need;
+  const bool deferred = out == nullptr && out_loc == CLDN_HIP_HOST && !table;
+  if (deferred || table) out_capacity = need;
   if (out_capacity < need)
     return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for worst-case compressed size (%llu < %llu)",
                 (unsigned long long)out_capacity, (unsigned long long)need);
-  if (need && !out && !deferred) return fail(CLDN_HIP_ERR_ARG, "out is NULL");
+  if (need && !out && !deferred && !table) return fail(CLDN_HIP_ERR_ARG, "out is NULL");
   c->pending_total = 0;
 
   const uint32_t n_adaptive = plan.n_adaptive;
@@ -809,7 +823,7 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
       }
       d_points = (const uint8_t*)c->d_in.p;
     }
-    if (out_loc == CLDN_HIP_HOST) {
+    if (out_loc == CLDN_HIP_HOST && !table) {
       if ((rc = c->d_out.ensure((size_t)need)) != CLDN_HIP_OK) return rc;
       d_outp = (uint8_t*)c->d_out.p;
     }
@@ -878,6 +892,8 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   L.fin_anchor = (unsigned long long*)((uint8_t*)c->d_status.p + z_anchor);
   L.fin_epoch = c->finish_epoch;
   L.fin_ticket = (uint32_t*)c->d_status.p + 40;
+  L.chunks_only = table != nullptr;
+  L.contiguous_flag = (uint32_t*)c->d_status.p + 42;
   if (pieces) {
     L.pieces = (const PieceDesc*)c->d_pieces.p;
     L.n_pieces = c->n_pieces;
@@ -964,6 +980,26 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   }
   if (n_slots) c->slot_valid[slot] = 1;
   ++c->call_index;
+  if (table) {
+    table->payload_base = (const uint8_t*)c->d_slots.p;
+    table->chunk_stride = slot_stride;
+    table->segments = (const cldn_hip_segment_t*)L.segs;
+    table->segments_per_chunk = segs_per_chunk;
+    table->chunk_sizes = (const uint32_t*)c->d_payload.p;
+    table->not_contiguous = (const uint32_t*)c->d_status.p + 42;
+    table->n_chunks = n_chunks;
+    c->ct_valid = true;
+    c->ct_n_chunks = n_chunks;
+    c->ct_n_clouds = n_clouds;
+    c->ct_slot_stride = slot_stride;
+    c->ct_segs_per_chunk = segs_per_chunk;
+    c->ct_segs_off = z_segs;
+    c->ct_anchor_off = z_anchor;
+    c->ct_need = need;
+    if (modes && (size_t)n_clouds * n_adaptive)
+      HIP_TRY(hipMemcpyAsync(modes, c->d_modes.p, (size_t)n_clouds * n_adaptive, hipMemcpyDeviceToDevice, c->stream));
+    return CLDN_HIP_OK;
+  }
 
   if (const char* dump = getenv("CLDN_HIP_DEBUG_DUMP")) {  // diagnostics: segment table of the last call
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1038,6 +1074,81 @@ int cldn_hip_encode_stage1_gather(cldn_hip_codec_t* c, const void* const* cloud_
   if (n_clouds && !cloud_ptrs) return fail(CLDN_HIP_ERR_ARG, "cloud_ptrs is NULL");
   return encode_stage1_impl(c, nullptr, CLDN_HIP_HOST, cloud_ptrs, cloud_points, n_clouds, out, out_capacity, out_loc,
                             stream_offsets, chunk_sizes, modes);
+}
+
+int cldn_hip_encode_stage1_chunks(cldn_hip_codec_t* c, const void* points, int points_loc, const uint64_t* cloud_points,
+                                  uint32_t n_clouds, cldn_hip_chunk_table_t* table, uint8_t* modes_device) {
+  if (!table) return fail(CLDN_HIP_ERR_ARG, "table is NULL");
+  return encode_stage1_impl(c, points, points_loc, nullptr, cloud_points, n_clouds, nullptr, 0, CLDN_HIP_DEVICE, nullptr, nullptr,
+                            modes_device, table);
+}
+
+int cldn_hip_frame_chunks(cldn_hip_codec_t* c, void* out, uint64_t out_capacity, int out_loc, uint64_t* stream_offsets,
+                          uint32_t* chunk_sizes) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if (!c->ct_valid) return fail(CLDN_HIP_ERR_ARG, "frame_chunks: no chunk table (cldn_hip_encode_stage1_chunks must be this codec's last encode call)");
+  if (out_loc != CLDN_HIP_HOST && out_loc != CLDN_HIP_DEVICE) return fail(CLDN_HIP_ERR_ARG, "invalid memory location tag");
+  if (out_capacity < c->ct_need)
+    return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for worst-case compressed size (%llu < %llu)",
+                (unsigned long long)out_capacity, (unsigned long long)c->ct_need);
+  if (c->ct_need && !out) return fail(CLDN_HIP_ERR_ARG, "out is NULL");
+  ENTER_DEVICE(c->device);
+  int rc;
+  const uint32_t n_chunks = c->ct_n_chunks, n_clouds = c->ct_n_clouds;
+  uint8_t* d_outp = (uint8_t*)out;
+  if (out_loc == CLDN_HIP_HOST) {
+    c->pending_total = 0;
+    if ((rc = c->d_out.ensure((size_t)std::max<uint64_t>(1, c->ct_need))) != CLDN_HIP_OK) return rc;
+    d_outp = (uint8_t*)c->d_out.p;
+  }
+  if (++c->finish_epoch == 0u) {
+    HIP_TRY(hipMemsetAsync(c->d_finrec.p, 0, c->d_finrec.cap, c->stream));
+    c->finish_epoch = 1u;
+  }
+  // (anchors: zero since the encode call, or holding the values an earlier framing of the same table left -- the same ones)
+  FrameLaunch F;
+  F.stream = c->stream;
+  F.chunks = (const ChunkDesc*)c->d_chunks.p;
+  F.n_chunks = n_chunks;
+  F.cloud_first_chunk = (const uint32_t*)c->d_cloud_first.p;
+  F.n_clouds = n_clouds;
+  F.slots = (const uint8_t*)c->d_slots.p;
+  F.slot_stride = c->ct_slot_stride;
+  F.segs = (const Seg*)((uint8_t*)c->d_status.p + c->ct_segs_off);
+  F.segs_per_chunk = c->ct_segs_per_chunk;
+  F.rec = (unsigned long long*)c->d_finrec.p;
+  F.anchor = (unsigned long long*)((uint8_t*)c->d_status.p + c->ct_anchor_off);
+  F.epoch = c->finish_epoch;
+  F.ticket = (uint32_t*)c->d_status.p + 40;
+  F.chunk_payload = (uint32_t*)c->d_payload.p;
+  F.chunk_dst = (uint64_t*)c->d_dst.p;
+  F.stream_offsets = (uint64_t*)c->d_offsets.p;
+  F.out = d_outp;
+  F.out_capacity = out_capacity;
+  F.status = (uint32_t*)c->d_status.p;
+  if ((rc = stage1_launch_frame(F)) != CLDN_HIP_OK) return rc;
+  if (out_loc == CLDN_HIP_DEVICE) {
+    if (stream_offsets)
+      HIP_TRY(hipMemcpyAsync(stream_offsets, c->d_offsets.p, (size_t)(n_clouds + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+    if (chunk_sizes && n_chunks)
+      HIP_TRY(hipMemcpyAsync(chunk_sizes, c->d_payload.p, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    return CLDN_HIP_OK;
+  }
+  if ((rc = c->h_result.ensure((size_t)(n_clouds + 1) * sizeof(uint64_t) + 64)) != CLDN_HIP_OK) return rc;
+  uint64_t* h_off = (uint64_t*)c->h_result.p;
+  uint32_t* h_status = (uint32_t*)((uint8_t*)c->h_result.p + (size_t)(n_clouds + 1) * sizeof(uint64_t));
+  HIP_TRY(hipMemcpyAsync(h_off, c->d_offsets.p, (size_t)(n_clouds + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(h_status, c->d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (*h_status & ST_FINISH_TIMEOUT) return fail(CLDN_HIP_ERR_DEVICE, "k_finish: a workgroup waited too long (status 0x%x)", *h_status);
+  if (*h_status & ST_OUT_OVERFLOW) return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for uncompressed chunk");
+  const uint64_t total = h_off[n_clouds];
+  if (total) HIP_TRY(hipMemcpyAsync(out, d_outp, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+  if (chunk_sizes && n_chunks)
+    HIP_TRY(hipMemcpyAsync(chunk_sizes, c->d_payload.p, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (stream_offsets) memcpy(stream_offsets, h_off, (size_t)(n_clouds + 1) * sizeof(uint64_t));
+  return CLDN_HIP_OK;
 }
 
 int cldn_hip_viz_preprocess(cldn_hip_codec_t* c, const void* points, int points_loc, uint64_t n_points,

@@ -175,6 +175,26 @@ __device__ __forceinline__ void fin_copy(const FinishLds& L, const uint8_t* __re
   }
 }
 
+// k_chunk_sizes: chunk-table output (no framing): payload bytes of every chunk = sum of its segments; *not_contiguous (zero
+// at launch) becomes 1 if some chunk's non-empty segments do not form one run of its slot (segment k + 1 starts where
+// segment k ends).
+__global__ __launch_bounds__(256) void k_chunk_sizes(const Seg* __restrict__ segs, uint32_t segs_per_chunk, uint32_t n_chunks,
+                                                     uint32_t* __restrict__ chunk_payload, uint32_t* __restrict__ not_contiguous) {
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c >= n_chunks) return;
+  uint32_t payload = 0u, next = 0xffffffffu;
+  bool contiguous = true;
+  for (uint32_t s = 0; s < segs_per_chunk; ++s) {
+    const Seg sg = segs[(size_t)c * segs_per_chunk + s];
+    if (sg.size == 0u) continue;
+    if (next != 0xffffffffu && sg.off != next) contiguous = false;
+    next = sg.off + sg.size;
+    payload += sg.size;
+  }
+  chunk_payload[c] = payload;
+  if (!contiguous) atomicOr(not_contiguous, 1u);
+}
+
 // T threads; FUSE_BPV = 0 (no section work), 2 or 4 (Palette section of A.fuse_field in-kernel; T = 512, or 1024 for small
 // batches: a chunk's section then has twice the threads)
 template <int T, int FUSE_BPV>

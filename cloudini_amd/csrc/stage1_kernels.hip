@@ -536,7 +536,7 @@ __device__ __forceinline__ void ring_flush_n(uint32_t* ring, uint8_t* dst, uint3
   for (uint32_t u = (from >> 4) + threadIdx.x; u < (to >> 4); u += T) {
     const uint32_t r = u & (RING_BYTES / 16u - 1u);
     const uint4 v = ring4[r];
-    *reinterpret_cast<uint4*>(dst + (size_t)u * 16u) = v;
+    __builtin_memcpy(dst + (size_t)u * 16u, &v, 16);  // (dst may be unaligned: a section appended behind the regular stream)
     ring4[r] = make_uint4(0u, 0u, 0u, 0u);
   }
 }
@@ -2123,7 +2123,10 @@ static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c
       else pal64.a[pal64.n++] = (uint8_t)a;
     }
   }
-#define SEC_ARGS(FL) *L.plan, FL, chunks, L.cols, L.modes, slots, L.slot_stride, L.reg_stride, segs, L.segs_per_chunk, L.subs, flags
+  // one adaptive field + one regular segment per chunk (intra-chunk placement): the section goes right behind the regular
+  // stream, so that the chunk's payload is one contiguous run of its slot
+  const uint32_t append = (L.intra && na == 1u && L.subs == 1u) ? 1u : 0u;
+#define SEC_ARGS(FL) *L.plan, FL, chunks, L.cols, L.modes, slots, L.slot_stride, L.reg_stride, segs, L.segs_per_chunk, L.subs, flags, append
   if (run16.n) {
     hipLaunchKernelGGL(k_section_delta32<uint16_t>, dim3(nch, run16.n), dim3(kS2Threads), kD32Lds, stream, SEC_ARGS(run16));
     hipLaunchKernelGGL(k_section_runs<uint16_t>, dim3(nch, run16.n), dim3(kS2Threads), 0, stream, SEC_ARGS(run16));
@@ -2164,7 +2167,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   static const int finish_mode = getenv("CLDN_HIP_FINISH") ? atoi(getenv("CLDN_HIP_FINISH")) : 2;
   // the field whose Palette sections k_finish builds itself: the first 2- or 4-byte adaptive field that may commit Palette
   uint32_t fused_field = kNoFusedField;
-  if (finish_mode >= 2 && L.n_chunks) {
+  if (finish_mode >= 2 && L.n_chunks && !L.chunks_only) {
     for (uint32_t a = 0; a < L.plan->n_adaptive && fused_field == kNoFusedField; ++a)
       if ((L.plan->adaptive[a].bpv == 2u || L.plan->adaptive[a].bpv == 4u) && (L.mode_hint[a] & 0x2u)) fused_field = a;
   }
@@ -2245,6 +2248,15 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     if (rc_sec != CLDN_HIP_OK) return rc_sec;
   }
   if (L.events) (void)hipEventRecord(L.events[3], L.stream);
+  if (L.chunks_only) {
+    if (L.n_chunks) {
+      hipLaunchKernelGGL(k_chunk_sizes, dim3((L.n_chunks + 255u) / 256u), dim3(256), 0, L.stream, L.segs, L.segs_per_chunk, L.n_chunks,
+                         L.chunk_payload, L.contiguous_flag);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_chunk_sizes");
+    }
+    if (L.events) (void)hipEventRecord(L.events[4], L.stream);
+    return CLDN_HIP_OK;
+  }
   if (finish_mode != 0) {
     if (L.n_chunks == 0u) {  // no chunk, no workgroup: every cloud's stream is empty
       if ((e = hipMemsetAsync(L.stream_offsets, 0, (size_t)(L.n_clouds + 1u) * sizeof(uint64_t), L.stream)) != hipSuccess)

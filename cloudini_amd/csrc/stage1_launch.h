@@ -38,6 +38,10 @@ struct EncodeLaunch {
   // Only a launch hint: a fast section kernel that is not launched leaves its chunks to k_encode_sections.
   uint8_t mode_hint[kMaxAdaptive];
   uint8_t* fallback_flags;    // device [n_chunks * n_adaptive], zeroed per call: 1 = section written by a fast path
+  // chunk-table output: no framing -- the call ends with the chunks' payloads in their slots (segment table) and
+  // k_chunk_sizes (payload sizes, contiguity flag)
+  bool chunks_only;
+  uint32_t* contiguous_flag;       // device word, 0 at launch: set to 1 when a chunk's payload is not one run of its slot
   // k_finish (stage1_finish.h)
   unsigned long long* fin_rec;     // device [n_chunks]: look-back records, tagged with fin_epoch
   unsigned long long* fin_rec2;    // device [n_chunks]

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kS2Threads) void k_section_palette(const DevPlan pl
                                                                 uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                                 uint64_t reg_stride, Seg* __restrict__ segs,
                                                                 uint32_t segs_per_chunk, uint32_t subs,
-                                                                uint8_t* __restrict__ handled_flags) {
+                                                                uint8_t* __restrict__ handled_flags, uint32_t /*append*/) {
   constexpr int T = kS2Threads;
   constexpr int NW = T / 64;
   constexpr uint32_t ROUND = T * 8u;  // values per round
@@ -837,7 +837,7 @@ template <typename RawT, int T = kS2Threads>
 __global__ __launch_bounds__(T, (T == 512 ? 8 : 4)) __attribute__((amdgpu_num_sgpr(80))) void k_section_palette32(
     const DevPlan plan, const SectionFields fl, const ChunkDesc* __restrict__ chunks, const ColumnPtrs cols,
     const uint8_t* __restrict__ modes, uint8_t* __restrict__ slots, uint64_t slot_stride, uint64_t reg_stride,
-    Seg* __restrict__ segs, uint32_t segs_per_chunk, uint32_t subs, uint8_t* __restrict__ handled_flags,
+    Seg* __restrict__ segs, uint32_t segs_per_chunk, uint32_t subs, uint8_t* __restrict__ handled_flags, uint32_t append,
     const ColumnPtrs first_cols, uint32_t* __restrict__ status) {
   static_assert(sizeof(RawT) == 2 || sizeof(RawT) == 4, "16- or 32-bit keys");
   static_assert(kS2Threads * 32u == 32768u && (T == kS2Threads || 2 * T == kS2Threads), "bitmap words per thread: 1 or 2");
@@ -849,20 +849,26 @@ __global__ __launch_bounds__(T, (T == 512 ? 8 : 4)) __attribute__((amdgpu_num_sg
   if (modes[cd.cloud * plan.n_adaptive + a] != 1u) return;
   const uint32_t n = cd.n_points;
   const RawT* col = reinterpret_cast<const RawT*>(cols.p[a]) + cd.first_point;
-  const uint32_t sec_off = (uint32_t)reg_stride + a * kSectionStride;
+  const uint32_t sec_off = append ? segs[(size_t)c * segs_per_chunk].size : (uint32_t)reg_stride + a * kSectionStride;
   uint8_t* dst = slots + (size_t)c * slot_stride + sec_off;
   const P p(smem);
   const uint32_t tid = threadIdx.x;
 
+  // the section in one piece: header, palette values, packed indexes right behind them (any alignment)
   uint32_t U;
   if (pal32_build<RawT, T>(p, col, n)) {
-    U = pal32_rank<RawT, T>(p, dst + 3u);
-    pal32_pack_chunk<RawT, T>(p, col, n, palette_bits(U), dst + kPaletteIndexOffset);
+    U = p.misc[0];
+    (void)pal32_rank<RawT, T>(p, dst + 3u);
+    pal32_pack_chunk<RawT, T>(p, col, n, palette_bits(U), dst + 3u + U * (uint32_t)sizeof(RawT));
   } else {
     uint16_t* first = reinterpret_cast<uint16_t*>(first_cols.p[a]) + cd.first_point;
     if (!pal32_slow_first<RawT, T>(p, col, n, first, status)) return;
-    U = pal32_slow_rank<RawT, T>(p, col, n, first, dst + 3u);
-    pal32_slow_pack<RawT, T>(p, n, palette_bits(U), first, dst + kPaletteIndexOffset);
+    uint32_t mine = 0u;
+    for (uint32_t i = tid; i < n; i += T) mine += first[i] == (uint16_t)i ? 1u : 0u;
+    (void)block_exclusive_scan<T>(mine, p.wtot, &U);
+    __syncthreads();
+    (void)pal32_slow_rank<RawT, T>(p, col, n, first, dst + 3u);
+    pal32_slow_pack<RawT, T>(p, n, palette_bits(U), first, dst + 3u + U * (uint32_t)sizeof(RawT));
   }
   if (tid == 0) {
     dst[0] = 1u;
@@ -870,10 +876,9 @@ __global__ __launch_bounds__(T, (T == 512 ? 8 : 4)) __attribute__((amdgpu_num_sg
     dst[2] = (uint8_t)((U >> 8) & 0xffu);  // static_cast<uint16_t>(palette.size()), v5_codec.cpp:464
     Seg s;
     s.off = sec_off;
-    s.size = 3u + U * (uint32_t)sizeof(RawT);
+    s.size = 3u + U * (uint32_t)sizeof(RawT) + ((palette_bits(U) * n + 7u) >> 3);
     segs[(size_t)c * segs_per_chunk + subs + 2u * a] = s;
-    s.off = sec_off + kPaletteIndexOffset;
-    s.size = (palette_bits(U) * n + 7u) >> 3;
+    s.size = 0u;
     segs[(size_t)c * segs_per_chunk + subs + 1u + 2u * a] = s;
     handled_flags[(size_t)c * plan.n_adaptive + a] = 1u;
   }
@@ -897,7 +902,7 @@ __global__ __launch_bounds__(kS2Threads) void k_section_delta32(const DevPlan pl
                                                                 uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                                 uint64_t reg_stride, Seg* __restrict__ segs,
                                                                 uint32_t segs_per_chunk, uint32_t subs,
-                                                                uint8_t* __restrict__ handled_flags) {
+                                                                uint8_t* __restrict__ handled_flags, uint32_t append) {
   static_assert(sizeof(RawT) == 2 || sizeof(RawT) == 4, "differences of at most 33 bits");
   constexpr int T = kS2Threads;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -910,7 +915,7 @@ __global__ __launch_bounds__(kS2Threads) void k_section_delta32(const DevPlan pl
   const uint32_t n = cd.n_points;
   const uint32_t type = plan.adaptive[a].type;
   const RawT* col = reinterpret_cast<const RawT*>(cols.p[a]) + cd.first_point;
-  const uint32_t sec_off = (uint32_t)reg_stride + a * kSectionStride;
+  const uint32_t sec_off = append ? segs[(size_t)c * segs_per_chunk].size : (uint32_t)reg_stride + a * kSectionStride;
   uint8_t* dst = slots + (size_t)c * slot_stride + sec_off;
   const uint32_t tid = threadIdx.x;
   for (uint32_t i = tid; i < kD32Ring / 16u; i += T) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -983,7 +988,7 @@ __global__ __launch_bounds__(kS2Threads) void k_section_runs(const DevPlan plan,
                                                              uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                              uint64_t reg_stride, Seg* __restrict__ segs,
                                                              uint32_t segs_per_chunk, uint32_t subs,
-                                                             uint8_t* __restrict__ handled_flags) {
+                                                             uint8_t* __restrict__ handled_flags, uint32_t append) {
   static_assert(sizeof(RawT) == 2 || sizeof(RawT) == 4, "differences of at most 33 bits");
   constexpr int T = kS2Threads;
   __shared__ uint32_t wtot[64];
@@ -996,7 +1001,7 @@ __global__ __launch_bounds__(kS2Threads) void k_section_runs(const DevPlan plan,
   const uint32_t n = cd.n_points;
   const uint32_t type = plan.adaptive[a].type;
   const RawT* col = reinterpret_cast<const RawT*>(cols.p[a]) + cd.first_point;
-  const uint32_t sec_off = (uint32_t)reg_stride + a * kSectionStride;
+  const uint32_t sec_off = append ? segs[(size_t)c * segs_per_chunk].size : (uint32_t)reg_stride + a * kSectionStride;
   uint8_t* dst = slots + (size_t)c * slot_stride + sec_off;
   const uint32_t tid = threadIdx.x;
   const uint32_t i0 = tid * 32u;

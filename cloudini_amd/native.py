@@ -19,6 +19,17 @@ HOST, DEVICE = 0, 1
 ERRORS = {-1: "ARG", -2: "CAPACITY", -3: "UNSUPPORTED", -4: "DEVICE", -5: "NO_DEVICE", -6: "CORRUPT", -7: "NOMEM"}
 
 
+class _Segment(C.Structure):
+    _fields_ = [("offset", C.c_uint32), ("size", C.c_uint32)]
+
+
+class ChunkTable(C.Structure):
+    """cldn_hip_chunk_table_t: device pointers into the codec's workspace (valid until the codec's next call)."""
+    _fields_ = [("payload_base", C.c_void_p), ("chunk_stride", C.c_uint64), ("segments", C.c_void_p),
+                ("segments_per_chunk", C.c_uint32), ("n_chunks", C.c_uint32), ("chunk_sizes", C.c_void_p),
+                ("not_contiguous", C.c_void_p)]
+
+
 class CloudiniHipError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"cloudini_hip error {code} ({ERRORS.get(code, '?')}): {message}")
@@ -97,6 +108,10 @@ def lib() -> C.CDLL:
     L.cldn_hip_codec_decode_stats.restype = C.c_int
     L.cldn_hip_codec_force_modes.argtypes = [vp, C.POINTER(C.c_uint8), C.c_uint32]
     L.cldn_hip_codec_force_modes.restype = C.c_int
+    L.cldn_hip_encode_stage1_chunks.restype = C.c_int
+    L.cldn_hip_encode_stage1_chunks.argtypes = [vp, vp, C.c_int, u64p, C.c_uint32, C.POINTER(ChunkTable), vp]
+    L.cldn_hip_frame_chunks.restype = C.c_int
+    L.cldn_hip_frame_chunks.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, vp]
     L.cldn_hip_codec_set_stage2.argtypes = [vp, C.c_int]
     L.cldn_hip_codec_set_stage2.restype = C.c_int
     L.cldn_hip_stage2_bound.argtypes = [vp, C.c_uint64, C.c_int]
@@ -270,6 +285,19 @@ class Codec:
             chunk_sizes.ctypes.data_as(C.c_void_p), modes.ctypes.data_as(C.c_void_p)))
         streams = [out[int(offs[k]):int(offs[k + 1])].copy() for k in range(len(arrs))]
         return streams, chunk_sizes[:n_chunks], modes[: len(arrs) * na].reshape(len(arrs), na)
+
+    # ---- chunk-table output ----------------------------------------------------------------------------
+    def encode_chunks_device(self, points_ptr: int, cloud_points: np.ndarray, modes_ptr: int = 0) -> ChunkTable:
+        """cldn_hip_encode_stage1_chunks on device-resident points: stage 1 without the framing (asynchronous)."""
+        cp = np.ascontiguousarray(cloud_points, dtype=np.uint64)
+        table = ChunkTable()
+        _check(lib().cldn_hip_encode_stage1_chunks(self._h, C.c_void_p(points_ptr), DEVICE, cp.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                   cp.size, C.byref(table), C.c_void_p(modes_ptr)))
+        return table
+
+    def frame_chunks_device(self, out_ptr: int, out_capacity: int, stream_offsets_ptr: int = 0, chunk_sizes_ptr: int = 0):
+        _check(lib().cldn_hip_frame_chunks(self._h, C.c_void_p(out_ptr), int(out_capacity), DEVICE, C.c_void_p(stream_offsets_ptr),
+                                           C.c_void_p(chunk_sizes_ptr)))
 
     # ---- device buffers (raw pointers, e.g. torch tensors' data_ptr()) ---------------------------------
     def encode_device(self, points_ptr: int, cloud_points: np.ndarray, out_ptr: int, out_capacity: int,

@@ -118,6 +118,36 @@ int cldn_hip_encode_stage1(cldn_hip_codec_t* codec, const void* points, int poin
                            const uint64_t* cloud_points, uint32_t n_clouds, void* out, uint64_t out_capacity,
                            int out_loc, uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes);
 
+/* Chunk-table output: stage 1 WITHOUT the framing. The reference's own boundary between stage 1 and stage 2 is a buffer
+ * per chunk (EncodeV5Stage1 / EncodeV4Stage1Chunk write one, WriteStage1Chunk compresses or copies it into the stream:
+ * src/cloudini.cpp:590-614, src/chunk_writer.cpp:27-48); this call stops there. The payload of chunk c (batch order) is
+ * the concatenation of its non-empty segments: segments[c * segments_per_chunk + k] = {offset inside the chunk's slot
+ * payload_base + c * chunk_stride, size}; chunk_sizes[c] = their sum. Schemas with at most one adaptive integer field
+ * on the piece-kernel path (XYZ, XYZI, XYZ + rgba, XYZI + ring ...) get every payload as ONE run of its slot
+ * (*not_contiguous stays 0): nothing is moved a second time, which is what a device-side stage 2 or any other consumer
+ * on the GPU wants. All pointers are DEVICE pointers into the codec's workspace: valid until the codec's next call, to
+ * be read behind the codec's stream. modes_device: DEVICE array [n_clouds * adaptive_fields] or NULL.
+ * cldn_hip_frame_chunks turns the table of the codec's last cldn_hip_encode_stage1_chunks call into the framed streams
+ * (one straight copy per chunk) exactly as cldn_hip_encode_stage1 would have written them. */
+typedef struct cldn_hip_segment {
+  uint32_t offset;
+  uint32_t size;
+} cldn_hip_segment_t;
+typedef struct cldn_hip_chunk_table {
+  const uint8_t* payload_base;
+  uint64_t chunk_stride;
+  const cldn_hip_segment_t* segments;
+  uint32_t segments_per_chunk;
+  uint32_t n_chunks;
+  const uint32_t* chunk_sizes;
+  const uint32_t* not_contiguous; /* one word: 0 = every chunk's payload is one run, starting at its first non-empty segment */
+} cldn_hip_chunk_table_t;
+int cldn_hip_encode_stage1_chunks(cldn_hip_codec_t* codec, const void* points, int points_loc,
+                                  const uint64_t* cloud_points, uint32_t n_clouds, cldn_hip_chunk_table_t* table,
+                                  uint8_t* modes_device);
+int cldn_hip_frame_chunks(cldn_hip_codec_t* codec, void* out, uint64_t out_capacity, int out_loc,
+                          uint64_t* stream_offsets, uint32_t* chunk_sizes);
+
 /* Two-step host output, for callers that do not want to provide the worst-case bound in host memory (50 bytes per point
  * for XYZI+ring against 8 produced): cldn_hip_encode_stage1 / _gather with out == NULL and out_loc == CLDN_HIP_HOST
  * encode into the codec's own device buffer and return the sizes (stream_offsets, chunk_sizes, modes in host memory);

@@ -259,3 +259,98 @@ def test_tail_op_behind_the_floatn_lanes(oracle, kind):
     got = codec.decode_host([streams[0]], [n], out=out)[0]
     assert np.array_equal(got, oracle.decode_stage1(info, streams[0], n, fill=0x5D))
     codec.close()
+
+
+# ---- chunk-table output (cldn_hip_encode_stage1_chunks / cldn_hip_frame_chunks) ------------------------------------------
+
+def _read_chunk_table(table, torch):
+    """Gather every chunk's payload from the codec's workspace (device pointers) through torch: list of numpy byte arrays."""
+    import ctypes as C
+    n = table.n_chunks
+    spc = table.segments_per_chunk
+
+    def dev_bytes(ptr, nbytes):
+        out = torch.empty(max(1, nbytes), dtype=torch.uint8, device="cuda:0")
+        assert torch.cuda.current_device() == 0
+        rc = C.CDLL("libamdhip64.so").hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), C.c_size_t(nbytes), 3)  # D2D
+        assert rc == 0
+        return out[:nbytes].cpu().numpy()
+    segs = dev_bytes(table.segments, n * spc * 8).view(np.uint32).reshape(n, spc, 2) if n else np.zeros((0, spc, 2), np.uint32)
+    sizes = dev_bytes(table.chunk_sizes, n * 4).view(np.uint32) if n else np.zeros(0, np.uint32)
+    flag = int(dev_bytes(table.not_contiguous, 4).view(np.uint32)[0])
+    payloads = []
+    for c in range(n):
+        parts = []
+        for off, size in segs[c]:
+            if size:
+                parts.append(dev_bytes(table.payload_base + c * table.chunk_stride + int(off), int(size)))
+        payloads.append(np.concatenate(parts) if parts else np.zeros(0, np.uint8))
+        assert payloads[-1].size == int(sizes[c])
+    return payloads, segs, flag
+
+
+@pytest.mark.parametrize("case", ["xyzi", "xyz", "depth_rgba", "velodyne", "two_fields", "ragged"])
+def test_chunk_table_holds_the_reference_payloads(oracle, case):
+    """Stage 1 without the framing: the chunk table's payloads are the reference's chunk payloads; schemas with at most one
+    adaptive field leave every payload as one run of its slot; cldn_hip_frame_chunks writes the framed streams."""
+    import torch
+    from cloudini_amd import native
+    if case == "xyzi":
+        info, clouds = synth.lidar_xyzi(70000, seed=3)[0], [synth.lidar_xyzi(70000, seed=3)[1], synth.lidar_xyzi(40000, seed=4)[1]]
+    elif case == "xyz":
+        info, clouds = synth.lidar_xyz(100000, seed=3)[0], [synth.lidar_xyz(100000, seed=3)[1]]
+    elif case == "depth_rgba":
+        info, clouds = synth.depthcam_xyzrgba(320, 240, seed=2)[0], [synth.depthcam_xyzrgba(320, 240, seed=2)[1]] * 2
+    elif case == "velodyne":
+        info, clouds = synth.velodyne_xyzir(130048, seed=3)[0], [synth.velodyne_xyzir(130048, seed=3)[1]]
+    elif case == "two_fields":
+        n = 70000
+        cols = mode_columns(n)
+        info, data = xyz_plus(n, [("a", F.UINT16, cols["palette"]), ("b", F.UINT16, cols["drle"])])
+        clouds = [data]
+    else:
+        info = synth.lidar_xyzi(10)[0]
+        clouds = [synth.lidar_xyzi(k, seed=20 + k)[1] for k in (0, 5, 40000, 0, 32768)]
+    dev = torch.device("cuda", 0)
+    codec = native.Codec(native.Plan(info))
+    step = info.point_step
+    npts = np.array([c.size // step for c in clouds], dtype=np.uint64)
+    host = np.concatenate(clouds) if sum(c.size for c in clouds) else np.zeros(1, np.uint8)
+    d_in = torch.from_numpy(host).to(dev)
+    for _round in range(2):  # (the second call runs with the mode hint of the first)
+        table = codec.encode_chunks_device(d_in.data_ptr(), npts)
+        codec.synchronize()
+        codec.status()
+        payloads, segs, not_contiguous = _read_chunk_table(table, torch)
+        want_streams = [oracle.encode_stage1(info, c) for c in clouds]
+        want_payloads = []
+        for s in want_streams:
+            o = 0
+            while o < s.size:
+                size = int.from_bytes(s[o:o + 4].tobytes(), "little")
+                want_payloads.append(s[o + 4:o + 4 + size])
+                o += 4 + size
+        assert len(payloads) == len(want_payloads)
+        for k, (a, b) in enumerate(zip(payloads, want_payloads)):
+            assert a.size == b.size and np.array_equal(a, b), (case, k)
+        if case != "two_fields":
+            assert not_contiguous == 0, case
+            for c in range(len(payloads)):  # one run: every non-empty segment starts where the one before ends
+                nz = [(int(o), int(sz)) for o, sz in segs[c] if sz]
+                assert all(nz[i][0] + nz[i][1] == nz[i + 1][0] for i in range(len(nz) - 1))
+        # framing of that table = the framed streams
+        cap = int(sum(codec.plan.stage1_bound(int(n)) for n in npts))
+        d_out = torch.empty(max(1, cap), dtype=torch.uint8, device=dev)
+        d_off = torch.zeros(len(clouds) + 1, dtype=torch.int64, device=dev)
+        codec.frame_chunks_device(d_out.data_ptr(), cap, d_off.data_ptr())
+        codec.synchronize()
+        codec.status()
+        offs = d_off.cpu().numpy()
+        for k, s in enumerate(want_streams):
+            got = d_out[int(offs[k]):int(offs[k + 1])].cpu().numpy()
+            assert got.size == s.size and np.array_equal(got, s), (case, k)
+    # an ordinary call afterwards takes the table away
+    codec.encode_host(clouds)
+    with pytest.raises(native.CloudiniHipError):
+        codec.frame_chunks_device(0, 1 << 40)
+    codec.close()
