@@ -275,6 +275,46 @@ def e2e_figures(info, cloud, dev, budget_s: float):
     return out
 
 
+def transcode_figures(n_msgs: int):
+    """BASELINE configs[3] through the batch transcoder (the loop it replaces:
+    tools/src/mcap_converter.cpp:170-222): n_msgs CDR sensor_msgs/PointCloud2 messages of 130048 XYZI+ring points in a
+    directory -> CompressedPointCloud2 messages, ZSTD second stage on the host pool. In process, second of two runs."""
+    import tempfile
+    from cloudini_amd import api, synth
+    from cloudini_amd.schema import CompressionOption
+    distinct = [synth.velodyne_xyzir(130048, seed=42 + k) for k in range(4)]
+    msgs = [synth.cdr_pointcloud2(distinct[k % 4][0], distinct[k % 4][1], stamp=(1700000000, k)) for k in range(n_msgs)]
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+        src, dst = os.path.join(tmp, "in"), os.path.join(tmp, "out")
+        os.makedirs(src)
+        for k, m in enumerate(msgs):
+            m.tofile(os.path.join(src, f"msg_{k:05d}.bin"))
+        st = None
+        for _rep in range(2):
+            t0 = time.perf_counter()
+            st = api.transcode_directory(src, dst, resolution=0.001, compression_opt=int(CompressionOption.ZSTD), batch_messages=32)
+            wall = time.perf_counter() - t0
+        out = {"workload": f"BASELINE configs[3]: {n_msgs} x 130048-pt XYZI(f32)+ring(u16) CDR PointCloud2 messages, 1 mm, ZSTD",
+               "Mpoints_per_s": st["points"] / wall / 1e6, "seconds": wall, "messages": int(st["messages"]),
+               "gpu_batches": int(st["gpu_batches"]), "gpu_stage_busy_fraction": st["seconds_gpu"] / max(wall, 1e-9),
+               "stage2_threads": api.stage2_threads(), "output_bytes_per_point": st["output_bytes"] / max(1.0, st["points"])}
+        try:
+            from oracle.binding import RefLib
+            ref = RefLib()
+            t0 = time.perf_counter()
+            ok = True
+            sample = min(4, n_msgs)
+            for k in range(sample):
+                want = ref.ros_compress(msgs[k], 0.001, int(CompressionOption.ZSTD))
+                ok = ok and bool(np.array_equal(np.fromfile(os.path.join(dst, f"msg_{k:05d}.bin"), dtype=np.uint8), want))
+            per = (time.perf_counter() - t0) / sample
+            out["reference_converter_Mpoints_per_s_1_thread"] = 130048 / per / 1e6
+            out["sample_messages_equal_reference"] = ok
+        except (OSError, FileNotFoundError):
+            pass
+        return out
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -311,6 +351,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic clouds generated (tiled to --clouds)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--e2e-seconds", type=float, default=6.0, help="budget of the e2e legs (0 = skip; N=1 only)")
+    ap.add_argument("--transcode-messages", type=int, default=256,
+                    help="messages of the batch-transcoder leg (BASELINE configs[3], ZSTD; 0 = skip; N=1 only)")
     ap.add_argument("--no-verify", dest="verify", action="store_false",
                     help="skip the bit-exactness check of the timed batch's streams (outside the timed region)")
     args = ap.parse_args()
@@ -665,6 +707,11 @@ def main():
                 result["e2e"] = e2e_figures(info, distinct[0], dev, args.e2e_seconds)
             except Exception as exc:  # the e2e legs must never cost the headline line
                 result["e2e"] = {"error": repr(exc)}
+        if args.transcode_messages > 0 and world == 1 and args.shard == "clouds":
+            try:
+                result["transcode"] = transcode_figures(args.transcode_messages)
+            except Exception as exc:
+                result["transcode"] = {"error": repr(exc)}
         print(json.dumps(result))
         sys.stdout.flush()
     if dist is not None:

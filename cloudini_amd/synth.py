@@ -122,3 +122,41 @@ def velodyne_xyzir(n: int = 130048, seed: int = 42, res: float = 0.001, rings: i
     pts["i"] = rs.randint(0, 256, size=n).astype(np.float32)
     pts["ring"] = ring.astype(np.uint16)
     return velodyne_info(n, res), pts.view(np.uint8).reshape(-1)
+
+
+def cdr_pointcloud2(info, data, frame_id="lidar_top", stamp=(1700000000, 123456789), is_dense=True):
+    """Serialise a sensor_msgs/PointCloud2 as little-endian CDR (what a DDS reader hands to the converter)."""
+    out = bytearray(b"\x00\x01\x00\x00")
+
+    def align(n):
+        while (len(out) - 4) % n:
+            out.append(0)
+
+    def u32(v):
+        align(4)
+        out.extend(int(v).to_bytes(4, "little"))
+
+    def string(s):
+        b = s.encode() + b"\0"
+        u32(len(b))
+        out.extend(b)
+
+    align(4)
+    out.extend(int(stamp[0]).to_bytes(4, "little", signed=True))
+    u32(stamp[1])
+    string(frame_id)
+    u32(info.height)
+    u32(info.width)
+    u32(len(info.fields))
+    for f in info.fields:
+        string(f.name)
+        u32(f.offset)
+        out.append(int(f.type))
+        u32(1)
+    out.append(0)  # is_bigendian
+    u32(info.point_step)
+    u32(info.point_step * info.width)
+    u32(len(data))
+    out.extend(bytes(data))
+    out.append(1 if is_dense else 0)
+    return np.frombuffer(bytes(out), dtype=np.uint8)

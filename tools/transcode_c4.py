@@ -7,7 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from cloudini_amd import synth
-from test_host_api import _cdr_pointcloud2
+_cdr_pointcloud2 = synth.cdr_pointcloud2
 
 n_msgs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 threads = sys.argv[2] if len(sys.argv) > 2 else None
