@@ -199,6 +199,296 @@ __global__ __launch_bounds__(256) void k_locate_sections(const DevPlan plan, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_sections_cols_fast: the common case of k_decode_sections_cols below -- ONE adaptive field of 2 or 4 bytes whose section
+// is DeltaVarint, Rle or DeltaRle (rgba of a depth camera, ring / timestamp of a lidar) -- with a quarter of the threads
+// and a third of the LDS, so that every chunk of a batch is in flight at once. Output: the dense column col0.
+//   DeltaVarint  tiles of 4 KiB that begin at a token boundary: token ends (bytes with a clear MSB) -> one block scan
+//                numbers them -> list of end positions in LDS; a thread then decodes 16 consecutive tokens (1..5 bytes:
+//                differences of 16/32-bit values have at most 33 bits), sums them, a block scan (wrapping 32-bit
+//                arithmetic: only the low bytes of a value are stored) turns the sums into values, which leave through
+//                LDS with consecutive lanes on consecutive values.
+//   DeltaRle     a section of at most 4 KiB / kScfMaxRuns runs: tokens numbered as above, pairs -> run table in LDS via two
+//                block scans; a thread then fills 8 consecutive values (one search, then a walk along the table).
+//   Rle          (few runs: a constant field) one lane parses the table, same fill.
+// Anything else (a marker byte, a longer token, more runs, a size that does not add up) leaves sec_cols[c] = 0: the
+// general kernel behind it, and in the end the serial decoder, take the chunk and raise the errors.
+// grid = n_chunks, 256 threads.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kScfThreads = 256;
+constexpr uint32_t kScfTileBytes = kScfThreads * 16u;
+constexpr uint32_t kScfMaxRuns = 1024;  // (three tables of this many entries share the value buffer)
+
+__global__ __launch_bounds__(kScfThreads) void k_sections_cols_fast(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                                    const DecChunk* __restrict__ chunks, uint8_t* __restrict__ col0,
+                                                                    const uint32_t* __restrict__ reg_end_pre,
+                                                                    uint8_t* __restrict__ sec_cols) {
+  constexpr int T = (int)kScfThreads;
+  __shared__ __attribute__((aligned(16))) uint32_t tile[kScfTileBytes / 4u + 8u];  // the tile's bytes (+ slack for 8-byte windows)
+  __shared__ uint16_t end_pos[kScfTileBytes + 8u];                                  // byte index of every token end, in order
+  __shared__ uint32_t vals[kScfTileBytes];                                          // values of the tile / run table
+  __shared__ uint32_t scan[40];
+  __shared__ uint32_t flags[4];  // [0] irregular, [1] runs parsed, [2] end offset of the runs
+  const uint32_t c = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const DecChunk dc = chunks[c];
+  if (tid == 0) sec_cols[c] = 0u;
+  if (!dc.valid || plan.n_adaptive != 1u || plan.adaptive[0].bpv > 4u) return;
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t src_size = dc.src_size;
+  const uint32_t n = dc.n_points;
+  uint32_t off = reg_end_pre[c];
+  if (off == 0xffffffffu || off >= src_size || n == 0u) return;
+  const uint32_t bpv = plan.adaptive[0].bpv;
+  uint8_t* col = col0 + (size_t)dc.first_point * bpv;
+  const uint32_t mode = src[off];
+  ++off;
+  if (tid == 0) flags[0] = 0u;
+  __syncthreads();
+
+  if (mode == 0u) {
+    uint32_t pos = off, done = 0u, carry = 0u;  // uniform
+    uint32_t b[4];
+    fp_load16u(src, src_size, pos + tid * 16u, b);  // (the next tile's bytes are requested while this one is decoded)
+    while (done < n) {
+      if (pos >= src_size) return;  // fewer tokens than points (uniform)
+      *reinterpret_cast<uint4*>(tile + tid * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
+      if (tid < 8u) tile[kScfTileBytes / 4u + tid] = 0xffffffffu;
+      const uint32_t ends = fp_ends16(b);
+      uint32_t n_tile;
+      const uint32_t tb = block_exclusive_scan<T>((uint32_t)__builtin_popcount(ends), scan, &n_tile);  // barrier inside
+      {
+        uint32_t k = tb;
+        for (uint32_t m = ends; m; m &= m - 1u) end_pos[k++] = (uint16_t)(tid * 16u + (uint32_t)__builtin_ctz(m));
+      }
+      __syncthreads();
+      const uint32_t take = min(n_tile, n - done);  // tokens of this tile (uniform)
+      if (take == 0u) return;                        // 4 KiB without a token end
+      const uint32_t next_pos = pos + (uint32_t)end_pos[take - 1u] + 1u;
+      if (done + take < n) fp_load16u(src, src_size, next_pos + tid * 16u, b);
+      // my tokens: [k0, k0 + 16)
+      const uint32_t k0 = tid * 16u;
+      const uint8_t* tb8 = reinterpret_cast<const uint8_t*>(tile);
+      uint32_t d[16];
+      uint32_t sum = 0u;
+      bool bad = false;
+#pragma unroll
+      for (uint32_t j = 0; j < 16u; ++j) {
+        const uint32_t k = k0 + j;
+        uint32_t dv = 0u;
+        if (k < take) {
+          const uint32_t start = k ? (uint32_t)end_pos[k - 1u] + 1u : 0u;
+          const uint32_t len = (uint32_t)end_pos[k] - start + 1u;
+          const uint32_t di = start >> 2, sh = (start & 3u) * 8u;
+          const uint32_t w0 = tile[di], w1 = tile[di + 1u], w2 = tile[di + 2u];
+          const uint32_t lo = sh ? ((w0 >> sh) | (w1 << (32u - sh))) : w0;   // bytes 0..3 of the token
+          const uint32_t b4 = (sh ? ((w1 >> sh) | (w2 << (32u - sh))) : w1) & 0xffu;  // byte 4
+          (void)tb8;
+          const uint32_t g = (lo & 0x7fu) | (((lo >> 8) & 0x7fu) << 7) | (((lo >> 16) & 0x7fu) << 14) | (((lo >> 24) & 0x7fu) << 21);
+          // the groups above the token's length are other tokens' bytes: mask by length; u = zigzag(d) + 1 has 35 bits at most
+          const uint32_t keep = len >= 4u ? 0x0fffffffu : ((1u << (7u * len)) - 1u);
+          const uint64_t u = (uint64_t)(g & keep) | (len == 5u ? ((uint64_t)(b4 & 0x7fu) << 28) : 0ull);
+          bad = bad || len > 5u || u == 0ull;  // the marker byte is no integer token (decodeVarint rejects it)
+          const uint64_t u1 = u - 1ull;
+          dv = (uint32_t)((u1 >> 1) ^ (0ull - (u1 & 1ull)));  // low 32 bits of the difference
+        }
+        d[j] = dv;
+        sum += dv;
+      }
+      if (bad) flags[0] = 1u;
+      uint32_t tile_sum;
+      const uint32_t before = block_exclusive_scan<T>(sum, scan + 20, &tile_sum);  // barrier inside (after every write of flags[0])
+      if (flags[0]) return;  // uniform
+      uint32_t v = carry + before;
+#pragma unroll
+      for (uint32_t j = 0; j < 16u; ++j) {
+        v += d[j];
+        if (k0 + j < take) vals[k0 + j] = v;
+      }
+      __syncthreads();
+      if (bpv == 2u) {
+        uint16_t* o = reinterpret_cast<uint16_t*>(col) + done;
+        for (uint32_t i = tid; i < take; i += kScfThreads) o[i] = (uint16_t)vals[i];
+      } else {
+        uint32_t* o = reinterpret_cast<uint32_t*>(col) + done;
+        for (uint32_t i = tid; i < take; i += kScfThreads) o[i] = vals[i];
+      }
+      pos = next_pos;
+      carry += tile_sum;  // (tokens behind `take` do not exist when take < n_tile: the loop ends)
+      done += take;
+      __syncthreads();
+    }
+    if (pos != src_size) return;  // trailing bytes: the serial decoder raises the error
+    if (tid == 0) sec_cols[c] = 1u;
+    return;
+  }
+
+  if (mode == 2u || mode == 3u) {
+    if (src_size - off < 4u) return;
+    const uint32_t runs = (uint32_t)src[off] | ((uint32_t)src[off + 1u] << 8) | ((uint32_t)src[off + 2u] << 16) | ((uint32_t)src[off + 3u] << 24);
+    off += 4u;
+    if (runs == 0u || runs > kScfMaxRuns || runs > n) return;
+    // run table: start index, value before the run (DeltaRle) or the value (Rle), difference per element
+    uint32_t* r_start = vals;                  // [runs + 1]
+    uint32_t* r_base = vals + kScfMaxRuns + 8u;  // [runs]
+    uint32_t* r_diff = r_base + kScfMaxRuns;     // [runs]
+    // the records go to LDS first (one lane parsing them from global memory would wait for every byte); sections that do
+    // not fit the tile buffer are left to the general kernel
+    const uint32_t sec_bytes = src_size - off;
+    if (sec_bytes > kScfTileBytes) return;
+    for (uint32_t i = tid; i < (sec_bytes + 15u) / 16u; i += kScfThreads) {
+      uint32_t w[4];
+      fp_load16u(src, src_size, off + i * 16u, w);
+      *reinterpret_cast<uint4*>(tile + i * 4u) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
+    if (mode == 3u) {
+      // DeltaRle: every token is a varint -- (difference, run length) pairs. Token ends are numbered by a block scan,
+      // a thread takes 16 consecutive tokens = 8 runs, and two more scans turn (length, difference * length) into the
+      // run's first index and the value in front of it.
+      uint32_t b[4];
+      {
+        const uint4 q = *reinterpret_cast<const uint4*>(tile + tid * 4u);
+        b[0] = q.x; b[1] = q.y; b[2] = q.z; b[3] = q.w;
+      }
+      uint32_t ends = fp_ends16(b);
+      {
+        const uint32_t first = tid * 16u;  // bytes behind the section are no tokens
+        ends = first >= sec_bytes ? 0u : (sec_bytes - first >= 16u ? ends : ends & ((1u << (sec_bytes - first)) - 1u));
+      }
+      uint32_t n_tok;
+      const uint32_t tb = block_exclusive_scan<T>((uint32_t)__builtin_popcount(ends), scan, &n_tok);
+      {
+        uint32_t k = tb;
+        for (uint32_t m = ends; m; m &= m - 1u) end_pos[k++] = (uint16_t)(tid * 16u + (uint32_t)__builtin_ctz(m));
+      }
+      __syncthreads();
+      // (uniform) the tokens are exactly the pairs and the last one closes the section
+      if (n_tok != runs * 2u || (uint32_t)end_pos[n_tok - 1u] + 1u != sec_bytes) return;
+      uint32_t dif[8], len[8];
+      uint32_t s_len = 0u, s_val = 0u;
+      bool bad = false;
+#pragma unroll
+      for (uint32_t j = 0; j < 16u; ++j) {
+        const uint32_t k = tid * 16u + j;
+        uint64_t u = 0ull;
+        if (k < n_tok) {
+          const uint32_t start = k ? (uint32_t)end_pos[k - 1u] + 1u : 0u;
+          const uint32_t tl = (uint32_t)end_pos[k] - start + 1u;
+          const uint32_t di = start >> 2, sh = (start & 3u) * 8u;
+          const uint32_t w0 = tile[di], w1 = tile[di + 1u], w2 = tile[di + 2u];
+          const uint32_t lo = sh ? ((w0 >> sh) | (w1 << (32u - sh))) : w0;
+          const uint32_t b4 = (sh ? ((w1 >> sh) | (w2 << (32u - sh))) : w1) & 0xffu;
+          const uint32_t g = (lo & 0x7fu) | (((lo >> 8) & 0x7fu) << 7) | (((lo >> 16) & 0x7fu) << 14) | (((lo >> 24) & 0x7fu) << 21);
+          const uint32_t keep = tl >= 4u ? 0x0fffffffu : ((1u << (7u * tl)) - 1u);
+          u = (uint64_t)(g & keep) | (tl == 5u ? ((uint64_t)(b4 & 0x7fu) << 28) : 0ull);
+          bad = bad || tl > 5u;
+        }
+        if ((j & 1u) == 0u) {  // the difference: zigzag + 1 (0 is the marker byte, no integer)
+          bad = bad || (k < n_tok && u == 0ull);
+          const uint64_t u1 = u - 1ull;
+          dif[j >> 1] = k < n_tok ? (uint32_t)((u1 >> 1) ^ (0ull - (u1 & 1ull))) : 0u;
+        } else {               // the run length: 1 .. n
+          bad = bad || (k < n_tok && (u == 0ull || u > (uint64_t)n));
+          len[j >> 1] = k < n_tok ? (uint32_t)u : 0u;
+          s_len += len[j >> 1];
+          s_val += dif[j >> 1] * len[j >> 1];
+        }
+      }
+      if (bad) flags[0] = 1u;
+      uint32_t tot_len, tot_val;
+      uint32_t idx = block_exclusive_scan<T>(s_len, scan, &tot_len);
+      uint32_t prev = block_exclusive_scan<T>(s_val, scan + 20, &tot_val);
+      (void)tot_val;
+      if (flags[0] || tot_len != n) return;  // uniform (the scans' barriers are behind every write of flags[0])
+#pragma unroll
+      for (uint32_t j = 0; j < 8u; ++j) {
+        const uint32_t r = tid * 8u + j;
+        if (r < runs) {
+          r_start[r] = idx;
+          r_base[r] = prev;
+          r_diff[r] = dif[j];
+        }
+        idx += len[j];
+        prev += dif[j] * len[j];
+      }
+      if (tid == 0) r_start[runs] = n;
+    } else {
+      // Rle: raw values between the run lengths, so that token ends cannot be told from value bytes -- a constant
+      // field is one run; more than a few runs go to the general kernel
+      if (runs > 32u) return;
+      if (tid == 0) {
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(tile);
+        const uint8_t* end = p + sec_bytes;
+        uint32_t idx = 0u;
+        bool bad = false;
+        for (uint32_t r = 0; r < runs && !bad; ++r) {
+          if ((uint32_t)(end - p) < bpv) { bad = true; break; }
+          uint32_t base_v = 0u;
+          for (uint32_t k = 0; k < bpv; ++k) base_v |= (uint32_t)p[k] << (8u * k);
+          p += bpv;
+          uint32_t len = 0u, sh = 0u;  // uvarint(run_len)
+          for (;;) {
+            if (p >= end || sh > 21u) { bad = true; break; }
+            const uint8_t byte = *p++;
+            len |= (uint32_t)(byte & 0x7fu) << sh;
+            if (!(byte & 0x80u)) break;
+            sh += 7u;
+          }
+          if (bad || len == 0u || len > n - idx) { bad = true; break; }
+          r_start[r] = idx;
+          r_base[r] = base_v;
+          r_diff[r] = 0u;
+          idx += len;
+        }
+        if (!bad && (idx != n || p != end)) bad = true;
+        r_start[runs] = n;
+        flags[0] = bad ? 1u : 0u;
+      }
+    }
+    __syncthreads();
+    if (flags[0]) return;
+    // fill: a thread owns 8 consecutive values -- one search for the first, a walk along the table for the rest, and
+    // one 16/32-byte store
+    for (uint32_t i0 = tid * 8u; i0 < n; i0 += kScfThreads * 8u) {
+      uint32_t lo = 0u, hi = runs;  // last r with r_start[r] <= i0
+      while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (r_start[mid] <= i0) lo = mid;
+        else hi = mid;
+      }
+      uint32_t nxt = r_start[lo + 1u], st = r_start[lo], bs = r_base[lo], df = r_diff[lo];
+      uint32_t v[8];
+#pragma unroll
+      for (uint32_t j = 0; j < 8u; ++j) {
+        const uint32_t i = i0 + j;
+        if (i >= nxt && i < n) {  // (runs are never empty: one step)
+          ++lo;
+          st = nxt; nxt = r_start[lo + 1u]; bs = r_base[lo]; df = r_diff[lo];
+        }
+        v[j] = bs + df * (i - st + 1u);
+      }
+      if (i0 + 8u <= n) {
+        if (bpv == 2u) {
+          const uint4 q = make_uint4((v[0] & 0xffffu) | (v[1] << 16), (v[2] & 0xffffu) | (v[3] << 16),
+                                     (v[4] & 0xffffu) | (v[5] << 16), (v[6] & 0xffffu) | (v[7] << 16));
+          __builtin_memcpy(col + (size_t)i0 * 2u, &q, 16);
+        } else {
+          const uint4 q0 = make_uint4(v[0], v[1], v[2], v[3]), q1 = make_uint4(v[4], v[5], v[6], v[7]);
+          __builtin_memcpy(col + (size_t)i0 * 4u, &q0, 16);
+          __builtin_memcpy(col + (size_t)i0 * 4u + 16u, &q1, 16);
+        }
+      } else {
+        for (uint32_t j = 0; j < 8u && i0 + j < n; ++j) {
+          if (bpv == 2u) { const uint16_t h = (uint16_t)v[j]; __builtin_memcpy(col + (size_t)(i0 + j) * 2u, &h, 2); }
+          else __builtin_memcpy(col + (size_t)(i0 + j) * 4u, &v[j], 4);
+        }
+      }
+    }
+    if (tid == 0) sec_cols[c] = 1u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_decode_sections_cols: in front of k_decode_points, for chunks whose sections it cannot fold from a palette table
 // (DeltaVarint / Rle / DeltaRle sections, large palettes). The sections are decoded into DENSE COLUMNS (value i of
 // the chunk at col[a] + (first_point + i) * bpv) with the parallel section decoder (decode_sections_core); the point
@@ -213,12 +503,16 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_sections_cols(const DevPl
                                                                      const DecChunk* __restrict__ chunks, uint32_t n_ops,
                                                                      uint8_t* __restrict__ col0, uint8_t* __restrict__ col1,
                                                                      const uint32_t* __restrict__ reg_end_pre,
-                                                                     uint8_t* __restrict__ sec_cols) {
+                                                                     uint8_t* __restrict__ sec_cols, uint32_t after_fast) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t c = blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const DecChunk dc = chunks[c];
-  if (tid == 0) sec_cols[c] = 0u;
+  if (after_fast) {
+    if (sec_cols[c]) return;  // k_sections_cols_fast took this chunk (it also cleared the flag of all others)
+  } else if (tid == 0) {
+    sec_cols[c] = 0u;
+  }
   if (!dc.valid || plan.n_adaptive == 0u || plan.n_adaptive > kFastPalFields) return;
   for (uint32_t a = 0; a < plan.n_adaptive; ++a)
     if (plan.adaptive[a].bpv > 4u) return;

@@ -2427,8 +2427,16 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         hipLaunchKernelGGL(k_locate_sections, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
+        static const bool no_scf = getenv("CLDN_HIP_NO_FAST_COLS") != nullptr;  // A/B switch
+        const bool scf = !no_scf && P.n_adaptive == 1u;
+        if (scf) {
+          hipLaunchKernelGGL(k_sections_cols_fast, dim3(L.n_chunks), dim3(kScfThreads), 0, L.stream, P, L.streams,
+                             reinterpret_cast<const DecChunk*>(L.chunks), L.cols[0], L.reg_end_pre, L.sec_cols);
+          if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_cols_fast");
+        }
         hipLaunchKernelGGL(k_decode_sections_cols, dim3(L.n_chunks), dim3(kDvThreads), (DecSecLds::kTotal), L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.cols[0], L.cols[1], L.reg_end_pre, L.sec_cols);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.cols[0], L.cols[1], L.reg_end_pre, L.sec_cols,
+                           scf ? 1u : 0u);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_sections_cols");
       }
       const uint8_t* c0 = cols ? L.cols[0] : nullptr;
