@@ -110,16 +110,17 @@ struct FpSection {   // a Palette section folded into the point pass
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_locate_sections: where a chunk's sections begin = behind token number n_points * n_ops of its payload. The token
-// ends (bytes with a clear MSB) are counted by four waves, each over a quarter of the payload, 64 bytes per lane and
+// ends (bytes with a clear MSB) are counted by NW waves (4, or 16 when a batch has few chunks), each over its share of the payload, 64 bytes per lane and
 // step; the wave that holds the last token walks its quarter again and finds the byte. A light kernel (no LDS to speak
 // of, eight workgroups per CU): the count is a plain streaming read of the regular stream.
 // reg_end_pre[c] = the offset, 0xffffffff = not found / not looked for (one-field plans whose section looks like a small
-// Palette from the end of the payload are left to k_decode_points' own guess). grid = n_chunks, 256 threads.
+// Palette from the end of the payload are left to k_decode_points' own guess). grid = n_chunks, NW * 64 threads.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_locate_sections(const DevPlan plan, const uint8_t* __restrict__ streams,
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                          const DecChunk* __restrict__ chunks, uint32_t n_ops,
                                                          uint32_t* __restrict__ reg_end_pre) {
-  __shared__ uint32_t wcnt[4];
+  __shared__ uint32_t wcnt[NW];
   __shared__ uint32_t found, pal_hit;
   const uint32_t c = blockIdx.x;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void k_locate_sections(const DevPlan plan, con
   __syncthreads();
   if (plan.n_adaptive == 1u) {
     const uint32_t bpv = plan.adaptive[0].bpv;
-    for (uint32_t U = tid + 1u; U <= kFastPalEntries; U += 256u) {
+    for (uint32_t U = tid + 1u; U <= kFastPalEntries; U += NW * 64u) {
       const uint64_t S = 3ull + (uint64_t)U * bpv + ((uint64_t)palette_bits(U) * n + 7u) / 8u;
       if (S <= src_size) {
         const uint8_t* h = src + (src_size - (uint32_t)S);
@@ -150,10 +151,12 @@ __global__ __launch_bounds__(256) void k_locate_sections(const DevPlan plan, con
     __syncthreads();
     if (pal_hit) return;  // uniform
   }
-  const uint32_t part = (((src_size + 15u) / 16u + 3u) / 4u) * 16u;  // bytes per wave, multiple of 16
+  const uint32_t part = (((src_size + 15u) / 16u + (NW - 1u)) / NW) * 16u;  // bytes per wave, multiple of 16
   const uint32_t w0 = min(src_size, wave * part), w1 = min(src_size, w0 + part);
   uint32_t cnt = 0u;
-  for (uint32_t o0 = w0; o0 < w1; o0 += 4096u) {  // four 16-byte units per lane, all loads before the first use
+  uint32_t step_cnt = 0u;  // lane s: my count after step s (steps 0..63; the walk below starts at the last such step)
+  uint32_t it = 0u;
+  for (uint32_t o0 = w0; o0 < w1; o0 += 4096u, ++it) {  // four 16-byte units per lane, all loads before the first use
     uint32_t b[4][4];
 #pragma unroll
     for (uint32_t u = 0; u < 4u; ++u) {
@@ -165,6 +168,8 @@ __global__ __launch_bounds__(256) void k_locate_sections(const DevPlan plan, con
     for (uint32_t u = 0; u < 4u; ++u)
 #pragma unroll
       for (int k = 0; k < 4; ++k) cnt += (uint32_t)__builtin_popcount(~b[u][k] & 0x80808080u);
+    const uint32_t upto = wave_sum(cnt);  // tokens of my part that end in steps 0..it
+    if (lane == it) step_cnt = upto;
   }
   const uint32_t wsum = wave_sum(cnt);
   if (lane == 0u) wcnt[wave] = wsum;
@@ -172,8 +177,12 @@ __global__ __launch_bounds__(256) void k_locate_sections(const DevPlan plan, con
   uint32_t before = 0u;
   for (uint32_t w = 0; w < wave; ++w) before += wcnt[w];
   if (target != 0u && before < target && target <= before + wsum) {  // the last token ends in my part (one wave)
-    uint32_t seen = before;
-    for (uint32_t o0 = w0; o0 < w1; o0 += 1024u) {
+    // the 4 KiB step that holds it: the first one whose running count reaches the target (steps beyond 63: walk from 63)
+    const uint32_t n_steps = min(it, 64u);
+    const uint64_t short_of = __ballot(lane < n_steps && before + step_cnt < target);
+    const uint32_t s0 = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_popcountll(short_of));  // steps 0..s0-1 end before the target
+    uint32_t seen = before + (s0 ? (uint32_t)__builtin_amdgcn_readlane((int)step_cnt, (int)(s0 - 1u)) : 0u);
+    for (uint32_t o0 = w0 + s0 * 4096u; o0 < w1; o0 += 1024u) {
       const uint32_t o = o0 + lane * 16u;
       uint32_t b[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
       if (o < w1) fp_load16u(src, src_size, o, b);

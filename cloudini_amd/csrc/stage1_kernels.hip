@@ -2424,8 +2424,14 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       bool cols = !no_cols && nf != 0u && L.cols[0] != nullptr && L.sec_cols != nullptr;
       for (uint32_t a = 0; a < P.n_adaptive && cols; ++a) cols = P.adaptive[a].bpv <= 4u && L.cols[a] != nullptr;
       if (cols) {
-        hipLaunchKernelGGL(k_locate_sections, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
+        {
+          static const int lw = getenv("CLDN_HIP_LOCATE_WAVES") ? atoi(getenv("CLDN_HIP_LOCATE_WAVES")) : 0;  // A/B switch
+          const bool wide = lw >= 16;  // (16 waves per chunk measured slower on C3 / C4 / C5: 0.452 / 0.572 / 0.140 against 0.433 / 0.552 / 0.137 ms)
+          if (wide) hipLaunchKernelGGL(k_locate_sections<16>, dim3(L.n_chunks), dim3(1024), 0, L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre);
+          else hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
         static const bool no_scf = getenv("CLDN_HIP_NO_FAST_COLS") != nullptr;  // A/B switch
         const bool scf = !no_scf && P.n_adaptive == 1u;
