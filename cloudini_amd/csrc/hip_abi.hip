@@ -170,6 +170,8 @@ struct cldn_hip_codec {
   int stage2 = 0;
   DevBuf d_s1, d_s1_offsets, d_lz_matches, d_lz_counts, d_lz_slots, d_lz_segs, d_payload2, d_dst2;
   DevBuf d_finrec;            // k_finish look-back records (rec, rec2), cleared only when (re)allocated
+  DevBuf d_dec_rec;           // k_sections_cols_fast slice records, tagged with dec_epoch, cleared only when (re)allocated
+  uint32_t dec_epoch = 0;
   uint32_t finish_epoch = 0;  // tag of this call's records
   DevBuf d_pieces;  // piece table of the piece kernel (stage1_fused.h)
   uint32_t n_pieces = 0;
@@ -512,7 +514,7 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   DeviceGuard guard;
   (void)guard.enter(c->device);
   (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec, &c->d_s1, &c->d_s1_offsets,
+  DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec, &c->d_dec_rec, &c->d_s1, &c->d_s1_offsets,
                     &c->d_lz_matches, &c->d_lz_counts, &c->d_lz_slots, &c->d_lz_segs, &c->d_payload2, &c->d_dst2,
                     &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_pre_ptrs, &c->d_dec_cols[0], &c->d_dec_cols[1],
                     &c->d_pre[0], &c->d_pre[1], &c->d_pre[2], &c->d_pre[3], &c->d_viz_keys, &c->d_viz_first,
@@ -1327,7 +1329,7 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
   h_fp[n_clouds] = fp;
   h_fc[n_clouds] = fc;
   const size_t chunk_table_bytes = ((size_t)std::max(1u, n_chunks) * kDecChunkBytes + 63) & ~size_t(63);
-  if ((rc = c->d_dec_meta.ensure(((table_bytes + 63) & ~size_t(63)) + chunk_table_bytes + (size_t)std::max(1u, n_chunks) * 14u + 64u)) != CLDN_HIP_OK)
+  if ((rc = c->d_dec_meta.ensure(((table_bytes + 63) & ~size_t(63)) + chunk_table_bytes + (size_t)std::max(1u, n_chunks) * 18u + 64u)) != CLDN_HIP_OK)
     return rc;
   const bool dec_cols = c->plan.uses_v5 && plan.n_adaptive >= 1u && plan.n_adaptive <= 2u;
   for (uint32_t a = 0; a < 2u; ++a)
@@ -1373,11 +1375,22 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
   L.sec_done = (uint8_t*)(L.reg_end_pre + std::max(1u, n_chunks));
   L.sec_cols = L.sec_done + std::max(1u, n_chunks);
   L.chunk_sizes = nullptr;
+  uint32_t* const d_sizes = (uint32_t*)(((uintptr_t)(L.sec_cols + std::max(1u, n_chunks)) + 3u) & ~uintptr_t(3));
+  L.slices_done = d_sizes + std::max(1u, n_chunks);
+  if (dec_cols && plan.n_adaptive == 1u && n_chunks) {  // slice records of k_sections_cols_fast
+    const void* before = c->d_dec_rec.p;
+    if ((rc = c->d_dec_rec.ensure((size_t)n_chunks * 48u * 16u)) != CLDN_HIP_OK) return rc;
+    if (c->d_dec_rec.p != before || ++c->dec_epoch == 0u) {  // fresh memory, or the tags have wrapped
+      HIP_TRY(hipMemsetAsync(c->d_dec_rec.p, 0, c->d_dec_rec.cap, c->stream));
+      c->dec_epoch = 1u;
+    }
+    L.slice_rec = (unsigned long long*)c->d_dec_rec.p;
+    L.slice_epoch = c->dec_epoch;
+  }
   if (chunk_sizes && n_chunks) {
     if (chunk_sizes_loc == CLDN_HIP_DEVICE) {
       L.chunk_sizes = chunk_sizes;
     } else {  // (pageable source: the copy is over when the call returns)
-      uint32_t* d_sizes = (uint32_t*)(((uintptr_t)(L.sec_cols + std::max(1u, n_chunks)) + 3u) & ~uintptr_t(3));
       HIP_TRY(hipMemcpyAsync(d_sizes, chunk_sizes, (size_t)n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
       L.chunk_sizes = d_sizes;
     }

@@ -119,7 +119,8 @@ struct FpSection {   // a Palette section folded into the point pass
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                          const DecChunk* __restrict__ chunks, uint32_t n_ops,
-                                                         uint32_t* __restrict__ reg_end_pre) {
+                                                         uint32_t* __restrict__ reg_end_pre, uint8_t* __restrict__ sec_cols,
+                                                         uint32_t* __restrict__ slices_done) {
   __shared__ uint32_t wcnt[NW];
   __shared__ uint32_t found, pal_hit;
   const uint32_t c = blockIdx.x;
@@ -128,6 +129,8 @@ __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan,
   const DecChunk dc = chunks[c];
   if (tid == 0) {
     reg_end_pre[c] = 0xffffffffu;
+    sec_cols[c] = 0u;
+    slices_done[c] = 0xffu << 24;
     found = 0xffffffffu;
     pal_hit = 0u;
   }
@@ -204,43 +207,53 @@ __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan,
   }
   if (target == 0u && tid == 0) found = 0u;
   __syncthreads();
-  if (tid == 0) reg_end_pre[c] = found;
+  if (tid == 0) {
+    reg_end_pre[c] = found;
+    // the section's mode byte in the top byte: the workgroups of k_sections_cols_fast that have nothing to do leave on it
+    slices_done[c] = (found < src_size ? (uint32_t)src[found] : 0xffu) << 24;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_sections_cols_fast: the common case of k_decode_sections_cols below -- ONE adaptive field of 2 or 4 bytes whose section
 // is DeltaVarint, Rle or DeltaRle (rgba of a depth camera, ring / timestamp of a lidar) -- with a quarter of the threads
 // and a third of the LDS, so that every chunk of a batch is in flight at once. Output: the dense column col0.
-//   DeltaVarint  tiles of 4 KiB that begin at a token boundary: token ends (bytes with a clear MSB) -> one block scan
-//                numbers them -> list of end positions in LDS; a thread then decodes 16 consecutive tokens (1..5 bytes:
-//                differences of 16/32-bit values have at most 33 bits), sums them, a block scan (wrapping 32-bit
-//                arithmetic: only the low bytes of a value are stored) turns the sums into values, which leave through
-//                LDS with consecutive lanes on consecutive values.
+//   DeltaVarint  slices of 4 KiB at fixed offsets, spread over the chunk's workgroups; a token belongs to the slice
+//                that holds its last byte. Token ends (bytes with a clear MSB) -> a block scan numbers them; a thread
+//                decodes the tokens that end in its 16 bytes (1..5 bytes: differences of 16/32-bit values have at
+//                most 33 bits), a second scan (wrapping 32-bit arithmetic: only the low bytes of a value are stored)
+//                and the (count, sum) records of the slices in front turn differences into values and their indexes.
 //   DeltaRle     a section of at most 4 KiB / kScfMaxRuns runs: tokens numbered as above, pairs -> run table in LDS via two
 //                block scans; a thread then fills 8 consecutive values (one search, then a walk along the table).
 //   Rle          (few runs: a constant field) one lane parses the table, same fill.
 // Anything else (a marker byte, a longer token, more runs, a size that does not add up) leaves sec_cols[c] = 0: the
 // general kernel behind it, and in the end the serial decoder, take the chunk and raise the errors.
-// grid = n_chunks, 256 threads.
+// k_locate_sections clears sec_cols[c] and leaves the section's mode byte in slices_done[c]. grid = n_chunks * parts
+// (parts: 1..kScfMaxParts, more when the batch has few chunks), 256 threads.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kScfThreads = 256;
 constexpr uint32_t kScfTileBytes = kScfThreads * 16u;
 constexpr uint32_t kScfMaxRuns = 1024;  // (three tables of this many entries share the value buffer)
+constexpr uint32_t kScfMaxParts = 16;   // workgroups per chunk (DeltaVarint slices round robin; runs: the first one): at most
+constexpr uint32_t kScfMaxSlices = 48;  // 32768 tokens of 5 bytes are 40 slices
+constexpr uint32_t kScfSpinLimit = 1u << 22;
 
 __global__ __launch_bounds__(kScfThreads) void k_sections_cols_fast(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                                     const DecChunk* __restrict__ chunks, uint8_t* __restrict__ col0,
                                                                     const uint32_t* __restrict__ reg_end_pre,
-                                                                    uint8_t* __restrict__ sec_cols) {
+                                                                    uint8_t* __restrict__ sec_cols, uint32_t* __restrict__ slices_done,
+                                                                    unsigned long long* __restrict__ slice_rec, uint32_t epoch, uint32_t parts) {
   constexpr int T = (int)kScfThreads;
-  __shared__ __attribute__((aligned(16))) uint32_t tile[kScfTileBytes / 4u + 8u];  // the tile's bytes (+ slack for 8-byte windows)
+  __shared__ __attribute__((aligned(16))) uint32_t tile[kScfTileBytes / 4u + 8u];  // 8 bytes of history, the slice's bytes, slack for 8-byte windows
   __shared__ uint16_t end_pos[kScfTileBytes + 8u];                                  // byte index of every token end, in order
   __shared__ uint32_t vals[kScfTileBytes];                                          // values of the tile / run table
   __shared__ uint32_t scan[40];
   __shared__ uint32_t flags[4];  // [0] irregular, [1] runs parsed, [2] end offset of the runs
-  const uint32_t c = blockIdx.x;
+  const uint32_t c = blockIdx.x / parts;
+  const uint32_t part = blockIdx.x % parts;
   const uint32_t tid = threadIdx.x;
+  if (part != 0u && (slices_done[c] >> 24) != 0u) return;  // only DeltaVarint sections are shared
   const DecChunk dc = chunks[c];
-  if (tid == 0) sec_cols[c] = 0u;
   if (!dc.valid || plan.n_adaptive != 1u || plan.adaptive[0].bpv > 4u) return;
   const uint8_t* src = streams + dc.src_off;
   const uint32_t src_size = dc.src_size;
@@ -255,83 +268,133 @@ __global__ __launch_bounds__(kScfThreads) void k_sections_cols_fast(const DevPla
   __syncthreads();
 
   if (mode == 0u) {
-    uint32_t pos = off, done = 0u, carry = 0u;  // uniform
-    uint32_t b[4];
-    fp_load16u(src, src_size, pos + tid * 16u, b);  // (the next tile's bytes are requested while this one is decoded)
-    while (done < n) {
-      if (pos >= src_size) return;  // fewer tokens than points (uniform)
-      *reinterpret_cast<uint4*>(tile + tid * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
-      if (tid < 8u) tile[kScfTileBytes / 4u + tid] = 0xffffffffu;
-      const uint32_t ends = fp_ends16(b);
-      uint32_t n_tile;
-      const uint32_t tb = block_exclusive_scan<T>((uint32_t)__builtin_popcount(ends), scan, &n_tile);  // barrier inside
-      {
-        uint32_t k = tb;
-        for (uint32_t m = ends; m; m &= m - 1u) end_pos[k++] = (uint16_t)(tid * 16u + (uint32_t)__builtin_ctz(m));
+    // DeltaVarint: the section is cut into slices of 4 KiB at FIXED offsets; a token belongs to the slice its last byte
+    // is in. The `parts` workgroups of a chunk take the slices round robin; how many tokens, and which sum of
+    // differences, lie in front of a slice is published per slice (records tagged with the launch's epoch) and read
+    // by the slices behind it -- the workgroups in front were dispatched earlier (lower block index).
+    const uint32_t sec_bytes = src_size - off;
+    const uint32_t n_slices = (sec_bytes + kScfTileBytes - 1u) / kScfTileBytes;
+    if (n_slices == 0u || n_slices > kScfMaxSlices) return;
+    unsigned long long* rec = slice_rec + (size_t)c * kScfMaxSlices * 2u;
+    uint32_t pre_cnt = 0u, pre_sum = 0u, have = 0u;  // tokens / sum of the slices [0, have)  (uniform)
+    for (uint32_t s = part; s < n_slices; s += parts) {
+      const uint32_t base = off + s * kScfTileBytes;  // >= 1: the mode byte (0, "a token end") is in front of slice 0
+      uint32_t b[4];
+      fp_load16u(src, src_size, base + tid * 16u, b);  // bytes behind the payload read 0xff: no token ends
+      *reinterpret_cast<uint4*>(tile + 2u + tid * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
+      if (tid == 0u) {  // the 8 bytes in front of the slice (a token has 5 at most); what is in front of the payload counts as ends
+        uint32_t h[2] = {0u, 0u};
+        if (base >= 8u) {
+          __builtin_memcpy(h, src + base - 8u, 8);
+        } else {
+          for (uint32_t j = 8u - base; j < 8u; ++j) h[j >> 2] |= (uint32_t)src[base - 8u + j] << (8u * (j & 3u));
+        }
+        tile[0] = h[0];
+        tile[1] = h[1];
       }
-      __syncthreads();
-      const uint32_t take = min(n_tile, n - done);  // tokens of this tile (uniform)
-      if (take == 0u) return;                        // 4 KiB without a token end
-      const uint32_t next_pos = pos + (uint32_t)end_pos[take - 1u] + 1u;
-      if (done + take < n) fp_load16u(src, src_size, next_pos + tid * 16u, b);
-      // my tokens: [k0, k0 + 16)
-      const uint32_t k0 = tid * 16u;
-      const uint8_t* tb8 = reinterpret_cast<const uint8_t*>(tile);
-      uint32_t d[16];
+      if (tid < 4u) tile[2u + kScfTileBytes / 4u + tid] = 0xffffffffu;
+      const uint32_t ends = fp_ends16(b);
+      const uint32_t my_cnt = (uint32_t)__builtin_popcount(ends);
+      uint32_t n_tile;
+      const uint32_t tb = block_exclusive_scan<T>(my_cnt, scan, &n_tile);  // barrier inside: the tile is complete
+      // my tokens end in my 16 bytes; the first one begins behind the last end among the 8 bytes in front of them
       uint32_t sum = 0u;
       bool bad = false;
-#pragma unroll
-      for (uint32_t j = 0; j < 16u; ++j) {
-        const uint32_t k = k0 + j;
-        uint32_t dv = 0u;
-        if (k < take) {
-          const uint32_t start = k ? (uint32_t)end_pos[k - 1u] + 1u : 0u;
-          const uint32_t len = (uint32_t)end_pos[k] - start + 1u;
-          const uint32_t di = start >> 2, sh = (start & 3u) * 8u;
+      if (ends) {
+        const uint32_t h0 = tile[tid * 4u], h1 = tile[tid * 4u + 1u];
+        const uint32_t hist = ((((~h0 & 0x80808080u) >> 7) * 0x00204081u) >> 21 & 0xfu) | ((((~h1 & 0x80808080u) >> 7) * 0x00204081u) >> 21 & 0xfu) << 4;
+        uint32_t start = hist ? 32u - (uint32_t)__builtin_clz(hist) : 0u;  // window index (0 = 8 bytes in front of mine)
+        uint32_t k = tb;
+        for (uint32_t m = ends; m; m &= m - 1u) {
+          const uint32_t endw = 8u + (uint32_t)__builtin_ctz(m);
+          const uint32_t tl = endw - start + 1u;
+          const uint32_t bo = tid * 16u + start;  // byte offset inside `tile` (which begins with the 8 bytes of history)
+          const uint32_t di = bo >> 2, sh = (bo & 3u) * 8u;
           const uint32_t w0 = tile[di], w1 = tile[di + 1u], w2 = tile[di + 2u];
-          const uint32_t lo = sh ? ((w0 >> sh) | (w1 << (32u - sh))) : w0;   // bytes 0..3 of the token
+          const uint32_t lo = sh ? ((w0 >> sh) | (w1 << (32u - sh))) : w0;             // bytes 0..3 of the token
           const uint32_t b4 = (sh ? ((w1 >> sh) | (w2 << (32u - sh))) : w1) & 0xffu;  // byte 4
-          (void)tb8;
           const uint32_t g = (lo & 0x7fu) | (((lo >> 8) & 0x7fu) << 7) | (((lo >> 16) & 0x7fu) << 14) | (((lo >> 24) & 0x7fu) << 21);
           // the groups above the token's length are other tokens' bytes: mask by length; u = zigzag(d) + 1 has 35 bits at most
-          const uint32_t keep = len >= 4u ? 0x0fffffffu : ((1u << (7u * len)) - 1u);
-          const uint64_t u = (uint64_t)(g & keep) | (len == 5u ? ((uint64_t)(b4 & 0x7fu) << 28) : 0ull);
-          bad = bad || len > 5u || u == 0ull;  // the marker byte is no integer token (decodeVarint rejects it)
+          const uint32_t keep = tl >= 4u ? 0x0fffffffu : ((1u << (7u * tl)) - 1u);
+          const uint64_t u = (uint64_t)(g & keep) | (tl == 5u ? ((uint64_t)(b4 & 0x7fu) << 28) : 0ull);
+          bad = bad || tl > 5u || u == 0ull;  // the marker byte is no integer token (decodeVarint rejects it)
           const uint64_t u1 = u - 1ull;
-          dv = (uint32_t)((u1 >> 1) ^ (0ull - (u1 & 1ull)));  // low 32 bits of the difference
+          const uint32_t dv = (uint32_t)((u1 >> 1) ^ (0ull - (u1 & 1ull)));  // low 32 bits of the difference
+          vals[k++] = dv;
+          sum += dv;
+          start = endw + 1u;
         }
-        d[j] = dv;
-        sum += dv;
       }
       if (bad) flags[0] = 1u;
       uint32_t tile_sum;
       const uint32_t before = block_exclusive_scan<T>(sum, scan + 20, &tile_sum);  // barrier inside (after every write of flags[0])
-      if (flags[0]) return;  // uniform
-      uint32_t v = carry + before;
-#pragma unroll
-      for (uint32_t j = 0; j < 16u; ++j) {
-        v += d[j];
-        if (k0 + j < take) vals[k0 + j] = v;
+      const bool irregular = flags[0] != 0u;
+      if (tid == 0u) {  // the slices behind wait for this
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        __hip_atomic_store(rec + s * 2u + 1u, tag | tile_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + s * 2u, tag | (irregular ? 0xffffffffu : n_tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (irregular) return;  // uniform; the chunk goes to the general kernel
+      // the slices between my previous one and this one
+      if (tid < 64u) {
+        uint32_t cnt_i = 0u, sum_i = 0u;
+        bool fail = false;
+        if (tid < s - have) {
+          const unsigned long long* r = rec + (have + tid) * 2u;
+          // (relaxed accesses: the records carry their data, each word its own tag -- a release / acquire pair at agent
+          // scope writes back and invalidates the L2, which multiplied the kernel's time by four)
+          unsigned long long x = 0ull, y = 0ull;
+          uint32_t spins = 0u;
+          for (;; ++spins) {
+            x = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            y = __hip_atomic_load(r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (((uint32_t)(x >> 32) == epoch && (uint32_t)(y >> 32) == epoch) || spins >= kScfSpinLimit) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+          fail = (uint32_t)(x >> 32) != epoch || (uint32_t)(y >> 32) != epoch || (uint32_t)x == 0xffffffffu;
+          cnt_i = (uint32_t)x;
+          sum_i = (uint32_t)y;
+        }
+        const uint32_t cs = wave_sum(fail ? 0u : cnt_i), ss = wave_sum(sum_i);
+        const bool any_fail = __ballot(fail) != 0ull;
+        if (tid == 0u) {
+          flags[1] = cs;
+          flags[2] = ss;
+          if (any_fail) flags[0] = 1u;
+        }
+      }
+      __syncthreads();
+      if (flags[0]) return;  // a slice in front is irregular (or never came: the general kernel decodes the chunk)
+      pre_cnt += flags[1];
+      pre_sum += flags[2];
+      if (pre_cnt + n_tile > n) return;  // more tokens than points
+      {
+        uint32_t v = pre_sum + before;
+        for (uint32_t k = tb; k < tb + my_cnt; ++k) {
+          v += vals[k];
+          vals[k] = v;
+        }
       }
       __syncthreads();
       if (bpv == 2u) {
-        uint16_t* o = reinterpret_cast<uint16_t*>(col) + done;
-        for (uint32_t i = tid; i < take; i += kScfThreads) o[i] = (uint16_t)vals[i];
+        uint16_t* o = reinterpret_cast<uint16_t*>(col) + pre_cnt;
+        for (uint32_t i = tid; i < n_tile; i += kScfThreads) o[i] = (uint16_t)vals[i];
       } else {
-        uint32_t* o = reinterpret_cast<uint32_t*>(col) + done;
-        for (uint32_t i = tid; i < take; i += kScfThreads) o[i] = vals[i];
+        uint32_t* o = reinterpret_cast<uint32_t*>(col) + pre_cnt;
+        for (uint32_t i = tid; i < n_tile; i += kScfThreads) o[i] = vals[i];
       }
-      pos = next_pos;
-      carry += tile_sum;  // (tokens behind `take` do not exist when take < n_tile: the loop ends)
-      done += take;
-      __syncthreads();
+      pre_cnt += n_tile;
+      pre_sum += tile_sum;
+      have = s + 1u;
+      // the last slice closes the section: every point has its token and the last byte ends one
+      const bool ok = s + 1u < n_slices || (pre_cnt == n && (src[src_size - 1u] & 0x80u) == 0u);
+      if (ok && tid == 0u && (atomicAdd(slices_done + c, 1u) & 0xffffffu) + 1u == n_slices) sec_cols[c] = 1u;
+      __syncthreads();  // (tile, vals and flags are written again)
     }
-    if (pos != src_size) return;  // trailing bytes: the serial decoder raises the error
-    if (tid == 0) sec_cols[c] = 1u;
     return;
   }
 
-  if (mode == 2u || mode == 3u) {
+  if ((mode == 2u || mode == 3u) && part == 0u) {
     if (src_size - off < 4u) return;
     const uint32_t runs = (uint32_t)src[off] | ((uint32_t)src[off + 1u] << 8) | ((uint32_t)src[off + 2u] << 16) | ((uint32_t)src[off + 3u] << 24);
     off += 4u;

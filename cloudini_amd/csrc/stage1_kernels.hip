@@ -2428,16 +2428,23 @@ int stage1_launch_decode(const DecodeLaunch& L) {
           static const int lw = getenv("CLDN_HIP_LOCATE_WAVES") ? atoi(getenv("CLDN_HIP_LOCATE_WAVES")) : 0;  // A/B switch
           const bool wide = lw >= 16;  // (16 waves per chunk measured slower on C3 / C4 / C5: 0.452 / 0.572 / 0.140 against 0.433 / 0.552 / 0.137 ms)
           if (wide) hipLaunchKernelGGL(k_locate_sections<16>, dim3(L.n_chunks), dim3(1024), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done);
           else hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done);
         }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
         static const bool no_scf = getenv("CLDN_HIP_NO_FAST_COLS") != nullptr;  // A/B switch
-        const bool scf = !no_scf && P.n_adaptive == 1u;
+        const bool scf = !no_scf && P.n_adaptive == 1u && L.slice_rec != nullptr && L.slices_done != nullptr;
         if (scf) {
-          hipLaunchKernelGGL(k_sections_cols_fast, dim3(L.n_chunks), dim3(kScfThreads), 0, L.stream, P, L.streams,
-                             reinterpret_cast<const DecChunk*>(L.chunks), L.cols[0], L.reg_end_pre, L.sec_cols);
+          // workgroups per chunk: one when the batch has chunks enough to fill the chip (C3, 512 chunks: 0.404 / 0.400 /
+          // 0.402 / 0.404 ms with 1 / 2 / 4 / 8; workgroups that find nothing to share cost C4 about 20 us per
+          // 1024 of them), more for a single cloud's few chunks
+          static const int parts_env = getenv("CLDN_HIP_SCF_PARTS") ? atoi(getenv("CLDN_HIP_SCF_PARTS")) : 0;  // A/B switch
+          uint32_t parts = parts_env > 0 ? (uint32_t)parts_env : (512u + L.n_chunks - 1u) / L.n_chunks;
+          parts = std::min<uint32_t>(std::max<uint32_t>(parts, 1u), kScfMaxParts);
+          hipLaunchKernelGGL(k_sections_cols_fast, dim3(L.n_chunks * parts), dim3(kScfThreads), 0, L.stream, P, L.streams,
+                             reinterpret_cast<const DecChunk*>(L.chunks), L.cols[0], L.reg_end_pre, L.sec_cols, L.slices_done,
+                             L.slice_rec, L.slice_epoch, parts);
           if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_cols_fast");
         }
         hipLaunchKernelGGL(k_decode_sections_cols, dim3(L.n_chunks), dim3(kDvThreads), (DecSecLds::kTotal), L.stream, P, L.streams,

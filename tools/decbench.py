@@ -10,7 +10,8 @@ from cloudini_amd import native, synth
 dev = torch.device("cuda", 0)
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 cases = (("c5 xyz 10M", lambda: synth.lidar_xyz(10_000_000), 1), ("c2 xyzi 32x1M", lambda: synth.lidar_xyzi(1_000_000), 32),
-         ("c3 xyzrgba 16x1M", lambda: synth.depthcam_xyzrgba(1280, 800), 16), ("c4 velodyne 256x130k", lambda: synth.velodyne_xyzir(130048), 256))
+         ("c3 xyzrgba 16x1M", lambda: synth.depthcam_xyzrgba(1280, 800), 16), ("c4 velodyne 256x130k", lambda: synth.velodyne_xyzir(130048), 256),
+         ("s3 xyzrgba 1x1M", lambda: synth.depthcam_xyzrgba(1280, 800), 1), ("s4 velodyne 1x130k", lambda: synth.velodyne_xyzir(130048), 1))
 for name, make, n_clouds in cases:
     if only and not name.startswith(only):
         continue
