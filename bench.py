@@ -688,7 +688,7 @@ def main():
             "chunk_table": chunk_table,
             "stage1_bytes_per_point": out_bpp,
             "device_ms_per_step": {dominant: regular_ms, "sections": sections_ms,
-                                   "offsets+compact": compact_ms, "all_kernels": device_ms},
+                                   "k_finish": compact_ms, "all_kernels": device_ms},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_measured_in_run": False,
