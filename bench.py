@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0 (see README/DESIGN.md for the field meanings):
   cpu_baseline     the real reference (oracle/_ref, kind "reference") or the C port (kind "port") timed on the
                    host cores on a bounded sample of the same workload (rank 0, N=1 only)
   e2e              PCIe-inclusive and single-cloud figures (never `value`), each next to the reference on the host
+  configs          encode + decode (ms, Mpoints/s, bit_exact) of BASELINE configs C1, C3, C4, C5 through the same calls (N=1 only)
   bit_exact        the streams of the timed batch equal the checker's (compiled reference, else the C port), byte for byte
 """
 from __future__ import annotations
@@ -315,6 +316,84 @@ def transcode_figures(n_msgs: int):
         return out
 
 
+def config_figures(dev, steps: int):
+    """extra (never `value`): the other BASELINE configs through the same two device-resident calls -- encode to the framed
+    streams, decode with the encoder's chunk sizes -- so that every config has a number in the bench line. Each config's
+    first cloud is compared with the reference (the C oracle where oracle/_ref is absent) and the decode with the
+    reference's decode of that stream, outside the timed loops."""
+    import torch
+    from cloudini_amd import native
+    checker, checker_kind = None, None
+    try:
+        from oracle.binding import RefLib
+        checker, checker_kind = RefLib(), "reference"
+    except (OSError, FileNotFoundError, ImportError):
+        try:
+            from oracle.binding import Oracle
+            checker, checker_kind = Oracle(), "port"
+        except (OSError, FileNotFoundError, ImportError):
+            pass
+    out = {}
+    stream = torch.cuda.current_stream(dev)
+    for name, clouds, points in (("c1", 256, 65536), ("c3", 16, 1024000), ("c4", 256, 130048), ("c5", 1, 10_000_000)):
+        try:
+            info, distinct = make_workload(name, points, min(4, clouds))
+            step = info.point_step
+            n = len(distinct[0]) // step
+            plan = native.Plan(info)
+            codec = native.Codec(plan, device=dev.index or 0, stream=stream.cuda_stream)
+            host = np.concatenate([distinct[k % len(distinct)] for k in range(clouds)])
+            cloud_points = np.full(clouds, n, dtype=np.uint64)
+            d_points = torch.from_numpy(host).to(dev)
+            cap = plan.stage1_bound(n) * clouds
+            d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+            d_off = torch.zeros(clouds + 1, dtype=torch.int64, device=dev)
+            n_chunks = clouds * ((n + 32767) // 32768)
+            d_sizes = torch.zeros(max(1, n_chunks), dtype=torch.int32, device=dev)
+
+            def enc():
+                codec.encode_device(d_points.data_ptr(), cloud_points, d_out.data_ptr(), cap, d_off.data_ptr(), d_sizes.data_ptr(), 0)
+
+            def timed(fn):
+                for _ in range(3):
+                    fn()
+                blocks = []
+                for _ in range(3):
+                    torch.cuda.synchronize(dev)
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        fn()
+                    torch.cuda.synchronize(dev)
+                    blocks.append((time.perf_counter() - t0) / steps)
+                return float(np.median(blocks)) * 1e3
+
+            enc_ms = timed(enc)
+            codec.status()
+            offs = d_off.cpu().numpy().astype(np.uint64)
+            d_dec = torch.zeros(host.size, dtype=torch.uint8, device=dev)
+            dec_ms = timed(lambda: codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size, d_sizes.data_ptr()))
+            codec.status()
+            dec_stats = codec.decode_stats()
+            entry = {"workload": WORKLOAD_DESC[name].format(clouds=clouds, points=n),
+                     "decode_chunks_parallel_regular/parallel_sections/serial/serial_sections": list(dec_stats),
+                     "encode_ms": enc_ms, "encode_Mpoints_per_s": clouds * n / (enc_ms * 1e-3) / 1e6,
+                     "decode_ms": dec_ms, "decode_Mpoints_per_s": clouds * n / (dec_ms * 1e-3) / 1e6,
+                     "stage1_bytes_per_point": int(offs[-1]) / (clouds * n)}
+            if checker is not None:
+                got = d_out[int(offs[0]):int(offs[1])].cpu().numpy()
+                want = checker.encode_stage1(info, distinct[0])
+                dec_got = d_dec[: n * step].cpu().numpy()
+                dec_want = (checker.decode_noheader(info, want, 0) if checker_kind == "reference" else checker.decode_stage1(info, want, n, 0))[: n * step]
+                entry["bit_exact"] = bool(np.array_equal(got, want)) and bool(np.array_equal(dec_got, dec_want))
+                entry["checker"] = checker_kind
+            out[name] = entry
+            codec.close()
+            del d_points, d_out, d_dec
+        except Exception as exc:  # an extra must not take the line down
+            out[name] = {"error": repr(exc)}
+    return out
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -353,6 +432,8 @@ def main():
     ap.add_argument("--e2e-seconds", type=float, default=6.0, help="budget of the e2e legs (0 = skip; N=1 only)")
     ap.add_argument("--transcode-messages", type=int, default=256,
                     help="messages of the batch-transcoder leg (BASELINE configs[3], ZSTD; 0 = skip; N=1 only)")
+    ap.add_argument("--config-legs", type=int, default=1,
+                    help="1: the `configs` object (encode + decode of the other BASELINE configs, N=1 only); 0 = skip")
     ap.add_argument("--no-verify", dest="verify", action="store_false",
                     help="skip the bit-exactness check of the timed batch's streams (outside the timed region)")
     args = ap.parse_args()
@@ -712,6 +793,11 @@ def main():
                 result["transcode"] = transcode_figures(args.transcode_messages)
             except Exception as exc:
                 result["transcode"] = {"error": repr(exc)}
+        if args.config_legs and world == 1 and args.shard == "clouds" and args.workload == "c2":
+            try:
+                result["configs"] = config_figures(dev, max(3, args.steps // 2))
+            except Exception as exc:
+                result["configs"] = {"error": repr(exc)}
         print(json.dumps(result))
         sys.stdout.flush()
     if dist is not None:

@@ -100,6 +100,76 @@ __device__ __forceinline__ uint32_t fp_ends16(const uint32_t (&b)[4]) {
   return ends;
 }
 
+// Where a lone Palette section would begin, found from the END of the payload: a Palette section of U entries has
+// 3 + U * bpv + ceil(bits(U) * n / 8) bytes (src/v5_codec.cpp:298-306), so every U has exactly one place where its header
+// [1][U lo][U hi] would have to be, and the threads try all U <= kFastPalEntries. Three bytes of a token stream that merely
+// look like a header are no rarity -- 2 to 6 % of the chunks of a lidar batch have such a place -- and every chunk that
+// follows a wrong guess ends in the serial section decoder (150 us for the whole launch). So the smallest candidate is
+// checked by the workgroup together (one independent load or two per thread, one round trip): the byte in front of it
+// ends a token, the first 8 entries are distinct, the first 32 indexes are below U. A real section always passes (the
+// encoder's entries are distinct, its indexes in range); a look-alike passes about once in 10^4. A candidate that fails
+// is skipped and the next one tried; after four of them the caller counts tokens instead.
+// All threads of the workgroup call it (barriers inside); sh = two LDS words. Returns U, or 0xffffffff.
+template <int T>
+__device__ __forceinline__ uint32_t pal_guess_from_end(const uint8_t* __restrict__ src, uint32_t src_size, uint32_t n, uint32_t bpv,
+                                                       uint32_t* sh) {
+  const uint32_t tid = threadIdx.x;
+  uint32_t floor = 0u;
+  for (uint32_t round = 0; round < 4u; ++round) {
+    if (tid == 0u) {
+      sh[0] = 0xffffffffu;
+      sh[1] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t U = tid + 1u; U <= kFastPalEntries; U += (uint32_t)T) {
+      const uint64_t S = 3ull + (uint64_t)U * bpv + ((uint64_t)palette_bits(U) * n + 7u) / 8u;
+      if (U > floor && S <= src_size) {
+        const uint8_t* h = src + (src_size - (uint32_t)S);
+        if (h[0] == 1u && ((uint32_t)h[1] | ((uint32_t)h[2] << 8)) == U) atomicMin(&sh[0], U);
+      }
+    }
+    __syncthreads();
+    const uint32_t U = sh[0];
+    if (U == 0xffffffffu) return U;
+    const uint32_t bits = palette_bits(U);
+    const uint32_t off = src_size - (uint32_t)(3ull + (uint64_t)U * bpv + ((uint64_t)bits * n + 7u) / 8u);
+    const uint8_t* tab = src + off + 3u;
+    bool bad = false;
+    if (tid == 0u) {
+      bad = off != 0u && (src[off - 1u] & 0x80u) != 0u;  // the token in front of the section would not be over
+    } else if (tid <= 32u) {
+      const uint32_t k = tid - 1u;  // index k of the section
+      if (bits != 0u && k < n) {
+        const uint8_t* idx = tab + (size_t)U * bpv;
+        const uint32_t avail = src_size - (off + 3u + U * bpv);
+        const uint32_t bit0 = k * bits, by = bit0 >> 3;
+        uint32_t w = 0u;
+        for (uint32_t b = 0; b < 3u; ++b)  // bits <= 10: three bytes hold an index
+          if (by + b < avail) w |= (uint32_t)idx[by + b] << (8u * b);
+        bad = ((w >> (bit0 & 7u)) & ((1u << bits) - 1u)) >= U;
+      }
+    } else if (tid < 41u) {
+      const uint32_t i = tid - 33u;  // entry i against the entries in front of it
+      if (i >= 1u && i < U) {
+        uint32_t v = 0u;
+        for (uint32_t b = 0; b < bpv; ++b) v |= (uint32_t)tab[i * bpv + b] << (8u * b);
+        for (uint32_t j = 0; j < i; ++j) {
+          uint32_t w = 0u;
+          for (uint32_t b = 0; b < bpv; ++b) w |= (uint32_t)tab[j * bpv + b] << (8u * b);
+          bad = bad || w == v;
+        }
+      }
+    }
+    if (bad) sh[1] = 1u;
+    __syncthreads();
+    const bool rejected = sh[1] != 0u;
+    __syncthreads();  // (sh is written again)
+    if (!rejected) return U;
+    floor = U;
+  }
+  return 0xffffffffu;
+}
+
 struct FpSection {   // a Palette section folded into the point pass
   uint32_t field_off;  // offset of the field inside the point
   uint32_t bpv;        // 2 or 4
@@ -122,7 +192,7 @@ __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan,
                                                          uint32_t* __restrict__ reg_end_pre, uint8_t* __restrict__ sec_cols,
                                                          uint32_t* __restrict__ slices_done) {
   __shared__ uint32_t wcnt[NW];
-  __shared__ uint32_t found, pal_hit;
+  __shared__ uint32_t found, pal_sh[2];
   const uint32_t c = blockIdx.x;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,7 +202,6 @@ __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan,
     sec_cols[c] = 0u;
     slices_done[c] = 0xffu << 24;
     found = 0xffffffffu;
-    pal_hit = 0u;
   }
   if (!dc.valid || plan.n_adaptive == 0u || plan.n_adaptive > kFastPalFields) return;
   for (uint32_t a = 0; a < plan.n_adaptive; ++a)
@@ -143,16 +212,7 @@ __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan,
   const uint32_t target = n * n_ops;
   __syncthreads();
   if (plan.n_adaptive == 1u) {
-    const uint32_t bpv = plan.adaptive[0].bpv;
-    for (uint32_t U = tid + 1u; U <= kFastPalEntries; U += NW * 64u) {
-      const uint64_t S = 3ull + (uint64_t)U * bpv + ((uint64_t)palette_bits(U) * n + 7u) / 8u;
-      if (S <= src_size) {
-        const uint8_t* h = src + (src_size - (uint32_t)S);
-        if (h[0] == 1u && ((uint32_t)h[1] | ((uint32_t)h[2] << 8)) == U) pal_hit = 1u;
-      }
-    }
-    __syncthreads();
-    if (pal_hit) return;  // uniform
+    if (pal_guess_from_end<NW * 64>(src, src_size, n, plan.adaptive[0].bpv, pal_sh) != 0xffffffffu) return;  // uniform
   }
   const uint32_t part = (((src_size + 15u) / 16u + (NW - 1u)) / NW) * 16u;  // bytes per wave, multiple of 16
   const uint32_t w0 = min(src_size, wave * part), w1 = min(src_size, w0 + part);
@@ -685,15 +745,7 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     // tiles end somewhere else: the chunk's sections are then left to the section kernels, like any chunk without a
     // hit. This spares the counting pass over the whole payload.
     const uint32_t bpv = plan.adaptive[0].bpv;
-    for (uint32_t U = tid + 1u; U <= kFastPalEntries; U += (uint32_t)T) {
-      const uint64_t S = 3ull + (uint64_t)U * bpv + ((uint64_t)palette_bits(U) * n + 7u) / 8u;
-      if (S <= src_size) {
-        const uint8_t* h = src + (src_size - (uint32_t)S);
-        if (h[0] == 1u && ((uint32_t)h[1] | ((uint32_t)h[2] << 8)) == U) atomicMin(&misc[42], U);
-      }
-    }
-    __syncthreads();
-    const uint32_t U = misc[42];
+    const uint32_t U = pal_guess_from_end<T>(src, src_size, n, bpv, misc + 42);
     if (U != 0xffffffffu) reg_size = src_size - (uint32_t)(3ull + (uint64_t)U * bpv + ((uint64_t)palette_bits(U) * n + 7u) / 8u);
     located = true;
   }

@@ -312,6 +312,18 @@ def test_section_guess_with_a_false_hit_in_the_token_stream(oracle, field):
     assert stats == (n_chunks, n_chunks, 0, 0)
 
 
+def test_section_guess_lookalikes_in_lidar_streams(oracle):
+    """Token streams of ordinary lidar clouds hold places that read as the header of a Palette section of the very size
+    that would put it there (velodyne generator, seeds 45 and 47: 695 entries in chunk 1; XYZI seed 42: 723 and 929 next
+    to the real 256): pal_guess_from_end checks its candidates (token end in front, distinct entries, indexes in range)
+    before anything is built on them. The bytes are the oracle's whatever the guess does."""
+    for gen, n, seed in ((synth.velodyne_xyzir, 130048, 45), (synth.velodyne_xyzir, 130048, 47), (synth.lidar_xyzi, 500000, 42)):
+        info, data = gen(n, seed=seed)
+        check_decode(oracle, info, [data])
+        stats, _modes, n_chunks = _stats_after_decode(oracle, info, data)
+        assert stats == (n_chunks, n_chunks, 0, 0)
+
+
 def test_decode_with_the_chunk_sizes_given(oracle):
     """cldn_hip_decode_stage1_sized: the caller's payload sizes replace the serial walk over the [u32] prefixes; every size
     is still checked against its prefix."""

@@ -16,11 +16,17 @@ for name, make, n_clouds in cases:
     if only and not name.startswith(only):
         continue
     info, data = make()
+    distinct = int(os.environ.get("DECBENCH_DISTINCT", "1"))  # the cases' generators take a seed: tile several clouds
+    datas = [data]
+    if distinct > 1 and n_clouds > 1:
+        gen = {"c2": synth.lidar_xyzi, "c4": synth.velodyne_xyzir}.get(name[:2])
+        if gen is not None:
+            datas = [gen(data.size // info.point_step, seed=42 + k)[1] for k in range(distinct)]
     plan = native.Plan(info)
     codec = native.Codec(plan, device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
     step = info.point_step
     n = data.size // step
-    host = np.concatenate([data] * n_clouds)
+    host = np.concatenate([datas[k % len(datas)] for k in range(n_clouds)])
     d_points = torch.from_numpy(host).to(dev)
     cloud_points = np.full(n_clouds, n, dtype=np.uint64)
     cap = plan.stage1_bound(n) * n_clouds

@@ -3,7 +3,7 @@
 #   1 kernel trace + stats          2 --pmc FETCH_SIZE     3 --pmc WRITE_SIZE     4 --pmc SQ instruction mix
 # Summaries land in gpurun_out/prof_<tag>_*.txt; copy the ones to keep into profiles/.
 TAG=${1:-run}
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-baseline-seconds 0 --e2e-seconds 0 --transcode-messages 0"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-baseline-seconds 0 --e2e-seconds 0 --transcode-messages 0 --config-legs 0"
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
