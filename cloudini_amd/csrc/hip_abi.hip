@@ -801,7 +801,7 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
       if ((rc = c->d_ranks[a].ensure((size_t)n_points * 2 + 64)) != CLDN_HIP_OK) return rc;
     }
     if (plan.n_gorilla) {
-      void* ptrs[kMaxGorilla] = {nullptr, nullptr, nullptr, nullptr};
+      void* ptrs[kMaxGorilla] = {};
       for (uint32_t g = 0; g < plan.n_gorilla; ++g) {
         // 16-byte tokens per point (generic kernel) or one window word per piece (piece kernel, kGorWinStride per chunk)
         if ((rc = c->d_pre[g].ensure(std::max((size_t)n_points * 16, (size_t)n_chunks * 256) + 64)) != CLDN_HIP_OK) return rc;

@@ -12,7 +12,7 @@ constexpr uint32_t kProbePoints = 4096;      // kAdaptiveModeProbePoints, src/v5
 // Schema limits of this build. The plan travels to the kernels by value: 64 ops * 40 B + 32 adaptive fields * 8 B plus
 // the column pointer table (32 * 8 B, twice in the general section kernel) stay below the 4 KB a launch may carry.
 constexpr int kMaxOps = 64;                  // regular tokens per point
-constexpr int kMaxAdaptive = 32;             // V5 adaptive-int fields per schema
+constexpr int kMaxAdaptive = 64;             // V5 adaptive-int fields per schema
 constexpr uint32_t kMaxPointStep = 1024;     // generic kernel: points wider than 256 bytes go in 64-point tiles (2 x 64 KiB of LDS)
 constexpr uint32_t kWidePointStep = 256;     // up to here a 1024-thread tile of 16 KiB holds at least 64 points
 
@@ -30,7 +30,7 @@ enum : uint8_t {
                      // DevOp::type = index of the op's token buffer)
 };
 
-constexpr int kMaxGorilla = 4;  // Gorilla-coded FLOAT64 fields per schema
+constexpr int kMaxGorilla = 64;  // Gorilla-coded FLOAT64 fields per schema
 
 struct DevOp {
   uint8_t kind;

@@ -38,9 +38,10 @@ extern "C" {
 
 /* Schema limits of this build (cldn_hip_plan_create answers CLDN_HIP_ERR_UNSUPPORTED beyond them; there is no CPU
  * fallback): point_step <= 1024 bytes; <= 64 per-point tokens (fields of the regular stream: a fused FloatN group
- * counts 3 or 4); <= 32 adaptive integer fields (16/32/64-bit integers of a V5 lossy schema); <= 4 Gorilla-coded FLOAT64
- * fields (FLOAT64 without resolution, version >= 4). The reference has no such limits (src/codec_common.cpp:116-153,
- * src/v5_codec.cpp:719-740). Points wider than 256 bytes take the generic kernel in 64-point tiles. */
+ * counts 3 or 4; Gorilla-coded FLOAT64 fields are tokens like any other); <= 64 adaptive integer fields (16/32/64-bit
+ * integers of a V5 lossy schema). The reference has no such limits (src/codec_common.cpp:116-153,
+ * src/v5_codec.cpp:719-740); the plan travels to the kernels as a launch argument, which bounds its size. Points wider than
+ * 256 bytes take the generic kernel in 64-point tiles. */
 
 /* Return codes. */
 enum {

@@ -143,7 +143,12 @@ def test_unsupported_schemas_fail_loudly():
     with pytest.raises(native.CloudiniHipError) as e:
         native.Plan(info)
     assert e.value.code == -3
-    info = cases.make_info([(f"g{k}", 8 * k, FieldType.FLOAT64, None) for k in range(5)], 40, 10)  # 5 Gorilla fields
+    info = cases.make_info([(f"g{k}", 8 * k, FieldType.FLOAT64, None) for k in range(65)], 520, 10)  # 65 per-point tokens
+    with pytest.raises(native.CloudiniHipError) as e:
+        native.Plan(info)
+    assert e.value.code == -3
+    info = cases.make_info([("x", 0, FieldType.FLOAT32, 0.001)] + [(f"u{k}", 4 + 2 * k, FieldType.UINT16, None) for k in range(65)],
+                           134, 10)  # 65 adaptive integer fields
     with pytest.raises(native.CloudiniHipError) as e:
         native.Plan(info)
     assert e.value.code == -3

@@ -102,7 +102,7 @@ def test_random_schema(oracle, seed):
 @pytest.mark.parametrize("seed", list(range(5000, 5040)))
 def test_random_wide_schema(oracle, seed):
     """Up to 64 fields, points of up to 1024 bytes: either byte-exact or refused with UNSUPPORTED for one of the limits
-    include/cloudini_hip.h lists (more than 64 per-point tokens, 32 adaptive fields, 4 Gorilla fields)."""
+    include/cloudini_hip.h lists (more than 64 per-point tokens or 64 adaptive fields)."""
     from cloudini_amd import native
     info, data = _random_case(seed, wide=True)
     n = data.size // info.point_step
