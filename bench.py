@@ -299,6 +299,22 @@ def transcode_figures(n_msgs: int):
                "Mpoints_per_s": st["points"] / wall / 1e6, "seconds": wall, "messages": int(st["messages"]),
                "gpu_batches": int(st["gpu_batches"]), "gpu_stage_busy_fraction": st["seconds_gpu"] / max(wall, 1e-9),
                "stage2_threads": api.stage2_threads(), "output_bytes_per_point": st["output_bytes"] / max(1.0, st["points"])}
+        # the same run with the stage-2 pool sized to the CPUs the box grants (minus the reader, GPU and writer threads):
+        # what a batch tool would set; the default above is the library's conservative min(4, cores)
+        usable = host_cpus()[0]
+        if usable - 3 > api.stage2_threads():
+            before = api.stage2_threads()
+            api.set_stage2_threads(usable - 3)
+            try:
+                st2 = None
+                for _rep in range(2):
+                    t0 = time.perf_counter()
+                    st2 = api.transcode_directory(src, dst, resolution=0.001, compression_opt=int(CompressionOption.ZSTD), batch_messages=32)
+                    wall2 = time.perf_counter() - t0
+                out["all_granted_cpus"] = {"stage2_threads": api.stage2_threads(), "Mpoints_per_s": st2["points"] / wall2 / 1e6,
+                                           "seconds": wall2, "gpu_stage_busy_fraction": st2["seconds_gpu"] / max(wall2, 1e-9)}
+            finally:
+                api.set_stage2_threads(before)
         try:
             from oracle.binding import RefLib
             ref = RefLib()

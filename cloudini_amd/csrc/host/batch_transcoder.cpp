@@ -7,16 +7,22 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <cerrno>
 #include <dirent.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <fstream>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <sys/stat.h>
 #include <thread>
+#include <unordered_map>
 
 #include "host_internal.hpp"
 
@@ -89,6 +95,69 @@ class BoundedQueue {
 
 // ---- directory I/O --------------------------------------------------------------------------------------------
 
+// ---- page-locked blocks, kept across calls ------------------------------------------------------------------------
+namespace {
+struct PinnedCache {
+  std::mutex mutex;
+  std::unordered_map<void*, size_t> capacity;       // every live block (handed out or cached)
+  std::multimap<size_t, void*> idle;                // cached blocks by capacity
+  size_t idle_bytes = 0;
+  static constexpr size_t kMaxIdleBytes = size_t(2) << 30;
+};
+PinnedCache& pinnedCache() {
+  static PinnedCache* c = new PinnedCache();  // (never destroyed: blocks may be freed from static destructors)
+  return *c;
+}
+}  // namespace
+
+void* pinnedAlloc(size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  PinnedCache& c = pinnedCache();
+  {
+    std::lock_guard<std::mutex> lock(c.mutex);
+    auto it = c.idle.lower_bound(bytes);
+    if (it != c.idle.end() && it->first <= 2 * bytes + 4096) {  // (a block much larger than asked for stays for a larger request)
+      void* p = it->second;
+      c.idle_bytes -= it->first;
+      c.idle.erase(it);
+      return p;
+    }
+  }
+  void* p = cldn_hip_host_alloc(bytes);
+  if (p) {
+    std::lock_guard<std::mutex> lock(c.mutex);
+    c.capacity[p] = bytes;
+  }
+  return p;
+}
+
+void pinnedFree(void* p) noexcept {
+  if (!p) return;
+  PinnedCache& c = pinnedCache();
+  {
+    std::lock_guard<std::mutex> lock(c.mutex);
+    auto it = c.capacity.find(p);
+    if (it != c.capacity.end() && c.idle_bytes + it->second <= PinnedCache::kMaxIdleBytes) {
+      c.idle.emplace(it->second, p);
+      c.idle_bytes += it->second;
+      return;
+    }
+    if (it != c.capacity.end()) c.capacity.erase(it);
+  }
+  cldn_hip_host_free(p);
+}
+
+void releasePinnedCache() noexcept {
+  PinnedCache& c = pinnedCache();
+  std::lock_guard<std::mutex> lock(c.mutex);
+  for (auto& kv : c.idle) {
+    c.capacity.erase(kv.second);
+    cldn_hip_host_free(kv.second);
+  }
+  c.idle.clear();
+  c.idle_bytes = 0;
+}
+
 DirectorySource::DirectorySource(const std::string& dir) : dir_(dir) {
   DIR* d = opendir(dir.c_str());
   if (!d) throw std::runtime_error("cannot open directory " + dir);
@@ -103,16 +172,38 @@ DirectorySource::DirectorySource(const std::string& dir) : dir_(dir) {
 }
 
 bool DirectorySource::next(Message& out) {
-  if (at_ >= files_.size()) return false;
-  out.name = files_[at_++];
-  std::ifstream f(dir_ + "/" + out.name, std::ios::binary | std::ios::ate);
-  if (!f) throw std::runtime_error("cannot read " + dir_ + "/" + out.name);
-  const std::streamsize size = f.tellg();
-  if (size < 0) throw std::runtime_error("cannot size " + dir_ + "/" + out.name);
-  f.seekg(0);
-  out.bytes.resize(static_cast<size_t>(size));
-  if (size && !f.read(reinterpret_cast<char*>(out.bytes.data()), size)) throw std::runtime_error("short read: " + out.name);
+  uint64_t ticket;
+  if (!claim(ticket)) return false;
+  fetch(ticket, out);
   return true;
+}
+
+bool DirectorySource::claim(uint64_t& ticket) {
+  if (at_ >= files_.size()) return false;
+  ticket = at_++;
+  return true;
+}
+
+void DirectorySource::fetch(uint64_t ticket, Message& out) {
+  out.name = files_[static_cast<size_t>(ticket)];
+  const std::string path = dir_ + "/" + out.name;
+  const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+  if (fd < 0) throw std::runtime_error("cannot read " + path);
+  struct stat st;
+  if (::fstat(fd, &st) != 0 || st.st_size < 0) {
+    ::close(fd);
+    throw std::runtime_error("cannot size " + path);
+  }
+  out.bytes.resize(static_cast<size_t>(st.st_size));  // (PinnedAllocator::construct leaves the bytes alone)
+  size_t got = 0;
+  while (got < out.bytes.size()) {
+    const ssize_t r = ::read(fd, out.bytes.data() + got, out.bytes.size() - got);
+    if (r < 0 && errno == EINTR) continue;
+    if (r <= 0) break;
+    got += static_cast<size_t>(r);
+  }
+  ::close(fd);
+  if (got != out.bytes.size()) throw std::runtime_error("short read: " + out.name);
 }
 
 DirectorySink::DirectorySink(const std::string& dir) : dir_(dir) {
@@ -466,6 +557,36 @@ void transcodeBatch(const std::vector<Message>& in, const TranscodeOptions& opt,
   out = std::move(b.out);
 }
 
+// fn(i) for i in [0, n) on up to `threads` threads (the caller is one of them); the first exception is rethrown
+template <typename Fn>
+void parallelFor(size_t n, unsigned threads, Fn&& fn) {
+  if (threads <= 1 || n <= 1) {
+    for (size_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::exception_ptr error;
+  std::mutex error_mutex;
+  auto work = [&] {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n) return;
+      try {
+        fn(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lock(error_mutex);
+        if (!error) error = std::current_exception();
+        next.store(n);
+      }
+    }
+  };
+  std::vector<std::thread> team;
+  for (unsigned t = 1; t < std::min<size_t>(threads, n); ++t) team.emplace_back(work);
+  work();
+  for (std::thread& t : team) t.join();
+  if (error) std::rethrow_exception(error);
+}
+
 // ---- the pipeline: reader -> GPU (this thread) -> stage 2 -> writer; batches circulate (page-locked buffers are reused) ---
 
 TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, const TranscodeOptions& opt) {
@@ -495,31 +616,46 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
   std::vector<std::exception_ptr> gpu_error(n_workers);
   std::atomic<bool> failed{false};
   const size_t batch = std::max<size_t>(1, opt.batch_messages);
+  double seconds_read = 0, seconds_write = 0;  // each written by one thread (diagnostics, CLDN_HOST_TIMING)
 
+  const unsigned io_threads = std::max(1u, opt.io_threads);
   std::thread reader([&] {
     try {
-      Batch* b = nullptr;
-      size_t used = 0;
       uint64_t seq = 0;
+      std::vector<uint64_t> tickets;
       for (;;) {
-        if (!b) {
-          if (!free_q.pop(b)) break;
-          used = 0;
+        Batch* b = nullptr;
+        if (!free_q.pop(b)) break;
+        if (failed.load()) {
+          free_q.push(b);
+          break;
         }
-        if (failed.load()) break;
-        if (b->in.size() <= used) b->in.emplace_back();
-        if (!source.next(b->in[used])) break;  // the source refills the Message (and reuses its page-locked capacity)
-        if (++used == batch) {
-          b->in.resize(used);
-          b->seq = seq++;
-          to_gpu.push(b);
-          b = nullptr;
+        size_t used = 0;
+        const auto t_read = Clock::now();
+        if (source.concurrent() && io_threads > 1) {
+          // tickets in input order by this thread, the messages themselves by the team
+          tickets.clear();
+          uint64_t t;
+          while (tickets.size() < batch && source.claim(t)) tickets.push_back(t);
+          used = tickets.size();
+          if (b->in.size() < used) b->in.resize(used);
+          parallelFor(used, io_threads, [&](size_t i) { source.fetch(tickets[i], b->in[i]); });
+        } else {
+          while (used < batch) {
+            if (b->in.size() <= used) b->in.emplace_back();
+            if (!source.next(b->in[used])) break;  // the source refills the Message (and reuses its page-locked capacity)
+            ++used;
+          }
         }
-      }
-      if (b && used && !failed.load()) {
+        seconds_read += since(t_read);
+        if (used == 0) {
+          free_q.push(b);
+          break;
+        }
         b->in.resize(used);
         b->seq = seq++;
         to_gpu.push(b);
+        if (used < batch) break;  // the source is exhausted
       }
     } catch (...) {
       reader_error = std::current_exception();
@@ -585,7 +721,10 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
     auto write_one = [&](Batch* x) {
       if (!failed.load()) {
         try {
-          for (size_t i = 0; i < x->in.size(); ++i) sink.write(x->in[i].name, x->out[i].data(), x->out[i].size());
+          const auto t_write = Clock::now();
+          parallelFor(x->in.size(), sink.concurrent() ? io_threads : 1u,
+                      [&](size_t i) { sink.write(x->in[i].name, x->out[i].data(), x->out[i].size()); });
+          seconds_write += since(t_write);
         } catch (...) {
           writer_error = std::current_exception();
           failed.store(true);
@@ -632,6 +771,9 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
   stats.seconds_stage2 = stats2.seconds_stage2;
   stats.seconds_total = since(t0);
   stats.gpu_workers = n_workers;
+  if (std::getenv("CLDN_HOST_TIMING"))
+    std::fprintf(stderr, "[cloudini_amd] transcode: %.3f s total; source %.3f s, GPU stages %.3f s, stage 2 %.3f s, sink %.3f s\n",
+                 stats.seconds_total, seconds_read, stats.seconds_gpu, stats.seconds_stage2, seconds_write);
   return stats;
 }
 

@@ -22,6 +22,7 @@
 #include <new>
 #include <optional>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "cloudini_hip.h"
@@ -31,6 +32,12 @@
 namespace cloudini_amd {
 
 // Page-locked host memory (cldn_hip_host_alloc): message buffers and staging areas the GPU copies from / to directly.
+// Freed blocks are kept (up to 2 GiB per process) and handed out again: page-locking 370 MB of batch buffers costs a
+// transcodePointClouds call 50 ms otherwise. releasePinnedCache() returns them to the driver.
+void* pinnedAlloc(size_t bytes);
+void pinnedFree(void* p) noexcept;
+void releasePinnedCache() noexcept;
+
 template <typename T>
 struct PinnedAllocator {
   using value_type = T;
@@ -39,6 +46,15 @@ struct PinnedAllocator {
   PinnedAllocator(const PinnedAllocator<U>&) {}
   T* allocate(size_t n);
   void deallocate(T* p, size_t) noexcept;
+  // resize() of a byte buffer that is about to be read into must not write it first (a 2.3 MB message would cross memory twice)
+  template <typename U>
+  void construct(U* p) noexcept {
+    ::new (static_cast<void*>(p)) U;
+  }
+  template <typename U, typename... Args>
+  void construct(U* p, Args&&... args) {
+    ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+  }
   template <typename U>
   bool operator==(const PinnedAllocator<U>&) const { return true; }
   template <typename U>
@@ -55,12 +71,27 @@ class MessageSource {
  public:
   virtual ~MessageSource() = default;
   virtual bool next(Message& out) = 0;  // false at the end
+  // Optional: a source whose messages can be fetched independently of each other (files of a directory, records of an
+  // indexed bag) lets the pipeline read a batch with several threads: claim() hands out the next message's ticket (one
+  // caller at a time, input order), fetch() may then run concurrently for different tickets. next() == claim + fetch.
+  virtual bool concurrent() const { return false; }
+  virtual bool claim(uint64_t& ticket) {
+    (void)ticket;
+    return false;
+  }
+  virtual void fetch(uint64_t ticket, Message& out) {
+    (void)ticket;
+    (void)out;
+  }
 };
 
 class MessageSink {
  public:
   virtual ~MessageSink() = default;
   virtual void write(const std::string& name, const uint8_t* data, size_t size) = 0;  // called in input order
+  // Optional: a sink whose messages are independent (one file each) may be written by several threads at once; batches
+  // still arrive in input order, the messages inside a batch in any order.
+  virtual bool concurrent() const { return false; }
 };
 
 // every regular file of a directory in lexicographic order / one file per message
@@ -68,6 +99,9 @@ class DirectorySource : public MessageSource {
  public:
   explicit DirectorySource(const std::string& dir);
   bool next(Message& out) override;
+  bool concurrent() const override { return true; }
+  bool claim(uint64_t& ticket) override;
+  void fetch(uint64_t ticket, Message& out) override;
 
  private:
   std::vector<std::string> files_;
@@ -79,6 +113,7 @@ class DirectorySink : public MessageSink {
  public:
   explicit DirectorySink(const std::string& dir);
   void write(const std::string& name, const uint8_t* data, size_t size) override;
+  bool concurrent() const override { return true; }
 
  private:
   std::string dir_;
@@ -90,6 +125,7 @@ struct TranscodeOptions {
   bool viz_lossy = false;                                       // applyVizLossyPreprocessing in front of the encoder
   Cloudini::CompressionOption compression = Cloudini::CompressionOption::ZSTD;  // toEncodingInfo's default
   size_t batch_messages = 32;                                   // messages per GPU batch
+  unsigned io_threads = 4;                                      // threads that read / write a batch of a concurrent() source / sink
   // The way back (McapConverter::decodePointClouds, tools/src/mcap_converter.cpp:240-300): the messages are
   // CompressedPointCloud2, every output is the sensor_msgs/PointCloud2 that convertCompressedCloudToPointCloud2
   // (src/ros_msg_utils.cpp:135-165) writes. profile / default_resolution / viz_lossy / compression are not used.
@@ -108,13 +144,13 @@ struct TranscodeStats {
 
 template <typename T>
 T* PinnedAllocator<T>::allocate(size_t n) {
-  void* p = cldn_hip_host_alloc(n * sizeof(T));
+  void* p = pinnedAlloc(n * sizeof(T));
   if (!p) throw std::bad_alloc();
   return static_cast<T*>(p);
 }
 template <typename T>
 void PinnedAllocator<T>::deallocate(T* p, size_t) noexcept {
-  cldn_hip_host_free(p);
+  pinnedFree(p);
 }
 
 // One batch, in memory (also the unit the pipeline below runs): out[i] = CompressedPointCloud2 of in[i].
