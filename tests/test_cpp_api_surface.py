@@ -33,3 +33,26 @@ def test_cpp_caller_roundtrip_on_the_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_transcoder_sources_and_sinks(tmp_path):
+    """tests/cpp/transcoder_sources.cpp: a sequential source with an order-checking sink and the concurrent directory
+    source with a concurrent sink give the same messages (MessageSource::claim/fetch, MessageSink::concurrent)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from cloudini_amd import synth
+    src = tmp_path / "in"
+    src.mkdir()
+    for k in range(8):
+        info, data = synth.velodyne_xyzir(3000 + 977 * k, seed=5 + k)
+        synth.cdr_pointcloud2(info, data, stamp=(1700000000, k)).tofile(str(src / f"msg_{k:03d}.bin"))
+    lib_dir = os.path.join(ROOT, "cloudini_amd", "lib")
+    exe = str(tmp_path / "transcoder_sources")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "transcoder_sources.cpp"), os.path.join(lib_dir, "libcloudini_amd.so"),
+                    os.path.join(lib_dir, "libcloudini_hip.so"), "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib",
+                    "-o", exe], check=True)
+    r = subprocess.run([exe, str(src)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout
