@@ -20,3 +20,8 @@ with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") els
         t0 = time.perf_counter()
         st = api.transcode_directory(src, dst, resolution=0.001, compression_opt=int(CompressionOption.ZSTD), batch_messages=32)
         print(f"rep {rep}: {time.perf_counter() - t0:.3f} s, {st['points'] / (time.perf_counter() - t0) / 1e6:.0f} Mpoints/s, stage-2 threads {api.stage2_threads()}", flush=True)
+    back = os.path.join(tmp, "back")
+    for rep in range(3):
+        t0 = time.perf_counter()
+        st = api.decode_directory(dst, back, batch_messages=32)
+        print(f"decode rep {rep}: {time.perf_counter() - t0:.3f} s, {st['points'] / (time.perf_counter() - t0) / 1e6:.0f} Mpoints/s", flush=True)
