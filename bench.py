@@ -244,6 +244,15 @@ def e2e_figures(info, cloud, dev, budget_s: float):
             dleg["reference"] = {"median_ms": float(np.median(t)) * 1e3, "min_ms": float(t.min()) * 1e3, "n": reps,
                                  "threads": "1 decode thread (the reference's decoder is single-threaded)"}
         out["host_mirror_decode_" + comp.name] = dleg
+        if comp == CompressionOption.NONE:
+            # the same decode into a buffer the caller has just zero-initialised (decode(info, data, std::vector&) on an
+            # empty vector, convertCompressedCloudToPointCloud2): nothing of it travels to the GPU first
+            def mirror_decode_zeroed():
+                n = hl.cldn_amd_decode_noheader_zeroed(C.byref(ci), api._ptr(body), body.size, api._ptr(dec_out), dec_out.size)
+                assert n == cloud.size
+            zleg = timed(mirror_decode_zeroed)
+            zleg["bracket"] = "as host_mirror_decode_NONE, output declared all-zero on entry (PointcloudDecoder::decodeInto)"
+            out["host_mirror_decode_NONE_zeroed_output"] = zleg
         if comp == CompressionOption.LZ4 and hasattr(api, "set_stage2_threads"):
             # the same call with the stage-2 knob at 16 threads (the box grants 16 CPUs): from 8 threads on encode() cuts
             # the cloud into two chunk groups and compresses the first while the GPU encodes the second

@@ -54,6 +54,8 @@ def lib() -> C.CDLL:
     L.cldn_amd_decode.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64, C.c_char_p, C.c_uint64, u8p]
     L.cldn_amd_decode_noheader.restype = C.c_int64
     L.cldn_amd_decode_noheader.argtypes = [C.POINTER(_Info), u8p, C.c_uint64, u8p, C.c_uint64]
+    L.cldn_amd_decode_noheader_zeroed.restype = C.c_int64
+    L.cldn_amd_decode_noheader_zeroed.argtypes = [C.POINTER(_Info), u8p, C.c_uint64, u8p, C.c_uint64]
     L.cldn_amd_ros_compress.restype = C.c_int64
     L.cldn_amd_ros_compress.argtypes = [u8p, C.c_uint64, C.c_float, C.c_uint8, u8p, C.c_uint64]
     L.cldn_amd_ros_decompress.restype = C.c_int64

@@ -170,6 +170,7 @@ struct cldn_hip_codec {
   int stage2 = 0;
   DevBuf d_s1, d_s1_offsets, d_lz_matches, d_lz_counts, d_lz_slots, d_lz_segs, d_payload2, d_dst2;
   DevBuf d_finrec;            // k_finish look-back records (rec, rec2), cleared only when (re)allocated
+  int decode_fill = CLDN_HIP_FILL_KEEP;  // cldn_hip_codec_set_decode_fill
   DevBuf d_dec_rec;           // k_sections_cols_fast slice records, tagged with dec_epoch, cleared only when (re)allocated
   uint32_t dec_epoch = 0;
   uint32_t finish_epoch = 0;  // tag of this call's records
@@ -1216,6 +1217,13 @@ int cldn_hip_viz_preprocess(cldn_hip_codec_t* c, const void* points, int points_
   return CLDN_HIP_OK;
 }
 
+int cldn_hip_codec_set_decode_fill(cldn_hip_codec_t* c, int fill) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if (fill != CLDN_HIP_FILL_KEEP && fill != CLDN_HIP_FILL_ZERO) return fail(CLDN_HIP_ERR_ARG, "unknown decode fill %d", fill);
+  c->decode_fill = fill;
+  return CLDN_HIP_OK;
+}
+
 int cldn_hip_codec_decode_stats(cldn_hip_codec_t* c, uint32_t stats[4]) {
   if (!c || !stats) return fail(CLDN_HIP_ERR_ARG, "decode_stats: NULL argument");
   memset(stats, 0, 4 * sizeof(uint32_t));
@@ -1354,8 +1362,10 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
     if ((rc = c->d_out.ensure((size_t)std::max<uint64_t>(1, need))) != CLDN_HIP_OK) return rc;
     d_outp = (uint8_t*)c->d_out.p;
     // bytes of a point that no field covers keep the caller's content (src/field_decoder.cpp:72-76): bring it along
-    if (need && c->plan.has_padding)
-      HIP_TRY(hipMemcpyAsync(d_outp, points_out, (size_t)need, hipMemcpyHostToDevice, c->stream));
+    if (need && c->plan.has_padding) {
+      if (c->decode_fill == CLDN_HIP_FILL_ZERO) HIP_TRY(hipMemsetAsync(d_outp, 0, (size_t)need, c->stream));
+      else HIP_TRY(hipMemcpyAsync(d_outp, points_out, (size_t)need, hipMemcpyHostToDevice, c->stream));
+    }
   }
 
   DecodeLaunch L;

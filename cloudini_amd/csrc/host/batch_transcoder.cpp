@@ -492,11 +492,11 @@ void decodeGpuPhase(Batch& b, TranscodeStats* stats) {
     run.offsets[run.count] = produced;
     const uint64_t out_bytes = run.out_at[run.count];
     if (run.decoded.size() < out_bytes) run.decoded.resize(out_bytes);
-    // bytes of a point that no field covers stay what they are: zero, like the freshly resized vector the reference
-    // decodes into (src/ros_msg_utils.cpp:150-153)
-    std::memset(run.decoded.data(), 0, out_bytes);
+    // bytes of a point that no field covers read zero, like in the freshly resized vector the reference decodes into
+    // (src/ros_msg_utils.cpp:150-153): CLDN_HIP_FILL_ZERO -- the device buffer is cleared, every byte of `decoded` comes
+    // back from it (no memset of 600 MB on this thread, no upload of zeros)
     Cloudini::amd_detail::decodeStage1Batch(info0, scratch, run.offsets.data(), pts.data(), run.count, run.decoded.data(),
-                                            out_bytes);
+                                            out_bytes, true);
     if (stats) {
       stats->seconds_gpu += since(t_gpu);
       stats->gpu_batches += 1;
@@ -513,7 +513,8 @@ void decodeWrapPhase(Batch& b, TranscodeStats* stats) {
   std::vector<const uint8_t*> data_of(n, nullptr);
   for (const Run& run : b.runs)
     for (uint32_t k = 0; k < run.count; ++k) data_of[run.first + k] = run.decoded.data() + run.out_at[k];
-  for (size_t i = 0; i < n; ++i) {
+  // (one message per job on the stage-2 pool: a 2.3 MB message is a resize and a copy, 0.25 ms on one thread)
+  Cloudini::amd_detail::runOnStage2Pool(n, [&](size_t i) {
     const Parsed& p = b.parsed[i];
     std::vector<uint8_t>& msg = b.out[i];
     const size_t cloud_bytes = messageCloudBytes(p.pc.width, p.pc.height, p.pc.point_step);
@@ -532,9 +533,11 @@ void decodeWrapPhase(Batch& b, TranscodeStats* stats) {
       nanocdr::Encoder tail(p.pc.cdr_header, msg, /*append=*/true);
       tail.encode(p.pc.is_dense);
     }
-    if (stats) stats->output_bytes += msg.size();
+  });
+  if (stats) {
+    for (size_t i = 0; i < n; ++i) stats->output_bytes += b.out[i].size();
+    stats->seconds_stage2 += since(t0);
   }
-  if (stats) stats->seconds_stage2 += since(t0);
 }
 
 }  // namespace

@@ -188,6 +188,18 @@ CLDN_EXPORT int64_t cldn_amd_decode_noheader(const cldn_amd_info_t* info_in, con
   });
 }
 
+CLDN_EXPORT int64_t cldn_amd_decode_noheader_zeroed(const cldn_amd_info_t* info_in, const uint8_t* data, uint64_t size,
+                                                    uint8_t* out, uint64_t capacity) {
+  return guarded([&] {
+    const Cloudini::EncodingInfo info = toInfo(info_in);
+    const uint64_t need = (uint64_t)info.width * info.height * info.point_step;
+    if (need > capacity) throw std::runtime_error("decode buffer too small");
+    Cloudini::PointcloudDecoder decoder;
+    decoder.decodeInto(info, Cloudini::ConstBufferView(data, size), Cloudini::BufferView(out, need), true);
+    return (int64_t)need;
+  });
+}
+
 CLDN_EXPORT int64_t cldn_amd_ros_compress(const uint8_t* dds, uint64_t size, float resolution, uint8_t compression_opt,
                                           uint8_t* out, uint64_t capacity) {
   return guarded([&] {

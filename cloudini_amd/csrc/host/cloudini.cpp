@@ -872,6 +872,10 @@ PointcloudDecoder::~PointcloudDecoder() {
 }
 
 void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compressed_data, BufferView output) {
+  decodeInto(info, compressed_data, output, false);
+}
+
+void PointcloudDecoder::decodeInto(const EncodingInfo& info, ConstBufferView compressed_data, BufferView output, bool output_is_zero) {
   if (compressed_data.size() >= size_t(kMagicHeaderLength) &&
       std::memcmp(compressed_data.data(), kMagicHeader, kMagicHeaderLength) == 0)
     throw std::runtime_error("compressed_data contains the header. You should use DecodeHeader first");
@@ -982,9 +986,11 @@ void PointcloudDecoder::decode(const EncodingInfo& info, ConstBufferView compres
   if (points == 0) return;
 
   const uint64_t offsets[2] = {0, s1_size};
-  if (cldn_hip_decode_stage1(impl_->codec, s1, CLDN_HIP_HOST, offsets, &points, 1, output.data(), out_bytes,
-                             CLDN_HIP_HOST) != CLDN_HIP_OK)
-    throw std::runtime_error(cldn_hip_last_error());
+  // (the codec comes from a pool: the fill mode is set for every call)
+  cldn_hip_codec_set_decode_fill(impl_->codec, output_is_zero ? CLDN_HIP_FILL_ZERO : CLDN_HIP_FILL_KEEP);
+  const int rc = cldn_hip_decode_stage1(impl_->codec, s1, CLDN_HIP_HOST, offsets, &points, 1, output.data(), out_bytes, CLDN_HIP_HOST);
+  cldn_hip_codec_set_decode_fill(impl_->codec, CLDN_HIP_FILL_KEEP);
+  if (rc != CLDN_HIP_OK) throw std::runtime_error(cldn_hip_last_error());
 }
 
 namespace amd_detail {
@@ -1085,12 +1091,14 @@ size_t stage1ChunkBound(const EncodingInfo& info) {
 }
 
 void decodeStage1Batch(const EncodingInfo& info, const uint8_t* streams, const uint64_t* offsets, const uint64_t* cloud_points,
-                       uint32_t n_clouds, uint8_t* out, uint64_t out_capacity) {
+                       uint32_t n_clouds, uint8_t* out, uint64_t out_capacity, bool out_is_zero) {
   if (info.point_step == 0) throw std::runtime_error("point_step cannot be 0");
   PlanHandle plan(info);
   cldn_hip_codec_t* codec = pool().acquire(info, plan);
+  cldn_hip_codec_set_decode_fill(codec, out_is_zero ? CLDN_HIP_FILL_ZERO : CLDN_HIP_FILL_KEEP);
   const int rc = cldn_hip_decode_stage1(codec, streams, CLDN_HIP_HOST, offsets, cloud_points, n_clouds, out, out_capacity,
                                         CLDN_HIP_HOST);
+  cldn_hip_codec_set_decode_fill(codec, CLDN_HIP_FILL_KEEP);
   const std::string err = rc != CLDN_HIP_OK ? cldn_hip_last_error() : "";
   pool().release(info, codec);
   if (rc != CLDN_HIP_OK) throw std::runtime_error(err);

@@ -44,9 +44,11 @@ uint32_t decompressChunkTo(Cloudini::CompressionOption opt, const uint8_t* src, 
 size_t stage1ChunkBound(const Cloudini::EncodingInfo& info);
 // One batched stage-1 decode: n clouds of the same schema, framed stage-1 streams back to back in `streams` (offsets has
 // n + 1 entries), decoded points back to back in `out` (cloud k: cloud_points[k] * point_step bytes). Bytes of a point that
-// no field covers keep the content of `out`. Throws std::runtime_error.
+// no field covers keep the content of `out`, or read 0 with out_is_zero (the caller does not need `out`'s content:
+// CLDN_HIP_FILL_ZERO). Throws std::runtime_error.
 void decodeStage1Batch(const Cloudini::EncodingInfo& info, const uint8_t* streams, const uint64_t* offsets,
-                       const uint64_t* cloud_points, uint32_t n_clouds, uint8_t* out, uint64_t out_capacity);
+                       const uint64_t* cloud_points, uint32_t n_clouds, uint8_t* out, uint64_t out_capacity,
+                       bool out_is_zero = false);
 // fn(i) for i in [0, n) on the bounded stage-2 pool (the caller takes part)
 void runOnStage2Pool(size_t n, const std::function<void(size_t)>& fn);
 

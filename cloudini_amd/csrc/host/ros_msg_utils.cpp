@@ -88,7 +88,8 @@ void convertCompressedCloudToPointCloud2(const RosPointCloud2& pc, std::vector<u
   Cloudini::ConstBufferView stream = pc.data;
   const Cloudini::EncodingInfo info = Cloudini::DecodeHeader(stream);
   Cloudini::PointcloudDecoder decoder;
-  decoder.decode(info, stream, Cloudini::BufferView(out_msg.data() + at, cloud_bytes));
+  // (the bytes just added by resize() are zero: nothing of them has to go to the GPU first)
+  decoder.decodeInto(info, stream, Cloudini::BufferView(out_msg.data() + at, cloud_bytes), true);
   enc.encode(pc.is_dense);
 }
 

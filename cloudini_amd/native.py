@@ -104,6 +104,8 @@ def lib() -> C.CDLL:
     L.cldn_hip_viz_preprocess.restype = C.c_int
     L.cldn_hip_viz_preprocess.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, vp, C.c_uint64,
                                           C.c_int, u64p]
+    L.cldn_hip_codec_set_decode_fill.argtypes = [vp, C.c_int]
+    L.cldn_hip_codec_set_decode_fill.restype = C.c_int
     L.cldn_hip_codec_decode_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.cldn_hip_codec_decode_stats.restype = C.c_int
     L.cldn_hip_codec_force_modes.argtypes = [vp, C.POINTER(C.c_uint8), C.c_uint32]
@@ -227,6 +229,10 @@ class Codec:
         _check(lib().cldn_hip_viz_preprocess(self._h, C.c_void_p(points_ptr), DEVICE, n_points, point_step, xyz_offset,
                                              resolution, C.c_void_p(out_ptr), out_capacity, DEVICE, C.byref(kept)))
         return int(kept.value)
+
+    def set_decode_fill(self, zero: bool):
+        """cldn_hip_codec_set_decode_fill: True = bytes no field covers may be written as 0 (no round trip of a host buffer)."""
+        _check(lib().cldn_hip_codec_set_decode_fill(self._h, 1 if zero else 0))
 
     def decode_stats(self):
         """Chunks of the last decode call per kernel: (fast regular, fast sections, serial chunks, serial sections)."""

@@ -48,6 +48,10 @@ int64_t cldn_amd_decode(const uint8_t* stream, uint64_t size, uint8_t* out, uint
 /* PointcloudDecoder::decode(info, data (no header), out) */
 int64_t cldn_amd_decode_noheader(const cldn_amd_info_t* info, const uint8_t* data, uint64_t size, uint8_t* out,
                                  uint64_t capacity);
+/* the same for an output buffer that is all zeros on entry (PointcloudDecoder::decodeInto(..., true): what
+ * decode(info, data, std::vector&) does for a vector that arrives empty) */
+int64_t cldn_amd_decode_noheader_zeroed(const cldn_amd_info_t* info, const uint8_t* data, uint64_t size, uint8_t* out,
+                                        uint64_t capacity);
 /* getDeserializedPointCloudMessage + applyResolutionProfile({}, fields, resolution) + toEncodingInfo (compression
  * as given) + convertPointCloud2ToCompressedCloud */
 int64_t cldn_amd_ros_compress(const uint8_t* dds, uint64_t size, float resolution, uint8_t compression_opt,

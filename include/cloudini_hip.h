@@ -237,6 +237,15 @@ int cldn_hip_viz_preprocess(cldn_hip_codec_t* codec, const void* points, int poi
                             uint32_t point_step, uint32_t xyz_offset, float resolution, void* out,
                             uint64_t out_capacity, int out_loc, uint64_t* kept_points);
 
+/* What a decode call may do to the bytes of a point that no field covers. CLDN_HIP_FILL_KEEP (default): they keep the
+ * content of points_out (src/field_decoder.cpp:72-76 writes fields only) -- for a HOST buffer of a layout with such bytes
+ * that means bringing the buffer to the device first. CLDN_HIP_FILL_ZERO: the caller hands over a buffer whose content
+ * it does not need (a freshly resized vector, like PointcloudDecoder::decode(info, data, std::vector&) of the reference
+ * on an empty vector): those bytes read 0 afterwards in a HOST buffer, and are 0 or untouched in a DEVICE buffer. */
+#define CLDN_HIP_FILL_KEEP 0
+#define CLDN_HIP_FILL_ZERO 1
+int cldn_hip_codec_set_decode_fill(cldn_hip_codec_t* codec, int fill);
+
 /* Which kernels the last cldn_hip_decode_stage1 call used, in chunks (synchronises):
  *   stats[0] regular stream by the parallel decoder      stats[1] V5 sections by the parallel decoder
  *   stats[2] whole chunks by the serial decoder          stats[3] only the sections by the serial decoder */

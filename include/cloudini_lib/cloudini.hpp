@@ -105,9 +105,17 @@ class PointcloudDecoder {
   // bytes. Bytes of a point that no field covers are left untouched.
   void decode(const EncodingInfo& info, ConstBufferView compressed_data, BufferView output);
   void decode(const EncodingInfo& info, ConstBufferView compressed_data, std::vector<uint8_t>& output) {
+    // a vector that arrives empty is all zeros after the resize: nothing of it has to travel to the GPU for the bytes
+    // of a point that no field covers (they read 0 afterwards, exactly as in the reference)
+    const bool fresh = output.empty();
     output.resize(static_cast<size_t>(info.width) * info.height * info.point_step);
-    decode(info, compressed_data, BufferView(output.data(), output.size()));
+    decodeInto(info, compressed_data, BufferView(output.data(), output.size()), fresh);
   }
+
+  // Not in the reference: decode() for a caller that knows every byte of `output` is 0 on entry (a buffer it has just
+  // value-initialised). Same result as decode(); a host buffer of a layout with uncovered bytes then needs no trip to
+  // the GPU before the decode.
+  void decodeInto(const EncodingInfo& info, ConstBufferView compressed_data, BufferView output, bool output_is_zero);
 
  private:
   struct Impl;

@@ -312,6 +312,25 @@ def test_section_guess_with_a_false_hit_in_the_token_stream(oracle, field):
     assert stats == (n_chunks, n_chunks, 0, 0)
 
 
+def test_decode_fill_zero_for_fresh_buffers(oracle):
+    """cldn_hip_codec_set_decode_fill(ZERO): the caller's buffer content is not needed, the bytes of a point that no field
+    covers read 0 afterwards (what the reference leaves in a freshly resized vector); KEEP (default) preserves them."""
+    from cloudini_amd import native
+    for info, data in (synth.lidar_xyzi(50000, seed=3), synth.depthcam_xyzrgba(320, 200, seed=4), synth.velodyne_xyzir(40000, seed=5)):
+        n = len(data) // info.point_step
+        stream = oracle.encode_stage1(info, data)
+        codec = native.Codec(native.Plan(info))
+        codec.set_decode_fill(True)
+        out = np.full(data.size, 0x5A, dtype=np.uint8)
+        got = codec.decode_host([stream], [n], out=out)[0]
+        assert np.array_equal(got, oracle.decode_stage1(info, stream, n, fill=0))
+        codec.set_decode_fill(False)
+        out = np.full(data.size, 0x5A, dtype=np.uint8)
+        got = codec.decode_host([stream], [n], out=out)[0]
+        assert np.array_equal(got, oracle.decode_stage1(info, stream, n, fill=0x5A))
+        codec.close()
+
+
 def test_section_guess_lookalikes_in_lidar_streams(oracle):
     """Token streams of ordinary lidar clouds hold places that read as the header of a Palette section of the very size
     that would put it there (velodyne generator, seeds 45 and 47: 695 entries in chunk 1; XYZI seed 42: 723 and 929 next
