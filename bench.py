@@ -399,7 +399,13 @@ def config_figures(dev, steps: int):
             dec_ms = timed(lambda: codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size, d_sizes.data_ptr()))
             codec.status()
             dec_stats = codec.decode_stats()
+            codec.set_decode_fill(True)
+            dec_zero_ms = timed(lambda: codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size, d_sizes.data_ptr()))
+            codec.set_decode_fill(False)
+            codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size, d_sizes.data_ptr())  # (the checked bytes: default mode)
+            codec.status()
             entry = {"workload": WORKLOAD_DESC[name].format(clouds=clouds, points=n),
+                     "decode_fill_zero_ms": dec_zero_ms,
                      "decode_chunks_parallel_regular/parallel_sections/serial/serial_sections": list(dec_stats),
                      "encode_ms": enc_ms, "encode_Mpoints_per_s": clouds * n / (enc_ms * 1e-3) / 1e6,
                      "decode_ms": dec_ms, "decode_Mpoints_per_s": clouds * n / (dec_ms * 1e-3) / 1e6,
@@ -637,6 +643,19 @@ def main():
             dec_blocks.append((time.perf_counter() - t1) / dec_steps)
         codec.status()
         dec_stats = codec.decode_stats()
+        # the same decode for a caller that does not need the buffer's content (CLDN_HIP_FILL_ZERO: a freshly created
+        # output, like the reference's decode into an empty vector): whole-point stores for the padded point
+        zero_blocks = []
+        codec.set_decode_fill(True)
+        for _rep in range(max(1, min(3, args.repeats))):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(dec_steps):
+                codec.decode_device(d_out.data_ptr(), so, cloud_points, d_dec.data_ptr(), host.size, d_chunk_sizes.data_ptr())
+            torch.cuda.synchronize(dev)
+            zero_blocks.append((time.perf_counter() - t1) / dec_steps)
+        codec.set_decode_fill(False)
+        codec.status()
         del d_dec
         dec_ms = float(np.median(dec_blocks)) * 1e3
         decode = {"value": points_local / (dec_ms * 1e-3) / 1e6,
@@ -644,6 +663,8 @@ def main():
                   "ms_per_step": dec_ms, "ms_per_step_min": float(min(dec_blocks)) * 1e3,
                   "ms_per_step_max": float(max(dec_blocks)) * 1e3,
                   "HBM_GBps": (total_out + points_local * step) / (dec_ms * 1e-3) / 1e9,
+                  "fill_zero_ms_per_step": float(np.median(zero_blocks)) * 1e3,
+                  "fill_zero_Mpoints_per_s": points_local / float(np.median(zero_blocks)) / 1e6,
                   "chunks_parallel_regular/parallel_sections/serial/serial_sections": list(dec_stats)}
     # extra (not `value`): stage 1 WITHOUT the framing -- cldn_hip_encode_stage1_chunks leaves every chunk's payload as one
     # run of its slot (the reference's own stage-1 / stage-2 boundary is a buffer per chunk, src/cloudini.cpp:590-614);

@@ -1408,6 +1408,7 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
   for (uint32_t a = 0; a < 2u; ++a)
     L.cols[a] = (dec_cols && a < plan.n_adaptive && plan.adaptive[a].bpv <= 4u) ? (uint8_t*)c->d_dec_cols[a].p : nullptr;
   L.out = d_outp;
+  L.fill_zero = c->decode_fill == CLDN_HIP_FILL_ZERO ? 1u : 0u;
   L.status = (uint32_t*)c->d_status.p;
   if ((rc = stage1_launch_decode(L)) != CLDN_HIP_OK) return rc;
 

@@ -673,7 +673,7 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
                                                               uint32_t uses_v5, uint32_t* __restrict__ status,
                                                               const uint8_t* __restrict__ col0, const uint8_t* __restrict__ col1,
                                                               const uint32_t* __restrict__ reg_end_pre,
-                                                              const uint8_t* __restrict__ sec_cols) {
+                                                              const uint8_t* __restrict__ sec_cols, uint32_t fill_zero) {
   using L = FpLds<NOPS, NF>;
   constexpr uint32_t NFA = NF ? NF : 1;  // array extents (NF == 0: nothing is ever folded)
   constexpr int T = kFpThreads;
@@ -1141,7 +1141,34 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
       }
     };
     const bool one_u16 = NOPS == 3 && contig && n_fold == 1u && fs_bpv[0] == 2u && ((fs_off[0] | step) & 1u) == 0u;  // XYZ + one 16-bit field
-    if (contig && n_fold == 0u) {
+    // fill_zero (CLDN_HIP_FILL_ZERO: the bytes no field covers may be written as 0): the two common padded layouts leave
+    // as whole 16-byte stores -- XYZ f32 + a 16-bit field in a 16-byte point, XYZ f32 + a 32-bit field at 16 in a
+    // 32-byte point
+    const bool full16 = fill_zero != 0u && one_u16 && step == 16u && foff[0] == 0u && fs_off[0] == 12u && ((uintptr_t)base & 15u) == 0u;
+    const bool full32 = fill_zero != 0u && NOPS == 3 && contig && n_fold == 1u && fs_bpv[0] == 4u && step == 32u && foff[0] == 0u &&
+                        fs_off[0] == 16u && ((uintptr_t)base & 15u) == 0u;
+    if (full16) {
+#pragma unroll
+      for (uint32_t r = 0; r < kFpPPT; ++r) {
+        const uint32_t q = r * (uint32_t)T + tid;
+        if (q < npts) {
+          float4 sv = *reinterpret_cast<const float4*>(stage + q * 4u);  // x, y, z, field
+          sv.w = __uint_as_float(__float_as_uint(sv.w) & 0xffffu);
+          *reinterpret_cast<float4*>(base + (size_t)(pts_done + q) * 16u) = sv;
+        }
+      }
+    } else if (full32) {
+#pragma unroll
+      for (uint32_t r = 0; r < kFpPPT; ++r) {
+        const uint32_t q = r * (uint32_t)T + tid;
+        if (q < npts) {
+          const float4 sv = *reinterpret_cast<const float4*>(stage + q * 4u);  // x, y, z, field
+          float4* pt = reinterpret_cast<float4*>(base + (size_t)(pts_done + q) * 32u);
+          pt[0] = make_float4(sv.x, sv.y, sv.z, 0.0f);
+          pt[1] = make_float4(sv.w, 0.0f, 0.0f, 0.0f);
+        }
+      }
+    } else if (contig && n_fold == 0u) {
 #pragma unroll
       for (uint32_t r = 0; r < kFpPPT; ++r) {
         const uint32_t q = r * (uint32_t)T + tid;

@@ -2455,10 +2455,11 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       const uint8_t* c0 = cols ? L.cols[0] : nullptr;
       const uint8_t* c1 = cols ? L.cols[1] : nullptr;
       const uint8_t* sc = cols ? L.sec_cols : nullptr;
+      const uint32_t fill_zero = L.fill_zero ? 1u : 0u;
 #define LAUNCH_POINTS(NOPS_, NF_)                                                                                         \
   hipLaunchKernelGGL((k_decode_points<NOPS_, NF_>), dim3(L.n_chunks), dim3(kFpThreads), (FpLds<NOPS_, NF_>::kTotal), L.stream, \
                      P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5,  \
-                     L.status, c0, c1, L.reg_end_pre, sc)
+                     L.status, c0, c1, L.reg_end_pre, sc, fill_zero)
       if (P.n_ops == 3u) {
         if (nf == 0u) LAUNCH_POINTS(3, 0);
         else if (nf == 1u) LAUNCH_POINTS(3, 1);

@@ -241,7 +241,10 @@ int cldn_hip_viz_preprocess(cldn_hip_codec_t* codec, const void* points, int poi
  * content of points_out (src/field_decoder.cpp:72-76 writes fields only) -- for a HOST buffer of a layout with such bytes
  * that means bringing the buffer to the device first. CLDN_HIP_FILL_ZERO: the caller hands over a buffer whose content
  * it does not need (a freshly resized vector, like PointcloudDecoder::decode(info, data, std::vector&) of the reference
- * on an empty vector): those bytes read 0 afterwards in a HOST buffer, and are 0 or untouched in a DEVICE buffer. */
+ * on an empty vector): those bytes read 0 afterwards in a HOST buffer, and are 0 or untouched in a DEVICE buffer. Besides
+ * the saved upload, the two common padded layouts (XYZ f32 + a 16-bit field in 16-byte points, XYZ f32 + a 32-bit field at
+ * offset 16 in 32-byte points) then leave the decoder as whole 16-byte stores: 15-18 % faster than stores around the
+ * padding (32 x 1 M XYZI: 0.33 -> 0.28 ms). */
 #define CLDN_HIP_FILL_KEEP 0
 #define CLDN_HIP_FILL_ZERO 1
 int cldn_hip_codec_set_decode_fill(cldn_hip_codec_t* codec, int fill);

@@ -331,6 +331,32 @@ def test_decode_fill_zero_for_fresh_buffers(oracle):
         codec.close()
 
 
+def test_decode_fill_zero_device_resident(oracle):
+    """Device buffers with CLDN_HIP_FILL_ZERO: the two padded layouts the decoder writes as whole 16-byte stores come
+    out with zero padding whatever the buffer held; a layout without such stores keeps the buffer's bytes."""
+    import torch
+    from cloudini_amd import native
+    dev = torch.device("cuda", 0)
+    xyz20 = cases.make_info([("x", 0, cases.F.FLOAT32, 0.001), ("y", 4, cases.F.FLOAT32, 0.001), ("z", 8, cases.F.FLOAT32, 0.001)],
+                            20, 5000)
+    rs = np.random.RandomState(3)
+    xyz20_data = cases.pack(xyz20, {k: rs.randn(5000).astype(np.float32) * 10 for k in "xyz"}, 5000)
+    for (info, data), zeroed in ((synth.lidar_xyzi(70000, seed=8), True), (synth.depthcam_xyzrgba(320, 200, seed=9), True),
+                                 ((xyz20, xyz20_data), False)):
+        n = len(data) // info.point_step
+        stream = oracle.encode_stage1(info, data)
+        codec = native.Codec(native.Plan(info), device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
+        codec.set_decode_fill(True)
+        d_stream = torch.from_numpy(np.ascontiguousarray(stream)).to(dev)
+        d_out = torch.full((data.size,), 0x5A, dtype=torch.uint8, device=dev)
+        codec.decode_device(d_stream.data_ptr(), np.array([0, stream.size], dtype=np.uint64), np.array([n], dtype=np.uint64),
+                            d_out.data_ptr(), data.size, 0)
+        codec.status()
+        got = d_out.cpu().numpy()
+        assert np.array_equal(got, oracle.decode_stage1(info, stream, n, fill=0 if zeroed else 0x5A))
+        codec.close()
+
+
 def test_section_guess_lookalikes_in_lidar_streams(oracle):
     """Token streams of ordinary lidar clouds hold places that read as the header of a Palette section of the very size
     that would put it there (velodyne generator, seeds 45 and 47: 695 entries in chunk 1; XYZI seed 42: 723 and 929 next
