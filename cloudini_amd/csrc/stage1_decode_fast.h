@@ -213,6 +213,53 @@ __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan,
   __syncthreads();
   if (plan.n_adaptive == 1u) {
     if (pal_guess_from_end<NW * 64>(src, src_size, n, plan.adaptive[0].bpv, pal_sh) != 0xffffffffu) return;  // uniform
+    // A lone DeltaRle section (ring / line index of a lidar) is also found from the end: [3][u32 runs][runs x (varint
+    // difference, varint length)] -- every position p of the payload's last bytes with src[p] == 3, a run count r in
+    // 1..n behind it, a token end in front of it and exactly 2 r token ends between p + 5 and the payload's end is a
+    // candidate; one candidate = the section (a regular token stream does not hold a 3 followed by a count whose upper
+    // bytes are 0: zeros are NaN markers). Spares the count over the whole payload (C4: 274 MB per batch); like the
+    // Palette guess it is verified by where k_decode_points' tiles end.
+    constexpr uint32_t T = NW * 64u, W = T * 16u;
+    __shared__ __attribute__((aligned(16))) uint32_t win[W / 4u + 4u];
+    __shared__ uint32_t end_mask[T], end_pre[T], scan_tmp[32], cand[2];
+    const uint32_t wbase = src_size > W ? src_size - W : 0u;  // payload offset of the window
+    uint32_t b[4];
+    fp_load16u(src, src_size, wbase + tid * 16u, b);           // (bytes behind the payload read 0xff: no ends)
+    *reinterpret_cast<uint4*>(win + tid * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
+    if (tid < 4u) win[W / 4u + tid] = 0xffffffffu;
+    if (tid == 0u) cand[0] = 0xffffffffu, cand[1] = 0u;
+    const uint32_t ends = fp_ends16(b);
+    uint32_t total_ends;
+    const uint32_t pre = block_exclusive_scan<(int)T>((uint32_t)__builtin_popcount(ends), scan_tmp, &total_ends);  // barrier inside
+    end_mask[tid] = ends;
+    end_pre[tid] = pre;
+    __syncthreads();
+    const bool closed = src_size != 0u && (src[src_size - 1u] & 0x80u) == 0u;  // the payload ends with a token end
+    if (closed) {
+      const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
+      for (uint32_t j = 0; j < 16u; ++j) {
+        const uint32_t x = tid * 16u + j;  // window offset
+        const uint32_t pos = wbase + x;
+        if (pos + 5u > src_size || ((b[j >> 2] >> (8u * (j & 3u))) & 0xffu) != 3u) continue;
+        const bool end_in_front = pos == 0u || (x != 0u ? (wb[x - 1u] & 0x80u) == 0u : (src[pos - 1u] & 0x80u) == 0u);
+        if (!end_in_front) continue;
+        const uint32_t r = (uint32_t)wb[x + 1u] | ((uint32_t)wb[x + 2u] << 8) | ((uint32_t)wb[x + 3u] << 16) | ((uint32_t)wb[x + 4u] << 24);
+        if (r == 0u || r > n) continue;
+        const uint32_t y = x + 5u;  // ends in [y, end of the window) -- y may be the window's end
+        const uint32_t before_y = y >= W ? total_ends : end_pre[y >> 4] + (uint32_t)__builtin_popcount(end_mask[y >> 4] & ((1u << (y & 15u)) - 1u));
+        if (total_ends - before_y != 2u * r) continue;
+        atomicMin(&cand[0], pos);
+        atomicAdd(&cand[1], 1u);
+      }
+    }
+    __syncthreads();
+    if (cand[1] == 1u) {  // uniform
+      if (tid == 0) {
+        reg_end_pre[c] = cand[0];
+        slices_done[c] = 3u << 24;
+      }
+      return;
+    }
   }
   const uint32_t part = (((src_size + 15u) / 16u + (NW - 1u)) / NW) * 16u;  // bytes per wave, multiple of 16
   const uint32_t w0 = min(src_size, wave * part), w1 = min(src_size, w0 + part);
