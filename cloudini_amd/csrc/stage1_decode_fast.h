@@ -896,6 +896,9 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
   bool contig = ((step | plan.ops[0].offset) & 3u) == 0u;
 #pragma unroll
   for (int o = 1; o < NOPS; ++o) contig = contig && plan.ops[o].offset == plan.ops[0].offset + 4u * (uint32_t)o;
+  bool packed = true;  // the floats back to back at any alignment, all of them stored
+#pragma unroll
+  for (int o = 0; o < NOPS; ++o) packed = packed && plan.ops[o].offset != 0xffffffffu && plan.ops[o].offset == plan.ops[0].offset + 4u * (uint32_t)o;
   float res[NOPS];
   uint32_t foff[NOPS];
 #pragma unroll
@@ -1242,18 +1245,37 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
           uint8_t* pt = base + (size_t)(pts_done + q) * step;
           if (contig) {
             store_floats_contig(pt, q);
+          } else if (packed) {  // the floats lie back to back at an odd address (18-byte points): ONE unaligned store
+            if (NOPS == 3) {    // (gfx950 takes the misalignment: a memcpy of 12 / 16 bytes is one global_store_dwordx3 / x4)
+              FloatVec<3> v;
+              v.v[0] = stage[q * SP]; v.v[1] = stage[q * SP + 1u]; v.v[2] = stage[q * SP + 2u];
+              __builtin_memcpy(pt + foff[0], &v, 12);
+            } else {
+              FloatVec<4> v;
+#pragma unroll
+              for (int o = 0; o < 4; ++o) v.v[o] = stage[q * SP + (uint32_t)o];
+              __builtin_memcpy(pt + foff[0], &v, 16);
+            }
           } else {
 #pragma unroll
             for (int o = 0; o < NOPS; ++o)
-              if (foff[o] != 0xffffffffu) st_raw(pt + foff[o], __float_as_uint(stage[q * SP + (uint32_t)o]), 4);
+              if (foff[o] != 0xffffffffu) {
+                const float f = stage[q * SP + (uint32_t)o];
+                __builtin_memcpy(pt + foff[o], &f, 4);
+              }
           }
 #pragma unroll
           for (uint32_t a = 0; a < NFA; ++a) {
             if (a >= n_fold) break;  // uniform
             const uint32_t v = __float_as_uint(stage[q * SP + (uint32_t)NOPS + a]);
-            if (fs_bpv[a] == 2u && ((fs_off[a] | step) & 1u) == 0u) *reinterpret_cast<uint16_t*>(pt + fs_off[a]) = (uint16_t)v;
-            else if (fs_bpv[a] == 4u && ((fs_off[a] | step) & 3u) == 0u) *reinterpret_cast<uint32_t*>(pt + fs_off[a]) = v;
-            else st_raw(pt + fs_off[a], v, fs_bpv[a]);
+            if (fs_bpv[a] == 2u) {
+              const uint16_t h = (uint16_t)v;
+              __builtin_memcpy(pt + fs_off[a], &h, 2);
+            } else if (fs_bpv[a] == 4u) {
+              __builtin_memcpy(pt + fs_off[a], &v, 4);
+            } else {
+              st_raw(pt + fs_off[a], v, fs_bpv[a]);
+            }
           }
         }
       }
