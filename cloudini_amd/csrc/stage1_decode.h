@@ -187,8 +187,20 @@ __device__ __forceinline__ uint64_t rd_raw(Rd& r, uint32_t nbytes) {
   return v;
 }
 
+// the low nbytes of v at any address: the field sizes are single stores (gfx950 takes unaligned stores of 2, 4 and 8
+// bytes: a memcpy compiles to one global_store_short / dword / dwordx2), anything else goes byte by byte
 __device__ __forceinline__ void st_raw(uint8_t* dst, uint64_t v, uint32_t nbytes) {
-  for (uint32_t b = 0; b < nbytes; ++b) dst[b] = (uint8_t)(v >> (8u * b));
+  if (nbytes == 4u) {
+    const uint32_t w = (uint32_t)v;
+    __builtin_memcpy(dst, &w, 4);
+  } else if (nbytes == 2u) {
+    const uint16_t h = (uint16_t)v;
+    __builtin_memcpy(dst, &h, 2);
+  } else if (nbytes == 8u) {
+    __builtin_memcpy(dst, &v, 8);
+  } else {
+    for (uint32_t b = 0; b < nbytes; ++b) dst[b] = (uint8_t)(v >> (8u * b));
+  }
 }
 
 // decodeV5AdaptiveIntSection, src/v5_codec.cpp:764-879
