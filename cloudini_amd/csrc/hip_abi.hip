@@ -518,13 +518,14 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec, &c->d_dec_rec, &c->d_s1, &c->d_s1_offsets,
                     &c->d_lz_matches, &c->d_lz_counts, &c->d_lz_slots, &c->d_lz_segs, &c->d_payload2, &c->d_dst2,
                     &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_pre_ptrs, &c->d_dec_cols[0], &c->d_dec_cols[1],
-                    &c->d_pre[0], &c->d_pre[1], &c->d_pre[2], &c->d_pre[3], &c->d_viz_keys, &c->d_viz_first,
+                    &c->d_viz_keys, &c->d_viz_first,
                     &c->d_viz_slot, &c->d_viz_blocks, &c->d_viz_total, &c->d_pieces};
   for (DevBuf* b : bufs) b->release();
   for (int a = 0; a < kMaxAdaptive; ++a) {
     c->d_cols[a].release();
     c->d_ranks[a].release();
   }
+  for (int g = 0; g < kMaxGorilla; ++g) c->d_pre[g].release();
   c->h_stage.release();
   for (int k = 0; k < cldn_hip_codec::kDecStageRing; ++k) {
     c->h_dec_stage[k].release();
