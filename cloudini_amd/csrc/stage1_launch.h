@@ -126,7 +126,7 @@ int stage1_launch_frame(const FrameLaunch& F);
 
 // ---- stage 2 on the device: LZ4 block per chunk (lz4_kernels.hip; parameters shared with oracle/lz4_model.c) ----
 constexpr uint32_t kLzSubBytes = 8192;    // a wave parses this much of a payload with its own hash table
-constexpr uint32_t kLzHashBits = 12;
+constexpr uint32_t kLzHashBits = 11;
 constexpr uint32_t kLzMaxMatches = 1024;  // per sub-range (the rest of it leaves as literals)
 struct LzMatch {
   uint32_t pos;  // in the chunk's payload

@@ -174,7 +174,7 @@ class Oracle:
             raise OracleError(f"orc_decode_stage1 failed: {r}")
         return out
 
-    def lz4_model(self, payload, sub_bytes: int = 8192, hash_bits: int = 12, max_matches: int = 1024) -> np.ndarray:
+    def lz4_model(self, payload, sub_bytes: int = 8192, hash_bits: int = 11, max_matches: int = 1024) -> np.ndarray:
         """Serial model of the device-side LZ4 block compressor (oracle/lz4_model.c): the block for `payload`."""
         a = _as_u8(payload)
         self.lib.orc_lz4_bound.restype = C.c_uint32
