@@ -9,7 +9,7 @@
  *
  * The device algorithm is deterministic, and this file restates it serially so that the GPU tests can ask for
  * byte equality (and the CPU tests for validity against the system's liblz4):
- *   - the payload is cut into sub-ranges of `sub_bytes` (8192 on the device, 4096-entry table, 1024 matches); a sub-range is parsed by one wave with its own hash table
+ *   - the payload is cut into sub-ranges of `sub_bytes` (8192 on the device, 2048-entry table, 1024 matches); a sub-range is parsed by one wave with its own hash table
  *     (2^hash_bits entries, position inside the sub-range + 1), so matches never leave their sub-range;
  *   - the wave looks at 64 consecutive positions per step: every lane hashes the 4 bytes at its position, checks the
  *     table's candidate (the table as it was before the step) and, on a hit, extends its match as far as it goes (up to

@@ -39,7 +39,7 @@ def _payload_kinds(rs, n):
 def test_model_blocks_are_valid_lz4(oracle, n):
     rs = np.random.RandomState(n)
     for kind, payload in _payload_kinds(rs, n):
-        for sub, hb, mm in ((8192, 12, 1024), (16384, 12, 2048), (64, 4, 3), (100, 6, 1 << 20), (8192, 12, 5)):
+        for sub, hb, mm in ((8192, 11, 1024), (8192, 12, 1024), (16384, 12, 2048), (64, 4, 3), (100, 6, 1 << 20), (8192, 12, 5)):
             block = oracle.lz4_model(payload, sub, hb, mm)
             assert _lz4_decompress(block, n) == payload, (kind, sub, hb, mm)
             assert block.size <= n + n // 255 + 16
