@@ -452,7 +452,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=50)  # (a step is 0.3 ms: 3 steps left the first timed block 5 % behind the others)
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps (the first one is `value`)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOAD_DESC))
     ap.add_argument("--shard", default="clouds", choices=("clouds", "chunks"))
