@@ -463,7 +463,8 @@ __global__ __launch_bounds__(64) void k_decode_general(const DevPlan plan, const
 //   dv_tokens_tile    one tile = 8 bytes per thread. End-of-token flags (MSB clear; the NaN marker 0x00 included) ->
 //                     one block scan gives every thread the index of its first token; the tokens ending inside a
 //                     thread's 8 bytes are consecutive, and the thread rebuilds each from the 8-byte window that ends
-//                     at the token's last byte (tokens of more than 7 bytes flag the chunk for the serial decoder).
+//                     at the token's last byte (tokens of more than 7 bytes flag the chunk for the serial decoder; the
+//                     64-bit instantiation takes up to 10 from the history bytes: a chunk's first epoch stamp).
 //   dv_stream         regular stream / DeltaVarint section: token values staged in LDS in token order; every thread
 //                     then takes a run of whole points: local sums per op with NaN resets -> segmented block scan ->
 //                     second walk that adds the incoming value, converts and stores (FieldDecoderFloatN_Lossy::decode,
@@ -489,7 +490,7 @@ constexpr uint32_t kDvTileBytes = kDvThreads * 8u;
 // store(kl, x, end_off): kl = index behind the `left` waiting tokens, x = the token's 7-bit groups joined (< 2^49),
 // end_off = payload offset behind the token. Tokens with a global index >= `limit` are left alone. Returns the
 // number of tokens ending in the tile (block-uniform). Contains barriers.
-template <typename Store>
+template <bool LONG_TOKENS = false, typename Store>
 __device__ __forceinline__ uint32_t dv_tokens_tile(const uint8_t* __restrict__ src, uint32_t src_size, uint32_t pos,
                                                    uint32_t* tileb, uint32_t* misc, uint32_t left, uint32_t seen,
                                                    uint32_t limit, Store store) {
@@ -533,15 +534,34 @@ __device__ __forceinline__ uint32_t dv_tokens_tile(const uint8_t* __restrict__ s
     const uint32_t c_lo = lo & 0x80808080u, c_hi = hi & 0x00808080u;
     const uint32_t cm = (((c_lo >> 7) * 0x00204081u) >> 21 & 0xfu) | ((((c_hi >> 7) * 0x00204081u) >> 21 & 0x7u) << 4);
     const uint32_t lencont = (uint32_t)__builtin_clz(~(cm << 25));  // leading ones of the 7-bit mask
-    if (lencont >= 7u) {
+    if (lencont >= 7u && !LONG_TOKENS) {
       misc[0] = 1u;  // token of 8 or more bytes
       continue;
     }
-    uint64_t x = ((((uint64_t)hi) << 32) | lo) >> (8u * (7u - lencont));
+    uint64_t x = ((((uint64_t)hi) << 32) | lo) >> (8u * (7u - min(lencont, 7u)));
     x &= 0x7f7f7f7f7f7f7f7full;
     x = (x & 0x007f007f007f007full) | ((x & 0x7f007f007f007f00ull) >> 1);
     x = (x & 0x00003fff00003fffull) | ((x & 0x3fff00003fff0000ull) >> 2);
     x = (x & 0x000000000fffffffull) | ((x & 0x0fffffff00000000ull) >> 4);
+    if (LONG_TOKENS && lencont >= 7u) {
+      // The window is the token's LAST 8 bytes; an int64 varint has up to 10 (the first value of a chunk's epoch time
+      // stamp at 1 us has 8): up to two more bytes in front of the window, inside the 16 bytes of history. Arithmetic
+      // modulo 2^64 like decodeVarint's shifts; the tenth byte may carry one bit (rd_varint's check).
+      const uint32_t p8 = e - 8u, p9 = e - 9u, p10 = e - 10u;
+      const uint32_t B8 = (tileb[p8 >> 2] >> ((p8 & 3u) * 8u)) & 0xffu;
+      const uint32_t B9 = (tileb[p9 >> 2] >> ((p9 & 3u) * 8u)) & 0xffu;
+      const uint32_t B10 = (tileb[p10 >> 2] >> ((p10 & 3u) * 8u)) & 0xffu;
+      if ((B8 & 0x80u) == 0u) {
+        // exactly 8 bytes: x is complete
+      } else if ((B9 & 0x80u) == 0u) {
+        x = (uint64_t)(B8 & 0x7fu) | (x << 7);
+      } else if ((B10 & 0x80u) == 0u && ((hi >> 24) & 0x7fu) <= 1u) {
+        x = (uint64_t)(B9 & 0x7fu) | ((uint64_t)(B8 & 0x7fu) << 7) | (x << 14);
+      } else {
+        misc[0] = 1u;  // more than 10 bytes, or bits beyond 64: the serial decoder raises the error
+        continue;
+      }
+    }
     store(kl, x, pos + tid * 8u + j + 1u);
   }
   __syncthreads();
@@ -607,7 +627,7 @@ __device__ __forceinline__ void dv_stream(OpAt op_at, uint32_t n_ops, const uint
       break;
     }
     const uint32_t seen = pts_done * n_ops;  // tokens handed to points so far
-    const uint32_t n_tile = dv_tokens_tile(src, src_size, pos, tileb, misc, left, seen, target,
+    const uint32_t n_tile = dv_tokens_tile<WIDE>(src, src_size, pos, tileb, misc, left, seen, target,
                                            [&](uint32_t kl, uint64_t x, uint32_t end_off) {
                                              const bool marker = (x == 0ull);
                                              const uint64_t u1 = x - 1ull;
@@ -858,12 +878,30 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
             const uint32_t c_lo = lo & 0x80808080u, c_hi = hi & 0x00808080u;
             const uint32_t cm = (((c_lo >> 7) * 0x00204081u) >> 21 & 0xfu) | ((((c_hi >> 7) * 0x00204081u) >> 21 & 0x7u) << 4);
             const uint32_t lencont = (uint32_t)__builtin_clz(~(cm << 25));  // continuation bytes before the end byte
-            if (lencont >= 7u) misc[0] = 1u;                                 // token of 8 or more bytes
-            uint64_t x = ((((uint64_t)hi) << 32) | lo) >> (8u * (7u - min(lencont, 6u)));
+            if (lencont >= 7u && !WIDE) misc[0] = 1u;                        // token of 8 or more bytes
+            uint64_t x = ((((uint64_t)hi) << 32) | lo) >> (8u * (7u - min(lencont, WIDE ? 7u : 6u)));
             x &= 0x7f7f7f7f7f7f7f7full;
             x = (x & 0x007f007f007f007full) | ((x & 0x7f007f007f007f00ull) >> 1);
             x = (x & 0x00003fff00003fffull) | ((x & 0x3fff00003fff0000ull) >> 2);
             x = (x & 0x000000000fffffffull) | ((x & 0x0fffffff00000000ull) >> 4);
+            if (WIDE && lencont >= 7u) {
+              // The window is the token's LAST 8 bytes; an int64 varint has up to 10 (the first value of a chunk's epoch
+              // time stamp at 1 us has 8): up to two more bytes in front of the window, inside the 16 bytes of history.
+              // Arithmetic modulo 2^64 like decodeVarint's shifts; the tenth byte may carry one bit (rd_varint's check).
+              const uint32_t p8 = e - 8u, p9 = e - 9u, p10 = e - 10u;
+              const uint32_t B8 = (tileb[p8 >> 2] >> ((p8 & 3u) * 8u)) & 0xffu;
+              const uint32_t B9 = (tileb[p9 >> 2] >> ((p9 & 3u) * 8u)) & 0xffu;
+              const uint32_t B10 = (tileb[p10 >> 2] >> ((p10 & 3u) * 8u)) & 0xffu;
+              if ((B8 & 0x80u) == 0u) {
+                // exactly 8 bytes: x is complete
+              } else if ((B9 & 0x80u) == 0u) {
+                x = (uint64_t)(B8 & 0x7fu) | (x << 7);
+              } else if ((B10 & 0x80u) == 0u && ((hi >> 24) & 0x7fu) <= 1u) {
+                x = (uint64_t)(B9 & 0x7fu) | ((uint64_t)(B8 & 0x7fu) << 7) | (x << 14);
+              } else {
+                misc[0] = 1u;  // more than 10 bytes, or bits beyond 64: the serial decoder raises the error
+              }
+            }
             const uint64_t u1 = x - 1ull;
             d[j] = (Acc)(UAcc)((u1 >> 1) ^ (0ull - (u1 & 1ull)));
             valid |= 1u << j;

@@ -312,6 +312,26 @@ def test_section_guess_with_a_false_hit_in_the_token_stream(oracle, field):
     assert stats == (n_chunks, n_chunks, 0, 0)
 
 
+def test_epoch_time_stamps_stay_on_the_parallel_decoder(oracle):
+    """A FLOAT64 stamp with a resolution (1 us) next to XYZI: the first value of every chunk is the epoch time itself, a
+    varint of 8 bytes (1.7e15 ticks); later ones are small. The 64-bit token walk takes tokens of up to 10 bytes from
+    the history bytes in front of its 8-byte window -- such chunks used to fall back to the one-lane decoder
+    (decodeVarint, include/cloudini_lib/encoding_utils.hpp:69-90)."""
+    F = cases.F
+    n = 70000
+    fields = [("x", 0, F.FLOAT32, 0.001), ("y", 4, F.FLOAT32, 0.001), ("z", 8, F.FLOAT32, 0.001), ("intensity", 12, F.FLOAT32, 0.001),
+              ("ring", 16, F.UINT16, None), ("timestamp", 18, F.FLOAT64, 1e-6)]
+    info = cases.make_info(fields, 26, n)
+    rs = np.random.RandomState(11)
+    p = rs.randn(n, 3).astype(np.float32) * 20
+    for t0 in (1.7e9, 9.2e12, 0.0):  # 8-byte, 10-byte (wraps the int64 like the reference) and 1-byte first tokens
+        data = cases.pack(info, {"x": p[:, 0], "y": p[:, 1], "z": p[:, 2], "intensity": rs.randint(0, 255, n).astype(np.float32),
+                                 "ring": (np.arange(n) % 64).astype(np.uint16), "timestamp": t0 + np.arange(n) * 1e-5}, n)
+        check_decode(oracle, info, [data])
+        stats, _modes, n_chunks = _stats_after_decode(oracle, info, data)
+        assert stats[2] == 0, (t0, stats)
+
+
 def test_decode_fill_zero_for_fresh_buffers(oracle):
     """cldn_hip_codec_set_decode_fill(ZERO): the caller's buffer content is not needed, the bytes of a point that no field
     covers read 0 afterwards (what the reference leaves in a freshly resized vector); KEEP (default) preserves them."""

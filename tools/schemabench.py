@@ -63,4 +63,18 @@ for name, (fields, step, cols) in layouts.items():
     dt = (time.perf_counter() - t0) / 10
     km = codec.kernel_ms(0)
     print(f"{name}: {n_clouds*n/dt/1e6:.0f} Mpoints/s ({dt*1e3:.3f} ms; regular {km['regular']:.3f}, sections {km['sections']:.3f}, compact {km['compact']:.3f}), {int(d_off.cpu()[-1])/(n_clouds*n):.2f} B/pt")
+    # and back (device resident, the walk over the chunk prefixes included)
+    offs = d_off.cpu().numpy().astype(np.uint64)
+    d_dec = torch.zeros(d_points.numel(), dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        codec.decode_device(d_out.data_ptr(), offs, cp, d_dec.data_ptr(), d_dec.numel(), 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        codec.decode_device(d_out.data_ptr(), offs, cp, d_dec.data_ptr(), d_dec.numel(), 0)
+    torch.cuda.synchronize()
+    ddt = (time.perf_counter() - t0) / 10
+    codec.status()
+    ok = bool(torch.equal(d_dec, d_points)) if all(f[3] is None for f in fields) else None
+    print(f"    decode {n_clouds*n/ddt/1e6:.0f} Mpoints/s ({ddt*1e3:.3f} ms), chunks (parallel regular, parallel sections, serial, serial sections) = {codec.decode_stats()}")
     codec.close()
