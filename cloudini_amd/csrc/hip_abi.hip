@@ -171,6 +171,7 @@ struct cldn_hip_codec {
   DevBuf d_s1, d_s1_offsets, d_lz_matches, d_lz_counts, d_lz_slots, d_lz_segs, d_payload2, d_dst2;
   DevBuf d_finrec;            // k_finish look-back records (rec, rec2), cleared only when (re)allocated
   int decode_fill = CLDN_HIP_FILL_KEEP;  // cldn_hip_codec_set_decode_fill
+  DevBuf d_dec_bits;          // k_mark_token_ends: token-end bitmap of the streams of a decode call
   DevBuf d_dec_rec;           // k_sections_cols_fast slice records, tagged with dec_epoch, cleared only when (re)allocated
   uint32_t dec_epoch = 0;
   uint32_t finish_epoch = 0;  // tag of this call's records
@@ -431,6 +432,21 @@ int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint
     delete plan;
     return rc;
   }
+  {  // decode: can the token ends of the regular stream be laid out from the point's form (k_mark_token_ends)?
+    bool ok = d.n_ops >= 1u && d.n_ops <= 8u && d.max_regular_bytes <= 256u;
+    uint32_t n_raw = 0u;
+    for (uint32_t o = 0; o < d.n_ops && ok; ++o) {
+      const uint32_t k = d.ops[o].kind;
+      if (k == OP_COPY) {
+        const uint32_t sz = d.ops[o].size;
+        ok = sz == 1u || sz == 2u || sz == 4u || sz == 8u;
+        ++n_raw;
+      } else {
+        ok = k == OP_QF32 || k == OP_LOSSY_F32 || k == OP_LOSSY_F64 || k == OP_INT;
+      }
+    }
+    d.varint_and_raw = (ok && n_raw != 0u) ? 1u : 0u;
+  }
   *out = plan;
   return CLDN_HIP_OK;
 }
@@ -515,7 +531,7 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   DeviceGuard guard;
   (void)guard.enter(c->device);
   (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec, &c->d_dec_rec, &c->d_s1, &c->d_s1_offsets,
+  DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec, &c->d_dec_rec, &c->d_dec_bits, &c->d_s1, &c->d_s1_offsets,
                     &c->d_lz_matches, &c->d_lz_counts, &c->d_lz_slots, &c->d_lz_segs, &c->d_payload2, &c->d_dst2,
                     &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_pre_ptrs, &c->d_dec_cols[0], &c->d_dec_cols[1],
                     &c->d_viz_keys, &c->d_viz_first,
@@ -1408,6 +1424,10 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
   }
   for (uint32_t a = 0; a < 2u; ++a)
     L.cols[a] = (dec_cols && a < plan.n_adaptive && plan.adaptive[a].bpv <= 4u) ? (uint8_t*)c->d_dec_cols[a].p : nullptr;
+  if (plan.varint_and_raw && n_chunks) {  // one bit per stream byte + a word per chunk (k_mark_token_ends)
+    if ((rc = c->d_dec_bits.ensure((size_t)((stream_bytes - base_off) / 8u) + (size_t)n_chunks * 4u + 256u)) != CLDN_HIP_OK) return rc;
+    L.token_ends = (uint32_t*)c->d_dec_bits.p;
+  }
   L.out = d_outp;
   L.fill_zero = c->decode_fill == CLDN_HIP_FILL_ZERO ? 1u : 0u;
   L.status = (uint32_t*)c->d_status.p;

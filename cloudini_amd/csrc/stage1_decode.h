@@ -777,6 +777,164 @@ __device__ __forceinline__ void dv_stream(OpAt op_at, uint32_t n_ops, const uint
 // consecutive fields of consecutive points, so the stores of neighbouring threads are neighbours too. Nothing
 // waits at a tile edge: a point cut by it simply continues with the carried per-op state.
 // ---------------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------
+// k_mark_token_ends: regular streams with raw fields between the varints (FieldEncoderCopy, field_encoder.hpp:342-357:
+// XYZ + a packed rgb float without resolution is the PCL PointXYZRGB layout). A raw byte may look like anything, so the
+// ends of the varints cannot be read off the MSBs; what is known is the FORM of a point -- op after op, a varint or
+// `size` raw bytes. Tiles of 1 KiB that start at a point boundary:
+//   J[0][p] = where the point that would start at byte p ends (every p of the tile, four per thread),
+//   J[k][p] = J[k-1][J[k-1][p]]                                   (pointer doubling, 10 levels),
+//   point t of the tile starts where the set bits of t lead from byte 0 through the J[k] -- every thread finds its
+//   point in 10 reads, walks it once more and sets the end bits of its tokens in an LDS bitmap,
+//   the tile's bits leave as whole 32-bit words (the partial last word is carried into the next tile).
+// The bitmap of chunk c begins at word token_ends_word(src_off, c): one bit per payload byte. A malformed or truncated
+// stream sets reg_end[c] = kDecRedo: the serial decoder takes the chunk and raises the error.
+// grid = n_chunks, 256 threads.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kMtThreads = 256;
+constexpr uint32_t kMtTile = 1024;
+constexpr uint32_t kMtLook = 256;      // a point has at most this many bytes
+constexpr uint32_t kMtLevels = 10;     // 2^10 points per tile at most (a point has at least one byte per op)
+constexpr uint32_t kMtMaxOps = 8;
+
+__host__ __device__ __forceinline__ uint64_t token_ends_word(uint64_t src_off, uint32_t c) { return (src_off >> 5) + c; }
+
+// end (exclusive) of the point that starts at byte p of the staged bytes, 0xffff when it is malformed or incomplete
+__device__ __forceinline__ uint32_t mt_point_end(const uint8_t* bytes, uint32_t avail, uint32_t p, uint32_t n_ops, const uint8_t* raw_size) {
+  uint32_t q = p;
+  for (uint32_t o = 0; o < n_ops; ++o) {
+    const uint32_t rs = raw_size[o];
+    if (rs != 0u) {
+      q += rs;
+    } else {
+      uint32_t len = 0u;
+      for (uint32_t k = 0; k < 10u; ++k) {
+        if (q + k >= avail) return 0xffffu;
+        if ((bytes[q + k] & 0x80u) == 0u) {
+          len = k + 1u;
+          break;
+        }
+      }
+      if (len == 0u) return 0xffffu;  // more than 10 bytes
+      q += len;
+    }
+    if (q > avail) return 0xffffu;
+  }
+  return q;
+}
+
+__global__ __launch_bounds__(kMtThreads) void k_mark_token_ends(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                                const DecChunk* __restrict__ chunks,
+                                                                uint32_t* __restrict__ token_ends, uint32_t* __restrict__ reg_end) {
+  __shared__ __attribute__((aligned(16))) uint8_t bytes[kMtTile + kMtLook + 16u];
+  __shared__ uint16_t J[kMtLevels][kMtTile];
+  __shared__ uint32_t bm[(kMtTile + kMtLook) / 32u + 2u];
+  __shared__ uint8_t raw_size[kMtMaxOps];
+  __shared__ uint32_t sh[4];  // [0] bad, [1] points of the tile, [2] bytes consumed, [3] carried partial word
+  const uint32_t c = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const DecChunk dc = chunks[c];
+  if (!dc.valid) return;
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t src_size = dc.src_size;
+  const uint32_t n = dc.n_points;
+  const uint32_t n_ops = plan.n_ops;
+  uint32_t* out_words = token_ends + token_ends_word(dc.src_off, c);
+  if (tid < kMtMaxOps) raw_size[tid] = (tid < n_ops && plan.ops[tid].kind == OP_COPY) ? plan.ops[tid].size : (uint8_t)0;
+  if (tid == 0) {
+    sh[0] = 0u;
+    sh[3] = 0u;
+    reg_end[c] = 0u;
+  }
+  __syncthreads();
+  uint32_t ps = 0u, pts_done = 0u;  // uniform
+  while (pts_done < n) {
+    if (ps >= src_size) {
+      if (tid == 0) sh[0] = 1u;
+      break;
+    }
+    const uint32_t avail = min(kMtTile + kMtLook, src_size - ps);
+    for (uint32_t i = tid; i < (kMtTile + kMtLook) / 4u; i += kMtThreads) {
+      uint32_t w = 0u;
+      const uint32_t o = i * 4u;
+      if (o + 4u <= avail) __builtin_memcpy(&w, src + ps + o, 4);
+      else
+        for (uint32_t bb = 0; bb < 4u && o + bb < avail; ++bb) w |= (uint32_t)src[ps + o + bb] << (8u * bb);
+      reinterpret_cast<uint32_t*>(bytes)[i] = w;
+    }
+    for (uint32_t i = tid; i < (kMtTile + kMtLook) / 32u + 2u; i += kMtThreads) bm[i] = 0u;
+    __syncthreads();
+    for (uint32_t p = tid; p < kMtTile; p += kMtThreads) J[0][p] = (uint16_t)(p < avail ? mt_point_end(bytes, avail, p, n_ops, raw_size) : 0xffffu);
+    __syncthreads();
+    for (uint32_t k = 1; k < kMtLevels; ++k) {
+      for (uint32_t p = tid; p < kMtTile; p += kMtThreads) {
+        const uint32_t j = J[k - 1u][p];
+        J[k][p] = j < kMtTile ? J[k - 1u][j] : (uint16_t)j;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {  // how many points start inside the tile: the longest walk from byte 0 that stays inside
+      uint32_t p = 0u, t = 0u;
+      for (int k = (int)kMtLevels - 1; k >= 0; --k) {
+        const uint32_t q = J[k][p];
+        if (q < kMtTile) {
+          p = q;
+          t += 1u << k;
+        }
+      }
+      sh[1] = min(t + 1u, n - pts_done);
+    }
+    __syncthreads();
+    const uint32_t want = sh[1];
+    for (uint32_t t = tid; t < want; t += kMtThreads) {
+      uint32_t p = 0u;
+      for (uint32_t k = 0; k < kMtLevels; ++k)
+        if ((t >> k) & 1u) p = J[k][p];
+      const uint32_t end = J[0][p];
+      if (end == 0xffffu) {
+        sh[0] = 1u;  // malformed, or the payload ends inside the point
+      } else {
+        uint32_t q = p;
+        for (uint32_t o = 0; o < n_ops; ++o) {
+          const uint32_t rs = raw_size[o];
+          if (rs != 0u) {
+            q += rs;
+          } else {
+            while (bytes[q] & 0x80u) ++q;  // (mt_point_end has checked the token)
+            ++q;
+          }
+          atomicOr(&bm[(q - 1u) >> 5], 1u << ((q - 1u) & 31u));
+        }
+        if (t + 1u == want) sh[2] = end;
+      }
+    }
+    __syncthreads();
+    if (sh[0]) break;  // uniform
+    const uint32_t consumed = sh[2];
+    {  // bits [0, consumed) of the tile = bits [ps, ps + consumed) of the chunk
+      const uint32_t s = ps & 31u, w0 = ps >> 5;
+      const uint32_t total_bits = s + consumed;
+      const uint32_t n_full = total_bits >> 5;  // whole words; the rest is carried
+      const uint32_t carry = sh[3];
+      __syncthreads();
+      for (uint32_t i = tid; i <= n_full; i += kMtThreads) {
+        uint32_t v = s ? ((bm[i] << s) | (i ? (bm[i - 1u] >> (32u - s)) : 0u)) : bm[i];
+        if (i == 0u) v |= carry;
+        if (i < n_full) out_words[w0 + i] = v;
+        else sh[3] = (total_bits & 31u) ? v : 0u;  // the partial last word waits for the next tile
+      }
+    }
+    ps += consumed;
+    pts_done += want;
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (sh[0]) reg_end[c] = kDecRedo;
+    else if (ps & 31u) out_words[ps >> 5] = sh[3];
+  }
+}
+
 template <int NOPS, bool WIDE, int BPT>
 struct Dv2Lds {
   using Acc = typename std::conditional<WIDE, long long, int>::type;
@@ -788,10 +946,13 @@ struct Dv2Lds {
   static constexpr uint32_t kTotal = kMiscOff + 256u;  // misc: [0] bad, [1] end offset, [2..34) block-scan scratch
 };
 
+// end_bits != NULL (WIDE, BPT = 8): the token ends are not read off the bytes' MSBs but from a bitmap (bit p = payload
+// byte p ends a token) that k_mark_token_ends has laid out -- streams with raw (FieldEncoderCopy) fields between the
+// varints. A raw field is a token like any other there: its value is its bytes, it resets its op's running sum.
 template <int NOPS, bool WIDE, int BPT, typename OpAt>
 __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uint8_t* __restrict__ src,
                                            uint32_t src_size, uint32_t start, uint32_t n_points, uint8_t* base,
-                                           uint32_t step, uint8_t* smem) {
+                                           uint32_t step, uint8_t* smem, const uint8_t* __restrict__ end_bits = nullptr) {
   using L = Dv2Lds<NOPS, WIDE, BPT>;
   using Acc = typename L::Acc;
   using UAcc = typename std::make_unsigned<Acc>::type;
@@ -855,15 +1016,25 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
       tileb[4u + tid * DW + k] = b[k];
       ends |= ((((~b[k] & 0x80808080u) >> 7) * 0x00204081u) >> 21 & 0xfu) << (4 * k);
     }
+    uint32_t ehist = 0u;  // bitmap mode: bit k = byte my - 16 + k ends a token (k < 16: in front of my bytes; the byte in front of the payload counts as an end)
+    if (WIDE && BPT == 8 && end_bits != nullptr) {
+      ends = my < src_size ? (uint32_t)end_bits[my >> 3] : 0u;  // (my is a multiple of 8)
+      const uint32_t g8 = my >> 3;
+      const uint32_t h1 = g8 >= 1u ? (uint32_t)end_bits[g8 - 1u] : 0x80u;                  // bytes my-8 .. my-1
+      const uint32_t h0 = g8 >= 2u ? (uint32_t)end_bits[g8 - 2u] : (g8 == 1u ? 0x80u : 0u);  // bytes my-16 .. my-9
+      ehist = h0 | (h1 << 8) | (ends << 16);
+    }
     uint32_t n_tile;
     const uint32_t tb = block_exclusive_scan<T>((uint32_t)__builtin_popcount(ends), misc + 2, &n_tile);  // barrier inside
     const uint32_t g0 = seen + tb;  // stream index of my first token
 
     // ---- my tokens -> registers (indexed by the byte position of the token's last byte)
     Acc d[BPT];
-    uint32_t valid = 0u, marks = 0u;
+    uint32_t valid = 0u, marks = 0u, raws = 0u;
+    const uint32_t p0 = g0 / n_ops, o0 = g0 - p0 * n_ops;  // point and op of my first token
     {
       uint32_t g = g0;
+      uint32_t og = o0;
 #pragma unroll
       for (int j = 0; j < BPT; ++j) {
         d[j] = 0;
@@ -877,7 +1048,18 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
             const uint32_t hi = sh ? ((d1 >> sh) | (d2 << (32u - sh))) : d1;
             const uint32_t c_lo = lo & 0x80808080u, c_hi = hi & 0x00808080u;
             const uint32_t cm = (((c_lo >> 7) * 0x00204081u) >> 21 & 0xfu) | ((((c_hi >> 7) * 0x00204081u) >> 21 & 0x7u) << 4);
-            const uint32_t lencont = (uint32_t)__builtin_clz(~(cm << 25));  // continuation bytes before the end byte
+            uint32_t lencont = (uint32_t)__builtin_clz(~(cm << 25));  // continuation bytes before the end byte
+            bool from_bits = false;
+            if (WIDE && BPT == 8 && end_bits != nullptr) {
+              // with raw fields in the stream the bytes in front of a token say nothing about it: its length is the
+              // distance to the end in front of it (bit 16 + j of `ehist` is this token's end)
+              const uint32_t P = 16u + (uint32_t)j;
+              const uint32_t below = ehist & ((1u << P) - 1u);
+              const uint32_t tl = below ? P - (31u - (uint32_t)__builtin_clz(below)) : 99u;
+              if (tl > 10u) misc[0] = 1u;
+              lencont = min(tl, 10u) - 1u;
+              from_bits = true;
+            }
             if (lencont >= 7u && !WIDE) misc[0] = 1u;                        // token of 8 or more bytes
             uint64_t x = ((((uint64_t)hi) << 32) | lo) >> (8u * (7u - min(lencont, WIDE ? 7u : 6u)));
             x &= 0x7f7f7f7f7f7f7f7full;
@@ -892,11 +1074,14 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
               const uint32_t B8 = (tileb[p8 >> 2] >> ((p8 & 3u) * 8u)) & 0xffu;
               const uint32_t B9 = (tileb[p9 >> 2] >> ((p9 & 3u) * 8u)) & 0xffu;
               const uint32_t B10 = (tileb[p10 >> 2] >> ((p10 & 3u) * 8u)) & 0xffu;
-              if ((B8 & 0x80u) == 0u) {
+              const bool is8 = from_bits ? lencont == 7u : (B8 & 0x80u) == 0u;
+              const bool is9 = from_bits ? lencont == 8u : (B9 & 0x80u) == 0u;
+              const bool is10 = from_bits ? lencont == 9u : (B10 & 0x80u) == 0u;
+              if (is8) {
                 // exactly 8 bytes: x is complete
-              } else if ((B9 & 0x80u) == 0u) {
+              } else if (is9) {
                 x = (uint64_t)(B8 & 0x7fu) | (x << 7);
-              } else if ((B10 & 0x80u) == 0u && ((hi >> 24) & 0x7fu) <= 1u) {
+              } else if (is10 && ((hi >> 24) & 0x7fu) <= 1u) {
                 x = (uint64_t)(B9 & 0x7fu) | ((uint64_t)(B8 & 0x7fu) << 7) | (x << 14);
               } else {
                 misc[0] = 1u;  // more than 10 bytes, or bits beyond 64: the serial decoder raises the error
@@ -906,13 +1091,28 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
             d[j] = (Acc)(UAcc)((u1 >> 1) ^ (0ull - (u1 & 1ull)));
             valid |= 1u << j;
             if (x == 0ull) marks |= 1u << j;
+            if (WIDE && end_bits != nullptr) {  // a raw field: the last `size` bytes of the window are its value
+              uint32_t kind = 0u, size = 0u;
+#pragma unroll
+              for (int oo = 0; oo < NOPS; ++oo)
+                if (og == (uint32_t)oo) {
+                  kind = op_at(oo).kind;
+                  size = op_at(oo).size;
+                }
+              if (kind == OP_COPY) {
+                const uint64_t win = (((uint64_t)hi) << 32) | lo;
+                d[j] = (Acc)(UAcc)(size >= 8u ? win : (win >> (64u - 8u * size)));
+                raws |= 1u << j;
+                marks &= ~(1u << j);
+              }
+            }
             if (g + 1u == target) misc[1] = pos + tid * BPT + (uint32_t)j + 1u;
           }
           ++g;
+          og = (og + 1u == n_ops) ? 0u : og + 1u;
         }
       }
     }
-    const uint32_t p0 = g0 / n_ops, o0 = g0 - p0 * n_ops;  // point and op of my first token
 
     // ---- partial sums per op with NaN resets
     Acc acc[NOPS];
@@ -925,10 +1125,12 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
       for (int j = 0; j < BPT; ++j) {
         if ((valid >> j) & 1u) {
           const bool mk = (marks >> j) & 1u;
+          const bool rw = (raws >> j) & 1u;
 #pragma unroll
           for (int oo = 0; oo < NOPS; ++oo) {
             if (o == (uint32_t)oo) {
-              acc[oo] = mk ? (Acc)0 : (Acc)((UAcc)acc[oo] + (UAcc)d[j]);
+              acc[oo] = rw ? d[j] : (mk ? (Acc)0 : (Acc)((UAcc)acc[oo] + (UAcc)d[j]));
+              if (rw) fl |= 1u << oo;
               if (mk) {
                 fl |= 1u << oo;
                 if (op_at(oo).kind == OP_INT) misc[0] = 1u;  // the marker is not a valid integer token
@@ -996,6 +1198,7 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
       for (int j = 0; j < BPT; ++j) {
         if ((valid >> j) & 1u) {
           const bool mk = (marks >> j) & 1u;
+          const bool rw = (raws >> j) & 1u;
           Acc cur = 0;
           uint32_t kind = 0u, size = 0u, off = 0xffffffffu;
           float resf = 0.0f;
@@ -1003,7 +1206,7 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
 #pragma unroll
           for (int oo = 0; oo < NOPS; ++oo) {
             if (o == (uint32_t)oo) {
-              in[oo] = mk ? (Acc)0 : (Acc)((UAcc)in[oo] + (UAcc)d[j]);
+              in[oo] = rw ? d[j] : (mk ? (Acc)0 : (Acc)((UAcc)in[oo] + (UAcc)d[j]));
               cur = in[oo];
               const DevOp& op = op_at(oo);
               kind = op.kind;
@@ -1057,7 +1260,8 @@ template <int NOPS, bool WIDE>
 __device__ __forceinline__ void decode_varint_body(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                               const DecChunk* __restrict__ chunks,
                                                               uint8_t* __restrict__ out, uint32_t* __restrict__ reg_end,
-                                                              uint32_t* __restrict__ status, uint32_t redo_only) {
+                                                              uint32_t* __restrict__ status, uint32_t redo_only,
+                                                              const uint32_t* __restrict__ token_ends = nullptr) {
   constexpr int BPT = WIDE ? 8 : 16;
   using L = Dv2Lds<NOPS, WIDE, BPT>;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1066,8 +1270,13 @@ __device__ __forceinline__ void decode_varint_body(const DevPlan plan, const uin
   if (!dc.valid) return;
   if (redo_only && reg_end[c] != kDecRedo) return;  // behind k_decode_points: only the chunks it handed back
   uint8_t* base = out + (size_t)dc.first_point * plan.point_step;
+  const uint8_t* end_bits = nullptr;
+  if (token_ends != nullptr) {
+    if (reg_end[c] == kDecRedo) return;  // k_mark_token_ends found the stream irregular: the serial decoder takes the chunk
+    end_bits = reinterpret_cast<const uint8_t*>(token_ends + token_ends_word(dc.src_off, c));
+  }
   dv_stream2<NOPS, WIDE, BPT>([&](int o) -> const DevOp& { return plan.ops[o]; }, plan.n_ops, streams + dc.src_off,
-                              dc.src_size, 0u, dc.n_points, base, plan.point_step, smem);
+                              dc.src_size, 0u, dc.n_points, base, plan.point_step, smem, end_bits);
   const uint32_t* misc = reinterpret_cast<const uint32_t*>(smem + L::kMiscOff);
   if (threadIdx.x == 0) {
     const bool redo = misc[0] || misc[1] == 0xffffffffu;
@@ -1080,8 +1289,9 @@ template <int NOPS, bool WIDE>
 __global__ __launch_bounds__(kDvThreads) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 : 8, 8))) void k_decode_varint(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                               const DecChunk* __restrict__ chunks,
                                                               uint8_t* __restrict__ out, uint32_t* __restrict__ reg_end,
-                                                              uint32_t* __restrict__ status, uint32_t redo_only) {
-  decode_varint_body<NOPS, WIDE>(plan, streams, chunks, out, reg_end, status, redo_only);
+                                                              uint32_t* __restrict__ status, uint32_t redo_only,
+                                                              const uint32_t* __restrict__ token_ends) {
+  decode_varint_body<NOPS, WIDE>(plan, streams, chunks, out, reg_end, status, redo_only, token_ends);
 }
 
 

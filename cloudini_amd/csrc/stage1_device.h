@@ -59,6 +59,8 @@ struct DevPlan {
   uint32_t min_regular_bytes;  // best case (decode sanity checks)
   uint32_t all_varint;         // every regular op is a varint/NaN token (decode can find token ends by MSB)
   uint32_t n_gorilla;          // OP_GORILLA64 ops
+  uint32_t varint_and_raw;     // decode: every regular op is a varint token or a raw copy of 1/2/4/8 bytes, at least one of
+                               // them raw, at most 8 ops and 256 bytes per point: k_mark_token_ends can lay out the token ends
   DevOp ops[kMaxOps];
   DevAdaptive adaptive[kMaxAdaptive];
 };

@@ -2486,14 +2486,28 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_tail");
       return CLDN_HIP_OK;
     }
-    if (fast) {
+    // regular streams with raw (FieldEncoderCopy) fields between the varints: k_mark_token_ends lays out where the tokens
+    // end, the 64-bit token kernel takes the ends from there (the plan says whether the stream has that form)
+    static const bool no_mixed = getenv("CLDN_HIP_NO_MIXED_DECODE") != nullptr;  // A/B switch
+    const bool mixed = !fast && !no_fast && !no_mixed && P.varint_and_raw != 0u && L.token_ends != nullptr;
+    if (mixed) {
+      hipLaunchKernelGGL(k_mark_token_ends, dim3(L.n_chunks), dim3(kMtThreads), 0, L.stream, P, L.streams,
+                         reinterpret_cast<const DecChunk*>(L.chunks), L.token_ends, L.reg_end);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_mark_token_ends");
+      hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<8, true, 8>::kTotal),
+                         L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, 0u,
+                         (const uint32_t*)L.token_ends);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_varint (mixed)");
+      fast = true;  // from here on like any stream the parallel kernels have taken
+    } else if (fast) {
       if (all_qf32 && P.n_ops <= 4u)
         hipLaunchKernelGGL((k_decode_varint<4, false>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<4, false, 16>::kTotal),
                            L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status,
-                           points_kernel ? 1u : 0u);
+                           points_kernel ? 1u : 0u, (const uint32_t*)nullptr);
       else
         hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<8, true, 8>::kTotal),
-                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, 0u);
+                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, 0u,
+                           (const uint32_t*)nullptr);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_varint");
     }
     const bool fast_sections = fast && L.uses_v5 && P.n_adaptive > 0u;

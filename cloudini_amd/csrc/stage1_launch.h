@@ -80,6 +80,7 @@ struct DecodeLaunch {
   uint32_t* reg_end_pre;              // device [n_chunks]: k_decode_sections_cols: where the regular stream ends
   uint8_t* sec_cols;                  // device [n_chunks]: 1 = the columns hold the chunk's integer fields
   const uint32_t* chunk_sizes;        // device [n_chunks] or NULL: the payload sizes, if the caller knows them (no serial walk)
+  uint32_t* token_ends;           // k_mark_token_ends: one bit per stream byte (+ a word per chunk), or NULL
   uint32_t fill_zero;             // CLDN_HIP_FILL_ZERO: bytes of a point that no field covers may be written as 0
   uint32_t* slices_done;          // [n_chunks] DeltaVarint slices of a chunk that k_sections_cols_fast finished
   unsigned long long* slice_rec;  // [n_chunks * 48 * 2] (count, sum) records of the slices, tagged with slice_epoch
