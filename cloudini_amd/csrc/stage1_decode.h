@@ -141,11 +141,42 @@ __global__ __launch_bounds__(256) void k_build_chunks(const uint8_t* __restrict_
 }
 
 // ---- serial helpers (one lane) ------------------------------------------------------------------------------
+// The payload is read through a window in LDS: the one lane that parses would otherwise wait for a global load per BYTE
+// (0.5-1 us each: 16 us per point of a layout with a Gorilla-coded stamp); a refill is 128 independent 16-byte loads.
+constexpr uint32_t kRdWindow = 2048;
 struct Rd {
   const uint8_t* p;
   const uint8_t* end;
   bool bad;
+  uint8_t* win = nullptr;          // LDS, kRdWindow + 16 bytes, 16-byte aligned; nullptr = read global memory directly
+  const uint8_t* wbase = nullptr;  // global address of win[0]
+  uint32_t wlen = 0u;
 };
+
+// (plain arguments, no reference to the reader: a reader whose address is taken lives in scratch memory, and every use
+// of its members becomes a memory round trip)
+__device__ __noinline__ uint32_t rd_refill(uint8_t* win, const uint8_t* b, const uint8_t* end) {
+  const size_t left = (size_t)(end - b);  // (unaligned 16-byte loads from b on: nothing in front of it is touched)
+  const uint32_t len = (uint32_t)(left < (size_t)kRdWindow ? left : (size_t)kRdWindow);
+  const uint32_t full = len >> 4;
+  for (uint32_t i = 0; i < full; ++i) {
+    uint4 v;
+    __builtin_memcpy(&v, b + 16u * i, 16);
+    reinterpret_cast<uint4*>(win)[i] = v;
+  }
+  for (uint32_t k = full * 16u; k < len; ++k) win[k] = b[k];
+  return len;
+}
+
+// the byte at q (p <= q < end)
+__device__ __forceinline__ uint8_t rd_at(Rd& r, const uint8_t* q) {
+  if (r.win == nullptr) return *q;
+  if (q < r.wbase || q >= r.wbase + r.wlen) {
+    r.wlen = rd_refill(r.win, q, r.end);
+    r.wbase = q;
+  }
+  return r.win[q - r.wbase];
+}
 
 // decodeVarint (include/cloudini_lib/encoding_utils.hpp:98-148); the NaN marker is rejected here
 __device__ __forceinline__ int64_t rd_varint(Rd& r) {
@@ -153,7 +184,8 @@ __device__ __forceinline__ int64_t rd_varint(Rd& r) {
   uint32_t shift = 0;
   for (;;) {
     if (r.p >= r.end) { r.bad = true; return 0; }
-    const uint8_t byte = *r.p++;
+    const uint8_t byte = rd_at(r, r.p);
+    ++r.p;
     const uint64_t payload = byte & 0x7fu;
     if (shift >= 64u || (shift == 63u && payload > 1u)) { r.bad = true; return 0; }
     uval |= payload << shift;
@@ -171,7 +203,8 @@ __device__ __forceinline__ uint64_t rd_uvarint(Rd& r) {  // readUVarint, src/v5_
   uint32_t shift = 0;
   for (;;) {
     if (r.p >= r.end) { r.bad = true; return 0; }
-    const uint8_t byte = *r.p++;
+    const uint8_t byte = rd_at(r, r.p);
+    ++r.p;
     value |= ((uint64_t)(byte & 0x7fu)) << shift;
     if ((byte & 0x80u) == 0) return value;
     shift += 7u;
@@ -182,7 +215,7 @@ __device__ __forceinline__ uint64_t rd_uvarint(Rd& r) {  // readUVarint, src/v5_
 __device__ __forceinline__ uint64_t rd_raw(Rd& r, uint32_t nbytes) {
   if ((size_t)(r.end - r.p) < nbytes) { r.bad = true; return 0; }
   uint64_t v = 0;
-  for (uint32_t b = 0; b < nbytes; ++b) v |= ((uint64_t)r.p[b]) << (8u * b);
+  for (uint32_t b = 0; b < nbytes; ++b) v |= ((uint64_t)rd_at(r, r.p + b)) << (8u * b);
   r.p += nbytes;
   return v;
 }
@@ -206,7 +239,8 @@ __device__ __forceinline__ void st_raw(uint8_t* dst, uint64_t v, uint32_t nbytes
 // decodeV5AdaptiveIntSection, src/v5_codec.cpp:764-879
 __device__ void decode_section_serial(Rd& r, uint8_t* base, uint32_t step, uint32_t field_off, uint32_t bpv, uint32_t n) {
   if (r.p >= r.end) { r.bad = true; return; }
-  const uint32_t mode = *r.p++;
+  const uint32_t mode = rd_at(r, r.p);
+  ++r.p;
   if (mode > 3u) { r.bad = true; return; }
   if (mode == 0u) {
     int64_t prev = 0;
@@ -281,10 +315,16 @@ __device__ __forceinline__ void decode_general_body(const DevPlan plan, const ui
   if (sec_done && sec_done[blockIdx.x]) return;  // regular stream and sections were decoded by the parallel kernels
   const uint32_t step = plan.point_step;
   uint8_t* base = out + (size_t)dc.first_point * step;
+  __shared__ __attribute__((aligned(16))) uint8_t rd_window[kRdWindow + 16u];
+  // the ops of the plan in LDS: an op read from the kernel-argument segment at a run-time index is a memory round trip
+  // per member, several per token
+  __shared__ DevOp ops_l[kMaxOps];
+  for (uint32_t k = 0; k < plan.n_ops; ++k) ops_l[k] = plan.ops[k];
   Rd r;
   r.p = streams + dc.src_off;
   r.end = r.p + dc.src_size;
   r.bad = false;
+  r.win = rd_window;
   const uint32_t n = dc.n_points;
   bool regular_done = false;
   if (only_sections) {
@@ -298,8 +338,9 @@ __device__ __forceinline__ void decode_general_body(const DevPlan plan, const ui
   }
   atomicAdd(&status[regular_done ? kStatSerialSections : kStatSerialChunks], 1u);
   if (!regular_done) {
-    int64_t prev[kMaxOps];
-    uint8_t gor_lead[kMaxOps], gor_trail[kMaxOps];
+    // (per-op state in LDS: a 64-entry array indexed at run time would live in scratch, one memory round trip per access)
+    __shared__ int64_t prev[kMaxOps];
+    __shared__ uint8_t gor_lead[kMaxOps], gor_trail[kMaxOps];
     for (uint32_t k = 0; k < plan.n_ops; ++k) {
       prev[k] = 0;
       gor_lead[k] = 255;  // kLeadingSentinel
@@ -314,13 +355,13 @@ __device__ __forceinline__ void decode_general_body(const DevPlan plan, const ui
       // "Truncated encoded data: not enough bytes for a complete point" (v4_codec.cpp:103-105)
       if (!uses_v5 && (size_t)(r.end - r.p) < plan.min_regular_bytes) { r.bad = true; break; }
       for (uint32_t k = 0; k < plan.n_ops && !r.bad; ++k) {
-        const DevOp& op = plan.ops[k];
+        const DevOp& op = ops_l[k];
         const bool store = op.offset != 0xffffffffu;  // kDecodeButSkipStore
         switch (op.kind) {
           case OP_QF32: {  // FieldDecoderFloatN_Lossy, src/field_decoder.cpp:43-86
             if (r.p >= r.end) { r.bad = true; break; }
             float f;
-            if (*r.p == 0) {
+            if (rd_at(r, r.p) == 0) {
               ++r.p;
               prev[k] = 0;
               f = __uint_as_float(0x7fc00000u);
@@ -335,7 +376,7 @@ __device__ __forceinline__ void decode_general_body(const DevPlan plan, const ui
           case OP_LOSSY_F64: {  // FieldDecoderFloat_Lossy, include/cloudini_lib/field_decoder.hpp:330-353
             if (r.p >= r.end) { r.bad = true; break; }
             uint64_t bits;
-            if (*r.p == 0) {
+            if (rd_at(r, r.p) == 0) {
               ++r.p;
               prev[k] = 0;
               bits = op.kind == OP_LOSSY_F32 ? 0x7fc00000ull : 0x7ff8000000000000ull;
@@ -373,7 +414,8 @@ __device__ __forceinline__ void decode_general_body(const DevPlan plan, const ui
               auto need = [&](uint32_t nb) {
                 while (have < nb && !r.bad) {
                   if (r.p >= r.end) { r.bad = true; break; }
-                  const uint64_t byte = *r.p++;
+                  const uint64_t byte = rd_at(r, r.p);
+                  ++r.p;
                   if (have < 64u) {
                     lo |= byte << have;
                     if (have > 56u) hi |= byte >> (64u - have);
@@ -847,6 +889,9 @@ __global__ __launch_bounds__(kMtThreads) void k_mark_token_ends(const DevPlan pl
     reg_end[c] = 0u;
   }
   __syncthreads();
+  // levels of the doubling: 2^levels > the most points a tile can hold (the plan knows a point's fewest bytes)
+  uint32_t levels = 1u;
+  while (levels < kMtLevels && (1u << levels) <= kMtTile / max(1u, plan.min_regular_bytes)) ++levels;
   uint32_t ps = 0u, pts_done = 0u;  // uniform
   while (pts_done < n) {
     if (ps >= src_size) {
@@ -866,7 +911,7 @@ __global__ __launch_bounds__(kMtThreads) void k_mark_token_ends(const DevPlan pl
     __syncthreads();
     for (uint32_t p = tid; p < kMtTile; p += kMtThreads) J[0][p] = (uint16_t)(p < avail ? mt_point_end(bytes, avail, p, n_ops, raw_size) : 0xffffu);
     __syncthreads();
-    for (uint32_t k = 1; k < kMtLevels; ++k) {
+    for (uint32_t k = 1; k < levels; ++k) {
       for (uint32_t p = tid; p < kMtTile; p += kMtThreads) {
         const uint32_t j = J[k - 1u][p];
         J[k][p] = j < kMtTile ? J[k - 1u][j] : (uint16_t)j;
@@ -875,7 +920,7 @@ __global__ __launch_bounds__(kMtThreads) void k_mark_token_ends(const DevPlan pl
     }
     if (tid == 0) {  // how many points start inside the tile: the longest walk from byte 0 that stays inside
       uint32_t p = 0u, t = 0u;
-      for (int k = (int)kMtLevels - 1; k >= 0; --k) {
+      for (int k = (int)levels - 1; k >= 0; --k) {
         const uint32_t q = J[k][p];
         if (q < kMtTile) {
           p = q;
@@ -888,7 +933,7 @@ __global__ __launch_bounds__(kMtThreads) void k_mark_token_ends(const DevPlan pl
     const uint32_t want = sh[1];
     for (uint32_t t = tid; t < want; t += kMtThreads) {
       uint32_t p = 0u;
-      for (uint32_t k = 0; k < kMtLevels; ++k)
+      for (uint32_t k = 0; k < levels; ++k)
         if ((t >> k) & 1u) p = J[k][p];
       const uint32_t end = J[0][p];
       if (end == 0xffffu) {
