@@ -437,7 +437,7 @@ int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint
     uint32_t n_raw = 0u;
     for (uint32_t o = 0; o < d.n_ops && ok; ++o) {
       const uint32_t k = d.ops[o].kind;
-      if (k == OP_COPY) {
+      if (k == OP_COPY || k == OP_XOR32 || k == OP_XOR64) {
         const uint32_t sz = d.ops[o].size;
         ok = sz == 1u || sz == 2u || sz == 4u || sz == 8u;
         ++n_raw;

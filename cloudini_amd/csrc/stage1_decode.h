@@ -882,7 +882,10 @@ __global__ __launch_bounds__(kMtThreads) void k_mark_token_ends(const DevPlan pl
   const uint32_t n = dc.n_points;
   const uint32_t n_ops = plan.n_ops;
   uint32_t* out_words = token_ends + token_ends_word(dc.src_off, c);
-  if (tid < kMtMaxOps) raw_size[tid] = (tid < n_ops && plan.ops[tid].kind == OP_COPY) ? plan.ops[tid].size : (uint8_t)0;
+  if (tid < kMtMaxOps) {
+    const uint32_t kd = tid < n_ops ? plan.ops[tid].kind : 0xffu;
+    raw_size[tid] = (kd == OP_COPY || kd == OP_XOR32 || kd == OP_XOR64) ? plan.ops[tid].size : (uint8_t)0;
+  }
   if (tid == 0) {
     sh[0] = 0u;
     sh[3] = 0u;
@@ -1075,7 +1078,7 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
 
     // ---- my tokens -> registers (indexed by the byte position of the token's last byte)
     Acc d[BPT];
-    uint32_t valid = 0u, marks = 0u, raws = 0u;
+    uint32_t valid = 0u, marks = 0u, raws = 0u, xors = 0u;
     const uint32_t p0 = g0 / n_ops, o0 = g0 - p0 * n_ops;  // point and op of my first token
     {
       uint32_t g = g0;
@@ -1144,10 +1147,11 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
                   kind = op_at(oo).kind;
                   size = op_at(oo).size;
                 }
-              if (kind == OP_COPY) {
+              if (kind == OP_COPY || kind == OP_XOR32 || kind == OP_XOR64) {
                 const uint64_t win = (((uint64_t)hi) << 32) | lo;
                 d[j] = (Acc)(UAcc)(size >= 8u ? win : (win >> (64u - 8u * size)));
-                raws |= 1u << j;
+                if (kind == OP_COPY) raws |= 1u << j;
+                else xors |= 1u << j;  // FieldDecoderFloat_XOR (field_decoder.hpp): the value is the bytes XOR the value before
                 marks &= ~(1u << j);
               }
             }
@@ -1171,10 +1175,11 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
         if ((valid >> j) & 1u) {
           const bool mk = (marks >> j) & 1u;
           const bool rw = (raws >> j) & 1u;
+          const bool xr = (xors >> j) & 1u;
 #pragma unroll
           for (int oo = 0; oo < NOPS; ++oo) {
             if (o == (uint32_t)oo) {
-              acc[oo] = rw ? d[j] : (mk ? (Acc)0 : (Acc)((UAcc)acc[oo] + (UAcc)d[j]));
+              acc[oo] = xr ? (Acc)((UAcc)acc[oo] ^ (UAcc)d[j]) : (rw ? d[j] : (mk ? (Acc)0 : (Acc)((UAcc)acc[oo] + (UAcc)d[j])));
               if (rw) fl |= 1u << oo;
               if (mk) {
                 fl |= 1u << oo;
@@ -1187,6 +1192,14 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
       }
     }
     // segmented inclusive scan over the threads: (f1, v1) o (f2, v2) = (f1 | f2, f2 ? v2 : v1 + v2)
+    // (XOR-coded ops combine with ^ instead of +; they never reset)
+    uint32_t xmask = 0u;
+    if (WIDE && end_bits != nullptr) {
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o)
+        if ((uint32_t)o < n_ops && (op_at(o).kind == OP_XOR32 || op_at(o).kind == OP_XOR64)) xmask |= 1u << o;
+    }
+    auto comb = [&](int o, Acc a, Acc b) -> Acc { return ((xmask >> o) & 1u) ? (Acc)((UAcc)a ^ (UAcc)b) : (Acc)((UAcc)a + (UAcc)b); };
     Acc inc[NOPS];
     uint32_t fin = fl;
 #pragma unroll
@@ -1203,7 +1216,7 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
       if (lane >= (uint32_t)dlt) {
 #pragma unroll
         for (int o = 0; o < NOPS; ++o)
-          if (!(fin & (1u << o))) inc[o] = (Acc)((UAcc)inc[o] + (UAcc)ov[o]);
+          if (!(fin & (1u << o))) inc[o] = comb(o, inc[o], ov[o]);
         fin |= of;
       }
     }
@@ -1224,7 +1237,7 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
         const Acc* rec = reinterpret_cast<const Acc*>(scanrec + w * L::kWaveRec);
         const uint32_t rf = *reinterpret_cast<const uint32_t*>(scanrec + w * L::kWaveRec + NOPS * sizeof(Acc));
 #pragma unroll
-        for (int o = 0; o < NOPS; ++o) in[o] = (rf & (1u << o)) ? rec[o] : (Acc)((UAcc)in[o] + (UAcc)rec[o]);
+        for (int o = 0; o < NOPS; ++o) in[o] = (rf & (1u << o)) ? rec[o] : comb(o, in[o], rec[o]);
       }
       const uint32_t pf = (uint32_t)__shfl_up((int)fin, 1);
 #pragma unroll
@@ -1232,7 +1245,7 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
         Acc pv;
         if (WIDE) pv = (Acc)__shfl_up((long long)inc[o], 1);
         else pv = (Acc)__shfl_up((int)inc[o], 1);
-        if (lane > 0u) in[o] = (pf & (1u << o)) ? pv : (Acc)((UAcc)in[o] + (UAcc)pv);
+        if (lane > 0u) in[o] = (pf & (1u << o)) ? pv : comb(o, in[o], pv);
       }
     }
     // ---- second walk: final values, converted and stored
@@ -1244,6 +1257,7 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
         if ((valid >> j) & 1u) {
           const bool mk = (marks >> j) & 1u;
           const bool rw = (raws >> j) & 1u;
+          const bool xr = (xors >> j) & 1u;
           Acc cur = 0;
           uint32_t kind = 0u, size = 0u, off = 0xffffffffu;
           float resf = 0.0f;
@@ -1251,7 +1265,7 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
 #pragma unroll
           for (int oo = 0; oo < NOPS; ++oo) {
             if (o == (uint32_t)oo) {
-              in[oo] = rw ? d[j] : (mk ? (Acc)0 : (Acc)((UAcc)in[oo] + (UAcc)d[j]));
+              in[oo] = xr ? (Acc)((UAcc)in[oo] ^ (UAcc)d[j]) : (rw ? d[j] : (mk ? (Acc)0 : (Acc)((UAcc)in[oo] + (UAcc)d[j])));
               cur = in[oo];
               const DevOp& op = op_at(oo);
               kind = op.kind;

@@ -41,8 +41,12 @@ layouts = {
         {"x": p[:, 0], "y": p[:, 1], "z": p[:, 2], "intensity": inten, "ring": (np.arange(n) % 64).astype(np.uint16),
          "timestamp": 1.7e9 + np.arange(n) * 1e-5}),
 }
+from cloudini_amd.schema import EncodingOptions
+layouts["xyzi_f32_lossless (EncodingOptions::LOSSLESS: XOR-coded floats)"] = (
+    [("x", 0, F.FLOAT32, None), ("y", 4, F.FLOAT32, None), ("z", 8, F.FLOAT32, None), ("intensity", 12, F.FLOAT32, None)], 16,
+    {"x": p[:, 0], "y": p[:, 1], "z": p[:, 2], "intensity": inten})
 for name, (fields, step, cols) in layouts.items():
-    info = cases.make_info(fields, step, n)
+    info = cases.make_info(fields, step, n, enc=EncodingOptions.LOSSLESS) if "lossless" in name else cases.make_info(fields, step, n)
     data = cases.pack(info, cols, n)
     n_clouds = 16
     d_points = torch.from_numpy(np.concatenate([data] * n_clouds)).to(dev)
