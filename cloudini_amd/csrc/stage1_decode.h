@@ -892,6 +892,38 @@ __global__ __launch_bounds__(kMtThreads) void k_mark_token_ends(const DevPlan pl
     reg_end[c] = 0u;
   }
   __syncthreads();
+  {
+    // every op raw (EncodingOptions::NONE, lossless floats): a point has a fixed size and the ends follow from the byte
+    // index alone -- the threads write the bitmap's words directly
+    uint32_t fixed = 0u;
+    bool all_raw = true;
+    for (uint32_t o = 0; o < n_ops; ++o) {
+      all_raw = all_raw && raw_size[o] != 0u;
+      fixed += raw_size[o];
+    }
+    if (all_raw) {  // uniform
+      if ((uint64_t)fixed * n > src_size) {
+        if (tid == 0) reg_end[c] = kDecRedo;  // truncated: the serial decoder raises the error
+        return;
+      }
+      const uint32_t used = fixed * n;
+      for (uint32_t w = tid; w < (used + 31u) / 32u; w += kMtThreads) {
+        uint32_t r = (w * 32u) % fixed, bits = 0u;
+        for (uint32_t b = 0; b < 32u && w * 32u + b < used; ++b) {
+          uint32_t acc = 0u;  // r + 1 == an op's end offset inside the point?
+          bool is_end = false;
+          for (uint32_t o = 0; o < n_ops; ++o) {
+            acc += raw_size[o];
+            is_end = is_end || r + 1u == acc;
+          }
+          if (is_end) bits |= 1u << b;
+          r = r + 1u == fixed ? 0u : r + 1u;
+        }
+        out_words[w] = bits;
+      }
+      return;
+    }
+  }
   // levels of the doubling: 2^levels > the most points a tile can hold (the plan knows a point's fewest bytes)
   uint32_t levels = 1u;
   while (levels < kMtLevels && (1u << levels) <= kMtTile / max(1u, plan.min_regular_bytes)) ++levels;
