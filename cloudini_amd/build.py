@@ -42,15 +42,46 @@ def _sources(folder: str, exts) -> list:
     return sorted(out)
 
 
+def _compile_one(src: str, obj: str, verbose: bool) -> None:
+    cmd = [HIPCC] + HIP_FLAGS + ["-c", "-MD", "-MF", obj + ".d", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+
+
+def _depfile_sources(depfile: str):
+    """Headers of this repository a translation unit included last time (make-style depfile of -MD), or None."""
+    if not os.path.exists(depfile):
+        return None
+    text = open(depfile).read().replace("\\\n", " ")
+    deps = [t for t in text.split()[1:] if t.startswith(ROOT) and os.path.exists(t)]
+    return deps or None
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
+    """Every .hip translation unit is compiled to an object under build/ (side by side), then linked."""
+    from concurrent.futures import ThreadPoolExecutor
+
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, "stage1_kernels.hip"), os.path.join(CSRC, "viz_kernels.hip"),
-            os.path.join(CSRC, "lz4_kernels.hip"), os.path.join(CSRC, "hip_abi.hip")]
-    deps = _sources(CSRC, (".hip", ".h")) + _sources(os.path.join(ROOT, "include"), (".h",))
+    objdir = os.path.join(ROOT, "build", "hip")
+    os.makedirs(objdir, exist_ok=True)
+    names = ["stage1_kernels", "stage1_decode", "viz_kernels", "lz4_kernels", "hip_abi"]
+    deps = _sources(CSRC, (".h",)) + _sources(os.path.join(ROOT, "include"), (".h",))
     deps = [d for d in deps if os.sep + "host" + os.sep not in d]
-    if force or _newer(HIP_SO, deps):
-        cmd = [HIPCC] + HIP_FLAGS + ["-shared", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + srcs + \
-              ["-o", HIP_SO]
+    jobs = []
+    for n in names:
+        src = os.path.join(CSRC, n + ".hip")
+        obj = os.path.join(objdir, n + ".o")
+        mine = _depfile_sources(obj + ".d") or (deps + [src])
+        if force or _newer(obj, mine):
+            jobs.append((src, obj))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            for f in [ex.submit(_compile_one, s, o, verbose) for s, o in jobs]:
+                f.result()
+    objs = [os.path.join(objdir, n + ".o") for n in names]
+    if force or jobs or _newer(HIP_SO, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", HIP_SO]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
@@ -90,10 +121,25 @@ def build_tools(force: bool = False, verbose: bool = False) -> str:
     return TRANSCODE_BIN
 
 
+CALIB_BIN = os.path.join(LIBDIR, "hbm_calib")
+
+
+def build_calib(force: bool = False, verbose: bool = False) -> str:
+    """HBM calibrator (tools/hbm_calib.hip): what hand-written copy kernels reach on the box."""
+    src = os.path.join(ROOT, "tools", "hbm_calib.hip")
+    if force or _newer(CALIB_BIN, [src]):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", src, "-o", CALIB_BIN]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return CALIB_BIN
+
+
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_hip(force, verbose)
     build_host(force, verbose)
     build_tools(force, verbose)
+    build_calib(force, verbose)
 
 
 if __name__ == "__main__":

@@ -429,7 +429,8 @@ void decodeGpuPhase(Batch& b, TranscodeStats* stats) {
       p.points = pts;
       // batchable only when the message's own geometry is the header's (always, for streams this library or the
       // reference wrote); anything else takes the single-message path in the wrap phase
-      if (pts * p.info.point_step == cloud_bytes && pts != 0) p.key = schemaKey(p.info);
+      // (wire version 2 has no chunk framing -- one unframed payload, src/cloudini.cpp:665-667 -- and goes one by one too)
+      if (pts * p.info.point_step == cloud_bytes && pts != 0 && p.info.version >= 3) p.key = schemaKey(p.info);
     }
     if (stats) {
       stats->messages += 1;

@@ -1093,6 +1093,9 @@ size_t stage1ChunkBound(const EncodingInfo& info) {
 void decodeStage1Batch(const EncodingInfo& info, const uint8_t* streams, const uint64_t* offsets, const uint64_t* cloud_points,
                        uint32_t n_clouds, uint8_t* out, uint64_t out_capacity, bool out_is_zero) {
   if (info.point_step == 0) throw std::runtime_error("point_step cannot be 0");
+  // framed streams only: a wire-version-2 payload has no [u32 size] prefixes (PointcloudDecoder::decode takes it through
+  // cldn_hip_decode_stage1_unframed); its first bytes must never be read as a chunk size here
+  if (info.version < 3) throw std::runtime_error("decodeStage1Batch: framed streams (wire version >= 3) only");
   PlanHandle plan(info);
   cldn_hip_codec_t* codec = pool().acquire(info, plan);
   cldn_hip_codec_set_decode_fill(codec, out_is_zero ? CLDN_HIP_FILL_ZERO : CLDN_HIP_FILL_KEEP);

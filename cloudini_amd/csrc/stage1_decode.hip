@@ -1,0 +1,222 @@
+// stage1_decode.hip -- the decode translation unit: stage-1 decode kernels (stage1_decode.h, stage1_decode_fast.h,
+// stage1_decode_wave.h) and their launchers. Split from stage1_kernels.hip so that the two halves compile side by side.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
+
+#include "stage1_device.h"
+#include "stage1_math.h"
+#include "stage1_prims.h"
+
+#include "stage1_decode.h"
+#include "stage1_decode_fast.h"
+#include "stage1_decode_wave.h"
+
+#include "cloudini_hip.h"
+#include "stage1_launch.h"
+
+namespace cldn {
+
+namespace {
+int hip_fail(hipError_t e, const char* what) { return launch_fail(e, what); }
+}  // namespace
+
+int stage1_configure_decode() {
+  hipError_t e;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_varint<4, false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Dv2Lds<4, false, 16>::kTotal);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_varint<4>)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_varint<8, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)Dv2Lds<8, true, 8>::kTotal);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_varint<8>)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)std::max<uint32_t>(std::max<uint32_t>((uint32_t)Dv2Lds<4, false, 16>::kTotal, kSmallSecLds), (uint32_t)DecSecLds::kTotal));
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_tail)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sections),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecSecLds::kTotal);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_sections)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sections_cols),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecSecLds::kTotal);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_sections_cols)");
+  return CLDN_HIP_OK;
+}
+
+static_assert(sizeof(DecChunk) <= kDecChunkBytes, "DecodeLaunch::chunks entries must hold a DecChunk");
+
+// wire version 2: one unframed payload, decoded by the serial restatement of DecodeV4Stage1Chunk (one lane)
+int stage1_launch_decode_unframed(const DevPlan& plan, hipStream_t stream, const uint8_t* payload, uint32_t size,
+                                  uint32_t capacity_points, void* chunk_slot, uint8_t* out, uint32_t* status) {
+  DecChunk dc;
+  dc.src_off = 0;
+  dc.src_size = size;
+  dc.n_points = capacity_points;
+  dc.first_point = 0;
+  dc.cloud = 0;
+  dc.valid = 2u;
+  hipError_t e = hipMemcpyAsync(chunk_slot, &dc, sizeof(dc), hipMemcpyHostToDevice, stream);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(DecChunk)");
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return hip_fail(e, "hipStreamSynchronize");  // `dc` lives on this frame
+  hipLaunchKernelGGL(k_decode_general, dim3(1), dim3(64), 0, stream, plan, payload, reinterpret_cast<const DecChunk*>(chunk_slot),
+                     out, 0u, 0u, (const uint32_t*)nullptr, (const uint8_t*)nullptr, status);
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_general");
+  return CLDN_HIP_OK;
+}
+
+int stage1_launch_decode(const DecodeLaunch& L) {
+  hipError_t e;
+  if (L.n_clouds == 0) return CLDN_HIP_OK;
+  if (L.chunk_sizes) {
+    hipLaunchKernelGGL(k_build_chunks, dim3(L.n_clouds), dim3(256), 0, L.stream, L.streams, L.stream_offsets, L.cloud_first_point,
+                       L.cloud_first_chunk, L.chunk_sizes, reinterpret_cast<DecChunk*>(L.chunks), L.status);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_build_chunks");
+  } else {
+    hipLaunchKernelGGL(k_walk_chunks, dim3((L.n_clouds + 63u) / 64u), dim3(64), 0, L.stream, L.streams, L.stream_offsets,
+                       L.cloud_first_point, L.cloud_first_chunk, L.n_clouds, reinterpret_cast<DecChunk*>(L.chunks),
+                       L.status);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_walk_chunks");
+  }
+  if (L.n_chunks) {
+    // regular streams made of varint tokens only go through the parallel kernel; the general kernel then decodes
+    // the V5 sections (and whole chunks the fast kernel handed back)
+    const DevPlan& P = *L.plan;
+    static const bool no_fast = getenv("CLDN_HIP_NO_FAST_DECODE") != nullptr;  // A/B switch
+    bool fast = !no_fast && P.all_varint && P.n_ops <= 8u;  // no regular ops at all (integer-only V5 cloud) is fine too
+    bool all_qf32 = true;
+    for (uint32_t k = 0; k < P.n_ops; ++k) all_qf32 = all_qf32 && P.ops[k].kind == OP_QF32;
+    // FloatN streams (3 or 4 int32-delta tokens per point): point-parallel kernel with the Palette sections folded in;
+    // it hands irregular chunks back (reg_end = kDecRedo) and k_decode_varint redoes only those
+    static const bool no_points = getenv("CLDN_HIP_NO_POINT_DECODE") != nullptr;  // A/B switch
+    const bool points_kernel = fast && !no_points && all_qf32 && (P.n_ops == 3u || P.n_ops == 4u) && P.n_gorilla == 0u;
+    if (points_kernel) {
+      // NF: Palette sections the launch can fold into the point pass (sizes its LDS)
+      const uint32_t nf = (L.uses_v5 && P.n_adaptive <= kFastPalFields) ? P.n_adaptive : 0u;
+      // sections that are no small palettes go to dense columns first (every point is then written once)
+      static const bool no_cols = getenv("CLDN_HIP_NO_DECODE_COLS") != nullptr;  // A/B switch
+      bool cols = !no_cols && nf != 0u && L.cols[0] != nullptr && L.sec_cols != nullptr;
+      for (uint32_t a = 0; a < P.n_adaptive && cols; ++a) cols = P.adaptive[a].bpv <= 4u && L.cols[a] != nullptr;
+      if (cols) {
+        {
+          static const int lw = getenv("CLDN_HIP_LOCATE_WAVES") ? atoi(getenv("CLDN_HIP_LOCATE_WAVES")) : 0;  // A/B switch
+          const bool wide = lw >= 16;  // (16 waves per chunk measured slower on C3 / C4 / C5: 0.452 / 0.572 / 0.140 against 0.433 / 0.552 / 0.137 ms)
+          if (wide) hipLaunchKernelGGL(k_locate_sections<16>, dim3(L.n_chunks), dim3(1024), 0, L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done);
+          else hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
+        static const bool no_scf = getenv("CLDN_HIP_NO_FAST_COLS") != nullptr;  // A/B switch
+        const bool scf = !no_scf && P.n_adaptive == 1u && L.slice_rec != nullptr && L.slices_done != nullptr;
+        if (scf) {
+          // workgroups per chunk: one when the batch has chunks enough to fill the chip (C3, 512 chunks: 0.404 / 0.400 /
+          // 0.402 / 0.404 ms with 1 / 2 / 4 / 8; workgroups that find nothing to share cost C4 about 20 us per
+          // 1024 of them), more for a single cloud's few chunks
+          static const int parts_env = getenv("CLDN_HIP_SCF_PARTS") ? atoi(getenv("CLDN_HIP_SCF_PARTS")) : 0;  // A/B switch
+          uint32_t parts = parts_env > 0 ? (uint32_t)parts_env : (512u + L.n_chunks - 1u) / L.n_chunks;
+          parts = std::min<uint32_t>(std::max<uint32_t>(parts, 1u), kScfMaxParts);
+          hipLaunchKernelGGL(k_sections_cols_fast, dim3(L.n_chunks * parts), dim3(kScfThreads), 0, L.stream, P, L.streams,
+                             reinterpret_cast<const DecChunk*>(L.chunks), L.cols[0], L.reg_end_pre, L.sec_cols, L.slices_done,
+                             L.slice_rec, L.slice_epoch, parts);
+          if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_cols_fast");
+        }
+        hipLaunchKernelGGL(k_decode_sections_cols, dim3(L.n_chunks), dim3(kDvThreads), (DecSecLds::kTotal), L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.cols[0], L.cols[1], L.reg_end_pre, L.sec_cols,
+                           scf ? 1u : 0u);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_sections_cols");
+      }
+      const uint8_t* c0 = cols ? L.cols[0] : nullptr;
+      const uint8_t* c1 = cols ? L.cols[1] : nullptr;
+      const uint8_t* sc = cols ? L.sec_cols : nullptr;
+      const uint32_t fill_zero = L.fill_zero ? 1u : 0u;
+      // round 4: the barrier-free kernel (stage1_decode_wave.h) is the default; CLDN_HIP_POINT_KERNEL=tiles brings the
+      // tile kernel back (A/B in the same binary), =w8 runs it with 8 waves per workgroup instead of 16
+      static const char* pk_env = getenv("CLDN_HIP_POINT_KERNEL");
+      static const int pk = pk_env == nullptr ? 16 : (strcmp(pk_env, "tiles") == 0 ? 0 : (strcmp(pk_env, "w8") == 0 ? 8 : 16));
+#define LAUNCH_POINTS(NOPS_, NF_)                                                                                         \
+  hipLaunchKernelGGL((k_decode_points<NOPS_, NF_>), dim3(L.n_chunks), dim3(kFpThreads), (FpLds<NOPS_, NF_>::kTotal), L.stream, \
+                     P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5,  \
+                     L.status, c0, c1, L.reg_end_pre, sc, fill_zero)
+#define LAUNCH_POINTS_W(NOPS_, NF_, NW_)                                                                                  \
+  hipLaunchKernelGGL((k_decode_points_w<NOPS_, NF_, NW_>), dim3(L.n_chunks), dim3(NW_ * 64), (WpLds<NOPS_, NF_, NW_>::kTotal), \
+                     L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done,   \
+                     L.uses_v5, L.status, c0, c1, L.reg_end_pre, sc, fill_zero)
+#define LAUNCH_POINTS_ANY(NOPS_, NF_)                      \
+  {                                                        \
+    if (pk == 0) LAUNCH_POINTS(NOPS_, NF_);                \
+    else if (pk == 8) LAUNCH_POINTS_W(NOPS_, NF_, 8);      \
+    else LAUNCH_POINTS_W(NOPS_, NF_, 16);                  \
+  }
+      if (P.n_ops == 3u) {
+        if (nf == 0u) LAUNCH_POINTS_ANY(3, 0)
+        else if (nf == 1u) LAUNCH_POINTS_ANY(3, 1)
+        else LAUNCH_POINTS_ANY(3, 2)
+      } else {
+        if (nf == 0u) LAUNCH_POINTS_ANY(4, 0)
+        else if (nf == 1u) LAUNCH_POINTS_ANY(4, 1)
+        else LAUNCH_POINTS_ANY(4, 2)
+      }
+#undef LAUNCH_POINTS_ANY
+#undef LAUNCH_POINTS_W
+#undef LAUNCH_POINTS
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_points");
+    }
+    // Behind k_decode_points, for plans whose sections it can fold, the rest is normally idle: one launch covers it
+    // (plans with more adaptive fields keep the separate kernels: their Palette chunks really run k_decode_sections_small,
+    // which wants its own, smaller LDS footprint)
+    static const bool no_tail = getenv("CLDN_HIP_NO_DECODE_TAIL") != nullptr;  // A/B switch
+    const bool sections_any = L.uses_v5 && P.n_adaptive > 0u;
+    if (points_kernel && !no_tail && (!sections_any || P.n_adaptive <= kFastPalFields)) {
+      const uint32_t lds = sections_any ? std::max<uint32_t>(std::max<uint32_t>((uint32_t)Dv2Lds<4, false, 16>::kTotal, kSmallSecLds), (uint32_t)DecSecLds::kTotal)
+                                        : (uint32_t)Dv2Lds<4, false, 16>::kTotal;
+      hipLaunchKernelGGL(k_decode_tail, dim3(L.n_chunks), dim3(kDvThreads), lds, L.stream, P, L.streams,
+                         reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.status, L.uses_v5,
+                         sections_any ? 1u : 0u);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_tail");
+      return CLDN_HIP_OK;
+    }
+    // regular streams with raw (FieldEncoderCopy) fields between the varints: k_mark_token_ends lays out where the tokens
+    // end, the 64-bit token kernel takes the ends from there (the plan says whether the stream has that form)
+    static const bool no_mixed = getenv("CLDN_HIP_NO_MIXED_DECODE") != nullptr;  // A/B switch
+    const bool mixed = !fast && !no_fast && !no_mixed && P.varint_and_raw != 0u && L.token_ends != nullptr;
+    if (mixed) {
+      hipLaunchKernelGGL(k_mark_token_ends, dim3(L.n_chunks), dim3(kMtThreads), 0, L.stream, P, L.streams,
+                         reinterpret_cast<const DecChunk*>(L.chunks), L.token_ends, L.reg_end);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_mark_token_ends");
+      hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<8, true, 8>::kTotal),
+                         L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, 0u,
+                         (const uint32_t*)L.token_ends);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_varint (mixed)");
+      fast = true;  // from here on like any stream the parallel kernels have taken
+    } else if (fast) {
+      if (all_qf32 && P.n_ops <= 4u)
+        hipLaunchKernelGGL((k_decode_varint<4, false>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<4, false, 16>::kTotal),
+                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status,
+                           points_kernel ? 1u : 0u, (const uint32_t*)nullptr);
+      else
+        hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<8, true, 8>::kTotal),
+                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, 0u,
+                           (const uint32_t*)nullptr);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_varint");
+    }
+    const bool fast_sections = fast && L.uses_v5 && P.n_adaptive > 0u;
+    if (fast_sections) {
+      hipLaunchKernelGGL(k_decode_sections_small, dim3(L.n_chunks), dim3(kDvThreads), kSmallSecLds, L.stream, P, L.streams,
+                         reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status,
+                         points_kernel ? 1u : 0u);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_sections_small");
+      hipLaunchKernelGGL(k_decode_sections, dim3(L.n_chunks), dim3(kDvThreads), (DecSecLds::kTotal), L.stream, P, L.streams,
+                         reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_sections");
+    }
+    hipLaunchKernelGGL(k_decode_general, dim3(L.n_chunks), dim3(64), 0, L.stream, P, L.streams,
+                       reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.uses_v5, fast ? 1u : 0u,
+                       (const uint32_t*)L.reg_end, fast_sections ? (const uint8_t*)L.sec_done : (const uint8_t*)nullptr,
+                       L.status);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_general");
+  }
+  return CLDN_HIP_OK;
+}
+
+}  // namespace cldn

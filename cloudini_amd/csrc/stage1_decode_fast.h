@@ -713,53 +713,24 @@ __global__ __launch_bounds__(kDvThreads) void k_decode_sections_cols(const DevPl
   if (ok && tid == 0) sec_cols[c] = 1u;
 }
 
-template <int NOPS, int NF>
-__global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decode_points(const DevPlan plan, const uint8_t* __restrict__ streams,
-                                                              const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
-                                                              uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done,
-                                                              uint32_t uses_v5, uint32_t* __restrict__ status,
-                                                              const uint8_t* __restrict__ col0, const uint8_t* __restrict__ col1,
-                                                              const uint32_t* __restrict__ reg_end_pre,
-                                                              const uint8_t* __restrict__ sec_cols, uint32_t fill_zero) {
-  using L = FpLds<NOPS, NF>;
-  constexpr uint32_t NFA = NF ? NF : 1;  // array extents (NF == 0: nothing is ever folded)
-  constexpr int T = kFpThreads;
-  constexpr uint32_t NW = kFpThreads / 64u;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint32_t* tile = reinterpret_cast<uint32_t*>(smem + L::kTileOff);             // dwords; byte 16 = first tile byte
-  uint16_t* pos_list = reinterpret_cast<uint16_t*>(smem + L::kPosOff);          // [0] = end of the token before the tile
-  float* stage = reinterpret_cast<float*>(smem);                                // overlays tile and list in phase B
-  uint8_t* scanrec = smem + L::kScanOff;
-  uint32_t* pal = reinterpret_cast<uint32_t*>(smem + L::kPalOff);
-  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + L::kMiscOff);             // [0] irregular, [2..34) scan scratch,
-                                                                                // [40..) pre-pass, [64..) sections
-  const uint32_t c = blockIdx.x;
+// ---------------------------------------------------------------------------------------------------------------
+// fp_setup: what both point kernels (k_decode_points, k_decode_points_w) do before their first byte of regular stream:
+// find out where the chunk's sections begin if that is cheap (columns from k_decode_sections_cols, or a lone Palette seen
+// from the end of the payload, or -- two fields, no columns -- a count over the payload), read the headers of sections
+// that can be folded into the point pass and copy their palette tables to LDS. All threads of the workgroup call it
+// (barriers inside). misc: [40] pre-pass result, [42..44) guess scratch, [44..60) wave counts, [64] folded sections,
+// [68..) table offsets, [72..) FpSection records. Returns reg_size (0xffffffff = unknown), *from_cols_out.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NOPS, int NF, int T>
+__device__ __forceinline__ uint32_t fp_setup(const DevPlan& plan, const uint8_t* __restrict__ src, uint32_t src_size, uint32_t n,
+                                             uint32_t uses_v5, uint32_t c, const uint32_t* __restrict__ reg_end_pre,
+                                             const uint8_t* __restrict__ sec_cols, uint32_t* misc, uint32_t* pal,
+                                             bool* from_cols_out) {
+  constexpr uint32_t NW = (uint32_t)T / 64u;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const DecChunk dc = chunks[c];
-  if (!dc.valid) {
-    if (tid == 0) sec_done[c] = 0u;
-    return;
-  }
-  const uint8_t* src = streams + dc.src_off;
-  const uint32_t src_size = dc.src_size;
-  const uint32_t n = dc.n_points;
-  const uint32_t step = plan.point_step;
-  uint8_t* base = out + (size_t)dc.first_point * step;
   const uint32_t target = n * NOPS;
-
-  if (tid < 4u) tile[tid] = 0u;  // the 16 bytes in front of a tile: token ends
-  if (tid == 0) {
-    misc[0] = 0u;
-    misc[1] = 0u;            // a folded Palette index was out of range
-    misc[40] = 0xffffffffu;  // pre-pass: payload offset behind the regular stream
-    misc[42] = 0xffffffffu;  // entries of the Palette section found by its size (smallest hit)
-    misc[64] = 0u;           // sections folded in
-  }
-  if (tid < (uint32_t)(NOPS + 2)) reinterpret_cast<uint32_t*>(scanrec + 16u * L::kWaveRec)[tid] = 0u;  // carry of tile 0: values 0
-  __syncthreads();
-
   // ---------------------------------------------------------------------------------------------------------
   // pre-pass: the payload offset behind token number `target`. Wave w counts the token ends of its 1/16 of the
   // payload; the wave that holds the last token walks its part again and finds the byte.
@@ -878,6 +849,57 @@ __global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8
     }
     __syncthreads();
   }
+  *from_cols_out = from_cols;
+  return reg_size;
+}
+
+template <int NOPS, int NF>
+__global__ __launch_bounds__(kFpThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decode_points(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                              const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
+                                                              uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done,
+                                                              uint32_t uses_v5, uint32_t* __restrict__ status,
+                                                              const uint8_t* __restrict__ col0, const uint8_t* __restrict__ col1,
+                                                              const uint32_t* __restrict__ reg_end_pre,
+                                                              const uint8_t* __restrict__ sec_cols, uint32_t fill_zero) {
+  using L = FpLds<NOPS, NF>;
+  constexpr uint32_t NFA = NF ? NF : 1;  // array extents (NF == 0: nothing is ever folded)
+  constexpr int T = kFpThreads;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem + L::kTileOff);             // dwords; byte 16 = first tile byte
+  uint16_t* pos_list = reinterpret_cast<uint16_t*>(smem + L::kPosOff);          // [0] = end of the token before the tile
+  float* stage = reinterpret_cast<float*>(smem);                                // overlays tile and list in phase B
+  uint8_t* scanrec = smem + L::kScanOff;
+  uint32_t* pal = reinterpret_cast<uint32_t*>(smem + L::kPalOff);
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + L::kMiscOff);             // [0] irregular, [2..34) scan scratch,
+                                                                                // [40..) pre-pass, [64..) sections
+  const uint32_t c = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const DecChunk dc = chunks[c];
+  if (!dc.valid) {
+    if (tid == 0) sec_done[c] = 0u;
+    return;
+  }
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t src_size = dc.src_size;
+  const uint32_t n = dc.n_points;
+  const uint32_t step = plan.point_step;
+  uint8_t* base = out + (size_t)dc.first_point * step;
+
+  if (tid < 4u) tile[tid] = 0u;  // the 16 bytes in front of a tile: token ends
+  if (tid == 0) {
+    misc[0] = 0u;
+    misc[1] = 0u;            // a folded Palette index was out of range
+    misc[40] = 0xffffffffu;  // pre-pass: payload offset behind the regular stream
+    misc[42] = 0xffffffffu;  // entries of the Palette section found by its size (smallest hit)
+    misc[64] = 0u;           // sections folded in
+  }
+  if (tid < (uint32_t)(NOPS + 2)) reinterpret_cast<uint32_t*>(scanrec + 16u * L::kWaveRec)[tid] = 0u;  // carry of tile 0: values 0
+  __syncthreads();
+
+  bool from_cols = false;
+  const uint32_t reg_size = fp_setup<NOPS, NF, T>(plan, src, src_size, n, uses_v5, c, reg_end_pre, sec_cols, misc, pal, &from_cols);
   const uint32_t n_fold = misc[64];
 
   // folded Palette sections: parameters in (uniform) registers for the read-out

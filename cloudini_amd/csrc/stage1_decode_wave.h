@@ -1,0 +1,524 @@
+// stage1_decode_wave.h -- k_decode_points_w: the barrier-free point decoder (round 4). Same job and same interface as
+// k_decode_points (stage1_decode_fast.h): chunks whose regular stream is one fused FloatN encoder (3 or 4 int32-delta
+// varint tokens per point; FieldDecoderFloatN_Lossy::decode, src/field_decoder.cpp:43-86; decodeVarint,
+// include/cloudini_lib/encoding_utils.hpp:98-148), Palette sections folded in / integer fields taken from columns.
+//
+// k_decode_points walks a chunk in tiles of 8 KiB with five workgroup barriers per tile. Here a chunk's payload is cut
+// into PIECES of 1 KiB at fixed (16-byte aligned) addresses and ONE WAVE decodes a piece from its first byte to its
+// last store without meeting a barrier; the waves of the workgroup take the pieces round robin. What a piece needs
+// from the pieces in front of it are two small things, handed from wave to wave through tagged LDS records:
+//   chain 1  T0 = how many token ends lie in front of the piece (known as soon as a piece's bytes are loaded: one
+//            v_dot4 per dword turns the MSBs into an end mask, popcount, one DPP scan). It tells which of the piece's
+//            ends close a point (end number e closes a point iff (e + 1) % NOPS == 0) and which points those are. A
+//            piece OWNS the points that begin behind such an end (and piece 0 owns point 0); their bytes may reach
+//            into the next piece (32 bytes of halo).
+//   chain 2  the running values in front of the piece's first point (int32 per lane of the FloatN encoder, NaN markers
+//            reset a lane). A piece needs them only for its last step: it decodes all its tokens and scans the deltas
+//            (DPP prefix sums; a DPP segmented scan when a row holds a marker) relative to its own start, publishes
+//            its aggregate, and adds the carry right before the conversion to float and the stores.
+// Every record is one aligned 8-byte LDS word {tag = piece + 1, value}: no ordering between LDS operations is assumed.
+// A wave waits only for the piece in front of its own, which belongs to the neighbouring wave at the same step of its
+// loop -- all waves of a workgroup are resident, so the waits cannot deadlock; they are bounded all the same.
+// Inside a piece the work is row-shaped like in the piece kernel of the encoder: phase A writes where every owned point
+// starts into a wave-private list (which ends close points: a 256-entry lookup table per phase), phase B takes 64
+// consecutive points per row, ONE POINT PER LANE: 4-5 LDS dwords -> NOPS tokens in registers -> scan -> values. A lane
+// stores its own point, so a store instruction covers 64 consecutive points and nothing is staged or transposed.
+// Irregular chunks (a token longer than 4 bytes, an overlong zero, a short stream) are handed back exactly like
+// k_decode_points does (reg_end = kDecRedo -> k_decode_varint / the serial decoder raise the errors).
+#pragma once
+
+namespace cldn {
+
+constexpr uint32_t kWpPiece = 1024u;       // bytes of stream per piece: one aligned 16-byte unit per lane
+constexpr uint32_t kWpHalo = 32u;          // a point that starts at the piece's last byte has at most 4 * 4 + 3 bytes more
+constexpr uint32_t kWpRing = 64u;          // chain records (slot = piece % kWpRing, tagged)
+constexpr uint32_t kWpSpinLimit = 1u << 20;
+
+template <int NOPS>
+struct WpGeom {
+  static constexpr uint32_t kMaxPts = kWpPiece / NOPS + 2u;             // points a piece can own
+  static constexpr uint32_t kRows = (kMaxPts + 63u) / 64u;               // 6 (3 lanes), 5 (4 lanes)
+  static constexpr uint32_t kListBytes = (kMaxPts * 2u + 15u) & ~15u;
+  static constexpr uint32_t kWaveBytes = kWpPiece + kWpHalo + kListBytes;  // bytes, halo, list of point starts
+};
+
+template <int NOPS, int NF, int NW>
+struct WpLds {
+  static constexpr uint32_t kLutOff = (uint32_t)NW * WpGeom<NOPS>::kWaveBytes;   // u16 [NOPS][256]
+  static constexpr uint32_t kTrecOff = kLutOff + (uint32_t)NOPS * 512u;          // u64 [kWpRing]
+  static constexpr uint32_t kVrecOff = kTrecOff + kWpRing * 8u;                  // u64 [kWpRing][NOPS]
+  static constexpr uint32_t kPalOff = kVrecOff + kWpRing * (uint32_t)NOPS * 8u;
+  static constexpr uint32_t kMiscOff = kPalOff + (uint32_t)NF * kFastPalEntries * 4u;
+  static constexpr uint32_t kTotal = kMiscOff + 512u;
+};
+
+// bit j = byte j of the 16 ends a token (MSB clear): one v_dot4_u32_u8 per dword gathers the four MSBs
+__device__ __forceinline__ uint32_t wp_ends16(const uint32_t (&b)[4]) {
+  uint32_t lo = __builtin_amdgcn_udot4(b[0] & 0x80808080u, 0x08040201u, 0u, false);
+  lo = __builtin_amdgcn_udot4(b[1] & 0x80808080u, 0x80402010u, lo, false);
+  uint32_t hi = __builtin_amdgcn_udot4(b[2] & 0x80808080u, 0x08040201u, 0u, false);
+  hi = __builtin_amdgcn_udot4(b[3] & 0x80808080u, 0x80402010u, hi, false);
+  return ~((lo >> 7) | (hi << 1)) & 0xffffu;  // (the sums are 128 x the masks of the bytes that CONTINUE)
+}
+
+// compiler-level ordering of a wave's own LDS traffic (the hardware keeps a wave's LDS operations in order)
+__device__ __forceinline__ void wp_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ unsigned long long wp_rec_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void wp_rec_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// inclusive segmented scan over the 64 lanes: inc[o] = sum of my lane's and the lanes' in front of me since the last lane
+// whose bit o of `fin` is set (that lane's own value included); fin becomes the OR of the flags up to my lane
+template <int NOPS>
+__device__ __forceinline__ void wp_seg_scan(int32_t (&inc)[NOPS], uint32_t& fin) {
+#define WP_SEG_STEP(CTRL, RMASK, BC)                                                                              \
+  {                                                                                                               \
+    const uint32_t of = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)fin, CTRL, RMASK, 0xf, BC);                 \
+    int32_t ov[NOPS];                                                                                             \
+    _Pragma("unroll") for (int o = 0; o < NOPS; ++o) ov[o] = __builtin_amdgcn_update_dpp(0, inc[o], CTRL, RMASK, 0xf, BC); \
+    _Pragma("unroll") for (int o = 0; o < NOPS; ++o)                                                              \
+      if (!(fin & (1u << o))) inc[o] = (int32_t)((uint32_t)inc[o] + (uint32_t)ov[o]);                             \
+    fin |= of;                                                                                                    \
+  }
+  WP_SEG_STEP(0x111, 0xf, true)   // row_shr:1 (lanes without a source read 0: nothing to add, no flag)
+  WP_SEG_STEP(0x112, 0xf, true)   // row_shr:2
+  WP_SEG_STEP(0x114, 0xf, true)   // row_shr:4
+  WP_SEG_STEP(0x118, 0xf, true)   // row_shr:8
+  WP_SEG_STEP(0x142, 0xa, false)  // row_bcast:15 -> rows 1, 3
+  WP_SEG_STEP(0x143, 0xc, false)  // row_bcast:31 -> rows 2, 3
+#undef WP_SEG_STEP
+}
+
+// The NOPS tokens of the point that starts at byte `byte0` of the wave's LDS copy -> deltas (0x80000000 = the NaN marker:
+// no token of at most 4 bytes decodes to it). Returns true when a token is irregular (no end within 4 bytes -- the chunk
+// goes to the 64-bit kernel -- or an overlong zero, which decodeVarint rejects); *zero: a token's value bits were all 0.
+template <int NOPS>
+__device__ __forceinline__ bool wp_tokens(const uint32_t* wbuf, uint32_t byte0, int32_t (&dlt)[NOPS], bool* zero) {
+  const uint32_t di = byte0 >> 2, sh = (byte0 & 3u) * 8u;
+  uint32_t d[NOPS + 1];
+#pragma unroll
+  for (int k = 0; k <= NOPS; ++k) d[k] = wbuf[di + (uint32_t)k];
+  uint32_t W[NOPS];  // W[k] = bytes [4k, 4k + 4) behind the current token's start
+#pragma unroll
+  for (int k = 0; k < NOPS; ++k) W[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
+  bool bad = false, z = false;
+#pragma unroll
+  for (int o = 0; o < NOPS; ++o) {
+    const uint32_t w = W[0];
+    const uint32_t t = ~w & 0x80808080u;                        // the bytes that can end the token
+    const uint32_t lo = w & ((t ^ (t - 1u)) & 0x7f7f7f7fu);     // value bits of the bytes up to the first of them
+    const uint32_t x1 = lo - ((lo & 0x7f007f00u) >> 1);         // 7-bit groups -> 14-bit groups
+    const uint32_t u = x1 - __umul24(x1 >> 16, 49152u);         // -> one value (< 2^28)
+    bad = bad || t == 0u || (lo == 0u && (w & 0x80u) != 0u);
+    z = z || lo == 0u;
+    const uint32_t u1 = u - 1u;
+    dlt[o] = (int32_t)((u1 >> 1) ^ (0u - (u1 & 1u)));           // u == 0 -> 0x80000000
+    if (o + 1 < NOPS) {
+      const uint32_t adv = (uint32_t)__ffs((int)t);             // bits of this token: 8, 16, 24, 32
+#pragma unroll
+      for (int k = 0; k + 1 < NOPS - o; ++k) W[k] = (uint32_t)(((((uint64_t)W[k + 1]) << 32) | W[k]) >> adv);
+    }
+  }
+  *zero = z;
+  return bad;
+}
+
+template <int NOPS, int NF, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decode_points_w(
+    const DevPlan plan, const uint8_t* __restrict__ streams, const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
+    uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done, uint32_t uses_v5, uint32_t* __restrict__ status,
+    const uint8_t* __restrict__ col0, const uint8_t* __restrict__ col1, const uint32_t* __restrict__ reg_end_pre,
+    const uint8_t* __restrict__ sec_cols, uint32_t fill_zero) {
+  using L = WpLds<NOPS, NF, NW>;
+  using G = WpGeom<NOPS>;
+  constexpr int T = NW * 64;
+  constexpr uint32_t NFA = NF ? NF : 1;  // array extents (NF == 0: nothing is ever folded)
+  constexpr uint32_t ROWS = G::kRows;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint16_t* lut = reinterpret_cast<uint16_t*>(smem + L::kLutOff);
+  unsigned long long* trec = reinterpret_cast<unsigned long long*>(smem + L::kTrecOff);
+  unsigned long long* vrec = reinterpret_cast<unsigned long long*>(smem + L::kVrecOff);
+  uint32_t* pal = reinterpret_cast<uint32_t*>(smem + L::kPalOff);
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + L::kMiscOff);  // [0] irregular, [1] palette index out of range,
+                                                                     // [2] end of the regular stream, [3] a wait gave up,
+                                                                     // [40..) fp_setup
+  const uint32_t c = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const DecChunk dc = chunks[c];
+  if (!dc.valid) {
+    if (tid == 0) sec_done[c] = 0u;
+    return;
+  }
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t src_size = dc.src_size;
+  const uint32_t n = dc.n_points;
+  const uint32_t step = plan.point_step;
+  uint8_t* base = out + (size_t)dc.first_point * step;
+  const uint32_t target = n * NOPS;
+
+  if (tid == 0) {
+    misc[0] = 0u;
+    misc[1] = 0u;
+    misc[2] = 0xffffffffu;
+    misc[3] = 0u;
+    misc[40] = 0xffffffffu;  // fp_setup: payload offset behind the regular stream
+    misc[42] = 0xffffffffu;  // fp_setup: entries of the Palette section found by its size
+    misc[64] = 0u;           // fp_setup: sections folded in
+  }
+  for (uint32_t i = tid; i < kWpRing * (1u + NOPS) * 2u; i += T) reinterpret_cast<uint32_t*>(trec)[i] = 0u;  // tags: none
+  // which ends of a byte's end mask close points when the first k0 of them do not: entry = mask | (next k0) << 8
+  for (uint32_t e = tid; e < (uint32_t)NOPS * 256u; e += T) {
+    uint32_t k = e >> 8, sel = 0u;
+    for (uint32_t bit = 0; bit < 8u; ++bit) {
+      if ((e >> bit) & 1u) {
+        if (k == 0u) {
+          sel |= 1u << bit;
+          k = (uint32_t)NOPS - 1u;
+        } else {
+          --k;
+        }
+      }
+    }
+    lut[e] = (uint16_t)(sel | (k << 8));
+  }
+  __syncthreads();
+
+  bool from_cols = false;
+  const uint32_t reg_size = fp_setup<NOPS, NF, T>(plan, src, src_size, n, uses_v5, c, reg_end_pre, sec_cols, misc, pal, &from_cols);
+  const uint32_t n_fold = misc[64];
+
+  // folded Palette sections / columns: parameters in (uniform) registers
+  uint32_t fs_off[NFA], fs_bpv[NFA], fs_count[NFA], fs_bits[NFA], fs_ioff[NFA];
+#pragma unroll
+  for (uint32_t a = 0; a < NFA; ++a) {
+    const FpSection sct = reinterpret_cast<const FpSection*>(misc + 72)[a < n_fold ? a : 0u];
+    fs_off[a] = sct.field_off;
+    fs_bpv[a] = sct.bpv;
+    fs_count[a] = sct.count;
+    fs_bits[a] = a < n_fold ? sct.bits : 0u;
+    fs_ioff[a] = a < n_fold ? sct.index_off : 0u;
+  }
+  // which store forms the layout allows (uniform)
+  bool contig = ((step | plan.ops[0].offset) & 3u) == 0u;
+#pragma unroll
+  for (int o = 1; o < NOPS; ++o) contig = contig && plan.ops[o].offset == plan.ops[0].offset + 4u * (uint32_t)o;
+  bool packed = true;  // the floats back to back at any alignment, all of them stored
+#pragma unroll
+  for (int o = 0; o < NOPS; ++o) packed = packed && plan.ops[o].offset != 0xffffffffu && plan.ops[o].offset == plan.ops[0].offset + 4u * (uint32_t)o;
+  float res[NOPS];
+  uint32_t foff[NOPS];
+#pragma unroll
+  for (int o = 0; o < NOPS; ++o) {
+    res[o] = plan.ops[o].res_f;
+    foff[o] = plan.ops[o].offset;
+  }
+  const bool one_u16 = NOPS == 3 && contig && n_fold == 1u && fs_bpv[0] == 2u && ((fs_off[0] | step) & 1u) == 0u;  // XYZ + one 16-bit field
+  // fill_zero (CLDN_HIP_FILL_ZERO: the bytes no field covers may be written as 0): the two common padded layouts leave
+  // as whole 16-byte stores
+  const bool full16 = fill_zero != 0u && one_u16 && step == 16u && foff[0] == 0u && fs_off[0] == 12u && ((uintptr_t)base & 15u) == 0u;
+  const bool full32 = fill_zero != 0u && NOPS == 3 && contig && n_fold == 1u && fs_bpv[0] == 4u && step == 32u && foff[0] == 0u &&
+                      fs_off[0] == 16u && ((uintptr_t)base & 15u) == 0u;
+
+  // ---------------------------------------------------------------------------------------------------------
+  // pieces. v = payload offset + a0 (a0 = misalignment of the payload): piece p holds v in [p, p + 1) * 1024
+  // ---------------------------------------------------------------------------------------------------------
+  const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
+  const uint8_t* src_al = src - a0;
+  const uint32_t vend = a0 + src_size;
+  const uint32_t n_pieces = src_size ? (vend + kWpPiece - 1u) / kWpPiece : 0u;
+  uint32_t* wbuf = reinterpret_cast<uint32_t*>(smem + wave * G::kWaveBytes);
+  uint16_t* plist = reinterpret_cast<uint16_t*>(smem + wave * G::kWaveBytes + kWpPiece + kWpHalo);
+
+  // an aligned unit that holds at least one payload byte lies in a mapped page; anything else is not touched (0xff:
+  // bytes that continue a token and end none)
+  auto load_unit = [&](uint32_t v0, uint32_t(&u)[4]) __attribute__((always_inline)) {
+    const bool ok = v0 < vend;
+    const uint4 w = *reinterpret_cast<const uint4*>(src_al + (ok ? v0 : 0u));
+    u[0] = ok ? w.x : 0xffffffffu;
+    u[1] = ok ? w.y : 0xffffffffu;
+    u[2] = ok ? w.z : 0xffffffffu;
+    u[3] = ok ? w.w : 0xffffffffu;
+  };
+
+  uint32_t b[4], bh[4];  // my unit of the piece; the halo's two units (every lane asks for unit lane & 1: no branch)
+  uint32_t p = wave;
+  if (n_pieces) {        // (no payload: nothing may be read)
+    load_unit(min(p, n_pieces) * kWpPiece + lane * 16u, b);
+    load_unit((min(p, n_pieces) + 1u) * kWpPiece + (lane & 1u) * 16u, bh);
+  }
+  bool gave_up = false;
+  for (; p < n_pieces; p += NW) {
+    // ---- bytes -> LDS, token ends
+    *reinterpret_cast<uint4*>(wbuf + lane * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
+    if (lane < 2u) *reinterpret_cast<uint4*>(wbuf + kWpPiece / 4u + lane * 4u) = make_uint4(bh[0], bh[1], bh[2], bh[3]);
+    const uint32_t v0 = p * kWpPiece + lane * 16u;
+    uint32_t ends = wp_ends16(b);
+    if (p * kWpPiece < a0 || (p + 1u) * kWpPiece > vend) {  // uniform: the payload's first / last piece
+      const uint32_t lo = a0 > v0 ? min(a0 - v0, 16u) : 0u;
+      const uint32_t hi = vend > v0 ? min(vend - v0, 16u) : 0u;
+      ends &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+    }
+    const uint32_t cl = (uint32_t)__builtin_popcount(ends);
+    const uint32_t incl = wave_inclusive_scan(cl);
+    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t tb = incl - cl;
+    // my next piece's bytes are requested now (b, bh are free)
+    {
+      const uint32_t pn = min(p + (uint32_t)NW, n_pieces);
+      load_unit(pn * kWpPiece + lane * 16u, b);
+      load_unit((pn + 1u) * kWpPiece + (lane & 1u) * 16u, bh);
+    }
+    // ---- chain 1: token ends in front of the piece
+    uint32_t T0 = 0u;
+    if (p != 0u) {
+      const unsigned long long* r = trec + ((p - 1u) & (kWpRing - 1u));
+      for (uint32_t spins = 0;; ++spins) {
+        const unsigned long long x = wp_rec_load(r);
+        if ((uint32_t)(x >> 32) == p) {
+          T0 = (uint32_t)x;
+          break;
+        }
+        if (spins >= kWpSpinLimit || *(volatile uint32_t*)&misc[3] != 0u) {
+          gave_up = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T0);
+    }
+    if (gave_up) break;  // uniform
+    if (lane == 0u) wp_rec_store(trec + (p & (kWpRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (T0 + cnt));
+    if (T0 >= target) break;  // the regular stream ended in front of this piece (sections; uniform)
+    if (T0 + cnt >= target) {  // uniform: the end that closes the last point lies in this piece
+      const uint32_t want = target - T0;  // its 1-based rank among the piece's ends
+      if (tb < want && want <= tb + cl) {
+        uint32_t m = ends;
+        for (uint32_t k = tb + 1u; k < want; ++k) m &= m - 1u;
+        misc[2] = v0 + (uint32_t)__builtin_ctz(m) + 1u - a0;
+      }
+    }
+    // ---- phase A: where the points this piece owns begin
+    const uint32_t A0 = T0 / (uint32_t)NOPS;
+    const uint32_t r0 = T0 - A0 * (uint32_t)NOPS;
+    const uint32_t extra = p == 0u ? 1u : 0u;             // piece 0 owns point 0 (list entry 0)
+    const uint32_t q_first = A0 + 1u - extra;             // < n (T0 < target)
+    const uint32_t npts = min((r0 + cnt) / (uint32_t)NOPS + extra, n - q_first);
+    {
+      const uint32_t x = r0 + tb;                         // <= 1026
+      const uint32_t a = NOPS == 4 ? (x >> 2) : ((x * 21846u) >> 16);  // x / NOPS
+      const uint32_t k0 = (uint32_t)NOPS - 1u - (x - a * (uint32_t)NOPS);
+      const uint32_t e0 = lut[k0 * 256u + (ends & 0xffu)];
+      const uint32_t e1 = lut[(e0 >> 8) * 256u + (ends >> 8)];
+      uint32_t sel = (e0 & 0xffu) | ((e1 & 0xffu) << 8);
+      uint32_t j = a + extra;
+      while (sel) {
+        plist[j] = (uint16_t)(lane * 16u + (uint32_t)__builtin_ctz(sel) + 1u);
+        ++j;
+        sel &= sel - 1u;
+      }
+      if (extra && lane == 0u) plist[0] = (uint16_t)a0;
+    }
+    wp_wave_sync();
+    // ---- phase B, first half: tokens -> values relative to the piece's start. bs = running value behind the rows so far
+    int32_t val[ROWS][NOPS];
+    uint32_t flagsv = 0u, marksv = 0u;  // bit 4 r + o: value r, o does not take the carry / is a NaN
+    int32_t bs[NOPS];
+    uint32_t bs_fl = 0u;
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) bs[o] = 0;
+    bool irregular = false;
+#pragma unroll
+    for (uint32_t r = 0; r < ROWS; ++r) {
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) val[r][o] = 0;
+      if (r * 64u < npts) {  // uniform
+        const uint32_t j = r * 64u + lane;
+        const bool have = j < npts;
+        const uint32_t byte0 = have ? (uint32_t)plist[j] : 0u;
+        int32_t dlt[NOPS];
+        bool zero;
+        const bool bad = wp_tokens<NOPS>(wbuf, byte0, dlt, &zero);
+        irregular = irregular || (have && bad);
+        if (__ballot(have && zero) == 0ull) {  // no marker in this row (the rule for lidar data): DPP prefix sums
+#pragma unroll
+          for (int o = 0; o < NOPS; ++o) {
+            const uint32_t inc = wave_inclusive_scan(have ? (uint32_t)dlt[o] : 0u);
+            val[r][o] = (int32_t)((uint32_t)bs[o] + inc);
+            bs[o] = (int32_t)((uint32_t)bs[o] + (uint32_t)__builtin_amdgcn_readlane((int)inc, 63));
+          }
+          flagsv |= bs_fl << (4u * r);
+        } else {
+          int32_t inc[NOPS];
+          uint32_t mk = 0u;
+#pragma unroll
+          for (int o = 0; o < NOPS; ++o) {
+            const bool m = have && dlt[o] == (int32_t)0x80000000;
+            mk |= m ? (1u << o) : 0u;
+            inc[o] = (m || !have) ? 0 : dlt[o];
+          }
+          uint32_t fin = mk;
+          wp_seg_scan<NOPS>(inc, fin);
+          const uint32_t f63 = (uint32_t)__builtin_amdgcn_readlane((int)fin, 63);
+#pragma unroll
+          for (int o = 0; o < NOPS; ++o) {
+            val[r][o] = (fin & (1u << o)) ? inc[o] : (int32_t)((uint32_t)bs[o] + (uint32_t)inc[o]);
+            const int32_t l63 = __builtin_amdgcn_readlane(inc[o], 63);
+            bs[o] = (f63 & (1u << o)) ? l63 : (int32_t)((uint32_t)bs[o] + (uint32_t)l63);
+          }
+          flagsv |= (fin | bs_fl) << (4u * r);
+          marksv |= mk << (4u * r);
+          bs_fl |= f63;
+        }
+      }
+    }
+    if (__ballot(irregular) != 0ull && lane == 0u) misc[0] = 1u;
+    // ---- chain 2: the values in front of the piece
+    int32_t carry[NOPS];
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) carry[o] = 0;
+    if (p != 0u) {
+      const unsigned long long* r = vrec + (size_t)((p - 1u) & (kWpRing - 1u)) * NOPS + min(lane, (uint32_t)NOPS - 1u);
+      unsigned long long x = 0ull;
+      for (uint32_t spins = 0;; ++spins) {
+        x = wp_rec_load(r);
+        if (__ballot((uint32_t)(x >> 32) != p) == 0ull) break;
+        if (spins >= kWpSpinLimit || *(volatile uint32_t*)&misc[3] != 0u) {
+          gave_up = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) carry[o] = __builtin_amdgcn_readlane((int)(uint32_t)x, o);
+    }
+    if (gave_up) break;  // uniform
+    {
+      uint32_t mine = 0u;
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) {
+        const uint32_t pre = (bs_fl & (1u << o)) ? (uint32_t)bs[o] : (uint32_t)carry[o] + (uint32_t)bs[o];
+        mine = lane == (uint32_t)o ? pre : mine;
+      }
+      if (lane < (uint32_t)NOPS)
+        wp_rec_store(vrec + (size_t)(p & (kWpRing - 1u)) * NOPS + lane, ((unsigned long long)(p + 1u) << 32) | mine);
+    }
+    // ---- phase B, second half: values -> floats -> the points. A lane stores its own point.
+    const bool piece_flags = bs_fl != 0u;  // uniform: a marker somewhere in the piece
+#pragma unroll
+    for (uint32_t r = 0; r < ROWS; ++r) {
+      if (r * 64u < npts) {  // uniform
+        const uint32_t j = r * 64u + lane;
+        const bool have = j < npts;
+        const uint32_t q = q_first + (have ? j : 0u);  // point of the chunk (lanes without one: a valid address, unused)
+        float f[NOPS];
+        if (!piece_flags) {
+#pragma unroll
+          for (int o = 0; o < NOPS; ++o) f[o] = __fmul_rn((float)(int32_t)((uint32_t)carry[o] + (uint32_t)val[r][o]), res[o]);
+        } else {
+#pragma unroll
+          for (int o = 0; o < NOPS; ++o) {
+            const uint32_t bit = 1u << (4u * r + (uint32_t)o);
+            const int32_t iv = (flagsv & bit) ? val[r][o] : (int32_t)((uint32_t)carry[o] + (uint32_t)val[r][o]);
+            f[o] = (marksv & bit) ? __uint_as_float(0x7fc00000u) : __fmul_rn((float)iv, res[o]);
+          }
+        }
+        uint32_t pv[NFA];
+#pragma unroll
+        for (uint32_t a = 0; a < NFA; ++a) pv[a] = 0u;
+        if (from_cols) {
+#pragma unroll
+          for (uint32_t a = 0; a < NFA; ++a) {
+            if (a >= n_fold) break;  // uniform
+            const uint8_t* colp = (a == 0u ? col0 : col1) + (size_t)dc.first_point * fs_bpv[a];
+            pv[a] = fs_bpv[a] == 2u ? (uint32_t)reinterpret_cast<const uint16_t*>(colp)[q] : reinterpret_cast<const uint32_t*>(colp)[q];
+          }
+        } else if (n_fold != 0u) {
+#pragma unroll
+          for (uint32_t a = 0; a < NFA; ++a) {
+            if (a >= n_fold) break;  // uniform
+            const uint32_t bits = fs_bits[a];
+            uint32_t idx = 0u;
+            if (bits != 0u) {  // uniform. (bits != 0: at least two table entries, the payload has 4 bytes)
+              const uint32_t bit0 = q * bits;                       // < 32768 * 10
+              const uint32_t o = fs_ioff[a] + (bit0 >> 3);          // payload offset of the index's first byte
+              const uint32_t oc = min(o, src_size - 4u);            // (the last indexes: the dword that ends with the payload)
+              uint32_t w;
+              __builtin_memcpy(&w, src + oc, 4);
+              idx = (w >> ((bit0 & 7u) + 8u * (o - oc))) & ((1u << bits) - 1u);
+            }
+            if (have && idx >= fs_count[a]) misc[1] = 1u;  // index beyond the palette: the serial decoder redoes the sections and raises the error
+            pv[a] = pal[a * kFastPalEntries + (idx & (kFastPalEntries - 1u))];
+          }
+        }
+        if (have) {
+          uint8_t* pt = base + (size_t)q * step;
+          if (full16) {
+            *reinterpret_cast<float4*>(pt) = make_float4(f[0], f[1], f[2], __uint_as_float(pv[0] & 0xffffu));
+          } else if (full32) {
+            reinterpret_cast<float4*>(pt)[0] = make_float4(f[0], f[1], f[2], 0.0f);
+            reinterpret_cast<float4*>(pt)[1] = make_float4(__uint_as_float(pv[0]), 0.0f, 0.0f, 0.0f);
+          } else {
+            if (contig) {
+              FloatVec<NOPS> v;
+#pragma unroll
+              for (int o = 0; o < NOPS; ++o) v.v[o] = f[o];
+              *reinterpret_cast<FloatVec<NOPS>*>(pt + foff[0]) = v;
+            } else if (packed) {  // the floats lie back to back at an odd address (18-byte points): ONE unaligned store
+              FloatVec<NOPS> v;
+#pragma unroll
+              for (int o = 0; o < NOPS; ++o) v.v[o] = f[o];
+              __builtin_memcpy(pt + foff[0], &v, NOPS * 4);
+            } else {
+#pragma unroll
+              for (int o = 0; o < NOPS; ++o)
+                if (foff[o] != 0xffffffffu) __builtin_memcpy(pt + foff[o], &f[o], 4);
+            }
+            if (one_u16) {
+              *reinterpret_cast<uint16_t*>(pt + fs_off[0]) = (uint16_t)pv[0];
+            } else {
+#pragma unroll
+              for (uint32_t a = 0; a < NFA; ++a) {
+                if (a >= n_fold) break;  // uniform
+                if (fs_bpv[a] == 2u) {
+                  const uint16_t h = (uint16_t)pv[a];
+                  __builtin_memcpy(pt + fs_off[a], &h, 2);
+                } else if (fs_bpv[a] == 4u) {
+                  __builtin_memcpy(pt + fs_off[a], &pv[a], 4);
+                } else {
+                  st_raw(pt + fs_off[a], pv[a], fs_bpv[a]);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    wp_wave_sync();  // the next piece's bytes and list overwrite this one's
+  }
+  if (gave_up && lane == 0u) {
+    misc[3] = 1u;
+    misc[0] = 1u;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t pos = misc[2];
+    const bool redo = misc[0] != 0u || pos == 0xffffffffu;
+    reg_end[c] = redo ? kDecRedo : pos;
+    const bool folded = !redo && n_fold != 0u && misc[1] == 0u && pos == reg_size;
+    sec_done[c] = folded ? 2u : 0u;
+    if (!redo) atomicAdd(&status[kStatFastRegular], 1u);
+    if (folded) atomicAdd(&status[kStatFastSections], 1u);
+  }
+}
+
+}  // namespace cldn

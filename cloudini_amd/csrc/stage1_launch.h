@@ -95,6 +95,7 @@ constexpr size_t kDecChunkBytes = 48;
 int launch_fail(hipError_t e, const char* what);
 
 int stage1_configure_kernels();
+int stage1_configure_decode();   // decode TU (stage1_decode.hip); called by stage1_configure_kernels
 int stage1_launch_encode(const EncodeLaunch& L);
 int stage1_launch_decode(const DecodeLaunch& L);
 int stage1_launch_decode_unframed(const DevPlan& plan, hipStream_t stream, const uint8_t* payload, uint32_t size,

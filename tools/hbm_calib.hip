@@ -1,0 +1,123 @@
+// hbm_calib.hip -- what this box's HBM delivers to hand-written kernels: the ceiling the
+// stage-1 kernels are held against, next to the 8 TB/s peak of MI355X_MICROARCH.md. Every kernel is a plain grid-stride
+// loop over 16-byte units; figures are total bytes moved (read + written) per second, best and median of the repeats.
+//
+//   copy        1 read : 1 write   (k_finish's copy half)
+//   read2write1 2 reads : 1 write  (the piece kernel's mix: 16 B of points in, ~6 B of stream + column out)
+//   write       fill
+//   read        sum (one store per workgroup)
+// each as plain and as non-temporal (__builtin_nontemporal_load/store) variant, for 256 / 512 / 1024-thread workgroups
+// and several grid sizes (workgroups per CU).
+//
+// build: hipcc --offload-arch=gfx950 -O3 tools/hbm_calib.hip -o cloudini_amd/lib/hbm_calib   (cloudini_amd/build.py does it)
+// run:   cloudini_amd/lib/hbm_calib [GiB per buffer, default 1]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                          \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess) {                                                               \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                             \
+      exit(1);                                                                            \
+    }                                                                                     \
+  } while (0)
+
+typedef float v4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ v4 ld(const v4* p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st(v4* p, v4 v) {
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+template <bool NT>
+__global__ void k_copy(const v4* __restrict__ a, v4* __restrict__ o, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) st<NT>(o + i, ld<NT>(a + i));
+}
+template <bool NT>
+__global__ void k_r2w1(const v4* __restrict__ a, const v4* __restrict__ b, v4* __restrict__ o, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) st<NT>(o + i, ld<NT>(a + i) + ld<NT>(b + i));
+}
+template <bool NT>
+__global__ void k_write(v4* __restrict__ o, size_t n, float x) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const v4 v = {x, x, x, x};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) st<NT>(o + i, v);
+}
+template <bool NT>
+__global__ void k_read(const v4* __restrict__ a, float* __restrict__ o, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  v4 s = {0, 0, 0, 0};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += ld<NT>(a + i);
+  const float t = s.x + s.y + s.z + s.w;
+  if (t == 123.456f) o[blockIdx.x] = t;  // (never true for the zero-filled buffers: keeps the loads alive)
+}
+
+template <class F>
+static void run(const char* name, double bytes, int threads, int wg_per_cu, int cus, F launch) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  const int grid = wg_per_cu * cus;
+  for (int w = 0; w < 3; ++w) launch(grid, threads);
+  std::vector<float> ms;
+  for (int r = 0; r < 9; ++r) {
+    CHECK(hipEventRecord(e0));
+    launch(grid, threads);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float t;
+    CHECK(hipEventElapsedTime(&t, e0, e1));
+    ms.push_back(t);
+  }
+  std::sort(ms.begin(), ms.end());
+  printf("%-16s threads %4d  wg/CU %2d  best %.3f ms = %.2f TB/s   median %.3f ms = %.2f TB/s\n", name, threads, wg_per_cu,
+         ms[0], bytes / ms[0] * 1e-9, ms[ms.size() / 2], bytes / ms[ms.size() / 2] * 1e-9);
+  CHECK(hipEventDestroy(e0));
+  CHECK(hipEventDestroy(e1));
+}
+
+int main(int argc, char** argv) {
+  const double gib = argc > 1 ? atof(argv[1]) : 1.0;
+  const size_t bytes = (size_t)(gib * (1ull << 30)) & ~(size_t)4095;
+  const size_t n = bytes / 16;
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  printf("device: %s, %d CUs, buffers of %.2f GiB\n", prop.name, cus, bytes / double(1ull << 30));
+  v4 *a, *b, *o;
+  float* s;
+  CHECK(hipMalloc(&a, bytes));
+  CHECK(hipMalloc(&b, bytes));
+  CHECK(hipMalloc(&o, bytes));
+  CHECK(hipMalloc(&s, 1 << 20));
+  CHECK(hipMemset(a, 0, bytes));
+  CHECK(hipMemset(b, 0, bytes));
+  CHECK(hipMemset(o, 0, bytes));
+  const int tvals[] = {256, 512, 1024};
+  const int wvals[] = {2, 4, 8, 16, 32};
+  for (int t : tvals)
+    for (int w : wvals) {
+      if (t * w > 2048 * 4) continue;  // more than fits a CU several times over tells nothing new
+      run("copy", 2.0 * bytes, t, w, cus, [&](int g, int th) { hipLaunchKernelGGL(k_copy<false>, dim3(g), dim3(th), 0, 0, a, o, n); });
+      run("copy nt", 2.0 * bytes, t, w, cus, [&](int g, int th) { hipLaunchKernelGGL(k_copy<true>, dim3(g), dim3(th), 0, 0, a, o, n); });
+      run("read2write1", 3.0 * bytes, t, w, cus, [&](int g, int th) { hipLaunchKernelGGL(k_r2w1<false>, dim3(g), dim3(th), 0, 0, a, b, o, n); });
+      run("read2write1 nt", 3.0 * bytes, t, w, cus, [&](int g, int th) { hipLaunchKernelGGL(k_r2w1<true>, dim3(g), dim3(th), 0, 0, a, b, o, n); });
+      run("write", 1.0 * bytes, t, w, cus, [&](int g, int th) { hipLaunchKernelGGL(k_write<false>, dim3(g), dim3(th), 0, 0, o, n, 1.0f); });
+      run("write nt", 1.0 * bytes, t, w, cus, [&](int g, int th) { hipLaunchKernelGGL(k_write<true>, dim3(g), dim3(th), 0, 0, o, n, 1.0f); });
+      run("read", 1.0 * bytes, t, w, cus, [&](int g, int th) { hipLaunchKernelGGL(k_read<false>, dim3(g), dim3(th), 0, 0, a, s, n); });
+      run("read nt", 1.0 * bytes, t, w, cus, [&](int g, int th) { hipLaunchKernelGGL(k_read<true>, dim3(g), dim3(th), 0, 0, a, s, n); });
+    }
+  return 0;
+}
