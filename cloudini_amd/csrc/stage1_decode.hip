@@ -133,20 +133,22 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       // round 4: the barrier-free kernel (stage1_decode_wave.h) is the default; CLDN_HIP_POINT_KERNEL=tiles brings the
       // tile kernel back (A/B in the same binary), =w8 runs it with 8 waves per workgroup instead of 16
       static const char* pk_env = getenv("CLDN_HIP_POINT_KERNEL");
-      static const int pk = pk_env == nullptr ? 16 : (strcmp(pk_env, "tiles") == 0 ? 0 : (strcmp(pk_env, "w8") == 0 ? 8 : 16));
+      static const int pk = pk_env == nullptr ? 16 : (strcmp(pk_env, "tiles") == 0 ? 0 : (strcmp(pk_env, "w8") == 0 ? 8 : (strcmp(pk_env, "w8o6") == 0 ? 86 : (strcmp(pk_env, "w12o6") == 0 ? 126 : 16))));
 #define LAUNCH_POINTS(NOPS_, NF_)                                                                                         \
   hipLaunchKernelGGL((k_decode_points<NOPS_, NF_>), dim3(L.n_chunks), dim3(kFpThreads), (FpLds<NOPS_, NF_>::kTotal), L.stream, \
                      P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5,  \
                      L.status, c0, c1, L.reg_end_pre, sc, fill_zero)
-#define LAUNCH_POINTS_W(NOPS_, NF_, NW_)                                                                                  \
-  hipLaunchKernelGGL((k_decode_points_w<NOPS_, NF_, NW_>), dim3(L.n_chunks), dim3(NW_ * 64), (WpLds<NOPS_, NF_, NW_>::kTotal), \
+#define LAUNCH_POINTS_W(NOPS_, NF_, NW_, WPE_)                                                                            \
+  hipLaunchKernelGGL((k_decode_points_w<NOPS_, NF_, NW_, WPE_>), dim3(L.n_chunks), dim3(NW_ * 64), (WpLds<NOPS_, NF_, NW_>::kTotal), \
                      L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done,   \
                      L.uses_v5, L.status, c0, c1, L.reg_end_pre, sc, fill_zero)
 #define LAUNCH_POINTS_ANY(NOPS_, NF_)                      \
   {                                                        \
     if (pk == 0) LAUNCH_POINTS(NOPS_, NF_);                \
-    else if (pk == 8) LAUNCH_POINTS_W(NOPS_, NF_, 8);      \
-    else LAUNCH_POINTS_W(NOPS_, NF_, 16);                  \
+    else if (pk == 8) LAUNCH_POINTS_W(NOPS_, NF_, 8, 8);   \
+    else if (pk == 86) LAUNCH_POINTS_W(NOPS_, NF_, 8, 6);  \
+    else if (pk == 126) LAUNCH_POINTS_W(NOPS_, NF_, 12, 6); \
+    else LAUNCH_POINTS_W(NOPS_, NF_, 16, 8);               \
   }
       if (P.n_ops == 3u) {
         if (nf == 0u) LAUNCH_POINTS_ANY(3, 0)

@@ -32,7 +32,11 @@ namespace cldn {
 constexpr uint32_t kWpPiece = 1024u;       // bytes of stream per piece: one aligned 16-byte unit per lane
 constexpr uint32_t kWpHalo = 32u;          // a point that starts at the piece's last byte has at most 4 * 4 + 3 bytes more
 constexpr uint32_t kWpRing = 64u;          // chain records (slot = piece % kWpRing, tagged)
-constexpr uint32_t kWpSpinLimit = 1u << 20;
+constexpr uint32_t kWpSpinLimit = 1u << 18;
+#ifndef CLDN_WP_SLEEP
+#define CLDN_WP_SLEEP 4
+#endif
+constexpr int kWpSleep = CLDN_WP_SLEEP;   // x 64 cycles between two polls of a record
 
 template <int NOPS>
 struct WpGeom {
@@ -131,8 +135,8 @@ __device__ __forceinline__ bool wp_tokens(const uint32_t* wbuf, uint32_t byte0, 
   return bad;
 }
 
-template <int NOPS, int NF, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decode_points_w(
+template <int NOPS, int NF, int NW, int WPE = 8>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_decode_points_w(
     const DevPlan plan, const uint8_t* __restrict__ streams, const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
     uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done, uint32_t uses_v5, uint32_t* __restrict__ status,
     const uint8_t* __restrict__ col0, const uint8_t* __restrict__ col1, const uint32_t* __restrict__ reg_end_pre,
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     load_unit((min(p, n_pieces) + 1u) * kWpPiece + (lane & 1u) * 16u, bh);
   }
   bool gave_up = false;
+  __builtin_amdgcn_s_setprio(1);  // (waves that poll a record step down to 0)
   for (; p < n_pieces; p += NW) {
     // ---- bytes -> LDS, token ends
     *reinterpret_cast<uint4*>(wbuf + lane * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
@@ -282,18 +287,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     uint32_t T0 = 0u;
     if (p != 0u) {
       const unsigned long long* r = trec + ((p - 1u) & (kWpRing - 1u));
-      for (uint32_t spins = 0;; ++spins) {
-        const unsigned long long x = wp_rec_load(r);
-        if ((uint32_t)(x >> 32) == p) {
-          T0 = (uint32_t)x;
-          break;
+      unsigned long long x = wp_rec_load(r);
+      if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p) {  // not there yet: poll at low priority
+        __builtin_amdgcn_s_setprio(0);
+        for (uint32_t spins = 1u;; ++spins) {
+          __builtin_amdgcn_s_sleep(kWpSleep);
+          x = wp_rec_load(r);
+          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) == p) break;
+          if ((spins & 63u) == 0u && (spins >= kWpSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
+            gave_up = true;
+            break;
+          }
         }
-        if (spins >= kWpSpinLimit || *(volatile uint32_t*)&misc[3] != 0u) {
-          gave_up = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_setprio(1);
       }
+      T0 = (uint32_t)x;
       T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T0);
     }
     if (gave_up) break;  // uniform
@@ -382,21 +390,55 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
       }
     }
     if (__ballot(irregular) != 0ull && lane == 0u) misc[0] = 1u;
+    // ---- the points' integer fields are requested now (a column value, or the dword that holds a folded Palette's
+    // index), rows and fields side by side: they arrive while the wave waits for its carry and converts
+    uint32_t raw[NFA][ROWS];
+#pragma unroll
+    for (uint32_t a = 0; a < NFA; ++a)
+#pragma unroll
+      for (uint32_t r = 0; r < ROWS; ++r) raw[a][r] = 0u;
+    if (n_fold != 0u) {  // uniform
+#pragma unroll
+      for (uint32_t r = 0; r < ROWS; ++r) {
+        if (r * 64u < npts) {  // uniform
+          const uint32_t j = r * 64u + lane;
+          const uint32_t q = q_first + (j < npts ? j : 0u);
+#pragma unroll
+          for (uint32_t a = 0; a < NFA; ++a) {
+            if (a >= n_fold) break;  // uniform
+            if (from_cols) {
+              const uint8_t* colp = (a == 0u ? col0 : col1) + (size_t)dc.first_point * fs_bpv[a];
+              raw[a][r] = fs_bpv[a] == 2u ? (uint32_t)reinterpret_cast<const uint16_t*>(colp)[q] : reinterpret_cast<const uint32_t*>(colp)[q];
+            } else if (fs_bits[a] != 0u) {  // (bits != 0: at least two table entries, the payload has 4 bytes)
+              const uint32_t o = fs_ioff[a] + (__umul24(q, fs_bits[a]) >> 3);  // payload offset of the index's first byte
+              const uint32_t oc = min(o, src_size - 4u);                       // (the last indexes: the dword that ends with the payload)
+              uint32_t w;
+              __builtin_memcpy(&w, src + oc, 4);
+              raw[a][r] = w;
+            }
+          }
+        }
+      }
+    }
     // ---- chain 2: the values in front of the piece
     int32_t carry[NOPS];
 #pragma unroll
     for (int o = 0; o < NOPS; ++o) carry[o] = 0;
     if (p != 0u) {
       const unsigned long long* r = vrec + (size_t)((p - 1u) & (kWpRing - 1u)) * NOPS + min(lane, (uint32_t)NOPS - 1u);
-      unsigned long long x = 0ull;
-      for (uint32_t spins = 0;; ++spins) {
-        x = wp_rec_load(r);
-        if (__ballot((uint32_t)(x >> 32) != p) == 0ull) break;
-        if (spins >= kWpSpinLimit || *(volatile uint32_t*)&misc[3] != 0u) {
-          gave_up = true;
-          break;
+      unsigned long long x = wp_rec_load(r);
+      if (__ballot((uint32_t)(x >> 32) != p) != 0ull) {  // not there yet: poll at low priority
+        __builtin_amdgcn_s_setprio(0);
+        for (uint32_t spins = 1u;; ++spins) {
+          __builtin_amdgcn_s_sleep(kWpSleep);
+          x = wp_rec_load(r);
+          if (__ballot((uint32_t)(x >> 32) != p) == 0ull) break;
+          if ((spins & 63u) == 0u && (spins >= kWpSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
+            gave_up = true;
+            break;
+          }
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_setprio(1);
       }
 #pragma unroll
       for (int o = 0; o < NOPS; ++o) carry[o] = __builtin_amdgcn_readlane((int)(uint32_t)x, o);
@@ -434,34 +476,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         }
         uint32_t pv[NFA];
 #pragma unroll
-        for (uint32_t a = 0; a < NFA; ++a) pv[a] = 0u;
-        if (from_cols) {
-#pragma unroll
-          for (uint32_t a = 0; a < NFA; ++a) {
-            if (a >= n_fold) break;  // uniform
-            const uint8_t* colp = (a == 0u ? col0 : col1) + (size_t)dc.first_point * fs_bpv[a];
-            pv[a] = fs_bpv[a] == 2u ? (uint32_t)reinterpret_cast<const uint16_t*>(colp)[q] : reinterpret_cast<const uint32_t*>(colp)[q];
-          }
-        } else if (n_fold != 0u) {
+        for (uint32_t a = 0; a < NFA; ++a) pv[a] = raw[a][r];
+        if (!from_cols && n_fold != 0u) {
 #pragma unroll
           for (uint32_t a = 0; a < NFA; ++a) {
             if (a >= n_fold) break;  // uniform
             const uint32_t bits = fs_bits[a];
             uint32_t idx = 0u;
-            if (bits != 0u) {  // uniform. (bits != 0: at least two table entries, the payload has 4 bytes)
-              const uint32_t bit0 = q * bits;                       // < 32768 * 10
-              const uint32_t o = fs_ioff[a] + (bit0 >> 3);          // payload offset of the index's first byte
-              const uint32_t oc = min(o, src_size - 4u);            // (the last indexes: the dword that ends with the payload)
-              uint32_t w;
-              __builtin_memcpy(&w, src + oc, 4);
-              idx = (w >> ((bit0 & 7u) + 8u * (o - oc))) & ((1u << bits) - 1u);
+            if (bits != 0u) {  // uniform
+              const uint32_t bit0 = __umul24(q, bits);              // < 32768 * 10
+              const uint32_t o = fs_ioff[a] + (bit0 >> 3);
+              const uint32_t oc = min(o, src_size - 4u);
+              idx = (raw[a][r] >> ((bit0 & 7u) + 8u * (o - oc))) & ((1u << bits) - 1u);
             }
             if (have && idx >= fs_count[a]) misc[1] = 1u;  // index beyond the palette: the serial decoder redoes the sections and raises the error
             pv[a] = pal[a * kFastPalEntries + (idx & (kFastPalEntries - 1u))];
           }
         }
         if (have) {
-          uint8_t* pt = base + (size_t)q * step;
+          uint8_t* pt = base + __umul24(q, step);  // (q < 32768, step <= 1024)
           if (full16) {
             *reinterpret_cast<float4*>(pt) = make_float4(f[0], f[1], f[2], __uint_as_float(pv[0] & 0xffffu));
           } else if (full32) {

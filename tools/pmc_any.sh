@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {
   local name=$1; shift
-  rm -rf /tmp/pmc_${TAG}_$name
+  mkdir -p $(dirname /tmp/pmc_${TAG}_$name) $(dirname $OUT/${TAG}_x); rm -rf /tmp/pmc_${TAG}_$name
   rocprofv3 "$@" -d /tmp/pmc_${TAG}_$name -o trace -- "${CMD[@]}" > /tmp/pmc_${TAG}_$name.log 2>&1
   local db=$(find /tmp/pmc_${TAG}_$name -name "*.db" | head -1)
   { echo "# rocprofv3 $* -- ${CMD[*]}"; python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $db --filter cldn; } > $OUT/${TAG}_${name}.txt
