@@ -14,6 +14,7 @@
 #include "stage1_decode.h"
 #include "stage1_decode_fast.h"
 #include "stage1_decode_wave.h"
+#include "stage1_decode_stream.h"
 
 #include "cloudini_hip.h"
 #include "stage1_launch.h"
@@ -186,19 +187,38 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       hipLaunchKernelGGL(k_mark_token_ends, dim3(L.n_chunks), dim3(kMtThreads), 0, L.stream, P, L.streams,
                          reinterpret_cast<const DecChunk*>(L.chunks), L.token_ends, L.reg_end);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_mark_token_ends");
-      hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<8, true, 8>::kTotal),
-                         L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, 0u,
-                         (const uint32_t*)L.token_ends);
-      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_varint (mixed)");
+      static const bool no_stream_mixed = getenv("CLDN_HIP_NO_STREAM_KERNEL") != nullptr;  // A/B switch
+      if (!no_stream_mixed && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes) {
+        // round 4: the barrier-free stream kernel reads the token ends from the bitmap (chunks it finds irregular go to the
+        // serial decoder, like the chunks k_mark_token_ends gave up on)
+        hipLaunchKernelGGL((k_decode_stream_w<16>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16>::kTotal), L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)L.token_ends);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (mixed)");
+      } else {
+        hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<8, true, 8>::kTotal),
+                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, 0u,
+                           (const uint32_t*)L.token_ends);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_varint (mixed)");
+      }
       fast = true;  // from here on like any stream the parallel kernels have taken
     } else if (fast) {
+      // round 4: general streams of varint tokens go through the barrier-free stream kernel first (stage1_decode_stream.h);
+      // the tile kernel behind it only redoes the chunks it hands back. CLDN_HIP_NO_STREAM_KERNEL=1: A/B switch
+      static const bool no_stream = getenv("CLDN_HIP_NO_STREAM_KERNEL") != nullptr;
+      const bool stream_kernel = !no_stream && !points_kernel && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes;
+      if (stream_kernel) {
+        hipLaunchKernelGGL((k_decode_stream_w<16>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16>::kTotal), L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w");
+      }
+      const uint32_t redo_only = (points_kernel || stream_kernel) ? 1u : 0u;
       if (all_qf32 && P.n_ops <= 4u)
         hipLaunchKernelGGL((k_decode_varint<4, false>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<4, false, 16>::kTotal),
                            L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status,
-                           points_kernel ? 1u : 0u, (const uint32_t*)nullptr);
+                           redo_only, (const uint32_t*)nullptr);
       else
         hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<8, true, 8>::kTotal),
-                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, 0u,
+                           L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, redo_only,
                            (const uint32_t*)nullptr);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_varint");
     }

@@ -1,0 +1,485 @@
+// stage1_decode_stream.h -- k_decode_stream_w: the barrier-free decoder of GENERAL regular streams (round 4): any list of
+// up to 8 per-point encoders -- FloatN lanes, FieldDecoderFloat_Lossy<float/double>, FieldDecoderInt<T> (varint tokens
+// of up to 10 bytes, include/cloudini_lib/field_decoder.hpp:79-106,330-353, encoding_utils.hpp:98-148), and, when the
+// token ends come from k_mark_token_ends' bitmap, raw FieldDecoderCopy fields and FieldDecoderFloat_XOR
+// (field_decoder.hpp:56-75,108-156). It takes the streams k_decode_points_w does not (that kernel keeps the FloatN-only
+// layouts of the BASELINE configs, with 32-bit arithmetic and a point's values held in registers).
+//
+// Same decomposition as stage1_decode_wave.h: pieces of 1 KiB at 16-byte aligned addresses, one wave per piece, the waves
+// of a chunk's workgroup take the pieces round robin; a piece owns the points that begin behind the token ends it holds;
+// two chains of tagged LDS records hand over the token count in front of a piece and the running values.
+// What differs: a point's tokens are walked op by op (uniform loop over the plan, token lengths from the piece's end
+// bits, values as int64), and the piece is decoded TWICE from its LDS copy -- a first walk only adds up every op's
+// differences (the piece's aggregate, published at once), the second walk, after the carry of the pieces in front has
+// arrived, scans, converts and stores. Nothing per point is kept in registers between the two, so a row of 64 points is
+// a loop iteration, whatever the number of ops. Per-op state (running value, aggregate) lives in LANE o of a register.
+#pragma once
+
+namespace cldn {
+
+constexpr uint32_t kSwPiece = 1024u;
+constexpr uint32_t kSwHalo = 96u;           // a point has at most kSwMaxPointBytes bytes behind its first
+constexpr uint32_t kSwMaxPointBytes = 88u;
+constexpr uint32_t kSwMaxOps = 8u;
+constexpr uint32_t kSwRing = 32u;
+constexpr uint32_t kSwListEntries = 1032u;  // points a piece can own (one op of one byte: one per byte) + slack
+constexpr uint32_t kSwSpinLimit = 1u << 18;
+
+template <int NW>
+struct SwLds {
+  static constexpr uint32_t kBytesOff = 0;                                    // per wave: [piece][halo]
+  static constexpr uint32_t kEndsOff = kSwPiece + kSwHalo;                    // u16 [64 + 6] + pad: end bits of the units
+  static constexpr uint32_t kListOff = kEndsOff + 160u;                       // u16 [kSwListEntries]
+  static constexpr uint32_t kWaveBytes = (kListOff + kSwListEntries * 2u + 15u) & ~15u;
+  static constexpr uint32_t kLutOff = (uint32_t)NW * kWaveBytes;              // u16 [kSwMaxOps][256]
+  static constexpr uint32_t kTrecOff = kLutOff + kSwMaxOps * 512u;            // u64 [kSwRing]
+  static constexpr uint32_t kVrecOff = kTrecOff + kSwRing * 8u;               // u64 [kSwRing][kSwMaxOps][2]: {tag, lo}, {tag, hi} of the value behind the piece
+  static constexpr uint32_t kMiscOff = kVrecOff + kSwRing * kSwMaxOps * 16u;
+  static constexpr uint32_t kTotal = kMiscOff + 256u;
+};
+
+#define SW_DPP64(X, CTRL, RMASK, BC)                                                                                  \
+  ((((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((X) >> 32), CTRL, RMASK, 0xf, BC)) << 32) |   \
+   (uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(X), CTRL, RMASK, 0xf, BC))
+
+// inclusive prefix over the 64 lanes with + or ^ (XOR = true)
+template <bool XOR>
+__device__ __forceinline__ uint64_t sw_scan64(uint64_t x) {
+#define SW_STEP(CTRL, RMASK, BC)                      \
+  {                                                   \
+    const uint64_t o = SW_DPP64(x, CTRL, RMASK, BC);  \
+    x = XOR ? (x ^ o) : (x + o);                      \
+  }
+  SW_STEP(0x111, 0xf, true)
+  SW_STEP(0x112, 0xf, true)
+  SW_STEP(0x114, 0xf, true)
+  SW_STEP(0x118, 0xf, true)
+  SW_STEP(0x142, 0xa, false)
+  SW_STEP(0x143, 0xc, false)
+#undef SW_STEP
+  return x;
+}
+
+// inclusive segmented prefix sum: lanes whose `f` is set restart the sum with their own value; f becomes the OR of the
+// flags up to the lane
+__device__ __forceinline__ void sw_seg_scan64(uint64_t& x, uint32_t& f) {
+#define SW_STEP(CTRL, RMASK, BC)                                                                      \
+  {                                                                                                   \
+    const uint64_t o = SW_DPP64(x, CTRL, RMASK, BC);                                                  \
+    const uint32_t of = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, CTRL, RMASK, 0xf, BC);      \
+    x = f ? x : x + o;                                                                                \
+    f |= of;                                                                                          \
+  }
+  SW_STEP(0x111, 0xf, true)
+  SW_STEP(0x112, 0xf, true)
+  SW_STEP(0x114, 0xf, true)
+  SW_STEP(0x118, 0xf, true)
+  SW_STEP(0x142, 0xa, false)
+  SW_STEP(0x143, 0xc, false)
+#undef SW_STEP
+}
+
+__device__ __forceinline__ uint64_t sw_lane64(uint64_t x, uint32_t l) {
+  return (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), (int)l)) << 32) |
+         (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, (int)l);
+}
+
+// One token of the stream copy in LDS: `len` bytes from byte `bp`. Varint tokens (raw == false): decodeVarint's value
+// (zig-zag undone), *marker = the token is the single byte 0x00 (the NaN marker of the float decoders), *bad = what
+// decodeVarint throws on (more than 10 bytes, bits beyond 64, a zero spread over several bytes). Raw tokens: the bytes.
+__device__ __forceinline__ uint64_t sw_token(const uint32_t* wbuf, uint32_t bp, uint32_t len, bool raw, bool* marker, bool* bad) {
+  const uint32_t di = bp >> 2, sh = (bp & 3u) * 8u;
+  const uint32_t d0 = wbuf[di], d1 = wbuf[di + 1u], d2 = wbuf[di + 2u];
+  const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+  uint64_t w = (((uint64_t)hi) << 32) | lo;  // the token's first 8 bytes
+  if (len < 8u) w &= (1ull << (8u * len)) - 1ull;
+  *marker = false;
+  if (raw) return w;
+  uint64_t x = w & 0x7f7f7f7f7f7f7f7full;
+  x = (x & 0x007f007f007f007full) | ((x & 0x7f007f007f007f00ull) >> 1);
+  x = (x & 0x00003fff00003fffull) | ((x & 0x3fff00003fff0000ull) >> 2);
+  x = (x & 0x000000000fffffffull) | ((x & 0x0fffffff00000000ull) >> 4);
+  if (len > 8u) {  // bytes 8 and 9: 7 more bits, then the one bit that is left of 64
+    const uint32_t d3 = wbuf[di + 3u];
+    const uint32_t top = __builtin_amdgcn_alignbit(d3, d2, sh);
+    x |= ((uint64_t)(top & 0x7fu)) << 56;
+    if (len > 9u) {
+      const uint32_t b9 = (top >> 8) & 0x7fu;
+      if (b9 > 1u || len > 10u) *bad = true;
+      x |= ((uint64_t)b9) << 63;
+    }
+  }
+  if (x == 0ull) {
+    if (len == 1u) *marker = true;
+    else *bad = true;
+  }
+  const uint64_t u1 = x - 1ull;
+  return (u1 >> 1) ^ (0ull - (u1 & 1ull));
+}
+
+// grid = n_chunks, NW * 64 threads, SwLds<NW>::kTotal bytes of LDS. token_ends == NULL: the token ends are the bytes with
+// a clear MSB (plans made of varint tokens only); else the bitmap k_mark_token_ends laid out.
+// reg_end[c] = where the regular stream ends, kDecRedo when the chunk is irregular (the 64-bit tile kernel / the serial
+// decoder take it and raise the errors).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_decode_stream_w(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                             const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
+                                                             uint32_t* __restrict__ reg_end, uint32_t* __restrict__ status,
+                                                             const uint32_t* __restrict__ token_ends) {
+  using L = SwLds<NW>;
+  constexpr int T = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint16_t* lut = reinterpret_cast<uint16_t*>(smem + L::kLutOff);
+  unsigned long long* trec = reinterpret_cast<unsigned long long*>(smem + L::kTrecOff);
+  unsigned long long* vrec = reinterpret_cast<unsigned long long*>(smem + L::kVrecOff);
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + L::kMiscOff);  // [0] irregular, [2] end of the regular stream, [3] a wait gave up
+  const uint32_t c = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const DecChunk dc = chunks[c];
+  if (!dc.valid) return;
+  if (token_ends != nullptr && reg_end[c] == kDecRedo) return;  // k_mark_token_ends found the stream irregular
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t src_size = dc.src_size;
+  const uint32_t n = dc.n_points;
+  const uint32_t n_ops = plan.n_ops;
+  const uint32_t step = plan.point_step;
+  uint8_t* base = out + (size_t)dc.first_point * step;
+  const uint32_t target = n * n_ops;
+  if (n_ops == 0u || n == 0u) {  // no per-point encoder (integer fields only): the sections begin at once
+    if (tid == 0) {
+      reg_end[c] = 0u;
+      atomicAdd(&status[kStatFastRegular], 1u);
+    }
+    return;
+  }
+  const uint8_t* ebits = token_ends != nullptr ? reinterpret_cast<const uint8_t*>(token_ends + token_ends_word(dc.src_off, c)) : nullptr;
+
+  if (tid == 0) {
+    misc[0] = 0u;
+    misc[2] = 0xffffffffu;
+    misc[3] = 0u;
+  }
+  for (uint32_t i = tid; i < (kSwRing * 8u + kSwRing * kSwMaxOps * 16u) / 4u; i += T) reinterpret_cast<uint32_t*>(trec)[i] = 0u;
+  // which ends of a byte's end mask close points when the first k0 of them do not: entry = mask | (next k0) << 8
+  for (uint32_t e = tid; e < n_ops * 256u; e += T) {
+    uint32_t k = e >> 8, sel = 0u;
+    for (uint32_t bit = 0; bit < 8u; ++bit) {
+      if ((e >> bit) & 1u) {
+        if (k == 0u) {
+          sel |= 1u << bit;
+          k = n_ops - 1u;
+        } else {
+          --k;
+        }
+      }
+    }
+    lut[e] = (uint16_t)(sel | (k << 8));
+  }
+  __syncthreads();
+
+  // x / n_ops for x < 2^19 without a division (n_ops <= 8: the error of the rounded-up reciprocal stays below 2^-13)
+  const uint32_t inv_ops = n_ops > 1u ? (uint32_t)((0x100000000ull + n_ops - 1u) / n_ops) : 0u;
+  auto div_ops = [&](uint32_t x) __attribute__((always_inline)) -> uint32_t { return n_ops > 1u ? __umulhi(x, inv_ops) : x; };
+  const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
+  const uint8_t* src_al = src - a0;
+  const uint32_t vend = a0 + src_size;
+  const uint32_t n_pieces = src_size ? (vend + kSwPiece - 1u) / kSwPiece : 0u;
+  uint8_t* wmem = smem + wave * L::kWaveBytes;
+  uint32_t* wbuf = reinterpret_cast<uint32_t*>(wmem + L::kBytesOff);
+  uint16_t* ebuf = reinterpret_cast<uint16_t*>(wmem + L::kEndsOff);
+  uint16_t* plist = reinterpret_cast<uint16_t*>(wmem + L::kListOff);
+
+  auto load_unit = [&](uint32_t v0, uint32_t(&u)[4]) __attribute__((always_inline)) {
+    const bool ok = v0 < vend;
+    const uint4 w = *reinterpret_cast<const uint4*>(src_al + (ok ? v0 : 0u));
+    u[0] = ok ? w.x : 0xffffffffu;
+    u[1] = ok ? w.y : 0xffffffffu;
+    u[2] = ok ? w.z : 0xffffffffu;
+    u[3] = ok ? w.w : 0xffffffffu;
+  };
+  // end bits of the unit at v0: MSBs, or 16 bits of the bitmap (bit p of it = payload byte p); bytes outside the payload end nothing
+  auto unit_ends = [&](uint32_t v0, const uint32_t(&u)[4]) __attribute__((always_inline)) -> uint32_t {
+    uint32_t ends;
+    if (ebits == nullptr) {
+      ends = wp_ends16(u);
+    } else {
+      const int32_t o = (int32_t)v0 - (int32_t)a0;  // payload offset of the unit's first byte (first unit: may be < 0)
+      const uint32_t ob = o > 0 ? (uint32_t)o : 0u;
+      uint32_t w = 0u;
+      if (ob < src_size) __builtin_memcpy(&w, ebits + (ob >> 3), 4);  // (the bitmap has a word of slack per chunk)
+      w >>= (ob & 7u);
+      ends = o >= 0 ? (w & 0xffffu) : ((w << (uint32_t)(-o)) & 0xffffu);
+    }
+    const uint32_t lo = a0 > v0 ? min(a0 - v0, 16u) : 0u;
+    const uint32_t hi = vend > v0 ? min(vend - v0, 16u) : 0u;
+    return ends & ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+  };
+
+  // per-op state: lane o of these registers belongs to op o
+  uint32_t kind_l = 0xffu, size_l = 0u;
+  if (lane < n_ops) {
+    kind_l = plan.ops[lane].kind;
+    size_l = plan.ops[lane].size;
+  }
+  const bool raw_l = kind_l == OP_COPY || kind_l == OP_XOR32 || kind_l == OP_XOR64;
+  const unsigned long long raw_ops = __ballot(raw_l);                                   // bit o: op o's token is `size` raw bytes
+  const unsigned long long xor_ops = __ballot(kind_l == OP_XOR32 || kind_l == OP_XOR64);  // its values combine with ^
+  const unsigned long long copy_ops = __ballot(kind_l == OP_COPY);                      // no state at all
+  const unsigned long long int_ops = __ballot(kind_l == OP_INT);                        // a marker is an error there
+  uint64_t run_l = 0ull;  // lane o: op o's running value (behind the last point handled so far)
+
+  uint32_t b[4], bh[4];
+  uint32_t p = wave;
+  if (n_pieces) {
+    load_unit(min(p, n_pieces) * kSwPiece + lane * 16u, b);
+    load_unit((min(p, n_pieces) + 1u) * kSwPiece + min(lane, 5u) * 16u, bh);
+  }
+  bool gave_up = false;
+  __builtin_amdgcn_s_setprio(1);
+  for (; p < n_pieces; p += NW) {
+    // ---- bytes and end bits -> LDS
+    *reinterpret_cast<uint4*>(wbuf + lane * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
+    if (lane < 6u) *reinterpret_cast<uint4*>(wbuf + kSwPiece / 4u + lane * 4u) = make_uint4(bh[0], bh[1], bh[2], bh[3]);
+    const uint32_t v0 = p * kSwPiece + lane * 16u;
+    const uint32_t ends = unit_ends(v0, b);
+    ebuf[lane] = (uint16_t)ends;
+    if (lane < 6u) ebuf[64u + lane] = (uint16_t)unit_ends((p + 1u) * kSwPiece + lane * 16u, bh);
+    if (lane == 6u) {
+      ebuf[70] = 0u;
+      ebuf[71] = 0u;
+    }
+    const uint32_t cl = (uint32_t)__builtin_popcount(ends);
+    const uint32_t incl = wave_inclusive_scan(cl);
+    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t tb = incl - cl;
+    {
+      const uint32_t pn = min(p + (uint32_t)NW, n_pieces);
+      load_unit(pn * kSwPiece + lane * 16u, b);
+      load_unit((pn + 1u) * kSwPiece + min(lane, 5u) * 16u, bh);
+    }
+    // ---- chain 1: token ends in front of the piece
+    uint32_t T0 = 0u;
+    if (p != 0u) {
+      const unsigned long long* r = trec + ((p - 1u) & (kSwRing - 1u));
+      unsigned long long x = wp_rec_load(r);
+      if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p) {
+        __builtin_amdgcn_s_setprio(0);
+        for (uint32_t spins = 1u;; ++spins) {
+          __builtin_amdgcn_s_sleep(kWpSleep);
+          x = wp_rec_load(r);
+          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) == p) break;
+          if ((spins & 63u) == 0u && (spins >= kSwSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
+            gave_up = true;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_setprio(1);
+      }
+      T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    }
+    if (gave_up) break;
+    if (lane == 0u) wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (T0 + cnt));
+    if (T0 >= target) break;
+    if (T0 + cnt >= target) {
+      const uint32_t want = target - T0;
+      if (tb < want && want <= tb + cl) {
+        uint32_t m = ends;
+        for (uint32_t k = tb + 1u; k < want; ++k) m &= m - 1u;
+        misc[2] = v0 + (uint32_t)__builtin_ctz(m) + 1u - a0;
+      }
+    }
+    // ---- where the points this piece owns begin
+    const uint32_t A0 = div_ops(T0);
+    const uint32_t r0 = T0 - A0 * n_ops;
+    const uint32_t extra = p == 0u ? 1u : 0u;
+    const uint32_t q_first = A0 + 1u - extra;
+    const uint32_t npts = min(div_ops(r0 + cnt) + extra, n - q_first);
+    {
+      const uint32_t x = r0 + tb;
+      const uint32_t a = div_ops(x);
+      const uint32_t k0 = n_ops - 1u - (x - a * n_ops);
+      const uint32_t e0 = lut[k0 * 256u + (ends & 0xffu)];
+      const uint32_t e1 = lut[(e0 >> 8) * 256u + (ends >> 8)];
+      uint32_t sel = (e0 & 0xffu) | ((e1 & 0xffu) << 8);
+      uint32_t j = a + extra;
+      while (sel) {
+        plist[j] = (uint16_t)(lane * 16u + (uint32_t)__builtin_ctz(sel) + 1u);
+        ++j;
+        sel &= sel - 1u;
+      }
+      if (extra && lane == 0u) plist[0] = (uint16_t)a0;
+    }
+    wp_wave_sync();
+
+    // A point's tokens, op by op. fn(o, value, marker) is called for every op (uniform o); returns false when the point
+    // is irregular. Token lengths: distance to the next end bit (varints), or the field's size (raw ops).
+    auto walk = [&](uint32_t byte0, bool have, auto&& fn) __attribute__((always_inline)) -> bool {
+      // the end bits of the 96 bytes behind the point's first
+      const uint32_t* eb32 = reinterpret_cast<const uint32_t*>(ebuf);
+      const uint32_t ei = byte0 >> 5, es = byte0 & 31u;
+      const uint32_t q0 = eb32[ei], q1 = eb32[ei + 1u], q2 = eb32[ei + 2u], q3 = eb32[ei + 3u];
+      uint32_t E[3] = {__builtin_amdgcn_alignbit(q1, q0, es), __builtin_amdgcn_alignbit(q2, q1, es), __builtin_amdgcn_alignbit(q3, q2, es)};
+      uint32_t pos = 0u;
+      bool bad = false;
+      for (uint32_t o = 0; o < n_ops; ++o) {  // uniform
+        const bool raw = (raw_ops >> o) & 1ull;
+        const uint32_t size = (uint32_t)__builtin_amdgcn_readlane((int)size_l, (int)o);
+        // end bits from `pos` on (pos < 88)
+        const uint32_t wi = pos >> 5, ws = pos & 31u;
+        const uint32_t elo = wi == 0u ? E[0] : (wi == 1u ? E[1] : E[2]);
+        const uint32_t ehi = wi == 0u ? E[1] : (wi == 1u ? E[2] : 0u);
+        const uint32_t e = __builtin_amdgcn_alignbit(ehi, elo, ws);
+        uint32_t len;
+        if (raw) {
+          len = size;
+          if (((e >> (size - 1u)) & 1u) == 0u) bad = true;  // the bitmap ends the field somewhere else
+        } else {
+          len = e ? (uint32_t)__builtin_ctz(e) + 1u : 11u;
+          if (len > 10u) {
+            bad = true;
+            len = 10u;
+          }
+        }
+        bool marker = false;
+        const uint64_t v = sw_token(wbuf, byte0 + pos, len, raw, &marker, &bad);
+        if (marker && ((int_ops >> o) & 1ull)) bad = true;  // "decodeVarint: unexpected NaN marker"
+        fn(o, have ? v : 0ull, have && marker);
+        pos = min(pos + len, kSwMaxPointBytes - 1u);
+      }
+      return bad;
+    };
+
+    // ---- first walk: every op's aggregate over the piece (lane o: op o)
+    uint64_t agg_l = 0ull;
+    uint32_t aggf_l = 0u;  // lane o: op o was reset inside the piece (a marker)
+    bool irregular = false;
+    for (uint32_t r = 0; r * 64u < npts; ++r) {  // uniform
+      const uint32_t j = r * 64u + lane;
+      const bool have = j < npts;
+      const uint32_t byte0 = have ? (uint32_t)plist[j] : 0u;
+      const bool bad = walk(byte0, have, [&](uint32_t o, uint64_t v, bool mk) __attribute__((always_inline)) {
+        if ((copy_ops >> o) & 1ull) return;
+        uint64_t tot;
+        bool reset = false;
+        if ((xor_ops >> o) & 1ull) {
+          tot = sw_lane64(sw_scan64<true>(v), 63u);
+        } else {
+          const unsigned long long mks = __ballot(mk);
+          if (mks == 0ull) {
+            tot = sw_lane64(sw_scan64<false>(v), 63u);
+          } else {  // the values behind the row's last marker
+            const uint32_t last = 63u - (uint32_t)__builtin_clzll(mks);
+            tot = sw_lane64(sw_scan64<false>(lane > last ? v : 0ull), 63u);
+            reset = true;
+          }
+        }
+        if (lane == o) {
+          if ((xor_ops >> o) & 1ull) agg_l ^= tot;
+          else agg_l = reset ? tot : agg_l + tot;
+          aggf_l |= reset ? 1u : 0u;
+        }
+      });
+      irregular = irregular || (have && bad);
+    }
+    if (__ballot(irregular) != 0ull && lane == 0u) misc[0] = 1u;
+    // ---- chain 2: the running values in front of the piece (lane o: {tag, lo}, {tag | reset, hi} of op o)
+    if (p != 0u) {
+      const unsigned long long* r = vrec + ((size_t)((p - 1u) & (kSwRing - 1u)) * kSwMaxOps + min(lane, n_ops - 1u)) * 2u;
+      unsigned long long xl = wp_rec_load(r), xh = wp_rec_load(r + 1);
+      if (__ballot((uint32_t)(xl >> 32) != p || (uint32_t)(xh >> 32) != p) != 0ull) {
+        __builtin_amdgcn_s_setprio(0);
+        for (uint32_t spins = 1u;; ++spins) {
+          __builtin_amdgcn_s_sleep(kWpSleep);
+          xl = wp_rec_load(r);
+          xh = wp_rec_load(r + 1);
+          if (__ballot((uint32_t)(xl >> 32) != p || (uint32_t)(xh >> 32) != p) == 0ull) break;
+          if ((spins & 63u) == 0u && (spins >= kSwSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
+            gave_up = true;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_setprio(1);
+      }
+      run_l = (xh << 32) | (xl & 0xffffffffull);
+    } else {
+      run_l = 0ull;
+    }
+    if (gave_up) break;
+    {
+      const uint64_t incl_l = ((xor_ops >> lane) & 1ull) ? (run_l ^ agg_l) : (aggf_l ? agg_l : run_l + agg_l);
+      if (lane < n_ops) {
+        unsigned long long* w = vrec + ((size_t)(p & (kSwRing - 1u)) * kSwMaxOps + lane) * 2u;
+        wp_rec_store(w, ((unsigned long long)(p + 1u) << 32) | (incl_l & 0xffffffffull));
+        wp_rec_store(w + 1, ((unsigned long long)(p + 1u) << 32) | (incl_l >> 32));
+      }
+    }
+    // ---- second walk: values, converted and stored; a lane stores its own point
+    for (uint32_t r = 0; r * 64u < npts; ++r) {  // uniform
+      const uint32_t j = r * 64u + lane;
+      const bool have = j < npts;
+      const uint32_t byte0 = have ? (uint32_t)plist[j] : 0u;
+      uint8_t* pt = base + __umul24(q_first + (have ? j : 0u), step);  // (q < 2^16, step <= 1024)
+      walk(byte0, have, [&](uint32_t o, uint64_t v, bool mk) __attribute__((always_inline)) {
+        const DevOp& op = plan.ops[o];
+        const uint32_t off = op.offset;
+        const uint32_t kind = op.kind;
+        if (kind == OP_COPY) {
+          if (have && off != 0xffffffffu) st_raw(pt + off, v, op.size);
+          return;
+        }
+        const uint64_t before = sw_lane64(run_l, o);  // (uniform)
+        uint64_t cur;
+        if (kind == OP_XOR32 || kind == OP_XOR64) {
+          const uint64_t inc = sw_scan64<true>(v);
+          cur = before ^ inc;
+          const uint64_t after = before ^ sw_lane64(inc, 63u);
+          if (lane == o) run_l = after;
+          if (have && off != 0xffffffffu) st_raw(pt + off, cur, op.size);
+          return;
+        }
+        const unsigned long long mks = __ballot(mk);
+        if (mks == 0ull) {
+          const uint64_t inc = sw_scan64<false>(v);
+          cur = before + inc;
+          const uint64_t after = before + sw_lane64(inc, 63u);
+          if (lane == o) run_l = after;
+        } else {
+          uint64_t inc = mk ? 0ull : v;
+          uint32_t f = mk ? 1u : 0u;
+          sw_seg_scan64(inc, f);
+          cur = f ? inc : before + inc;
+          const uint32_t f63 = (uint32_t)__builtin_amdgcn_readlane((int)f, 63);
+          const uint64_t i63 = sw_lane64(inc, 63u);
+          if (lane == o) run_l = f63 ? i63 : before + i63;
+        }
+        if (have && off != 0xffffffffu) {
+          if (kind == OP_QF32) {
+            st_raw(pt + off, mk ? 0x7fc00000u : __float_as_uint(__fmul_rn((float)(int32_t)cur, op.res_f)), 4);
+          } else if (kind == OP_LOSSY_F32) {
+            st_raw(pt + off, mk ? 0x7fc00000u : __float_as_uint(__fmul_rn((float)(long long)cur, op.res_f)), 4);
+          } else if (kind == OP_LOSSY_F64) {
+            st_raw(pt + off, mk ? 0x7ff8000000000000ull : (uint64_t)__double_as_longlong(__dmul_rn((double)(long long)cur, op.res_d)), 8);
+          } else {
+            st_raw(pt + off, cur, op.size);
+          }
+        }
+      });
+    }
+    wp_wave_sync();
+  }
+  if (gave_up && lane == 0u) {
+    misc[3] = 1u;
+    misc[0] = 1u;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t pos = misc[2];
+    const bool redo = misc[0] != 0u || pos == 0xffffffffu;
+    reg_end[c] = redo ? kDecRedo : pos;
+    if (!redo) atomicAdd(&status[kStatFastRegular], 1u);
+  }
+}
+
+}  // namespace cldn
