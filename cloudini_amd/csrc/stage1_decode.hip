@@ -42,6 +42,9 @@ int stage1_configure_decode() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sections_cols),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecSecLds::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_sections_cols)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_stream_w<12, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)SwLds<12, true>::kTotal);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_stream_w form)");
   return CLDN_HIP_OK;
 }
 
@@ -184,15 +187,30 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     static const bool no_mixed = getenv("CLDN_HIP_NO_MIXED_DECODE") != nullptr;  // A/B switch
     const bool mixed = !fast && !no_fast && !no_mixed && P.varint_and_raw != 0u && L.token_ends != nullptr;
     if (mixed) {
-      hipLaunchKernelGGL(k_mark_token_ends, dim3(L.n_chunks), dim3(kMtThreads), 0, L.stream, P, L.streams,
-                         reinterpret_cast<const DecChunk*>(L.chunks), L.token_ends, L.reg_end);
-      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_mark_token_ends");
       static const bool no_stream_mixed = getenv("CLDN_HIP_NO_STREAM_KERNEL") != nullptr;  // A/B switch
-      if (!no_stream_mixed && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes) {
+      const bool stream_ok = !no_stream_mixed && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes;
+      bool all_raw = true;  // points of a fixed size: the stream kernel needs no bitmap
+      for (uint32_t k = 0; k < P.n_ops; ++k) all_raw = all_raw && (P.ops[k].kind == OP_COPY || P.ops[k].kind == OP_XOR32 || P.ops[k].kind == OP_XOR64);
+      // layouts with varints AND raw fields: the stream kernel finds the points from their form (FORM instantiation);
+      // CLDN_HIP_STREAM_BITMAP=1 keeps k_mark_token_ends' bitmap in front of it (A/B switch)
+      static const bool force_bitmap = getenv("CLDN_HIP_STREAM_BITMAP") != nullptr;
+      const bool form = stream_ok && !all_raw && !force_bitmap;
+      const bool bitmap = !(stream_ok && all_raw) && !form;
+      if (bitmap) {
+        hipLaunchKernelGGL(k_mark_token_ends, dim3(L.n_chunks), dim3(kMtThreads), 0, L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.token_ends, L.reg_end);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_mark_token_ends");
+      }
+      if (form) {
+        hipLaunchKernelGGL((k_decode_stream_w<12, true>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, true>::kTotal), L.stream, P,
+                           L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (form)");
+      } else if (stream_ok) {
         // round 4: the barrier-free stream kernel reads the token ends from the bitmap (chunks it finds irregular go to the
         // serial decoder, like the chunks k_mark_token_ends gave up on)
-        hipLaunchKernelGGL((k_decode_stream_w<16>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16>::kTotal), L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)L.token_ends);
+        hipLaunchKernelGGL((k_decode_stream_w<16, false>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status,
+                           bitmap ? (const uint32_t*)L.token_ends : (const uint32_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (mixed)");
       } else {
         hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<8, true, 8>::kTotal),
@@ -207,7 +225,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       static const bool no_stream = getenv("CLDN_HIP_NO_STREAM_KERNEL") != nullptr;
       const bool stream_kernel = !no_stream && !points_kernel && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes;
       if (stream_kernel) {
-        hipLaunchKernelGGL((k_decode_stream_w<16>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16>::kTotal), L.stream, P, L.streams,
+        hipLaunchKernelGGL((k_decode_stream_w<16, false>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w");
       }

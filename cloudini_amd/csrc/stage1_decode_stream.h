@@ -25,12 +25,15 @@ constexpr uint32_t kSwRing = 32u;
 constexpr uint32_t kSwListEntries = 1032u;  // points a piece can own (one op of one byte: one per byte) + slack
 constexpr uint32_t kSwSpinLimit = 1u << 18;
 
-template <int NW>
+template <int NW, bool FORM = false>
 struct SwLds {
   static constexpr uint32_t kBytesOff = 0;                                    // per wave: [piece][halo]
   static constexpr uint32_t kEndsOff = kSwPiece + kSwHalo;                    // u16 [64 + 6] + pad: end bits of the units
-  static constexpr uint32_t kListOff = kEndsOff + 160u;                       // u16 [kSwListEntries]
-  static constexpr uint32_t kWaveBytes = (kListOff + kSwListEntries * 2u + 15u) & ~15u;
+  static constexpr uint32_t kListOff = kEndsOff + 160u;                       // u16 [kSwListEntries] (FORM: a point has 2 bytes at least)
+  static constexpr uint32_t kListEntries = FORM ? kSwPiece / 2u + 8u : kSwListEntries;
+  static constexpr uint32_t kJumpOff = (kListOff + kListEntries * 2u + 15u) & ~15u;  // FORM: u16 [kSwPiece]: where the point that starts at a byte ends
+  static constexpr uint32_t kCheckOff = kJumpOff + (FORM ? kSwPiece * 2u : 0u);      // FORM: u16 [kSwMaxPointBytes][8]: a candidate's first point in every 128-byte block
+  static constexpr uint32_t kWaveBytes = kCheckOff + (FORM ? kSwMaxPointBytes * 16u : 0u);
   static constexpr uint32_t kLutOff = (uint32_t)NW * kWaveBytes;              // u16 [kSwMaxOps][256]
   static constexpr uint32_t kTrecOff = kLutOff + kSwMaxOps * 512u;            // u64 [kSwRing]
   static constexpr uint32_t kVrecOff = kTrecOff + kSwRing * 8u;               // u64 [kSwRing][kSwMaxOps][2]: {tag, lo}, {tag, hi} of the value behind the piece
@@ -121,12 +124,19 @@ __device__ __forceinline__ uint64_t sw_token(const uint32_t* wbuf, uint32_t bp, 
 // a clear MSB (plans made of varint tokens only); else the bitmap k_mark_token_ends laid out.
 // reg_end[c] = where the regular stream ends, kDecRedo when the chunk is irregular (the 64-bit tile kernel / the serial
 // decoder take it and raise the errors).
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_decode_stream_w(const DevPlan plan, const uint8_t* __restrict__ streams,
+// FORM = true (token_ends == NULL): streams with raw fields between the varints (FieldDecoderCopy / XOR: a raw byte may look
+// like anything, so the MSBs do not say where tokens end). What is known is the FORM of a point -- op after op, a varint
+// or `size` raw bytes: every lane works out where the points that would start at its 16 bytes end (jump table), the first
+// kSwMaxPointBytes lanes follow the jumps from their byte to the piece's end (where the next piece is entered, how many
+// points start on the way), and chain 1 hands over {entry offset, points so far} instead of a token count: one lookup per
+// piece; the owner of the entry then writes the piece's point starts by following the jumps once more. This replaces
+// k_mark_token_ends' bitmap (one workgroup per chunk, tiles in sequence: 3.6 ms per 16 M points) for these layouts.
+template <int NW, bool FORM>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 6 : 8, 8))) void k_decode_stream_w(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                              const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
                                                              uint32_t* __restrict__ reg_end, uint32_t* __restrict__ status,
                                                              const uint32_t* __restrict__ token_ends) {
-  using L = SwLds<NW>;
+  using L = SwLds<NW, FORM>;
   constexpr int T = NW * 64;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t* lut = reinterpret_cast<uint16_t*>(smem + L::kLutOff);
@@ -155,6 +165,35 @@ __global__ __launch_bounds__(NW * 64) void k_decode_stream_w(const DevPlan plan,
     return;
   }
   const uint8_t* ebits = token_ends != nullptr ? reinterpret_cast<const uint8_t*>(token_ends + token_ends_word(dc.src_off, c)) : nullptr;
+  // every op raw (EncodingOptions::NONE, lossless floats): a point has a fixed size F and the token ends follow from the
+  // byte offset alone -- pat[r] = end bits of the 16 bytes that begin r bytes into a point (no bitmap is read)
+  uint16_t* pat = reinterpret_cast<uint16_t*>(smem + L::kMiscOff + 64u);  // [kSwMaxPointBytes]
+  uint32_t fixed_F = 0u;
+  {
+    bool all_raw = true;
+    uint32_t F = 0u;
+    for (uint32_t o = 0; o < n_ops; ++o) {
+      const uint32_t k = plan.ops[o].kind;
+      all_raw = all_raw && (k == OP_COPY || k == OP_XOR32 || k == OP_XOR64);
+      F += plan.ops[o].size;
+    }
+    if (all_raw && F <= kSwMaxPointBytes) fixed_F = F;
+  }
+  if (fixed_F != 0u && tid < fixed_F) {
+    uint32_t bits = 0u, r = tid;
+    for (uint32_t i = 0; i < 16u; ++i) {
+      uint32_t acc = 0u;
+      bool is_end = false;
+      for (uint32_t o = 0; o < n_ops; ++o) {
+        acc += plan.ops[o].size;
+        is_end = is_end || r + 1u == acc;
+      }
+      if (is_end) bits |= 1u << i;
+      r = r + 1u == fixed_F ? 0u : r + 1u;
+    }
+    pat[tid] = (uint16_t)bits;
+  }
+  const uint32_t inv_F = fixed_F > 1u ? (uint32_t)((0x100000000ull + fixed_F - 1u) / fixed_F) : 0u;
 
   if (tid == 0) {
     misc[0] = 0u;
@@ -190,6 +229,8 @@ __global__ __launch_bounds__(NW * 64) void k_decode_stream_w(const DevPlan plan,
   uint32_t* wbuf = reinterpret_cast<uint32_t*>(wmem + L::kBytesOff);
   uint16_t* ebuf = reinterpret_cast<uint16_t*>(wmem + L::kEndsOff);
   uint16_t* plist = reinterpret_cast<uint16_t*>(wmem + L::kListOff);
+  uint16_t* jt = reinterpret_cast<uint16_t*>(wmem + L::kJumpOff);    // (FORM)
+  uint16_t* cpt = reinterpret_cast<uint16_t*>(wmem + L::kCheckOff);  // (FORM)
 
   auto load_unit = [&](uint32_t v0, uint32_t(&u)[4]) __attribute__((always_inline)) {
     const bool ok = v0 < vend;
@@ -202,7 +243,12 @@ __global__ __launch_bounds__(NW * 64) void k_decode_stream_w(const DevPlan plan,
   // end bits of the unit at v0: MSBs, or 16 bits of the bitmap (bit p of it = payload byte p); bytes outside the payload end nothing
   auto unit_ends = [&](uint32_t v0, const uint32_t(&u)[4]) __attribute__((always_inline)) -> uint32_t {
     uint32_t ends;
-    if (ebits == nullptr) {
+    if (fixed_F != 0u) {
+      const uint32_t o = v0 > a0 ? v0 - a0 : 0u;                              // payload offset (the first unit: bytes in front are cut below)
+      const uint32_t r = fixed_F > 1u ? o - __umulhi(o, inv_F) * fixed_F : 0u;  // o % F (o < 2^22, F <= 88)
+      ends = pat[r];
+      if (v0 < a0) ends <<= (a0 - v0);
+    } else if (FORM || ebits == nullptr) {
       ends = wp_ends16(u);
     } else {
       const int32_t o = (int32_t)v0 - (int32_t)a0;  // payload offset of the unit's first byte (first unit: may be < 0)
@@ -259,58 +305,203 @@ __global__ __launch_bounds__(NW * 64) void k_decode_stream_w(const DevPlan plan,
       load_unit(pn * kSwPiece + lane * 16u, b);
       load_unit((pn + 1u) * kSwPiece + min(lane, 5u) * 16u, bh);
     }
-    // ---- chain 1: token ends in front of the piece
-    uint32_t T0 = 0u;
-    if (p != 0u) {
-      const unsigned long long* r = trec + ((p - 1u) & (kSwRing - 1u));
-      unsigned long long x = wp_rec_load(r);
-      if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p) {
-        __builtin_amdgcn_s_setprio(0);
-        for (uint32_t spins = 1u;; ++spins) {
-          __builtin_amdgcn_s_sleep(kWpSleep);
-          x = wp_rec_load(r);
-          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) == p) break;
-          if ((spins & 63u) == 0u && (spins >= kSwSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
-            gave_up = true;
-            break;
+    uint32_t q_first = 0u, npts = 0u;
+    bool stop = false;  // the regular stream ended in front of this piece (uniform)
+    if constexpr (FORM) {
+      // ---- jump table: where the point that would start at each of my 16 bytes ends (0xffff: no point can start there)
+      wp_wave_sync();  // (ebuf is complete)
+      {
+        const uint32_t* eb32 = reinterpret_cast<const uint32_t*>(ebuf);
+        const uint32_t wi = lane >> 1, wsft = (lane & 1u) * 16u;
+        uint32_t R[4];  // end bits of the 128 bytes from my first
+        {
+          const uint32_t q0 = eb32[wi], q1 = eb32[wi + 1u], q2 = eb32[wi + 2u], q3 = eb32[wi + 3u], q4 = eb32[wi + 4u];
+          R[0] = __builtin_amdgcn_alignbit(q1, q0, wsft);
+          R[1] = __builtin_amdgcn_alignbit(q2, q1, wsft);
+          R[2] = __builtin_amdgcn_alignbit(q3, q2, wsft);
+          R[3] = __builtin_amdgcn_alignbit(q4, q3, wsft);
+        }
+        uint32_t packed[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) {
+          uint32_t rel = i;
+          bool ok = true;
+          for (uint32_t o = 0; o < n_ops; ++o) {  // uniform
+            if ((raw_ops >> o) & 1ull) {
+              rel += (uint32_t)__builtin_amdgcn_readlane((int)size_l, (int)o);
+            } else {
+              const uint32_t idx = rel >> 5, sh = rel & 31u;
+              const uint32_t elo = idx == 0u ? R[0] : (idx == 1u ? R[1] : (idx == 2u ? R[2] : R[3]));
+              const uint32_t ehi = idx == 0u ? R[1] : (idx == 1u ? R[2] : (idx == 2u ? R[3] : 0u));
+              const uint32_t e = __builtin_amdgcn_alignbit(ehi, elo, sh) & 0x3ffu;  // a varint has 10 bytes at most
+              ok = ok && e != 0u;
+              rel += e ? (uint32_t)__builtin_ctz(e) + 1u : 1u;
+            }
+            rel = min(rel, 120u);
+          }
+          const uint32_t x = lane * 16u + i;        // byte of the piece
+          const uint32_t end = x + (rel - i);       // (v-space, relative to the piece)
+          ok = ok && rel - i <= kSwMaxPointBytes && p * kSwPiece + x >= a0 && p * kSwPiece + end <= vend;
+          const uint32_t jv = ok ? end : 0xffffu;
+          if (i & 1u) packed[i >> 1] |= jv << 16;
+          else packed[i >> 1] = jv;
+        }
+        uint4* dst = reinterpret_cast<uint4*>(jt + lane * 16u);
+        dst[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        dst[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+      }
+      wp_wave_sync();
+      // ---- the first lanes follow the jumps from their byte: where the next piece is entered, and after how many points.
+      // On the way a candidate leaves a checkpoint in every 128-byte block it passes: its first point there and how many
+      // came before -- the owner of the true entry then lists its points eight blocks side by side.
+      const uint32_t maxpt = min(plan.max_regular_bytes, kSwMaxPointBytes);  // candidates: entry offsets [0, maxpt)
+      uint32_t ex[2] = {0xffffu, 0xffffu}, ec[2] = {0u, 0u};
+      {
+        uint32_t x0 = lane < maxpt ? lane : 0xffffu, x1 = 64u + lane < maxpt ? 64u + lane : 0xffffu;
+        uint32_t c0 = 0u, c1 = 0u, pb0 = 0xffu, pb1 = 0xffu;
+        for (uint32_t b8 = 0; b8 < 8u; ++b8) {
+          if (lane < maxpt) cpt[lane * 8u + b8] = 0xffffu;
+          if (64u + lane < maxpt) cpt[(64u + lane) * 8u + b8] = 0xffffu;
+        }
+        while (__ballot(x0 < kSwPiece || x1 < kSwPiece) != 0ull) {  // (the two rounds of candidates side by side)
+          if (x0 < kSwPiece) {
+            const uint32_t bk = x0 >> 7;
+            if (bk != pb0) cpt[lane * 8u + bk] = (uint16_t)((x0 & 127u) | (c0 << 7));
+            pb0 = bk;
+            x0 = jt[x0];
+            ++c0;
+          }
+          if (x1 < kSwPiece) {
+            const uint32_t bk = x1 >> 7;
+            if (bk != pb1) cpt[(64u + lane) * 8u + bk] = (uint16_t)((x1 & 127u) | (c1 << 7));
+            pb1 = bk;
+            x1 = jt[x1];
+            ++c1;
           }
         }
-        __builtin_amdgcn_s_setprio(1);
+        ex[0] = x0;
+        ec[0] = c0;
+        ex[1] = x1;
+        ec[1] = c1;
       }
-      T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
-    }
-    if (gave_up) break;
-    if (lane == 0u) wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (T0 + cnt));
-    if (T0 >= target) break;
-    if (T0 + cnt >= target) {
-      const uint32_t want = target - T0;
-      if (tb < want && want <= tb + cl) {
-        uint32_t m = ends;
-        for (uint32_t k = tb + 1u; k < want; ++k) m &= m - 1u;
-        misc[2] = v0 + (uint32_t)__builtin_ctz(m) + 1u - a0;
+      // ---- chain 1: {entry offset, points in front} of the piece
+      uint32_t entry = a0, pts0 = 0u;
+      if (p != 0u) {
+        const unsigned long long* r = trec + ((p - 1u) & (kSwRing - 1u));
+        unsigned long long x = wp_rec_load(r);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p) {
+          __builtin_amdgcn_s_setprio(0);
+          for (uint32_t spins = 1u;; ++spins) {
+            __builtin_amdgcn_s_sleep(kWpSleep);
+            x = wp_rec_load(r);
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) == p) break;
+            if ((spins & 63u) == 0u && (spins >= kSwSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
+              gave_up = true;
+              break;
+            }
+          }
+          __builtin_amdgcn_s_setprio(1);
+        }
+        const uint32_t rv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+        entry = rv & 0xffu;
+        pts0 = rv >> 8;
+      }
+      if (gave_up) break;
+      // (entry 0xff: the piece in front could not be left through a well-formed point -- malformed, or only the bytes
+      // behind the regular stream's end; either way nothing starts here)
+      const bool dead = entry == 0xffu || entry >= kSwMaxPointBytes;
+      const uint32_t el = dead ? 0u : entry;
+      const uint32_t my_exit = (uint32_t)__builtin_amdgcn_readlane((int)(el < 64u ? ex[0] : ex[1]), (int)(el & 63u));
+      const uint32_t my_cnt = (uint32_t)__builtin_amdgcn_readlane((int)(el < 64u ? ec[0] : ec[1]), (int)(el & 63u));
+      const uint32_t out_entry = (dead || my_exit == 0xffffu) ? 0xffu : my_exit - kSwPiece;
+      const uint32_t pts1 = dead ? pts0 : min(pts0 + my_cnt, n);
+      if (lane == 0u) wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
+      if (pts0 >= n) stop = true;
+      else if (dead) {
+        if (lane == 0u) misc[0] = 1u;  // points are missing and the stream cannot be followed: the serial decoder raises the error
+        stop = true;
+      } else {
+        q_first = pts0;
+        npts = min(my_cnt, n - pts0);
+        // ---- the points' first bytes, in order: lane b lists the points that begin in block b, from the entry's checkpoint
+        wp_wave_sync();
+        bool broken = false;
+        if (lane < 8u) {
+          const uint32_t ck = cpt[entry * 8u + lane];
+          if (ck != 0xffffu) {
+            uint32_t x = lane * 128u + (ck & 127u), j = ck >> 7;
+            while (x < (lane + 1u) * 128u && j < npts) {
+              plist[j] = (uint16_t)x;
+              const uint32_t nx = jt[x];
+              if (nx == 0xffffu) {
+                broken = true;  // (the candidates' walk counted the points up to here only)
+                break;
+              }
+              if (pts0 + j + 1u == n) misc[2] = p * kSwPiece + nx - a0;  // behind the chunk's last point: the sections
+              x = nx;
+              ++j;
+            }
+          }
+        }
+        if (__ballot(broken) != 0ull && lane == 0u) misc[0] = 1u;
+      }
+    } else {
+      // ---- chain 1: token ends in front of the piece
+      uint32_t T0 = 0u;
+      if (p != 0u) {
+        const unsigned long long* r = trec + ((p - 1u) & (kSwRing - 1u));
+        unsigned long long x = wp_rec_load(r);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p) {
+          __builtin_amdgcn_s_setprio(0);
+          for (uint32_t spins = 1u;; ++spins) {
+            __builtin_amdgcn_s_sleep(kWpSleep);
+            x = wp_rec_load(r);
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) == p) break;
+            if ((spins & 63u) == 0u && (spins >= kSwSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
+              gave_up = true;
+              break;
+            }
+          }
+          __builtin_amdgcn_s_setprio(1);
+        }
+        T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+      }
+      if (gave_up) break;
+      if (lane == 0u) wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (T0 + cnt));
+      if (T0 >= target) stop = true;
+      if (!stop) {
+      if (T0 + cnt >= target) {
+        const uint32_t want = target - T0;
+        if (tb < want && want <= tb + cl) {
+          uint32_t m = ends;
+          for (uint32_t k = tb + 1u; k < want; ++k) m &= m - 1u;
+          misc[2] = v0 + (uint32_t)__builtin_ctz(m) + 1u - a0;
+        }
+      }
+      // ---- where the points this piece owns begin
+      const uint32_t A0 = div_ops(T0);
+      const uint32_t r0 = T0 - A0 * n_ops;
+      const uint32_t extra = p == 0u ? 1u : 0u;
+      q_first = A0 + 1u - extra;
+      npts = min(div_ops(r0 + cnt) + extra, n - q_first);
+      {
+        const uint32_t x = r0 + tb;
+        const uint32_t a = div_ops(x);
+        const uint32_t k0 = n_ops - 1u - (x - a * n_ops);
+        const uint32_t e0 = lut[k0 * 256u + (ends & 0xffu)];
+        const uint32_t e1 = lut[(e0 >> 8) * 256u + (ends >> 8)];
+        uint32_t sel = (e0 & 0xffu) | ((e1 & 0xffu) << 8);
+        uint32_t j = a + extra;
+        while (sel) {
+          plist[j] = (uint16_t)(lane * 16u + (uint32_t)__builtin_ctz(sel) + 1u);
+          ++j;
+          sel &= sel - 1u;
+        }
+        if (extra && lane == 0u) plist[0] = (uint16_t)a0;
+      }
       }
     }
-    // ---- where the points this piece owns begin
-    const uint32_t A0 = div_ops(T0);
-    const uint32_t r0 = T0 - A0 * n_ops;
-    const uint32_t extra = p == 0u ? 1u : 0u;
-    const uint32_t q_first = A0 + 1u - extra;
-    const uint32_t npts = min(div_ops(r0 + cnt) + extra, n - q_first);
-    {
-      const uint32_t x = r0 + tb;
-      const uint32_t a = div_ops(x);
-      const uint32_t k0 = n_ops - 1u - (x - a * n_ops);
-      const uint32_t e0 = lut[k0 * 256u + (ends & 0xffu)];
-      const uint32_t e1 = lut[(e0 >> 8) * 256u + (ends >> 8)];
-      uint32_t sel = (e0 & 0xffu) | ((e1 & 0xffu) << 8);
-      uint32_t j = a + extra;
-      while (sel) {
-        plist[j] = (uint16_t)(lane * 16u + (uint32_t)__builtin_ctz(sel) + 1u);
-        ++j;
-        sel &= sel - 1u;
-      }
-      if (extra && lane == 0u) plist[0] = (uint16_t)a0;
-    }
+    if (stop) break;
     wp_wave_sync();
 
     // A point's tokens, op by op. fn(o, value, marker) is called for every op (uniform o); returns false when the point
@@ -334,7 +525,7 @@ __global__ __launch_bounds__(NW * 64) void k_decode_stream_w(const DevPlan plan,
         uint32_t len;
         if (raw) {
           len = size;
-          if (((e >> (size - 1u)) & 1u) == 0u) bad = true;  // the bitmap ends the field somewhere else
+          if (ebits != nullptr && ((e >> (size - 1u)) & 1u) == 0u) bad = true;  // the bitmap ends the field somewhere else
         } else {
           len = e ? (uint32_t)__builtin_ctz(e) + 1u : 11u;
           if (len > 10u) {
