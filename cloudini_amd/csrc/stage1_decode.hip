@@ -42,9 +42,12 @@ int stage1_configure_decode() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sections_cols),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecSecLds::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_sections_cols)");
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_stream_w<12, true>),
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_stream_w<12, 1>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)SwLds<12, true>::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_stream_w form)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_stream_w<12, 2>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)SwLds<12, true>::kTotal);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_stream_w gorilla)");
   return CLDN_HIP_OK;
 }
 
@@ -202,7 +205,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_mark_token_ends");
       }
       if (form) {
-        hipLaunchKernelGGL((k_decode_stream_w<12, true>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, true>::kTotal), L.stream, P,
+        hipLaunchKernelGGL((k_decode_stream_w<12, 1>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, true>::kTotal), L.stream, P,
                            L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (form)");
       } else if (stream_ok) {
@@ -239,6 +242,23 @@ int stage1_launch_decode(const DecodeLaunch& L) {
                            L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, redo_only,
                            (const uint32_t*)nullptr);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_varint");
+    }
+    // round 4: streams with ONE Gorilla-coded field (FLOAT64 without resolution, wire version >= 4: the reference's own DDS
+    // sample layout) next to varints and raw fields: MODE 2 of the stream kernel; CLDN_HIP_NO_GORILLA_KERNEL=1: A/B switch
+    static const bool no_gor = getenv("CLDN_HIP_NO_GORILLA_KERNEL") != nullptr;
+    if (!fast && !no_fast && !no_gor && P.n_gorilla == 1u && P.n_ops >= 2u && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes) {
+      bool ok = true;
+      for (uint32_t k = 0; k < P.n_ops && ok; ++k) {
+        const uint32_t kd = P.ops[k].kind, sz = P.ops[k].size;
+        if (kd == OP_COPY || kd == OP_XOR32 || kd == OP_XOR64) ok = sz == 1u || sz == 2u || sz == 4u || sz == 8u;
+        else ok = kd == OP_QF32 || kd == OP_LOSSY_F32 || kd == OP_LOSSY_F64 || kd == OP_INT || kd == OP_GORILLA64;
+      }
+      if (ok) {
+        hipLaunchKernelGGL((k_decode_stream_w<12, 2>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, true>::kTotal), L.stream, P,
+                           L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (gorilla)");
+        fast = true;  // from here on like any stream the parallel kernels have taken
+      }
     }
     const bool fast_sections = fast && L.uses_v5 && P.n_adaptive > 0u;
     if (fast_sections) {

@@ -37,7 +37,8 @@ struct SwLds {
   static constexpr uint32_t kLutOff = (uint32_t)NW * kWaveBytes;              // u16 [kSwMaxOps][256]
   static constexpr uint32_t kTrecOff = kLutOff + kSwMaxOps * 512u;            // u64 [kSwRing]
   static constexpr uint32_t kVrecOff = kTrecOff + kSwRing * 8u;               // u64 [kSwRing][kSwMaxOps][2]: {tag, lo}, {tag, hi} of the value behind the piece
-  static constexpr uint32_t kMiscOff = kVrecOff + kSwRing * kSwMaxOps * 16u;
+  static constexpr uint32_t kGrecOff = kVrecOff + kSwRing * kSwMaxOps * 16u;  // u64 [kSwRing]: {tag, Gorilla window behind the piece} (MODE 2)
+  static constexpr uint32_t kMiscOff = kGrecOff + kSwRing * 8u;
   static constexpr uint32_t kTotal = kMiscOff + 256u;
 };
 
@@ -120,6 +121,51 @@ __device__ __forceinline__ uint64_t sw_token(const uint32_t* wbuf, uint32_t bp, 
   return (u1 >> 1) ^ (0ull - (u1 & 1ull));
 }
 
+// One token of FieldDecoderFloat_Gorilla<double> (field_decoder.hpp:262-305; bits LSB-first, every token a whole number of
+// bytes) at byte `bp` of the LDS copy -> the XOR difference against the value before (the chunk's first value: its raw
+// bits), *len = the token's bytes. st = the window in effect (valid << 16 | leading << 8 | trailing). *bad: what the serial
+// decoder refuses (a reuse token without a window, a window of more than 64 bits).
+__device__ __forceinline__ uint64_t sw_gorilla(const uint32_t* wbuf, uint32_t bp, bool first, uint32_t st, uint32_t* len, bool* bad) {
+  const uint32_t di = bp >> 2, sh = (bp & 3u) * 8u;
+  const uint32_t d0 = wbuf[di], d1 = wbuf[di + 1u], d2 = wbuf[di + 2u], d3 = wbuf[di + 3u];
+  const uint32_t W0 = __builtin_amdgcn_alignbit(d1, d0, sh), W1 = __builtin_amdgcn_alignbit(d2, d1, sh), W2 = __builtin_amdgcn_alignbit(d3, d2, sh);
+  if (first) {
+    *len = 8u;
+    return (((uint64_t)W1) << 32) | W0;
+  }
+  if ((W0 & 1u) == 0u) {  // '0': the value before, again
+    *len = 1u;
+    return 0ull;
+  }
+  uint32_t k, m, tr;
+  if ((W0 & 2u) == 0u) {  // '10': the window in effect
+    const uint32_t ld = (st >> 8) & 0xffu;
+    tr = st & 0xffu;
+    if ((st >> 16) == 0u || ld + tr >= 64u) {
+      *bad = true;
+      *len = 1u;
+      return 0ull;
+    }
+    m = 64u - ld - tr;
+    k = 2u;
+  } else {  // '11': 5 bits of leading zeros, 6 bits of (meaningful - 1)
+    const uint32_t sl = (W0 >> 2) & 31u;
+    m = ((W0 >> 7) & 63u) + 1u;
+    if (sl + m > 64u) {
+      *bad = true;
+      *len = 2u;
+      return 0ull;
+    }
+    tr = 64u - sl - m;
+    k = 13u;
+  }
+  *len = (k + m + 7u) >> 3;
+  const uint32_t lo = __builtin_amdgcn_alignbit(W1, W0, k), hi = __builtin_amdgcn_alignbit(W2, W1, k);
+  uint64_t bits = (((uint64_t)hi) << 32) | lo;
+  if (m < 64u) bits &= (1ull << m) - 1ull;
+  return bits << tr;
+}
+
 // grid = n_chunks, NW * 64 threads, SwLds<NW>::kTotal bytes of LDS. token_ends == NULL: the token ends are the bytes with
 // a clear MSB (plans made of varint tokens only); else the bitmap k_mark_token_ends laid out.
 // reg_end[c] = where the regular stream ends, kDecRedo when the chunk is irregular (the 64-bit tile kernel / the serial
@@ -131,17 +177,26 @@ __device__ __forceinline__ uint64_t sw_token(const uint32_t* wbuf, uint32_t bp, 
 // points start on the way), and chain 1 hands over {entry offset, points so far} instead of a token count: one lookup per
 // piece; the owner of the entry then writes the piece's point starts by following the jumps once more. This replaces
 // k_mark_token_ends' bitmap (one workgroup per chunk, tiles in sequence: 3.6 ms per 16 M points) for these layouts.
-template <int NW, bool FORM>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 6 : 8, 8))) void k_decode_stream_w(const DevPlan plan, const uint8_t* __restrict__ streams,
+// MODE 2 (one FieldDecoderFloat_Gorilla<double> op in the point, field_decoder.hpp:158-302): the length of a window-reuse
+// token is a state the tokens in front of it left ('11' tokens open a window of `meaningful` bits, '10' tokens reuse it), so
+// the jump table can only be built once the state at the piece's entry is known: chain 1 is waited for FIRST (it carries
+// {entry, points, window}), then the table is built for that window and one lane follows the jumps; a point whose '11'
+// token changes the window ends the round -- the table is rebuilt for the new window from there. The token's value bits
+// are XOR differences: the op joins the XOR-coded ones in both walks.
+template <int NW, int MODE>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 6 : 8, 8))) void k_decode_stream_w(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                              const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
                                                              uint32_t* __restrict__ reg_end, uint32_t* __restrict__ status,
                                                              const uint32_t* __restrict__ token_ends) {
+  constexpr bool FORM = MODE != 0;
+  constexpr bool GOR = MODE == 2;
   using L = SwLds<NW, FORM>;
   constexpr int T = NW * 64;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t* lut = reinterpret_cast<uint16_t*>(smem + L::kLutOff);
   unsigned long long* trec = reinterpret_cast<unsigned long long*>(smem + L::kTrecOff);
   unsigned long long* vrec = reinterpret_cast<unsigned long long*>(smem + L::kVrecOff);
+  unsigned long long* grec = reinterpret_cast<unsigned long long*>(smem + L::kGrecOff);
   uint32_t* misc = reinterpret_cast<uint32_t*>(smem + L::kMiscOff);  // [0] irregular, [2] end of the regular stream, [3] a wait gave up
   const uint32_t c = blockIdx.x;
   const uint32_t tid = threadIdx.x;
@@ -200,7 +255,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 
     misc[2] = 0xffffffffu;
     misc[3] = 0u;
   }
-  for (uint32_t i = tid; i < (kSwRing * 8u + kSwRing * kSwMaxOps * 16u) / 4u; i += T) reinterpret_cast<uint32_t*>(trec)[i] = 0u;
+  for (uint32_t i = tid; i < (L::kMiscOff - L::kTrecOff) / 4u; i += T) reinterpret_cast<uint32_t*>(trec)[i] = 0u;
   // which ends of a byte's end mask close points when the first k0 of them do not: entry = mask | (next k0) << 8
   for (uint32_t e = tid; e < n_ops * 256u; e += T) {
     uint32_t k = e >> 8, sel = 0u;
@@ -231,6 +286,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 
   uint16_t* plist = reinterpret_cast<uint16_t*>(wmem + L::kListOff);
   uint16_t* jt = reinterpret_cast<uint16_t*>(wmem + L::kJumpOff);    // (FORM)
   uint16_t* cpt = reinterpret_cast<uint16_t*>(wmem + L::kCheckOff);  // (FORM)
+  uint32_t* rstate = reinterpret_cast<uint32_t*>(wmem + L::kCheckOff);       // (MODE 2, instead of the checkpoints) [9]: window of round r
+  uint16_t* rstart = reinterpret_cast<uint16_t*>(wmem + L::kCheckOff + 40u);  // [10]: first point of round r, 0xffff behind the last
 
   auto load_unit = [&](uint32_t v0, uint32_t(&u)[4]) __attribute__((always_inline)) {
     const bool ok = v0 < vend;
@@ -271,7 +328,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 
   }
   const bool raw_l = kind_l == OP_COPY || kind_l == OP_XOR32 || kind_l == OP_XOR64;
   const unsigned long long raw_ops = __ballot(raw_l);                                   // bit o: op o's token is `size` raw bytes
-  const unsigned long long xor_ops = __ballot(kind_l == OP_XOR32 || kind_l == OP_XOR64);  // its values combine with ^
+  const unsigned long long gor_ops = __ballot(kind_l == OP_GORILLA64);                  // (MODE 2: exactly one)
+  const uint32_t gor_op = gor_ops ? (uint32_t)__builtin_ctzll(gor_ops) : 0xffu;
+  const unsigned long long xor_ops = __ballot(kind_l == OP_XOR32 || kind_l == OP_XOR64 || kind_l == OP_GORILLA64);  // its values combine with ^
   const unsigned long long copy_ops = __ballot(kind_l == OP_COPY);                      // no state at all
   const unsigned long long int_ops = __ballot(kind_l == OP_INT);                        // a marker is an error there
   uint64_t run_l = 0ull;  // lane o: op o's running value (behind the last point handled so far)
@@ -305,51 +364,202 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 
       load_unit(pn * kSwPiece + lane * 16u, b);
       load_unit((pn + 1u) * kSwPiece + min(lane, 5u) * 16u, bh);
     }
-    uint32_t q_first = 0u, npts = 0u;
+    uint32_t q_first = 0u, npts = 0u, n_rounds = 1u, st_first = 0u;  // (MODE 2: rounds of the piece, window of the first)
     bool stop = false;  // the regular stream ended in front of this piece (uniform)
     if constexpr (FORM) {
-      // ---- jump table: where the point that would start at each of my 16 bytes ends (0xffff: no point can start there)
+      // ---- jump table: where the point that would start at each of my 16 bytes ends (0xffff: no point can start there).
+      // st (MODE 2) = the Gorilla window in effect: valid << 16 | leading << 8 | trailing; bit 15 of an entry: the point's
+      // '11' token opens a DIFFERENT window (the table is not valid behind that point)
       wp_wave_sync();  // (ebuf is complete)
+      const uint32_t* eb32j = reinterpret_cast<const uint32_t*>(ebuf);
+      uint32_t R[4];  // end bits of the 128 bytes from my first
       {
-        const uint32_t* eb32 = reinterpret_cast<const uint32_t*>(ebuf);
         const uint32_t wi = lane >> 1, wsft = (lane & 1u) * 16u;
-        uint32_t R[4];  // end bits of the 128 bytes from my first
-        {
-          const uint32_t q0 = eb32[wi], q1 = eb32[wi + 1u], q2 = eb32[wi + 2u], q3 = eb32[wi + 3u], q4 = eb32[wi + 4u];
-          R[0] = __builtin_amdgcn_alignbit(q1, q0, wsft);
-          R[1] = __builtin_amdgcn_alignbit(q2, q1, wsft);
-          R[2] = __builtin_amdgcn_alignbit(q3, q2, wsft);
-          R[3] = __builtin_amdgcn_alignbit(q4, q3, wsft);
+        const uint32_t q0 = eb32j[wi], q1 = eb32j[wi + 1u], q2 = eb32j[wi + 2u], q3 = eb32j[wi + 3u], q4 = eb32j[wi + 4u];
+        R[0] = __builtin_amdgcn_alignbit(q1, q0, wsft);
+        R[1] = __builtin_amdgcn_alignbit(q2, q1, wsft);
+        R[2] = __builtin_amdgcn_alignbit(q3, q2, wsft);
+        R[3] = __builtin_amdgcn_alignbit(q4, q3, wsft);
+      }
+      // the form of the point that would start at byte i of mine: returns its end (relative to my first byte), *ok,
+      // *new_st = the window its '11' token opens (0 = none)
+      auto point_form = [&](uint32_t i, uint32_t st, bool* ok_out, uint32_t* new_st) __attribute__((always_inline)) -> uint32_t {
+        uint32_t rel = i;
+        bool ok = true;
+        *new_st = 0u;
+        for (uint32_t o = 0; o < n_ops; ++o) {  // uniform
+          if (GOR && o == gor_op) {
+            const uint32_t bp = lane * 16u + rel;  // byte of the piece's LDS copy
+            const uint32_t w = __builtin_amdgcn_alignbit(wbuf[(bp >> 2) + 1u], wbuf[bp >> 2], (bp & 3u) * 8u);
+            uint32_t len;
+            if (p == 0u && lane * 16u + i == a0) {
+              len = 8u;  // the chunk's first value: raw bits
+            } else if ((w & 1u) == 0u) {
+              len = 1u;
+            } else if ((w & 2u) == 0u) {
+              const uint32_t m = 64u - ((st >> 8) & 0xffu) - (st & 0xffu);
+              ok = ok && (st >> 16) != 0u;  // (no window yet: the serial decoder raises the error)
+              len = (2u + m + 7u) >> 3;
+            } else {
+              const uint32_t sl = (w >> 2) & 31u, m = ((w >> 7) & 63u) + 1u;
+              ok = ok && sl + m <= 64u;
+              len = (13u + m + 7u) >> 3;
+              *new_st = 0x10000u | (sl << 8) | ((64u - sl - m) & 0xffu);
+            }
+            rel += len;
+          } else if ((raw_ops >> o) & 1ull) {
+            rel += (uint32_t)__builtin_amdgcn_readlane((int)size_l, (int)o);
+          } else {
+            const uint32_t idx = rel >> 5, sh = rel & 31u;
+            const uint32_t elo = idx == 0u ? R[0] : (idx == 1u ? R[1] : (idx == 2u ? R[2] : R[3]));
+            const uint32_t ehi = idx == 0u ? R[1] : (idx == 1u ? R[2] : (idx == 2u ? R[3] : 0u));
+            const uint32_t e = __builtin_amdgcn_alignbit(ehi, elo, sh) & 0x3ffu;  // a varint has 10 bytes at most
+            ok = ok && e != 0u;
+            rel += e ? (uint32_t)__builtin_ctz(e) + 1u : 1u;
+          }
+          rel = min(rel, 120u);
         }
+        *ok_out = ok;
+        return rel;
+      };
+      auto make_jt = [&](uint32_t st) __attribute__((always_inline)) {
         uint32_t packed[8];
 #pragma unroll
         for (uint32_t i = 0; i < 16u; ++i) {
-          uint32_t rel = i;
-          bool ok = true;
-          for (uint32_t o = 0; o < n_ops; ++o) {  // uniform
-            if ((raw_ops >> o) & 1ull) {
-              rel += (uint32_t)__builtin_amdgcn_readlane((int)size_l, (int)o);
-            } else {
-              const uint32_t idx = rel >> 5, sh = rel & 31u;
-              const uint32_t elo = idx == 0u ? R[0] : (idx == 1u ? R[1] : (idx == 2u ? R[2] : R[3]));
-              const uint32_t ehi = idx == 0u ? R[1] : (idx == 1u ? R[2] : (idx == 2u ? R[3] : 0u));
-              const uint32_t e = __builtin_amdgcn_alignbit(ehi, elo, sh) & 0x3ffu;  // a varint has 10 bytes at most
-              ok = ok && e != 0u;
-              rel += e ? (uint32_t)__builtin_ctz(e) + 1u : 1u;
-            }
-            rel = min(rel, 120u);
-          }
+          bool ok;
+          uint32_t nst;
+          const uint32_t rel = point_form(i, st, &ok, &nst);
           const uint32_t x = lane * 16u + i;        // byte of the piece
           const uint32_t end = x + (rel - i);       // (v-space, relative to the piece)
           ok = ok && rel - i <= kSwMaxPointBytes && p * kSwPiece + x >= a0 && p * kSwPiece + end <= vend;
-          const uint32_t jv = ok ? end : 0xffffu;
+          uint32_t jv = ok ? end : 0xffffu;
+          if (GOR && ok && nst != 0u && nst != st) jv |= 0x8000u;
           if (i & 1u) packed[i >> 1] |= jv << 16;
           else packed[i >> 1] = jv;
         }
         uint4* dst = reinterpret_cast<uint4*>(jt + lane * 16u);
         dst[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
         dst[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
-      }
+      };
+      if constexpr (GOR) {
+        // ---- chain 1 FIRST: {entry offset, points in front} and the window at the piece's entry
+        uint32_t entry = a0, pts0 = 0u, st = 0u;
+        if (p != 0u) {
+          const unsigned long long* r = trec + ((p - 1u) & (kSwRing - 1u));
+          const unsigned long long* rg = grec + ((p - 1u) & (kSwRing - 1u));
+          unsigned long long x = wp_rec_load(r), xg = wp_rec_load(rg);
+          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p ||
+              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xg >> 32)) != p) {
+            __builtin_amdgcn_s_setprio(0);
+            for (uint32_t spins = 1u;; ++spins) {
+              __builtin_amdgcn_s_sleep(kWpSleep);
+              x = wp_rec_load(r);
+              xg = wp_rec_load(rg);
+              if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) == p &&
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xg >> 32)) == p)
+                break;
+              if ((spins & 63u) == 0u && (spins >= kSwSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
+                gave_up = true;
+                break;
+              }
+            }
+            __builtin_amdgcn_s_setprio(1);
+          }
+          const uint32_t rv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+          entry = rv & 0xffu;
+          pts0 = rv >> 8;
+          st = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xg);
+        }
+        if (gave_up) break;
+        const bool dead = entry == 0xffu || entry >= kSwMaxPointBytes;
+        uint32_t out_entry = 0xffu, pts1 = pts0;
+        if (pts0 >= n) {
+          stop = true;
+        } else if (dead) {
+          if (lane == 0u) misc[0] = 1u;
+          stop = true;
+        } else {
+          // ---- rounds: table for the current window, one lane follows the jumps and lists the points, until the piece
+          // is left, the chunk's points are complete, or a point changes the window
+          const uint32_t limit = min(n - pts0, L::kListEntries - 8u);
+          st_first = st;
+          uint32_t xcur = entry, j = 0u, rounds = 0u;
+          bool broken = false;
+          for (;;) {
+            make_jt(st);
+            wp_wave_sync();
+            if (lane == 0u) {
+              rstart[rounds] = (uint16_t)j;
+              rstate[rounds] = st;
+            }
+            uint32_t wx = xcur, wj = j, flag = 0u;
+            if (lane == 0u) {
+              while (wx < kSwPiece && wj < limit) {
+                plist[wj] = (uint16_t)wx;
+                const uint32_t e = jt[wx];
+                if (e == 0xffffu) {
+                  flag = 2u;
+                  break;
+                }
+                ++wj;
+                if (pts0 + wj == n) misc[2] = p * kSwPiece + (e & 0x7ffu) - a0;  // behind the chunk's last point: the sections
+                wx = e & 0x7ffu;
+                if (e & 0x8000u) {
+                  flag = 1u;
+                  break;
+                }
+              }
+            }
+            wx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wx);
+            wj = (uint32_t)__builtin_amdgcn_readfirstlane((int)wj);
+            flag = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag);
+            ++rounds;
+            if (flag == 2u) {
+              broken = true;
+              break;
+            }
+            if (flag == 1u) {
+              // the window the last listed point's '11' token opened: its owner lane works the point's form out once more
+              const uint32_t xf = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)plist[wj - 1u]);
+              uint32_t nst = 0u;
+#pragma unroll
+              for (uint32_t i = 0; i < 16u; ++i) {
+                if (i == (xf & 15u)) {  // uniform
+                  bool ok;
+                  uint32_t t;
+                  point_form(i, st, &ok, &t);
+                  nst = t;
+                }
+              }
+              st = (uint32_t)__builtin_amdgcn_readlane((int)nst, (int)(xf >> 4));
+            }
+            xcur = wx;
+            j = wj;
+            if (flag == 0u || wx >= kSwPiece || wj >= limit) break;
+            if (rounds >= 8u) {  // the window changes all the time: the serial decoder takes the chunk
+              broken = true;
+              break;
+            }
+          }
+          if (lane == 0u) rstart[rounds] = 0xffffu;
+          if (broken || (j < n - pts0 && xcur < kSwPiece)) {
+            // (a list that ran out of room before the piece's end cannot happen: a point has two bytes at least)
+            if (lane == 0u) misc[0] = 1u;
+            stop = true;
+          } else {
+            q_first = pts0;
+            npts = j;
+            n_rounds = rounds;
+            pts1 = pts0 + j;
+            out_entry = xcur >= kSwPiece ? xcur - kSwPiece : 0xffu;
+          }
+        }
+        if (lane == 0u) {
+          wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
+          wp_rec_store(grec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | st);
+        }
+      } else {
+      make_jt(0u);
       wp_wave_sync();
       // ---- the first lanes follow the jumps from their byte: where the next piece is entered, and after how many points.
       // On the way a candidate leaves a checkpoint in every 128-byte block it passes: its first point there and how many
@@ -445,6 +655,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 
         }
         if (__ballot(broken) != 0ull && lane == 0u) misc[0] = 1u;
       }
+      }
     } else {
       // ---- chain 1: token ends in front of the piece
       uint32_t T0 = 0u;
@@ -506,7 +717,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 
 
     // A point's tokens, op by op. fn(o, value, marker) is called for every op (uniform o); returns false when the point
     // is irregular. Token lengths: distance to the next end bit (varints), or the field's size (raw ops).
-    auto walk = [&](uint32_t byte0, bool have, auto&& fn) __attribute__((always_inline)) -> bool {
+    auto walk = [&](uint32_t j, uint32_t byte0, bool have, auto&& fn) __attribute__((always_inline)) -> bool {
       // the end bits of the 96 bytes behind the point's first
       const uint32_t* eb32 = reinterpret_cast<const uint32_t*>(ebuf);
       const uint32_t ei = byte0 >> 5, es = byte0 & 31u;
@@ -515,6 +726,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 
       uint32_t pos = 0u;
       bool bad = false;
       for (uint32_t o = 0; o < n_ops; ++o) {  // uniform
+        if (GOR && o == gor_op) {
+          uint32_t stp = st_first;  // the window in effect: that of the point's round
+          if (n_rounds > 1u) {      // uniform
+            for (uint32_t r = 1; r < n_rounds; ++r)
+              if (j >= (uint32_t)rstart[r]) stp = rstate[r];
+          }
+          uint32_t len = 1u;
+          const uint64_t v = sw_gorilla(wbuf, byte0 + pos, q_first + j == 0u, stp, &len, &bad);
+          fn(o, have ? v : 0ull, false);
+          pos = min(pos + len, kSwMaxPointBytes - 1u);
+          continue;
+        }
         const bool raw = (raw_ops >> o) & 1ull;
         const uint32_t size = (uint32_t)__builtin_amdgcn_readlane((int)size_l, (int)o);
         // end bits from `pos` on (pos < 88)
@@ -550,7 +773,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 
       const uint32_t j = r * 64u + lane;
       const bool have = j < npts;
       const uint32_t byte0 = have ? (uint32_t)plist[j] : 0u;
-      const bool bad = walk(byte0, have, [&](uint32_t o, uint64_t v, bool mk) __attribute__((always_inline)) {
+      const bool bad = walk(j, byte0, have, [&](uint32_t o, uint64_t v, bool mk) __attribute__((always_inline)) {
         if ((copy_ops >> o) & 1ull) return;
         uint64_t tot;
         bool reset = false;
@@ -612,7 +835,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 
       const bool have = j < npts;
       const uint32_t byte0 = have ? (uint32_t)plist[j] : 0u;
       uint8_t* pt = base + __umul24(q_first + (have ? j : 0u), step);  // (q < 2^16, step <= 1024)
-      walk(byte0, have, [&](uint32_t o, uint64_t v, bool mk) __attribute__((always_inline)) {
+      walk(j, byte0, have, [&](uint32_t o, uint64_t v, bool mk) __attribute__((always_inline)) {
         const DevOp& op = plan.ops[o];
         const uint32_t off = op.offset;
         const uint32_t kind = op.kind;
@@ -622,7 +845,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(FORM ? 
         }
         const uint64_t before = sw_lane64(run_l, o);  // (uniform)
         uint64_t cur;
-        if (kind == OP_XOR32 || kind == OP_XOR64) {
+        if (kind == OP_XOR32 || kind == OP_XOR64 || kind == OP_GORILLA64) {
           const uint64_t inc = sw_scan64<true>(v);
           cur = before ^ inc;
           const uint64_t after = before ^ sw_lane64(inc, 63u);
