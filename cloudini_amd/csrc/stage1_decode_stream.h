@@ -334,6 +334,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   const unsigned long long copy_ops = __ballot(kind_l == OP_COPY);                      // no state at all
   const unsigned long long int_ops = __ballot(kind_l == OP_INT);                        // a marker is an error there
   uint64_t run_l = 0ull;  // lane o: op o's running value (behind the last point handled so far)
+  uint32_t st_last = 0u;  // MODE 2: the Gorilla window behind the piece this wave handled last (uniform)
 
   uint32_t b[4], bh[4];
   uint32_t p = wave;
@@ -441,125 +442,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         dst[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
         dst[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
       };
-      if constexpr (GOR) {
-        // ---- chain 1 FIRST: {entry offset, points in front} and the window at the piece's entry
-        uint32_t entry = a0, pts0 = 0u, st = 0u;
-        if (p != 0u) {
-          const unsigned long long* r = trec + ((p - 1u) & (kSwRing - 1u));
-          const unsigned long long* rg = grec + ((p - 1u) & (kSwRing - 1u));
-          unsigned long long x = wp_rec_load(r), xg = wp_rec_load(rg);
-          if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p ||
-              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xg >> 32)) != p) {
-            __builtin_amdgcn_s_setprio(0);
-            for (uint32_t spins = 1u;; ++spins) {
-              __builtin_amdgcn_s_sleep(kWpSleep);
-              x = wp_rec_load(r);
-              xg = wp_rec_load(rg);
-              if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) == p &&
-                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xg >> 32)) == p)
-                break;
-              if ((spins & 63u) == 0u && (spins >= kSwSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
-                gave_up = true;
-                break;
-              }
-            }
-            __builtin_amdgcn_s_setprio(1);
-          }
-          const uint32_t rv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
-          entry = rv & 0xffu;
-          pts0 = rv >> 8;
-          st = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xg);
-        }
-        if (gave_up) break;
-        const bool dead = entry == 0xffu || entry >= kSwMaxPointBytes;
-        uint32_t out_entry = 0xffu, pts1 = pts0;
-        if (pts0 >= n) {
-          stop = true;
-        } else if (dead) {
-          if (lane == 0u) misc[0] = 1u;
-          stop = true;
-        } else {
-          // ---- rounds: table for the current window, one lane follows the jumps and lists the points, until the piece
-          // is left, the chunk's points are complete, or a point changes the window
-          const uint32_t limit = min(n - pts0, L::kListEntries - 8u);
-          st_first = st;
-          uint32_t xcur = entry, j = 0u, rounds = 0u;
-          bool broken = false;
-          for (;;) {
-            make_jt(st);
-            wp_wave_sync();
-            if (lane == 0u) {
-              rstart[rounds] = (uint16_t)j;
-              rstate[rounds] = st;
-            }
-            uint32_t wx = xcur, wj = j, flag = 0u;
-            if (lane == 0u) {
-              while (wx < kSwPiece && wj < limit) {
-                plist[wj] = (uint16_t)wx;
-                const uint32_t e = jt[wx];
-                if (e == 0xffffu) {
-                  flag = 2u;
-                  break;
-                }
-                ++wj;
-                if (pts0 + wj == n) misc[2] = p * kSwPiece + (e & 0x7ffu) - a0;  // behind the chunk's last point: the sections
-                wx = e & 0x7ffu;
-                if (e & 0x8000u) {
-                  flag = 1u;
-                  break;
-                }
-              }
-            }
-            wx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wx);
-            wj = (uint32_t)__builtin_amdgcn_readfirstlane((int)wj);
-            flag = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag);
-            ++rounds;
-            if (flag == 2u) {
-              broken = true;
-              break;
-            }
-            if (flag == 1u) {
-              // the window the last listed point's '11' token opened: its owner lane works the point's form out once more
-              const uint32_t xf = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)plist[wj - 1u]);
-              uint32_t nst = 0u;
-#pragma unroll
-              for (uint32_t i = 0; i < 16u; ++i) {
-                if (i == (xf & 15u)) {  // uniform
-                  bool ok;
-                  uint32_t t;
-                  point_form(i, st, &ok, &t);
-                  nst = t;
-                }
-              }
-              st = (uint32_t)__builtin_amdgcn_readlane((int)nst, (int)(xf >> 4));
-            }
-            xcur = wx;
-            j = wj;
-            if (flag == 0u || wx >= kSwPiece || wj >= limit) break;
-            if (rounds >= 8u) {  // the window changes all the time: the serial decoder takes the chunk
-              broken = true;
-              break;
-            }
-          }
-          if (lane == 0u) rstart[rounds] = 0xffffu;
-          if (broken || (j < n - pts0 && xcur < kSwPiece)) {
-            // (a list that ran out of room before the piece's end cannot happen: a point has two bytes at least)
-            if (lane == 0u) misc[0] = 1u;
-            stop = true;
-          } else {
-            q_first = pts0;
-            npts = j;
-            n_rounds = rounds;
-            pts1 = pts0 + j;
-            out_entry = xcur >= kSwPiece ? xcur - kSwPiece : 0xffu;
-          }
-        }
-        if (lane == 0u) {
-          wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
-          wp_rec_store(grec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | st);
-        }
-      } else {
-      make_jt(0u);
+      // MODE 2: the table is built for the window this wave saw last (windows change rarely: the guess is right for all but a
+      // few pieces); a piece whose guess was wrong, or whose own '11' tokens change the window, is redone in rounds below
+      const uint32_t st_pred = GOR ? st_last : 0u;
+      make_jt(st_pred);
       wp_wave_sync();
       // ---- the first lanes follow the jumps from their byte: where the next piece is entered, and after how many points.
       // On the way a candidate leaves a checkpoint in every 128-byte block it passes: its first point there and how many
@@ -579,6 +465,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
             if (bk != pb0) cpt[lane * 8u + bk] = (uint16_t)((x0 & 127u) | (c0 << 7));
             pb0 = bk;
             x0 = jt[x0];
+            if (GOR && x0 != 0xffffu && (x0 & 0x8000u)) x0 = 0xfffeu;  // the window changes behind this point: rounds
             ++c0;
           }
           if (x1 < kSwPiece) {
@@ -586,6 +473,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
             if (bk != pb1) cpt[(64u + lane) * 8u + bk] = (uint16_t)((x1 & 127u) | (c1 << 7));
             pb1 = bk;
             x1 = jt[x1];
+            if (GOR && x1 != 0xffffu && (x1 & 0x8000u)) x1 = 0xfffeu;
             ++c1;
           }
         }
@@ -594,17 +482,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         ex[1] = x1;
         ec[1] = c1;
       }
-      // ---- chain 1: {entry offset, points in front} of the piece
-      uint32_t entry = a0, pts0 = 0u;
+      // ---- chain 1: {entry offset, points in front} of the piece (MODE 2: and the window at its entry)
+      uint32_t entry = a0, pts0 = 0u, st = 0u;
       if (p != 0u) {
         const unsigned long long* r = trec + ((p - 1u) & (kSwRing - 1u));
-        unsigned long long x = wp_rec_load(r);
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p) {
+        const unsigned long long* rg = grec + ((p - 1u) & (kSwRing - 1u));
+        unsigned long long x = wp_rec_load(r), xg = GOR ? wp_rec_load(rg) : 0ull;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p ||
+            (GOR && (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xg >> 32)) != p)) {
           __builtin_amdgcn_s_setprio(0);
           for (uint32_t spins = 1u;; ++spins) {
             __builtin_amdgcn_s_sleep(kWpSleep);
             x = wp_rec_load(r);
-            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) == p) break;
+            if (GOR) xg = wp_rec_load(rg);
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) == p &&
+                (!GOR || (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xg >> 32)) == p))
+              break;
             if ((spins & 63u) == 0u && (spins >= kSwSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
               gave_up = true;
               break;
@@ -615,6 +508,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         const uint32_t rv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
         entry = rv & 0xffu;
         pts0 = rv >> 8;
+        if (GOR) st = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xg);
       }
       if (gave_up) break;
       // (entry 0xff: the piece in front could not be left through a well-formed point -- malformed, or only the bytes
@@ -623,38 +517,129 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       const uint32_t el = dead ? 0u : entry;
       const uint32_t my_exit = (uint32_t)__builtin_amdgcn_readlane((int)(el < 64u ? ex[0] : ex[1]), (int)(el & 63u));
       const uint32_t my_cnt = (uint32_t)__builtin_amdgcn_readlane((int)(el < 64u ? ec[0] : ec[1]), (int)(el & 63u));
-      const uint32_t out_entry = (dead || my_exit == 0xffffu) ? 0xffu : my_exit - kSwPiece;
-      const uint32_t pts1 = dead ? pts0 : min(pts0 + my_cnt, n);
-      if (lane == 0u) wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
-      if (pts0 >= n) stop = true;
-      else if (dead) {
-        if (lane == 0u) misc[0] = 1u;  // points are missing and the stream cannot be followed: the serial decoder raises the error
-        stop = true;
-      } else {
-        q_first = pts0;
-        npts = min(my_cnt, n - pts0);
-        // ---- the points' first bytes, in order: lane b lists the points that begin in block b, from the entry's checkpoint
-        wp_wave_sync();
-        bool broken = false;
-        if (lane < 8u) {
-          const uint32_t ck = cpt[entry * 8u + lane];
-          if (ck != 0xffffu) {
-            uint32_t x = lane * 128u + (ck & 127u), j = ck >> 7;
-            while (x < (lane + 1u) * 128u && j < npts) {
-              plist[j] = (uint16_t)x;
-              const uint32_t nx = jt[x];
-              if (nx == 0xffffu) {
-                broken = true;  // (the candidates' walk counted the points up to here only)
-                break;
+      const bool rounds_needed = GOR && !dead && pts0 < n && (st != st_pred || my_exit == 0xfffeu);
+      if (!rounds_needed) {
+        const uint32_t out_entry = (dead || my_exit >= 0xfffeu) ? 0xffu : my_exit - kSwPiece;
+        const uint32_t pts1 = dead ? pts0 : min(pts0 + my_cnt, n);
+        if (lane == 0u) {
+          wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
+          if (GOR) wp_rec_store(grec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | st);
+        }
+        st_last = st;
+        if (pts0 >= n) stop = true;
+        else if (dead) {
+          if (lane == 0u) misc[0] = 1u;  // points are missing and the stream cannot be followed: the serial decoder raises the error
+          stop = true;
+        } else {
+          q_first = pts0;
+          npts = min(my_cnt, n - pts0);
+          st_first = st;
+          // ---- the points' first bytes, in order: lane b lists the points that begin in block b, from the entry's checkpoint
+          wp_wave_sync();
+          bool broken = false;
+          if (lane < 8u) {
+            const uint32_t ck = cpt[entry * 8u + lane];
+            if (ck != 0xffffu) {
+              uint32_t x = lane * 128u + (ck & 127u), j = ck >> 7;
+              while (x < (lane + 1u) * 128u && j < npts) {
+                plist[j] = (uint16_t)x;
+                const uint32_t nx = jt[x] & 0x7fffu;
+                if (nx == 0x7fffu) {
+                  broken = true;  // (the candidates' walk counted the points up to here only)
+                  break;
+                }
+                if (pts0 + j + 1u == n) misc[2] = p * kSwPiece + nx - a0;  // behind the chunk's last point: the sections
+                x = nx;
+                ++j;
               }
-              if (pts0 + j + 1u == n) misc[2] = p * kSwPiece + nx - a0;  // behind the chunk's last point: the sections
-              x = nx;
-              ++j;
             }
           }
+          if (__ballot(broken) != 0ull && lane == 0u) misc[0] = 1u;
         }
-        if (__ballot(broken) != 0ull && lane == 0u) misc[0] = 1u;
-      }
+      } else {
+        // ---- MODE 2, rounds: table for the current window, one lane follows the jumps and lists the points, until the piece
+        // is left, the chunk's points are complete, or a point changes the window
+        uint32_t out_entry = 0xffu, pts1 = pts0;
+        const uint32_t limit = min(n - pts0, L::kListEntries - 8u);
+        st_first = st;
+        uint32_t xcur = entry, j = 0u, rounds = 0u;
+        bool broken = false;
+        for (;;) {
+          if (rounds != 0u || st != st_pred) {
+            wp_wave_sync();
+            make_jt(st);
+          }
+          wp_wave_sync();
+          if (lane == 0u) {
+            rstart[rounds] = (uint16_t)j;
+            rstate[rounds] = st;
+          }
+          uint32_t wx = xcur, wj = j, flag = 0u;
+          if (lane == 0u) {
+            while (wx < kSwPiece && wj < limit) {
+              plist[wj] = (uint16_t)wx;
+              const uint32_t e = jt[wx];
+              if (e == 0xffffu) {
+                flag = 2u;
+                break;
+              }
+              ++wj;
+              if (pts0 + wj == n) misc[2] = p * kSwPiece + (e & 0x7ffu) - a0;  // behind the chunk's last point: the sections
+              wx = e & 0x7ffu;
+              if (e & 0x8000u) {
+                flag = 1u;
+                break;
+              }
+            }
+          }
+          wx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wx);
+          wj = (uint32_t)__builtin_amdgcn_readfirstlane((int)wj);
+          flag = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag);
+          ++rounds;
+          if (flag == 2u) {
+            broken = true;
+            break;
+          }
+          if (flag == 1u) {
+            // the window the last listed point's '11' token opened: its owner lane works the point's form out once more
+            const uint32_t xf = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)plist[wj - 1u]);
+            uint32_t nst = 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < 16u; ++i) {
+              if (i == (xf & 15u)) {  // uniform
+                bool ok;
+                uint32_t t;
+                point_form(i, st, &ok, &t);
+                nst = t;
+              }
+            }
+            st = (uint32_t)__builtin_amdgcn_readlane((int)nst, (int)(xf >> 4));
+          }
+          xcur = wx;
+          j = wj;
+          if (flag == 0u || wx >= kSwPiece || wj >= limit) break;
+          if (rounds >= 8u) {  // the window changes all the time: the serial decoder takes the chunk
+            broken = true;
+            break;
+          }
+        }
+        if (lane == 0u) rstart[rounds] = 0xffffu;
+        if (broken || (j < n - pts0 && xcur < kSwPiece)) {
+          // (a list that ran out of room before the piece's end cannot happen: a point has two bytes at least)
+          if (lane == 0u) misc[0] = 1u;
+          stop = true;
+        } else {
+          q_first = pts0;
+          npts = j;
+          n_rounds = rounds;
+          pts1 = pts0 + j;
+          out_entry = xcur >= kSwPiece ? xcur - kSwPiece : 0xffu;
+        }
+        if (lane == 0u) {
+          wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
+          wp_rec_store(grec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | st);
+        }
+        st_last = st;
       }
     } else {
       // ---- chain 1: token ends in front of the piece
