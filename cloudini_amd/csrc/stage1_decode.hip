@@ -246,7 +246,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     // round 4: streams with ONE Gorilla-coded field (FLOAT64 without resolution, wire version >= 4: the reference's own DDS
     // sample layout) next to varints and raw fields: MODE 2 of the stream kernel; CLDN_HIP_NO_GORILLA_KERNEL=1: A/B switch
     static const bool no_gor = getenv("CLDN_HIP_NO_GORILLA_KERNEL") != nullptr;
-    if (!fast && !no_fast && !no_gor && P.n_gorilla == 1u && P.n_ops >= 2u && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes) {
+    if (!fast && !no_fast && !no_gor && P.n_gorilla >= 1u && P.n_ops >= 2u && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes) {
       bool ok = true;
       for (uint32_t k = 0; k < P.n_ops && ok; ++k) {
         const uint32_t kd = P.ops[k].kind, sz = P.ops[k].size;

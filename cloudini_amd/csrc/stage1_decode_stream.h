@@ -24,6 +24,7 @@ constexpr uint32_t kSwMaxOps = 8u;
 constexpr uint32_t kSwRing = 32u;
 constexpr uint32_t kSwListEntries = 1032u;  // points a piece can own (one op of one byte: one per byte) + slack
 constexpr uint32_t kSwSpinLimit = 1u << 18;
+constexpr uint32_t kSwMaxRounds = 40u;      // MODE 2: window changes inside one piece (a chunk's first stamps settle through several)
 
 template <int NW, bool FORM = false>
 struct SwLds {
@@ -34,11 +35,12 @@ struct SwLds {
   static constexpr uint32_t kJumpOff = (kListOff + kListEntries * 2u + 15u) & ~15u;  // FORM: u16 [kSwPiece]: where the point that starts at a byte ends
   static constexpr uint32_t kCheckOff = kJumpOff + (FORM ? kSwPiece * 2u : 0u);      // FORM: u16 [kSwMaxPointBytes][8]: a candidate's first point in every 128-byte block
   static constexpr uint32_t kWaveBytes = kCheckOff + (FORM ? kSwMaxPointBytes * 16u : 0u);
+  static_assert(kSwMaxRounds * kSwMaxOps * 4u + (kSwMaxRounds + 1u) * 2u <= kSwMaxPointBytes * 16u, "MODE 2 keeps its rounds where MODE 1 keeps its checkpoints");
   static constexpr uint32_t kLutOff = (uint32_t)NW * kWaveBytes;              // u16 [kSwMaxOps][256]
   static constexpr uint32_t kTrecOff = kLutOff + kSwMaxOps * 512u;            // u64 [kSwRing]
   static constexpr uint32_t kVrecOff = kTrecOff + kSwRing * 8u;               // u64 [kSwRing][kSwMaxOps][2]: {tag, lo}, {tag, hi} of the value behind the piece
-  static constexpr uint32_t kGrecOff = kVrecOff + kSwRing * kSwMaxOps * 16u;  // u64 [kSwRing]: {tag, Gorilla window behind the piece} (MODE 2)
-  static constexpr uint32_t kMiscOff = kGrecOff + kSwRing * 8u;
+  static constexpr uint32_t kGrecOff = kVrecOff + kSwRing * kSwMaxOps * 16u;  // u64 [kSwRing][kSwMaxOps]: {tag, Gorilla window of op o behind the piece} (MODE 2)
+  static constexpr uint32_t kMiscOff = kGrecOff + kSwRing * kSwMaxOps * 8u;
   static constexpr uint32_t kTotal = kMiscOff + 256u;
 };
 
@@ -286,8 +288,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   uint16_t* plist = reinterpret_cast<uint16_t*>(wmem + L::kListOff);
   uint16_t* jt = reinterpret_cast<uint16_t*>(wmem + L::kJumpOff);    // (FORM)
   uint16_t* cpt = reinterpret_cast<uint16_t*>(wmem + L::kCheckOff);  // (FORM)
-  uint32_t* rstate = reinterpret_cast<uint32_t*>(wmem + L::kCheckOff);       // (MODE 2, instead of the checkpoints) [9]: window of round r
-  uint16_t* rstart = reinterpret_cast<uint16_t*>(wmem + L::kCheckOff + 40u);  // [10]: first point of round r, 0xffff behind the last
+  uint32_t* rstate = reinterpret_cast<uint32_t*>(wmem + L::kCheckOff);        // (MODE 2, instead of the checkpoints) [kSwMaxRounds][kSwMaxOps]: windows of round r
+  uint16_t* rstart = reinterpret_cast<uint16_t*>(wmem + L::kCheckOff + kSwMaxRounds * kSwMaxOps * 4u);  // [kSwMaxRounds + 1]: first point of round r
 
   auto load_unit = [&](uint32_t v0, uint32_t(&u)[4]) __attribute__((always_inline)) {
     const bool ok = v0 < vend;
@@ -328,13 +330,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   }
   const bool raw_l = kind_l == OP_COPY || kind_l == OP_XOR32 || kind_l == OP_XOR64;
   const unsigned long long raw_ops = __ballot(raw_l);                                   // bit o: op o's token is `size` raw bytes
-  const unsigned long long gor_ops = __ballot(kind_l == OP_GORILLA64);                  // (MODE 2: exactly one)
-  const uint32_t gor_op = gor_ops ? (uint32_t)__builtin_ctzll(gor_ops) : 0xffu;
+  const unsigned long long gor_ops = __ballot(kind_l == OP_GORILLA64);                  // (MODE 2: one or more)
   const unsigned long long xor_ops = __ballot(kind_l == OP_XOR32 || kind_l == OP_XOR64 || kind_l == OP_GORILLA64);  // its values combine with ^
   const unsigned long long copy_ops = __ballot(kind_l == OP_COPY);                      // no state at all
   const unsigned long long int_ops = __ballot(kind_l == OP_INT);                        // a marker is an error there
   uint64_t run_l = 0ull;  // lane o: op o's running value (behind the last point handled so far)
-  uint32_t st_last = 0u;  // MODE 2: the Gorilla window behind the piece this wave handled last (uniform)
+  uint32_t st_last = 0u;  // MODE 2, lane o: op o's Gorilla window behind the piece this wave handled last
 
   uint32_t b[4], bh[4];
   uint32_t p = wave;
@@ -384,28 +385,35 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       }
       // the form of the point that would start at byte i of mine: returns its end (relative to my first byte), *ok,
       // *new_st = the window its '11' token opens (0 = none)
-      auto point_form = [&](uint32_t i, uint32_t st, bool* ok_out, uint32_t* new_st) __attribute__((always_inline)) -> uint32_t {
+      // (st: lane o = the window of op o in effect. owner < 64: the windows the '11' tokens of THAT lane's point open are
+      // captured into *st_out, lane o again.)
+      auto point_form = [&](uint32_t i, uint32_t st, bool* ok_out, bool* changed, uint32_t owner, uint32_t* st_out) __attribute__((always_inline)) -> uint32_t {
         uint32_t rel = i;
-        bool ok = true;
-        *new_st = 0u;
+        bool ok = true, chg = false;
         for (uint32_t o = 0; o < n_ops; ++o) {  // uniform
-          if (GOR && o == gor_op) {
+          if (GOR && ((gor_ops >> o) & 1ull)) {
+            const uint32_t sto = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)o);
             const uint32_t bp = lane * 16u + rel;  // byte of the piece's LDS copy
             const uint32_t w = __builtin_amdgcn_alignbit(wbuf[(bp >> 2) + 1u], wbuf[bp >> 2], (bp & 3u) * 8u);
-            uint32_t len;
+            uint32_t len, nst = 0u;
             if (p == 0u && lane * 16u + i == a0) {
               len = 8u;  // the chunk's first value: raw bits
             } else if ((w & 1u) == 0u) {
               len = 1u;
             } else if ((w & 2u) == 0u) {
-              const uint32_t m = 64u - ((st >> 8) & 0xffu) - (st & 0xffu);
-              ok = ok && (st >> 16) != 0u;  // (no window yet: the serial decoder raises the error)
+              const uint32_t m = 64u - ((sto >> 8) & 0xffu) - (sto & 0xffu);
+              ok = ok && (sto >> 16) != 0u;  // (no window yet: the serial decoder raises the error)
               len = (2u + m + 7u) >> 3;
             } else {
               const uint32_t sl = (w >> 2) & 31u, m = ((w >> 7) & 63u) + 1u;
               ok = ok && sl + m <= 64u;
               len = (13u + m + 7u) >> 3;
-              *new_st = 0x10000u | (sl << 8) | ((64u - sl - m) & 0xffu);
+              nst = 0x10000u | (sl << 8) | ((64u - sl - m) & 0xffu);
+              chg = chg || nst != sto;
+            }
+            if (owner < 64u) {
+              const uint32_t cv = (uint32_t)__builtin_amdgcn_readlane((int)nst, (int)owner);
+              if (lane == o && cv != 0u) *st_out = cv;
             }
             rel += len;
           } else if ((raw_ops >> o) & 1ull) {
@@ -421,20 +429,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
           rel = min(rel, 120u);
         }
         *ok_out = ok;
+        *changed = chg;
         return rel;
       };
       auto make_jt = [&](uint32_t st) __attribute__((always_inline)) {
         uint32_t packed[8];
 #pragma unroll
         for (uint32_t i = 0; i < 16u; ++i) {
-          bool ok;
-          uint32_t nst;
-          const uint32_t rel = point_form(i, st, &ok, &nst);
+          bool ok, chg;
+          uint32_t unused = 0u;
+          const uint32_t rel = point_form(i, st, &ok, &chg, 64u, &unused);
           const uint32_t x = lane * 16u + i;        // byte of the piece
           const uint32_t end = x + (rel - i);       // (v-space, relative to the piece)
           ok = ok && rel - i <= kSwMaxPointBytes && p * kSwPiece + x >= a0 && p * kSwPiece + end <= vend;
           uint32_t jv = ok ? end : 0xffffu;
-          if (GOR && ok && nst != 0u && nst != st) jv |= 0x8000u;
+          if (GOR && ok && chg) jv |= 0x8000u;
           if (i & 1u) packed[i >> 1] |= jv << 16;
           else packed[i >> 1] = jv;
         }
@@ -483,21 +492,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         ec[1] = c1;
       }
       // ---- chain 1: {entry offset, points in front} of the piece (MODE 2: and the window at its entry)
-      uint32_t entry = a0, pts0 = 0u, st = 0u;
+      uint32_t entry = a0, pts0 = 0u, st = 0u;  // (st: lane o = window of op o)
       if (p != 0u) {
         const unsigned long long* r = trec + ((p - 1u) & (kSwRing - 1u));
-        const unsigned long long* rg = grec + ((p - 1u) & (kSwRing - 1u));
+        const unsigned long long* rg = grec + (size_t)((p - 1u) & (kSwRing - 1u)) * kSwMaxOps + min(lane, n_ops - 1u);
         unsigned long long x = wp_rec_load(r), xg = GOR ? wp_rec_load(rg) : 0ull;
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p ||
-            (GOR && (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xg >> 32)) != p)) {
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p || (GOR && __ballot((uint32_t)(xg >> 32) != p) != 0ull)) {
           __builtin_amdgcn_s_setprio(0);
           for (uint32_t spins = 1u;; ++spins) {
             __builtin_amdgcn_s_sleep(kWpSleep);
             x = wp_rec_load(r);
             if (GOR) xg = wp_rec_load(rg);
-            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) == p &&
-                (!GOR || (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(xg >> 32)) == p))
-              break;
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) == p && (!GOR || __ballot((uint32_t)(xg >> 32) != p) == 0ull)) break;
             if ((spins & 63u) == 0u && (spins >= kSwSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
               gave_up = true;
               break;
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         const uint32_t rv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
         entry = rv & 0xffu;
         pts0 = rv >> 8;
-        if (GOR) st = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xg);
+        if (GOR) st = lane < n_ops ? (uint32_t)xg : 0u;
       }
       if (gave_up) break;
       // (entry 0xff: the piece in front could not be left through a well-formed point -- malformed, or only the bytes
@@ -517,14 +523,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       const uint32_t el = dead ? 0u : entry;
       const uint32_t my_exit = (uint32_t)__builtin_amdgcn_readlane((int)(el < 64u ? ex[0] : ex[1]), (int)(el & 63u));
       const uint32_t my_cnt = (uint32_t)__builtin_amdgcn_readlane((int)(el < 64u ? ec[0] : ec[1]), (int)(el & 63u));
-      const bool rounds_needed = GOR && !dead && pts0 < n && (st != st_pred || my_exit == 0xfffeu);
+      const bool rounds_needed = GOR && !dead && pts0 < n && (__ballot(st != st_pred) != 0ull || my_exit == 0xfffeu);
       if (!rounds_needed) {
         const uint32_t out_entry = (dead || my_exit >= 0xfffeu) ? 0xffu : my_exit - kSwPiece;
         const uint32_t pts1 = dead ? pts0 : min(pts0 + my_cnt, n);
-        if (lane == 0u) {
-          wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
-          if (GOR) wp_rec_store(grec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | st);
-        }
+        if (lane == 0u) wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
+        if (GOR && lane < n_ops) wp_rec_store(grec + (size_t)(p & (kSwRing - 1u)) * kSwMaxOps + lane, ((unsigned long long)(p + 1u) << 32) | st);
         st_last = st;
         if (pts0 >= n) stop = true;
         else if (dead) {
@@ -565,15 +569,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         uint32_t xcur = entry, j = 0u, rounds = 0u;
         bool broken = false;
         for (;;) {
-          if (rounds != 0u || st != st_pred) {
+          if (rounds != 0u || __ballot(st != st_pred) != 0ull) {
             wp_wave_sync();
             make_jt(st);
           }
           wp_wave_sync();
-          if (lane == 0u) {
-            rstart[rounds] = (uint16_t)j;
-            rstate[rounds] = st;
-          }
+          if (lane == 0u) rstart[rounds] = (uint16_t)j;
+          if (lane < kSwMaxOps) rstate[rounds * kSwMaxOps + lane] = st;
           uint32_t wx = xcur, wj = j, flag = 0u;
           if (lane == 0u) {
             while (wx < kSwPiece && wj < limit) {
@@ -601,29 +603,26 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
             break;
           }
           if (flag == 1u) {
-            // the window the last listed point's '11' token opened: its owner lane works the point's form out once more
+            // the windows the last listed point's '11' tokens opened: its owner lane works the point's form out once more
             const uint32_t xf = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)plist[wj - 1u]);
-            uint32_t nst = 0u;
+            uint32_t st_new = st;
 #pragma unroll
             for (uint32_t i = 0; i < 16u; ++i) {
               if (i == (xf & 15u)) {  // uniform
-                bool ok;
-                uint32_t t;
-                point_form(i, st, &ok, &t);
-                nst = t;
+                bool ok, chg;
+                point_form(i, st, &ok, &chg, xf >> 4, &st_new);
               }
             }
-            st = (uint32_t)__builtin_amdgcn_readlane((int)nst, (int)(xf >> 4));
+            st = st_new;
           }
           xcur = wx;
           j = wj;
           if (flag == 0u || wx >= kSwPiece || wj >= limit) break;
-          if (rounds >= 8u) {  // the window changes all the time: the serial decoder takes the chunk
+          if (rounds >= kSwMaxRounds) {  // the window changes all the time: the serial decoder takes the chunk
             broken = true;
             break;
           }
         }
-        if (lane == 0u) rstart[rounds] = 0xffffu;
         if (broken || (j < n - pts0 && xcur < kSwPiece)) {
           // (a list that ran out of room before the piece's end cannot happen: a point has two bytes at least)
           if (lane == 0u) misc[0] = 1u;
@@ -635,10 +634,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
           pts1 = pts0 + j;
           out_entry = xcur >= kSwPiece ? xcur - kSwPiece : 0xffu;
         }
-        if (lane == 0u) {
-          wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
-          wp_rec_store(grec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | st);
-        }
+        if (lane == 0u) wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
+        if (lane < n_ops) wp_rec_store(grec + (size_t)(p & (kSwRing - 1u)) * kSwMaxOps + lane, ((unsigned long long)(p + 1u) << 32) | st);
         st_last = st;
       }
     } else {
@@ -711,11 +708,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       uint32_t pos = 0u;
       bool bad = false;
       for (uint32_t o = 0; o < n_ops; ++o) {  // uniform
-        if (GOR && o == gor_op) {
-          uint32_t stp = st_first;  // the window in effect: that of the point's round
+        if (GOR && ((gor_ops >> o) & 1ull)) {
+          uint32_t stp = (uint32_t)__builtin_amdgcn_readlane((int)st_first, (int)o);  // the window in effect: that of the point's round
           if (n_rounds > 1u) {      // uniform
             for (uint32_t r = 1; r < n_rounds; ++r)
-              if (j >= (uint32_t)rstart[r]) stp = rstate[r];
+              if (j >= (uint32_t)rstart[r]) stp = rstate[r * kSwMaxOps + o];
           }
           uint32_t len = 1u;
           const uint64_t v = sw_gorilla(wbuf, byte0 + pos, q_first + j == 0u, stp, &len, &bad);

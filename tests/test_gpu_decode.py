@@ -332,6 +332,35 @@ def test_epoch_time_stamps_stay_on_the_parallel_decoder(oracle):
         assert stats[2] == 0, (t0, stats)
 
 
+def test_gorilla_coded_streams_stay_on_the_parallel_decoder(oracle):
+    """Streams with Gorilla-coded FLOAT64 fields (FieldDecoderFloat_Gorilla, include/cloudini_lib/field_decoder.hpp:158-302;
+    the layout of the reference's samples/dds_message.bin) are decoded by the stream kernel's window chain, not one lane per
+    chunk: one and two Gorilla fields, window changes, repeated stamps, random bit patterns, raw first values -- and the
+    bytes are the oracle's."""
+    F = cases.F
+    for info, data in (cases.ouster_like(), cases.gorilla_pair()):
+        stats, _modes, n_chunks = _stats_after_decode(oracle, info, data)
+        assert stats[0] == n_chunks and stats[2] == 0, stats
+    # smooth stamps (one window for long stretches) over several chunks, and windows that change every few points
+    n = 100_000
+    rs = np.random.RandomState(5)
+    fields = [("x", 0, F.FLOAT32, 0.001), ("y", 4, F.FLOAT32, 0.001), ("z", 8, F.FLOAT32, 0.001), ("intensity", 12, F.FLOAT32, 0.001),
+              ("ring", 16, F.UINT16, None), ("timestamp", 18, F.FLOAT64, None)]
+    info = cases.make_info(fields, 26, n)
+    p = rs.randn(n, 3).astype(np.float32) * 20
+    variants = (("smooth", 1.7e9 + np.arange(n) * 1e-5), ("runs", np.repeat(rs.uniform(0, 1, n // 50), 50)),
+                ("wild", np.cumsum(rs.choice([1e-9, 1e-3, 7.0, 1e6], n))))
+    for kind, stamps in variants:
+        data = cases.pack(info, {"x": p[:, 0], "y": p[:, 1], "z": p[:, 2], "intensity": rs.randint(0, 255, n).astype(np.float32),
+                                 "ring": (np.arange(n) % 64).astype(np.uint16), "timestamp": stamps}, n)
+        stats, _modes, n_chunks = _stats_after_decode(oracle, info, data)
+        assert stats[0] + stats[2] == n_chunks
+        # (a chunk in which the window changes more than 40 times inside one KiB of stream goes to the serial decoder:
+        # the "wild" stamps may do that -- their bytes are still the oracle's)
+        if kind != "wild":
+            assert stats[0] == n_chunks, (kind, stats)
+
+
 def test_decode_fill_zero_for_fresh_buffers(oracle):
     """cldn_hip_codec_set_decode_fill(ZERO): the caller's buffer content is not needed, the bytes of a point that no field
     covers read 0 afterwards (what the reference leaves in a freshly resized vector); KEEP (default) preserves them."""
