@@ -18,7 +18,7 @@ Multi-GPU, one process per GPU over RCCL:
 running under a launcher; under a launcher WORLD_SIZE must equal --gpus. A box with fewer than N GPUs fails loudly.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the field meanings):
-  value            whole-job Mpoints/s over all ranks (first timed block of --steps steps)
+  value            whole-job Mpoints/s over all ranks (median of the --repeats timed blocks of --steps steps each)
   repeats          median/min/max ms_per_step over --repeats blocks of --steps steps
   roofline         dominant kernel: algorithmic bytes per launch / its average duration measured with HIP events on
                    the codec's stream inside the timed region
@@ -599,7 +599,8 @@ def main():
         if rep == 0 and points_local:
             kms = [codec.kernel_ms(s) for s in range(args.steps)]
     codec.status()
-    elapsed = block_times[0]
+    # value / ms_per_step: the MEDIAN block of --steps steps (round 4; the first block is reported next to it)
+    elapsed = float(np.median(block_times))
 
     if kms:
         regular_ms = float(np.mean([k["regular"] for k in kms]))
@@ -806,6 +807,7 @@ def main():
             "repeats": {"blocks": int(blocks_ms.size), "steps_per_block": args.steps,
                         "ms_per_step_median": float(np.median(blocks_ms)), "ms_per_step_min": float(blocks_ms.min()),
                         "ms_per_step_max": float(blocks_ms.max()),
+                        "ms_per_step_first_block": float(blocks_ms[0]),
                         "value_median": points_job / (float(np.median(blocks_ms)) * 1e-3) / 1e6},
             "input_MBps": points_job * step * args.steps / elapsed / 1e6,
             "job_stage1_bytes": job_bytes,

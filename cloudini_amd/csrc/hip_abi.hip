@@ -175,6 +175,8 @@ struct cldn_hip_codec {
   DevBuf d_dec_rec;           // k_sections_cols_fast slice records, tagged with dec_epoch, cleared only when (re)allocated
   uint32_t dec_epoch = 0;
   uint32_t finish_epoch = 0;  // tag of this call's records
+  bool force_ticket = false;      // k_finish waited in vain once (ST_FINISH_TIMEOUT): from then on its workgroups take tickets
+  uint32_t finish_retries = 0;    // calls redone through the ticket path
   DevBuf d_pieces;  // piece table of the piece kernel (stage1_fused.h)
   uint32_t n_pieces = 0;
   uint32_t last_piece_pts = 0;
@@ -598,7 +600,10 @@ int cldn_hip_codec_status(cldn_hip_codec_t* c) {
   uint32_t st = 0;
   HIP_TRY(hipMemcpyAsync(&st, c->d_status.p, sizeof(st), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (st & ST_FINISH_TIMEOUT) return fail(CLDN_HIP_ERR_DEVICE, "k_finish: a workgroup waited too long for the sizes of the chunks before it (status 0x%x)", st);
+  if (st & ST_FINISH_TIMEOUT) {
+    c->force_ticket = true;  // (device-resident outputs cannot be redone here: the caller repeats the call, which then takes tickets)
+    return fail(CLDN_HIP_ERR_DEVICE, "k_finish: a workgroup waited too long for the sizes of the chunks before it (status 0x%x); the codec uses the ticket order from now on, repeat the call", st);
+  }
   if (st & ST_OUT_OVERFLOW) return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for the encoded stream");
   if (st & ST_CORRUPT) return fail(CLDN_HIP_ERR_CORRUPT, "malformed stage-1 stream");
   return CLDN_HIP_OK;
@@ -709,7 +714,9 @@ static int upload_batch_shape(cldn_hip_codec* c, const uint64_t* cloud_points, u
 
 // cloud_ptrs != NULL: the clouds live in separate HOST buffers (`points` is ignored)
 // table != NULL: chunk-table output (cldn_hip_encode_stage1_chunks): no framing, `out` is not used
-static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int points_loc, const void* const* cloud_ptrs,
+constexpr int kRetryWithTicket = 0x7fff0001;  // encode_stage1_once: k_finish timed out without the ticket, the call is redone with it
+
+static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int points_loc, const void* const* cloud_ptrs,
                               const uint64_t* cloud_points, uint32_t n_clouds, void* out, uint64_t out_capacity, int out_loc,
                               uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes,
                               cldn_hip_chunk_table_t* table = nullptr) {
@@ -912,6 +919,9 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   L.fin_anchor = (unsigned long long*)((uint8_t*)c->d_status.p + z_anchor);
   L.fin_epoch = c->finish_epoch;
   L.fin_ticket = (uint32_t*)c->d_status.p + 40;
+  static const bool test_timeout = getenv("CLDN_HIP_TEST_FINISH_TIMEOUT") != nullptr;  // test hook: the first attempt reports a timeout
+  L.use_ticket = c->force_ticket ? 1u : 0u;
+  L.test_timeout = test_timeout ? 1u : 0u;
   L.chunks_only = table != nullptr;
   L.contiguous_flag = (uint32_t*)c->d_status.p + 42;
   if (pieces) {
@@ -975,6 +985,8 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
     F.anchor = (unsigned long long*)((uint8_t*)c->d_status.p + z_anchor2);
     F.epoch = c->finish_epoch;
     F.ticket = (uint32_t*)c->d_status.p + 41;
+    F.use_ticket = c->force_ticket ? 1u : 0u;
+    F.test_timeout = 0u;
     F.chunk_payload = (uint32_t*)c->d_payload2.p;
     F.chunk_dst = (uint64_t*)c->d_dst2.p;
     F.stream_offsets = (uint64_t*)c->d_offsets.p;
@@ -1064,7 +1076,18 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
                          c->stream));
   HIP_TRY(hipMemcpyAsync(h_status, c->d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (*h_status & ST_FINISH_TIMEOUT) return fail(CLDN_HIP_ERR_DEVICE, "k_finish: a workgroup waited too long for the sizes of the chunks before it (status 0x%x)", *h_status);
+  if (*h_status & ST_FINISH_TIMEOUT) {
+    // k_finish takes its workgroups in index order and waits for the records of those in front; a device that hands them
+    // out in another order (or pre-empts them) makes the wait run into its bound. The ticket counter does not depend on
+    // the order: the call is redone with it once, and the codec keeps it from then on.
+    if (!c->force_ticket) {
+      c->force_ticket = true;
+      ++c->finish_retries;
+      HIP_TRY(hipMemsetAsync(c->d_status.p, 0, sizeof(uint32_t), c->stream));
+      return kRetryWithTicket;
+    }
+    return fail(CLDN_HIP_ERR_DEVICE, "k_finish: a workgroup waited too long for the sizes of the chunks before it (status 0x%x)", *h_status);
+  }
   if (*h_status & ST_OUT_OVERFLOW)
     return fail(CLDN_HIP_ERR_CAPACITY, "Output buffer too small for uncompressed chunk");  // chunk_writer.cpp:34-36
   const uint64_t total = h_off[n_clouds];
@@ -1079,7 +1102,21 @@ static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int point
   return CLDN_HIP_OK;
 }
 
+static int encode_stage1_impl(cldn_hip_codec_t* c, const void* points, int points_loc, const void* const* cloud_ptrs,
+                              const uint64_t* cloud_points, uint32_t n_clouds, void* out, uint64_t out_capacity, int out_loc,
+                              uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes,
+                              cldn_hip_chunk_table_t* table = nullptr) {
+  int rc = encode_stage1_once(c, points, points_loc, cloud_ptrs, cloud_points, n_clouds, out, out_capacity, out_loc, stream_offsets,
+                              chunk_sizes, modes, table);
+  if (rc == kRetryWithTicket)
+    rc = encode_stage1_once(c, points, points_loc, cloud_ptrs, cloud_points, n_clouds, out, out_capacity, out_loc, stream_offsets,
+                            chunk_sizes, modes, table);
+  return rc;
+}
+
 extern "C" {
+
+uint32_t cldn_hip_codec_finish_retries(const cldn_hip_codec_t* c) { return c ? c->finish_retries : 0u; }
 
 int cldn_hip_encode_stage1(cldn_hip_codec_t* c, const void* points, int points_loc, const uint64_t* cloud_points,
                            uint32_t n_clouds, void* out, uint64_t out_capacity, int out_loc,

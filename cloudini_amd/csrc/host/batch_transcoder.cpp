@@ -110,6 +110,8 @@ PinnedCache& pinnedCache() {
 }
 }  // namespace
 
+void releasePinnedCache() noexcept;
+
 void* pinnedAlloc(size_t bytes) {
   if (bytes == 0) bytes = 1;
   PinnedCache& c = pinnedCache();
@@ -124,6 +126,10 @@ void* pinnedAlloc(size_t bytes) {
     }
   }
   void* p = cldn_hip_host_alloc(bytes);
+  if (!p) {  // page-locked memory is short while idle blocks of other sizes sit in the cache: give them back, try once more
+    releasePinnedCache();
+    p = cldn_hip_host_alloc(bytes);
+  }
   if (p) {
     std::lock_guard<std::mutex> lock(c.mutex);
     c.capacity[p] = bytes;

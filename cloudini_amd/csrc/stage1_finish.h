@@ -50,6 +50,7 @@ struct FinishArgs {
   uint32_t epoch;                     // != 0, changes with every call
   uint32_t* ticket;                   // zero at launch
   uint32_t use_ticket;
+  uint32_t test_timeout;              // test hook (CLDN_HIP_TEST_FINISH_TIMEOUT): without the ticket the launch reports ST_FINISH_TIMEOUT at once
   uint32_t order;                     // fused Palette: 0 even chunks section first, odd chunks copy first; 1 all section first; 2 all copy first
   uint32_t* chunk_payload;            // out [n_chunks]
   uint64_t* chunk_dst;                // out [n_chunks]
@@ -207,6 +208,10 @@ __global__ __launch_bounds__(T, (T == 1024 ? 4 : 8)) __attribute__((amdgpu_num_s
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+  if (A.test_timeout != 0u && A.use_ticket == 0u) {  // (uniform)
+    if (tid == 0u && blockIdx.x == 0u) atomicOr(A.status, (uint32_t)ST_FINISH_TIMEOUT);
+    return;
+  }
   if (tid == 0u) {
     // Order: the workgroup index. The hardware hands out a grid's workgroups in index order (per XCD), so every
     // workgroup a workgroup waits for -- all of lower index -- has started or finished. A.use_ticket replaces that

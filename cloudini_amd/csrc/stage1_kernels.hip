@@ -2198,7 +2198,8 @@ int stage1_launch_encode(const EncodeLaunch& L) {
       F.ticket = L.fin_ticket;
       static const uint32_t use_ticket = getenv("CLDN_HIP_FINISH_TICKET") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_TICKET")) : 0u;
       static const uint32_t order = getenv("CLDN_HIP_FINISH_ORDER") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_ORDER")) : 0u;  // A/B switch
-      F.use_ticket = use_ticket;
+      F.use_ticket = (use_ticket || L.use_ticket) ? 1u : 0u;
+      F.test_timeout = L.test_timeout;
       F.order = order;
       F.chunk_payload = L.chunk_payload;
       F.chunk_dst = L.chunk_dst;
@@ -2217,7 +2218,8 @@ int stage1_launch_encode(const EncodeLaunch& L) {
         // small batches: 1024-thread workgroups (a chunk's Palette section is latency-bound: twice the threads, 0.6x the time)
         static const uint32_t big_at = getenv("CLDN_HIP_FINISH_1024_BELOW") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_1024_BELOW")) : 200u;  // A/B switch
         const bool big = L.n_chunks < big_at;
-        const uint32_t splits = big ? 4u : (L.n_chunks >= 512u ? 1u : 2u);
+        static const uint32_t splits_env = getenv("CLDN_HIP_FINISH_SPLITS") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_SPLITS")) : 0u;  // A/B switch
+        const uint32_t splits = splits_env ? splits_env : (big ? 4u : (L.n_chunks >= 512u ? 1u : 2u));
         F.splits = splits;
         const bool u16 = L.plan->adaptive[fused_field].bpv == 2u;
         if (big && u16)
@@ -2275,7 +2277,9 @@ int stage1_launch_frame(const FrameLaunch& L) {
   F.anchor = L.anchor;
   F.epoch = L.epoch;
   F.ticket = L.ticket;
-  F.use_ticket = 0u;
+  F.use_ticket = L.use_ticket;
+  F.test_timeout = L.test_timeout;
+  F.order = 0u;
   F.chunk_payload = L.chunk_payload;
   F.chunk_dst = L.chunk_dst;
   F.stream_offsets = L.stream_offsets;

@@ -48,6 +48,8 @@ struct EncodeLaunch {
   unsigned long long* fin_anchor;  // device [n_chunks / 1024 + 1], zero at launch
   uint32_t fin_epoch;              // != 0, changes with every call
   uint32_t* fin_ticket;            // device, zero at launch
+  uint32_t use_ticket;             // k_finish takes its workgroups' order from the ticket counter (retry after ST_FINISH_TIMEOUT)
+  uint32_t test_timeout;           // test hook: see FinishArgs
   uint8_t* out;               // device, framed streams
   uint64_t out_capacity;
   uint32_t* status;           // device status word
@@ -117,6 +119,8 @@ struct FrameLaunch {
   unsigned long long* anchor;  // [n_chunks / 1024 + 1], zero at launch
   uint32_t epoch;
   uint32_t* ticket;            // zero at launch
+  uint32_t use_ticket;
+  uint32_t test_timeout;
   uint32_t* chunk_payload;     // out
   uint64_t* chunk_dst;         // out
   uint64_t* stream_offsets;    // out

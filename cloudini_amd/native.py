@@ -108,6 +108,8 @@ def lib() -> C.CDLL:
     L.cldn_hip_codec_set_decode_fill.restype = C.c_int
     L.cldn_hip_codec_decode_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.cldn_hip_codec_decode_stats.restype = C.c_int
+    L.cldn_hip_codec_finish_retries.argtypes = [vp]
+    L.cldn_hip_codec_finish_retries.restype = C.c_uint32
     L.cldn_hip_codec_force_modes.argtypes = [vp, C.POINTER(C.c_uint8), C.c_uint32]
     L.cldn_hip_codec_force_modes.restype = C.c_int
     L.cldn_hip_encode_stage1_chunks.restype = C.c_int
@@ -240,6 +242,10 @@ class Codec:
         _check(lib().cldn_hip_codec_decode_stats(self._h, v))
         return tuple(int(x) for x in v)
 
+    def finish_retries(self) -> int:
+        """Calls redone through k_finish's ticket order after ST_FINISH_TIMEOUT (cldn_hip_codec_finish_retries)."""
+        return int(lib().cldn_hip_codec_finish_retries(self._h))
+
     def force_modes(self, modes=None):
         """Adaptive-int modes committed elsewhere (cldn_hip_codec_force_modes); None / empty returns to probing."""
         if modes is None or len(modes) == 0:
@@ -328,6 +334,10 @@ class Codec:
         if out is None:
             out = np.zeros(max(1, total), dtype=np.uint8)
         cs = None if chunk_sizes is None else np.ascontiguousarray(chunk_sizes, dtype=np.uint32)
+        if cs is not None:
+            n_chunks = int(sum((int(n) + 32767) // 32768 for n in npts))
+            if cs.size < n_chunks:  # the C side reads n_chunks sizes
+                raise ValueError(f"chunk_sizes has {cs.size} entries, the batch has {n_chunks} chunks")
         _check(lib().cldn_hip_decode_stage1_sized(
             self._h, data.ctypes.data_as(C.c_void_p), HOST, offs.ctypes.data_as(C.POINTER(C.c_uint64)),
             npts.ctypes.data_as(C.POINTER(C.c_uint64)), len(arrs), None if cs is None else cs.ctypes.data_as(C.c_void_p), HOST,

@@ -257,6 +257,16 @@ int cldn_hip_codec_decode_stats(cldn_hip_codec_t* codec, uint32_t stats[4]);
 /* Synchronise and return the status word of the last asynchronous call (0 or a negative error). */
 int cldn_hip_codec_status(cldn_hip_codec_t* codec);
 
+/* Forward progress of the framing kernel (k_finish). Its workgroups wait for the size records of the workgroups of LOWER
+ * index, which the hardware has started earlier when it hands a grid out in index order -- an observation about gfx950, not
+ * a guarantee of the programming model (another device, a shared or pre-empted GPU). The wait is bounded (~1 s); when it
+ * runs out the launch reports ST_FINISH_TIMEOUT. A call with HOST outputs is then redone ONCE with the order taken from a
+ * ticket counter (an atomic per workgroup, 11 us per 1000 chunks: independent of the dispatch order), and the codec keeps
+ * the ticket order from then on; a call with DEVICE outputs cannot be redone by the library: cldn_hip_codec_status returns
+ * CLDN_HIP_ERR_DEVICE, the codec switches to tickets, the caller repeats the call. CLDN_HIP_FINISH_TICKET=1 selects the
+ * ticket order from the start. Returns the number of calls this codec has redone. */
+uint32_t cldn_hip_codec_finish_retries(const cldn_hip_codec_t* codec);
+
 /* Optional instrumentation for bench.py's roofline line: with n_slots > 0 every encode call records HIP
  * events on the codec's stream around its kernels into slot (call_index % n_slots); n_slots = 0 turns it off.
  * cldn_hip_codec_kernel_ms waits for that slot's last event and returns milliseconds:

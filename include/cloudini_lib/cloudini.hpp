@@ -5,8 +5,8 @@
 //
 // Differences a caller can observe:
 //   * a GPU is required; every error (including "no device") is a std::runtime_error like the reference's own;
-//   * schemas beyond the limits listed in cloudini_hip.h (point_step > 1024, > 64 per-point tokens, > 32 adaptive
-//     integer fields, > 4 Gorilla-coded FLOAT64 fields) are rejected with a std::runtime_error: there is no CPU path;
+//   * schemas beyond the limits listed in cloudini_hip.h (point_step > 1024, > 64 per-point tokens, > 64 adaptive
+//     integer fields) are rejected with a std::runtime_error: there is no CPU path;
 //   * the classes hold an opaque implementation pointer instead of the reference's private members.
 #pragma once
 
