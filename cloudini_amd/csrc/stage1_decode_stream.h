@@ -123,6 +123,24 @@ __device__ __forceinline__ uint64_t sw_token(const uint32_t* wbuf, uint32_t bp, 
   return (u1 >> 1) ^ (0ull - (u1 & 1ull));
 }
 
+// The same for tokens of at most 4 bytes (the common case: the caller asks the whole wave): 32-bit arithmetic
+__device__ __forceinline__ uint64_t sw_token32(const uint32_t* wbuf, uint32_t bp, uint32_t len, bool raw, bool* marker, bool* bad) {
+  const uint32_t di = bp >> 2, sh = (bp & 3u) * 8u;
+  uint32_t w = __builtin_amdgcn_alignbit(wbuf[di + 1u], wbuf[di], sh);
+  if (len < 4u) w &= (1u << (8u * len)) - 1u;
+  *marker = false;
+  if (raw) return w;
+  const uint32_t lo = w & 0x7f7f7f7fu;
+  const uint32_t x1 = lo - ((lo & 0x7f007f00u) >> 1);   // 7-bit groups -> 14-bit groups
+  const uint32_t x = x1 - __umul24(x1 >> 16, 49152u);   // -> one value (< 2^28)
+  if (x == 0u) {
+    if (len == 1u) *marker = true;
+    else *bad = true;
+  }
+  const uint32_t u1 = x - 1u;
+  return (uint64_t)(int64_t)(int32_t)((u1 >> 1) ^ (0u - (u1 & 1u)));  // (the marker's value is never used)
+}
+
 // One token of FieldDecoderFloat_Gorilla<double> (field_decoder.hpp:262-305; bits LSB-first, every token a whole number of
 // bytes) at byte `bp` of the LDS copy -> the XOR difference against the value before (the chunk's first value: its raw
 // bits), *len = the token's bytes. st = the window in effect (valid << 16 | leading << 8 | trailing). *bad: what the serial
@@ -334,6 +352,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   const unsigned long long xor_ops = __ballot(kind_l == OP_XOR32 || kind_l == OP_XOR64 || kind_l == OP_GORILLA64);  // its values combine with ^
   const unsigned long long copy_ops = __ballot(kind_l == OP_COPY);                      // no state at all
   const unsigned long long int_ops = __ballot(kind_l == OP_INT);                        // a marker is an error there
+  const unsigned long long narrow_ops = __ballot(kind_l == OP_QF32 || (kind_l == OP_INT && size_l <= 4u));  // 32 bits of the running value are all that is used
   uint64_t run_l = 0ull;  // lane o: op o's running value (behind the last point handled so far)
   uint32_t st_last = 0u;  // MODE 2, lane o: op o's Gorilla window behind the piece this wave handled last
 
@@ -739,7 +758,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
           }
         }
         bool marker = false;
-        const uint64_t v = sw_token(wbuf, byte0 + pos, len, raw, &marker, &bad);
+        const uint64_t v = __ballot(len > 4u) == 0ull ? sw_token32(wbuf, byte0 + pos, len, raw, &marker, &bad)
+                                                      : sw_token(wbuf, byte0 + pos, len, raw, &marker, &bad);
         if (marker && ((int_ops >> o) & 1ull)) bad = true;  // "decodeVarint: unexpected NaN marker"
         fn(o, have ? v : 0ull, have && marker);
         pos = min(pos + len, kSwMaxPointBytes - 1u);
@@ -759,7 +779,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         if ((copy_ops >> o) & 1ull) return;
         uint64_t tot;
         bool reset = false;
-        if ((xor_ops >> o) & 1ull) {
+        if ((narrow_ops >> o) & 1ull) {  // int32 wrap-around arithmetic (FloatN lanes), fields of at most 4 bytes
+          const unsigned long long mks = __ballot(mk);
+          uint32_t v32 = (uint32_t)v;
+          if (mks != 0ull) {  // the values behind the row's last marker
+            const uint32_t last = 63u - (uint32_t)__builtin_clzll(mks);
+            v32 = lane > last ? v32 : 0u;
+            reset = true;
+          }
+          tot = wave_sum(v32);
+        } else if ((xor_ops >> o) & 1ull) {
           tot = sw_lane64(sw_scan64<true>(v), 63u);
         } else {
           const unsigned long long mks = __ballot(mk);
@@ -836,7 +865,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
           return;
         }
         const unsigned long long mks = __ballot(mk);
-        if (mks == 0ull) {
+        if ((narrow_ops >> o) & 1ull) {
+          const uint32_t b32 = (uint32_t)before;
+          if (mks == 0ull) {
+            const uint32_t inc = wave_inclusive_scan((uint32_t)v);
+            cur = b32 + inc;
+            const uint32_t after = b32 + (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if (lane == o) run_l = after;
+          } else {
+            int32_t inc[1] = {mk ? 0 : (int32_t)(uint32_t)v};
+            uint32_t f = mk ? 1u : 0u;
+            wp_seg_scan<1>(inc, f);
+            cur = f ? (uint32_t)inc[0] : b32 + (uint32_t)inc[0];
+            const uint32_t f63 = (uint32_t)__builtin_amdgcn_readlane((int)f, 63);
+            const uint32_t i63 = (uint32_t)__builtin_amdgcn_readlane(inc[0], 63);
+            if (lane == o) run_l = f63 ? i63 : b32 + i63;
+          }
+        } else if (mks == 0ull) {
           const uint64_t inc = sw_scan64<false>(v);
           cur = before + inc;
           const uint64_t after = before + sw_lane64(inc, 63u);
