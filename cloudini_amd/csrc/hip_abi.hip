@@ -160,7 +160,7 @@ struct cldn_hip_codec {
   DevBuf d_cols[kMaxAdaptive];
   DevBuf d_ranks[kMaxAdaptive];
   DevBuf d_dec_meta, d_pre_ptrs;
-  DevBuf d_dec_cols[2];       // decode: dense columns of the adaptive fields that k_decode_points takes its integer fields from
+  DevBuf d_dec_cols[8];       // decode: dense columns of the adaptive fields that k_decode_points takes its integer fields from
   // stage 2 on the device (cldn_hip_codec_set_stage2): the stage-1 streams stay in d_s1, LZ4 blocks go to d_lz_slots
   // chunk table of the last cldn_hip_encode_stage1_chunks call (cldn_hip_frame_chunks frames it)
   bool ct_valid = false;
@@ -172,6 +172,7 @@ struct cldn_hip_codec {
   DevBuf d_finrec;            // k_finish look-back records (rec, rec2), cleared only when (re)allocated
   int decode_fill = CLDN_HIP_FILL_KEEP;  // cldn_hip_codec_set_decode_fill
   DevBuf d_dec_bits;          // k_mark_token_ends: token-end bitmap of the streams of a decode call
+  DevBuf d_dec_secs;          // k_section_offsets: per (field, chunk) section records + per-chunk counters
   DevBuf d_dec_rec;           // k_sections_cols_fast slice records, tagged with dec_epoch, cleared only when (re)allocated
   uint32_t dec_epoch = 0;
   uint32_t finish_epoch = 0;  // tag of this call's records
@@ -533,9 +534,9 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   DeviceGuard guard;
   (void)guard.enter(c->device);
   (void)hipStreamSynchronize(c->stream);
-  DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec, &c->d_dec_rec, &c->d_dec_bits, &c->d_s1, &c->d_s1_offsets,
+  DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec, &c->d_dec_rec, &c->d_dec_bits, &c->d_dec_secs, &c->d_s1, &c->d_s1_offsets,
                     &c->d_lz_matches, &c->d_lz_counts, &c->d_lz_slots, &c->d_lz_segs, &c->d_payload2, &c->d_dst2,
-                    &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_pre_ptrs, &c->d_dec_cols[0], &c->d_dec_cols[1],
+                    &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_pre_ptrs, &c->d_dec_cols[0], &c->d_dec_cols[1], &c->d_dec_cols[2], &c->d_dec_cols[3], &c->d_dec_cols[4], &c->d_dec_cols[5], &c->d_dec_cols[6], &c->d_dec_cols[7],
                     &c->d_viz_keys, &c->d_viz_first,
                     &c->d_viz_slot, &c->d_viz_blocks, &c->d_viz_total, &c->d_pieces};
   for (DevBuf* b : bufs) b->release();
@@ -1393,8 +1394,8 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
   const size_t chunk_table_bytes = ((size_t)std::max(1u, n_chunks) * kDecChunkBytes + 63) & ~size_t(63);
   if ((rc = c->d_dec_meta.ensure(((table_bytes + 63) & ~size_t(63)) + chunk_table_bytes + (size_t)std::max(1u, n_chunks) * 18u + 64u)) != CLDN_HIP_OK)
     return rc;
-  const bool dec_cols = c->plan.uses_v5 && plan.n_adaptive >= 1u && plan.n_adaptive <= 2u;
-  for (uint32_t a = 0; a < 2u; ++a)
+  const bool dec_cols = c->plan.uses_v5 && plan.n_adaptive >= 1u && plan.n_adaptive <= 8u;
+  for (uint32_t a = 0; a < 8u; ++a)
     if (dec_cols && a < plan.n_adaptive && plan.adaptive[a].bpv <= 4u &&
         (rc = c->d_dec_cols[a].ensure((size_t)n_points * plan.adaptive[a].bpv + 64)) != CLDN_HIP_OK)
       return rc;
@@ -1459,8 +1460,18 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
       L.chunk_sizes = d_sizes;
     }
   }
-  for (uint32_t a = 0; a < 2u; ++a)
+  for (uint32_t a = 0; a < 8u; ++a)
     L.cols[a] = (dec_cols && a < plan.n_adaptive && plan.adaptive[a].bpv <= 4u) ? (uint8_t*)c->d_dec_cols[a].p : nullptr;
+  L.dsec = nullptr;
+  L.secs_ok = nullptr;
+  L.done_cnt = nullptr;
+  if (c->plan.uses_v5 && plan.n_adaptive >= 1u && plan.n_adaptive <= 8u && n_chunks) {  // sections side by side (stage1_decode_sections_w.h)
+    const size_t rows = (size_t)plan.n_adaptive * n_chunks * kDecChunkBytes;
+    if ((rc = c->d_dec_secs.ensure(rows + (size_t)n_chunks * 8u + 256u)) != CLDN_HIP_OK) return rc;
+    L.dsec = c->d_dec_secs.p;
+    L.done_cnt = (uint32_t*)((uint8_t*)c->d_dec_secs.p + ((rows + 63u) & ~size_t(63)));
+    L.secs_ok = (uint8_t*)(L.done_cnt + n_chunks);
+  }
   if (plan.varint_and_raw && n_chunks) {  // one bit per stream byte + a word per chunk (k_mark_token_ends)
     if ((rc = c->d_dec_bits.ensure((size_t)((stream_bytes - base_off) / 8u) + (size_t)n_chunks * 4u + 256u)) != CLDN_HIP_OK) return rc;
     L.token_ends = (uint32_t*)c->d_dec_bits.p;

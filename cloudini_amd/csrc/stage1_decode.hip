@@ -15,6 +15,7 @@
 #include "stage1_decode_fast.h"
 #include "stage1_decode_wave.h"
 #include "stage1_decode_stream.h"
+#include "stage1_decode_sections_w.h"
 
 #include "cloudini_hip.h"
 #include "stage1_launch.h"
@@ -23,6 +24,28 @@ namespace cldn {
 
 namespace {
 int hip_fail(hipError_t e, const char* what) { return launch_fail(e, what); }
+
+// the plan the stream kernel decodes DeltaVarint SECTIONS with: op a = the integer field a as a stream of its own
+// (to_cols: into the field's dense column, offset 0; else into the points)
+DevPlan sections_plan(const DevPlan& P, bool to_cols) {
+  DevPlan S = P;
+  S.n_ops = 1u;
+  S.n_gorilla = 0u;
+  S.all_varint = 1u;
+  S.varint_and_raw = 0u;
+  S.max_regular_bytes = 10u;
+  S.min_regular_bytes = 1u;
+  for (uint32_t a = 0; a < P.n_adaptive && a < 8u; ++a) {
+    DevOp op = {};
+    op.kind = OP_INT;
+    op.type = P.adaptive[a].type;
+    op.size = P.adaptive[a].bpv;
+    op.max_bytes = 10;
+    op.offset = to_cols ? 0u : P.adaptive[a].offset;
+    S.ops[a] = op;
+  }
+  return S;
+}
 }  // namespace
 
 int stage1_configure_decode() {
@@ -97,12 +120,46 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     // it hands irregular chunks back (reg_end = kDecRedo) and k_decode_varint redoes only those
     static const bool no_points = getenv("CLDN_HIP_NO_POINT_DECODE") != nullptr;  // A/B switch
     const bool points_kernel = fast && !no_points && all_qf32 && (P.n_ops == 3u || P.n_ops == 4u) && P.n_gorilla == 0u;
+    bool many_used = false;  // the point kernel merged the columns of 3..8 integer channels (chunks it left: the old section kernels)
     if (points_kernel) {
       // NF: Palette sections the launch can fold into the point pass (sizes its LDS)
-      const uint32_t nf = (L.uses_v5 && P.n_adaptive <= kFastPalFields) ? P.n_adaptive : 0u;
+      // round 4: the barrier-free kernel (stage1_decode_wave.h) is the default; CLDN_HIP_POINT_KERNEL=tiles brings the
+      // tile kernel back (A/B in the same binary), =w8 runs it with 8 waves per workgroup instead of 16
+      static const char* pk_env = getenv("CLDN_HIP_POINT_KERNEL");
+      static const int pk = pk_env == nullptr ? 16 : (strcmp(pk_env, "tiles") == 0 ? 0 : (strcmp(pk_env, "w8") == 0 ? 8 : (strcmp(pk_env, "w8o6") == 0 ? 86 : (strcmp(pk_env, "w12o6") == 0 ? 126 : 16))));
+      uint32_t nf = (L.uses_v5 && P.n_adaptive <= kFastPalFields) ? P.n_adaptive : 0u;
+      // round 4: 3..8 integer channels (all of 2 or 4 bytes): their sections go to dense columns side by side in front of the
+      // point kernel (stage1_decode_sections_w.h), which merges them -- every point is written once
+      static const bool no_many = getenv("CLDN_HIP_NO_SECTIONS_W") != nullptr;  // A/B switch
+      bool many = !no_many && pk != 0 && L.uses_v5 && P.n_adaptive > kFastPalFields && P.n_adaptive <= kSoMaxFields && L.dsec != nullptr &&
+                  L.sec_cols != nullptr && L.reg_end_pre != nullptr;
+      for (uint32_t a = 0; a < P.n_adaptive && many; ++a) many = P.adaptive[a].bpv <= 4u && L.cols[a] != nullptr;
+      DecColumns dcols = {};
+      for (uint32_t a = 0; a < 8u; ++a) dcols.p[a] = L.cols[a];
+      if (many) {
+        nf = 8u;
+        many_used = true;
+        hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
+        DecChunk* dsec = reinterpret_cast<DecChunk*>(L.dsec);
+        hipLaunchKernelGGL(k_section_offsets, dim3(L.n_chunks), dim3(kSoThreads), 0, L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.n_chunks, (const uint32_t*)L.reg_end_pre, dsec, L.secs_ok, L.done_cnt);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_offsets");
+        hipLaunchKernelGGL(k_sections_w, dim3(L.n_chunks, P.n_adaptive), dim3(kSwsThreads), 0, L.stream, P, L.streams,
+                           (const DecChunk*)dsec, L.n_chunks, L.out, L.done_cnt, 1u, dcols);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_w");
+        const DevPlan S = sections_plan(P, true);
+        hipLaunchKernelGGL((k_decode_stream_w<16, 0>), dim3(L.n_chunks, P.n_adaptive), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, S,
+                           L.streams, (const DecChunk*)dsec, (uint8_t*)nullptr, L.done_cnt, L.status, (const uint32_t*)nullptr, L.n_chunks, dcols);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (sections)");
+        hipLaunchKernelGGL(k_sections_done, dim3((L.n_chunks + 255u) / 256u), dim3(256), 0, L.stream, L.n_chunks, P.n_adaptive,
+                           (const uint8_t*)L.secs_ok, (const uint32_t*)L.done_cnt, L.sec_cols, L.status, 0u);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_done");
+      }
       // sections that are no small palettes go to dense columns first (every point is then written once)
       static const bool no_cols = getenv("CLDN_HIP_NO_DECODE_COLS") != nullptr;  // A/B switch
-      bool cols = !no_cols && nf != 0u && L.cols[0] != nullptr && L.sec_cols != nullptr;
+      bool cols = !no_cols && !many && nf != 0u && L.cols[0] != nullptr && L.sec_cols != nullptr;
       for (uint32_t a = 0; a < P.n_adaptive && cols; ++a) cols = P.adaptive[a].bpv <= 4u && L.cols[a] != nullptr;
       if (cols) {
         {
@@ -135,12 +192,8 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       }
       const uint8_t* c0 = cols ? L.cols[0] : nullptr;
       const uint8_t* c1 = cols ? L.cols[1] : nullptr;
-      const uint8_t* sc = cols ? L.sec_cols : nullptr;
+      const uint8_t* sc = (cols || many) ? L.sec_cols : nullptr;
       const uint32_t fill_zero = L.fill_zero ? 1u : 0u;
-      // round 4: the barrier-free kernel (stage1_decode_wave.h) is the default; CLDN_HIP_POINT_KERNEL=tiles brings the
-      // tile kernel back (A/B in the same binary), =w8 runs it with 8 waves per workgroup instead of 16
-      static const char* pk_env = getenv("CLDN_HIP_POINT_KERNEL");
-      static const int pk = pk_env == nullptr ? 16 : (strcmp(pk_env, "tiles") == 0 ? 0 : (strcmp(pk_env, "w8") == 0 ? 8 : (strcmp(pk_env, "w8o6") == 0 ? 86 : (strcmp(pk_env, "w12o6") == 0 ? 126 : 16))));
 #define LAUNCH_POINTS(NOPS_, NF_)                                                                                         \
   hipLaunchKernelGGL((k_decode_points<NOPS_, NF_>), dim3(L.n_chunks), dim3(kFpThreads), (FpLds<NOPS_, NF_>::kTotal), L.stream, \
                      P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5,  \
@@ -148,7 +201,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
 #define LAUNCH_POINTS_W(NOPS_, NF_, NW_, WPE_)                                                                            \
   hipLaunchKernelGGL((k_decode_points_w<NOPS_, NF_, NW_, WPE_>), dim3(L.n_chunks), dim3(NW_ * 64), (WpLds<NOPS_, NF_, NW_>::kTotal), \
                      L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done,   \
-                     L.uses_v5, L.status, c0, c1, L.reg_end_pre, sc, fill_zero)
+                     L.uses_v5, L.status, c0, c1, L.reg_end_pre, sc, fill_zero, dcols)
 #define LAUNCH_POINTS_ANY(NOPS_, NF_)                      \
   {                                                        \
     if (pk == 0) LAUNCH_POINTS(NOPS_, NF_);                \
@@ -160,11 +213,13 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       if (P.n_ops == 3u) {
         if (nf == 0u) LAUNCH_POINTS_ANY(3, 0)
         else if (nf == 1u) LAUNCH_POINTS_ANY(3, 1)
-        else LAUNCH_POINTS_ANY(3, 2)
+        else if (nf == 2u) LAUNCH_POINTS_ANY(3, 2)
+        else LAUNCH_POINTS_W(3, 8, 16, 8);
       } else {
         if (nf == 0u) LAUNCH_POINTS_ANY(4, 0)
         else if (nf == 1u) LAUNCH_POINTS_ANY(4, 1)
-        else LAUNCH_POINTS_ANY(4, 2)
+        else if (nf == 2u) LAUNCH_POINTS_ANY(4, 2)
+        else LAUNCH_POINTS_W(4, 8, 16, 8);
       }
 #undef LAUNCH_POINTS_ANY
 #undef LAUNCH_POINTS_W
@@ -206,14 +261,14 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       }
       if (form) {
         hipLaunchKernelGGL((k_decode_stream_w<12, 1>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, true>::kTotal), L.stream, P,
-                           L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr);
+                           L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{});
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (form)");
       } else if (stream_ok) {
         // round 4: the barrier-free stream kernel reads the token ends from the bitmap (chunks it finds irregular go to the
         // serial decoder, like the chunks k_mark_token_ends gave up on)
         hipLaunchKernelGGL((k_decode_stream_w<16, false>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status,
-                           bitmap ? (const uint32_t*)L.token_ends : (const uint32_t*)nullptr);
+                           bitmap ? (const uint32_t*)L.token_ends : (const uint32_t*)nullptr, 0u, DecColumns{});
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (mixed)");
       } else {
         hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<8, true, 8>::kTotal),
@@ -229,7 +284,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       const bool stream_kernel = !no_stream && !points_kernel && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes;
       if (stream_kernel) {
         hipLaunchKernelGGL((k_decode_stream_w<16, false>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr);
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{});
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w");
       }
       const uint32_t redo_only = (points_kernel || stream_kernel) ? 1u : 0u;
@@ -255,13 +310,37 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       }
       if (ok) {
         hipLaunchKernelGGL((k_decode_stream_w<12, 2>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, true>::kTotal), L.stream, P,
-                           L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr);
+                           L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{});
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (gorilla)");
         fast = true;  // from here on like any stream the parallel kernels have taken
       }
     }
     const bool fast_sections = fast && L.uses_v5 && P.n_adaptive > 0u;
-    if (fast_sections) {
+    // round 4: the sections of a chunk side by side (stage1_decode_sections_w.h): sized without decoding, then one
+    // workgroup per (chunk, field); chunks it does not finish stay with the kernels below. CLDN_HIP_NO_SECTIONS_W=1: A/B switch
+    static const bool no_sw = getenv("CLDN_HIP_NO_SECTIONS_W") != nullptr;
+    bool sections_w = fast_sections && !no_sw && !many_used && L.dsec != nullptr && P.n_adaptive <= kSoMaxFields;
+    for (uint32_t a = 0; a < P.n_adaptive && sections_w; ++a) sections_w = P.adaptive[a].bpv <= 4u;
+    if (sections_w) {
+      DecChunk* dsec = reinterpret_cast<DecChunk*>(L.dsec);
+      hipLaunchKernelGGL(k_section_offsets, dim3(L.n_chunks), dim3(kSoThreads), 0, L.stream, P, L.streams,
+                         reinterpret_cast<const DecChunk*>(L.chunks), L.n_chunks, (const uint32_t*)L.reg_end, dsec, L.secs_ok, L.done_cnt);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_offsets");
+      hipLaunchKernelGGL(k_sections_w, dim3(L.n_chunks, P.n_adaptive), dim3(kSwsThreads), 0, L.stream, P, L.streams,
+                         (const DecChunk*)dsec, L.n_chunks, L.out, L.done_cnt, 0u, DecColumns{});
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_w");
+      // DeltaVarint sections: streams of n tokens of one integer op -> the stream kernel, row a of the grid = field a
+      const DevPlan S = sections_plan(P, false);
+      hipLaunchKernelGGL((k_decode_stream_w<16, 0>), dim3(L.n_chunks, P.n_adaptive), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, S,
+                         L.streams, (const DecChunk*)dsec, L.out, L.done_cnt, L.status, (const uint32_t*)nullptr, L.n_chunks, DecColumns{});
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (sections)");
+      hipLaunchKernelGGL(k_sections_done, dim3((L.n_chunks + 255u) / 256u), dim3(256), 0, L.stream, L.n_chunks, P.n_adaptive,
+                         (const uint8_t*)L.secs_ok, (const uint32_t*)L.done_cnt, L.sec_done, L.status, 1u);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_done");
+      hipLaunchKernelGGL(k_decode_sections, dim3(L.n_chunks), dim3(kDvThreads), (DecSecLds::kTotal), L.stream, P, L.streams,
+                         reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_sections");
+    } else if (fast_sections) {
       hipLaunchKernelGGL(k_decode_sections_small, dim3(L.n_chunks), dim3(kDvThreads), kSmallSecLds, L.stream, P, L.streams,
                          reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status,
                          points_kernel ? 1u : 0u);

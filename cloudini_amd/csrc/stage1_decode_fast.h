@@ -170,6 +170,10 @@ __device__ __forceinline__ uint32_t pal_guess_from_end(const uint8_t* __restrict
   return 0xffffffffu;
 }
 
+struct DecColumns {   // dense columns of up to 8 adaptive fields (value i of the batch at p[a] + i * bpv)
+  const uint8_t* p[8];
+};
+
 struct FpSection {   // a Palette section folded into the point pass
   uint32_t field_off;  // offset of the field inside the point
   uint32_t bpv;        // 2 or 4
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan,
     slices_done[c] = 0xffu << 24;
     found = 0xffffffffu;
   }
-  if (!dc.valid || plan.n_adaptive == 0u || plan.n_adaptive > kFastPalFields) return;
+  if (!dc.valid || plan.n_adaptive == 0u || plan.n_adaptive > 8u) return;  // (more than kFastPalFields: the columns of stage1_decode_sections_w.h)
   for (uint32_t a = 0; a < plan.n_adaptive; ++a)
     if (plan.adaptive[a].bpv > 4u) return;
   const uint8_t* src = streams + dc.src_off;
@@ -740,6 +744,10 @@ __device__ __forceinline__ uint32_t fp_setup(const DevPlan& plan, const uint8_t*
   bool located = false;
   // k_decode_sections_cols has decoded this chunk's sections into columns: every point takes its integer fields from there
   const bool from_cols = NF != 0 && v5_sections && sec_cols != nullptr && sec_cols[c] != 0u && plan.n_adaptive <= (uint32_t)NF;
+  if (NF > 2 && !from_cols) {  // (uniform) instantiations for many fields only merge columns: nothing is located or folded here
+    *from_cols_out = false;
+    return 0xffffffffu;
+  }
   if (from_cols) {
     reg_size = reg_end_pre[c];
     located = true;

@@ -207,7 +207,8 @@ template <int NW, int MODE>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 6 : 8, 8))) void k_decode_stream_w(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                              const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
                                                              uint32_t* __restrict__ reg_end, uint32_t* __restrict__ status,
-                                                             const uint32_t* __restrict__ token_ends) {
+                                                             const uint32_t* __restrict__ token_ends, uint32_t sect_chunks,
+                                                             const DecColumns sect_cols) {
   constexpr bool FORM = MODE != 0;
   constexpr bool GOR = MODE == 2;
   using L = SwLds<NW, FORM>;
@@ -218,28 +219,36 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   unsigned long long* vrec = reinterpret_cast<unsigned long long*>(smem + L::kVrecOff);
   unsigned long long* grec = reinterpret_cast<unsigned long long*>(smem + L::kGrecOff);
   uint32_t* misc = reinterpret_cast<uint32_t*>(smem + L::kMiscOff);  // [0] irregular, [2] end of the regular stream, [3] a wait gave up
+  // sect_chunks != 0 (MODE 0 only): SECTION MODE -- grid (chunks, fields); `chunks` holds the DeltaVarint sections
+  // k_section_offsets sized (row = field), the section of field a is a stream of n tokens of the ONE integer op
+  // plan.ops[a], and reg_end is the per-chunk counter of finished sections (stage1_decode_sections_w.h)
+  const bool sect = MODE == 0 && sect_chunks != 0u;
+  const uint32_t ob = sect ? blockIdx.y : 0u;  // first op of the plan this launch row uses
   const uint32_t c = blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const DecChunk dc = chunks[c];
+  const DecChunk dc = chunks[sect ? (size_t)blockIdx.y * sect_chunks + c : (size_t)c];
   if (!dc.valid) return;
-  if (token_ends != nullptr && reg_end[c] == kDecRedo) return;  // k_mark_token_ends found the stream irregular
+  if (sect && dc.valid != 1u) return;  // another mode: k_sections_w
+  if (!sect && token_ends != nullptr && reg_end[c] == kDecRedo) return;  // k_mark_token_ends found the stream irregular
   const uint8_t* src = streams + dc.src_off;
   const uint32_t src_size = dc.src_size;
   const uint32_t n = dc.n_points;
-  const uint32_t n_ops = plan.n_ops;
-  const uint32_t step = plan.point_step;
-  uint8_t* base = out + (size_t)dc.first_point * step;
+  const uint32_t n_ops = sect ? 1u : plan.n_ops;
+  // (section mode with out == NULL: the values go to the field's dense column instead of the points)
+  const bool sect_to_cols = sect && out == nullptr;
+  const uint32_t step = sect_to_cols ? (uint32_t)plan.ops[ob].size : plan.point_step;
+  uint8_t* base = sect_to_cols ? const_cast<uint8_t*>(sect_cols.p[ob]) + (size_t)dc.first_point * step : out + (size_t)dc.first_point * step;
   const uint32_t target = n * n_ops;
-  if (n_ops == 0u || n == 0u) {  // no per-point encoder (integer fields only): the sections begin at once
+  if (!sect && (n_ops == 0u || n == 0u)) {  // no per-point encoder (integer fields only): the sections begin at once
     if (tid == 0) {
       reg_end[c] = 0u;
       atomicAdd(&status[kStatFastRegular], 1u);
     }
     return;
   }
-  const uint8_t* ebits = token_ends != nullptr ? reinterpret_cast<const uint8_t*>(token_ends + token_ends_word(dc.src_off, c)) : nullptr;
+  const uint8_t* ebits = (!sect && token_ends != nullptr) ? reinterpret_cast<const uint8_t*>(token_ends + token_ends_word(dc.src_off, c)) : nullptr;
   // every op raw (EncodingOptions::NONE, lossless floats): a point has a fixed size F and the token ends follow from the
   // byte offset alone -- pat[r] = end bits of the 16 bytes that begin r bytes into a point (no bitmap is read)
   uint16_t* pat = reinterpret_cast<uint16_t*>(smem + L::kMiscOff + 64u);  // [kSwMaxPointBytes]
@@ -248,9 +257,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
     bool all_raw = true;
     uint32_t F = 0u;
     for (uint32_t o = 0; o < n_ops; ++o) {
-      const uint32_t k = plan.ops[o].kind;
+      const uint32_t k = plan.ops[ob + o].kind;
       all_raw = all_raw && (k == OP_COPY || k == OP_XOR32 || k == OP_XOR64);
-      F += plan.ops[o].size;
+      F += plan.ops[ob + o].size;
     }
     if (all_raw && F <= kSwMaxPointBytes) fixed_F = F;
   }
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       uint32_t acc = 0u;
       bool is_end = false;
       for (uint32_t o = 0; o < n_ops; ++o) {
-        acc += plan.ops[o].size;
+        acc += plan.ops[ob + o].size;
         is_end = is_end || r + 1u == acc;
       }
       if (is_end) bits |= 1u << i;
@@ -343,8 +352,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   // per-op state: lane o of these registers belongs to op o
   uint32_t kind_l = 0xffu, size_l = 0u;
   if (lane < n_ops) {
-    kind_l = plan.ops[lane].kind;
-    size_l = plan.ops[lane].size;
+    kind_l = plan.ops[ob + lane].kind;
+    size_l = plan.ops[ob + lane].size;
   }
   const bool raw_l = kind_l == OP_COPY || kind_l == OP_XOR32 || kind_l == OP_XOR64;
   const unsigned long long raw_ops = __ballot(raw_l);                                   // bit o: op o's token is `size` raw bytes
@@ -847,7 +856,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       const uint32_t byte0 = have ? (uint32_t)plist[j] : 0u;
       uint8_t* pt = base + __umul24(q_first + (have ? j : 0u), step);  // (q < 2^16, step <= 1024)
       walk(j, byte0, have, [&](uint32_t o, uint64_t v, bool mk) __attribute__((always_inline)) {
-        const DevOp& op = plan.ops[o];
+        const DevOp& op = plan.ops[ob + o];
         const uint32_t off = op.offset;
         const uint32_t kind = op.kind;
         if (kind == OP_COPY) {
@@ -918,8 +927,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   if (tid == 0) {
     const uint32_t pos = misc[2];
     const bool redo = misc[0] != 0u || pos == 0xffffffffu;
-    reg_end[c] = redo ? kDecRedo : pos;
-    if (!redo) atomicAdd(&status[kStatFastRegular], 1u);
+    if (sect) {
+      if (!redo && pos == src_size) atomicAdd(reg_end + c, 1u);  // the section's n tokens end exactly with it
+    } else {
+      reg_end[c] = redo ? kDecRedo : pos;
+      if (!redo) atomicAdd(&status[kStatFastRegular], 1u);
+    }
   }
 }
 

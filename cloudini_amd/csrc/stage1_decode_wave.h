@@ -52,7 +52,7 @@ struct WpLds {
   static constexpr uint32_t kTrecOff = kLutOff + (uint32_t)NOPS * 512u;          // u64 [kWpRing]
   static constexpr uint32_t kVrecOff = kTrecOff + kWpRing * 8u;                  // u64 [kWpRing][NOPS]
   static constexpr uint32_t kPalOff = kVrecOff + kWpRing * (uint32_t)NOPS * 8u;
-  static constexpr uint32_t kMiscOff = kPalOff + (uint32_t)NF * kFastPalEntries * 4u;
+  static constexpr uint32_t kMiscOff = kPalOff + (uint32_t)(NF > 2 ? 0 : NF) * kFastPalEntries * 4u;  // (NF > 2: columns only, nothing is folded)
   static constexpr uint32_t kTotal = kMiscOff + 512u;
 };
 
@@ -140,11 +140,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     const DevPlan plan, const uint8_t* __restrict__ streams, const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
     uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done, uint32_t uses_v5, uint32_t* __restrict__ status,
     const uint8_t* __restrict__ col0, const uint8_t* __restrict__ col1, const uint32_t* __restrict__ reg_end_pre,
-    const uint8_t* __restrict__ sec_cols, uint32_t fill_zero) {
+    const uint8_t* __restrict__ sec_cols, uint32_t fill_zero, const DecColumns many) {
   using L = WpLds<NOPS, NF, NW>;
   using G = WpGeom<NOPS>;
   constexpr int T = NW * 64;
-  constexpr uint32_t NFA = NF ? NF : 1;  // array extents (NF == 0: nothing is ever folded)
+  // NF > 2 (round 4): layouts with 3..8 integer channels -- their sections were decoded into dense columns in front of this
+  // kernel (stage1_decode_sections_w.h); a point's fields are read from `many` when the point is stored
+  constexpr bool MANY = NF > 2;
+  constexpr uint32_t NFA = MANY ? 1 : (NF ? NF : 1);  // array extents (NF == 0: nothing is ever folded)
   constexpr uint32_t ROWS = G::kRows;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t* lut = reinterpret_cast<uint16_t*>(smem + L::kLutOff);
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     for (uint32_t a = 0; a < NFA; ++a)
 #pragma unroll
       for (uint32_t r = 0; r < ROWS; ++r) raw[a][r] = 0u;
-    if (n_fold != 0u) {  // uniform
+    if (!MANY && n_fold != 0u) {  // uniform
 #pragma unroll
       for (uint32_t r = 0; r < ROWS; ++r) {
         if (r * 64u < npts) {  // uniform
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
         uint32_t pv[NFA];
 #pragma unroll
         for (uint32_t a = 0; a < NFA; ++a) pv[a] = raw[a][r];
-        if (!from_cols && n_fold != 0u) {
+        if (!MANY && !from_cols && n_fold != 0u) {
 #pragma unroll
           for (uint32_t a = 0; a < NFA; ++a) {
             if (a >= n_fold) break;  // uniform
@@ -516,7 +519,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
               for (int o = 0; o < NOPS; ++o)
                 if (foff[o] != 0xffffffffu) __builtin_memcpy(pt + foff[o], &f[o], 4);
             }
-            if (one_u16) {
+            if (MANY) {
+              for (uint32_t a = 0; a < n_fold; ++a) {  // uniform: the plan and the column table are read with scalar loads
+                const uint32_t f_off = plan.adaptive[a].offset, f_bpv = plan.adaptive[a].bpv;
+                const uint8_t* colp = many.p[a] + (size_t)dc.first_point * f_bpv;
+                if (f_bpv == 2u) {
+                  const uint16_t h = reinterpret_cast<const uint16_t*>(colp)[q];
+                  __builtin_memcpy(pt + f_off, &h, 2);
+                } else {
+                  const uint32_t w = reinterpret_cast<const uint32_t*>(colp)[q];
+                  __builtin_memcpy(pt + f_off, &w, 4);
+                }
+              }
+            } else if (one_u16) {
               *reinterpret_cast<uint16_t*>(pt + fs_off[0]) = (uint16_t)pv[0];
             } else {
 #pragma unroll

@@ -78,7 +78,7 @@ struct DecodeLaunch {
   void* chunks;                       // device [n_chunks] DecChunk (48 bytes each)
   uint32_t* reg_end;                  // device [n_chunks]: end of the regular stream per chunk (fast path)
   uint8_t* sec_done;                  // device [n_chunks]: 1 = sections decoded by k_decode_sections
-  uint8_t* cols[2];                   // device: dense columns of the first two adaptive fields (n_points * bpv each), or NULL
+  uint8_t* cols[8];                   // device: dense columns of the first adaptive fields (n_points * bpv each), or NULL
   uint32_t* reg_end_pre;              // device [n_chunks]: k_decode_sections_cols: where the regular stream ends
   uint8_t* sec_cols;                  // device [n_chunks]: 1 = the columns hold the chunk's integer fields
   const uint32_t* chunk_sizes;        // device [n_chunks] or NULL: the payload sizes, if the caller knows them (no serial walk)
@@ -87,6 +87,9 @@ struct DecodeLaunch {
   uint32_t* slices_done;          // [n_chunks] DeltaVarint slices of a chunk that k_sections_cols_fast finished
   unsigned long long* slice_rec;  // [n_chunks * 48 * 2] (count, sum) records of the slices, tagged with slice_epoch
   uint32_t slice_epoch;           // != 0, different from every earlier launch on slice_rec since it was cleared
+  void* dsec;                     // [n_adaptive * n_chunks] DecChunk: the sections k_section_offsets sized (stage1_decode_sections_w.h), or NULL
+  uint8_t* secs_ok;               // [n_chunks]
+  uint32_t* done_cnt;             // [n_chunks]
   uint8_t* out;                       // device: decoded AoS points
   uint32_t* status;
 };
