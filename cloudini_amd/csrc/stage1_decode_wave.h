@@ -520,15 +520,28 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
                 if (foff[o] != 0xffffffffu) __builtin_memcpy(pt + foff[o], &f[o], 4);
             }
             if (MANY) {
-              for (uint32_t a = 0; a < n_fold; ++a) {  // uniform: the plan and the column table are read with scalar loads
-                const uint32_t f_off = plan.adaptive[a].offset, f_bpv = plan.adaptive[a].bpv;
-                const uint8_t* colp = many.p[a] + (size_t)dc.first_point * f_bpv;
-                if (f_bpv == 2u) {
-                  const uint16_t h = reinterpret_cast<const uint16_t*>(colp)[q];
-                  __builtin_memcpy(pt + f_off, &h, 2);
-                } else {
-                  const uint32_t w = reinterpret_cast<const uint32_t*>(colp)[q];
-                  __builtin_memcpy(pt + f_off, &w, 4);
+              // all of the point's column values are requested before the first one is stored (one round trip, not one per
+              // field); uniform guards, the plan and the column table are read with scalar loads
+              uint32_t cv[8];
+#pragma unroll
+              for (uint32_t a = 0; a < 8u; ++a) {
+                cv[a] = 0u;
+                if (a < n_fold) {
+                  const uint32_t f_bpv = plan.adaptive[a].bpv;
+                  const uint8_t* colp = many.p[a] + (size_t)dc.first_point * f_bpv;
+                  cv[a] = f_bpv == 2u ? (uint32_t)reinterpret_cast<const uint16_t*>(colp)[q] : reinterpret_cast<const uint32_t*>(colp)[q];
+                }
+              }
+#pragma unroll
+              for (uint32_t a = 0; a < 8u; ++a) {
+                if (a < n_fold) {
+                  const uint32_t f_off = plan.adaptive[a].offset;
+                  if (plan.adaptive[a].bpv == 2u) {
+                    const uint16_t h = (uint16_t)cv[a];
+                    __builtin_memcpy(pt + f_off, &h, 2);
+                  } else {
+                    __builtin_memcpy(pt + f_off, &cv[a], 4);
+                  }
                 }
               }
             } else if (one_u16) {
