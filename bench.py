@@ -628,7 +628,7 @@ def main():
 
     # extra (not `value`): decode of the streams just produced, device resident, same synchronisation bracket
     decode = None
-    if rank == 0 and points_local:
+    if points_local:  # (every rank: the job-wide decode figure of a multi-GPU run is the slowest rank's)
         d_dec = torch.empty(max(1, host.size), dtype=torch.uint8, device=dev)
         so = offsets.astype(np.uint64)
         dec_steps = max(1, args.steps // 2)
@@ -716,7 +716,7 @@ def main():
     # outside the timed region with the compiled reference (oracle/_ref) or, where that is absent, the C port: every
     # distinct cloud against the checker, every tiled copy against its first occurrence
     bit_exact = None
-    if rank == 0 and points_local and args.shard == "clouds" and args.verify:
+    if points_local and args.shard == "clouds" and args.verify:  # (every rank checks its own streams)
         from oracle import binding
         try:
             checker, checker_kind = binding.RefLib(), "reference"
@@ -735,6 +735,18 @@ def main():
             else:
                 ok = ok and got.numel() == first_of[j].numel() and bool(torch.equal(got, first_of[j]))
         bit_exact = {"ok": bool(ok), "checker": checker_kind, "clouds_vs_checker": compared, "clouds_vs_first_copy": n_clouds - compared}
+    # job-wide figures of this rank count (round 4: the same object for every --workload and --gpus, so that the first run on
+    # a multi-GPU node is a measurement): the slowest rank's decode, every rank's bit-exactness
+    job = None
+    if dist is not None and world > 1:
+        t = torch.tensor([decode["ms_per_step"] if decode else 0.0, 1.0 if (bit_exact is None or bit_exact["ok"]) else 0.0],
+                         dtype=torch.float64, device=dev)
+        tmax, tmin = t.clone(), t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        job = {"decode_ms_per_step_max_over_ranks": float(tmax[0].item()), "bit_exact_all_ranks": bool(tmin[1].item() > 0.5)}
+    elif decode is not None:
+        job = {"decode_ms_per_step_max_over_ranks": decode["ms_per_step"], "bit_exact_all_ranks": bit_exact["ok"] if bit_exact else None}
     if dist is not None:
         dist.barrier()
 
@@ -814,6 +826,11 @@ def main():
             "bit_exact": bit_exact["ok"] if bit_exact else None,
             "bit_exact_detail": bit_exact,
             "decode": decode,
+            "job": None if job is None else dict(job, n_gpus=world, workload=args.workload, shard=args.shard,
+                                                 encode_ms_per_step=ms_per_step, encode_Mpoints_per_s=mpts,
+                                                 decode_Mpoints_per_s=(points_job / (job["decode_ms_per_step_max_over_ranks"] * 1e-3) / 1e6
+                                                                       if job["decode_ms_per_step_max_over_ranks"] else None),
+                                                 stage1_bytes=job_bytes),
             "chunk_table": chunk_table,
             "stage1_bytes_per_point": out_bpp,
             "device_ms_per_step": {dominant: regular_ms, "sections": sections_ms,

@@ -125,6 +125,8 @@ void* pinnedAlloc(size_t bytes) {
       return p;
     }
   }
+  static const bool no_device = cldn_hip_device_count() <= 0;  // (message buffers of a process without a GPU: ordinary memory)
+  if (no_device) return std::malloc(bytes);
   void* p = cldn_hip_host_alloc(bytes);
   if (!p) {  // page-locked memory is short while idle blocks of other sizes sit in the cache: give them back, try once more
     releasePinnedCache();
@@ -139,6 +141,11 @@ void* pinnedAlloc(size_t bytes) {
 
 void pinnedFree(void* p) noexcept {
   if (!p) return;
+  static const bool no_device = cldn_hip_device_count() <= 0;
+  if (no_device) {
+    std::free(p);
+    return;
+  }
   PinnedCache& c = pinnedCache();
   {
     std::lock_guard<std::mutex> lock(c.mutex);
@@ -606,13 +613,18 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
   // pooled codecs (the pool key carries the device, host/cloudini.cpp); batches go to whichever worker is free and are put
   // back into input order in front of the writer
   std::vector<int> devices = opt.devices;
-  if (devices.empty()) devices.push_back(-1);  // -1: the calling thread's current device
-  const int caller_device = cldn_hip_current_device();
-  for (int& d : devices)
-    if (d < 0) d = caller_device;
-  const int n_devices = cldn_hip_device_count();
-  for (int d : devices)
-    if (d < 0 || d >= n_devices) throw std::runtime_error("transcodePointClouds: device " + std::to_string(d) + " does not exist");
+  const bool fake = static_cast<bool>(opt.test_stage);  // test hook: the stages are the caller's function, no device is touched
+  if (fake) {
+    devices.assign(std::max<size_t>(1, opt.test_workers), 0);
+  } else {
+    if (devices.empty()) devices.push_back(-1);  // -1: the calling thread's current device
+    const int caller_device = cldn_hip_current_device();
+    for (int& d : devices)
+      if (d < 0) d = caller_device;
+    const int n_devices = cldn_hip_device_count();
+    for (int d : devices)
+      if (d < 0 || d >= n_devices) throw std::runtime_error("transcodePointClouds: device " + std::to_string(d) + " does not exist");
+  }
   const size_t n_workers = devices.size();
   const size_t batches_in_flight = 2 * n_workers + 1;
   std::vector<std::unique_ptr<Batch>> storage;
@@ -684,12 +696,19 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
       while (to_gpu.pop(b)) {
         if (!failed.load()) {
           try {
-            if (!device_set) {
-              if (cldn_hip_set_current_device(devices[w]) != CLDN_HIP_OK) throw std::runtime_error(cldn_hip_last_error());
-              device_set = true;
+            if (fake) {
+              b->out.assign(b->in.size(), {});
+              opt.test_stage(w, b->in, b->out);
+              mine.messages += b->in.size();
+              mine.gpu_batches += 1;
+            } else {
+              if (!device_set) {
+                if (cldn_hip_set_current_device(devices[w]) != CLDN_HIP_OK) throw std::runtime_error(cldn_hip_last_error());
+                device_set = true;
+              }
+              if (opt.decode) decodeGpuPhase(*b, &mine);
+              else gpuPhase(*b, opt, &mine);
             }
-            if (opt.decode) decodeGpuPhase(*b, &mine);
-            else gpuPhase(*b, opt, &mine);
           } catch (...) {
             gpu_error[w] = std::current_exception();
             failed.store(true);
@@ -711,7 +730,7 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
   std::thread stage2([&] {
     Batch* b = nullptr;
     while (to_stage2.pop(b)) {
-      if (!failed.load()) {
+      if (!failed.load() && !fake) {
         try {
           if (opt.decode) decodeWrapPhase(*b, &stats2);
           else stage2Phase(*b, opt, &stats2);

@@ -20,6 +20,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <new>
+#include <functional>
 #include <optional>
 #include <string>
 #include <utility>
@@ -134,6 +135,11 @@ struct TranscodeOptions {
   // ordered writer; batches go to whichever GPU stage is free. Empty = the calling thread's current device. The same
   // device may be listed more than once (two batches in flight on one GPU).
   std::vector<int> devices;
+  // Test hook (tests/cpp/transcoder_order.cpp, runs without a GPU): when set, `test_workers` stage threads call it instead of
+  // the GPU stage and stage 2 passes the batch on untouched -- what remains is the pipeline itself: batches handed to
+  // whichever stage is free, the writer putting them back into input order, an error on any stage stopping all of them.
+  std::function<void(size_t worker, const std::vector<Message>& in, std::vector<std::vector<uint8_t>>& out)> test_stage;
+  size_t test_workers = 0;
 };
 
 struct TranscodeStats {

@@ -211,3 +211,50 @@ def test_wrapping_geometry_is_refused_on_the_way_back(tmp_path):
     _write_messages(src, [np.frombuffer(bytes(msg), dtype=np.uint8)])
     with pytest.raises(RuntimeError):
         api.decode_directory(src, str(tmp_path / "out"))
+
+
+def _swap_stream(msg: np.ndarray, new_stream: bytes) -> np.ndarray:
+    """A CompressedPointCloud2 CDR message with its compressed_data replaced: [u32 length][bytes] is followed by is_dense
+    (1 byte) and the format string ([pad to 4][u32 length]["cloudini\0"]), src/ros_msg_utils.cpp:167-213."""
+    raw = msg.tobytes()
+    at = raw.find(b"CLOUDINI_V")
+    assert at >= 8
+    old_len = int.from_bytes(raw[at - 4:at], "little")
+    tail = raw[at + old_len:]
+    is_dense = tail[:1]
+    k = tail.find(b"cloudini")
+    fmt = tail[k - 4:]                                   # [u32 9]["cloudini\0"]
+    head = raw[:at - 4] + len(new_stream).to_bytes(4, "little") + new_stream + is_dense
+    pad = (-(len(head) - 4)) % 4                         # CDR aligns relative to the end of the 4-byte encapsulation header
+    return np.frombuffer(head + b"\0" * pad + fmt, dtype=np.uint8)
+
+
+def test_wire_version_2_messages_in_a_bag_decode_one_by_one(tmp_path, reflib):
+    """A CompressedPointCloud2 whose stream has wire version 2 (no chunk framing: one unframed payload,
+    src/cloudini.cpp:665-667) between version-5 messages: the batched way back must not read its first bytes as a chunk
+    size -- it takes the single-message path, and every output equals the reference's converter."""
+    from test_host_api import _stage2
+    msgs, packed = [], []
+    for k, n in enumerate([9000, 20000, 7000]):
+        info, data = synth.lidar_xyzi(n, seed=70 + k)
+        m = _cdr_pointcloud2(info, data, stamp=(1700000100 + k, 5 * k))
+        msgs.append(m)
+        packed.append(reflib.ros_compress(m, 0.001, int(CompressionOption.NONE)))
+    # message 1 becomes a version-2 stream of the same cloud: header "CLOUDINI_V02" + the stage-1 payload without its prefix
+    info, data = synth.lidar_xyzi(20000, seed=71)
+    info3 = info.copy(version=3, compression_opt=CompressionOption.NONE)
+    framed = reflib.encode_stage1(info3, data)
+    assert int.from_bytes(framed[:4].tobytes(), "little") + 4 == framed.size  # one chunk
+    for comp in (CompressionOption.NONE, CompressionOption.ZSTD):
+        info2 = info3.copy(version=2, compression_opt=comp, width=20000, height=1)
+        v2 = reflib.header(info2) + _stage2(comp, framed[4:].tobytes())
+        bag = [packed[0], _swap_stream(packed[1], v2), packed[2]]
+        want1 = reflib.ros_decompress(bag[1], msgs[1].size + 4096)      # the reference reads the message
+        src, dst = str(tmp_path / f"in{int(comp)}"), str(tmp_path / f"out{int(comp)}")
+        _write_messages(src, bag)
+        stats = api.decode_directory(src, dst, batch_messages=4)
+        assert int(stats["messages"]) == 3
+        for k in range(3):
+            got = np.fromfile(os.path.join(dst, f"msg_{k:05d}.bin"), dtype=np.uint8)
+            want = want1 if k == 1 else reflib.ros_decompress(bag[k], msgs[k].size + 4096)
+            assert got.size == want.size and np.array_equal(got, want), (int(comp), k)

@@ -18,6 +18,20 @@ def test_public_headers_compile_and_behave(tmp_path):
     assert "all checks passed" in r.stdout
 
 
+def test_transcoder_pipeline_order_with_fake_stages(tmp_path):
+    """tests/cpp/transcoder_order.cpp (no GPU): 1 / 3 / 5 stage threads of different speed keep the input order, a failing
+    stage stops the run with a prefix written -- the logic a multi-GPU transcode (TranscodeOptions::devices) adds."""
+    lib_dir = os.path.join(ROOT, "cloudini_amd", "lib")
+    exe = str(tmp_path / "transcoder_order")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "transcoder_order.cpp"), os.path.join(lib_dir, "libcloudini_amd.so"),
+                    os.path.join(lib_dir, "libcloudini_hip.so"), "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib",
+                    "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout
+
+
 import pytest  # noqa: E402
 
 
