@@ -51,6 +51,9 @@ struct FinishArgs {
   uint32_t* ticket;                   // zero at launch
   uint32_t use_ticket;
   uint32_t test_timeout;              // test hook (CLDN_HIP_TEST_FINISH_TIMEOUT): without the ticket the launch reports ST_FINISH_TIMEOUT at once
+  uint32_t copy_mode;                 // fin_copy: 0 one unit per lane and two loads, 1 neighbour's load by DPP, 2 ... and two rows per iteration
+  uint32_t ablate;                    // profiling only: 1 no copy, 2 no section body (wrong output)
+  unsigned long long* trace;          // profiling only (CLDN_HIP_FINISH_TRACE): [n_chunks][16] wall_clock64() stamps of the leaders' phases
   uint32_t order;                     // fused Palette: 0 even chunks section first, odd chunks copy first; 1 all section first; 2 all copy first
   uint32_t* chunk_payload;            // out [n_chunks]
   uint64_t* chunk_dst;                // out [n_chunks]
@@ -94,44 +97,60 @@ __device__ __forceinline__ uint32_t fin_wait(const unsigned long long* p, uint32
   }
 }
 
-// thread 0: payload size, destination offsets and the work-item table from the segment table in LDS. Segments with
-// skip[s] (the fused section's two, written by the workgroup itself) get a place but no items.
+// wave 0: payload size, destination offsets and the work-item table from the segment table in LDS (lane l owns segments
+// l, l + 64, ...: wave scans instead of a serial walk). Segments skip0 / skip1 (the fused section's two, written by the
+// workgroup itself) get a place but no items.
 __device__ __forceinline__ void fin_layout(FinishLds& L, uint32_t n_segs, uint32_t skip0, uint32_t skip1,
-                                           uint32_t dst_mis /* (dst0 + 4) & 15 */) {
+                                           uint32_t dst_mis /* (dst0 + 4) & 15 */, uint32_t lane) {
+  constexpr uint32_t K = (kFinMaxSegs + 63u) / 64u;
+  uint32_t z[K], d[K], cnt[K], ibase[K];
   uint32_t payload = 0u;
-  for (uint32_t s = 0; s < n_segs; ++s) payload += L.seg[s].size;
+#pragma unroll
+  for (uint32_t k = 0; k < K; ++k) {
+    const uint32_t s = lane + 64u * k;
+    z[k] = s < n_segs ? L.seg[s].size : 0u;
+    const uint32_t incl = wave_inclusive_scan(z[k]);
+    d[k] = payload + incl - z[k];
+    payload += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  }
   // work items of 4 KiB, larger when the chunk is so big (wide raw points: up to 32768 * 1024 bytes) that 4 KiB items
   // would not fit the table
   const uint32_t item_units = max(kFinItemUnits, (payload >> 4) / (kFinMaxItems - kFinMaxSegs - 8u) + 1u);
-  uint32_t d = 0u, n_items = 0u;
-  for (uint32_t s = 0; s < n_segs; ++s) {
-    L.doff[s] = d;
-    const uint32_t size = L.seg[s].size;
-    if (size && s != skip0 && s != skip1) {
+  uint32_t n_items = 0u;  // <= payload / 16 / item_units + n_segs < kFinMaxItems
+#pragma unroll
+  for (uint32_t k = 0; k < K; ++k) {
+    const uint32_t s = lane + 64u * k;
+    cnt[k] = 0u;
+    if (z[k] != 0u && s != skip0 && s != skip1) {
       // items cover the destination-aligned 16-byte units of the segment (+ one item for a segment without any)
-      const uint32_t head = min(size, (16u - ((dst_mis + d) & 15u)) & 15u);
-      const uint32_t units = (size - head) >> 4;
-      uint32_t u0 = 0u;
-      do {
-        if (n_items < kFinMaxItems) {
-          L.item_seg[n_items] = s;
-          L.item_u0[n_items] = u0;
-          ++n_items;
-        }
-        u0 += item_units;
-      } while (u0 < units);
+      const uint32_t head = min(z[k], (16u - ((dst_mis + d[k]) & 15u)) & 15u);
+      const uint32_t units = (z[k] - head) >> 4;
+      cnt[k] = max(1u, (units + item_units - 1u) / item_units);
     }
-    d += size;
+    const uint32_t incl = wave_inclusive_scan(cnt[k]);
+    ibase[k] = n_items + incl - cnt[k];
+    n_items += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   }
-  L.n_items = n_items;
-  L.item_units = item_units;
-  L.payload = payload;
+#pragma unroll
+  for (uint32_t k = 0; k < K; ++k) {
+    const uint32_t s = lane + 64u * k;
+    if (s < n_segs) L.doff[s] = d[k];
+    for (uint32_t j = 0, it = ibase[k]; j < cnt[k] && it < kFinMaxItems; ++j, ++it) {
+      L.item_seg[it] = s;
+      L.item_u0[it] = j * item_units;
+    }
+  }
+  if (lane == 0u) {
+    L.n_items = min(n_items, kFinMaxItems);
+    L.item_units = item_units;
+    L.payload = payload;
+  }
 }
 
 // the waves of the chunk's workgroups take the items round-robin: byte-exact copy of the segments, source segments
 // start 16-byte aligned, the destination position is arbitrary (16-byte destination units built with byte funnel shifts)
 __device__ __forceinline__ void fin_copy(const FinishLds& L, const uint8_t* __restrict__ slot, uint8_t* __restrict__ chunk_out,
-                                         uint32_t wid, uint32_t n_waves, uint32_t lane) {
+                                         uint32_t wid, uint32_t n_waves, uint32_t lane, uint32_t mode) {
   const uint32_t n_items = L.n_items, item_units = L.item_units;
   for (uint32_t it = wid; it < n_items; it += n_waves) {
     const uint32_t sidx = L.item_seg[it], u0 = L.item_u0[it];
@@ -155,10 +174,7 @@ __device__ __forceinline__ void fin_copy(const FinishLds& L, const uint8_t* __re
     const uint4* src4 = reinterpret_cast<const uint4*>(src);
     uint4* dst4 = reinterpret_cast<uint4*>(dst + head);
     const uint32_t u1 = min(body_units, u0 + item_units);
-    for (uint32_t j = u0 + lane; j < u1; j += 64u) {  // (four units per lane and iteration: 1.5x slower, twice measured)
-      const uint4 a = src4[j];
-      uint4 b = make_uint4(0u, 0u, 0u, 0u);
-      if (head != 0u) b = src4[j + 1u];
+    auto build = [&](const uint4& a, const uint4& b) __attribute__((always_inline)) {
       uint32_t w0, w1, w2, w3, w4;
       switch (sdw) {
         case 0: w0 = a.x; w1 = a.y; w2 = a.z; w3 = a.w; w4 = b.x; break;
@@ -171,7 +187,64 @@ __device__ __forceinline__ void fin_copy(const FinishLds& L, const uint8_t* __re
       o.y = funnel_bytes(w1, w2, sb);
       o.z = funnel_bytes(w2, w3, sb);
       o.w = funnel_bytes(w3, w4, sb);
-      dst4[j] = o;
+      return o;
+    };
+    if (mode == 1u) {  // A/B switch: one unit per lane, both of its source units loaded by the lane itself (rounds 2-3)
+      for (uint32_t j = u0 + lane; j < u1; j += 64u) {
+        const uint4 a = src4[j];
+        uint4 b = make_uint4(0u, 0u, 0u, 0u);
+        if (head != 0u) b = src4[j + 1u];
+        dst4[j] = build(a, b);
+      }
+    } else if (u0 < u1) {
+      // the unit behind mine is my neighbour's: lane l takes lane l + 1's load by DPP (wave_shl:1), lane 63 the next
+      // row's first unit. All lanes load (clamped index), the loop is wave-uniform. `last` = the last unit that may be
+      // read: one behind the item's last when the units straddle (the per-lane variant reads it as well).
+      const uint32_t last = head != 0u ? u1 : u1 - 1u;
+      auto shl1 = [&](const uint4& a, const uint4& lane63) __attribute__((always_inline)) {
+        uint4 r;
+        r.x = (uint32_t)__builtin_amdgcn_update_dpp((int)lane63.x, (int)a.x, 0x130, 0xf, 0xf, false);
+        r.y = (uint32_t)__builtin_amdgcn_update_dpp((int)lane63.y, (int)a.y, 0x130, 0xf, 0xf, false);
+        r.z = (uint32_t)__builtin_amdgcn_update_dpp((int)lane63.z, (int)a.z, 0x130, 0xf, 0xf, false);
+        r.w = (uint32_t)__builtin_amdgcn_update_dpp((int)lane63.w, (int)a.w, 0x130, 0xf, 0xf, false);
+        return r;
+      };
+      auto lane0 = [&](const uint4& a) __attribute__((always_inline)) {
+        return make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)a.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)a.y),
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)a.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)a.w));
+      };
+      auto ld = [&](uint32_t j, bool nt) __attribute__((always_inline)) {
+        const uint4* q = src4 + min(j, last);
+        if (!nt) return *q;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q));
+        return make_uint4(v.x, v.y, v.z, v.w);
+      };
+      auto st = [&](uint32_t j, const uint4& v, bool nt) __attribute__((always_inline)) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 q;
+        q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+        if (nt) __builtin_nontemporal_store(q, reinterpret_cast<u32x4*>(dst4 + j));
+        else dst4[j] = v;
+      };
+      auto rows_loop = [&](auto rows_tag, auto nt_tag) __attribute__((always_inline)) {
+        constexpr uint32_t RW = decltype(rows_tag)::value;
+        constexpr bool NT = decltype(nt_tag)::value;
+        for (uint32_t jb = u0; jb < u1; jb += 64u * RW) {  // RW rows of 64 units in flight per iteration
+          const uint32_t j = jb + lane;
+          uint4 a[RW + 1];
+#pragma unroll
+          for (uint32_t r = 0; r < RW; ++r) a[r] = ld(j + 64u * r, NT);
+          a[RW] = make_uint4(0u, 0u, 0u, 0u);
+          if (lane == 63u && head != 0u) a[RW] = ld(j + 64u * (RW - 1u) + 1u, NT);
+#pragma unroll
+          for (uint32_t r = 0; r < RW; ++r) {
+            const uint4 b = shl1(a[r], r + 1u < RW ? lane0(a[r + 1u]) : a[RW]);
+            if (j + 64u * r < u1) st(j + 64u * r, build(a[r], b), NT);
+          }
+        }
+      };
+      rows_loop(std::integral_constant<uint32_t, 2>{}, std::true_type{});
     }
   }
 }
@@ -227,6 +300,7 @@ __global__ __launch_bounds__(T, (T == 1024 ? 4 : 8)) __attribute__((amdgpu_num_s
   const bool leader = (y == 0u);
   const ChunkDesc cd = A.chunks[c];
   const uint32_t n_segs = A.segs_per_chunk;
+  if (A.trace != nullptr && tid == 0u && leader) A.trace[(size_t)c * 16u + 0u] = wall_clock64();
   if (tid < n_segs) L.seg[tid] = A.segs[(size_t)c * n_segs + tid];
 
   // ---- fused Palette: build the table, which gives the section's size
@@ -245,7 +319,7 @@ __global__ __launch_bounds__(T, (T == 1024 ? 4 : 8)) __attribute__((amdgpu_num_s
       first = A.fuse_first + cd.first_point;
       if (leader) {
         const P p(smem);
-        if (pal32_build<RawT, T>(p, col, n)) {
+        if (pal32_build<RawT, T>(p, col, n, A.trace ? A.trace + (size_t)c * 16u + 8u : nullptr)) {
           U = p.misc[0];
         } else {
           slow = true;
@@ -268,6 +342,7 @@ __global__ __launch_bounds__(T, (T == 1024 ? 4 : 8)) __attribute__((amdgpu_num_s
       }
     }
   }
+  if (A.trace != nullptr && tid == 0u && leader) A.trace[(size_t)c * 16u + 1u] = wall_clock64();
   __syncthreads();  // L.seg is complete
   if (fuse && tid == 0u) {
     L.seg[s_a].size = 3u + U * (uint32_t)sizeof(RawT);
@@ -293,6 +368,8 @@ __global__ __launch_bounds__(T, (T == 1024 ? 4 : 8)) __attribute__((amdgpu_num_s
         const uint32_t j = (blk << 10) + tid + k * T;
         x[k] = j < c ? fin_load(A.rec + j) : ((unsigned long long)A.epoch << 32);
       }
+      // the ranks of the fused section need nothing from outside: they are computed while the records arrive
+      if (FUSE_BPV != 0 && fuse && leader && !slow && !(A.ablate & 2u)) (void)pal32_rank<RawT, T>(P(smem), nullptr);
 #pragma unroll
       for (uint32_t k = 0; k < PER; ++k) {
         const uint32_t j = (blk << 10) + tid + k * T;
@@ -331,8 +408,10 @@ __global__ __launch_bounds__(T, (T == 1024 ? 4 : 8)) __attribute__((amdgpu_num_s
     return;
   }
   const unsigned long long dst0 = L.base;
-  if (tid == 0u) fin_layout(L, n_segs, s_a, s_b, (uint32_t)((dst0 + 4ull) & 15ull));
+  if (A.trace != nullptr && tid == 0u && leader) A.trace[(size_t)c * 16u + 2u] = wall_clock64();
+  if (wave == 0u) fin_layout(L, n_segs, s_a, s_b, (uint32_t)((dst0 + 4ull) & 15ull), lane);
   __syncthreads();
+  if (A.trace != nullptr && tid == 0u && leader) A.trace[(size_t)c * 16u + 7u] = wall_clock64();
   const uint32_t payload = L.payload;
   if (dst0 + 4ull + payload > A.out_capacity) {
     if (tid == 0u && leader) atomicOr(A.status, (uint32_t)ST_OUT_OVERFLOW);
@@ -354,18 +433,20 @@ __global__ __launch_bounds__(T, (T == 1024 ? 4 : 8)) __attribute__((amdgpu_num_s
     }
   }
 
+  if (A.trace != nullptr && tid == 0u && leader) A.trace[(size_t)c * 16u + 3u] = wall_clock64();
   // ---- placement
   const uint8_t* slot = A.slots + (size_t)c * A.slot_stride;
   const uint32_t wid = y * (T / 64) + wave;
   const uint32_t n_waves = A.splits * (T / 64);
   const bool section_first = !fuse || !leader || A.order == 1u || (A.order == 0u && (c & 1u) == 0u);
-  if (!section_first) fin_copy(L, slot, chunk_out, wid, n_waves, lane);
-  if (FUSE_BPV != 0 && fuse && leader) {
+  if (!section_first && !(A.ablate & 1u)) fin_copy(L, slot, chunk_out, wid, n_waves, lane, A.copy_mode);
+  if (A.trace != nullptr && tid == 0u && leader) A.trace[(size_t)c * 16u + 4u] = wall_clock64();
+  if (FUSE_BPV != 0 && fuse && leader && !(A.ablate & 2u)) {
     const P p(smem);
     uint8_t* sec = chunk_out + 4u + L.doff[s_a];
     uint8_t* idx = chunk_out + 4u + L.doff[s_b];
     if (!slow) {
-      (void)pal32_rank<RawT, T>(p, sec + 3u);
+      pal32_values<RawT, T>(p, sec + 3u);
       pal32_pack_chunk<RawT, T>(p, col, n, palette_bits(U), idx);
     } else {
       (void)pal32_slow_rank<RawT, T>(p, col, n, first, sec + 3u);
@@ -377,7 +458,9 @@ __global__ __launch_bounds__(T, (T == 1024 ? 4 : 8)) __attribute__((amdgpu_num_s
       sec[2] = (uint8_t)((U >> 8) & 0xffu);  // static_cast<uint16_t>(palette.size()), v5_codec.cpp:464
     }
   }
-  if (section_first) fin_copy(L, slot, chunk_out, wid, n_waves, lane);
+  if (A.trace != nullptr && tid == 0u && leader) A.trace[(size_t)c * 16u + 5u] = wall_clock64();
+  if (section_first && !(A.ablate & 1u)) fin_copy(L, slot, chunk_out, wid, n_waves, lane, A.copy_mode);
+  if (A.trace != nullptr && tid == 0u && leader) A.trace[(size_t)c * 16u + 6u] = wall_clock64();
 }
 
 }  // namespace cldn

@@ -2079,6 +2079,25 @@ static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c
 
 constexpr uint32_t kNoFusedField = 0xffffffffu;
 
+// profiling only: phase stamps of k_finish's leaders (CLDN_HIP_FINISH_TRACE=1), read back by tools/fintrace.py through
+// cldn_hip_debug_finish_trace (not part of include/cloudini_hip.h)
+static unsigned long long* g_fin_trace = nullptr;
+static uint32_t g_fin_trace_chunks = 0u;
+static unsigned long long* stage1_finish_trace_buffer(uint32_t n_chunks) {
+  if (n_chunks > g_fin_trace_chunks) {
+    if (g_fin_trace) (void)hipFree(g_fin_trace);
+    g_fin_trace = nullptr;
+    if (hipMalloc(&g_fin_trace, (size_t)n_chunks * 16u * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    g_fin_trace_chunks = n_chunks;
+  }
+  return g_fin_trace;
+}
+extern "C" __attribute__((visibility("default"))) int cldn_hip_debug_finish_trace(unsigned long long* host_out, uint32_t n_chunks) {
+  if (!g_fin_trace || n_chunks > g_fin_trace_chunks) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  return hipMemcpy(host_out, g_fin_trace, (size_t)n_chunks * 16u * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+
 int stage1_launch_encode(const EncodeLaunch& L) {
   hipError_t e;
   // CLDN_HIP_FINISH (A/B switch): 0 = the round-2 kernels (k_chunk_offsets + k_compact), 1 = k_finish without the fused
@@ -2201,6 +2220,13 @@ int stage1_launch_encode(const EncodeLaunch& L) {
       F.use_ticket = (use_ticket || L.use_ticket) ? 1u : 0u;
       F.test_timeout = L.test_timeout;
       F.order = order;
+      static const uint32_t copy_mode = getenv("CLDN_HIP_FINISH_COPY") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_COPY")) : 0u;  // A/B switch
+      static const uint32_t fin_ablate = getenv("CLDN_HIP_FINISH_ABLATE") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_ABLATE")) : 0u;  // profiling only
+      F.copy_mode = copy_mode;
+      F.trace = nullptr;
+      static const bool fin_trace = getenv("CLDN_HIP_FINISH_TRACE") != nullptr;  // profiling only
+      if (fin_trace) F.trace = stage1_finish_trace_buffer(L.n_chunks);
+      F.ablate = fin_ablate;
       F.chunk_payload = L.chunk_payload;
       F.chunk_dst = L.chunk_dst;
       F.stream_offsets = L.stream_offsets;
@@ -2280,6 +2306,9 @@ int stage1_launch_frame(const FrameLaunch& L) {
   F.use_ticket = L.use_ticket;
   F.test_timeout = L.test_timeout;
   F.order = 0u;
+  F.copy_mode = 0u;
+  F.ablate = 0u;
+  F.trace = nullptr;
   F.chunk_payload = L.chunk_payload;
   F.chunk_dst = L.chunk_dst;
   F.stream_offsets = L.stream_offsets;

@@ -443,6 +443,35 @@ __global__ __launch_bounds__(kS2Threads) void k_section_palette(const DevPlan pl
   }
 }
 
+// 8 consecutive values of a 2- or 4-byte column as raw dwords, loaded WITHOUT a branch (any alignment: gfx950 performs
+// unaligned dwordx4 loads natively). The column buffers end with 64 spare bytes, so a group that starts inside a chunk
+// may run past the chunk's end: the callers ignore those elements. Branch-free loads are what lets the compiler keep
+// several groups in flight (exact s_waitcnt counting, see k_encode_fused).
+template <typename RawT>
+struct Grp8 {
+  uint32_t dw[2 * sizeof(RawT)];
+  __device__ __forceinline__ uint32_t get(int j) const {  // j known at compile time
+    return sizeof(RawT) == 2 ? ((dw[j >> 1] >> ((j & 1) * 16)) & 0xffffu) : dw[j];
+  }
+  __device__ __forceinline__ uint32_t get_dyn(uint32_t j) const {  // run-time j: select chain, no indexed registers
+    const uint32_t di = sizeof(RawT) == 2 ? (j >> 1) : j;
+    uint32_t x = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 2 * sizeof(RawT); ++k) {
+      uint32_t a = dw[k];
+      asm volatile("" : "+v"(a));  // (keeps the chain a chain: folded into an indexed load, the group would move to scratch)
+      x = di == k ? a : x;
+    }
+    return sizeof(RawT) == 2 ? ((x >> ((j & 1u) * 16u)) & 0xffffu) : x;
+  }
+};
+template <typename RawT>
+__device__ __forceinline__ Grp8<RawT> grp8_load(const RawT* col, uint32_t i0) {
+  Grp8<RawT> g;
+  __builtin_memcpy(g.dw, col + i0, 8u * sizeof(RawT));
+  return g;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // k_section_palette32<RawT> (2- and 4-byte fields): same output as k_section_palette, built for few LDS round
 // trips per value and no per-value state in registers. A table word holds key and first-occurrence index
@@ -579,40 +608,63 @@ __device__ __forceinline__ void pal32_pack(const Pal32<RawT>& p, const RawT* col
 // clear + seed + pass 1: afterwards the table holds every distinct value with its first index and misc[0] = their
 // number -- unless it returns false (more than kS2PalCapacity distinct values: pal32_slow_* take over)
 template <typename RawT, int T>
-__device__ __forceinline__ bool pal32_build(const Pal32<RawT>& p, const RawT* col, uint32_t n) {
+__device__ __forceinline__ bool pal32_build(const Pal32<RawT>& p, const RawT* col, uint32_t n, unsigned long long* tr = nullptr) {
   using P = Pal32<RawT>;
   using Word = typename P::Word;
   constexpr uint32_t WPT = kS2Threads / T;
   const uint32_t tid = threadIdx.x;
+  // the seed's values are requested before the table is cleared, all rounds at once (branch-free loads: one memory
+  // latency instead of one per round)
+  uint32_t seedv[4096u / T];
+#pragma unroll
+  for (uint32_t r = 0; r < 4096u / T; ++r) seedv[r] = (uint32_t)col[min(r * T + tid, n - 1u)];
   for (uint32_t s = tid; s < kS2PalSlots; s += T) p.tab[s] = P::kFree;
 #pragma unroll
   for (uint32_t w = 0; w < WPT; ++w) p.bitmap[w * T + tid] = 0u;
   if (tid < 4u) p.misc[tid] = 0u;
   __syncthreads();
+  if (tr != nullptr && tid == 0u) tr[0] = wall_clock64();
   // seed
 #pragma unroll
   for (uint32_t r = 0; r < 4096u / T; ++r) {
     const uint32_t i = r * T + tid;
-    if (i < n) {
-      const uint32_t v = (uint32_t)col[i];
-      p.insert(v, i, p.tab[P::home(v)]);
-    }
+    if (i < n) p.insert(seedv[r], i, p.tab[P::home(seedv[r])]);
   }
   __syncthreads();
-  // pass 1
-  for (uint32_t s = 0; s < 4096u / T; ++s) {
-    const uint32_t i0 = (s * T + tid) * 8u;
-    if (i0 >= n) break;
-    RawT v[8];
-    load8<RawT>(col, i0, n, v);
-    Word w[8];
+  if (tr != nullptr && tid == 0u) tr[1] = wall_clock64();
+  // pass 1: the groups of a batch are requested together (branch-free loads, one memory latency per batch: 8 groups of
+  // 2-byte values or 4 groups of 4-byte values = 32 VGPRs); a group's values that are not settled yet -- rare after
+  // the seed -- go through ONE insert site, picked off a bit mask
+  constexpr uint32_t STEPS = 4096u / T;
+  constexpr uint32_t GB = sizeof(RawT) == 2 ? (STEPS < 8u ? STEPS : 8u) : 4u;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w[j] = p.tab[P::home((uint32_t)v[j])];
+  for (uint32_t b = 0; b < STEPS; b += GB) {
+    Grp8<RawT> g[GB];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t idx = i0 + (uint32_t)j;
-      const bool settled = w[j] != P::kFree && P::key_of(w[j]) == (uint32_t)v[j] && P::low_of(w[j]) <= idx;
-      if (idx < n && !settled) p.insert((uint32_t)v[j], idx, w[j]);
+    for (uint32_t k = 0; k < GB; ++k) {
+      const uint32_t i0 = ((b + k) * T + tid) * 8u;
+      g[k] = grp8_load<RawT>(col, i0 < n ? i0 : 0u);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < GB; ++k) {
+      const uint32_t i0 = ((b + k) * T + tid) * 8u;
+      if (i0 >= n || i0 + 8u <= 4096u) continue;  // (the seed settled the first 4096 values)
+      Word w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = p.tab[P::home(g[k].get(j))];
+      uint32_t todo = 0u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t idx = i0 + (uint32_t)j;
+        const bool settled = w[j] != P::kFree && P::key_of(w[j]) == g[k].get(j) && P::low_of(w[j]) <= idx;
+        todo |= (idx < n && !settled) ? (1u << j) : 0u;
+      }
+      while (todo != 0u) {
+        const uint32_t j = (uint32_t)__builtin_ctz(todo);
+        todo &= todo - 1u;
+        const uint32_t v = g[k].get_dyn(j);
+        p.insert(v, i0 + j, p.tab[P::home(v)]);
+      }
     }
   }
   __syncthreads();
@@ -657,14 +709,35 @@ __device__ __forceinline__ uint32_t pal32_rank(const Pal32<RawT>& p, uint8_t* va
       const uint32_t f = P::low_of(w);
       const uint32_t rk = p.prefix[f >> 5] + (uint32_t)__builtin_popcount(p.bitmap[f >> 5] & ((1u << (f & 31u)) - 1u));
       p.tab[q * T + tid] = (w & ~(Word)0xffffu) | rk;
-      const uint32_t val = P::key_of(w);
-      uint8_t* out = vals_out + (size_t)rk * sizeof(RawT);  // palette value rk
+      if (vals_out != nullptr) {
+        const uint32_t val = P::key_of(w);
+        uint8_t* out = vals_out + (size_t)rk * sizeof(RawT);  // palette value rk
 #pragma unroll
-      for (uint32_t b = 0; b < sizeof(RawT); ++b) out[b] = (uint8_t)(val >> (8u * b));
+        for (uint32_t b = 0; b < sizeof(RawT); ++b) out[b] = (uint8_t)(val >> (8u * b));
+      }
     }
   }
   __syncthreads();
   return U;
+}
+
+// palette values of a table whose words already hold the ranks (pal32_rank with vals_out = nullptr ran before the
+// section's place was known: k_finish ranks while it waits for the sizes of the chunks in front)
+template <typename RawT, int T>
+__device__ __forceinline__ void pal32_values(const Pal32<RawT>& p, uint8_t* vals_out) {
+  using P = Pal32<RawT>;
+  using Word = typename P::Word;
+  const uint32_t tid = threadIdx.x;
+#pragma unroll
+  for (uint32_t q = 0; q < kS2PalSlots / T; ++q) {
+    const Word w = p.tab[q * T + tid];
+    if (w != P::kFree) {
+      const uint32_t val = P::key_of(w);
+      uint8_t* out = vals_out + (size_t)P::low_of(w) * sizeof(RawT);
+#pragma unroll
+      for (uint32_t b = 0; b < sizeof(RawT); ++b) out[b] = (uint8_t)(val >> (8u * b));
+    }
+  }
 }
 
 // pass 3: thread t packs the ranks of its groups of 32 values into `bits` dwords each (appendBitpackedIndexes,
