@@ -271,9 +271,11 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
         // non-temporal: the points are read once, and left out of L2 / Infinity Cache they do not push out the slot
         // and column data this kernel writes for k_finish (same-box A/B, C2: step 0.296 -> 0.288 ms, k_finish -6 %;
         // non-temporal STORES of slots or columns cost what this gains). Scalar loads: the compiler merges them.
+        // Not for the padded layouts (L3 == 4): their integer fields may lie outside the loaded dwords and are then
+        // read from the same lines a second time (Ouster-style 48-byte points: 0.336 -> 0.410 ms with these loads bypassing).
         const float* f = reinterpret_cast<const float*>(a);
 #pragma unroll
-        for (int k = 0; k < LOADW; ++k) rows[r].v[k] = __builtin_nontemporal_load(f + k);
+        for (int k = 0; k < LOADW; ++k) rows[r].v[k] = (L3 != 4) ? __builtin_nontemporal_load(f + k) : f[k];
       } else {
         const uint32_t mis = (uint32_t)((uintptr_t)a & 3u);
         const uint32_t* q = reinterpret_cast<const uint32_t*>(a - mis);

@@ -1867,12 +1867,8 @@ int stage1_configure_kernels() {
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_palette)");
   }
   if (int rc = stage1_configure_decode()) return rc;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_section_delta32<uint16_t>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD32Lds);
-  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_delta32<u16>)");
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_section_delta32<uint32_t>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD32Lds);
-  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_delta32<u32>)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_section_fast), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kD32Lds);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_section_fast)");
   const void* pk32[] = {reinterpret_cast<const void*>(&k_section_palette32<uint16_t, kS2Threads>),
                         reinterpret_cast<const void*>(&k_section_palette32<uint16_t, 512>),
                         reinterpret_cast<const void*>(&k_section_palette32<uint32_t, 512>)};
@@ -2046,15 +2042,14 @@ static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c
   // stream, so that the chunk's payload is one contiguous run of its slot
   const uint32_t append = (L.intra && na == 1u && L.subs == 1u) ? 1u : 0u;
 #define SEC_ARGS(FL) *L.plan, FL, chunks, L.cols, L.modes, slots, L.slot_stride, L.reg_stride, segs, L.segs_per_chunk, L.subs, flags, append
-  if (run16.n) {
-    hipLaunchKernelGGL(k_section_delta32<uint16_t>, dim3(nch, run16.n), dim3(kS2Threads), kD32Lds, stream, SEC_ARGS(run16));
-    hipLaunchKernelGGL(k_section_runs<uint16_t>, dim3(nch, run16.n), dim3(kS2Threads), 0, stream, SEC_ARGS(run16));
+  {
+    SectionFields runs;  // every 2- and 4-byte field that may be DeltaVarint / Rle / DeltaRle somewhere: one launch
+    runs.n = 0u;
+    for (uint32_t k = 0; k < run16.n; ++k) runs.a[runs.n++] = run16.a[k];
+    for (uint32_t k = 0; k < run32.n; ++k) runs.a[runs.n++] = run32.a[k];
+    if (runs.n) hipLaunchKernelGGL(k_section_fast, dim3(nch, runs.n), dim3(kS2Threads), kD32Lds, stream, SEC_ARGS(runs));
   }
-  if (run32.n) {
-    hipLaunchKernelGGL(k_section_delta32<uint32_t>, dim3(nch, run32.n), dim3(kS2Threads), kD32Lds, stream, SEC_ARGS(run32));
-    hipLaunchKernelGGL(k_section_runs<uint32_t>, dim3(nch, run32.n), dim3(kS2Threads), 0, stream, SEC_ARGS(run32));
-  }
-  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_delta32/runs");
+  if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_fast");
   if (pal16.n)
   {
     // 512-thread workgroups (two bitmap words and two groups of 32 values per thread): four of them fit a CU, so a batch

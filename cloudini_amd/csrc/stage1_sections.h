@@ -969,40 +969,42 @@ constexpr uint32_t kD32Ring = 65536;  // >= 8192 values * 5 bytes + 16
 constexpr uint32_t kD32Lds = kD32Ring + 256u;
 
 template <typename RawT>
-__global__ __launch_bounds__(kS2Threads) void k_section_delta32(const DevPlan plan, const SectionFields fl,
-                                                                const ChunkDesc* __restrict__ chunks,
-                                                                const ColumnPtrs cols, const uint8_t* __restrict__ modes,
-                                                                uint8_t* __restrict__ slots, uint64_t slot_stride,
-                                                                uint64_t reg_stride, Seg* __restrict__ segs,
-                                                                uint32_t segs_per_chunk, uint32_t subs,
-                                                                uint8_t* __restrict__ handled_flags, uint32_t append) {
+__device__ __forceinline__ void section_delta32_body(const DevPlan& plan, uint32_t c, uint32_t a, const ChunkDesc& cd, const ColumnPtrs& cols,
+                                                     uint8_t* __restrict__ slots, uint64_t slot_stride, uint64_t reg_stride,
+                                                     Seg* __restrict__ segs, uint32_t segs_per_chunk, uint32_t subs,
+                                                     uint8_t* __restrict__ handled_flags, uint32_t append, uint8_t* smem) {
   static_assert(sizeof(RawT) == 2 || sizeof(RawT) == 4, "differences of at most 33 bits");
   constexpr int T = kS2Threads;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* ring = reinterpret_cast<uint32_t*>(smem);
   uint32_t* wtot = reinterpret_cast<uint32_t*>(smem + kD32Ring);
-  const uint32_t c = blockIdx.x;
-  const uint32_t a = fl.a[blockIdx.y];  // one launch covers every field of this kernel's type (grid.y)
-  const ChunkDesc cd = chunks[c];
-  if (modes[cd.cloud * plan.n_adaptive + a] != 0u) return;
   const uint32_t n = cd.n_points;
   const uint32_t type = plan.adaptive[a].type;
   const RawT* col = reinterpret_cast<const RawT*>(cols.p[a]) + cd.first_point;
   const uint32_t sec_off = append ? segs[(size_t)c * segs_per_chunk].size : (uint32_t)reg_stride + a * kSectionStride;
   uint8_t* dst = slots + (size_t)c * slot_stride + sec_off;
   const uint32_t tid = threadIdx.x;
+  // every value the thread will look at is requested before the ring is cleared (branch-free loads: the four quarters
+  // used to wait for two memory round trips each -- the kernel is bound by exactly that latency)
+  Grp8<RawT> pre[4];
+  RawT pre_prev[4];
+#pragma unroll
+  for (uint32_t q = 0; q < 4u; ++q) {
+    const uint32_t i0 = q * (T * 8u) + threadIdx.x * 8u;
+    pre[q] = grp8_load<RawT>(col, i0 < n ? i0 : 0u);
+    pre_prev[q] = col[(i0 > 0u && i0 < n) ? i0 - 1u : 0u];
+  }
   for (uint32_t i = tid; i < kD32Ring / 16u; i += T) reinterpret_cast<uint4*>(ring)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
 
   uint32_t R = 1u, F = 0u;  // byte 0 = mode 0
+#pragma unroll
   for (uint32_t q = 0; q < 4u; ++q) {
     const uint32_t i0 = q * (T * 8u) + tid * 8u;
     if (q * (T * 8u) >= n) break;
     RawT v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (RawT)0;
-    if (i0 < n) load8<RawT>(col, i0, n, v);
-    int64_t prev = (i0 > 0u && i0 < n) ? int_field_as_i64((uint64_t)col[i0 - 1u], type) : 0;
+    for (int j = 0; j < 8; ++j) v[j] = (RawT)pre[q].get(j);  // (elements behind the chunk's end get length 0 below)
+    int64_t prev = (i0 > 0u && i0 < n) ? int_field_as_i64((uint64_t)pre_prev[q], type) : 0;
     uint32_t w0[8], w1[8], lens = 0u, total = 0u;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1055,21 +1057,13 @@ __global__ __launch_bounds__(kS2Threads) void k_section_delta32(const DevPlan pl
 // the records are written straight to the slot.
 // ---------------------------------------------------------------------------------------------------------
 template <typename RawT>
-__global__ __launch_bounds__(kS2Threads) void k_section_runs(const DevPlan plan, const SectionFields fl,
-                                                             const ChunkDesc* __restrict__ chunks, const ColumnPtrs cols,
-                                                             const uint8_t* __restrict__ modes,
-                                                             uint8_t* __restrict__ slots, uint64_t slot_stride,
-                                                             uint64_t reg_stride, Seg* __restrict__ segs,
-                                                             uint32_t segs_per_chunk, uint32_t subs,
-                                                             uint8_t* __restrict__ handled_flags, uint32_t append) {
+__device__ __forceinline__ void section_runs_body(const DevPlan& plan, uint32_t c, uint32_t a, const ChunkDesc& cd, uint32_t mode,
+                                                  const ColumnPtrs& cols, uint8_t* __restrict__ slots, uint64_t slot_stride,
+                                                  uint64_t reg_stride, Seg* __restrict__ segs, uint32_t segs_per_chunk, uint32_t subs,
+                                                  uint8_t* __restrict__ handled_flags, uint32_t append, uint8_t* smem) {
   static_assert(sizeof(RawT) == 2 || sizeof(RawT) == 4, "differences of at most 33 bits");
   constexpr int T = kS2Threads;
-  __shared__ uint32_t wtot[64];
-  const uint32_t c = blockIdx.x;
-  const uint32_t a = fl.a[blockIdx.y];  // one launch covers every field of this kernel's type (grid.y)
-  const ChunkDesc cd = chunks[c];
-  const uint32_t mode = modes[cd.cloud * plan.n_adaptive + a];
-  if (mode != 2u && mode != 3u) return;
+  uint32_t* wtot = reinterpret_cast<uint32_t*>(smem);  // [64]
   const bool delta = (mode == 3u);
   const uint32_t n = cd.n_points;
   const uint32_t type = plan.adaptive[a].type;
@@ -1085,18 +1079,19 @@ __global__ __launch_bounds__(kS2Threads) void k_section_runs(const DevPlan plan,
   uint64_t key[32];
   uint64_t key_before = 0u;
   {
+    // the thread's 32 values and the two in front of them: six branch-free loads in flight together
     RawT v[32];
+    Grp8<RawT> g8[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      RawT t8[8];
+    for (uint32_t g = 0; g < 4u; ++g) g8[g] = grp8_load<RawT>(col, i0 + 8u * g < n ? i0 + 8u * g : 0u);
+    const RawT pm1r = col[(cnt && i0 >= 1u) ? i0 - 1u : 0u];
+    const RawT pm2r = col[(cnt && i0 >= 2u) ? i0 - 2u : 0u];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t8[j] = (RawT)0;
-      if (i0 + 8u * g < n) load8<RawT>(col, i0 + 8u * g, n, t8);
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[8 * g + j] = t8[j];
-    }
-    const RawT pm1 = (cnt && i0 >= 1u) ? col[i0 - 1u] : (RawT)0;
-    const RawT pm2 = (cnt && i0 >= 2u) ? col[i0 - 2u] : (RawT)0;
+      for (int j = 0; j < 8; ++j) v[8 * g + j] = (i0 + (uint32_t)(8 * g + j) < n) ? (RawT)g8[g].get(j) : (RawT)0;
+    const RawT pm1 = (cnt && i0 >= 1u) ? pm1r : (RawT)0;
+    const RawT pm2 = (cnt && i0 >= 2u) ? pm2r : (RawT)0;
     if (delta) {
       int64_t prev = i0 >= 1u ? as64(pm1) : 0;
       key_before = (uint64_t)prev - (uint64_t)(i0 >= 2u ? as64(pm2) : 0);
@@ -1169,6 +1164,34 @@ __global__ __launch_bounds__(kS2Threads) void k_section_runs(const DevPlan plan,
     sg.size = 0u;
     segs[(size_t)c * segs_per_chunk + subs + 1u + 2u * a] = sg;
     handled_flags[(size_t)c * plan.n_adaptive + a] = 1u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_section_fast: ONE launch for the DeltaVarint / Rle / DeltaRle sections of every 2- and 4-byte field (grid.y = field).
+// Rounds 2-3 launched k_section_delta32 and k_section_runs per width -- four launches in a row for a sensor layout, in
+// each of which every (chunk, field) whose mode belonged to the other kernel cost a workgroup that returned at once. The
+// mode a cloud committed picks the body here, so every workgroup of the launch has work and the fields' workgroups share
+// the chip (1024-thread workgroups: two per CU whatever their LDS).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kS2Threads) void k_section_fast(const DevPlan plan, const SectionFields fl,
+                                                             const ChunkDesc* __restrict__ chunks, const ColumnPtrs cols,
+                                                             const uint8_t* __restrict__ modes, uint8_t* __restrict__ slots,
+                                                             uint64_t slot_stride, uint64_t reg_stride, Seg* __restrict__ segs,
+                                                             uint32_t segs_per_chunk, uint32_t subs,
+                                                             uint8_t* __restrict__ handled_flags, uint32_t append) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t c = blockIdx.x;
+  const uint32_t a = fl.a[blockIdx.y];
+  const ChunkDesc cd = chunks[c];
+  const uint32_t mode = modes[cd.cloud * plan.n_adaptive + a];  // (uniform)
+  const bool wide = plan.adaptive[a].bpv == 4u;
+  if (mode == 0u) {
+    if (wide) section_delta32_body<uint32_t>(plan, c, a, cd, cols, slots, slot_stride, reg_stride, segs, segs_per_chunk, subs, handled_flags, append, smem);
+    else section_delta32_body<uint16_t>(plan, c, a, cd, cols, slots, slot_stride, reg_stride, segs, segs_per_chunk, subs, handled_flags, append, smem);
+  } else if (mode == 2u || mode == 3u) {
+    if (wide) section_runs_body<uint32_t>(plan, c, a, cd, mode, cols, slots, slot_stride, reg_stride, segs, segs_per_chunk, subs, handled_flags, append, smem);
+    else section_runs_body<uint16_t>(plan, c, a, cd, mode, cols, slots, slot_stride, reg_stride, segs, segs_per_chunk, subs, handled_flags, append, smem);
   }
 }
 

@@ -1,0 +1,4 @@
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r4
+timeout 600 python tools/lz4bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4/t28_lz4.txt
+bash tools/prof_any.sh r4_lz4 python /root/repo/tools/lz4bench.py 2>&1 | grep "k_lz4" | cut -c1-150
