@@ -1,0 +1,3 @@
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r4
+CLDN_FUZZ_EXTRA=5000 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x 2>&1 | tail -4 | tee gpurun_out/r4/fuzz_campaign.txt
