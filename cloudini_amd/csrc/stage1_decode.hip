@@ -120,6 +120,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     // it hands irregular chunks back (reg_end = kDecRedo) and k_decode_varint redoes only those
     static const bool no_points = getenv("CLDN_HIP_NO_POINT_DECODE") != nullptr;  // A/B switch
     const bool points_kernel = fast && !no_points && all_qf32 && (P.n_ops == 3u || P.n_ops == 4u) && P.n_gorilla == 0u;
+    bool stream_cols = false;  // the stream kernel stores the integer fields with the points (columns in front of it)
     bool many_used = false;  // the point kernel merged the columns of 3..8 integer channels (chunks it left: the old section kernels)
     if (points_kernel) {
       // NF: Palette sections the launch can fold into the point pass (sizes its LDS)
@@ -144,14 +145,14 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
         DecChunk* dsec = reinterpret_cast<DecChunk*>(L.dsec);
         hipLaunchKernelGGL(k_section_offsets, dim3(L.n_chunks), dim3(kSoThreads), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), L.n_chunks, (const uint32_t*)L.reg_end_pre, dsec, L.secs_ok, L.done_cnt);
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.n_chunks, (const uint32_t*)L.reg_end_pre, dsec, L.secs_ok, L.done_cnt, (const uint8_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_offsets");
         hipLaunchKernelGGL(k_sections_w, dim3(L.n_chunks, P.n_adaptive), dim3(kSwsThreads), 0, L.stream, P, L.streams,
                            (const DecChunk*)dsec, L.n_chunks, L.out, L.done_cnt, 1u, dcols);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_w");
         const DevPlan S = sections_plan(P, true);
         hipLaunchKernelGGL((k_decode_stream_w<16, 0>), dim3(L.n_chunks, P.n_adaptive), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, S,
-                           L.streams, (const DecChunk*)dsec, (uint8_t*)nullptr, L.done_cnt, L.status, (const uint32_t*)nullptr, L.n_chunks, dcols);
+                           L.streams, (const DecChunk*)dsec, (uint8_t*)nullptr, L.done_cnt, L.status, (const uint32_t*)nullptr, L.n_chunks, dcols, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (sections)");
         hipLaunchKernelGGL(k_sections_done, dim3((L.n_chunks + 255u) / 256u), dim3(256), 0, L.stream, L.n_chunks, P.n_adaptive,
                            (const uint8_t*)L.secs_ok, (const uint32_t*)L.done_cnt, L.sec_cols, L.status, 0u);
@@ -261,14 +262,14 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       }
       if (form) {
         hipLaunchKernelGGL((k_decode_stream_w<12, 1>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, true>::kTotal), L.stream, P,
-                           L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{});
+                           L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{}, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (form)");
       } else if (stream_ok) {
         // round 4: the barrier-free stream kernel reads the token ends from the bitmap (chunks it finds irregular go to the
         // serial decoder, like the chunks k_mark_token_ends gave up on)
         hipLaunchKernelGGL((k_decode_stream_w<16, false>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status,
-                           bitmap ? (const uint32_t*)L.token_ends : (const uint32_t*)nullptr, 0u, DecColumns{});
+                           bitmap ? (const uint32_t*)L.token_ends : (const uint32_t*)nullptr, 0u, DecColumns{}, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (mixed)");
       } else {
         hipLaunchKernelGGL((k_decode_varint<8, true>), dim3(L.n_chunks), dim3(kDvThreads), (Dv2Lds<8, true, 8>::kTotal),
@@ -282,9 +283,42 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       // the tile kernel behind it only redoes the chunks it hands back. CLDN_HIP_NO_STREAM_KERNEL=1: A/B switch
       static const bool no_stream = getenv("CLDN_HIP_NO_STREAM_KERNEL") != nullptr;
       const bool stream_kernel = !no_stream && !points_kernel && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes;
-      if (stream_kernel) {
+      // round 4: the integer fields of such a stream (1..8 of 2 / 4 bytes) go to dense columns FIRST -- the sections are
+      // found by counting token ends (k_locate_sections), sized and decoded side by side -- and the stream kernel stores them
+      // with the points: every point is written once (DDS layout with 1 us stamps: the ring column behind the points cost
+      // 0.17 of 0.74 ms). Chunks whose sections did not all arrive take the passes below. CLDN_HIP_NO_STREAM_COLS=1: A/B switch
+      static const bool no_stream_cols = getenv("CLDN_HIP_NO_STREAM_COLS") != nullptr;
+      stream_cols = stream_kernel && !no_stream_cols && L.uses_v5 && P.n_adaptive >= 1u && P.n_adaptive <= kSoMaxFields && L.dsec != nullptr &&
+                    L.sec_cols != nullptr && L.reg_end_pre != nullptr && L.slices_done != nullptr;
+      for (uint32_t a = 0; a < P.n_adaptive && stream_cols; ++a) stream_cols = P.adaptive[a].bpv <= 4u && L.cols[a] != nullptr;
+      if (stream_cols) {
+        DecColumns dcols = {};
+        for (uint32_t a = 0; a < 8u; ++a) dcols.p[a] = L.cols[a];
+        hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
+        DecChunk* dsec = reinterpret_cast<DecChunk*>(L.dsec);
+        hipLaunchKernelGGL(k_section_offsets, dim3(L.n_chunks), dim3(kSoThreads), 0, L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.n_chunks, (const uint32_t*)L.reg_end_pre, dsec, L.secs_ok, L.done_cnt, (const uint8_t*)nullptr);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_offsets");
+        hipLaunchKernelGGL(k_sections_w, dim3(L.n_chunks, P.n_adaptive), dim3(kSwsThreads), 0, L.stream, P, L.streams,
+                           (const DecChunk*)dsec, L.n_chunks, L.out, L.done_cnt, 1u, dcols);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_w");
+        const DevPlan S = sections_plan(P, true);
+        hipLaunchKernelGGL((k_decode_stream_w<16, 0>), dim3(L.n_chunks, P.n_adaptive), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, S,
+                           L.streams, (const DecChunk*)dsec, (uint8_t*)nullptr, L.done_cnt, L.status, (const uint32_t*)nullptr, L.n_chunks, dcols,
+                           (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (sections)");
+        hipLaunchKernelGGL(k_sections_done, dim3((L.n_chunks + 255u) / 256u), dim3(256), 0, L.stream, L.n_chunks, P.n_adaptive,
+                           (const uint8_t*)L.secs_ok, (const uint32_t*)L.done_cnt, L.sec_cols, L.status, 0u);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_done");
         hipLaunchKernelGGL((k_decode_stream_w<16, false>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{});
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, dcols,
+                           (const uint8_t*)L.sec_cols, (const uint32_t*)L.reg_end_pre, L.sec_done);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w");
+      } else if (stream_kernel) {
+        hipLaunchKernelGGL((k_decode_stream_w<16, false>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{}, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w");
       }
       const uint32_t redo_only = (points_kernel || stream_kernel) ? 1u : 0u;
@@ -310,7 +344,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       }
       if (ok) {
         hipLaunchKernelGGL((k_decode_stream_w<12, 2>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, true>::kTotal), L.stream, P,
-                           L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{});
+                           L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{}, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (gorilla)");
         fast = true;  // from here on like any stream the parallel kernels have taken
       }
@@ -324,7 +358,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     if (sections_w) {
       DecChunk* dsec = reinterpret_cast<DecChunk*>(L.dsec);
       hipLaunchKernelGGL(k_section_offsets, dim3(L.n_chunks), dim3(kSoThreads), 0, L.stream, P, L.streams,
-                         reinterpret_cast<const DecChunk*>(L.chunks), L.n_chunks, (const uint32_t*)L.reg_end, dsec, L.secs_ok, L.done_cnt);
+                         reinterpret_cast<const DecChunk*>(L.chunks), L.n_chunks, (const uint32_t*)L.reg_end, dsec, L.secs_ok, L.done_cnt, stream_cols ? (const uint8_t*)L.sec_done : (const uint8_t*)nullptr);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_offsets");
       hipLaunchKernelGGL(k_sections_w, dim3(L.n_chunks, P.n_adaptive), dim3(kSwsThreads), 0, L.stream, P, L.streams,
                          (const DecChunk*)dsec, L.n_chunks, L.out, L.done_cnt, 0u, DecColumns{});
@@ -332,10 +366,10 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       // DeltaVarint sections: streams of n tokens of one integer op -> the stream kernel, row a of the grid = field a
       const DevPlan S = sections_plan(P, false);
       hipLaunchKernelGGL((k_decode_stream_w<16, 0>), dim3(L.n_chunks, P.n_adaptive), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, S,
-                         L.streams, (const DecChunk*)dsec, L.out, L.done_cnt, L.status, (const uint32_t*)nullptr, L.n_chunks, DecColumns{});
+                         L.streams, (const DecChunk*)dsec, L.out, L.done_cnt, L.status, (const uint32_t*)nullptr, L.n_chunks, DecColumns{}, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (sections)");
       hipLaunchKernelGGL(k_sections_done, dim3((L.n_chunks + 255u) / 256u), dim3(256), 0, L.stream, L.n_chunks, P.n_adaptive,
-                         (const uint8_t*)L.secs_ok, (const uint32_t*)L.done_cnt, L.sec_done, L.status, 1u);
+                         (const uint8_t*)L.secs_ok, (const uint32_t*)L.done_cnt, L.sec_done, L.status, stream_cols ? 2u : 1u);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_done");
       hipLaunchKernelGGL(k_decode_sections, dim3(L.n_chunks), dim3(kDvThreads), (DecSecLds::kTotal), L.stream, P, L.streams,
                          reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status);

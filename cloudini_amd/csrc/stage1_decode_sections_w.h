@@ -62,7 +62,8 @@ __device__ __forceinline__ uint32_t so_nth_end(const uint8_t* __restrict__ src, 
 __global__ __launch_bounds__(kSoThreads) void k_section_offsets(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                                 const DecChunk* __restrict__ chunks, uint32_t n_chunks,
                                                                 const uint32_t* __restrict__ reg_end, DecChunk* __restrict__ dsec,
-                                                                uint8_t* __restrict__ secs_ok, uint32_t* __restrict__ done_cnt) {
+                                                                uint8_t* __restrict__ secs_ok, uint32_t* __restrict__ done_cnt,
+                                                                const uint8_t* __restrict__ merged) {
   __shared__ uint32_t sh[48];
   __shared__ __attribute__((aligned(16))) uint8_t stage[kSoRleStage + 16u];
   const uint32_t c = blockIdx.x;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(kSoThreads) void k_section_offsets(const DevPlan pl
     dsec[(size_t)a * n_chunks + c] = z;
   }
   if (!dc.valid || na == 0u || na > kSoMaxFields) return;
+  if (merged != nullptr && merged[c] == 2u) return;  // the stream kernel wrote the chunk's integer fields with its points
   uint32_t off = reg_end[c];
   if (off == kDecRedo || off > dc.src_size) return;
   const uint8_t* src = streams + dc.src_off;
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(256) void k_sections_done(uint32_t n_chunks, uint32
   const uint32_t c = blockIdx.x * 256u + threadIdx.x;
   if (c >= n_chunks) return;
   const bool ok = secs_ok[c] != 0u && done_cnt[c] == n_adaptive;
+  if (count_stat >= 2u && sec_done[c] == 2u) return;  // (count_stat 2: chunks the stream kernel merged stay marked)
   sec_done[c] = ok ? 1u : 0u;  // (column mode: this is the point kernel's sec_cols flag, which does the counting itself)
   if (ok && count_stat) atomicAdd(&status[kStatFastSections], 1u);
 }

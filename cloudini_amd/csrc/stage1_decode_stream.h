@@ -208,7 +208,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
                                                              const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
                                                              uint32_t* __restrict__ reg_end, uint32_t* __restrict__ status,
                                                              const uint32_t* __restrict__ token_ends, uint32_t sect_chunks,
-                                                             const DecColumns sect_cols) {
+                                                             const DecColumns sect_cols, const uint8_t* __restrict__ col_flags,
+                                                             const uint32_t* __restrict__ reg_end_pre, uint8_t* __restrict__ sec_done) {
   constexpr bool FORM = MODE != 0;
   constexpr bool GOR = MODE == 2;
   using L = SwLds<NW, FORM>;
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const DecChunk dc = chunks[sect ? (size_t)blockIdx.y * sect_chunks + c : (size_t)c];
+  if (!sect && sec_done != nullptr && tid == 0) sec_done[c] = 0u;  // (set again at the end; nothing stale survives an early return)
   if (!dc.valid) return;
   if (sect && dc.valid != 1u) return;  // another mode: k_sections_w
   if (!sect && token_ends != nullptr && reg_end[c] == kDecRedo) return;  // k_mark_token_ends found the stream irregular
@@ -241,6 +243,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   const uint32_t step = sect_to_cols ? (uint32_t)plan.ops[ob].size : plan.point_step;
   uint8_t* base = sect_to_cols ? const_cast<uint8_t*>(sect_cols.p[ob]) + (size_t)dc.first_point * step : out + (size_t)dc.first_point * step;
   const uint32_t target = n * n_ops;
+  // COLUMN MERGE (regular mode, col_flags != NULL): the chunk's integer fields were decoded into dense columns in front of
+  // this launch (sect_cols, flag per chunk) -- every point then leaves complete, no second pass over the cloud. What the
+  // columns were read from is checked at the end: the sections must begin where this stream turns out to end.
+  const bool use_cols = !sect && col_flags != nullptr && col_flags[c] != 0u && plan.n_adaptive != 0u && plan.n_adaptive <= 8u;  // (uniform)
+  const uint32_t n_cols = use_cols ? plan.n_adaptive : 0u;
   if (!sect && (n_ops == 0u || n == 0u)) {  // no per-point encoder (integer fields only): the sections begin at once
     if (tid == 0) {
       reg_end[c] = 0u;
@@ -916,6 +923,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
           }
         }
       });
+      if (n_cols != 0u) {  // (uniform) the point's column values: all requested before the first one is stored
+        const uint32_t q = q_first + (have ? j : 0u);
+        uint32_t cv[8];
+#pragma unroll
+        for (uint32_t a = 0; a < 8u; ++a) {
+          cv[a] = 0u;
+          if (a < n_cols) {
+            const uint32_t f_bpv = plan.adaptive[a].bpv;
+            const uint8_t* colp = sect_cols.p[a] + (size_t)dc.first_point * f_bpv;
+            cv[a] = f_bpv == 2u ? (uint32_t)reinterpret_cast<const uint16_t*>(colp)[q] : reinterpret_cast<const uint32_t*>(colp)[q];
+          }
+        }
+#pragma unroll
+        for (uint32_t a = 0; a < 8u; ++a) {
+          if (a < n_cols && have) st_raw(pt + plan.adaptive[a].offset, cv[a], plan.adaptive[a].bpv);
+        }
+      }
     }
     wp_wave_sync();
   }
@@ -932,6 +956,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
     } else {
       reg_end[c] = redo ? kDecRedo : pos;
       if (!redo) atomicAdd(&status[kStatFastRegular], 1u);
+      if (sec_done != nullptr) {  // like k_decode_points_w: 2 = the sections went out with the points
+        const bool merged = !redo && use_cols && reg_end_pre != nullptr && reg_end_pre[c] == pos;
+        sec_done[c] = merged ? 2u : 0u;
+        if (merged) atomicAdd(&status[kStatFastSections], 1u);
+      }
     }
   }
 }

@@ -46,6 +46,8 @@ layouts["xyzi_f32_lossless (EncodingOptions::LOSSLESS: XOR-coded floats)"] = (
     [("x", 0, F.FLOAT32, None), ("y", 4, F.FLOAT32, None), ("z", 8, F.FLOAT32, None), ("intensity", 12, F.FLOAT32, None)], 16,
     {"x": p[:, 0], "y": p[:, 1], "z": p[:, 2], "intensity": inten})
 for name, (fields, step, cols) in layouts.items():
+    if os.environ.get("SCHEMABENCH_ONLY") and os.environ["SCHEMABENCH_ONLY"] not in name:
+        continue
     info = cases.make_info(fields, step, n, enc=EncodingOptions.LOSSLESS) if "lossless" in name else cases.make_info(fields, step, n)
     data = cases.pack(info, cols, n)
     n_clouds = 16
