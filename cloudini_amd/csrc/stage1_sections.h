@@ -8,6 +8,12 @@
 //                             (64-bit CAS on the key, atomicMin on the first-occurrence index), first-occurrence
 //                             ranks from ONE block-wide scan, 32 indexes per thread bit-packed into `bits` dwords.
 #pragma once
+// values of a chunk the Palette build inserts one per thread and round, in index order, before the blocked pass (same-box A/B of
+// k_finish on C2, 4096 / 2048 / 1024: 117.8 / 109.4 / 110.5 us -- the seed's compare-and-swaps contend for the few slots a
+// palette-coded field has; tools/dev/variants.sh stage1_kernels CLDN_PAL_SEED ...)
+#ifndef CLDN_PAL_SEED
+#define CLDN_PAL_SEED 2048u
+#endif
 
 namespace cldn {
 
@@ -477,7 +483,7 @@ __device__ __forceinline__ Grp8<RawT> grp8_load(const RawT* col, uint32_t i0) {
 // trips per value and no per-value state in registers. A table word holds key and first-occurrence index
 // together (key << SHIFT | index, all-ones = free): claiming is a CAS, lowering the index an atomicMin on the
 // same word; once the ranks are known the index is replaced by the palette rank.
-//   seed    the chunk's first 4 * T values in index order, one per thread and round: palette-coded fields have
+//   seed    the chunk's first CLDN_PAL_SEED (2048) values in index order, one per thread and round: palette-coded fields have
 //           few distinct values, so afterwards (nearly) every key sits at its true first index
 //   pass 1  all values, 8 per thread and step; the home words of the 8 are read together and the CAS / probe /
 //           atomicMin path runs only for new keys or lower indexes
@@ -615,9 +621,9 @@ __device__ __forceinline__ bool pal32_build(const Pal32<RawT>& p, const RawT* co
   const uint32_t tid = threadIdx.x;
   // the seed's values are requested before the table is cleared, all rounds at once (branch-free loads: one memory
   // latency instead of one per round)
-  uint32_t seedv[4096u / T];
+  uint32_t seedv[CLDN_PAL_SEED / T];
 #pragma unroll
-  for (uint32_t r = 0; r < 4096u / T; ++r) seedv[r] = (uint32_t)col[min(r * T + tid, n - 1u)];
+  for (uint32_t r = 0; r < CLDN_PAL_SEED / T; ++r) seedv[r] = (uint32_t)col[min(r * T + tid, n - 1u)];
   for (uint32_t s = tid; s < kS2PalSlots; s += T) p.tab[s] = P::kFree;
 #pragma unroll
   for (uint32_t w = 0; w < WPT; ++w) p.bitmap[w * T + tid] = 0u;
@@ -626,7 +632,7 @@ __device__ __forceinline__ bool pal32_build(const Pal32<RawT>& p, const RawT* co
   if (tr != nullptr && tid == 0u) tr[0] = wall_clock64();
   // seed
 #pragma unroll
-  for (uint32_t r = 0; r < 4096u / T; ++r) {
+  for (uint32_t r = 0; r < CLDN_PAL_SEED / T; ++r) {
     const uint32_t i = r * T + tid;
     if (i < n) p.insert(seedv[r], i, p.tab[P::home(seedv[r])]);
   }
@@ -648,7 +654,7 @@ __device__ __forceinline__ bool pal32_build(const Pal32<RawT>& p, const RawT* co
 #pragma unroll
     for (uint32_t k = 0; k < GB; ++k) {
       const uint32_t i0 = ((b + k) * T + tid) * 8u;
-      if (i0 >= n || i0 + 8u <= 4096u) continue;  // (the seed settled the first 4096 values)
+      if (i0 >= n || i0 + 8u <= CLDN_PAL_SEED) continue;  // (the seed settled the first CLDN_PAL_SEED values)
       Word w[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) w[j] = p.tab[P::home(g[k].get(j))];
