@@ -270,13 +270,45 @@ __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan,
   uint32_t cnt = 0u;
   uint32_t step_cnt = 0u;  // lane s: my count after step s (steps 0..63; the walk below starts at the last such step)
   uint32_t it = 0u;
-  for (uint32_t o0 = w0; o0 < w1; o0 += 4096u, ++it) {  // four 16-byte units per lane, all loads before the first use
-    uint32_t b[4][4];
+  // Steps of 4 KiB, four 16-byte units per lane. The loads carry no branch (a unit that begins behind my part reads my part's
+  // first unit and counts nothing; the payload's last, partial unit is the one load that checks its bytes) and the NEXT step's
+  // units are requested before this step's are counted: the loop used to wait for memory once per step (C3: 51 us for 102 MB).
+  auto step_loads = [&](uint32_t o0, uint32_t (&b)[4][4]) __attribute__((always_inline)) {
 #pragma unroll
     for (uint32_t u = 0; u < 4u; ++u) {
       const uint32_t o = o0 + u * 1024u + lane * 16u;
-      b[u][0] = b[u][1] = b[u][2] = b[u][3] = 0xffffffffu;
-      if (o < w1) fp_load16u(src, src_size, o, b[u]);
+      const bool whole = o + 16u <= w1;      // (w1 <= src_size)
+      uint4 w;
+      __builtin_memcpy(&w, src + (whole ? o : w0), 16);  // w0 + 16 <= w1 whenever a whole unit exists; else the tail path below
+      b[u][0] = whole ? w.x : 0xffffffffu;
+      b[u][1] = whole ? w.y : 0xffffffffu;
+      b[u][2] = whole ? w.z : 0xffffffffu;
+      b[u][3] = whole ? w.w : 0xffffffffu;
+    }
+  };
+  const bool any_whole = w0 + 16u <= w1;  // (uniform) my part holds at least one whole unit
+  uint32_t nb[4][4];
+  if (any_whole) step_loads(w0, nb);
+  for (uint32_t o0 = w0; o0 < w1; o0 += 4096u, ++it) {
+    uint32_t b[4][4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) b[u][k] = any_whole ? nb[u][k] : 0xffffffffu;
+    if (any_whole && o0 + 4096u < w1) step_loads(o0 + 4096u, nb);  // (uniform)
+    // the part's last, partial unit (only the payload's end is not a multiple of 16): its lane reads it byte-safe
+    if (o0 + 4096u >= w1 && (w1 & 15u) != 0u) {  // (uniform) last step of a part that ends inside a unit
+      const uint32_t ot = w0 + ((w1 - w0) & ~15u);  // the partial unit's offset
+      const uint32_t rel = ot - o0;
+      if (lane == ((rel & 1023u) >> 4)) {
+        uint32_t t[4];
+        fp_load16(src, src_size, ot, t);
+        const uint32_t u = rel >> 10;
+#pragma unroll
+        for (uint32_t uu = 0; uu < 4u; ++uu)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) b[uu][k] = uu == u ? t[k] : b[uu][k];
+      }
     }
 #pragma unroll
     for (uint32_t u = 0; u < 4u; ++u)
