@@ -1,0 +1,555 @@
+// MCAP container reader / writer and the bag converter on top of the batched transcoder (include/cloudini_amd/mcap_io.hpp).
+// Record layouts follow the published specification (https://mcap.dev/spec): every record is [opcode u8][length u64][body],
+// strings are [u32 length][bytes], maps are [u32 byte length]([string key][string value])*, all little endian.
+#include "cloudini_amd/mcap_io.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+extern "C" {
+size_t ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
+size_t ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);
+size_t ZSTD_compressBound(size_t srcSize);
+unsigned ZSTD_isError(size_t code);
+// LZ4 frame format (liblz4): MCAP's "lz4" chunks are frames, not blocks
+size_t LZ4F_compressFrameBound(size_t srcSize, const void* preferences);
+size_t LZ4F_compressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const void* preferences);
+unsigned LZ4F_isError(size_t code);
+size_t LZ4F_createDecompressionContext(void** ctx, unsigned version);
+size_t LZ4F_freeDecompressionContext(void* ctx);
+size_t LZ4F_decompress(void* ctx, void* dst, size_t* dstSize, const void* src, size_t* srcSize, const void* options);
+}
+
+namespace cloudini_amd {
+
+const char* const kPointCloud2SchemaName = "sensor_msgs/msg/PointCloud2";
+const char* const kCompressedPointCloud2SchemaName = "point_cloud_interfaces/msg/CompressedPointCloud2";
+
+#define CLDN_MSG_SEP "================================================================================\n"
+#define CLDN_MSG_COMMON                                                                                              \
+  CLDN_MSG_SEP "MSG: sensor_msgs/PointField\n"                                                                       \
+               "uint8 INT8=1\nuint8 UINT8=2\nuint8 INT16=3\nuint8 UINT16=4\nuint8 INT32=5\nuint8 UINT32=6\n"         \
+               "uint8 FLOAT32=7\nuint8 FLOAT64=8\nstring name\nuint32 offset\nuint8 datatype\nuint32 count\n"        \
+  CLDN_MSG_SEP "MSG: std_msgs/Header\nbuiltin_interfaces/Time stamp\nstring frame_id\n"                              \
+  CLDN_MSG_SEP "MSG: builtin_interfaces/Time\nint32 sec\nuint32 nanosec\n"
+// (field lines of the ROS 2 definitions without their comments: the reference embeds the packages' .msg files verbatim)
+const char* const kPointCloud2SchemaText =
+    "std_msgs/Header header\nuint32 height\nuint32 width\nsensor_msgs/PointField[] fields\nbool is_bigendian\n"
+    "uint32 point_step\nuint32 row_step\nuint8[] data\nbool is_dense\n" CLDN_MSG_COMMON;
+const char* const kCompressedPointCloud2SchemaText =
+    "std_msgs/Header header\nuint32 height\nuint32 width\nsensor_msgs/PointField[] fields\nbool is_bigendian\n"
+    "uint32 point_step\nuint32 row_step\nuint8[] compressed_data\nbool is_dense\nstring format\n" CLDN_MSG_COMMON;
+
+namespace {
+
+constexpr uint8_t kMagic[8] = {0x89, 'M', 'C', 'A', 'P', 0x30, '\r', '\n'};
+enum : uint8_t {
+  OP_HEADER = 0x01, OP_FOOTER = 0x02, OP_SCHEMA = 0x03, OP_CHANNEL = 0x04, OP_MESSAGE = 0x05, OP_CHUNK = 0x06,
+  OP_MESSAGE_INDEX = 0x07, OP_CHUNK_INDEX = 0x08, OP_ATTACHMENT = 0x09, OP_ATTACHMENT_INDEX = 0x0A, OP_STATISTICS = 0x0B,
+  OP_METADATA = 0x0C, OP_METADATA_INDEX = 0x0D, OP_SUMMARY_OFFSET = 0x0E, OP_DATA_END = 0x0F
+};
+
+[[noreturn]] void bad(const std::string& what) { throw std::runtime_error("MCAP: " + what); }
+
+// ---- little-endian cursor over a record body
+struct Cur {
+  const uint8_t* p;
+  const uint8_t* end;
+  void need(size_t n) const {
+    if ((size_t)(end - p) < n) bad("record ends inside a field");
+  }
+  uint8_t u8() { need(1); return *p++; }
+  uint16_t u16() { need(2); uint16_t v; std::memcpy(&v, p, 2); p += 2; return v; }
+  uint32_t u32() { need(4); uint32_t v; std::memcpy(&v, p, 4); p += 4; return v; }
+  uint64_t u64() { need(8); uint64_t v; std::memcpy(&v, p, 8); p += 8; return v; }
+  std::string str() {
+    const uint32_t n = u32();
+    need(n);
+    std::string s(reinterpret_cast<const char*>(p), n);
+    p += n;
+    return s;
+  }
+  std::vector<std::pair<std::string, std::string>> map() {
+    const uint32_t bytes = u32();
+    need(bytes);
+    Cur m{p, p + bytes};
+    std::vector<std::pair<std::string, std::string>> out;
+    while (m.p < m.end) {
+      std::string k = m.str();
+      std::string v = m.str();
+      out.emplace_back(std::move(k), std::move(v));
+    }
+    p += bytes;
+    return out;
+  }
+};
+
+// ---- record builder
+struct Rec {
+  std::vector<uint8_t> b;
+  explicit Rec(uint8_t op) : b(9, 0) { b[0] = op; }
+  void raw(const void* d, size_t n) { b.insert(b.end(), static_cast<const uint8_t*>(d), static_cast<const uint8_t*>(d) + n); }
+  void u8(uint8_t v) { b.push_back(v); }
+  void u16(uint16_t v) { raw(&v, 2); }
+  void u32(uint32_t v) { raw(&v, 4); }
+  void u64(uint64_t v) { raw(&v, 8); }
+  void str(const std::string& s) { u32((uint32_t)s.size()); raw(s.data(), s.size()); }
+  void map(const std::vector<std::pair<std::string, std::string>>& m) {
+    size_t bytes = 0;
+    for (const auto& kv : m) bytes += 8 + kv.first.size() + kv.second.size();
+    u32((uint32_t)bytes);
+    for (const auto& kv : m) { str(kv.first); str(kv.second); }
+  }
+  std::vector<uint8_t>& done() {
+    const uint64_t len = b.size() - 9;
+    std::memcpy(&b[1], &len, 8);
+    return b;
+  }
+};
+
+std::vector<uint8_t> readFile(const std::string& path) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) bad("cannot open " + path);
+  std::vector<uint8_t> v;
+  if (std::fseek(f, 0, SEEK_END) == 0) {
+    const long n = std::ftell(f);
+    std::rewind(f);
+    if (n > 0) {
+      v.resize((size_t)n);
+      if (std::fread(v.data(), 1, v.size(), f) != v.size()) { std::fclose(f); bad("short read of " + path); }
+    }
+  }
+  std::fclose(f);
+  return v;
+}
+
+std::vector<uint8_t> lz4FrameDecompress(const uint8_t* src, size_t n, size_t expect) {
+  void* ctx = nullptr;
+  if (LZ4F_isError(LZ4F_createDecompressionContext(&ctx, 100))) bad("LZ4F context");
+  std::vector<uint8_t> out(expect);
+  size_t done = 0, at = 0;
+  while (at < n) {
+    size_t dst = out.size() - done, srcn = n - at;
+    const size_t r = LZ4F_decompress(ctx, out.data() + done, &dst, src + at, &srcn, nullptr);
+    if (LZ4F_isError(r)) { LZ4F_freeDecompressionContext(ctx); bad("corrupt lz4 chunk"); }
+    done += dst;
+    at += srcn;
+    if (r == 0) break;
+    if (dst == 0 && srcn == 0) break;
+  }
+  LZ4F_freeDecompressionContext(ctx);
+  if (done != expect) bad("lz4 chunk has another size than its record says");
+  return out;
+}
+
+}  // namespace
+
+// -----------------------------------------------------------------------------------------------------------------
+// reader
+// -----------------------------------------------------------------------------------------------------------------
+McapFile::McapFile(const std::string& path) : image_(readFile(path)) {
+  if (image_.size() < 16 + 9 || std::memcmp(image_.data(), kMagic, 8) != 0) bad(path + " does not begin with the MCAP magic");
+  if (std::memcmp(image_.data() + image_.size() - 8, kMagic, 8) != 0) bad(path + " does not end with the MCAP magic (truncated?)");
+  parseRecords(image_.data() + 8, image_.data() + image_.size() - 8, false);
+}
+
+void McapFile::parseRecords(const uint8_t* p, const uint8_t* end, bool in_chunk) {
+  while (p < end) {
+    if ((size_t)(end - p) < 9) bad("record header cut short");
+    const uint8_t op = p[0];
+    uint64_t len;
+    std::memcpy(&len, p + 1, 8);
+    p += 9;
+    if (len > (uint64_t)(end - p)) bad("record longer than what is left of the file");
+    Cur c{p, p + len};
+    p += len;
+    switch (op) {
+      case OP_HEADER:
+        profile = c.str();
+        library = c.str();
+        break;
+      case OP_SCHEMA: {
+        McapSchema s;
+        s.id = c.u16();
+        s.name = c.str();
+        s.encoding = c.str();
+        const uint32_t n = c.u32();
+        c.need(n);
+        s.data.assign(c.p, c.p + n);
+        if (s.id != 0) schemas[s.id] = std::move(s);  // (the summary section repeats them: same content)
+        break;
+      }
+      case OP_CHANNEL: {
+        McapChannel ch;
+        ch.id = c.u16();
+        ch.schema_id = c.u16();
+        ch.topic = c.str();
+        ch.message_encoding = c.str();
+        ch.metadata = c.map();
+        channels[ch.id] = std::move(ch);
+        break;
+      }
+      case OP_MESSAGE: {
+        McapMessage m;
+        m.channel_id = c.u16();
+        m.sequence = c.u32();
+        m.log_time = c.u64();
+        m.publish_time = c.u64();
+        m.data = c.p;
+        m.size = (size_t)(c.end - c.p);
+        messages.push_back(m);
+        break;
+      }
+      case OP_CHUNK: {
+        if (in_chunk) bad("chunk inside a chunk");
+        c.u64();  // message_start_time
+        c.u64();  // message_end_time
+        const uint64_t usize = c.u64();
+        c.u32();  // uncompressed_crc (0 = not computed; not checked)
+        const std::string comp = c.str();
+        const uint64_t n = c.u64();
+        c.need(n);
+        if (comp.empty()) {
+          if (n != usize) bad("uncompressed chunk whose sizes disagree");
+          parseRecords(c.p, c.p + n, true);
+        } else {
+          std::vector<uint8_t> raw;
+          if (comp == "zstd") {
+            raw.resize(usize);
+            const size_t r = ZSTD_decompress(raw.data(), raw.size(), c.p, n);
+            if (ZSTD_isError(r) || r != usize) bad("corrupt zstd chunk");
+          } else if (comp == "lz4") {
+            raw = lz4FrameDecompress(c.p, n, usize);
+          } else {
+            bad("chunk compression '" + comp + "' is not supported");
+          }
+          chunks_.push_back(std::move(raw));
+          parseRecords(chunks_.back().data(), chunks_.back().data() + chunks_.back().size(), true);
+        }
+        break;
+      }
+      case OP_METADATA: {
+        McapMetadata md;
+        md.name = c.str();
+        md.entries = c.map();
+        metadata.push_back(std::move(md));
+        break;
+      }
+      case OP_DATA_END:
+        return;  // the summary section behind it repeats schemas / channels and holds indexes: not needed
+      case OP_FOOTER:
+        return;
+      default:
+        break;  // message / chunk / attachment indexes, attachments, statistics, summary offsets, unknown opcodes: skipped
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// writer
+// -----------------------------------------------------------------------------------------------------------------
+McapWriter::McapWriter(const std::string& path, const std::string& profile, McapCompression compression, size_t chunk_size)
+    : compression_(compression), chunk_size_(chunk_size ? chunk_size : 1) {
+  FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) bad("cannot create " + path);
+  file_ = f;
+  if (std::fwrite(kMagic, 1, 8, f) != 8) bad("write failed");
+  pos_ = 8;
+  Rec h(OP_HEADER);
+  h.str(profile);
+  h.str("cloudini_amd");
+  put(h.done());
+}
+
+McapWriter::~McapWriter() {
+  try {
+    close();
+  } catch (...) {
+  }
+}
+
+void McapWriter::put(const std::vector<uint8_t>& r) {
+  if (std::fwrite(r.data(), 1, r.size(), static_cast<FILE*>(file_)) != r.size()) bad("write failed");
+  pos_ += r.size();
+}
+
+void McapWriter::addSchema(const McapSchema& s) {
+  Rec r(OP_SCHEMA);
+  r.u16(s.id);
+  r.str(s.name);
+  r.str(s.encoding);
+  r.u32((uint32_t)s.data.size());
+  r.raw(s.data.data(), s.data.size());
+  const auto& rec = r.done();
+  chunk_.insert(chunk_.end(), rec.begin(), rec.end());  // schemas and channels travel inside the chunks, ahead of their messages
+  schema_records_.push_back(rec);
+}
+
+void McapWriter::addChannel(const McapChannel& c) {
+  Rec r(OP_CHANNEL);
+  r.u16(c.id);
+  r.u16(c.schema_id);
+  r.str(c.topic);
+  r.str(c.message_encoding);
+  r.map(c.metadata);
+  const auto& rec = r.done();
+  chunk_.insert(chunk_.end(), rec.begin(), rec.end());
+  channel_records_.push_back(rec);
+  channel_counts_[c.id] += 0;
+}
+
+void McapWriter::addMetadata(const McapMetadata& m) {
+  flushChunk();  // metadata records live outside chunks
+  Rec r(OP_METADATA);
+  r.str(m.name);
+  r.map(m.entries);
+  put(r.done());
+  ++n_metadata_;
+}
+
+void McapWriter::writeMessage(uint16_t channel_id, uint32_t sequence, uint64_t log_time, uint64_t publish_time,
+                              const uint8_t* data, size_t size) {
+  Rec r(OP_MESSAGE);
+  r.u16(channel_id);
+  r.u32(sequence);
+  r.u64(log_time);
+  r.u64(publish_time);
+  r.raw(data, size);
+  const auto& rec = r.done();
+  chunk_.insert(chunk_.end(), rec.begin(), rec.end());
+  if (!chunk_has_msg_) {
+    chunk_t0_ = chunk_t1_ = log_time;
+    chunk_has_msg_ = true;
+  } else {
+    chunk_t0_ = std::min(chunk_t0_, log_time);
+    chunk_t1_ = std::max(chunk_t1_, log_time);
+  }
+  if (n_messages_ == 0) {
+    t_min_ = t_max_ = log_time;
+  } else {
+    t_min_ = std::min(t_min_, log_time);
+    t_max_ = std::max(t_max_, log_time);
+  }
+  ++n_messages_;
+  ++channel_counts_[channel_id];
+  if (chunk_.size() >= chunk_size_) flushChunk();
+}
+
+void McapWriter::flushChunk() {
+  if (chunk_.empty()) return;
+  std::vector<uint8_t> packed;
+  const char* name = "";
+  if (compression_ == McapCompression::Zstd) {
+    packed.resize(ZSTD_compressBound(chunk_.size()));
+    const size_t r = ZSTD_compress(packed.data(), packed.size(), chunk_.data(), chunk_.size(), 1);
+    if (ZSTD_isError(r)) bad("zstd failed");
+    packed.resize(r);
+    name = "zstd";
+  } else if (compression_ == McapCompression::Lz4) {
+    packed.resize(LZ4F_compressFrameBound(chunk_.size(), nullptr));
+    const size_t r = LZ4F_compressFrame(packed.data(), packed.size(), chunk_.data(), chunk_.size(), nullptr);
+    if (LZ4F_isError(r)) bad("lz4 failed");
+    packed.resize(r);
+    name = "lz4";
+  }
+  const std::vector<uint8_t>& body = compression_ == McapCompression::None ? chunk_ : packed;
+  Rec r(OP_CHUNK);
+  r.u64(chunk_t0_);
+  r.u64(chunk_t1_);
+  r.u64(chunk_.size());
+  r.u32(0u);  // uncompressed_crc: 0 = not computed
+  r.str(name);
+  r.u64(body.size());
+  r.raw(body.data(), body.size());
+  const auto& rec = r.done();
+  ChunkIndex ci{chunk_t0_, chunk_t1_, pos_, rec.size(), body.size(), chunk_.size()};
+  put(rec);
+  chunk_index_.push_back(ci);
+  chunk_.clear();
+  chunk_has_msg_ = false;
+  chunk_t0_ = chunk_t1_ = 0;
+}
+
+void McapWriter::close() {
+  if (closed_ || !file_) return;
+  closed_ = true;
+  flushChunk();
+  {
+    Rec r(OP_DATA_END);
+    r.u32(0u);  // data_section_crc: 0 = not computed
+    put(r.done());
+  }
+  // ---- summary section: groups of records + the offsets of the groups
+  const uint64_t summary_start = pos_;
+  struct Group {
+    uint8_t op;
+    uint64_t start, length;
+  };
+  std::vector<Group> groups;
+  auto group = [&](uint8_t op, const std::vector<std::vector<uint8_t>>& recs) {
+    if (recs.empty()) return;
+    const uint64_t start = pos_;
+    for (const auto& rec : recs) put(rec);
+    groups.push_back({op, start, pos_ - start});
+  };
+  group(OP_SCHEMA, schema_records_);
+  group(OP_CHANNEL, channel_records_);
+  {
+    std::vector<std::vector<uint8_t>> recs;
+    for (const ChunkIndex& ci : chunk_index_) {
+      Rec r(OP_CHUNK_INDEX);
+      r.u64(ci.start_time);
+      r.u64(ci.end_time);
+      r.u64(ci.offset);
+      r.u64(ci.length);
+      r.u32(0u);  // message_index_offsets: empty map (no message index records are written)
+      r.u64(0u);  // message_index_length
+      r.str(compression_ == McapCompression::Zstd ? "zstd" : compression_ == McapCompression::Lz4 ? "lz4" : "");
+      r.u64(ci.compressed_size);
+      r.u64(ci.uncompressed_size);
+      recs.push_back(r.done());
+    }
+    group(OP_CHUNK_INDEX, recs);
+  }
+  {
+    Rec r(OP_STATISTICS);
+    r.u64(n_messages_);
+    r.u16((uint16_t)schema_records_.size());
+    r.u32((uint32_t)channel_records_.size());
+    r.u32(0u);  // attachments
+    r.u32(n_metadata_);
+    r.u32((uint32_t)chunk_index_.size());
+    r.u64(t_min_);
+    r.u64(t_max_);
+    r.u32((uint32_t)(channel_counts_.size() * 10u));  // map<u16, u64>
+    for (const auto& kv : channel_counts_) {
+      r.u16(kv.first);
+      r.u64(kv.second);
+    }
+    std::vector<std::vector<uint8_t>> recs{r.done()};
+    group(OP_STATISTICS, recs);
+  }
+  const uint64_t summary_offset_start = pos_;
+  for (const Group& g : groups) {
+    Rec r(OP_SUMMARY_OFFSET);
+    r.u8(g.op);
+    r.u64(g.start);
+    r.u64(g.length);
+    put(r.done());
+  }
+  {
+    Rec r(OP_FOOTER);
+    r.u64(summary_start);
+    r.u64(summary_offset_start);
+    r.u32(0u);  // summary_crc: 0 = not computed
+    put(r.done());
+  }
+  FILE* f = static_cast<FILE*>(file_);
+  const bool ok = std::fwrite(kMagic, 1, 8, f) == 8;
+  file_ = nullptr;
+  if (std::fclose(f) != 0 || !ok) bad("write failed");
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// converter
+// -----------------------------------------------------------------------------------------------------------------
+namespace {
+
+// the point-cloud messages of the bag, in file order; name = index into McapFile::messages
+class McapSource : public MessageSource {
+ public:
+  McapSource(const McapFile& file, const std::vector<size_t>& picks) : file_(file), picks_(picks) {}
+  bool next(Message& out) override {
+    if (at_ >= picks_.size()) return false;
+    const size_t idx = picks_[at_++];
+    const McapMessage& m = file_.messages[idx];
+    out.name = std::to_string(idx);
+    out.bytes.resize(m.size);
+    if (m.size) std::memcpy(out.bytes.data(), m.data, m.size);
+    return true;
+  }
+
+ private:
+  const McapFile& file_;
+  const std::vector<size_t>& picks_;
+  size_t at_ = 0;
+};
+
+// converted messages arrive in input order; every other message of the bag is copied through in front of the converted
+// message that follows it in the file
+class McapSink : public MessageSink {
+ public:
+  McapSink(const McapFile& file, McapWriter& writer, const std::vector<bool>& is_cloud, McapTranscodeStats& stats)
+      : file_(file), writer_(writer), is_cloud_(is_cloud), stats_(stats) {}
+  void write(const std::string& name, const uint8_t* data, size_t size) override {
+    const size_t idx = (size_t)std::stoull(name);
+    copyUpTo(idx);
+    const McapMessage& m = file_.messages[idx];
+    writer_.writeMessage(m.channel_id, m.sequence, m.log_time, m.publish_time, data, size);
+    stats_.input_bytes += m.size;
+    stats_.output_bytes += size;
+    ++stats_.converted;
+    next_ = idx + 1;
+  }
+  void copyUpTo(size_t idx) {
+    for (; next_ < idx; ++next_) {
+      if (is_cloud_[next_]) continue;  // (cannot happen: converted messages arrive in order)
+      const McapMessage& m = file_.messages[next_];
+      writer_.writeMessage(m.channel_id, m.sequence, m.log_time, m.publish_time, m.data, m.size);
+    }
+  }
+
+ private:
+  const McapFile& file_;
+  McapWriter& writer_;
+  const std::vector<bool>& is_cloud_;
+  McapTranscodeStats& stats_;
+  size_t next_ = 0;
+};
+
+}  // namespace
+
+McapTranscodeStats transcodeMcap(const std::string& file_in, const std::string& file_out, TranscodeOptions options,
+                                 McapCompression mcap_compression) {
+  const McapFile in(file_in);
+  McapTranscodeStats stats;
+  stats.messages = in.messages.size();
+  const std::string from = options.decode ? kCompressedPointCloud2SchemaName : kPointCloud2SchemaName;
+  const std::string to = options.decode ? kPointCloud2SchemaName : kCompressedPointCloud2SchemaName;
+  const char* to_text = options.decode ? kPointCloud2SchemaText : kCompressedPointCloud2SchemaText;
+  // no need to compress twice (mcap_converter.cpp:199-202)
+  if (!options.decode && mcap_compression == McapCompression::Zstd) options.compression = Cloudini::CompressionOption::NONE;
+
+  McapWriter out(file_out, in.profile, mcap_compression);
+  for (const auto& kv : in.schemas) {  // ascending ids, like duplicateSchemasAndChannels
+    McapSchema s = kv.second;
+    if (s.name == from) {
+      s.name = to;
+      s.data.assign(to_text, to_text + std::strlen(to_text));
+    }
+    out.addSchema(s);
+  }
+  for (const auto& kv : in.channels) out.addChannel(kv.second);
+  for (const McapMetadata& m : in.metadata) out.addMetadata(m);
+
+  std::vector<bool> is_cloud(in.messages.size(), false);
+  std::vector<size_t> picks;
+  for (size_t i = 0; i < in.messages.size(); ++i) {
+    const auto ch = in.channels.find(in.messages[i].channel_id);
+    if (ch == in.channels.end()) bad("message on a channel the file does not declare");
+    const auto sc = in.schemas.find(ch->second.schema_id);
+    if (sc != in.schemas.end() && sc->second.name == from) {
+      is_cloud[i] = true;
+      picks.push_back(i);
+    }
+  }
+  McapSource source(in, picks);
+  McapSink sink(in, out, is_cloud, stats);
+  if (!picks.empty()) stats.pipeline = transcodePointClouds(source, sink, options);
+  sink.copyUpTo(in.messages.size());
+  out.close();
+  return stats;
+}
+
+}  // namespace cloudini_amd

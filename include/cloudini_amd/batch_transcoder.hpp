@@ -13,8 +13,9 @@
 //   writer thread   hands the messages to a MessageSink in input order
 // so the GPU works on batch k+1 while the host cores compress batch k and the sink writes batch k-1.
 //
-// Container I/O is pluggable (this image has no MCAP library): DirectorySource / DirectorySink read and write one CDR
-// message per file; an MCAP reader / writer only has to implement the two interfaces.
+// Container I/O is pluggable: DirectorySource / DirectorySink read and write one CDR message per file; bags go through
+// include/cloudini_amd/mcap_io.hpp (its own MCAP reader / writer: this image has no mcap library), which implements the two
+// interfaces and copies every other message of the bag through.
 #pragma once
 
 #include <cstddef>

@@ -1,0 +1,151 @@
+"""MCAP container I/O of the batch transcoder (include/cloudini_amd/mcap_io.hpp).
+
+The reference reads and writes bags through the upstream mcap library (tools/src/mcap_converter.cpp:32-57, :141-300), which
+this image does not have -- nor any sample bag. What can be pinned here:
+  * the C++ writer and reader against each other (three chunk compressions, many small chunks);
+  * both against tests/mcap_py.py, a second statement of the published record layouts in another language: Python reads what
+    C++ wrote (every record, the summary section and its offsets included), C++ reads what Python wrote (chunked or not);
+  * on the GPU: a bag with point clouds and other topics goes through `cloudini_batch_transcode in.mcap out.mcap` -- every
+    converted message equals the reference's converter byte for byte, everything else arrives untouched and in file order,
+    the schema of the cloud topics is swapped -- and back again.
+Against the mcap library itself the parity is UNPINNED."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import mcap_py
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "cloudini_amd", "lib")
+
+
+def _build(tmp_path, name):
+    exe = str(tmp_path / name)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", name + ".cpp"), os.path.join(LIB, "libcloudini_amd.so"),
+                    os.path.join(LIB, "libcloudini_hip.so"), "-Wl,-rpath," + LIB, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    return exe
+
+
+def _payload(i):
+    n = 17 + (i * 37) % 400
+    return bytes((((i * 131 + k * 7) & 0xffffffff) >> (k & 3)) & 0xff for k in range(n))
+
+
+def _fnv(b):
+    h = 1469598103934665603
+    for x in b:
+        h = ((h ^ x) * 1099511628211) & 0xffffffffffffffff
+    return h
+
+
+def test_cpp_writer_and_reader_round_trip_and_python_reads_the_file(tmp_path):
+    exe = _build(tmp_path, "mcap_roundtrip")
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, r.stdout + r.stderr
+    f = mcap_py.read(str(tmp_path / "rt_none.mcap"))
+    assert f["header"] == ("ros2", "cloudini_amd")
+    assert set(f["schemas"]) == {1, 7} and f["schemas"][1][0] == "sensor_msgs/msg/PointCloud2" and f["schemas"][7][2] == b"string data"
+    assert f["channels"][3] == (1, "/lidar/points", "cdr", [("offered_qos_profiles", "x")])
+    assert f["channels"][9] == (1, "/depth/points", "cdr", [("k", "v"), ("k2", "")])
+    assert f["metadata"] == [("rosbag2", [("ROS_DISTRO", "jazzy")])]
+    assert len(f["messages"]) == 60
+    for i, (ch, seq, lt, pt, data) in enumerate(f["messages"]):
+        assert (ch, seq, lt, pt) == ((3, 4, 9)[i % 3], i, 1000 + 10 * i, 999 + 10 * i) and data == _payload(i)
+    assert len(f["chunks"]) > 10  # 700-byte chunks
+    # the summary section says where things are, and it is right
+    s = f["summary"]
+    assert s["schemas"] == f["schemas"] and s["channels"] == f["channels"]
+    st = s["statistics"]
+    assert (st["messages"], st["schemas"], st["channels"], st["metadata"], st["chunks"]) == (60, 2, 3, 1, len(f["chunks"]))
+    assert (st["t0"], st["t1"]) == (1000, 1590) and st["counts"] == {3: 20, 4: 20, 9: 20}
+    assert [(c[2], c[3]) for c in s["chunk_index"]] == [(c[0], c[1]) for c in f["chunks"]]           # offset, record length
+    assert [(c[0], c[1], c[6], c[7]) for c in s["chunk_index"]] == [(c[2], c[3], c[6], c[4]) for c in f["chunks"]]  # times, sizes
+    summary_recs = [x for x in f["records"] if x[3] == "summary" and x[0] not in (mcap_py.DATA_END,)]
+    first_summary = min(x[1] for x in summary_recs if x[0] not in (mcap_py.FOOTER,))
+    first_offset = min(x[1] for x in summary_recs if x[0] == mcap_py.SUMMARY_OFFSET)
+    assert f["footer"] == (first_summary, first_offset, 0)
+    for g, start, length in s["offsets"]:
+        inside = [x for x in f["records"] if x[3] == "summary" and start <= x[1] < start + length]
+        assert inside and all(x[0] == g for x in inside) and sum(x[2] for x in inside) == length
+
+
+@pytest.mark.parametrize("chunked", [None, 7])
+def test_cpp_reader_takes_what_python_wrote(tmp_path, chunked):
+    exe = _build(tmp_path, "mcap_dump")
+    schemas = [(1, "sensor_msgs/msg/PointCloud2", "ros2msg", b"abc"), (2, "x/msg/Y", "ros2msg", b"")]
+    channels = [(5, 1, "/a", "cdr", [("q", "1")]), (6, 2, "/b", "cdr", []), (8, 0, "/schemaless", "json", [])]
+    msgs = [((5, 6, 8)[i % 3], i, 50 + i, 40 + i, _payload(i)) for i in range(25)]
+    path = str(tmp_path / "py.mcap")
+    mcap_py.write(path, "ros2", schemas, channels, msgs, metadata=[("m", [("k", "v")])], chunk_messages=chunked)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert lines[0] == "header ros2"
+    assert [l for l in lines if l.startswith("schema")] == ["schema 1 sensor_msgs/msg/PointCloud2 ros2msg 3", "schema 2 x/msg/Y ros2msg 0"]
+    assert [l for l in lines if l.startswith("channel")] == ["channel 5 1 /a cdr 1", "channel 6 2 /b cdr 0", "channel 8 0 /schemaless json 0"]
+    assert [l for l in lines if l.startswith("metadata")] == ["metadata m 1"]
+    got = [l for l in lines if l.startswith("message")]
+    assert got == [f"message {c} {q} {lt} {pt} {len(d)} {_fnv(d)}" for c, q, lt, pt, d in msgs]
+    # a file cut short is an error, not a crash
+    cut = str(tmp_path / "cut.mcap")
+    open(cut, "wb").write(open(path, "rb").read()[:-20])
+    r = subprocess.run([exe, cut], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and r.stdout.startswith("error MCAP:")
+
+
+@pytest.mark.gpu
+def test_a_bag_goes_through_the_tool_and_back(tmp_path, reflib):
+    from cloudini_amd import synth
+    from test_host_api import _cdr_pointcloud2
+    tool = os.path.join(LIB, "cloudini_batch_transcode")
+    clouds = []
+    for k, n in enumerate([40000, 1, 70000, 0, 32768, 5000]):
+        info, data = synth.lidar_xyzi(n, seed=10 + k)
+        clouds.append(_cdr_pointcloud2(info, data, stamp=(1700000000 + k, 1000 * k)))
+    info, data = synth.velodyne_xyzir(130048, seed=3)
+    clouds.append(_cdr_pointcloud2(info, data, frame_id="velodyne"))
+    pc2 = "sensor_msgs/msg/PointCloud2"
+    schemas = [(1, pc2, "ros2msg", b"whatever the recorder wrote"), (2, "std_msgs/msg/String", "ros2msg", b"string data")]
+    channels = [(1, 1, "/lidar", "cdr", []), (2, 2, "/chatter", "cdr", [("k", "v")]), (3, 1, "/velodyne", "cdr", [])]
+    msgs, t = [], 1000
+    for k, c in enumerate(clouds):
+        msgs.append((2, 2 * k, t, t, b"hello %d" % k)); t += 5
+        msgs.append((3 if k == 6 else 1, 2 * k + 1, t, t - 1, c.tobytes())); t += 5
+    msgs.append((2, 99, t, t, b"bye"))
+    src, enc, dec = str(tmp_path / "in.mcap"), str(tmp_path / "enc.mcap"), str(tmp_path / "dec.mcap")
+    mcap_py.write(src, "ros2", schemas, channels, msgs, metadata=[("rosbag2", [("a", "b")])], chunk_messages=4)
+    r = subprocess.run([tool, src, enc, "--resolution", "0.001", "--compression", "lz4", "--mcap-compression", "none", "--batch", "3"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    f = mcap_py.read(enc)
+    assert f["header"][0] == "ros2" and f["metadata"] == [("rosbag2", [("a", "b")])]
+    assert f["schemas"][1][0] == "point_cloud_interfaces/msg/CompressedPointCloud2" and b"compressed_data" in f["schemas"][1][2]
+    assert f["schemas"][2] == ("std_msgs/msg/String", "ros2msg", b"string data")
+    assert f["channels"] == {c[0]: (c[1], c[2], c[3], c[4]) for c in channels}
+    assert len(f["messages"]) == len(msgs)
+    for (ch, seq, lt, pt, data), (ch0, seq0, lt0, pt0, data0) in zip(f["messages"], msgs):
+        assert (ch, seq, lt, pt) == (ch0, seq0, lt0, pt0)
+        if ch0 == 2:
+            assert data == data0
+        else:
+            want = reflib.ros_compress(np.frombuffer(data0, dtype=np.uint8), 0.001, 1)  # LZ4
+            assert data == want.tobytes()
+    # the way back: zstd chunks this time (read by the C++ reader only), then once more uncompressed for the comparison
+    r = subprocess.run([tool, enc, dec, "--decode", "--mcap-compression", "none"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    g = mcap_py.read(dec)
+    assert g["schemas"][1][0] == pc2 and len(g["messages"]) == len(msgs)
+    for (ch, seq, lt, pt, data), (ch0, seq0, lt0, pt0, data0), (_, _, _, _, e) in zip(g["messages"], msgs, f["messages"]):
+        assert (ch, seq, lt, pt) == (ch0, seq0, lt0, pt0)
+        if ch0 == 2:
+            assert data == data0
+        else:
+            assert data == reflib.ros_decompress(np.frombuffer(e, dtype=np.uint8), len(data0) + 4096).tobytes()
+    # compressed containers: zstd out, read again by the tool (lz4 out), sizes sane
+    z, l = str(tmp_path / "z.mcap"), str(tmp_path / "l.mcap")
+    assert subprocess.run([tool, src, z, "--mcap-compression", "zstd"], capture_output=True, timeout=300).returncode == 0
+    assert subprocess.run([tool, z, l, "--decode", "--mcap-compression", "lz4"], capture_output=True, timeout=300).returncode == 0
+    assert os.path.getsize(z) < os.path.getsize(src) and os.path.getsize(l) > os.path.getsize(z)

@@ -5,12 +5,15 @@
 //   cloudini_batch_transcode <in_dir> <out_dir> [--resolution 0.001] [--compression none|lz4|zstd] [--viz] [--batch 64]
 //   cloudini_batch_transcode <in_dir> <out_dir> --decode [--batch 64]      (CompressedPointCloud2 -> PointCloud2)
 //   ... --devices 0,1,2,3   spreads the batches over these GPUs (one GPU stage per entry; "0,0" = two stages on GPU 0)
+//   cloudini_batch_transcode <in.mcap> <out.mcap> [...same options] [--mcap-compression none|lz4|zstd]
+//       a bag: point-cloud messages converted, everything else copied (McapConverter, tools/src/mcap_converter.cpp:141-300)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 
 #include "cloudini_amd/batch_transcoder.hpp"
+#include "cloudini_amd/mcap_io.hpp"
 
 int main(int argc, char** argv) {
   if (argc < 3) {
@@ -18,12 +21,17 @@ int main(int argc, char** argv) {
     return 2;
   }
   cloudini_amd::TranscodeOptions opt;
+  cloudini_amd::McapCompression mcap_comp = cloudini_amd::McapCompression::Zstd;
   for (int i = 3; i < argc; ++i) {
     const std::string a = argv[i];
     if (a == "--resolution" && i + 1 < argc) opt.default_resolution = std::strtof(argv[++i], nullptr);
     else if (a == "--compression" && i + 1 < argc) opt.compression = Cloudini::CompressionOptionFromString(
         std::string(argv[i + 1]) == "none" ? "NONE" : (std::string(argv[i + 1]) == "lz4" ? "LZ4" : "ZSTD")), ++i;
     else if (a == "--viz") opt.viz_lossy = true;
+    else if (a == "--mcap-compression" && i + 1 < argc) {
+      const std::string v = argv[++i];
+      mcap_comp = v == "none" ? cloudini_amd::McapCompression::None : (v == "lz4" ? cloudini_amd::McapCompression::Lz4 : cloudini_amd::McapCompression::Zstd);
+    }
     else if (a == "--decode") opt.decode = true;
     else if (a == "--batch" && i + 1 < argc) opt.batch_messages = (size_t)std::strtoul(argv[++i], nullptr, 10);
     else if (a == "--devices" && i + 1 < argc) {
@@ -43,6 +51,16 @@ int main(int argc, char** argv) {
     }
   }
   try {
+    const std::string in_path = argv[1];
+    if (in_path.size() > 5 && in_path.compare(in_path.size() - 5, 5, ".mcap") == 0) {
+      const cloudini_amd::McapTranscodeStats ms = cloudini_amd::transcodeMcap(in_path, argv[2], opt, mcap_comp);
+      std::printf("{\"messages\": %llu, \"converted\": %llu, \"input_bytes\": %llu, \"output_bytes\": %llu, \"points\": %llu, "
+                  "\"seconds_total\": %.6f, \"gpu_batches\": %llu}\n",
+                  (unsigned long long)ms.messages, (unsigned long long)ms.converted, (unsigned long long)ms.input_bytes,
+                  (unsigned long long)ms.output_bytes, (unsigned long long)ms.pipeline.points, ms.pipeline.seconds_total,
+                  (unsigned long long)ms.pipeline.gpu_batches);
+      return 0;
+    }
     cloudini_amd::DirectorySource source(argv[1]);
     cloudini_amd::DirectorySink sink(argv[2]);
     const cloudini_amd::TranscodeStats st = cloudini_amd::transcodePointClouds(source, sink, opt);
