@@ -141,7 +141,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         nf = 8u;
         many_used = true;
         hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
         DecChunk* dsec = reinterpret_cast<DecChunk*>(L.dsec);
         hipLaunchKernelGGL(k_section_offsets, dim3(L.n_chunks), dim3(kSoThreads), 0, L.stream, P, L.streams,
@@ -167,9 +167,9 @@ int stage1_launch_decode(const DecodeLaunch& L) {
           static const int lw = getenv("CLDN_HIP_LOCATE_WAVES") ? atoi(getenv("CLDN_HIP_LOCATE_WAVES")) : 0;  // A/B switch
           const bool wide = lw >= 16;  // (16 waves per chunk measured slower on C3 / C4 / C5: 0.452 / 0.572 / 0.140 against 0.433 / 0.552 / 0.137 ms)
           if (wide) hipLaunchKernelGGL(k_locate_sections<16>, dim3(L.n_chunks), dim3(1024), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u);
           else hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u);
         }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
         static const bool no_scf = getenv("CLDN_HIP_NO_FAST_COLS") != nullptr;  // A/B switch
@@ -295,7 +295,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         DecColumns dcols = {};
         for (uint32_t a = 0; a < 8u; ++a) dcols.p[a] = L.cols[a];
         hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 1u);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
         DecChunk* dsec = reinterpret_cast<DecChunk*>(L.dsec);
         hipLaunchKernelGGL(k_section_offsets, dim3(L.n_chunks), dim3(kSoThreads), 0, L.stream, P, L.streams,
@@ -353,7 +353,8 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     // round 4: the sections of a chunk side by side (stage1_decode_sections_w.h): sized without decoding, then one
     // workgroup per (chunk, field); chunks it does not finish stay with the kernels below. CLDN_HIP_NO_SECTIONS_W=1: A/B switch
     static const bool no_sw = getenv("CLDN_HIP_NO_SECTIONS_W") != nullptr;
-    bool sections_w = fast_sections && !no_sw && !many_used && L.dsec != nullptr && P.n_adaptive <= kSoMaxFields;
+    // (stream_cols: the sections went out with the points; what is left -- irregular chunks -- takes the two launches below)
+    bool sections_w = fast_sections && !no_sw && !many_used && !stream_cols && L.dsec != nullptr && P.n_adaptive <= kSoMaxFields;
     for (uint32_t a = 0; a < P.n_adaptive && sections_w; ++a) sections_w = P.adaptive[a].bpv <= 4u;
     if (sections_w) {
       DecChunk* dsec = reinterpret_cast<DecChunk*>(L.dsec);
@@ -377,7 +378,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     } else if (fast_sections) {
       hipLaunchKernelGGL(k_decode_sections_small, dim3(L.n_chunks), dim3(kDvThreads), kSmallSecLds, L.stream, P, L.streams,
                          reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status,
-                         points_kernel ? 1u : 0u);
+                         (points_kernel || stream_cols) ? 1u : 0u);
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_sections_small");
       hipLaunchKernelGGL(k_decode_sections, dim3(L.n_chunks), dim3(kDvThreads), (DecSecLds::kTotal), L.stream, P, L.streams,
                          reinterpret_cast<const DecChunk*>(L.chunks), L.out, (const uint32_t*)L.reg_end, L.sec_done, L.status);

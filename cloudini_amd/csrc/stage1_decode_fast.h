@@ -194,7 +194,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                          const DecChunk* __restrict__ chunks, uint32_t n_ops,
                                                          uint32_t* __restrict__ reg_end_pre, uint8_t* __restrict__ sec_cols,
-                                                         uint32_t* __restrict__ slices_done) {
+                                                         uint32_t* __restrict__ slices_done, uint32_t keep_guess) {
   __shared__ uint32_t wcnt[NW];
   __shared__ uint32_t found, pal_sh[2];
   const uint32_t c = blockIdx.x;
@@ -216,7 +216,17 @@ __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan,
   const uint32_t target = n * n_ops;
   __syncthreads();
   if (plan.n_adaptive == 1u) {
-    if (pal_guess_from_end<NW * 64>(src, src_size, n, plan.adaptive[0].bpv, pal_sh) != 0xffffffffu) return;  // uniform
+    {
+      const uint32_t U = pal_guess_from_end<NW * 64>(src, src_size, n, plan.adaptive[0].bpv, pal_sh);  // uniform
+      if (U != 0xffffffffu) {
+        // k_decode_points_w makes this guess again itself; the stream kernel's column flow (keep_guess) wants the place
+        if (keep_guess && tid == 0) {
+          reg_end_pre[c] = src_size - (3u + U * plan.adaptive[0].bpv + (palette_bits(U) * n + 7u) / 8u);
+          slices_done[c] = 1u << 24;
+        }
+        return;
+      }
+    }
     // A lone DeltaRle section (ring / line index of a lidar) is also found from the end: [3][u32 runs][runs x (varint
     // difference, varint length)] -- every position p of the payload's last bytes with src[p] == 3, a run count r in
     // 1..n behind it, a token end in front of it and exactly 2 r token ends between p + 5 and the payload's end is a
