@@ -95,6 +95,12 @@ int stage1_launch_decode_unframed(const DevPlan& plan, hipStream_t stream, const
   return CLDN_HIP_OK;
 }
 
+// DeltaVarint sections into columns: k_sections_dv_cols (round 4), or the stream kernel's section mode (CLDN_HIP_DV_COLS=0: A/B switch)
+static bool dv_cols_kernel() {
+  static const bool off = getenv("CLDN_HIP_DV_COLS") && atoi(getenv("CLDN_HIP_DV_COLS")) == 0;
+  return !off;
+}
+
 int stage1_launch_decode(const DecodeLaunch& L) {
   hipError_t e;
   if (L.n_clouds == 0) return CLDN_HIP_OK;
@@ -150,10 +156,16 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         hipLaunchKernelGGL(k_sections_w, dim3(L.n_chunks, P.n_adaptive), dim3(kSwsThreads), 0, L.stream, P, L.streams,
                            (const DecChunk*)dsec, L.n_chunks, L.out, L.done_cnt, 1u, dcols);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_w");
-        const DevPlan S = sections_plan(P, true);
-        hipLaunchKernelGGL((k_decode_stream_w<16, 0>), dim3(L.n_chunks, P.n_adaptive), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, S,
-                           L.streams, (const DecChunk*)dsec, (uint8_t*)nullptr, L.done_cnt, L.status, (const uint32_t*)nullptr, L.n_chunks, dcols, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
-        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (sections)");
+        if (dv_cols_kernel()) {
+          hipLaunchKernelGGL(k_sections_dv_cols, dim3(L.n_chunks, P.n_adaptive), dim3(kScfThreads), 0, L.stream, P, L.streams,
+                             (const DecChunk*)dsec, L.n_chunks, L.done_cnt, dcols);
+          if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_dv_cols");
+        } else {
+          const DevPlan S = sections_plan(P, true);
+          hipLaunchKernelGGL((k_decode_stream_w<16, 0>), dim3(L.n_chunks, P.n_adaptive), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, S,
+                             L.streams, (const DecChunk*)dsec, (uint8_t*)nullptr, L.done_cnt, L.status, (const uint32_t*)nullptr, L.n_chunks, dcols, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
+          if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (sections)");
+        }
         hipLaunchKernelGGL(k_sections_done, dim3((L.n_chunks + 255u) / 256u), dim3(256), 0, L.stream, L.n_chunks, P.n_adaptive,
                            (const uint8_t*)L.secs_ok, (const uint32_t*)L.done_cnt, L.sec_cols, L.status, 0u);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_done");
@@ -304,11 +316,16 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         hipLaunchKernelGGL(k_sections_w, dim3(L.n_chunks, P.n_adaptive), dim3(kSwsThreads), 0, L.stream, P, L.streams,
                            (const DecChunk*)dsec, L.n_chunks, L.out, L.done_cnt, 1u, dcols);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_w");
-        const DevPlan S = sections_plan(P, true);
-        hipLaunchKernelGGL((k_decode_stream_w<16, 0>), dim3(L.n_chunks, P.n_adaptive), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, S,
-                           L.streams, (const DecChunk*)dsec, (uint8_t*)nullptr, L.done_cnt, L.status, (const uint32_t*)nullptr, L.n_chunks, dcols,
-                           (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
-        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (sections)");
+        if (dv_cols_kernel()) {
+          hipLaunchKernelGGL(k_sections_dv_cols, dim3(L.n_chunks, P.n_adaptive), dim3(kScfThreads), 0, L.stream, P, L.streams,
+                             (const DecChunk*)dsec, L.n_chunks, L.done_cnt, dcols);
+          if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_dv_cols");
+        } else {
+          const DevPlan S = sections_plan(P, true);
+          hipLaunchKernelGGL((k_decode_stream_w<16, 0>), dim3(L.n_chunks, P.n_adaptive), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, S,
+                             L.streams, (const DecChunk*)dsec, (uint8_t*)nullptr, L.done_cnt, L.status, (const uint32_t*)nullptr, L.n_chunks, dcols, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
+          if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (sections)");
+        }
         hipLaunchKernelGGL(k_sections_done, dim3((L.n_chunks + 255u) / 256u), dim3(256), 0, L.stream, L.n_chunks, P.n_adaptive,
                            (const uint8_t*)L.secs_ok, (const uint32_t*)L.done_cnt, L.sec_cols, L.status, 0u);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_done");

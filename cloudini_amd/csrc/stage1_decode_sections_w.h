@@ -362,6 +362,106 @@ __global__ __launch_bounds__(kSwsThreads) void k_sections_w(const DevPlan plan, 
   if (tid == 0) atomicAdd(done_cnt + c, 1u);
 }
 
+// k_sections_dv_cols: the DeltaVarint sections k_section_offsets sized (dsec record with valid == 1) -> the field's dense
+// column, grid (chunks, fields) x 256 threads. The stream kernel's section mode decodes the same sections with its two walks
+// and chains (289 us for the two DeltaVarint fields of an Ouster-style batch); a section is ONE integer op, and what
+// k_sections_cols_fast does for the plans with one integer field is all it takes: slices of 4 KiB in sequence, a thread
+// decodes the tokens that END in its 16 bytes (the first one begins behind the last end among the 8 bytes in front), two block
+// scans number the tokens and add up the differences, the running count and sum stay in registers from slice to slice.
+// A section that is not exactly n tokens, a token of more than 5 bytes or a marker byte leaves the field to the kernels
+// behind (done_cnt is not raised).
+__global__ __launch_bounds__(kScfThreads) void k_sections_dv_cols(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                                  const DecChunk* __restrict__ dsec, uint32_t n_chunks,
+                                                                  uint32_t* __restrict__ done_cnt, const DecColumns cols) {
+  constexpr int T = (int)kScfThreads;
+  __shared__ __attribute__((aligned(16))) uint32_t tile[kScfTileBytes / 4u + 8u];  // 8 bytes of history, the slice's bytes, slack
+  __shared__ uint32_t vals[kScfTileBytes];
+  __shared__ uint32_t scan[40];
+  __shared__ uint32_t flags[2];
+  const uint32_t c = blockIdx.x, a = blockIdx.y;
+  const uint32_t tid = threadIdx.x;
+  const DecChunk dc = dsec[(size_t)a * n_chunks + c];
+  if (dc.valid != 1u) return;  // another mode: k_sections_w
+  const uint8_t* src = streams + dc.src_off;  // the section's body (behind the mode byte)
+  const uint32_t src_size = dc.src_size;
+  const uint32_t n = dc.n_points;
+  const uint32_t bpv = plan.adaptive[a].bpv;
+  if (n == 0u || src_size == 0u || bpv > 4u || cols.p[a] == nullptr) return;
+  uint8_t* col = const_cast<uint8_t*>(cols.p[a]) + (size_t)dc.first_point * bpv;
+  const uint32_t n_slices = (src_size + kScfTileBytes - 1u) / kScfTileBytes;
+  if (tid == 0) flags[0] = 0u;
+  __syncthreads();
+  uint32_t pre_cnt = 0u, pre_sum = 0u;
+  for (uint32_t s = 0; s < n_slices; ++s) {
+    const uint32_t base = s * kScfTileBytes;
+    uint32_t b[4];
+    fp_load16u(src, src_size, base + tid * 16u, b);  // bytes behind the section read 0xff: no token ends
+    *reinterpret_cast<uint4*>(tile + 2u + tid * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
+    if (tid == 0u) {  // the 8 bytes in front of the slice (a token has 5 at most); in front of the body: the mode byte, an end
+      uint32_t h[2] = {0u, 0u};
+      if (base >= 8u) __builtin_memcpy(h, src + base - 8u, 8);
+      tile[0] = h[0];
+      tile[1] = h[1];
+    }
+    if (tid < 4u) tile[2u + kScfTileBytes / 4u + tid] = 0xffffffffu;
+    const uint32_t ends = fp_ends16(b);
+    const uint32_t my_cnt = (uint32_t)__builtin_popcount(ends);
+    uint32_t n_tile;
+    const uint32_t tb = block_exclusive_scan<T>(my_cnt, scan, &n_tile);  // barrier inside: the tile is complete
+    uint32_t sum = 0u;
+    bool bad = false;
+    if (ends) {
+      const uint32_t h0 = tile[tid * 4u], h1 = tile[tid * 4u + 1u];
+      const uint32_t hist = ((((~h0 & 0x80808080u) >> 7) * 0x00204081u) >> 21 & 0xfu) | ((((~h1 & 0x80808080u) >> 7) * 0x00204081u) >> 21 & 0xfu) << 4;
+      uint32_t start = hist ? 32u - (uint32_t)__builtin_clz(hist) : 0u;  // window index (0 = 8 bytes in front of mine)
+      uint32_t k = tb;
+      for (uint32_t m = ends; m; m &= m - 1u) {
+        const uint32_t endw = 8u + (uint32_t)__builtin_ctz(m);
+        const uint32_t tl = endw - start + 1u;
+        const uint32_t bo = tid * 16u + start;  // byte offset inside `tile` (which begins with the 8 bytes of history)
+        const uint32_t di = bo >> 2, sh = (bo & 3u) * 8u;
+        const uint32_t w0 = tile[di], w1 = tile[di + 1u], w2 = tile[di + 2u];
+        const uint32_t lo = sh ? ((w0 >> sh) | (w1 << (32u - sh))) : w0;
+        const uint32_t b4 = (sh ? ((w1 >> sh) | (w2 << (32u - sh))) : w1) & 0xffu;
+        const uint32_t g = (lo & 0x7fu) | (((lo >> 8) & 0x7fu) << 7) | (((lo >> 16) & 0x7fu) << 14) | (((lo >> 24) & 0x7fu) << 21);
+        const uint32_t keep = tl >= 4u ? 0x0fffffffu : ((1u << (7u * tl)) - 1u);
+        const uint64_t u = (uint64_t)(g & keep) | (tl == 5u ? ((uint64_t)(b4 & 0x7fu) << 28) : 0ull);
+        bad = bad || tl > 5u || u == 0ull;  // the marker byte is no integer token (decodeVarint rejects it)
+        const uint64_t u1 = u - 1ull;
+        const uint32_t dv = (uint32_t)((u1 >> 1) ^ (0ull - (u1 & 1ull)));  // low 32 bits of the difference
+        vals[k++] = dv;
+        sum += dv;
+        start = endw + 1u;
+      }
+    }
+    if (bad) flags[0] = 1u;
+    uint32_t tile_sum;
+    const uint32_t before = block_exclusive_scan<T>(sum, scan + 20, &tile_sum);  // barrier inside (after every write of flags[0])
+    if (flags[0] != 0u) return;              // (uniform)
+    if (pre_cnt + n_tile > n) return;        // more tokens than points
+    {
+      uint32_t v = pre_sum + before;
+      for (uint32_t k = tb; k < tb + my_cnt; ++k) {
+        v += vals[k];
+        vals[k] = v;
+      }
+    }
+    __syncthreads();
+    if (bpv == 2u) {
+      uint16_t* o = reinterpret_cast<uint16_t*>(col) + pre_cnt;
+      for (uint32_t i = tid; i < n_tile; i += kScfThreads) o[i] = (uint16_t)vals[i];
+    } else {
+      uint32_t* o = reinterpret_cast<uint32_t*>(col) + pre_cnt;
+      for (uint32_t i = tid; i < n_tile; i += kScfThreads) o[i] = vals[i];
+    }
+    pre_cnt += n_tile;
+    pre_sum += tile_sum;
+    __syncthreads();  // (tile, vals and flags are written again)
+  }
+  // every point has its token and the section's last byte ends one
+  if (tid == 0u && pre_cnt == n && (src[src_size - 1u] & 0x80u) == 0u) atomicAdd(done_cnt + c, 1u);
+}
+
 // grid = ceil(n_chunks / 256): sec_done[c] = 1 for the chunks whose sections all arrived
 __global__ __launch_bounds__(256) void k_sections_done(uint32_t n_chunks, uint32_t n_adaptive, const uint8_t* __restrict__ secs_ok,
                                                        const uint32_t* __restrict__ done_cnt, uint8_t* __restrict__ sec_done,
