@@ -96,9 +96,10 @@ int stage1_launch_decode_unframed(const DevPlan& plan, hipStream_t stream, const
 }
 
 // DeltaVarint sections into columns: k_sections_dv_cols (round 4), or the stream kernel's section mode (CLDN_HIP_DV_COLS=0: A/B switch)
-static bool dv_cols_kernel() {
-  static const bool off = getenv("CLDN_HIP_DV_COLS") && atoi(getenv("CLDN_HIP_DV_COLS")) == 0;
-  return !off;
+// 0 = the stream kernel's section mode, 1 = k_sections_dv_cols as a launch of its own, 2 (default) = inside k_sections_w's launch
+static int dv_cols_kernel() {
+  static const int mode = getenv("CLDN_HIP_DV_COLS") ? atoi(getenv("CLDN_HIP_DV_COLS")) : 2;
+  return mode;
 }
 
 int stage1_launch_decode(const DecodeLaunch& L) {
@@ -154,9 +155,10 @@ int stage1_launch_decode(const DecodeLaunch& L) {
                            reinterpret_cast<const DecChunk*>(L.chunks), L.n_chunks, (const uint32_t*)L.reg_end_pre, dsec, L.secs_ok, L.done_cnt, (const uint8_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_offsets");
         hipLaunchKernelGGL(k_sections_w, dim3(L.n_chunks, P.n_adaptive), dim3(kSwsThreads), 0, L.stream, P, L.streams,
-                           (const DecChunk*)dsec, L.n_chunks, L.out, L.done_cnt, 1u, dcols);
+                           (const DecChunk*)dsec, L.n_chunks, L.out, L.done_cnt, dv_cols_kernel() == 2 ? 2u : 1u, dcols);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_w");
-        if (dv_cols_kernel()) {
+        if (dv_cols_kernel() == 2) {
+        } else if (dv_cols_kernel() == 1) {
           hipLaunchKernelGGL(k_sections_dv_cols, dim3(L.n_chunks, P.n_adaptive), dim3(kScfThreads), 0, L.stream, P, L.streams,
                              (const DecChunk*)dsec, L.n_chunks, L.done_cnt, dcols);
           if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_dv_cols");
@@ -314,9 +316,10 @@ int stage1_launch_decode(const DecodeLaunch& L) {
                            reinterpret_cast<const DecChunk*>(L.chunks), L.n_chunks, (const uint32_t*)L.reg_end_pre, dsec, L.secs_ok, L.done_cnt, (const uint8_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_offsets");
         hipLaunchKernelGGL(k_sections_w, dim3(L.n_chunks, P.n_adaptive), dim3(kSwsThreads), 0, L.stream, P, L.streams,
-                           (const DecChunk*)dsec, L.n_chunks, L.out, L.done_cnt, 1u, dcols);
+                           (const DecChunk*)dsec, L.n_chunks, L.out, L.done_cnt, dv_cols_kernel() == 2 ? 2u : 1u, dcols);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_w");
-        if (dv_cols_kernel()) {
+        if (dv_cols_kernel() == 2) {
+        } else if (dv_cols_kernel() == 1) {
           hipLaunchKernelGGL(k_sections_dv_cols, dim3(L.n_chunks, P.n_adaptive), dim3(kScfThreads), 0, L.stream, P, L.streams,
                              (const DecChunk*)dsec, L.n_chunks, L.done_cnt, dcols);
           if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_dv_cols");

@@ -159,18 +159,30 @@ __global__ __launch_bounds__(kSoThreads) void k_section_offsets(const DevPlan pl
 // grid = (n_chunks, n_adaptive), kSwsThreads threads: the Palette (valid == 2), Rle (3) and DeltaRle (4) sections, values
 // written into the points. A section it cannot take (more than kSwsMaxPal entries / kSwsMaxRuns runs, anything irregular)
 // does not count for its chunk, which then goes through the old kernels.
+__device__ __forceinline__ void sections_dv_body(const DevPlan& plan, const uint8_t* __restrict__ streams, const DecChunk& dc, uint32_t c,
+                                                 uint32_t a, uint32_t* __restrict__ done_cnt, const DecColumns& cols, uint32_t* tile,
+                                                 uint32_t* vals, uint32_t* scan, uint32_t* flags);  // (below)
+
 __global__ __launch_bounds__(kSwsThreads) void k_sections_w(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                             const DecChunk* __restrict__ dsec, uint32_t n_chunks,
                                                             uint8_t* __restrict__ out, uint32_t* __restrict__ done_cnt,
                                                             uint32_t to_cols, const DecColumns cols) {
   constexpr int T = (int)kSwsThreads;
   __shared__ __attribute__((aligned(16))) uint32_t tab[kSwsMaxPal];  // palette entries / run table (3 x kSwsMaxRuns + 16) / staged bytes
-  __shared__ uint16_t end_pos[kSwsMaxRuns * 2u + 16u];
+  __shared__ __attribute__((aligned(16))) uint16_t end_pos[kSwsMaxRuns * 2u + 16u];
   __shared__ uint32_t scan[48];
   __shared__ uint32_t flags[2];
   const uint32_t c = blockIdx.x, a = blockIdx.y;
   const uint32_t tid = threadIdx.x;
   const DecChunk ds = dsec[(size_t)a * n_chunks + c];
+  if (ds.valid == 1u && to_cols >= 2u) {
+    // to_cols = 2: the DeltaVarint fields of the grid as well (sections_dv_body, in the arrays of the other modes) -- the
+    // workgroups of all modes share ONE launch instead of two half-idle ones in a row
+    static_assert(kSwsThreads == kScfThreads && kSwsMaxPal >= kScfTileBytes, "the DeltaVarint body's values fit `tab`");
+    static_assert(sizeof(end_pos) >= (kScfTileBytes / 4u + 8u) * 4u, "... and its tile `end_pos`");
+    sections_dv_body(plan, streams, ds, c, a, done_cnt, cols, reinterpret_cast<uint32_t*>(end_pos), tab, scan, flags);
+    return;
+  }
   if (ds.valid < 2u) return;  // not sized, or DeltaVarint (the stream kernel's)
   const uint32_t mode = ds.valid - 1u;
   const uint8_t* src = streams + ds.src_off;
@@ -370,18 +382,13 @@ __global__ __launch_bounds__(kSwsThreads) void k_sections_w(const DevPlan plan, 
 // scans number the tokens and add up the differences, the running count and sum stay in registers from slice to slice.
 // A section that is not exactly n tokens, a token of more than 5 bytes or a marker byte leaves the field to the kernels
 // behind (done_cnt is not raised).
-__global__ __launch_bounds__(kScfThreads) void k_sections_dv_cols(const DevPlan plan, const uint8_t* __restrict__ streams,
-                                                                  const DecChunk* __restrict__ dsec, uint32_t n_chunks,
-                                                                  uint32_t* __restrict__ done_cnt, const DecColumns cols) {
+// (LDS handed in: k_sections_w runs this body for the DeltaVarint fields of its grid in the arrays it has for the other modes)
+__device__ __forceinline__ void sections_dv_body(const DevPlan& plan, const uint8_t* __restrict__ streams, const DecChunk& dc, uint32_t c,
+                                                 uint32_t a, uint32_t* __restrict__ done_cnt, const DecColumns& cols,
+                                                 uint32_t* tile /* [kScfTileBytes / 4 + 8], 16-byte aligned */,
+                                                 uint32_t* vals /* [kScfTileBytes] */, uint32_t* scan /* [40] */, uint32_t* flags) {
   constexpr int T = (int)kScfThreads;
-  __shared__ __attribute__((aligned(16))) uint32_t tile[kScfTileBytes / 4u + 8u];  // 8 bytes of history, the slice's bytes, slack
-  __shared__ uint32_t vals[kScfTileBytes];
-  __shared__ uint32_t scan[40];
-  __shared__ uint32_t flags[2];
-  const uint32_t c = blockIdx.x, a = blockIdx.y;
   const uint32_t tid = threadIdx.x;
-  const DecChunk dc = dsec[(size_t)a * n_chunks + c];
-  if (dc.valid != 1u) return;  // another mode: k_sections_w
   const uint8_t* src = streams + dc.src_off;  // the section's body (behind the mode byte)
   const uint32_t src_size = dc.src_size;
   const uint32_t n = dc.n_points;
@@ -460,6 +467,19 @@ __global__ __launch_bounds__(kScfThreads) void k_sections_dv_cols(const DevPlan 
   }
   // every point has its token and the section's last byte ends one
   if (tid == 0u && pre_cnt == n && (src[src_size - 1u] & 0x80u) == 0u) atomicAdd(done_cnt + c, 1u);
+}
+
+__global__ __launch_bounds__(kScfThreads) void k_sections_dv_cols(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                                  const DecChunk* __restrict__ dsec, uint32_t n_chunks,
+                                                                  uint32_t* __restrict__ done_cnt, const DecColumns cols) {
+  __shared__ __attribute__((aligned(16))) uint32_t tile[kScfTileBytes / 4u + 8u];  // 8 bytes of history, the slice's bytes, slack
+  __shared__ uint32_t vals[kScfTileBytes];
+  __shared__ uint32_t scan[40];
+  __shared__ uint32_t flags[2];
+  const uint32_t c = blockIdx.x, a = blockIdx.y;
+  const DecChunk dc = dsec[(size_t)a * n_chunks + c];
+  if (dc.valid != 1u) return;  // another mode: k_sections_w
+  sections_dv_body(plan, streams, dc, c, a, done_cnt, cols, tile, vals, scan, flags);
 }
 
 // grid = ceil(n_chunks / 256): sec_done[c] = 1 for the chunks whose sections all arrived
