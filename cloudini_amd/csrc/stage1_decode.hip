@@ -217,6 +217,10 @@ int stage1_launch_decode(const DecodeLaunch& L) {
   hipLaunchKernelGGL((k_decode_points_w<NOPS_, NF_, NW_, WPE_>), dim3(L.n_chunks), dim3(NW_ * 64), (WpLds<NOPS_, NF_, NW_>::kTotal), \
                      L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done,   \
                      L.uses_v5, L.status, c0, c1, L.reg_end_pre, sc, fill_zero, dcols)
+#define LAUNCH_POINTS_W_SM(NOPS_, NF_, SM_)                                                                               \
+  hipLaunchKernelGGL((k_decode_points_w<NOPS_, NF_, 16, 8, SM_>), dim3(L.n_chunks), dim3(16 * 64), (WpLds<NOPS_, NF_, 16>::kTotal), \
+                     L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done,   \
+                     L.uses_v5, L.status, c0, c1, L.reg_end_pre, sc, fill_zero, dcols)
 #define LAUNCH_POINTS_ANY(NOPS_, NF_)                      \
   {                                                        \
     if (pk == 0) LAUNCH_POINTS(NOPS_, NF_);                \
@@ -225,7 +229,27 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     else if (pk == 126) LAUNCH_POINTS_W(NOPS_, NF_, 12, 6); \
     else LAUNCH_POINTS_W(NOPS_, NF_, 16, 8);               \
   }
-      if (P.n_ops == 3u) {
+      // store-mode instantiations of the two headline layouts (XYZ, XYZ + one 16-bit field): the layout facts the kernel
+      // otherwise keeps as uniform flags are checked here. CLDN_HIP_NO_STORE_MODES=1: A/B switch
+      static const bool no_sm = getenv("CLDN_HIP_NO_STORE_MODES") != nullptr;
+      int sm = 0;
+      if (!no_sm && pk == 16 && P.n_ops == 3u && nf <= 1u) {
+        bool ok = ((P.point_step | P.ops[0].offset) & 3u) == 0u && P.ops[0].offset != 0xffffffffu &&
+                  P.ops[1].offset == P.ops[0].offset + 4u && P.ops[2].offset == P.ops[0].offset + 8u;
+        if (nf == 1u) ok = ok && P.adaptive[0].bpv == 2u && ((P.adaptive[0].offset | P.point_step) & 1u) == 0u;
+        if (ok) {
+          sm = 1;
+          if (nf == 1u && fill_zero && P.point_step == 16u && P.ops[0].offset == 0u && P.adaptive[0].offset == 12u &&
+              ((uintptr_t)L.out & 15u) == 0u)
+            sm = 2;
+        }
+      }
+      if (P.n_ops == 3u && sm == 1) {
+        if (nf == 0u) LAUNCH_POINTS_W_SM(3, 0, 1);
+        else LAUNCH_POINTS_W_SM(3, 1, 1);
+      } else if (P.n_ops == 3u && sm == 2) {
+        LAUNCH_POINTS_W_SM(3, 1, 2);
+      } else if (P.n_ops == 3u) {
         if (nf == 0u) LAUNCH_POINTS_ANY(3, 0)
         else if (nf == 1u) LAUNCH_POINTS_ANY(3, 1)
         else if (nf == 2u) LAUNCH_POINTS_ANY(3, 2)
@@ -237,6 +261,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         else LAUNCH_POINTS_W(4, 8, 16, 8);
       }
 #undef LAUNCH_POINTS_ANY
+#undef LAUNCH_POINTS_W_SM
 #undef LAUNCH_POINTS_W
 #undef LAUNCH_POINTS
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_points");

@@ -135,7 +135,7 @@ __device__ __forceinline__ bool wp_tokens(const uint32_t* wbuf, uint32_t byte0, 
   return bad;
 }
 
-template <int NOPS, int NF, int NW, int WPE = 8>
+template <int NOPS, int NF, int NW, int WPE = 8, int SM = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_decode_points_w(
     const DevPlan plan, const uint8_t* __restrict__ streams, const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
     uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done, uint32_t uses_v5, uint32_t* __restrict__ status,
@@ -216,16 +216,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     fs_ioff[a] = a < n_fold ? sct.index_off : 0u;
   }
   // which store forms the layout allows (uniform)
+  // SM != 0: the launcher has checked the layout (stage1_launch_decode: three floats back to back at a 4-byte aligned offset,
+  // at most one integer field, of 2 bytes at an even offset; SM == 2: 16-byte points x y z + the field at 12, an aligned cloud and
+  // CLDN_HIP_FILL_ZERO) -- the forms below are then compile-time facts instead of seven uniform flags and their branches
   bool contig = ((step | plan.ops[0].offset) & 3u) == 0u;
 #pragma unroll
   for (int o = 1; o < NOPS; ++o) contig = contig && plan.ops[o].offset == plan.ops[0].offset + 4u * (uint32_t)o;
+  if (SM != 0) contig = true;
   // the first three floats back to back and 4-byte aligned, the rest of the lanes elsewhere. Only for the many-column merge
   // (Ouster-style points, same box: 1.24 -> 1.11 ms); PCL's padded PointXYZI alone is 3 % slower with the 12-byte store
-  const bool lead3 = MANY && NOPS > 3 && ((step | plan.ops[0].offset) & 3u) == 0u && plan.ops[0].offset != 0xffffffffu &&
+  const bool lead3 = SM == 0 && MANY && NOPS > 3 && ((step | plan.ops[0].offset) & 3u) == 0u && plan.ops[0].offset != 0xffffffffu &&
                      plan.ops[1].offset == plan.ops[0].offset + 4u && plan.ops[2].offset == plan.ops[0].offset + 8u;
   bool packed = true;  // the floats back to back at any alignment, all of them stored
 #pragma unroll
   for (int o = 0; o < NOPS; ++o) packed = packed && plan.ops[o].offset != 0xffffffffu && plan.ops[o].offset == plan.ops[0].offset + 4u * (uint32_t)o;
+  if (SM != 0) packed = false;
   float res[NOPS];
   uint32_t foff[NOPS];
 #pragma unroll
@@ -233,11 +238,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     res[o] = plan.ops[o].res_f;
     foff[o] = plan.ops[o].offset;
   }
-  const bool one_u16 = NOPS == 3 && contig && n_fold == 1u && fs_bpv[0] == 2u && ((fs_off[0] | step) & 1u) == 0u;  // XYZ + one 16-bit field
+  const bool one_u16 = SM != 0 ? (n_fold == 1u) : (NOPS == 3 && contig && n_fold == 1u && fs_bpv[0] == 2u && ((fs_off[0] | step) & 1u) == 0u);  // XYZ + one 16-bit field
   // fill_zero (CLDN_HIP_FILL_ZERO: the bytes no field covers may be written as 0): the two common padded layouts leave
   // as whole 16-byte stores
-  const bool full16 = fill_zero != 0u && one_u16 && step == 16u && foff[0] == 0u && fs_off[0] == 12u && ((uintptr_t)base & 15u) == 0u;
-  const bool full32 = fill_zero != 0u && NOPS == 3 && contig && n_fold == 1u && fs_bpv[0] == 4u && step == 32u && foff[0] == 0u &&
+  const bool full16 = SM == 2 ? one_u16 : (SM == 1 ? false : (fill_zero != 0u && one_u16 && step == 16u && foff[0] == 0u && fs_off[0] == 12u && ((uintptr_t)base & 15u) == 0u));
+  const bool full32 = SM == 0 && fill_zero != 0u && NOPS == 3 && contig && n_fold == 1u && fs_bpv[0] == 4u && step == 32u && foff[0] == 0u &&
                       fs_off[0] == 16u && ((uintptr_t)base & 15u) == 0u;
 
   // ---------------------------------------------------------------------------------------------------------
