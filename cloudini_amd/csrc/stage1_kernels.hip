@@ -1260,6 +1260,92 @@ namespace cldn {
 
 }  // namespace cldn
 
+namespace cldn {
+
+// ---------------------------------------------------------------------------------------------------------
+// k_encode_fixed (round 4): regular streams whose per-point encoders all write a FIXED number of bytes --
+// FieldEncoderFloat_XOR<float / double> (EncodingOptions::LOSSLESS: bits(cur) ^ bits(prev), prev = 0 at a chunk's first
+// point, include/cloudini_lib/field_encoder.hpp:359-370) and FieldEncoderCopy (:56-60). Point i of a chunk then lies at byte
+// i * P of the chunk's stream, P = the sum of the field sizes: no lengths, no scan, one thread per point. The general kernel
+// (op interpreter over an LDS tile, two passes) ran a lossless XYZI batch at 1.7 TB/s.
+// grid (chunks, 32768 / 256) x 256. The stream leaves as the `subs` sub-streams the slot layout of the call reserves.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t fixed_load(const uint8_t* q, uint32_t nbytes) {
+  uint64_t v = 0u;
+  if (nbytes == 4u) {
+    uint32_t w;
+    __builtin_memcpy(&w, q, 4);
+    v = w;
+  } else if (nbytes == 8u) {
+    __builtin_memcpy(&v, q, 8);
+  } else if (nbytes == 2u) {
+    uint16_t h;
+    __builtin_memcpy(&h, q, 2);
+    v = h;
+  } else {
+    for (uint32_t b = 0; b < nbytes; ++b) v |= (uint64_t)q[b] << (8u * b);
+  }
+  return v;
+}
+__device__ __forceinline__ void fixed_store(uint8_t* q, uint64_t v, uint32_t nbytes) {
+  if (nbytes == 4u) {
+    const uint32_t w = (uint32_t)v;
+    __builtin_memcpy(q, &w, 4);
+  } else if (nbytes == 8u) {
+    __builtin_memcpy(q, &v, 8);
+  } else if (nbytes == 2u) {
+    const uint16_t h = (uint16_t)v;
+    __builtin_memcpy(q, &h, 2);
+  } else {
+    for (uint32_t b = 0; b < nbytes; ++b) q[b] = (uint8_t)(v >> (8u * b));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_encode_fixed(const DevPlan plan, const uint8_t* __restrict__ points,
+                                                      const ChunkDesc* __restrict__ chunks, uint8_t* __restrict__ slots,
+                                                      uint64_t slot_stride, Seg* __restrict__ segs, uint32_t segs_per_chunk,
+                                                      uint32_t subs, uint32_t sub_points, uint32_t sub_stride, uint32_t point_bytes) {
+  const uint32_t c = blockIdx.x;
+  const uint32_t i = blockIdx.y * 256u + threadIdx.x;  // point of the chunk
+  const ChunkDesc cd = chunks[c];
+  const uint32_t n = cd.n_points;
+  const uint32_t step = plan.point_step;
+  uint8_t* slot = slots + (size_t)c * slot_stride;
+  if (i < subs) {  // segment s: the points [s, s + 1) * sub_points of the chunk
+    const uint32_t first = i * sub_points;
+    Seg sg;
+    sg.off = i * sub_stride;
+    sg.size = (n > first ? min(sub_points, n - first) : 0u) * point_bytes;
+    segs[(size_t)c * segs_per_chunk + i] = sg;
+  }
+  if (i >= n) return;
+  const uint8_t* src = points + ((size_t)cd.first_point + i) * step;
+  const uint32_t s = i / sub_points;
+  uint8_t* dst = slot + (size_t)s * sub_stride + (size_t)(i - s * sub_points) * point_bytes;
+  // four 32-bit XOR fields back to back in a 16-byte point (lossless XYZI): whole-point loads and one store
+  const bool quad = step == 16u && point_bytes == 16u && plan.n_ops == 4u && plan.ops[0].kind == OP_XOR32 &&
+                    plan.ops[1].kind == OP_XOR32 && plan.ops[2].kind == OP_XOR32 && plan.ops[3].kind == OP_XOR32 &&
+                    plan.ops[0].offset == 0u && plan.ops[1].offset == 4u && plan.ops[2].offset == 8u && plan.ops[3].offset == 12u;  // (uniform)
+  if (quad) {
+    uint4 cur, pv = make_uint4(0u, 0u, 0u, 0u);
+    __builtin_memcpy(&cur, src, 16);
+    if (i != 0u) __builtin_memcpy(&pv, src - 16, 16);
+    const uint4 o = make_uint4(cur.x ^ pv.x, cur.y ^ pv.y, cur.z ^ pv.z, cur.w ^ pv.w);
+    __builtin_memcpy(dst, &o, 16);
+    return;
+  }
+  uint32_t at = 0u;
+  for (uint32_t k = 0; k < plan.n_ops; ++k) {  // (uniform)
+    const uint32_t size = plan.ops[k].size, off = plan.ops[k].offset;
+    uint64_t v = fixed_load(src + off, size);
+    if (plan.ops[k].kind != OP_COPY && i != 0u) v ^= fixed_load(src - step + off, size);
+    fixed_store(dst + at, v, size);
+    at += size;
+  }
+}
+
+}  // namespace cldn
+
 #include "stage1_sections.h"
 #include "stage1_fused.h"
 #include "stage1_finish.h"
@@ -2093,6 +2179,19 @@ extern "C" __attribute__((visibility("default"))) int cldn_hip_debug_finish_trac
   return hipMemcpy(host_out, g_fin_trace, (size_t)n_chunks * 16u * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
 
+// bytes per point of a regular stream made of fixed-size encoders only (XOR-coded floats, raw copies), 0 otherwise
+static uint32_t fixed_point_bytes(const DevPlan& P) {
+  static const bool off = getenv("CLDN_HIP_NO_FIXED_ENCODE") != nullptr;  // A/B switch
+  if (off || P.n_ops == 0u || P.n_adaptive != 0u || P.n_gorilla != 0u) return 0u;
+  uint32_t bytes = 0u;
+  for (uint32_t k = 0; k < P.n_ops; ++k) {
+    const uint32_t kd = P.ops[k].kind;
+    if (kd != OP_COPY && kd != OP_XOR32 && kd != OP_XOR64) return 0u;
+    bytes += P.ops[k].size;
+  }
+  return bytes;
+}
+
 int stage1_launch_encode(const EncodeLaunch& L) {
   hipError_t e;
   // CLDN_HIP_FINISH (A/B switch): 0 = the round-2 kernels (k_chunk_offsets + k_compact), 1 = k_finish without the fused
@@ -2123,6 +2222,12 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   if (L.n_chunks && L.pieces) {  // slot pipeline, regular stream by the barrier-free piece kernel
     const int rc = launch_fused(L, L.stream, 0u, L.n_pieces, &modes_probed);
     if (rc != CLDN_HIP_OK) return rc;
+  } else if (L.n_chunks && fixed_point_bytes(*L.plan) != 0u) {
+    // every per-point encoder writes a fixed number of bytes (lossless floats, raw copies) and no integer field leaves as
+    // a column: one thread per point. CLDN_HIP_NO_FIXED_ENCODE=1: A/B switch (handled in fixed_point_bytes)
+    hipLaunchKernelGGL(k_encode_fixed, dim3(L.n_chunks, kPointsPerChunk / 256u), dim3(256), 0, L.stream, *L.plan, L.points, L.chunks,
+                       L.slots, L.slot_stride, L.segs, L.segs_per_chunk, L.subs, L.sub_points, L.sub_stride, fixed_point_bytes(*L.plan));
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_fixed");
   } else if (L.n_chunks) {
     int l3 = 3;
     const int lanes = floatn_lanes(*L.plan, L.points, &l3);
