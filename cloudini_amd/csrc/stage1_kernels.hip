@@ -1266,7 +1266,8 @@ namespace cldn {
 // k_encode_fixed (round 4): regular streams whose per-point encoders all write a FIXED number of bytes --
 // FieldEncoderFloat_XOR<float / double> (EncodingOptions::LOSSLESS: bits(cur) ^ bits(prev), prev = 0 at a chunk's first
 // point, include/cloudini_lib/field_encoder.hpp:359-370) and FieldEncoderCopy (:56-60). Point i of a chunk then lies at byte
-// i * P of the chunk's stream, P = the sum of the field sizes: no lengths, no scan, one thread per point. The general kernel
+// i * P of the chunk's stream, P = the sum of the field sizes: no lengths, no scan, one thread per point (which also writes the
+// point's integer fields to their SoA columns, the section kernels' input). The general kernel
 // (op interpreter over an LDS tile, two passes) ran a lossless XYZI batch at 1.7 TB/s.
 // grid (chunks, 32768 / 256) x 256. The stream leaves as the `subs` sub-streams the slot layout of the call reserves.
 // ---------------------------------------------------------------------------------------------------------
@@ -1304,7 +1305,8 @@ __device__ __forceinline__ void fixed_store(uint8_t* q, uint64_t v, uint32_t nby
 __global__ __launch_bounds__(256) void k_encode_fixed(const DevPlan plan, const uint8_t* __restrict__ points,
                                                       const ChunkDesc* __restrict__ chunks, uint8_t* __restrict__ slots,
                                                       uint64_t slot_stride, Seg* __restrict__ segs, uint32_t segs_per_chunk,
-                                                      uint32_t subs, uint32_t sub_points, uint32_t sub_stride, uint32_t point_bytes) {
+                                                      uint32_t subs, uint32_t sub_points, uint32_t sub_stride, uint32_t point_bytes,
+                                                      const ColumnPtrs cols) {
   const uint32_t c = blockIdx.x;
   const uint32_t i = blockIdx.y * 256u + threadIdx.x;  // point of the chunk
   const ChunkDesc cd = chunks[c];
@@ -1320,6 +1322,11 @@ __global__ __launch_bounds__(256) void k_encode_fixed(const DevPlan plan, const 
   }
   if (i >= n) return;
   const uint8_t* src = points + ((size_t)cd.first_point + i) * step;
+  // the integer fields of the schema (V5 sections): AoS -> SoA columns for the section kernels (uniform loop)
+  for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
+    const uint32_t bpv = plan.adaptive[a].bpv;
+    fixed_store(cols.p[a] + ((size_t)cd.first_point + i) * bpv, fixed_load(src + plan.adaptive[a].offset, bpv), bpv);
+  }
   const uint32_t s = i / sub_points;
   uint8_t* dst = slot + (size_t)s * sub_stride + (size_t)(i - s * sub_points) * point_bytes;
   // four 32-bit XOR fields back to back in a 16-byte point (lossless XYZI): whole-point loads and one store
@@ -2182,7 +2189,7 @@ extern "C" __attribute__((visibility("default"))) int cldn_hip_debug_finish_trac
 // bytes per point of a regular stream made of fixed-size encoders only (XOR-coded floats, raw copies), 0 otherwise
 static uint32_t fixed_point_bytes(const DevPlan& P) {
   static const bool off = getenv("CLDN_HIP_NO_FIXED_ENCODE") != nullptr;  // A/B switch
-  if (off || P.n_ops == 0u || P.n_adaptive != 0u || P.n_gorilla != 0u) return 0u;
+  if (off || P.n_ops == 0u || P.n_gorilla != 0u) return 0u;
   uint32_t bytes = 0u;
   for (uint32_t k = 0; k < P.n_ops; ++k) {
     const uint32_t kd = P.ops[k].kind;
@@ -2223,10 +2230,10 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     const int rc = launch_fused(L, L.stream, 0u, L.n_pieces, &modes_probed);
     if (rc != CLDN_HIP_OK) return rc;
   } else if (L.n_chunks && fixed_point_bytes(*L.plan) != 0u) {
-    // every per-point encoder writes a fixed number of bytes (lossless floats, raw copies) and no integer field leaves as
-    // a column: one thread per point. CLDN_HIP_NO_FIXED_ENCODE=1: A/B switch (handled in fixed_point_bytes)
+    // every per-point encoder writes a fixed number of bytes (lossless floats, raw copies): one thread per point, which also
+    // splits the integer fields off into their columns. CLDN_HIP_NO_FIXED_ENCODE=1: A/B switch (handled in fixed_point_bytes)
     hipLaunchKernelGGL(k_encode_fixed, dim3(L.n_chunks, kPointsPerChunk / 256u), dim3(256), 0, L.stream, *L.plan, L.points, L.chunks,
-                       L.slots, L.slot_stride, L.segs, L.segs_per_chunk, L.subs, L.sub_points, L.sub_stride, fixed_point_bytes(*L.plan));
+                       L.slots, L.slot_stride, L.segs, L.segs_per_chunk, L.subs, L.sub_points, L.sub_stride, fixed_point_bytes(*L.plan), L.cols);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_fixed");
   } else if (L.n_chunks) {
     int l3 = 3;
