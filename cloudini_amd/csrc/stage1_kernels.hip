@@ -1306,14 +1306,26 @@ __global__ __launch_bounds__(256) void k_encode_fixed(const DevPlan plan, const 
                                                       const ChunkDesc* __restrict__ chunks, uint8_t* __restrict__ slots,
                                                       uint64_t slot_stride, Seg* __restrict__ segs, uint32_t segs_per_chunk,
                                                       uint32_t subs, uint32_t sub_points, uint32_t sub_stride, uint32_t point_bytes,
-                                                      const ColumnPtrs cols) {
+                                                      const ColumnPtrs cols, uint8_t* __restrict__ direct_out,
+                                                      uint32_t* __restrict__ chunk_payload, uint64_t* __restrict__ chunk_dst) {
   const uint32_t c = blockIdx.x;
   const uint32_t i = blockIdx.y * 256u + threadIdx.x;  // point of the chunk
   const ChunkDesc cd = chunks[c];
   const uint32_t n = cd.n_points;
   const uint32_t step = plan.point_step;
   uint8_t* slot = slots + (size_t)c * slot_stride;
-  if (i < subs) {  // segment s: the points [s, s + 1) * sub_points of the chunk
+  // DIRECT PLACEMENT (direct_out != NULL; schemas without integer columns): every chunk's payload is n * P bytes, so chunk c of
+  // the batch begins at byte 4 c + P * (points in front of it) of the framed streams -- the bytes go straight to their final
+  // place, [u32 size] included: no slot, no k_finish
+  const uint64_t d0 = 4ull * c + (uint64_t)point_bytes * cd.first_point;
+  if (direct_out != nullptr) {
+    if (i == 0u) {
+      const uint32_t payload = n * point_bytes;
+      __builtin_memcpy(direct_out + d0, &payload, 4);
+      chunk_payload[c] = payload;
+      chunk_dst[c] = d0;
+    }
+  } else if (i < subs) {  // segment s: the points [s, s + 1) * sub_points of the chunk
     const uint32_t first = i * sub_points;
     Seg sg;
     sg.off = i * sub_stride;
@@ -1328,7 +1340,8 @@ __global__ __launch_bounds__(256) void k_encode_fixed(const DevPlan plan, const 
     fixed_store(cols.p[a] + ((size_t)cd.first_point + i) * bpv, fixed_load(src + plan.adaptive[a].offset, bpv), bpv);
   }
   const uint32_t s = i / sub_points;
-  uint8_t* dst = slot + (size_t)s * sub_stride + (size_t)(i - s * sub_points) * point_bytes;
+  uint8_t* dst = direct_out != nullptr ? direct_out + d0 + 4u + (size_t)i * point_bytes
+                                       : slot + (size_t)s * sub_stride + (size_t)(i - s * sub_points) * point_bytes;
   // four 32-bit XOR fields back to back in a 16-byte point (lossless XYZI): whole-point loads and one store
   const bool quad = step == 16u && point_bytes == 16u && plan.n_ops == 4u && plan.ops[0].kind == OP_XOR32 &&
                     plan.ops[1].kind == OP_XOR32 && plan.ops[2].kind == OP_XOR32 && plan.ops[3].kind == OP_XOR32 &&
@@ -1349,6 +1362,17 @@ __global__ __launch_bounds__(256) void k_encode_fixed(const DevPlan plan, const 
     fixed_store(dst + at, v, size);
     at += size;
   }
+}
+
+// stream offset of every cloud for the direct placement of k_encode_fixed: where its first chunk begins (a cloud without chunks:
+// where the next one does), and the batch's end
+__global__ __launch_bounds__(256) void k_fixed_offsets(const ChunkDesc* __restrict__ chunks, const uint32_t* __restrict__ cloud_first_chunk,
+                                                       uint32_t n_clouds, uint32_t n_chunks, uint32_t point_bytes, uint64_t total,
+                                                       uint64_t* __restrict__ stream_offsets) {
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k > n_clouds) return;
+  const uint32_t fc = k < n_clouds ? cloud_first_chunk[k] : n_chunks;
+  stream_offsets[k] = fc < n_chunks ? 4ull * fc + (uint64_t)point_bytes * chunks[fc].first_point : total;
 }
 
 }  // namespace cldn
@@ -2232,9 +2256,28 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   } else if (L.n_chunks && fixed_point_bytes(*L.plan) != 0u) {
     // every per-point encoder writes a fixed number of bytes (lossless floats, raw copies): one thread per point, which also
     // splits the integer fields off into their columns. CLDN_HIP_NO_FIXED_ENCODE=1: A/B switch (handled in fixed_point_bytes)
+    const uint32_t pb = fixed_point_bytes(*L.plan);
+    const uint64_t total_points = (uint64_t)(L.points_end - L.points) / L.plan->point_step;
+    const uint64_t total = 4ull * L.n_chunks + (uint64_t)pb * total_points;
+    // without integer columns every size is known here: the kernel writes the framed streams themselves (an output that is too
+    // small takes the slot path, whose k_finish reports it). CLDN_HIP_NO_FIXED_DIRECT=1: A/B switch
+    static const bool no_direct = getenv("CLDN_HIP_NO_FIXED_DIRECT") != nullptr;
+    const bool direct = !no_direct && !L.chunks_only && finish_mode != 0 && L.plan->n_adaptive == 0u && total <= L.out_capacity;
     hipLaunchKernelGGL(k_encode_fixed, dim3(L.n_chunks, kPointsPerChunk / 256u), dim3(256), 0, L.stream, *L.plan, L.points, L.chunks,
-                       L.slots, L.slot_stride, L.segs, L.segs_per_chunk, L.subs, L.sub_points, L.sub_stride, fixed_point_bytes(*L.plan), L.cols);
+                       L.slots, L.slot_stride, L.segs, L.segs_per_chunk, L.subs, L.sub_points, L.sub_stride, pb, L.cols,
+                       direct ? L.out : (uint8_t*)nullptr, L.chunk_payload, L.chunk_dst);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_fixed");
+    if (direct) {
+      hipLaunchKernelGGL(k_fixed_offsets, dim3((L.n_clouds + 256u) / 256u), dim3(256), 0, L.stream, L.chunks, L.cloud_first_chunk, L.n_clouds,
+                         L.n_chunks, pb, total, L.stream_offsets);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_fixed_offsets");
+      if (L.events) {
+        (void)hipEventRecord(L.events[2], L.stream);
+        (void)hipEventRecord(L.events[3], L.stream);
+        (void)hipEventRecord(L.events[4], L.stream);
+      }
+      return CLDN_HIP_OK;
+    }
   } else if (L.n_chunks) {
     int l3 = 3;
     const int lanes = floatn_lanes(*L.plan, L.points, &l3);
