@@ -293,13 +293,23 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       // CLDN_HIP_STREAM_BITMAP=1 keeps k_mark_token_ends' bitmap in front of it (A/B switch)
       static const bool force_bitmap = getenv("CLDN_HIP_STREAM_BITMAP") != nullptr;
       const bool form = stream_ok && !all_raw && !force_bitmap;
-      const bool bitmap = !(stream_ok && all_raw) && !form;
+      // streams of fixed-size tokens only (lossless floats, raw copies; <= 8 fields): nothing to find, k_decode_fixed.
+      // CLDN_HIP_NO_FIXED_DECODE=1: the stream kernel (A/B switch)
+      static const bool no_fixed_dec = getenv("CLDN_HIP_NO_FIXED_DECODE") != nullptr;
+      uint32_t fixed_bytes = 0u;
+      if (!no_fixed_dec && all_raw && P.n_ops <= kFxMaxOps && P.n_gorilla == 0u)
+        for (uint32_t k = 0; k < P.n_ops; ++k) fixed_bytes += P.ops[k].size;
+      const bool bitmap = !(stream_ok && all_raw) && !form && fixed_bytes == 0u;
       if (bitmap) {
         hipLaunchKernelGGL(k_mark_token_ends, dim3(L.n_chunks), dim3(kMtThreads), 0, L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), L.token_ends, L.reg_end);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_mark_token_ends");
       }
-      if (form) {
+      if (fixed_bytes != 0u) {
+        hipLaunchKernelGGL(k_decode_fixed, dim3(L.n_chunks), dim3(kFxThreads), 0, L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, fixed_bytes);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_fixed");
+      } else if (form) {
         hipLaunchKernelGGL((k_decode_stream_w<12, 1>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, true>::kTotal), L.stream, P,
                            L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{}, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (form)");

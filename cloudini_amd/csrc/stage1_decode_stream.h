@@ -965,4 +965,158 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_decode_fixed (end of round 4): regular streams of fixed-size tokens only -- FieldDecoderFloat_XOR<float / double>
+// (EncodingOptions::LOSSLESS, include/cloudini_lib/field_decoder.hpp: the value is the running XOR of the stream's words) and
+// FieldDecoderCopy. Point i of a chunk lies at byte i * P of the stream (P = the sum of the field sizes), so nothing has to be
+// found: one workgroup per chunk walks it in tiles of 1024 points, a thread loads its point's fields, the running XOR of every
+// field is one DPP scan per wave + one exchange of the waves' totals per tile (double-buffered: one barrier), and the point leaves
+// with one store per field. The stream kernel decoded these streams with its token machinery at 1.35 TB/s.
+// At most kFxMaxOps fields; anything else (or a payload shorter than n * P) leaves the chunk to the kernels behind (kDecRedo).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kFxMaxOps = 8;
+constexpr uint32_t kFxThreads = 1024;
+
+__global__ __launch_bounds__(kFxThreads) void k_decode_fixed(const DevPlan plan, const uint8_t* __restrict__ streams,
+                                                             const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
+                                                             uint32_t* __restrict__ reg_end, uint32_t* __restrict__ status,
+                                                             uint32_t point_bytes) {
+  __shared__ uint64_t wtot[2][kFxThreads / 64u][kFxMaxOps];
+  const uint32_t c = blockIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const DecChunk dc = chunks[c];
+  if (!dc.valid) return;
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t n = dc.n_points;
+  const uint32_t n_ops = plan.n_ops;
+  const uint64_t need = (uint64_t)n * point_bytes;
+  const bool ok = n_ops <= kFxMaxOps && need <= dc.src_size && (plan.n_adaptive != 0u || need == dc.src_size);  // (uniform)
+  if (!ok) {
+    if (tid == 0) reg_end[c] = kDecRedo;
+    return;
+  }
+  const uint32_t step = plan.point_step;
+  uint8_t* base = out + (size_t)dc.first_point * step;
+  // four 32-bit XOR fields back to back in a 16-byte point (lossless XYZI): one 16-byte load and store per point, 32-bit scans,
+  // the waves' totals scanned by 16 lanes instead of read by everybody
+  const bool quad = step == 16u && point_bytes == 16u && n_ops == 4u && plan.ops[0].kind == OP_XOR32 && plan.ops[1].kind == OP_XOR32 &&
+                    plan.ops[2].kind == OP_XOR32 && plan.ops[3].kind == OP_XOR32 && plan.ops[0].offset == 0u && plan.ops[1].offset == 4u &&
+                    plan.ops[2].offset == 8u && plan.ops[3].offset == 12u;  // (uniform)
+  if (quad) {
+    uint32_t* wt32 = reinterpret_cast<uint32_t*>(&wtot[0][0][0]);  // [2][16 waves][4]
+    auto xscan = [](uint32_t x) __attribute__((always_inline)) {
+#define FX_STEP(CTRL, RMASK, BC) x ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, RMASK, 0xf, BC);
+      FX_STEP(0x111, 0xf, true)
+      FX_STEP(0x112, 0xf, true)
+      FX_STEP(0x114, 0xf, true)
+      FX_STEP(0x118, 0xf, true)
+      FX_STEP(0x142, 0xa, false)
+      FX_STEP(0x143, 0xc, false)
+#undef FX_STEP
+      return x;
+    };
+    uint32_t r[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t t0 = 0, tile = 0; t0 < n; t0 += kFxThreads, ++tile) {
+      const uint32_t i = t0 + tid;
+      const bool have = i < n;
+      uint4 q4 = make_uint4(0u, 0u, 0u, 0u);
+      __builtin_memcpy(&q4, src + (size_t)(have ? i : 0u) * 16u, 16);
+      uint32_t in[4] = {have ? q4.x : 0u, have ? q4.y : 0u, have ? q4.z : 0u, have ? q4.w : 0u};
+      uint32_t inc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) inc[k] = xscan(in[k]);
+      uint32_t* wt = wt32 + (tile & 1u) * 64u;
+      if (lane == 63u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wt[wave * 4u + k] = inc[k];
+      }
+      __syncthreads();
+      uint32_t before[4], all[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t tw = lane < 16u ? wt[lane * 4u + k] : 0u;  // lane w: wave w's total
+        const uint32_t sc = xscan(tw);                             // inclusive over the waves
+        all[k] = (uint32_t)__builtin_amdgcn_readlane((int)sc, 15);
+        const uint32_t ex = sc ^ tw;                               // exclusive
+        before[k] = (uint32_t)__builtin_amdgcn_readlane((int)ex, (int)wave);
+      }
+      if (have) {
+        const uint4 o = make_uint4(r[0] ^ before[0] ^ inc[0], r[1] ^ before[1] ^ inc[1], r[2] ^ before[2] ^ inc[2], r[3] ^ before[3] ^ inc[3]);
+        __builtin_memcpy(base + (size_t)i * 16u, &o, 16);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] ^= all[k];
+    }
+    if (tid == 0) {
+      reg_end[c] = (uint32_t)need;
+      atomicAdd(&status[kStatFastRegular], 1u);
+    }
+    return;
+  }
+  uint64_t run[kFxMaxOps];  // running XOR of every field in front of the tile (uniform)
+#pragma unroll
+  for (uint32_t k = 0; k < kFxMaxOps; ++k) run[k] = 0ull;
+  for (uint32_t t0 = 0, tile = 0; t0 < n; t0 += kFxThreads, ++tile) {
+    const uint32_t i = t0 + tid;
+    const bool have = i < n;
+    const uint8_t* q = src + (size_t)(have ? i : 0u) * point_bytes;
+    uint64_t v[kFxMaxOps], incl[kFxMaxOps];
+    uint32_t at = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < kFxMaxOps; ++k) {
+      v[k] = 0ull;
+      if (k < n_ops) {  // (uniform)
+        const uint32_t size = plan.ops[k].size;
+        uint64_t x = 0ull;
+        if (size == 4u) {
+          uint32_t w;
+          __builtin_memcpy(&w, q + at, 4);
+          x = w;
+        } else if (size == 8u) {
+          __builtin_memcpy(&x, q + at, 8);
+        } else {
+          for (uint32_t b = 0; b < size; ++b) x |= (uint64_t)q[at + b] << (8u * b);
+        }
+        v[k] = have ? x : 0ull;
+        at += size;
+      }
+    }
+    const uint32_t buf = tile & 1u;
+#pragma unroll
+    for (uint32_t k = 0; k < kFxMaxOps; ++k) {
+      incl[k] = 0ull;
+      if (k < n_ops && plan.ops[k].kind != OP_COPY) {
+        incl[k] = sw_scan64<true>(v[k]);
+        if (lane == 63u) wtot[buf][wave][k] = incl[k];
+      }
+    }
+    __syncthreads();  // (the other buffer is read by nobody any more: the previous tile's readers passed the barrier before it)
+#pragma unroll
+    for (uint32_t k = 0; k < kFxMaxOps; ++k) {
+      if (k < n_ops) {
+        const uint32_t off = plan.ops[k].offset;
+        const uint32_t size = plan.ops[k].size;
+        uint64_t val = v[k];
+        if (plan.ops[k].kind != OP_COPY) {
+          uint64_t before = run[k], all = 0ull;
+#pragma unroll
+          for (uint32_t w = 0; w < kFxThreads / 64u; ++w) {
+            const uint64_t x = wtot[buf][w][k];
+            before ^= w < wave ? x : 0ull;
+            all ^= x;
+          }
+          val = before ^ incl[k];
+          run[k] ^= all;
+        }
+        if (have && off != 0xffffffffu) st_raw(base + (size_t)i * step + off, val, size);
+      }
+    }
+  }
+  if (tid == 0) {
+    reg_end[c] = (uint32_t)need;
+    atomicAdd(&status[kStatFastRegular], 1u);
+  }
+}
+
 }  // namespace cldn
