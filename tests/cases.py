@@ -347,6 +347,8 @@ def encode_cases(small=False):
     out.append(("mixed_v4", *mixed_schema(40000, 4)))
     out.append(("mixed_lossless", *mixed_schema_lossless(30000)))
     out.append(("mixed_none", *mixed_schema(20000, 5, EncodingOptions.NONE)))
+    for name, case in lossless_float_clouds(small):
+        out.append((name, *case))
     out.append(("ouster_like_gorilla", *ouster_like()))
     out.append(("gorilla_pair_lossless", *gorilla_pair()))
     out.append(("five_floats", *five_floats()))
@@ -363,6 +365,32 @@ def encode_cases(small=False):
     out.append(("pcl_xyzi_step32", *padded_fourth_lane("pcl_xyzi")))
     out.append(("ouster_step48", *padded_fourth_lane("ouster")))
     out.extend(stride_variants())
+    return out
+
+
+def lossless_float_clouds(small=False):
+    """EncodingOptions::LOSSLESS clouds made of floats only: every per-point encoder is FieldEncoderFloat_XOR (fixed-size
+    tokens) -- the layouts k_encode_fixed / k_decode_fixed take, with their 16-byte fast path (x y z intensity), the general
+    path (12-byte points, doubles, a padded stride) and chunk tails that are no multiple of a tile or of a sub-stream."""
+    rs = np.random.RandomState(77)
+    out = []
+    n = 40001 if small else 70001
+    f4 = [("x", 0, F.FLOAT32, None), ("y", 4, F.FLOAT32, None), ("z", 8, F.FLOAT32, None), ("intensity", 12, F.FLOAT32, None)]
+    info = make_info(f4, 16, n, enc=EncodingOptions.LOSSLESS)
+    cols = {"x": np.cumsum(rs.normal(0, 0.01, n)).astype(np.float32), "y": rs.uniform(-5, 5, n).astype(np.float32),
+            "z": rs.uniform(-1, 1, n).astype(np.float32), "intensity": rs.randint(0, 255, n).astype(np.float32)}
+    cols["y"][100:110] = np.nan
+    cols["z"][5] = np.inf
+    out.append(("lossless_xyzi", (info, pack(info, cols, n))))
+    n3 = 32768 + 1
+    f3 = [("x", 0, F.FLOAT32, None), ("y", 4, F.FLOAT32, None), ("z", 8, F.FLOAT32, None)]
+    info3 = make_info(f3, 12, n3, enc=EncodingOptions.LOSSLESS)
+    out.append(("lossless_xyz12", (info3, pack(info3, {k: cols[k][:n3] for k in ("x", "y", "z")}, n3))))
+    nd = 33000
+    fd = [("a", 0, F.FLOAT64, 1e-6), ("f", 8, F.FLOAT32, None), ("b", 16, F.FLOAT64, 1e-9)]   # padded 28-byte stride, a gap at 12
+    infod = make_info(fd, 28, nd, enc=EncodingOptions.LOSSLESS)
+    out.append(("lossless_f64_padded", (infod, pack(infod, {"a": np.cumsum(rs.uniform(0, 1e-3, nd)), "f": rs.uniform(-1, 1, nd).astype(np.float32),
+                                                             "b": np.sin(np.arange(nd) / 300.0)}, nd))))
     return out
 
 
