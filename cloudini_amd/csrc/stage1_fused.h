@@ -28,10 +28,36 @@ __host__ __device__ constexpr uint32_t fused_piece_points(int lanes) { return fu
 __host__ __device__ constexpr uint32_t fused_region_bytes(int lanes) {
   return ((fused_piece_points(lanes) * 5u * (uint32_t)lanes + 15u) & ~15u) + 32u;
 }
+// Round 5: the instantiations without a TAIL op size the region for 3 bytes per token (18.3 KB per workgroup instead of 30.4:
+// more workgroups per CU). A piece whose tokens do not fit -- deltas of 2^20 ticks and more on average, i.e. noise over
+// kilometres at 1 mm -- is written by fused_slow_piece straight from the input instead (same bytes, slowly).
+#ifndef CLDN_FUSED_SMALL_REGION
+#define CLDN_FUSED_SMALL_REGION 1
+#endif
+__host__ __device__ constexpr uint32_t fused_region_cap_small(int lanes) {
+  return (fused_piece_points(lanes) * 3u * (uint32_t)lanes + 15u) & ~15u;
+}
+__host__ __device__ constexpr uint32_t fused_region_bytes_small(int lanes) { return fused_region_cap_small(lanes) + 32u; }
 // ... with one more token of up to kTailMaxBytes behind the FloatN tokens of every point (TAIL instantiations)
 constexpr uint32_t kTailMaxBytes = 10;  // varint of an int64 delta, Gorilla token (13 + 64 bits), raw 8 bytes
 __host__ __device__ constexpr uint32_t fused_region_bytes_tail(int lanes) {
   return ((fused_piece_points(lanes) * (5u * (uint32_t)lanes + kTailMaxBytes) + 15u) & ~15u) + 32u;
+}
+
+// ceil(bits / 7) for bits < 2^16 on the full-rate 24-bit multiply-add (groups7's 32-bit product becomes a v_mad_u64_u32,
+// which issues at a quarter of the rate)
+#ifndef CLDN_FUSED_MAD24
+#define CLDN_FUSED_MAD24 1
+#endif
+#ifndef CLDN_FUSED_HOIST_COLS
+#define CLDN_FUSED_HOIST_COLS 2
+#endif
+__device__ __forceinline__ uint32_t groups7_u24(uint32_t bits) {
+#if CLDN_FUSED_MAD24
+  return (__umul24(bits, 37u) + 222u) >> 8;
+#else
+  return groups7(bits);
+#endif
 }
 
 // value of lane l-1; lane 0 receives `carry` (wave_shr:1 leaves lane 0 untouched, so it keeps the `old` operand)
@@ -203,11 +229,13 @@ struct FusedArgs {
 // that the compiler's s_waitcnt counting stays exact -- a conditional load inside a loop made it fall back to
 // vmcnt(0) before every row, which serialised the whole kernel on memory latency. The rows are unrolled for the same
 // reason.
-template <int LANES, int LOADW, bool UNAL, int L3, bool TAIL = false>
-__global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan plan, const FusedArgs A) {
+template <int LANES, int LOADW, bool UNAL, int L3, bool TAIL>
+__device__ __forceinline__ void fused_body(const DevPlan& plan, const FusedArgs& A) {
   constexpr uint32_t ROWS = fused_piece_rows(LANES);
   constexpr uint32_t PIECE = fused_piece_points(LANES);
-  constexpr uint32_t REGION = TAIL ? fused_region_bytes_tail(LANES) : fused_region_bytes(LANES);
+  constexpr bool SMALL = !TAIL && CLDN_FUSED_SMALL_REGION;  // 3 bytes per token, overflowing pieces go to the slow path below
+  constexpr uint32_t REGION = TAIL ? fused_region_bytes_tail(LANES) : (SMALL ? fused_region_bytes_small(LANES) : fused_region_bytes(LANES));
+  constexpr uint32_t CAP = REGION - 32u;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint32_t* wg_misc = reinterpret_cast<uint32_t*>(smem);                       // [wave] bytes of the wave's stream
   uint8_t* regions = smem + 16u;
@@ -311,7 +339,48 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
 #pragma unroll
   for (int k = 0; k < LANES; ++k) mult[k] = plan.ops[k].mult_f;
 
+  // AoS -> SoA split of one adaptive-int field for the row's points; all arguments but `cur`, `emits`, `idx` are uniform.
+  // rel = field offset behind plan.ops[0].offset, colp = the column at the piece's first point.
+  auto col_store = [&](uint32_t f_off, uint32_t rel, uint32_t bpv, bool in_regs, uint8_t* colp, const FloatVec<LOADW>& cur, bool emits,
+                       int32_t idx) __attribute__((always_inline)) {
+    uint64_t raw;
+    if (in_regs) {
+      if (LOADW == LANES + 1) raw = __float_as_uint(cur.v[LOADW - 1]) >> ((rel & 3u) * 8u);
+      else raw = field_from_regs<LOADW>(cur, rel);
+    } else {
+      raw = emits ? aos_field(A.points + first_point * step + (uint32_t)idx * step + f_off, bpv) : 0u;
+    }
+    // uniform base + 32-bit element index: the store takes the scalar-base addressing form, no 64-bit lane math
+    if (emits) {
+      if (bpv == 2u) reinterpret_cast<uint16_t*>(colp)[idx] = (uint16_t)raw;
+      else if (bpv == 4u) reinterpret_cast<uint32_t*>(colp)[idx] = (uint32_t)raw;
+      else reinterpret_cast<uint64_t*>(colp)[idx] = raw;
+    }
+  };
+  auto col_args = [&](uint32_t a, uint32_t& f_off, uint32_t& rel, uint32_t& bpv, bool& in_regs, uint8_t*& colp) __attribute__((always_inline)) {
+    uint32_t f_type;
+    adaptive_field(plan, a, f_off, f_type, bpv);
+    rel = f_off - plan.ops[0].offset;
+    // uniform: the field lies inside the dwords loaded for the point (always, except for the padded-fourth-lane layout)
+    in_regs = LOADW > LANES && (L3 != 4 || (f_off >= plan.ops[0].offset && rel + bpv <= (uint32_t)LOADW * 4u));
+    colp = A.cols.p[a] + first_point * bpv;
+  };
+  // the first fields' arguments are worked out once (round 5: the row loop fetched the plan entry with scalar loads and
+  // decoded it again for every row -- 45 SALU instructions and a scalar-cache round trip per row and field)
+  constexpr uint32_t kHoistCols = CLDN_FUSED_HOIST_COLS;
+  uint32_t hc_off[kHoistCols ? kHoistCols : 1], hc_rel[kHoistCols ? kHoistCols : 1], hc_bpv[kHoistCols ? kHoistCols : 1];
+  bool hc_in[kHoistCols ? kHoistCols : 1];
+  uint8_t* hc_ptr[kHoistCols ? kHoistCols : 1];
+#pragma unroll
+  for (uint32_t a = 0; a < kHoistCols; ++a) {
+    hc_off[a] = hc_rel[a] = hc_bpv[a] = 0u;
+    hc_in[a] = false;
+    hc_ptr[a] = nullptr;
+    if (a < na) col_args(a, hc_off[a], hc_rel[a], hc_bpv[a], hc_in[a], hc_ptr[a]);
+  }
+
   uint32_t R = 0u;  // bytes of my stream so far (wave-uniform)
+  bool ovf = false; // SMALL: the piece's tokens do not fit the region (wave-uniform); nothing more is written to it
   auto run_rows = [&](auto nan_tier_tag) __attribute__((always_inline)) {
     constexpr bool NAN_TIER = decltype(nan_tier_tag)::value;
 #pragma unroll
@@ -323,7 +392,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
         for (int k = 0; k < LOADW; ++k) cur.v[k] = lane == 0u ? 0.0f : cur.v[k];
       }
       const int32_t idx = (int32_t)(r * kRowPts + lane) - 1;
-      const bool emits = (lane > 0u) && (idx < (int32_t)n);
+      const bool emits = (lane > 0u) && (lane < n + 1u - r * kRowPts);  // idx < n, as one compare against a uniform limit
 
       // tokens of the row (common case in the float domain, see k_encode_floatn)
       uint32_t tok[LANES], lens = 0u, total = 0u;
@@ -335,7 +404,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
         const float nd = __fsub_rn(__uint_as_float(dpp_wave_shr1(__float_as_uint(rr))), rr);
         const float uf = fabsf(__fmaf_rn(nd, -2.0f, 0.5f)) + 0.5f;
         const uint32_t u = (uint32_t)uf;
-        const uint32_t l = groups7((uint32_t)__builtin_amdgcn_frexp_expf(uf));
+        const uint32_t l = groups7_u24((uint32_t)__builtin_amdgcn_frexp_expf(uf));
         tok[k] = token4(u, l);
         lens |= l << (8 * k);
         total += l;
@@ -353,7 +422,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
           hard |= !(fabsf(rr) < 2097152.0f);
           const float nrp = __uint_as_float(dpp_wave_shr1(__float_as_uint(rr) ^ 0x80000000u));
           const float uf = fabsf(__fmaf_rn(__fadd_rn(rr, nrp), 2.0f, 0.5f)) + 0.5f;
-          const uint32_t l = isn ? 1u : groups7((uint32_t)__builtin_amdgcn_frexp_expf(uf));
+          const uint32_t l = isn ? 1u : groups7_u24((uint32_t)__builtin_amdgcn_frexp_expf(uf));
           tok[k] = isn ? 0u : token4((uint32_t)uf, l);
           lens2 |= l << (8 * k);
           total2 += l;
@@ -462,7 +531,11 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
       const uint32_t plen = emits ? total : 0u;
       const uint32_t incl = wave_inclusive_scan(plen);
       uint32_t off = R + incl - plen;
-      if (__builtin_expect(hard_row, 0)) {  // wave-uniform: rebuild the general tokens (all lanes take part in the DPP)
+      const uint32_t row_bytes = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      if (SMALL) ovf |= (R + row_bytes > CAP);
+      if (SMALL && __builtin_expect(ovf, 0)) {
+        // (the piece is rewritten by the slow path below: only its size is still counted)
+      } else if (__builtin_expect(hard_row, 0)) {  // wave-uniform: rebuild the general tokens (all lanes take part in the DPP)
 #pragma unroll
         for (int k = 0; k < LANES; ++k) {
           const float v = cur.v[(LANES == 4 && k == 3) ? L3 : k];
@@ -471,41 +544,30 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
           const uint32_t nqp = dpp_wave_shr1(isn ? 0u : (0u - (uint32_t)q));
           uint32_t a0, a1, l;
           floatn_token(isn, (int32_t)((uint32_t)q + nqp), a0, a1, l);
-          if (plen) lds_or5(region, off, a0, a1, l);
+          if (emits) lds_or5(region, off, a0, a1, l);
           off += l;
         }
-      } else if (plen) {
+      } else if (emits) {
 #pragma unroll
         for (int k = 0; k < LANES; ++k) {
           lds_or4(region, off, tok[k]);
           off += (lens >> (8 * k)) & 0xffu;
         }
       }
-      if (TAIL && plen) lds_or12(region, off, tt.w0, tt.w1, tt.w2, tt.len);
-      R += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      if (TAIL && emits) lds_or12(region, off, tt.w0, tt.w1, tt.w2, tt.len);
+      R += row_bytes;
 
-      // AoS -> SoA split of the adaptive-int fields (uniform loop: the plan is read with scalar loads)
+      // AoS -> SoA split of the adaptive-int fields
       if (!(A.ablate & 4u)) {
-        for (uint32_t a = 0; a < na; ++a) {
-          uint32_t f_off, f_type, bpv;
-          adaptive_field(plan, a, f_off, f_type, bpv);
-          const uint32_t rel = f_off - plan.ops[0].offset;
-          // uniform: the field lies inside the dwords loaded for the point (always, except for the padded-fourth-lane layout)
-          const bool in_regs = LOADW > LANES && (L3 != 4 || (f_off >= plan.ops[0].offset && rel + bpv <= (uint32_t)LOADW * 4u));
-          uint64_t raw;
-          if (in_regs) {
-            if (LOADW == LANES + 1) raw = __float_as_uint(cur.v[LOADW - 1]) >> ((rel & 3u) * 8u);
-            else raw = field_from_regs<LOADW>(cur, rel);
-          } else {
-            raw = emits ? aos_field(A.points + first_point * step + (uint32_t)idx * step + f_off, bpv) : 0u;
-          }
-          // uniform base + 32-bit element index: the store takes the scalar-base addressing form, no 64-bit lane math
-          uint8_t* colp = A.cols.p[a] + first_point * bpv;
-          if (emits) {
-            if (bpv == 2u) reinterpret_cast<uint16_t*>(colp)[idx] = (uint16_t)raw;
-            else if (bpv == 4u) reinterpret_cast<uint32_t*>(colp)[idx] = (uint32_t)raw;
-            else reinterpret_cast<uint64_t*>(colp)[idx] = raw;
-          }
+#pragma unroll
+        for (uint32_t a = 0; a < kHoistCols; ++a)
+          if (a < na) col_store(hc_off[a], hc_rel[a], hc_bpv[a], hc_in[a], hc_ptr[a], cur, emits, idx);
+        for (uint32_t a = kHoistCols; a < na; ++a) {  // uniform loop: the plan is read with scalar loads
+          uint32_t f_off, rel, bpv;
+          bool in_regs;
+          uint8_t* colp;
+          col_args(a, f_off, rel, bpv, in_regs, colp);
+          col_store(f_off, rel, bpv, in_regs, colp, cur, emits, idx);
         }
       }
     }
@@ -523,6 +585,47 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
       run_rows(std::false_type{});
     }
   }
+
+  // SMALL, a piece that did not fit its region: the same R bytes once more, straight from the input to `dst` with the
+  // general integer formulas (FieldEncoderFloatN_Lossy::encode, src/field_encoder.cpp:42-91), one point per lane and
+  // row, byte stores. Rare by construction (more than 3 bytes per token on average over 378 / 504 points).
+  auto slow_piece = [&](uint8_t* dst) __attribute__((always_inline)) {
+    uint32_t RR = 0u;
+    for (uint32_t r0 = 0; r0 < n; r0 += kRowPts) {
+      const uint32_t idx = r0 + lane - 1u;
+      const bool emits = (lane > 0u) && (idx < n);
+      uint32_t w0[LANES], w1[LANES], l[LANES], tot = 0u;
+#pragma unroll
+      for (int k = 0; k < LANES; ++k) {
+        w0[k] = w1[k] = l[k] = 0u;
+        if (emits) {
+          const uint8_t* fp = A.points + (first_point + idx) * step + plan.ops[k].offset;
+          const float v = __uint_as_float((uint32_t)aos_field(fp, 4u));
+          int32_t qp = 0;
+          if (first + idx > 0u) {  // the chunk's first point has the reference 0; a NaN resets it to 0
+            const float pv = __uint_as_float((uint32_t)aos_field(fp - step, 4u));
+            qp = is_nan_f32(pv) ? 0 : quant_rne_i32(pv, mult[k]);
+          }
+          const int32_t q = quant_rne_i32(v, mult[k]);
+          floatn_token(is_nan_f32(v), (int32_t)((uint32_t)q - (uint32_t)qp), w0[k], w1[k], l[k]);
+        }
+        tot += l[k];
+      }
+      const uint32_t incl = wave_inclusive_scan(tot);
+      uint32_t off = RR + incl - tot;
+#pragma unroll
+      for (int k = 0; k < LANES; ++k) {
+        const uint64_t t = (((uint64_t)w1[k]) << 32) | w0[k];
+        for (uint32_t b = 0; b < l[k]; ++b) dst[off + b] = (uint8_t)(t >> (8u * b));
+        off += l[k];
+      }
+      RR += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+  };
+  auto write_out = [&](uint8_t* dst) __attribute__((always_inline)) {
+    if (SMALL && __builtin_expect(ovf, 0)) slow_piece(dst);
+    else copy_region_out(region, R, dst, lane);
+  };
 
   // the four streams of the workgroup go back to back into the workgroup's range of the chunk slot
   // (one segment of ~11 KB for k_compact instead of four small ones)
@@ -556,7 +659,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
       __builtin_amdgcn_s_sleep(1);
     }
     const uint32_t wg_off = wave_sum(mine);  // bytes of the chunk's workgroups before mine
-    if (R) copy_region_out(region, R, A.slots + (size_t)pd.chunk * A.slot_stride + wg_off + before, lane);
+    if (R) write_out(A.slots + (size_t)pd.chunk * A.slot_stride + wg_off + before);
     if (wave == 0u && lane == 0u && quad + 1u == (pd.P >> 2)) {  // the chunk's last workgroup: the regular stream is complete
       Seg sg;
       sg.off = 0u;
@@ -566,13 +669,26 @@ __global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan pl
     return;
   }
   const uint32_t seg_off = quad * kFusedWaves * A.piece_stride;
-  if (R) copy_region_out(region, R, A.slots + (size_t)pd.chunk * A.slot_stride + seg_off + before, lane);
+  if (R) write_out(A.slots + (size_t)pd.chunk * A.slot_stride + seg_off + before);
   if (wave == 0u && lane == 0u) {
     Seg sg;
     sg.off = seg_off;
     sg.size = total;
     A.segs[(size_t)pd.chunk * A.segs_per_chunk + quad] = sg;
   }
+}
+
+template <int LANES, int LOADW, bool UNAL, int L3, bool TAIL = false>
+__global__ __launch_bounds__(kFusedThreads) void k_encode_fused(const DevPlan plan, const FusedArgs A) {
+  fused_body<LANES, LOADW, UNAL, L3, TAIL>(plan, A);
+}
+// Round 5: the instantiations that prefetch at most 5 dwords per point and row and have no TAIL op fit 64 VGPRs without a
+// spill; with the 18.3 KB of four 3-byte-per-token regions a CU then holds 8 workgroups = 8 waves per SIMD instead of 5
+// (same-box A/B, C2: 136 -> 130 us). The wider ones would spill (up to 88 VGPRs' worth) and keep the compiler's choice.
+template <int LANES, int LOADW, bool UNAL, int L3>
+__global__ __launch_bounds__(kFusedThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_fused_w8(const DevPlan plan,
+                                                                                                            const FusedArgs A) {
+  fused_body<LANES, LOADW, UNAL, L3, false>(plan, A);
 }
 
 }  // namespace cldn

@@ -2049,6 +2049,15 @@ uint32_t stage1_piece_slot_stride(const DevPlan& plan, const uint8_t* points) {
   return (fused_piece_points(v.lanes) * per_point + 255u) & ~255u;
 }
 
+// instantiations without a TAIL op that prefetch at most 5 dwords per point: the 64-VGPR kernel (8 waves per SIMD)
+template <int LL, int WW, bool UU, int L3>
+static void launch_fused_variant(dim3 grid, dim3 block, uint32_t lds, hipStream_t stream, const DevPlan& plan, const FusedArgs& A) {
+  if constexpr (WW <= 5 && CLDN_FUSED_SMALL_REGION != 0)
+    hipLaunchKernelGGL((k_encode_fused_w8<LL, WW, UU, L3>), grid, block, lds, stream, plan, A);
+  else
+    hipLaunchKernelGGL((k_encode_fused<LL, WW, UU, L3>), grid, block, lds, stream, plan, A);
+}
+
 static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piece0, uint32_t piece1, bool* probed) {
   FusedVariant v;
   if (!fused_variant(*L.plan, L.points, &v)) return launch_fail(hipErrorInvalidValue, "k_encode_fused (no variant)");
@@ -2088,14 +2097,21 @@ static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piec
     A.tail_size = top.size;
     if (top.kind == OP_GORILLA64) A.tail_windows = reinterpret_cast<const uint16_t*>(L.pre.p[top.type]);
   }
-  const uint32_t region = v.tail >= 0 ? fused_region_bytes_tail(v.lanes) : fused_region_bytes(v.lanes);
-  const uint32_t lds = 16u + kFusedWaves * region;
-  if (lds < 6144u * 4u + 272u) A.n_probe = 0u;  // (never: four regions are 30 KB and more)
+  const uint32_t region = v.tail >= 0 ? fused_region_bytes_tail(v.lanes)
+                                      : (CLDN_FUSED_SMALL_REGION ? fused_region_bytes_small(v.lanes) : fused_region_bytes(v.lanes));
+  uint32_t lds = 16u + kFusedWaves * region;
+  // the probe workgroups of the launch share its LDS size: a 16-bit field needs its 8 KiB value bitmap, a 32-bit field a
+  // hash table of 6144 slots (24.8 KB: above the 18.3 KB of four 3-byte-per-token regions -- such launches keep 6
+  // workgroups per CU instead of 8)
+  if (A.n_probe) {
+    bool wide = false;
+    for (uint32_t a = 0; a < L.plan->n_adaptive; ++a) wide = wide || L.plan->adaptive[a].bpv == 4u;
+    if (wide) lds = std::max(lds, 6144u * 4u + 272u);
+  }
   A.probe_lds = lds;
   if (probed) *probed = A.n_probe != 0u;
   const dim3 grid(A.n_probe + (piece1 - piece0) / kFusedWaves), block(kFusedThreads);
-#define LAUNCH_FUSED(LL, WW, UU, L3)                                                                             \
-  hipLaunchKernelGGL((k_encode_fused<LL, WW, UU, L3>), grid, block, lds, stream, *L.plan, A)
+#define LAUNCH_FUSED(LL, WW, UU, L3) launch_fused_variant<LL, WW, UU, L3>(grid, block, lds, stream, *L.plan, A)
 #define LAUNCH_FUSED_TAIL(LL, WW, UU, L3)                                                                        \
   hipLaunchKernelGGL((k_encode_fused<LL, WW, UU, L3, true>), grid, block, lds, stream, *L.plan, A)
   if (v.tail >= 0) {

@@ -230,6 +230,43 @@ def float_domain_boundary(n=30000, seed=53, lanes=3, with_u16=False):
     return info, pack(info, cols, n)
 
 
+def region_overflow(n=70000, seed=71, lanes=3, with_u16=False, pad=0):
+    """Round 5: the piece kernel's LDS region holds 3 bytes per token; pieces (378 / 504 points) whose tokens are larger
+    on average are rewritten by its slow path. Stretches of every length around a piece -- quiet, 4-byte tokens (noise
+    over kilometres), 5-byte tokens (|ticks| beyond 2^27, int32 wrap-around), NaN / Inf inside the noisy stretches --
+    so that overflowing and fitting pieces alternate inside a workgroup and across chunk boundaries."""
+    rs = np.random.RandomState(seed)
+    pts = np.cumsum(rs.normal(0, 0.01, size=(n, lanes)), axis=0).astype(np.float32)
+    pos = 100
+    k = 0
+    while pos < n - 3000:
+        length = int(rs.choice([30, 200, 378, 504, 505, 800, 1600, 2500]))
+        kind = k % 4
+        if kind == 0:
+            pts[pos:pos + length] = rs.uniform(-3000, 3000, size=(length, lanes))          # 4-byte tokens
+        elif kind == 1:
+            pts[pos:pos + length] = rs.uniform(-2.0e6, 2.0e6, size=(length, lanes))        # 5-byte tokens, wrap-around
+        elif kind == 2:
+            pts[pos:pos + length] = rs.uniform(-900, 900, size=(length, lanes))            # 3-byte tokens: just fits
+        else:
+            blk = rs.uniform(-5000, 5000, size=(length, lanes)).astype(np.float32)
+            blk[rs.randint(0, length, max(1, length // 9)), rs.randint(0, lanes, max(1, length // 9))] = np.nan
+            blk[rs.randint(0, length, 3), rs.randint(0, lanes, 3)] = np.inf
+            pts[pos:pos + length] = blk
+        pos += length + int(rs.choice([0, 1, 63, 500, 1500]))
+        k += 1
+    pts[32768 - 200:32768 + 300] = rs.uniform(-4000, 4000, size=(500, lanes))               # across the chunk boundary
+    fields = [("xyzw"[j], pad + 4 * j, F.FLOAT32, 0.001) for j in range(lanes)]
+    step = pad + 4 * lanes
+    cols = {"xyzw"[j]: pts[:, j].copy() for j in range(lanes)}
+    if with_u16:
+        fields.append(("i", step, F.UINT16, None))
+        cols["i"] = (rs.randint(0, 200, n) * 3).astype(np.uint16)
+        step += 2 if pad else 4
+    info = make_info(fields, step, n)
+    return info, pack(info, cols, n)
+
+
 def padded_fourth_lane(kind, n=90000, seed=61):
     """Real-world layouts whose fused FloatN encoder has its 4th lane one dword further: PCL PointXYZI (x y z pad
     intensity@16, 32-byte points) and an Ouster-style 48-byte point with five integer channels behind the floats."""
@@ -362,6 +399,11 @@ def encode_cases(small=False):
     out.append(("float_boundary3", *float_domain_boundary(lanes=3)))
     out.append(("float_boundary4", *float_domain_boundary(lanes=4, seed=54)))
     out.append(("float_boundary3_u16", *float_domain_boundary(lanes=3, seed=55, with_u16=True)))
+    out.append(("region_overflow3", *region_overflow(lanes=3)))
+    out.append(("region_overflow4", *region_overflow(lanes=4, seed=72)))
+    out.append(("region_overflow3_u16", *region_overflow(lanes=3, seed=73, with_u16=True)))
+    out.append(("region_overflow3_u16_unaligned", *region_overflow(lanes=3, seed=74, with_u16=True, pad=1)))
+    out.append(("region_overflow4_unaligned", *region_overflow(n=40000, lanes=4, seed=75, pad=2)))
     out.append(("pcl_xyzi_step32", *padded_fourth_lane("pcl_xyzi")))
     out.append(("ouster_step48", *padded_fourth_lane("ouster")))
     out.extend(stride_variants())

@@ -10,12 +10,13 @@
 // and several grid sizes (workgroups per CU).
 //
 // build: hipcc --offload-arch=gfx950 -O3 tools/hbm_calib.hip -o cloudini_amd/lib/hbm_calib   (cloudini_amd/build.py does it)
-// run:   cloudini_amd/lib/hbm_calib [GiB per buffer, default 1]
+// run:   cloudini_amd/lib/hbm_calib [GiB per buffer, default 1] [piece]   (piece: only the piece kernel's own shape)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CHECK(x)                                                                          \
@@ -64,6 +65,50 @@ __global__ void k_read(const v4* __restrict__ a, float* __restrict__ o, size_t n
   if (t == 123.456f) o[blockIdx.x] = t;  // (never true for the zero-filled buffers: keeps the loads alive)
 }
 
+
+// ---- the piece kernel's own shape (round 5) -----------------------------------------------
+// k_encode_fused<3,4,...> as a memory pattern, with its arithmetic taken out: 256-thread workgroups, one wave per PIECE of
+// 8 rows x 63 points, lane l of row r loads the 16-byte point r*63 + l - 1 (all eight loads requested before the first is
+// used, non-temporal), the wave leaves OUT_B bytes per point as 16-byte units (the regular stream, ~5.46 B/pt: staged in
+// LDS like the real kernel's region, then read back and stored) and one 2-byte column value per point. LDS bytes per
+// workgroup are a launch parameter: they set how many workgroups a CU holds (30.4 KB: 5; 18 KB: 8). PERSIST: the grid is
+// wg_per_cu x CUs workgroups that take their pieces round robin instead of one workgroup per four pieces.
+template <bool PERSIST, bool NT_STORE>
+__global__ __launch_bounds__(256) void k_piece_shape(const v4* __restrict__ pts, uint8_t* __restrict__ out, uint16_t* __restrict__ col,
+                                                      uint32_t n_pieces, uint32_t out_bytes_per_piece, uint32_t lds_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint8_t* region = smem + wave * lds_per_wave;
+  const uint32_t step = PERSIST ? gridDim.x * 4u : 0u;
+  for (uint32_t g = blockIdx.x * 4u + wave; g < n_pieces; g += step) {
+    const size_t first = (size_t)g * 504u;
+    v4 rows[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const size_t idx = first + (size_t)(r * 63 + (int)lane) - (first || r || lane ? 1u : 0u);
+      rows[r] = __builtin_nontemporal_load(pts + idx);
+    }
+    // stage: every lane leaves 16 bytes per row in the region (the real kernel ORs ~16 bytes of tokens per lane and row)
+    uint32_t R = out_bytes_per_piece;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const uint32_t off = ((uint32_t)r * 64u + lane) * 16u;
+      if (off + 16u <= lds_per_wave) *reinterpret_cast<v4*>(region + off) = rows[r];
+      if (lane) {
+        const uint16_t cv = (uint16_t)__float_as_uint(rows[r].w);
+        col[first + (size_t)(r * 63 + (int)lane) - 1u] = cv;
+      }
+    }
+    uint8_t* dst = out + (size_t)g * ((out_bytes_per_piece + 15u) & ~15u);
+    for (uint32_t j = lane; j < (R >> 4); j += 64u) {
+      const v4 v = *reinterpret_cast<const v4*>(region + j * 16u);
+      if (NT_STORE) __builtin_nontemporal_store(v, reinterpret_cast<v4*>(dst) + j);
+      else reinterpret_cast<v4*>(dst)[j] = v;
+    }
+    if (!PERSIST) break;
+  }
+}
+
 template <class F>
 static void run(const char* name, double bytes, int threads, int wg_per_cu, int cus, F launch) {
   hipEvent_t e0, e1;
@@ -105,6 +150,39 @@ int main(int argc, char** argv) {
   CHECK(hipMemset(a, 0, bytes));
   CHECK(hipMemset(b, 0, bytes));
   CHECK(hipMemset(o, 0, bytes));
+
+  if (argc > 2 && !strcmp(argv[2], "piece")) {
+    // 32 M points of 16 bytes (the bench line's batch), 5.46 B/pt of stream + a u16 column
+    const uint32_t n_pieces = (uint32_t)((32000000ull + 503ull) / 504ull) & ~3u;
+    const size_t n_pts = (size_t)n_pieces * 504u;
+    if (n_pts * 16u > bytes) { fprintf(stderr, "buffer too small\n"); return 1; }
+    const uint32_t out_pp = 2752u;  // 504 points x 5.46 B
+    uint16_t* colp = reinterpret_cast<uint16_t*>(b);
+    const double moved = (double)n_pts * 16.0 + (double)n_pieces * out_pp + (double)n_pts * 2.0;
+    const int ldsv[] = {30400, 25600, 18432, 12288};
+    for (int lds : ldsv) {
+      char nm[64];
+      snprintf(nm, sizeof nm, "piece lds %5d", lds);
+      CHECK(hipFuncSetAttribute((const void*)k_piece_shape<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 64));
+      CHECK(hipFuncSetAttribute((const void*)k_piece_shape<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 64));
+      CHECK(hipFuncSetAttribute((const void*)k_piece_shape<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 64));
+      run(nm, moved, 256, (int)(n_pieces / 4 / cus), cus, [&](int, int) {
+        hipLaunchKernelGGL((k_piece_shape<false, false>), dim3(n_pieces / 4), dim3(256), lds, 0, a, (uint8_t*)o, colp, n_pieces, out_pp, (uint32_t)lds / 4u);
+      });
+      snprintf(nm, sizeof nm, "piece ntst %5d", lds);
+      run(nm, moved, 256, (int)(n_pieces / 4 / cus), cus, [&](int, int) {
+        hipLaunchKernelGGL((k_piece_shape<false, true>), dim3(n_pieces / 4), dim3(256), lds, 0, a, (uint8_t*)o, colp, n_pieces, out_pp, (uint32_t)lds / 4u);
+      });
+      const int pw[] = {2, 4, 5, 8};
+      for (int w : pw) {
+        snprintf(nm, sizeof nm, "piece pers %5d", lds);
+        run(nm, moved, 256, w, cus, [&](int g, int) {
+          hipLaunchKernelGGL((k_piece_shape<true, false>), dim3(g), dim3(256), lds, 0, a, (uint8_t*)o, colp, n_pieces, out_pp, (uint32_t)lds / 4u);
+        });
+      }
+    }
+    return 0;
+  }
   const int tvals[] = {256, 512, 1024};
   const int wvals[] = {2, 4, 8, 16, 32};
   for (int t : tvals)

@@ -1,0 +1,4 @@
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+bash tools/ab_env.sh - 2>&1 | grep -v amdgpu
