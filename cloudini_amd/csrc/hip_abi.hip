@@ -146,6 +146,15 @@ struct cldn_hip_plan {
   bool uses_v5 = false;
   uint32_t ref_max_point_bytes = 0;  // detail::MaxSerializedPointSize
   bool has_padding = false;          // some byte of a point is not covered by any field
+  // WIDE route (stage1_wide.h): the schema does not fit the launch-argument plan (more than kMaxOps regular tokens,
+  // kMaxAdaptive adaptive fields or kMaxPointStep bytes per point). `dev` then keeps only its scalar members (n_ops,
+  // n_adaptive and n_gorilla are 0: nothing on the host walks its arrays), the entries are here
+  bool wide = false;
+  std::vector<DevOp> ops_all;
+  std::vector<uint32_t> op_aux;          // OP_GORILLA64: index of the op's token buffer
+  std::vector<DevAdaptive> adaptive_all;
+  uint32_t n_gorilla_all = 0;
+  uint32_t n_adaptive_total() const { return wide ? (uint32_t)adaptive_all.size() : dev.n_adaptive; }
 };
 
 struct cldn_hip_codec {
@@ -186,6 +195,11 @@ struct cldn_hip_codec {
   int pipeline = 0;           // cldn_hip_codec_pipeline: 0 auto, 1 tile kernel + slots, 2 piece kernel + slots
   DevBuf d_viz_keys, d_viz_first, d_viz_slot, d_viz_blocks, d_viz_total;  // applyVizLossyPreprocessing workspace
   DevBuf d_pre[kMaxGorilla];
+  // WIDE route: the plan's arrays in device memory (uploaded by cldn_hip_codec_create), per-chunk scratch of the encoder,
+  // per-op state of the serial decoder, Gorilla token buffers
+  DevBuf d_wide_plan, d_wide_scratch, d_wide_state;
+  std::vector<DevBuf> d_wide_pre;
+  WidePlan wide_desc = {};
   PinnedBuf h_stage;   // chunk table upload
   // decode table upload: a ring of staging buffers, each guarded by the event recorded behind its copy, so that a call
   // does not have to drain the stream before it fills the next one
@@ -258,9 +272,6 @@ int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint
   if (!out) return fail(CLDN_HIP_ERR_ARG, "plan_create: out is NULL");
   *out = nullptr;
   if (point_step == 0) return fail(CLDN_HIP_ERR_ARG, "point_step cannot be 0");  // cloudini.cpp:250-252
-  if (point_step > kMaxPointStep)
-    return fail(CLDN_HIP_ERR_UNSUPPORTED, "point_step %u > %u is not supported by the HIP kernels", point_step,
-                kMaxPointStep);
   if (n_fields && !fields) return fail(CLDN_HIP_ERR_ARG, "fields is NULL");
   if (encoding_opt > 2) return fail(CLDN_HIP_ERR_ARG, "invalid encoding_opt %u", encoding_opt);
 
@@ -317,10 +328,10 @@ int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint
     for (uint32_t i = lead; i < n_fields; ++i) plan->uses_v5 |= is_adaptive_int(fields[i].type);
   }
 
+  // (every op and adaptive field goes to the plan's vectors first; they move into `d`'s arrays at the end if they fit)
   auto add_op = [&](DevOp op) -> int {
-    if (d.n_ops >= (uint32_t)kMaxOps)
-      return fail(CLDN_HIP_ERR_UNSUPPORTED, "more than %d per-point tokens are not supported", kMaxOps);
-    d.ops[d.n_ops++] = op;
+    plan->ops_all.push_back(op);
+    plan->op_aux.push_back(op.kind == OP_GORILLA64 ? plan->n_gorilla_all++ : 0u);
     d.max_regular_bytes += op.max_bytes;
     return CLDN_HIP_OK;
   };
@@ -355,14 +366,12 @@ int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint
       continue;
     }
     if (plan->uses_v5 && is_adaptive_int(f.type)) {  // buildV5Plan, v5_codec.cpp:725-737
-      if (d.n_adaptive >= (uint32_t)kMaxAdaptive) {
-        rc = fail(CLDN_HIP_ERR_UNSUPPORTED, "more than %d adaptive integer fields are not supported", kMaxAdaptive);
-        break;
-      }
-      DevAdaptive& a = d.adaptive[d.n_adaptive++];
+      DevAdaptive a;
+      memset(&a, 0, sizeof(a));
       a.offset = f.offset;
       a.type = f.type;
       a.bpv = op.size;
+      plan->adaptive_all.push_back(a);
       continue;
     }
     switch (f.type) {  // CreateCompatibleEncoder, codec_common.cpp:116-153
@@ -401,12 +410,8 @@ int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint
           op.max_bytes = 10;
           d.min_regular_bytes += 1;
         } else if (!f.has_resolution && version >= 4) {
-          if (d.n_gorilla >= (uint32_t)kMaxGorilla) {
-            rc = fail(CLDN_HIP_ERR_UNSUPPORTED, "more than %d Gorilla-coded FLOAT64 fields are not supported", kMaxGorilla);
-            break;
-          }
           op.kind = OP_GORILLA64;  // FieldEncoderFloat_Gorilla<double>
-          op.type = (uint8_t)d.n_gorilla++;
+          op.type = (uint8_t)(plan->n_gorilla_all & 0xffu);  // index of the op's token buffer (the WIDE route reads op_aux instead)
           op.max_bytes = 10;       // 1 + 1 + 5 + 6 + 64 = 77 bits
           d.all_varint = 0;
           d.min_regular_bytes += 1;
@@ -435,6 +440,17 @@ int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint
     delete plan;
     return rc;
   }
+  plan->wide = plan->ops_all.size() > (size_t)kMaxOps || plan->adaptive_all.size() > (size_t)kMaxAdaptive ||
+               plan->n_gorilla_all > (uint32_t)kMaxGorilla || point_step > kMaxPointStep;
+  if (!plan->wide) {
+    d.n_ops = (uint32_t)plan->ops_all.size();
+    for (uint32_t k = 0; k < d.n_ops; ++k) d.ops[k] = plan->ops_all[k];
+    d.n_adaptive = (uint32_t)plan->adaptive_all.size();
+    for (uint32_t a = 0; a < d.n_adaptive; ++a) d.adaptive[a] = plan->adaptive_all[a];
+    d.n_gorilla = plan->n_gorilla_all;
+  } else {
+    d.all_varint = 0;  // (no kernel of the ordinary route may take this plan)
+  }
   {  // decode: can the token ends of the regular stream be laid out from the point's form (k_mark_token_ends)?
     bool ok = d.n_ops >= 1u && d.n_ops <= 8u && d.max_regular_bytes <= 256u;
     uint32_t n_raw = 0u;
@@ -456,7 +472,7 @@ int cldn_hip_plan_create(const cldn_hip_field_t* fields, uint32_t n_fields, uint
 
 void cldn_hip_plan_destroy(cldn_hip_plan_t* plan) { delete plan; }
 int cldn_hip_plan_uses_v5(const cldn_hip_plan_t* plan) { return plan && plan->uses_v5 ? 1 : 0; }
-uint32_t cldn_hip_plan_adaptive_fields(const cldn_hip_plan_t* plan) { return plan ? plan->dev.n_adaptive : 0; }
+uint32_t cldn_hip_plan_adaptive_fields(const cldn_hip_plan_t* plan) { return plan ? plan->n_adaptive_total() : 0; }
 uint32_t cldn_hip_plan_max_point_bytes(const cldn_hip_plan_t* plan) { return plan ? plan->ref_max_point_bytes : 0; }
 
 uint64_t cldn_hip_stage1_bound(const cldn_hip_plan_t* plan, uint64_t n_points) {  // cloudini.cpp:249-292 (NONE)
@@ -521,6 +537,35 @@ int cldn_hip_codec_create(const cldn_hip_plan_t* plan, int device, void* hip_str
     c->own_stream = true;
   }
   int rc = stage1_configure_kernels();
+  if (rc == CLDN_HIP_OK && c->plan.wide) {
+    // WIDE route: [ops | op_aux | adaptive] in one device buffer, the descriptor that points into it
+    const cldn_hip_plan& P = c->plan;
+    const size_t ops_b = (P.ops_all.size() * sizeof(DevOp) + 63u) & ~size_t(63);
+    const size_t aux_b = (P.op_aux.size() * sizeof(uint32_t) + 63u) & ~size_t(63);
+    const size_t ada_b = (P.adaptive_all.size() * sizeof(DevAdaptive) + 63u) & ~size_t(63);
+    rc = c->d_wide_plan.ensure(ops_b + aux_b + ada_b + 64u);
+    if (rc == CLDN_HIP_OK) {
+      uint8_t* base = (uint8_t*)c->d_wide_plan.p;
+      hipError_t he = hipSuccess;
+      if (!P.ops_all.empty()) he = hipMemcpy(base, P.ops_all.data(), P.ops_all.size() * sizeof(DevOp), hipMemcpyHostToDevice);
+      if (he == hipSuccess && !P.op_aux.empty())
+        he = hipMemcpy(base + ops_b, P.op_aux.data(), P.op_aux.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+      if (he == hipSuccess && !P.adaptive_all.empty())
+        he = hipMemcpy(base + ops_b + aux_b, P.adaptive_all.data(), P.adaptive_all.size() * sizeof(DevAdaptive), hipMemcpyHostToDevice);
+      if (he != hipSuccess) rc = fail(CLDN_HIP_ERR_DEVICE, "upload of the wide plan: %s", hipGetErrorString(he));
+      WidePlan& W = c->wide_desc;
+      W.point_step = P.point_step;
+      W.n_ops = (uint32_t)P.ops_all.size();
+      W.n_adaptive = (uint32_t)P.adaptive_all.size();
+      W.n_gorilla = P.n_gorilla_all;
+      W.min_regular_bytes = P.dev.min_regular_bytes;
+      W.reserved = 0u;
+      W.ops = reinterpret_cast<const DevOp*>(base);
+      W.op_aux = reinterpret_cast<const uint32_t*>(base + ops_b);
+      W.adaptive = reinterpret_cast<const DevAdaptive*>(base + ops_b + aux_b);
+      c->d_wide_pre.resize(P.n_gorilla_all);
+    }
+  }
   if (rc != CLDN_HIP_OK) {
     cldn_hip_codec_destroy(c);
     return rc;
@@ -545,6 +590,10 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
     c->d_ranks[a].release();
   }
   for (int g = 0; g < kMaxGorilla; ++g) c->d_pre[g].release();
+  c->d_wide_plan.release();
+  c->d_wide_scratch.release();
+  c->d_wide_state.release();
+  for (DevBuf& b : c->d_wide_pre) b.release();
   c->h_stage.release();
   for (int k = 0; k < cldn_hip_codec::kDecStageRing; ++k) {
     c->h_dec_stage[k].release();
@@ -740,7 +789,8 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   uint64_t n_points = 0;
   // device-resident inputs decide the kernel variant by their address; host inputs are staged into an aligned buffer
   const uint8_t* variant_ptr = points_loc == CLDN_HIP_DEVICE ? (const uint8_t*)points : nullptr;
-  const uint32_t piece_pts = c->pipeline == 1 ? 0u : stage1_piece_points(plan, variant_ptr);
+  const bool wide = c->plan.wide;  // stage1_wide.h: the plan's arrays live in device memory, one segment per chunk
+  const uint32_t piece_pts = (c->pipeline == 1 || wide) ? 0u : stage1_piece_points(plan, variant_ptr);
   static const bool intra_env0 = getenv("CLDN_HIP_INTRA") && atoi(getenv("CLDN_HIP_INTRA")) != 0;  // A/B switch
   const bool intra_env = intra_env0 || table != nullptr;  // chunk tables want one regular segment per chunk
   static const bool quad_major_env = !(getenv("CLDN_HIP_QUAD_MAJOR") && atoi(getenv("CLDN_HIP_QUAD_MAJOR")) == 0);
@@ -767,7 +817,7 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   if (need && !out && !deferred && !table) return fail(CLDN_HIP_ERR_ARG, "out is NULL");
   c->pending_total = 0;
 
-  const uint32_t n_adaptive = plan.n_adaptive;
+  const uint32_t n_adaptive = c->plan.n_adaptive_total();
   // Sub-chunks: the regular stream of a chunk is produced as `subs` independent sub-streams (one workgroup each)
   // that the compaction kernel concatenates; this multiplies the parallelism of small batches at no extra work.
   uint32_t subs = 1;
@@ -776,7 +826,7 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   } else {
     while (subs < 32u && (uint64_t)n_chunks * subs < 6000u) subs *= 2u;
   }
-  if (subs < 1u || subs > 32u || (subs & (subs - 1u))) subs = 1u;
+  if (subs < 1u || subs > 32u || (subs & (subs - 1u)) || wide) subs = 1u;
   const bool pieces = piece_pts != 0u && n_chunks != 0u;   // regular stream by the piece kernel
   const bool intra = pieces && intra_env;
   const uint32_t piece_wgs = ((((kPointsPerChunk + piece_pts - 1u) / std::max(1u, piece_pts)) + 3u) & ~3u) / 4u;  // workgroups (4 pieces) per full chunk
@@ -785,9 +835,12 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   // (intra: the slot still reserves the worst case of every workgroup, the streams are packed at its start)
   const uint32_t sub_stride = pieces ? 4u * stage1_piece_slot_stride(plan, variant_ptr) * (intra ? piece_wgs : 1u)
                                      : (uint32_t)((((uint64_t)sub_points * plan.max_regular_bytes + 64u) + 255u) & ~uint64_t(255));
-  const uint32_t segs_per_chunk = subs + 2u * n_adaptive;
+  const uint32_t segs_per_chunk = wide ? 1u : subs + 2u * n_adaptive;
   const uint64_t reg_stride = (uint64_t)subs * sub_stride;
-  const uint64_t slot_stride = reg_stride + (uint64_t)n_adaptive * kSectionStride;
+  // WIDE: the slot takes the chunk's whole payload as one run -- the regular stream's worst case and, per adaptive field,
+  // the largest section any mode can write (DeltaRle: 5 + 11 bytes per value)
+  const uint64_t wide_slot = (((uint64_t)kPointsPerChunk * ((uint64_t)plan.max_regular_bytes + 11ull * n_adaptive) + 16ull * n_adaptive + 64ull) + 255ull) & ~255ull;
+  const uint64_t slot_stride = wide ? wide_slot : reg_stride + (uint64_t)n_adaptive * kSectionStride;
 
   // one zero-filled block per call (one memset launch instead of three)
   const size_t z_anchor = 256;
@@ -822,9 +875,23 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
         c->finish_epoch = 1u;
       }
     }
-    for (uint32_t a = 0; a < n_adaptive; ++a) {
+    for (uint32_t a = 0; a < plan.n_adaptive; ++a) {  // (WIDE: plan.n_adaptive == 0, the columns live in the chunk scratch)
       if ((rc = c->d_cols[a].ensure((size_t)n_points * plan.adaptive[a].bpv + 64)) != CLDN_HIP_OK) return rc;
       if ((rc = c->d_ranks[a].ensure((size_t)n_points * 2 + 64)) != CLDN_HIP_OK) return rc;
+    }
+    if (wide) {
+      if ((rc = c->d_wide_scratch.ensure((size_t)n_chunks * stage1_wide_scratch_bytes())) != CLDN_HIP_OK) return rc;
+      const uint32_t ng = c->plan.n_gorilla_all;
+      if (ng) {
+        std::vector<void*> ptrs(ng);
+        for (uint32_t g = 0; g < ng; ++g) {
+          if ((rc = c->d_wide_pre[g].ensure((size_t)n_points * 16 + 64)) != CLDN_HIP_OK) return rc;
+          ptrs[g] = c->d_wide_pre[g].p;
+        }
+        if ((rc = c->d_pre_ptrs.ensure(ptrs.size() * sizeof(void*))) != CLDN_HIP_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_pre_ptrs.p, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // `ptrs` lives on this stack frame
+      }
     }
     if (plan.n_gorilla) {
       void* ptrs[kMaxGorilla] = {};
@@ -880,9 +947,15 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   L.sub_stride = sub_stride;
   L.segs = (Seg*)((uint8_t*)c->d_status.p + z_segs);
   L.segs_per_chunk = segs_per_chunk;
-  for (uint32_t a = 0; a < n_adaptive; ++a) {
+  for (uint32_t a = 0; a < plan.n_adaptive; ++a) {
     L.cols.p[a] = (uint8_t*)c->d_cols[a].p;
     L.ranks[a] = (uint16_t*)c->d_ranks[a].p;
+  }
+  if (wide) {
+    L.wide = &c->wide_desc;
+    L.wide_ops_host = c->plan.ops_all.data();
+    L.wide_scratch = (uint8_t*)c->d_wide_scratch.p;
+    L.wide_pre = (const uint4* const*)c->d_pre_ptrs.p;
   }
   for (uint32_t g = 0; g < plan.n_gorilla; ++g) L.pre.p[g] = (const uint4*)c->d_pre[g].p;
   L.pre_out = (uint4* const*)c->d_pre_ptrs.p;
@@ -891,7 +964,7 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   L.stream_offsets = lz4 ? (uint64_t*)c->d_s1_offsets.p : (uint64_t*)c->d_offsets.p;
   L.modes = (uint8_t*)c->d_modes.p;
   L.modes_forced = false;
-  if (c->last_modes_count && c->ev_last_modes && hipEventQuery(c->ev_last_modes) == hipSuccess) {
+  if (!wide && c->last_modes_count && c->ev_last_modes && hipEventQuery(c->ev_last_modes) == hipSuccess) {
     // a copy of an earlier call's modes has landed: it becomes the hint until a newer one lands
     const uint8_t* lm = (const uint8_t*)c->h_last_modes.p;
     const uint32_t nf = c->last_modes_fields;
@@ -905,7 +978,7 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   }
   for (uint32_t a = 0; a < (uint32_t)kMaxAdaptive; ++a) L.mode_hint[a] = c->hint_valid ? c->hint_cache[a] : (uint8_t)0xF;
   if (!c->forced_modes.empty() && n_adaptive && n_clouds) {
-    for (uint32_t a = 0; a < n_adaptive; ++a) L.mode_hint[a] = (uint8_t)(1u << c->forced_modes[a]);
+    for (uint32_t a = 0; a < plan.n_adaptive; ++a) L.mode_hint[a] = (uint8_t)(1u << c->forced_modes[a]);
     HIP_TRY(hipStreamSynchronize(c->stream));  // the previous call's upload from h_modes has to be over
     if ((rc = c->h_modes.ensure((size_t)n_clouds * n_adaptive)) != CLDN_HIP_OK) return rc;
     for (uint32_t k = 0; k < n_clouds; ++k)
@@ -1001,7 +1074,7 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   }
   // remember this call's modes for the next call's launch hint (no synchronisation: the copy is only looked at
   // once its event has fired)
-  if (n_adaptive && n_clouds && (size_t)n_clouds * n_adaptive <= 65536u && c->last_modes_count == 0) {
+  if (!wide && n_adaptive && n_clouds && (size_t)n_clouds * n_adaptive <= 65536u && c->last_modes_count == 0) {
     if (!c->ev_last_modes) HIP_TRY(hipEventCreateWithFlags(&c->ev_last_modes, hipEventDisableTiming));
     if (c->h_last_modes.ensure((size_t)n_clouds * n_adaptive) == CLDN_HIP_OK) {  // no copy in flight: buffer is free
       HIP_TRY(hipMemcpyAsync(c->h_last_modes.p, c->d_modes.p, (size_t)n_clouds * n_adaptive, hipMemcpyDeviceToHost,
@@ -1319,9 +1392,9 @@ int cldn_hip_codec_force_modes(cldn_hip_codec_t* c, const uint8_t* modes, uint32
     c->forced_modes.clear();
     return CLDN_HIP_OK;
   }
-  if (n_modes != c->plan.dev.n_adaptive)
+  if (n_modes != c->plan.n_adaptive_total())
     return fail(CLDN_HIP_ERR_ARG, "force_modes: %u modes given, the plan has %u adaptive fields", n_modes,
-                c->plan.dev.n_adaptive);
+                c->plan.n_adaptive_total());
   for (uint32_t a = 0; a < n_modes; ++a)
     if (modes[a] > 3u) return fail(CLDN_HIP_ERR_ARG, "force_modes: invalid adaptive-int mode %u", modes[a]);
   c->forced_modes.assign(modes, modes + n_modes);
@@ -1479,6 +1552,11 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
   L.out = d_outp;
   L.fill_zero = c->decode_fill == CLDN_HIP_FILL_ZERO ? 1u : 0u;
   L.status = (uint32_t*)c->d_status.p;
+  if (c->plan.wide) {  // the serial decoder with the plan in device memory; its per-op state: 16 bytes per op and chunk
+    if ((rc = c->d_wide_state.ensure((size_t)std::max(1u, n_chunks) * std::max<size_t>(1, c->plan.ops_all.size()) * 16u)) != CLDN_HIP_OK) return rc;
+    L.wide = &c->wide_desc;
+    L.wide_state = c->d_wide_state.p;
+  }
   if ((rc = stage1_launch_decode(L)) != CLDN_HIP_OK) return rc;
 
   if (out_loc == CLDN_HIP_DEVICE) return CLDN_HIP_OK;
@@ -1522,8 +1600,10 @@ int cldn_hip_decode_stage1_unframed(cldn_hip_codec_t* c, const void* payload, ui
     // content (uncovered bytes of a point, and all points behind the last decoded one)
     if (out_bytes) HIP_TRY(hipMemcpyAsync(d_outp, points_out, (size_t)out_bytes, hipMemcpyHostToDevice, c->stream));
   }
+  if (c->plan.wide && (rc = c->d_wide_state.ensure(std::max<size_t>(1, c->plan.ops_all.size()) * 16u)) != CLDN_HIP_OK) return rc;
   if ((rc = stage1_launch_decode_unframed(c->plan.dev, c->stream, d_payload, (uint32_t)size, (uint32_t)cap_points, c->d_dec_meta.p,
-                                          d_outp, (uint32_t*)c->d_status.p)) != CLDN_HIP_OK)
+                                          d_outp, (uint32_t*)c->d_status.p, c->plan.wide ? &c->wide_desc : nullptr,
+                                          c->d_wide_state.p)) != CLDN_HIP_OK)
     return rc;
   if (out_loc == CLDN_HIP_DEVICE) return CLDN_HIP_OK;
   uint32_t st = 0;

@@ -304,11 +304,16 @@ __device__ void decode_section_serial(Rd& r, uint8_t* base, uint32_t step, uint3
 
 // grid = n_chunks, 64 threads, lane 0 works. `only_sections`: the regular stream was decoded by the fast kernel, which
 // left the offset of the first section byte in reg_end[c].
-__device__ __forceinline__ void decode_general_body(const DevPlan plan, const uint8_t* __restrict__ streams,
-                                                       const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
-                                                       uint32_t uses_v5, uint32_t only_sections,
-                                                       const uint32_t* __restrict__ reg_end,
-                                                       const uint8_t* __restrict__ sec_done, uint32_t* __restrict__ status) {
+// WIDE (round 5): PLAN = WidePlan -- a schema beyond the launch-argument plan (stage1_wide.h). Its ops are read from device
+// memory and the per-op state lives in `wide_state` (n_ops * 16 bytes per chunk: [int64 prev][u8 lead][u8 trail]) instead of
+// the fixed LDS arrays.
+template <bool WIDE, class PLAN>
+__device__ __forceinline__ void decode_general_body_t(const PLAN& plan, const uint8_t* __restrict__ streams,
+                                                         const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
+                                                         uint32_t uses_v5, uint32_t only_sections,
+                                                         const uint32_t* __restrict__ reg_end,
+                                                         const uint8_t* __restrict__ sec_done, uint32_t* __restrict__ status,
+                                                         uint8_t* wide_state) {
   if (threadIdx.x != 0) return;
   const DecChunk dc = chunks[blockIdx.x];
   if (!dc.valid) return;
@@ -318,8 +323,9 @@ __device__ __forceinline__ void decode_general_body(const DevPlan plan, const ui
   __shared__ __attribute__((aligned(16))) uint8_t rd_window[kRdWindow + 16u];
   // the ops of the plan in LDS: an op read from the kernel-argument segment at a run-time index is a memory round trip
   // per member, several per token
-  __shared__ DevOp ops_l[kMaxOps];
-  for (uint32_t k = 0; k < plan.n_ops; ++k) ops_l[k] = plan.ops[k];
+  __shared__ DevOp ops_l[WIDE ? 1 : kMaxOps];
+  if (!WIDE)
+    for (uint32_t k = 0; k < plan.n_ops; ++k) ops_l[k] = plan.ops[k];
   Rd r;
   r.p = streams + dc.src_off;
   r.end = r.p + dc.src_size;
@@ -339,8 +345,12 @@ __device__ __forceinline__ void decode_general_body(const DevPlan plan, const ui
   atomicAdd(&status[regular_done ? kStatSerialSections : kStatSerialChunks], 1u);
   if (!regular_done) {
     // (per-op state in LDS: a 64-entry array indexed at run time would live in scratch, one memory round trip per access)
-    __shared__ int64_t prev[kMaxOps];
-    __shared__ uint8_t gor_lead[kMaxOps], gor_trail[kMaxOps];
+    __shared__ int64_t prev_l[WIDE ? 1 : kMaxOps];
+    __shared__ uint8_t gor_lead_l[WIDE ? 1 : kMaxOps], gor_trail_l[WIDE ? 1 : kMaxOps];
+    uint8_t* ws = WIDE ? wide_state + (size_t)blockIdx.x * plan.n_ops * 16u : nullptr;
+    int64_t* prev = WIDE ? reinterpret_cast<int64_t*>(ws) : prev_l;
+    uint8_t* gor_lead = WIDE ? ws + (size_t)plan.n_ops * 8u : gor_lead_l;
+    uint8_t* gor_trail = WIDE ? ws + (size_t)plan.n_ops * 9u : gor_trail_l;
     for (uint32_t k = 0; k < plan.n_ops; ++k) {
       prev[k] = 0;
       gor_lead[k] = 255;  // kLeadingSentinel
@@ -355,7 +365,7 @@ __device__ __forceinline__ void decode_general_body(const DevPlan plan, const ui
       // "Truncated encoded data: not enough bytes for a complete point" (v4_codec.cpp:103-105)
       if (!uses_v5 && (size_t)(r.end - r.p) < plan.min_regular_bytes) { r.bad = true; break; }
       for (uint32_t k = 0; k < plan.n_ops && !r.bad; ++k) {
-        const DevOp& op = ops_l[k];
+        const DevOp& op = WIDE ? plan.ops[k] : ops_l[k];
         const bool store = op.offset != 0xffffffffu;  // kDecodeButSkipStore
         switch (op.kind) {
           case OP_QF32: {  // FieldDecoderFloatN_Lossy, src/field_decoder.cpp:43-86
@@ -488,6 +498,21 @@ __device__ __forceinline__ void decode_general_body(const DevPlan plan, const ui
     if (!r.bad && r.p != r.end) r.bad = true;  // "V5 chunk has trailing bytes after decode" (v5_codec.cpp:1008-1010)
   }
   if (r.bad) atomicOr(status, (uint32_t)ST_CORRUPT);
+}
+
+__device__ __forceinline__ void decode_general_body(const DevPlan& plan, const uint8_t* __restrict__ streams,
+                                                       const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
+                                                       uint32_t uses_v5, uint32_t only_sections,
+                                                       const uint32_t* __restrict__ reg_end,
+                                                       const uint8_t* __restrict__ sec_done, uint32_t* __restrict__ status) {
+  decode_general_body_t<false>(plan, streams, chunks, out, uses_v5, only_sections, reg_end, sec_done, status, nullptr);
+}
+
+// the WIDE route's decoder: grid = n_chunks, 64 threads, lane 0 works (whole chunks, regular stream and sections)
+__global__ __launch_bounds__(64) void k_decode_wide(const WidePlan plan, const uint8_t* __restrict__ streams,
+                                                    const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
+                                                    uint32_t uses_v5, uint32_t* __restrict__ status, uint8_t* wide_state) {
+  decode_general_body_t<true>(plan, streams, chunks, out, uses_v5, 0u, nullptr, nullptr, status, wide_state);
 }
 
 __global__ __launch_bounds__(64) void k_decode_general(const DevPlan plan, const uint8_t* __restrict__ streams,

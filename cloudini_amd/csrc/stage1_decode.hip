@@ -78,7 +78,8 @@ static_assert(sizeof(DecChunk) <= kDecChunkBytes, "DecodeLaunch::chunks entries 
 
 // wire version 2: one unframed payload, decoded by the serial restatement of DecodeV4Stage1Chunk (one lane)
 int stage1_launch_decode_unframed(const DevPlan& plan, hipStream_t stream, const uint8_t* payload, uint32_t size,
-                                  uint32_t capacity_points, void* chunk_slot, uint8_t* out, uint32_t* status) {
+                                  uint32_t capacity_points, void* chunk_slot, uint8_t* out, uint32_t* status, const WidePlan* wide,
+                                  void* wide_state) {
   DecChunk dc;
   dc.src_off = 0;
   dc.src_size = size;
@@ -89,6 +90,12 @@ int stage1_launch_decode_unframed(const DevPlan& plan, hipStream_t stream, const
   hipError_t e = hipMemcpyAsync(chunk_slot, &dc, sizeof(dc), hipMemcpyHostToDevice, stream);
   if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(DecChunk)");
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return hip_fail(e, "hipStreamSynchronize");  // `dc` lives on this frame
+  if (wide) {
+    hipLaunchKernelGGL(k_decode_wide, dim3(1), dim3(64), 0, stream, *wide, payload, reinterpret_cast<const DecChunk*>(chunk_slot), out, 0u,
+                       status, reinterpret_cast<uint8_t*>(wide_state));
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_wide");
+    return CLDN_HIP_OK;
+  }
   hipLaunchKernelGGL(k_decode_general, dim3(1), dim3(64), 0, stream, plan, payload, reinterpret_cast<const DecChunk*>(chunk_slot),
                      out, 0u, 0u, (const uint32_t*)nullptr, (const uint8_t*)nullptr, status);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_general");
@@ -114,6 +121,12 @@ int stage1_launch_decode(const DecodeLaunch& L) {
                        L.cloud_first_point, L.cloud_first_chunk, L.n_clouds, reinterpret_cast<DecChunk*>(L.chunks),
                        L.status);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_walk_chunks");
+  }
+  if (L.n_chunks && L.wide) {  // schemas beyond the launch-argument plan: the serial decoder with the plan in device memory
+    hipLaunchKernelGGL(k_decode_wide, dim3(L.n_chunks), dim3(64), 0, L.stream, *L.wide, L.streams, reinterpret_cast<const DecChunk*>(L.chunks),
+                       L.out, L.uses_v5, L.status, reinterpret_cast<uint8_t*>(L.wide_state));
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_wide");
+    return CLDN_HIP_OK;
   }
   if (L.n_chunks) {
     // regular streams made of varint tokens only go through the parallel kernel; the general kernel then decodes

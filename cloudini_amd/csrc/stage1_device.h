@@ -9,8 +9,10 @@ namespace cldn {
 
 constexpr uint32_t kPointsPerChunk = 32768;  // detail::kPointsPerChunk, src/codec_common.hpp:28
 constexpr uint32_t kProbePoints = 4096;      // kAdaptiveModeProbePoints, src/v5_codec.cpp:76
-// Schema limits of this build. The plan travels to the kernels by value: 64 ops * 40 B + 32 adaptive fields * 8 B plus
-// the column pointer table (32 * 8 B, twice in the general section kernel) stay below the 4 KB a launch may carry.
+// Limits of the launch-argument plan (DevPlan travels to the kernels by value: 64 ops * 32 B + 64 adaptive fields * 8 B plus
+// the column pointer table stay below the 4 KB a launch may carry). Schemas beyond them -- the reference has no limits,
+// src/codec_common.cpp:116-153, src/v5_codec.cpp:719-740 -- take the WIDE route (stage1_wide.h): the plan lives in device
+// memory (WidePlan), one workgroup per chunk writes the chunk's payload in one piece, the decoder is the serial one.
 constexpr int kMaxOps = 64;                  // regular tokens per point
 constexpr int kMaxAdaptive = 64;             // V5 adaptive-int fields per schema
 constexpr uint32_t kMaxPointStep = 1024;     // generic kernel: points wider than 256 bytes go in 64-point tiles (2 x 64 KiB of LDS)
@@ -63,6 +65,19 @@ struct DevPlan {
                                // them raw, at most 8 ops and 256 bytes per point: k_mark_token_ends can lay out the token ends
   DevOp ops[kMaxOps];
   DevAdaptive adaptive[kMaxAdaptive];
+};
+
+// Plan of a schema beyond kMaxOps / kMaxAdaptive / kMaxPointStep: same entries, arrays in device memory (stage1_wide.h).
+struct WidePlan {
+  uint32_t point_step;
+  uint32_t n_ops;
+  uint32_t n_adaptive;
+  uint32_t n_gorilla;
+  uint32_t min_regular_bytes;
+  uint32_t reserved;
+  const DevOp* ops;             // device [n_ops]; OP_GORILLA64: DevOp::type is not used, the token buffer index is op_aux[k]
+  const uint32_t* op_aux;       // device [n_ops]
+  const DevAdaptive* adaptive;  // device [n_adaptive]
 };
 
 // One 32768-point chunk of one cloud of the batch.

@@ -49,6 +49,9 @@ __host__ __device__ constexpr uint32_t fused_region_bytes_tail(int lanes) {
 #ifndef CLDN_FUSED_MAD24
 #define CLDN_FUSED_MAD24 1
 #endif
+#ifndef CLDN_FUSED_OR2_ALWAYS
+#define CLDN_FUSED_OR2_ALWAYS 1
+#endif
 #ifndef CLDN_FUSED_HOIST_COLS
 #define CLDN_FUSED_HOIST_COLS 2
 #endif
@@ -105,7 +108,11 @@ __device__ __forceinline__ void lds_or4(uint8_t* region, uint32_t off, uint32_t 
   const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
   uint32_t* w = reinterpret_cast<uint32_t*>(region + (off & ~3u));
   atomicOr(w, lo);
+#if CLDN_FUSED_OR2_ALWAYS
+  atomicOr(w + 1, hi);  // (a zero OR costs an LDS cycle; the test around it a compare, two exec-mask instructions and a branch)
+#else
   if (hi) atomicOr(w + 1, hi);
+#endif
 }
 // token of <= 5 bytes (w1 holds byte 4)
 __device__ __forceinline__ void lds_or5(uint8_t* region, uint32_t off, uint32_t w0, uint32_t w1, uint32_t len) {

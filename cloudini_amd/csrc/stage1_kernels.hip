@@ -1859,6 +1859,7 @@ __global__ __launch_bounds__(kSecThreads) void k_encode_sections(const DevPlan p
 
 }  // namespace cldn
 
+#include "stage1_wide.h"
 
 // ------------------------------------------------------------------------------------------------------------
 // launchers
@@ -1976,6 +1977,10 @@ int stage1_configure_kernels() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_probe_fast), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kProbeLds);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_probe_fast)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide_probe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kProbeLds);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_wide_probe)");
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide_encode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSecLdsTotal);
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_wide_encode)");
   const void* pk[] = {reinterpret_cast<const void*>(&k_section_palette<uint16_t>),
                       reinterpret_cast<const void*>(&k_section_palette<uint32_t>),
                       reinterpret_cast<const void*>(&k_section_palette<uint64_t>)};
@@ -2239,8 +2244,97 @@ static uint32_t fixed_point_bytes(const DevPlan& P) {
   return bytes;
 }
 
+size_t stage1_wide_scratch_bytes() { return kWideScratchBytes; }
+
+// WIDE route (stage1_wide.h): Gorilla pre-pass in groups, mode probe, one workgroup per chunk, framing
+static int launch_encode_wide(const EncodeLaunch& L) {
+  hipError_t e;
+  const WidePlan& W = *L.wide;
+  if (L.events) {
+    (void)hipEventRecord(L.events[0], L.stream);
+    (void)hipEventRecord(L.events[1], L.stream);
+  }
+  if (L.n_chunks) {
+    if (W.n_gorilla) {
+      // k_gorilla_tokens finds "the blockIdx.y-th Gorilla op of the plan": a plan of at most kMaxOps such ops per launch
+      DevPlan mini;
+      mini = DevPlan{};
+      mini.point_step = W.point_step;
+      uint32_t g0 = 0u;
+      for (uint32_t k = 0; k <= W.n_ops; ++k) {
+        if (k < W.n_ops && L.wide_ops_host[k].kind == OP_GORILLA64) mini.ops[mini.n_ops++] = L.wide_ops_host[k];
+        if (mini.n_ops == (uint32_t)kMaxOps || (k == W.n_ops && mini.n_ops != 0u)) {
+          mini.n_gorilla = mini.n_ops;
+          hipLaunchKernelGGL(k_gorilla_tokens, dim3(L.n_chunks, mini.n_ops), dim3(kGorThreads), 0, L.stream, mini, L.points, L.points_end,
+                             L.chunks, L.pre_out + g0);
+          if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_gorilla_tokens (wide)");
+          g0 += mini.n_ops;
+          mini.n_ops = 0u;
+        }
+      }
+    }
+    WideEncodeArgs A;
+    A.plan = W;
+    A.points = L.points;
+    A.points_end = L.points_end;
+    A.chunks = L.chunks;
+    A.cloud_first_chunk = L.cloud_first_chunk;
+    A.modes = L.modes;
+    A.slots = L.slots;
+    A.slot_stride = L.slot_stride;
+    A.segs = L.segs;
+    A.scratch = L.wide_scratch;
+    A.pre = L.wide_pre;
+    if (W.n_adaptive && !L.modes_forced) {
+      hipLaunchKernelGGL(k_wide_probe, dim3(L.n_clouds * W.n_adaptive), dim3(kS2Threads), kProbeLds, L.stream, A, L.n_clouds);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_wide_probe");
+    }
+    hipLaunchKernelGGL(k_wide_encode, dim3(L.n_chunks), dim3(kWideThreads), kSecLdsTotal, L.stream, A);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_wide_encode");
+  }
+  if (L.events) {
+    (void)hipEventRecord(L.events[2], L.stream);
+    (void)hipEventRecord(L.events[3], L.stream);
+  }
+  if (L.chunks_only) {
+    if (L.n_chunks) {
+      hipLaunchKernelGGL(k_chunk_sizes, dim3((L.n_chunks + 255u) / 256u), dim3(256), 0, L.stream, L.segs, 1u, L.n_chunks, L.chunk_payload,
+                         L.contiguous_flag);
+      if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_chunk_sizes (wide)");
+    }
+  } else {
+    FrameLaunch F;
+    F.stream = L.stream;
+    F.chunks = L.chunks;
+    F.n_chunks = L.n_chunks;
+    F.cloud_first_chunk = L.cloud_first_chunk;
+    F.n_clouds = L.n_clouds;
+    F.slots = L.slots;
+    F.slot_stride = L.slot_stride;
+    F.segs = L.segs;
+    F.segs_per_chunk = 1u;
+    F.rec = L.fin_rec;
+    F.anchor = L.fin_anchor;
+    F.epoch = L.fin_epoch;
+    F.ticket = L.fin_ticket;
+    F.use_ticket = L.use_ticket;
+    F.test_timeout = L.test_timeout;
+    F.chunk_payload = L.chunk_payload;
+    F.chunk_dst = L.chunk_dst;
+    F.stream_offsets = L.stream_offsets;
+    F.out = L.out;
+    F.out_capacity = L.out_capacity;
+    F.status = L.status;
+    const int rc = stage1_launch_frame(F);
+    if (rc != CLDN_HIP_OK) return rc;
+  }
+  if (L.events) (void)hipEventRecord(L.events[4], L.stream);
+  return CLDN_HIP_OK;
+}
+
 int stage1_launch_encode(const EncodeLaunch& L) {
   hipError_t e;
+  if (L.wide) return launch_encode_wide(L);
   // CLDN_HIP_FINISH (A/B switch): 0 = the round-2 kernels (k_chunk_offsets + k_compact), 1 = k_finish without the fused
   // Palette section, 2 (default) = k_finish with it where the schema allows
   static const int finish_mode = getenv("CLDN_HIP_FINISH") ? atoi(getenv("CLDN_HIP_FINISH")) : 2;

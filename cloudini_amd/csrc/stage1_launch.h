@@ -60,7 +60,14 @@ struct EncodeLaunch {
   uint32_t n_pieces;          // multiple of 4
   bool intra;                 // the piece kernel's workgroups place a chunk's regular stream contiguously (subs == 1)
   unsigned long long* wgrec;  // device [n_chunks * 32]: their look-back records, tagged with fin_epoch
+  // WIDE route (stage1_wide.h): schemas beyond the launch-argument plan. wide != NULL: `plan` holds only the scalar members,
+  // subs == 1 and segs_per_chunk == 1 (one segment per chunk), the slots take a chunk's whole payload.
+  const WidePlan* wide;       // host copy of the descriptor (its arrays are device memory), or NULL
+  const DevOp* wide_ops_host; // host copy of the regular ops (the Gorilla pre-pass is launched per group of them)
+  uint8_t* wide_scratch;      // device [n_chunks * stage1_wide_scratch_bytes()]
+  const uint4* const* wide_pre;  // device [n_gorilla] token buffers (same array as pre_out)
 };
+size_t stage1_wide_scratch_bytes();  // per chunk
 
 uint32_t stage1_piece_points(const DevPlan& plan, const uint8_t* points);        // piece kernel applies: points per piece, else 0
 uint32_t stage1_piece_slot_stride(const DevPlan& plan, const uint8_t* points);   // bytes a piece may produce, 256-aligned
@@ -92,6 +99,9 @@ struct DecodeLaunch {
   uint32_t* done_cnt;             // [n_chunks]
   uint8_t* out;                       // device: decoded AoS points
   uint32_t* status;
+  // WIDE route: the serial decoder with the plan in device memory (schemas beyond the launch-argument plan)
+  const WidePlan* wide;               // host copy of the descriptor, or NULL
+  void* wide_state;                   // device [n_chunks * n_ops * 16]: the decoder's per-op state
 };
 
 constexpr size_t kDecChunkBytes = 48;
@@ -104,7 +114,8 @@ int stage1_configure_decode();   // decode TU (stage1_decode.hip); called by sta
 int stage1_launch_encode(const EncodeLaunch& L);
 int stage1_launch_decode(const DecodeLaunch& L);
 int stage1_launch_decode_unframed(const DevPlan& plan, hipStream_t stream, const uint8_t* payload, uint32_t size,
-                                  uint32_t capacity_points, void* chunk_slot, uint8_t* out, uint32_t* status);
+                                  uint32_t capacity_points, void* chunk_slot, uint8_t* out, uint32_t* status,
+                                  const WidePlan* wide = nullptr, void* wide_state = nullptr);
 
 // k_finish alone (no section work): frames the chunks of a batch -- one or more segments per chunk in per-chunk slots --
 // as [u32 size][bytes] streams. Used for the chunks the device-side stage 2 leaves (lz4_kernels.hip).

@@ -36,19 +36,18 @@ extern "C" {
 #define CLDN_HIP_POINTS_PER_CHUNK 32768u /* detail::kPointsPerChunk, src/codec_common.hpp:28 */
 #define CLDN_HIP_PROBE_POINTS 4096u      /* kAdaptiveModeProbePoints, src/v5_codec.cpp:76 */
 
-/* Schema limits of this build (cldn_hip_plan_create answers CLDN_HIP_ERR_UNSUPPORTED beyond them; there is no CPU
- * fallback): point_step <= 1024 bytes; <= 64 per-point tokens (fields of the regular stream: a fused FloatN group
- * counts 3 or 4; Gorilla-coded FLOAT64 fields are tokens like any other); <= 64 adaptive integer fields (16/32/64-bit
- * integers of a V5 lossy schema). The reference has no such limits (src/codec_common.cpp:116-153,
- * src/v5_codec.cpp:719-740); the plan travels to the kernels as a launch argument, which bounds its size. Points wider than
- * 256 bytes take the generic kernel in 64-point tiles. */
+/* Schemas: every schema the reference's factory accepts (CreateCompatibleEncoder, src/codec_common.cpp:116-153;
+ * buildV5Plan, src/v5_codec.cpp:719-740) is accepted here -- no limit on fields, tokens or point_step. Schemas of at
+ * most 64 per-point tokens (a fused FloatN group counts 3 or 4), 64 adaptive integer fields and 1024-byte points take the
+ * ordinary kernels (their plan is a launch argument); anything larger takes the WIDE route (csrc/stage1_wide.h: plan in
+ * device memory, one workgroup per chunk on the way in, the serial decoder on the way back), byte-exact and slow. */
 
 /* Return codes. */
 enum {
   CLDN_HIP_OK = 0,
   CLDN_HIP_ERR_ARG = -1,          /* invalid argument / schema */
   CLDN_HIP_ERR_CAPACITY = -2,     /* output buffer smaller than the worst-case bound (cloudini.cpp:531-534) */
-  CLDN_HIP_ERR_UNSUPPORTED = -3,  /* schema needs a codec this library has no kernel for (no CPU fallback) */
+  CLDN_HIP_ERR_UNSUPPORTED = -3,  /* a call this build cannot serve (e.g. more than 2^32 - 2 points for the viz pre-filter); no schema is refused */
   CLDN_HIP_ERR_DEVICE = -4,       /* HIP runtime error */
   CLDN_HIP_ERR_NO_DEVICE = -5,    /* no usable GPU */
   CLDN_HIP_ERR_CORRUPT = -6,      /* decode: malformed stream (truncated, bad mode byte, trailing bytes, ...) */

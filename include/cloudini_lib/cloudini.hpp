@@ -5,8 +5,8 @@
 //
 // Differences a caller can observe:
 //   * a GPU is required; every error (including "no device") is a std::runtime_error like the reference's own;
-//   * schemas beyond the limits listed in cloudini_hip.h (point_step > 1024, > 64 per-point tokens, > 64 adaptive
-//     integer fields) are rejected with a std::runtime_error: there is no CPU path;
+//   * every schema the reference accepts is accepted (round 5: very wide ones -- more than 64 per-point tokens or adaptive
+//     integer fields, points beyond 1024 bytes -- run on a slow route of their own, see cloudini_hip.h);
 //   * the classes hold an opaque implementation pointer instead of the reference's private members.
 #pragma once
 

@@ -129,8 +129,8 @@ class Oracle:
         s, _keep = self._schema(info)
         cap = int(self.lib.orc_stage1_bound(C.byref(s), n)) + 64 + 32 * n  # slack beyond the reference bound
         out = np.empty(cap, dtype=np.uint8)
-        modes = np.zeros(64, dtype=np.uint8)
-        r = self.lib.orc_encode_stage1(C.byref(s), _ptr(data), n, _ptr(out), cap, _ptr(modes), 64)
+        modes = np.zeros(max(64, len(info.fields)), dtype=np.uint8)
+        r = self.lib.orc_encode_stage1(C.byref(s), _ptr(data), n, _ptr(out), cap, _ptr(modes), len(modes))
         if r < 0:
             raise OracleError(f"orc_encode_stage1 failed: {r}")
         res = out[:r].copy()

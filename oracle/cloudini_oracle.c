@@ -662,7 +662,8 @@ static int afields_build(const orc_schema_t* s, afield_t* a, int max) {
  * WriteStage1Chunk (chunk_writer.cpp:27-48, NONE branch)
  * ---------------------------------------------------------------------------------------------- */
 
-#define ORC_MAX_OPS 256
+/* capacity of the op / adaptive-field tables of one call: every field yields at most one entry */
+#define ORC_MAX_OPS(s) ((int)(s)->n_fields + 8)
 
 static int64_t encode_stage1_impl(const orc_schema_t* s, const uint8_t* data, uint64_t n_points, uint8_t* out,
                                   uint64_t capacity, uint8_t* modes_out, uint32_t modes_capacity,
@@ -686,13 +687,13 @@ static int64_t encode_stage1_impl(const orc_schema_t* s, const uint8_t* data, ui
                                   const uint8_t* forced_modes, uint32_t n_forced) {
   if (!s || s->point_step == 0 || (!data && n_points) || (!out && capacity)) return ORC_ERR_ARG;
   const int v5 = orc_uses_v5(s);
-  op_t* ops = (op_t*)malloc(sizeof(op_t) * ORC_MAX_OPS);
-  afield_t* af = (afield_t*)malloc(sizeof(afield_t) * ORC_MAX_OPS);
+  op_t* ops = (op_t*)malloc(sizeof(op_t) * (size_t)ORC_MAX_OPS(s));
+  afield_t* af = (afield_t*)malloc(sizeof(afield_t) * (size_t)ORC_MAX_OPS(s));
   if (!ops || !af) { free(ops); free(af); return ORC_ERR_NOMEM; }
   int64_t result;
-  const int n_ops = build_ops(s, v5, ops, ORC_MAX_OPS);
+  const int n_ops = build_ops(s, v5, ops, ORC_MAX_OPS(s));
   if (n_ops < 0) { free(ops); free(af); return n_ops; }
-  const int n_af = afields_build(s, af, ORC_MAX_OPS);
+  const int n_af = afields_build(s, af, ORC_MAX_OPS(s));
   if (n_af < 0) { free(ops); free(af); return n_af; }
   if (forced_modes) {
     if ((int)n_forced != n_af) { afields_free(af, n_af); free(ops); free(af); return ORC_ERR_ARG; }
@@ -1028,11 +1029,11 @@ int64_t orc_decode_stage1(const orc_schema_t* s, const uint8_t* stream, uint64_t
                           uint64_t n_points, uint8_t* out) {
   if (!s || s->point_step == 0) return ORC_ERR_ARG;
   const int v5 = orc_uses_v5(s);
-  op_t* ops = (op_t*)malloc(sizeof(op_t) * ORC_MAX_OPS);
-  afield_t* af = (afield_t*)calloc(ORC_MAX_OPS, sizeof(afield_t));
+  op_t* ops = (op_t*)malloc(sizeof(op_t) * (size_t)ORC_MAX_OPS(s));
+  afield_t* af = (afield_t*)calloc((size_t)ORC_MAX_OPS(s), sizeof(afield_t));
   if (!ops || !af) { free(ops); free(af); return ORC_ERR_NOMEM; }
   int64_t result = 0;
-  const int n_ops = build_ops(s, v5, ops, ORC_MAX_OPS);
+  const int n_ops = build_ops(s, v5, ops, ORC_MAX_OPS(s));
   if (n_ops < 0) { free(ops); free(af); return n_ops; }
   int n_af = 0;
   if (v5) {

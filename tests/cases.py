@@ -367,6 +367,79 @@ def gorilla_pair(n=35000, seed=41):
     return info, pack(info, cols, n)
 
 
+_FT_SIZE = {F.INT8: 1, F.UINT8: 1, F.INT16: 2, F.UINT16: 2, F.INT32: 4, F.UINT32: 4, F.FLOAT32: 4, F.FLOAT64: 8,
+            F.INT64: 8, F.UINT64: 8}
+_FT_NP = {F.INT8: np.int8, F.UINT8: np.uint8, F.INT16: np.int16, F.UINT16: np.uint16, F.INT32: np.int32, F.UINT32: np.uint32,
+          F.FLOAT32: np.float32, F.FLOAT64: np.float64, F.INT64: np.int64, F.UINT64: np.uint64}
+
+
+def very_wide_schema(seed):
+    """Round 5: schemas beyond the launch-argument plan of the ordinary kernels -- 65 to 200 fields (so more than 64
+    per-point tokens and / or more than 64 adaptive integer fields, sometimes more than 64 Gorilla-coded doubles) and
+    points of 1 to 4 KiB. The reference has no such limits (src/codec_common.cpp:116-153, src/v5_codec.cpp:719-740);
+    the library's WIDE route (stage1_wide.h) takes them. Fixed seeds; every encoding option and wire version."""
+    rs = np.random.RandomState(seed)
+    n = int(rs.choice([1, 100, 4097, 9000])) if seed % 10 else 33000        # every tenth seed: two chunks
+    n_fields = int(rs.choice([65, 70, 100, 130, 200])) if n < 33000 else int(rs.choice([65, 80]))
+    flavour = int(rs.randint(0, 4))   # 0 mixed, 1 mostly integers (adaptive fields), 2 mostly doubles (Gorilla), 3 mostly floats
+    lead_floats = int(rs.choice([0, 2, 3, 4, 5]))
+    types = []
+    for i in range(n_fields):
+        if i < lead_floats:
+            types.append(F.FLOAT32)
+        elif flavour == 1 and rs.rand() < 0.85:
+            types.append(F(int(rs.choice([3, 4, 5, 6, 9, 10]))))
+        elif flavour == 2 and rs.rand() < 0.8:
+            types.append(F.FLOAT64)
+        elif flavour == 3 and rs.rand() < 0.8:
+            types.append(F.FLOAT32)
+        else:
+            types.append(F(int(rs.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10]))))
+    fields, off, cols = [], int(rs.choice([0, 0, 1, 4])), {}
+    for i, t in enumerate(types):
+        res = None
+        if t == F.FLOAT32 and (i < lead_floats or rs.rand() < 0.5):
+            res = float(rs.choice([0.001, 0.01, 1.0]))
+        if t == F.FLOAT64 and rs.rand() < (0.15 if flavour == 2 else 0.5):
+            res = float(rs.choice([1e-6, 0.001]))
+        name = f"f{i}"
+        fields.append((name, off, t, res))
+        kind = rs.randint(0, 4)
+        if t in (F.FLOAT32, F.FLOAT64):
+            if kind == 0:
+                v = np.cumsum(rs.normal(0, 0.01, n))
+            elif kind == 1:
+                v = rs.uniform(-100, 100, n)
+            elif kind == 2:
+                v = np.round(rs.uniform(-5, 5, n), 2)
+            else:
+                v = rs.uniform(0, 1, n) + 1.6e9
+            v = v.astype(_FT_NP[t])
+            if rs.rand() < 0.3 and n > 10:
+                v[rs.randint(0, n, max(1, n // 50))] = np.nan
+        else:
+            ii = np.iinfo(_FT_NP[t])
+            if kind == 0:
+                v = rs.randint(0, 7, n) * 3
+            elif kind == 1:
+                v = np.arange(n) % 50
+            elif kind == 2:
+                v = np.repeat(rs.randint(0, 100, n // 300 + 1), 300)[:n]
+            else:
+                v = rs.randint(max(ii.min, -2**62), min(ii.max, 2**62), n, dtype=np.int64)
+            v = v.astype(_FT_NP[t])
+        cols[name] = v
+        off += _FT_SIZE[t] + int(rs.choice([0, 0, 0, 1, 2, 4, 16]))
+    step = max(off + int(rs.choice([0, 3, 8])), int(rs.choice([1025, 1500, 2048, 3000, 4096])))
+    enc = EncodingOptions(int(rs.choice([0, 1, 1, 1, 2])))
+    version = int(rs.choice([4, 5, 5, 5]))
+    info = make_info(fields, step, n, enc=enc, version=version)
+    return info, pack(info, cols, n)
+
+
+VERY_WIDE_SEEDS = list(range(9000, 9040))
+
+
 def encode_cases(small=False):
     """(name, info, data) for every schema family; `small` trims sizes for the CPU-only suite."""
     out = []

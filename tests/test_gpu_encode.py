@@ -140,22 +140,38 @@ def test_batch_mixed_clouds_v5(oracle):
     check_encode(oracle, info, clouds)
 
 
-def test_unsupported_schemas_fail_loudly():
-    """No CPU fallback: what the kernels cannot do is refused with CLDN_HIP_ERR_UNSUPPORTED."""
+def _check_both_ways(oracle, info, data):
     from cloudini_amd import native
-    info = cases.make_info([("x", 0, FieldType.FLOAT32, 0.001)], 1025, 10)  # point_step beyond kMaxPointStep
-    with pytest.raises(native.CloudiniHipError) as e:
-        native.Plan(info)
-    assert e.value.code == -3
-    info = cases.make_info([(f"g{k}", 8 * k, FieldType.FLOAT64, None) for k in range(65)], 520, 10)  # 65 per-point tokens
-    with pytest.raises(native.CloudiniHipError) as e:
-        native.Plan(info)
-    assert e.value.code == -3
-    info = cases.make_info([("x", 0, FieldType.FLOAT32, 0.001)] + [(f"u{k}", 4 + 2 * k, FieldType.UINT16, None) for k in range(65)],
-                           134, 10)  # 65 adaptive integer fields
-    with pytest.raises(native.CloudiniHipError) as e:
-        native.Plan(info)
-    assert e.value.code == -3
+    check_encode(oracle, info, [data])
+    n = data.size // info.point_step
+    want = oracle.encode_stage1(info, data)
+    codec = native.Codec(native.Plan(info))
+    out = np.full(max(1, data.size), 0xC3, dtype=np.uint8)
+    got = codec.decode_host([want], [n], out=out)[0]
+    assert np.array_equal(got, oracle.decode_stage1(info, want, n, fill=0xC3))
+    codec.close()
+
+
+def test_schemas_just_beyond_the_launch_argument_plan(oracle):
+    """Round 5: the three schemas rounds 2-4 refused with CLDN_HIP_ERR_UNSUPPORTED -- a 1025-byte point, 65 per-point tokens
+    (Gorilla-coded doubles), 65 adaptive integer fields -- take the WIDE route (stage1_wide.h) and match the oracle both ways.
+    (Without a GPU cldn_hip_codec_create still fails with NO_DEVICE: there is no CPU fallback.)"""
+    rs = np.random.RandomState(5)
+    n = 5000
+    x = np.cumsum(rs.normal(0, 0.01, n)).astype(np.float32)
+    info = cases.make_info([("x", 0, FieldType.FLOAT32, 0.001)], 1025, n)  # point_step beyond kMaxPointStep
+    _check_both_ways(oracle, info, cases.pack(info, {"x": x}, n))
+    fields = [(f"g{k}", 8 * k, FieldType.FLOAT64, None) for k in range(65)]  # 65 per-point tokens, all Gorilla-coded
+    info = cases.make_info(fields, 520, n)
+    cols = {f"g{k}": (np.cumsum(rs.normal(0, 1e-3, n)) + k).astype(np.float64) for k in range(65)}
+    _check_both_ways(oracle, info, cases.pack(info, cols, n))
+    fields = [("x", 0, FieldType.FLOAT32, 0.001)] + [(f"u{k}", 4 + 2 * k, FieldType.UINT16, None) for k in range(65)]
+    info = cases.make_info(fields, 134, n)  # 65 adaptive integer fields
+    cols = {"x": x}
+    for k in range(65):
+        cols[f"u{k}"] = [(np.arange(n) % 64), rs.randint(0, 200, n) * 3, np.repeat(rs.randint(0, 9, n // 100 + 1), 100)[:n],
+                         rs.randint(0, 65536, n)][k % 4].astype(np.uint16)
+    _check_both_ways(oracle, info, cases.pack(info, cols, n))
 
 
 def test_capacity_contract():

@@ -1,6 +1,7 @@
 """Randomised schemas (fixed seeds): field types, offsets with padding, resolutions, encoding options and wire versions
-drawn at random; GPU encode and decode against the oracle, bit for bit. Every schema the oracle accepts must either
-match or be refused by cldn_hip_plan_create with UNSUPPORTED (never differ)."""
+drawn at random; GPU encode and decode against the oracle, bit for bit. Round 5: no schema the oracle accepts may be
+refused any more (cldn_hip_plan_create has no UNSUPPORTED answer left: schemas beyond the launch-argument plan take the
+WIDE route)."""
 import numpy as np
 import pytest
 
@@ -82,11 +83,7 @@ def test_random_schema(oracle, seed):
     info, data = _random_case(seed)
     n = data.size // info.point_step
     want, want_modes = oracle.encode_stage1(info, data, return_modes=True)
-    try:
-        plan = native.Plan(info)
-    except native.CloudiniHipError as e:
-        assert e.code == -3, e  # CLDN_HIP_ERR_UNSUPPORTED is the only acceptable refusal
-        pytest.skip(f"schema refused: {e}")
+    plan = native.Plan(info)  # (never refused)
     codec = native.Codec(plan)
     streams, _sizes, modes = codec.encode_host([data])
     assert np.array_equal(streams[0], want), (seed, [(f.name, int(f.type), f.offset, f.resolution) for f in info.fields],
@@ -101,17 +98,12 @@ def test_random_schema(oracle, seed):
 
 @pytest.mark.parametrize("seed", list(range(5000, 5040)))
 def test_random_wide_schema(oracle, seed):
-    """Up to 64 fields, points of up to 1024 bytes: either byte-exact or refused with UNSUPPORTED for one of the limits
-    include/cloudini_hip.h lists (more than 64 per-point tokens or 64 adaptive fields)."""
+    """Up to 64 fields, points of up to 1024 bytes (the launch-argument plan's limits): byte-exact."""
     from cloudini_amd import native
     info, data = _random_case(seed, wide=True)
     n = data.size // info.point_step
     want, want_modes = oracle.encode_stage1(info, data, return_modes=True)
-    try:
-        plan = native.Plan(info)
-    except native.CloudiniHipError as e:
-        assert e.code == -3, e
-        pytest.skip(f"schema refused: {e}")
+    plan = native.Plan(info)
     codec = native.Codec(plan)
     streams, _sizes, modes = codec.encode_host([data])
     assert np.array_equal(streams[0], want), (seed, len(info.fields), info.point_step, int(info.encoding_opt), info.version)
@@ -121,6 +113,47 @@ def test_random_wide_schema(oracle, seed):
     got = codec.decode_host([want], [n], out=out)[0]
     assert np.array_equal(got, oracle.decode_stage1(info, want, n, fill=0xC3)), seed
     codec.close()
+
+
+@pytest.mark.parametrize("seed", cases.VERY_WIDE_SEEDS)
+def test_very_wide_schema(oracle, seed):
+    """65-200 fields, points of 1-4 KiB: beyond the launch-argument plan of the ordinary kernels (more than 64 per-point
+    tokens / adaptive fields / Gorilla-coded doubles, point_step > 1024) -- the WIDE route. Byte-exact both ways, modes
+    included; the oracle is pinned to the reference on the same seeds by test_oracle_vs_reference.py."""
+    from cloudini_amd import native
+    info, data = cases.very_wide_schema(seed)
+    n = data.size // info.point_step
+    want, want_modes = oracle.encode_stage1(info, data, return_modes=True)
+    plan = native.Plan(info)
+    codec = native.Codec(plan)
+    streams, _sizes, modes = codec.encode_host([data])
+    assert np.array_equal(streams[0], want), (seed, len(info.fields), info.point_step, int(info.encoding_opt), info.version)
+    if plan.adaptive_fields:
+        assert list(modes[0]) == list(want_modes)
+    out = np.full(max(1, data.size), 0xC3, dtype=np.uint8)
+    got = codec.decode_host([want], [n], out=out)[0]
+    assert np.array_equal(got, oracle.decode_stage1(info, want, n, fill=0xC3)), seed
+    # a batch of three clouds (one of them empty) through the same codec
+    streams3, _s, modes3 = codec.encode_host([data, data[:0], data[: (n // 2) * info.point_step]])
+    assert np.array_equal(streams3[0], want) and streams3[1].size == 0
+    assert np.array_equal(streams3[2], oracle.encode_stage1(info, data[: (n // 2) * info.point_step]))
+    codec.close()
+
+
+@pytest.mark.parametrize("seed", cases.VERY_WIDE_SEEDS[::8])
+def test_very_wide_schema_through_the_host_mirror(reflib, seed):
+    """PointcloudEncoder / PointcloudDecoder (header, framing, LZ4 / ZSTD) on very wide schemas against the reference itself."""
+    from cloudini_amd import api
+    from cloudini_amd.schema import CompressionOption
+    info, data = cases.very_wide_schema(seed)
+    info = info.copy(compression_opt=CompressionOption(seed % 3))
+    want = reflib.encode(info, data)
+    got = api.PointcloudEncoder(info).encode(data)
+    assert np.array_equal(got, want), seed
+    n = data.size // info.point_step
+    want_dec, _ = reflib.decode(want, max(1, data.size), fill=0x42)
+    got_dec, _got_info = api.PointcloudDecoder().decode_stream(want, fill=0x42)
+    assert np.array_equal(got_dec[: n * info.point_step], want_dec[: n * info.point_step]), seed
 
 
 _CORRUPT_SEEDS = list(range(3000, 3080 + int(os.environ.get("CLDN_FUZZ_EXTRA", "0"))))

@@ -40,6 +40,19 @@ def test_decode_matches_reference(oracle, reflib, name, info, data):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("seed", cases.VERY_WIDE_SEEDS)
+def test_very_wide_schemas_match_reference(oracle, reflib, seed):
+    """65-200 fields, points of 1-4 KiB (the WIDE route of the library): the oracle against the reference itself, both ways."""
+    info, data = cases.very_wide_schema(seed)
+    n = len(data) // info.point_step
+    want = reflib.encode_stage1(info, data)
+    got = oracle.encode_stage1(info, data)
+    assert np.array_equal(got, want), seed
+    full = reflib.encode(info, data)
+    want_dec, _yaml = reflib.decode(full, len(data), fill=0x5A)
+    assert np.array_equal(oracle.decode_stage1(info, want, n, fill=0x5A), want_dec), seed
+
+
 def test_reference_mode_bytes(oracle):
     """Per-chunk mode bytes pinned by test_field_encoders.cpp:590-674."""
     for name, info, data, modes in cases.reference_int_sequences():
