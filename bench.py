@@ -341,6 +341,36 @@ def transcode_figures(n_msgs: int):
         return out
 
 
+def leg_roofline(alg_bytes: float, kernel: str, kernel_ms: float, whole_ms: float, what: str):
+    """Round 5: every leg of the line carries its own fractions. algorithmic_bytes = the leg's useful HBM bytes per step
+    (input read + output written, nothing counted twice); `frac` = those bytes over the HIP-event time of
+    the leg's dominant kernel (a lower bound of what that kernel moves: it is charged with the whole leg's bytes) against the
+    8 TB/s peak; `whole_leg_frac` = the same bytes over the leg's wall time per step."""
+    k = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms and kernel_ms > 0 else None
+    w = alg_bytes / (whole_ms * 1e-3) / 1e9 if whole_ms and whole_ms > 0 else None
+    return {"bound": "hbm", "algorithmic_bytes": alg_bytes, "bytes_counted": what, "kernel": kernel, "kernel_ms": kernel_ms,
+            "kernel_GBps": k, "frac": None if k is None else k / HBM_PEAK_GBPS, "whole_leg_ms": whole_ms, "whole_leg_GBps": w,
+            "whole_leg_frac": None if w is None else w / HBM_PEAK_GBPS, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+
+
+def decode_kernel_name(info) -> str:
+    """The kernel stage1_launch_decode gives the regular streams of this schema (stage1_decode.hip)."""
+    lead = 0
+    for f in info.fields:
+        if int(f.type) == 7 and f.resolution is not None and int(info.encoding_opt) == 1:
+            lead += 1
+        else:
+            break
+    rest = info.fields[lead:] if lead in (3, 4) else info.fields
+    v5 = int(info.version) >= 5 and int(info.encoding_opt) == 1
+    if lead in (3, 4) and all(int(f.type) in (3, 4, 5, 6, 9, 10) for f in rest) and (v5 or not rest):
+        return "k_decode_points_w"
+    if int(info.encoding_opt) != 1 and all(int(f.type) in (1, 2, 7, 8) for f in info.fields) and not (
+            int(info.encoding_opt) == 2 and int(info.version) >= 4 and any(int(f.type) == 8 for f in info.fields)):
+        return "k_decode_fixed"
+    return "k_decode_stream_w"
+
+
 def config_figures(dev, steps: int):
     """extra (never `value`): the other BASELINE configs through the same two device-resident calls -- encode to the framed
     streams, decode with the encoder's chunk sizes -- so that every config has a number in the bench line. Each config's
@@ -402,7 +432,14 @@ def config_figures(dev, steps: int):
             codec.set_decode_fill(True)
             dec_zero_ms = timed(lambda: codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size, d_sizes.data_ptr()))
             codec.set_decode_fill(False)
-            codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size, d_sizes.data_ptr())  # (the checked bytes: default mode)
+            codec.enable_timing(4)  # HIP events around the kernels: behind the timed loops (the records cost a few per cent)
+            for _ in range(4):
+                enc()
+            enc_k = [codec.kernel_ms(s_) for s_ in range(4)]
+            dec_k = []
+            for _ in range(4):  # (the last one leaves the checked bytes: default mode)
+                codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), host.size, d_sizes.data_ptr())
+                dec_k.append(codec.decode_ms())
             codec.status()
             entry = {"workload": WORKLOAD_DESC[name].format(clouds=clouds, points=n),
                      "decode_fill_zero_ms": dec_zero_ms,
@@ -410,6 +447,16 @@ def config_figures(dev, steps: int):
                      "encode_ms": enc_ms, "encode_Mpoints_per_s": clouds * n / (enc_ms * 1e-3) / 1e6,
                      "decode_ms": dec_ms, "decode_Mpoints_per_s": clouds * n / (dec_ms * 1e-3) / 1e6,
                      "stage1_bytes_per_point": int(offs[-1]) / (clouds * n)}
+            alg = float(clouds * n * step + int(offs[-1]))
+            pipeline = codec.pipeline(0, d_points.data_ptr())
+            entry["encode_roofline"] = leg_roofline(alg, "k_encode_fused" if pipeline >= 2 else "k_encode_regular / k_encode_floatn",
+                                                    float(np.mean([k["regular"] for k in enc_k])), enc_ms,
+                                                    "point bytes read + framed stream bytes written")
+            entry["encode_device_ms"] = {"regular": float(np.mean([k["regular"] for k in enc_k])),
+                                         "sections": float(np.mean([k["sections"] for k in enc_k])),
+                                         "k_finish": float(np.mean([k["compact"] for k in enc_k]))}
+            entry["decode_roofline"] = leg_roofline(alg, decode_kernel_name(info), float(np.median([k["regular_kernel"] for k in dec_k])),
+                                                    dec_ms, "stream bytes read + point bytes written")
             if checker is not None:
                 got = d_out[int(offs[0]):int(offs[1])].cpu().numpy()
                 want = checker.encode_stage1(info, distinct[0])
@@ -580,7 +627,7 @@ def main():
     codec.enable_timing(max(1, args.steps))
 
     block_times = []
-    kms = None
+    kms, kms_blocks = None, []
     for rep in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
@@ -596,11 +643,14 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         block_times.append(elapsed)
-        if rep == 0 and points_local:
-            kms = [codec.kernel_ms(s) for s in range(args.steps)]
+        if points_local:  # (the slots hold the block's last --steps calls)
+            kms_blocks.append([codec.kernel_ms(s) for s in range(args.steps)])
     codec.status()
-    # value / ms_per_step: the MEDIAN block of --steps steps (round 4; the first block is reported next to it)
+    # value / ms_per_step: the MEDIAN block of --steps steps (round 4; the first block is reported next to it); round 5: the
+    # per-kernel HIP-event times are those of the same block
     elapsed = float(np.median(block_times))
+    if kms_blocks:
+        kms = kms_blocks[int(np.argsort(block_times)[len(block_times) // 2])]
 
     if kms:
         regular_ms = float(np.mean([k["regular"] for k in kms]))
@@ -632,6 +682,7 @@ def main():
         d_dec = torch.empty(max(1, host.size), dtype=torch.uint8, device=dev)
         so = offsets.astype(np.uint64)
         dec_steps = max(1, args.steps // 2)
+        codec.enable_timing(0)  # (the event records between the kernels cost the decode legs 4-17 %: timed without them)
         for _ in range(min(2, max(1, args.warmup))):
             codec.decode_device(d_out.data_ptr(), so, cloud_points, d_dec.data_ptr(), host.size, d_chunk_sizes.data_ptr())
         dec_blocks = []
@@ -657,6 +708,13 @@ def main():
             zero_blocks.append((time.perf_counter() - t1) / dec_steps)
         codec.set_decode_fill(False)
         codec.status()
+        # HIP-event time of the kernel that decodes the regular streams (cldn_hip_codec_decode_ms), a few more calls
+        dec_kernel_ms = []
+        codec.enable_timing(1)
+        for _ in range(5):
+            codec.decode_device(d_out.data_ptr(), so, cloud_points, d_dec.data_ptr(), host.size, d_chunk_sizes.data_ptr())
+            dec_kernel_ms.append(codec.decode_ms())
+        codec.status()
         del d_dec
         dec_ms = float(np.median(dec_blocks)) * 1e3
         decode = {"value": points_local / (dec_ms * 1e-3) / 1e6,
@@ -667,6 +725,9 @@ def main():
                   "fill_zero_ms_per_step": float(np.median(zero_blocks)) * 1e3,
                   "fill_zero_Mpoints_per_s": points_local / float(np.median(zero_blocks)) / 1e6,
                   "chunks_parallel_regular/parallel_sections/serial/serial_sections": list(dec_stats)}
+        decode["roofline"] = leg_roofline(total_out + points_local * step, decode_kernel_name(info),
+                                          float(np.median([k["regular_kernel"] for k in dec_kernel_ms])), dec_ms,
+                                          "stream bytes read + point bytes written")
     # extra (not `value`): stage 1 WITHOUT the framing -- cldn_hip_encode_stage1_chunks leaves every chunk's payload as one
     # run of its slot (the reference's own stage-1 / stage-2 boundary is a buffer per chunk, src/cloudini.cpp:590-614);
     # a device-side stage 2 or any other consumer on the GPU starts from there. Same steps, same bracket; the table is
@@ -706,7 +767,10 @@ def main():
                                                   "sections": float(np.mean([k["sections"] for k in ct_k])), "all_kernels": ct_dev},
                            "whole_stage1_GBps": points_local * (step + out_bpp) / (ct_dev * 1e-3) / 1e9,
                            "payloads_contiguous": int(flag.item()) == 0,
-                           "framed_afterwards_equals_the_timed_batch": same}
+                           "framed_afterwards_equals_the_timed_batch": same,
+                           "roofline": leg_roofline(points_local * (step + out_bpp), "k_encode_fused (intra-chunk placement)",
+                                                    float(np.mean([k["regular"] for k in ct_k])), ct_ms,
+                                                    "point bytes read + payload bytes written")}
             del d_out2
             ct_codec.close()
         except Exception as exc:  # never costs the headline line

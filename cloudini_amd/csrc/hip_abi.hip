@@ -221,6 +221,8 @@ struct cldn_hip_codec {
   uint32_t last_n_chunks = 0;
   // timing
   std::vector<hipEvent_t> events;  // 5 per timing slot
+  hipEvent_t dec_events[4] = {nullptr, nullptr, nullptr, nullptr};  // the last decode call's (timing enabled)
+  bool dec_events_valid = false;
   std::vector<uint8_t> slot_valid;
   uint64_t call_index = 0;
   // modes committed elsewhere (continuation of a cloud from a chunk boundary); empty = probe
@@ -506,7 +508,8 @@ uint64_t cldn_hip_stage2_bound(const cldn_hip_plan_t* plan, uint64_t n_points, i
 
 int cldn_hip_codec_set_stage2(cldn_hip_codec_t* c, int stage2) {
   if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
-  if (stage2 != CLDN_HIP_STAGE2_NONE && stage2 != CLDN_HIP_STAGE2_LZ4) return fail(CLDN_HIP_ERR_ARG, "invalid stage-2 mode %d", stage2);
+  if (stage2 != CLDN_HIP_STAGE2_NONE && stage2 != CLDN_HIP_STAGE2_LZ4 && stage2 != CLDN_HIP_STAGE2_LZ4_FAST)
+    return fail(CLDN_HIP_ERR_ARG, "invalid stage-2 mode %d", stage2);
   c->stage2 = stage2;
   return CLDN_HIP_OK;
 }
@@ -605,6 +608,8 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   if (c->ev_last_modes) (void)hipEventDestroy(c->ev_last_modes);
   for (hipEvent_t& ev : c->events)
     if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t& ev : c->dec_events)
+    if (ev) (void)hipEventDestroy(ev);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -628,6 +633,23 @@ int cldn_hip_codec_enable_timing(cldn_hip_codec_t* c, uint32_t n_slots) {
   c->slot_valid.assign(n_slots, 0);
   for (hipEvent_t& ev : c->events) HIP_TRY(hipEventCreate(&ev));
   c->call_index = 0;
+  c->dec_events_valid = false;
+  for (hipEvent_t& ev : c->dec_events) {
+    if (n_slots && !ev) HIP_TRY(hipEventCreate(&ev));
+    if (!n_slots && ev) {
+      (void)hipEventDestroy(ev);
+      ev = nullptr;
+    }
+  }
+  return CLDN_HIP_OK;
+}
+
+int cldn_hip_codec_decode_ms(cldn_hip_codec_t* c, float ms[2]) {
+  if (!c || !ms) return fail(CLDN_HIP_ERR_ARG, "NULL argument");
+  if (!c->dec_events_valid) return fail(CLDN_HIP_ERR_ARG, "no timed decode call (cldn_hip_codec_enable_timing first)");
+  HIP_TRY(hipEventSynchronize(c->dec_events[3]));
+  HIP_TRY(hipEventElapsedTime(&ms[0], c->dec_events[1], c->dec_events[2]));
+  HIP_TRY(hipEventElapsedTime(&ms[1], c->dec_events[0], c->dec_events[3]));
   return CLDN_HIP_OK;
 }
 
@@ -807,7 +829,8 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
     need_s1 += cldn_hip_stage1_bound(&c->plan, cloud_points[k]);
     need += cldn_hip_stage2_bound(&c->plan, cloud_points[k], c->stage2);
   }
-  const bool lz4 = c->stage2 == CLDN_HIP_STAGE2_LZ4;
+  const bool lz4 = c->stage2 == CLDN_HIP_STAGE2_LZ4 || c->stage2 == CLDN_HIP_STAGE2_LZ4_FAST;
+  const bool lz4_fast = c->stage2 == CLDN_HIP_STAGE2_LZ4_FAST;
   // two-step host output (cldn_hip_codec_fetch_output): no caller buffer yet, the codec's own device buffer takes the bound
   const bool deferred = out == nullptr && out_loc == CLDN_HIP_HOST && !table;
   if (deferred || table) out_capacity = need;
@@ -1018,9 +1041,19 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
     uint64_t chunk_bound = (uint64_t)kPointsPerChunk * c->plan.ref_max_point_bytes;
     if (c->plan.uses_v5) chunk_bound += (uint64_t)c->plan.fields.size() * 32u + 1024u;
     // every chunk has ceil(payload / 16 KiB) sub-ranges; the payloads of the batch are bounded by need_s1
-    const uint64_t max_subs = need_s1 / kLzSubBytes + n_chunks;
+    const uint32_t lz_sub = lz4_fast ? kLzFastSubBytes : kLzSubBytes, lz_mm = lz4_fast ? kLzFastMaxMatches : kLzMaxMatches;
+    uint64_t max_subs = need_s1 / lz_sub + n_chunks;
+    // the match lists take as many bytes as the payloads they describe: sized from the worst-case stage-1 bound that is
+    // gigabytes for a large batch (32 x 1 M XYZI points: 1.3 GB for 207 MB of payload). Beyond 256 MB the call waits for
+    // stage 1 and sizes them from the bytes it really wrote (one 8-byte read; the wait is ~5 % of what the LZ4 stage takes)
+    if (max_subs * lz_mm * sizeof(LzMatch) > (256ull << 20)) {
+      uint64_t total_s1 = 0;
+      HIP_TRY(hipMemcpyAsync(&total_s1, (const uint64_t*)c->d_s1_offsets.p + n_clouds, sizeof(total_s1), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (total_s1 <= need_s1) max_subs = total_s1 / lz_sub + n_chunks;  // (every chunk's last sub-range may be partial)
+    }
     const uint64_t out_stride = (lz4_block_bound(chunk_bound) + 255u) & ~uint64_t(255);
-    if ((rc = c->d_lz_matches.ensure((size_t)max_subs * kLzMaxMatches * sizeof(LzMatch))) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_lz_matches.ensure((size_t)max_subs * lz_mm * sizeof(LzMatch))) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_lz_counts.ensure((size_t)(max_subs * 4u + n_chunks + 1u) * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_lz_slots.ensure((size_t)n_chunks * out_stride)) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_lz_segs.ensure((size_t)n_chunks * sizeof(Seg))) != CLDN_HIP_OK) return rc;
@@ -1030,6 +1063,7 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
     Z.chunk_dst = (const uint64_t*)c->d_dst.p;
     Z.chunk_payload = (const uint32_t*)c->d_payload.p;
     Z.n_chunks = n_chunks;
+    Z.fast = lz4_fast ? 1u : 0u;
     Z.max_subs = max_subs;
     Z.matches = (LzMatch*)c->d_lz_matches.p;
     Z.counts = (uint32_t*)c->d_lz_counts.p;
@@ -1557,7 +1591,17 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
     L.wide = &c->wide_desc;
     L.wide_state = c->d_wide_state.p;
   }
+  L.events = c->dec_events[0] ? c->dec_events : nullptr;
+  if (L.events) {
+    (void)hipEventRecord(L.events[0], c->stream);
+    (void)hipEventRecord(L.events[1], c->stream);  // (recorded again in front of the regular-stream kernel, if the call has one)
+    (void)hipEventRecord(L.events[2], c->stream);
+  }
   if ((rc = stage1_launch_decode(L)) != CLDN_HIP_OK) return rc;
+  if (L.events) {
+    (void)hipEventRecord(L.events[3], c->stream);
+    c->dec_events_valid = true;
+  }
 
   if (out_loc == CLDN_HIP_DEVICE) return CLDN_HIP_OK;
   uint32_t st = 0;

@@ -37,7 +37,6 @@ namespace cldn {
 namespace {
 
 constexpr uint32_t kLzHashMul = 2654435761u;
-constexpr uint32_t kLzTableSize = 1u << kLzHashBits;
 
 __device__ __forceinline__ uint32_t lz_wave_excl_scan(uint32_t x, uint32_t lane, uint32_t* total) {
   uint32_t incl = x;
@@ -100,7 +99,7 @@ __device__ __forceinline__ uint32_t lz_chunk_of(const uint32_t* __restrict__ sub
 // (a chunk without a byte of payload has no sub-range and no wave below: its block, the single token 0x00, is written here)
 __global__ __launch_bounds__(1024) void k_lz4_plan(const uint32_t* __restrict__ chunk_payload, uint32_t n_chunks,
                                                    uint32_t* __restrict__ sub_first, uint8_t* __restrict__ out_slots,
-                                                   uint64_t out_stride, Seg* __restrict__ out_segs) {
+                                                   uint64_t out_stride, Seg* __restrict__ out_segs, uint32_t sub_bytes) {
   __shared__ uint32_t wtot[16];
   __shared__ uint32_t carry;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(1024) void k_lz4_plan(const uint32_t* __restrict__ 
   __syncthreads();
   for (uint32_t base = 0; base < n_chunks; base += 1024u) {
     const uint32_t c = base + tid;
-    const uint32_t mine = c < n_chunks ? (chunk_payload[c] + kLzSubBytes - 1u) / kLzSubBytes : 0u;
+    const uint32_t mine = c < n_chunks ? (chunk_payload[c] + sub_bytes - 1u) / sub_bytes : 0u;
     if (c < n_chunks && mine == 0u) {
       out_slots[(size_t)c * out_stride] = 0u;
       Seg sg;
@@ -131,22 +130,25 @@ __global__ __launch_bounds__(1024) void k_lz4_plan(const uint32_t* __restrict__ 
 }
 
 // workgroups of one wave; every workgroup takes the sub-ranges blockIdx.x, blockIdx.x + gridDim.x, ...
+// SUB / HASH_BITS / MAX_MATCHES: kLzSubBytes, kLzHashBits, kLzMaxMatches, or the kLzFast* set
+template <uint32_t SUB, uint32_t HASH_BITS, uint32_t MAX_MATCHES>
 __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ stream, const uint64_t* __restrict__ chunk_dst,
                                                   const uint32_t* __restrict__ chunk_payload, uint32_t n_chunks,
                                                   const uint32_t* __restrict__ sub_first, LzMatch* __restrict__ matches,
                                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ last_end) {
-  __shared__ __attribute__((aligned(16))) uint32_t data[kLzSubBytes / 4u + 8u];  // the sub-range (+ slack for the straddling dword reads)
-  __shared__ uint32_t table[kLzTableSize];          // position inside the sub-range + 1; 0 = free
+  constexpr uint32_t kTable = 1u << HASH_BITS;
+  __shared__ __attribute__((aligned(16))) uint32_t data[SUB / 4u + 8u];  // the sub-range (+ slack for the straddling dword reads)
+  __shared__ uint32_t table[kTable];                // position inside the sub-range + 1; 0 = free
   const uint32_t lane = threadIdx.x;
   const uint32_t total = sub_first[n_chunks];
   for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
     const uint32_t c = lz_chunk_of(sub_first, n_chunks, idx);
     const uint32_t k = idx - sub_first[c];
     const uint32_t n = chunk_payload[c];
-    const uint32_t s = k * kLzSubBytes;
-    const uint32_t e = n - s < kLzSubBytes ? n : s + kLzSubBytes;
+    const uint32_t s = k * SUB;
+    const uint32_t e = n - s < SUB ? n : s + SUB;
     const uint8_t* in = stream + chunk_dst[c] + 4u;
-    LzMatch* out = matches + (size_t)idx * kLzMaxMatches;
+    LzMatch* out = matches + (size_t)idx * MAX_MATCHES;
     uint32_t count = 0u, lend = 0u;
     __syncthreads();  // the previous sub-range's LDS contents are done with
     if (n >= 13u && e - s >= 4u) {
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ st
         const uint32_t bytes = e - s;
         const uint8_t* src = in + s;
         const uint32_t full = bytes >> 4;  // 16 bytes per lane and load (unaligned dwordx4), all loads before the stores
-        constexpr uint32_t kRounds = kLzSubBytes / 16u / 64u;
+        constexpr uint32_t kRounds = SUB / 16u / 64u;
         uint4 w[kRounds];
 #pragma unroll
         for (uint32_t r = 0; r < kRounds; ++r) {
@@ -164,10 +166,10 @@ __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ st
         }
 #pragma unroll
         for (uint32_t r = 0; r < kRounds; ++r) reinterpret_cast<uint4*>(data)[r * 64u + lane] = w[r];
-        if (lane < 2u) reinterpret_cast<uint4*>(data)[kLzSubBytes / 16u + lane] = make_uint4(0u, 0u, 0u, 0u);  // the slack
+        if (lane < 2u) reinterpret_cast<uint4*>(data)[SUB / 16u + lane] = make_uint4(0u, 0u, 0u, 0u);  // the slack
         __syncthreads();
         if (lane < (bytes & 15u)) reinterpret_cast<uint8_t*>(data)[(full << 4) + lane] = src[(full << 4) + lane];  // last partial unit
-        for (uint32_t i = lane; i < kLzTableSize; i += 64u) table[i] = 0u;
+        for (uint32_t i = lane; i < kTable; i += 64u) table[i] = 0u;
       }
       __syncthreads();
       // positions below are relative to s
@@ -175,11 +177,11 @@ __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ st
       const uint32_t end_limit = min(e, n - 5u) - s;                                        // where a match ends at the latest
       const uint8_t* bytes = reinterpret_cast<const uint8_t*>(data);
       int32_t i = 0;
-      while (i <= last_start && count < kLzMaxMatches) {
+      while (i <= last_start && count < MAX_MATCHES) {
         const int32_t p = i + (int32_t)lane;
         const bool active = p <= last_start;
         const uint32_t seq = lz_lds_u32(data, active ? (uint32_t)p : 0u);
-        const uint32_t h = (seq * kLzHashMul) >> (32u - kLzHashBits);
+        const uint32_t h = (seq * kLzHashMul) >> (32u - HASH_BITS);
         const uint32_t cand = active ? table[h] : 0u;
         const bool ok = cand != 0u && lz_lds_u32(data, cand - 1u) == seq;
         // every hit extends its own match, 4 bytes per round, up to kLaneRounds rounds; what is still open then is
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ st
         const uint64_t okmask = __ballot(ok);
         const uint64_t openmask = __ballot(going);
         uint32_t cur = 0u;
-        while (count < kLzMaxMatches && cur < 64u) {
+        while (count < MAX_MATCHES && cur < 64u) {
           const uint64_t mask = okmask & (~0ull << cur);
           if (mask == 0ull) break;
           const uint32_t f = (uint32_t)__builtin_ctzll(mask);
@@ -269,7 +271,7 @@ __device__ __forceinline__ void lz_seq_fields(const LzMatch* __restrict__ list, 
 __global__ __launch_bounds__(64) void k_lz4_sizes(uint32_t n_chunks, const uint32_t* __restrict__ sub_first,
                                                   const LzMatch* __restrict__ matches, const uint32_t* __restrict__ counts,
                                                   const uint32_t* __restrict__ last_end, uint32_t* __restrict__ anchor_in,
-                                                  uint32_t* __restrict__ sub_size) {
+                                                  uint32_t* __restrict__ sub_size, uint32_t max_matches) {
   const uint32_t lane = threadIdx.x;
   const uint32_t total = sub_first[n_chunks];
   for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(64) void k_lz4_sizes(uint32_t n_chunks, const uint3
         break;
       }
     }
-    const LzMatch* list = matches + (size_t)idx * kLzMaxMatches;
+    const LzMatch* list = matches + (size_t)idx * max_matches;
     const uint32_t m = counts[idx];
     uint32_t acc = 0u;
     for (uint32_t j = lane; j < m; j += 64u) {
@@ -310,15 +312,16 @@ __global__ __launch_bounds__(64) void k_lz4_emit(const uint8_t* __restrict__ str
                                                  const uint32_t* __restrict__ sub_first, const LzMatch* __restrict__ matches,
                                                  const uint32_t* __restrict__ counts, const uint32_t* __restrict__ last_end,
                                                  const uint32_t* __restrict__ anchor_in, const uint32_t* __restrict__ sub_size,
-                                                 uint8_t* __restrict__ out_slots, uint64_t out_stride, Seg* __restrict__ out_segs) {
+                                                 uint8_t* __restrict__ out_slots, uint64_t out_stride, Seg* __restrict__ out_segs,
+                                                 uint32_t sub_bytes, uint32_t max_matches) {
   const uint32_t lane = threadIdx.x;
   const uint32_t total = sub_first[n_chunks];
   for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
     const uint32_t c = lz_chunk_of(sub_first, n_chunks, idx);
     const uint32_t first = sub_first[c], end = sub_first[c + 1u];
     const uint32_t n = chunk_payload[c];
-    const uint32_t s = (idx - first) * kLzSubBytes;
-    const uint32_t e = n - s < kLzSubBytes ? n : s + kLzSubBytes;
+    const uint32_t s = (idx - first) * sub_bytes;
+    const uint32_t e = n - s < sub_bytes ? n : s + sub_bytes;
     const uint8_t* in = stream + chunk_dst[c] + 4u;
     uint8_t* out = out_slots + (size_t)c * out_stride;
     // bytes of the sequences before mine / of all sequences; where the last match of the chunk ends
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(64) void k_lz4_emit(const uint8_t* __restrict__ str
       all += (uint32_t)__shfl_xor((int)all, d);
       tail_anchor = max(tail_anchor, (uint32_t)__shfl_xor((int)tail_anchor, d));
     }
-    const LzMatch* list = matches + (size_t)idx * kLzMaxMatches;
+    const LzMatch* list = matches + (size_t)idx * max_matches;
     const uint32_t m = counts[idx];
     const uint32_t a_in = anchor_in[idx];
 
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(64) void k_lz4_emit(const uint8_t* __restrict__ str
       uint32_t a2, dst0;
       if (nxt < end) {  // first sequence of sub-range nxt: everything between has no sequences, so it starts where mine end
         a2 = anchor_in[nxt];
-        const LzMatch r0 = matches[(size_t)nxt * kLzMaxMatches];
+        const LzMatch r0 = matches[(size_t)nxt * max_matches];
         dst0 = before + sub_size[idx] + 1u + lz_ext_bytes(r0.pos - a2);
       } else {  // the block's last sequence
         a2 = tail_anchor;
@@ -440,19 +443,25 @@ __global__ __launch_bounds__(64) void k_lz4_emit(const uint8_t* __restrict__ str
 int lz4_launch(const Lz4Launch& L) {
   if (L.n_chunks == 0u) return CLDN_HIP_OK;
   hipError_t e;
+  const uint32_t sub_bytes = L.fast ? kLzFastSubBytes : kLzSubBytes;
+  const uint32_t max_matches = L.fast ? kLzFastMaxMatches : kLzMaxMatches;
   hipLaunchKernelGGL(k_lz4_plan, dim3(1), dim3(1024), 0, L.stream, L.chunk_payload, L.n_chunks, L.sub_first, L.out_slots, L.out_stride,
-                     L.out_segs);
+                     L.out_segs, sub_bytes);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_plan");
   // one wave per sub-range, at most `max_subs` of them: workgroups beyond the real number find nothing to do
-  const uint32_t grid = (uint32_t)std::min<uint64_t>(L.max_subs, 256u * 16u);
-  hipLaunchKernelGGL(k_lz4_match, dim3(grid), dim3(64), 0, L.stream, L.stage1, L.chunk_dst, L.chunk_payload, L.n_chunks, L.sub_first,
-                     L.matches, L.counts, L.last_end);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(L.max_subs, 256u * (L.fast ? 32u : 16u));
+  if (L.fast)
+    hipLaunchKernelGGL((k_lz4_match<kLzFastSubBytes, kLzFastHashBits, kLzFastMaxMatches>), dim3(grid), dim3(64), 0, L.stream, L.stage1,
+                       L.chunk_dst, L.chunk_payload, L.n_chunks, L.sub_first, L.matches, L.counts, L.last_end);
+  else
+    hipLaunchKernelGGL((k_lz4_match<kLzSubBytes, kLzHashBits, kLzMaxMatches>), dim3(grid), dim3(64), 0, L.stream, L.stage1, L.chunk_dst,
+                       L.chunk_payload, L.n_chunks, L.sub_first, L.matches, L.counts, L.last_end);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_match");
   hipLaunchKernelGGL(k_lz4_sizes, dim3(grid), dim3(64), 0, L.stream, L.n_chunks, L.sub_first, L.matches, L.counts, L.last_end,
-                     L.anchor_in, L.sub_size);
+                     L.anchor_in, L.sub_size, max_matches);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_sizes");
   hipLaunchKernelGGL(k_lz4_emit, dim3(grid), dim3(64), 0, L.stream, L.stage1, L.chunk_dst, L.chunk_payload, L.n_chunks, L.sub_first,
-                     L.matches, L.counts, L.last_end, L.anchor_in, L.sub_size, L.out_slots, L.out_stride, L.out_segs);
+                     L.matches, L.counts, L.last_end, L.anchor_in, L.sub_size, L.out_slots, L.out_stride, L.out_segs, sub_bytes, max_matches);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_emit");
   return CLDN_HIP_OK;
 }

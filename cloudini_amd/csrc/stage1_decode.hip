@@ -112,6 +112,9 @@ static int dv_cols_kernel() {
 int stage1_launch_decode(const DecodeLaunch& L) {
   hipError_t e;
   if (L.n_clouds == 0) return CLDN_HIP_OK;
+  // timing (cldn_hip_codec_decode_ms): events in front of / behind the kernel that decodes the regular streams
+  auto ev_before = [&]() { if (L.events) (void)hipEventRecord(L.events[1], L.stream); };
+  auto ev_after = [&]() { if (L.events) (void)hipEventRecord(L.events[2], L.stream); };
   if (L.chunk_sizes) {
     hipLaunchKernelGGL(k_build_chunks, dim3(L.n_clouds), dim3(256), 0, L.stream, L.streams, L.stream_offsets, L.cloud_first_point,
                        L.cloud_first_chunk, L.chunk_sizes, reinterpret_cast<DecChunk*>(L.chunks), L.status);
@@ -257,6 +260,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
             sm = 2;
         }
       }
+      ev_before();
       if (P.n_ops == 3u && sm == 1) {
         if (nf == 0u) LAUNCH_POINTS_W_SM(3, 0, 1);
         else LAUNCH_POINTS_W_SM(3, 1, 1);
@@ -277,6 +281,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
 #undef LAUNCH_POINTS_W_SM
 #undef LAUNCH_POINTS_W
 #undef LAUNCH_POINTS
+      ev_after();
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_points");
     }
     // Behind k_decode_points, for plans whose sections it can fold, the rest is normally idle: one launch covers it
@@ -318,6 +323,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
                            reinterpret_cast<const DecChunk*>(L.chunks), L.token_ends, L.reg_end);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_mark_token_ends");
       }
+      ev_before();
       if (fixed_bytes != 0u) {
         hipLaunchKernelGGL(k_decode_fixed, dim3(L.n_chunks), dim3(kFxThreads), 0, L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, fixed_bytes);
@@ -339,6 +345,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
                            (const uint32_t*)L.token_ends);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_varint (mixed)");
       }
+      ev_after();
       fast = true;  // from here on like any stream the parallel kernels have taken
     } else if (fast) {
       // round 4: general streams of varint tokens go through the barrier-free stream kernel first (stage1_decode_stream.h);
@@ -380,13 +387,17 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         hipLaunchKernelGGL(k_sections_done, dim3((L.n_chunks + 255u) / 256u), dim3(256), 0, L.stream, L.n_chunks, P.n_adaptive,
                            (const uint8_t*)L.secs_ok, (const uint32_t*)L.done_cnt, L.sec_cols, L.status, 0u);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_done");
+        ev_before();
         hipLaunchKernelGGL((k_decode_stream_w<16, false>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, dcols,
                            (const uint8_t*)L.sec_cols, (const uint32_t*)L.reg_end_pre, L.sec_done);
+        ev_after();
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w");
       } else if (stream_kernel) {
+        ev_before();
         hipLaunchKernelGGL((k_decode_stream_w<16, false>), dim3(L.n_chunks), dim3(16 * 64), (SwLds<16, false>::kTotal), L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{}, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
+        ev_after();
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w");
       }
       const uint32_t redo_only = (points_kernel || stream_kernel) ? 1u : 0u;
@@ -411,8 +422,10 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         else ok = kd == OP_QF32 || kd == OP_LOSSY_F32 || kd == OP_LOSSY_F64 || kd == OP_INT || kd == OP_GORILLA64;
       }
       if (ok) {
+        ev_before();
         hipLaunchKernelGGL((k_decode_stream_w<12, 2>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, true>::kTotal), L.stream, P,
                            L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{}, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
+        ev_after();
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (gorilla)");
         fast = true;  // from here on like any stream the parallel kernels have taken
       }

@@ -136,7 +136,15 @@ __device__ __forceinline__ bool wp_tokens(const uint32_t* wbuf, uint32_t byte0, 
 }
 
 template <int NOPS, int NF, int NW, int WPE = 8, int SM = 0>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_decode_points_w(
+#ifndef CLDN_WP_SGPR
+#define CLDN_WP_SGPR 0
+#endif
+#if CLDN_WP_SGPR
+#define CLDN_WP_SGPR_ATTR __attribute__((amdgpu_num_sgpr(CLDN_WP_SGPR)))
+#else
+#define CLDN_WP_SGPR_ATTR
+#endif
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) CLDN_WP_SGPR_ATTR void k_decode_points_w(
     const DevPlan plan, const uint8_t* __restrict__ streams, const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
     uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done, uint32_t uses_v5, uint32_t* __restrict__ status,
     const uint8_t* __restrict__ col0, const uint8_t* __restrict__ col1, const uint32_t* __restrict__ reg_end_pre,

@@ -99,6 +99,7 @@ struct DecodeLaunch {
   uint32_t* done_cnt;             // [n_chunks]
   uint8_t* out;                       // device: decoded AoS points
   uint32_t* status;
+  hipEvent_t* events;                 // 4 events (start, before / behind the regular-stream kernel, end) or NULL
   // WIDE route: the serial decoder with the plan in device memory (schemas beyond the launch-argument plan)
   const WidePlan* wide;               // host copy of the descriptor, or NULL
   void* wide_state;                   // device [n_chunks * n_ops * 16]: the decoder's per-op state
@@ -148,6 +149,11 @@ int stage1_launch_frame(const FrameLaunch& F);
 constexpr uint32_t kLzSubBytes = 8192;    // a wave parses this much of a payload with its own hash table
 constexpr uint32_t kLzHashBits = 11;
 constexpr uint32_t kLzMaxMatches = 1024;  // per sub-range (the rest of it leaves as literals)
+// CLDN_HIP_STAGE2_LZ4_FAST (round 5): sub-ranges of 4 KiB with a 1024-entry table and 512 matches -- 8.2 KB of LDS per wave
+// instead of 16.4, twice the resident waves (round 4 measured 1.53 x the speed for 3 % of the ratio: 0.894 -> 0.922)
+constexpr uint32_t kLzFastSubBytes = 4096;
+constexpr uint32_t kLzFastHashBits = 10;
+constexpr uint32_t kLzFastMaxMatches = 512;
 struct LzMatch {
   uint32_t pos;  // in the chunk's payload
   uint16_t len;  // 4 .. kLzSubBytes
@@ -159,9 +165,10 @@ struct Lz4Launch {
   const uint64_t* chunk_dst;
   const uint32_t* chunk_payload;
   uint32_t n_chunks;
-  uint64_t max_subs;              // upper bound of the sub-ranges of the batch (payload bound / kLzSubBytes + n_chunks)
+  uint32_t fast;                  // 1 = the CLDN_HIP_STAGE2_LZ4_FAST parameters
+  uint64_t max_subs;              // upper bound of the sub-ranges of the batch (payload bound / sub-range bytes + n_chunks)
   uint32_t* sub_first;            // [n_chunks + 1]: compact sub-range numbering
-  LzMatch* matches;               // [max_subs * kLzMaxMatches]
+  LzMatch* matches;               // [max_subs * kLzMaxMatches] (fast: kLzFastMaxMatches)
   uint32_t* counts;               // [max_subs] and the three arrays behind it: last_end, anchor_in, sub_size
   uint32_t* last_end;
   uint32_t* anchor_in;

@@ -39,7 +39,7 @@ def _payload_kinds(rs, n):
 def test_model_blocks_are_valid_lz4(oracle, n):
     rs = np.random.RandomState(n)
     for kind, payload in _payload_kinds(rs, n):
-        for sub, hb, mm in ((8192, 11, 1024), (8192, 12, 1024), (16384, 12, 2048), (64, 4, 3), (100, 6, 1 << 20), (8192, 12, 5)):
+        for sub, hb, mm in ((8192, 11, 1024), (4096, 10, 512), (8192, 12, 1024), (16384, 12, 2048), (64, 4, 3), (100, 6, 1 << 20), (8192, 12, 5)):
             block = oracle.lz4_model(payload, sub, hb, mm)
             assert _lz4_decompress(block, n) == payload, (kind, sub, hb, mm)
             assert block.size <= n + n // 255 + 16
@@ -78,14 +78,18 @@ GPU_CASES = {
 }
 
 
+_MODEL_PARAMS = {1: (8192, 11, 1024), 2: (4096, 10, 512)}   # CLDN_HIP_STAGE2_LZ4, CLDN_HIP_STAGE2_LZ4_FAST (stage1_launch.h)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("stage2", [1, 2])
 @pytest.mark.parametrize("name", sorted(GPU_CASES))
-def test_device_blocks_equal_the_model_and_decode(oracle, name):
+def test_device_blocks_equal_the_model_and_decode(oracle, name, stage2):
     from cloudini_amd import native
     info, data = GPU_CASES[name]()
     codec = native.Codec(native.Plan(info))
     want_s1 = oracle.encode_stage1(info, data)
-    codec.set_stage2(1)
+    codec.set_stage2(stage2)
     streams, chunk_sizes, _modes = codec.encode_host([data, data[: (data.size // info.point_step // 2) * info.point_step]])
     codec.set_stage2(0)
     plain, plain_sizes, _ = codec.encode_host([data])
@@ -95,7 +99,7 @@ def test_device_blocks_equal_the_model_and_decode(oracle, name):
     assert len(blocks) == len(payloads) and [b.size for b in blocks] == [int(x) for x in chunk_sizes[: len(blocks)]]
     for k, (block, payload) in enumerate(zip(blocks, payloads)):
         assert _lz4_decompress(np.ascontiguousarray(block), payload.size) == payload.tobytes(), (name, k)
-        model = oracle.lz4_model(payload)
+        model = oracle.lz4_model(payload, *_MODEL_PARAMS[stage2])
         assert block.size == model.size and np.array_equal(block, model), (name, k)
     codec.close()
 

@@ -19,7 +19,7 @@ for wl, gen in (("c2 xyzi", lambda: synth.lidar_xyzi(1_000_000)), ("c3 depth rgb
         d_in = torch.from_numpy(np.concatenate([data] * n_clouds)).to(dev)
         cp = np.full(n_clouds, pts, dtype=np.uint64)
         res = {}
-        for stage2 in (0, 1):
+        for stage2 in (0, 1, 2):
             codec.set_stage2(stage2)
             cap = plan.stage2_bound(pts, stage2) * n_clouds
             d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
@@ -34,7 +34,9 @@ for wl, gen in (("c2 xyzi", lambda: synth.lidar_xyzi(1_000_000)), ("c3 depth rgb
             codec.synchronize()
             codec.status()
             res[stage2] = ((time.perf_counter() - t0) / reps, int(d_off.cpu()[-1]))
-        (t0_, b0), (t1_, b1) = res[0], res[1]
-        print(f"{wl} x{n_clouds}: stage 1 only {t0_*1e3:.3f} ms ({b0/n_clouds/pts:.3f} B/pt); + device LZ4 {t1_*1e3:.3f} ms "
-              f"({b1/n_clouds/pts:.3f} B/pt, ratio {b1/b0:.4f}) -> LZ4 part {1e3*(t1_-t0_):.3f} ms, {b0/(t1_-t0_)/1e9:.1f} GB/s of payload")
+        (t0_, b0) = res[0]
+        for mode, tag in ((1, "device LZ4"), (2, "device LZ4 FAST")):
+            (t1_, b1) = res[mode]
+            print(f"{wl} x{n_clouds}: stage 1 only {t0_*1e3:.3f} ms ({b0/n_clouds/pts:.3f} B/pt); + {tag} {t1_*1e3:.3f} ms "
+                  f"({b1/n_clouds/pts:.3f} B/pt, ratio {b1/b0:.4f}) -> LZ4 part {1e3*(t1_-t0_):.3f} ms, {b0/(t1_-t0_)/1e9:.1f} GB/s of payload")
         codec.close()
