@@ -141,21 +141,22 @@ void* pinnedAlloc(size_t bytes) {
 
 void pinnedFree(void* p) noexcept {
   if (!p) return;
-  static const bool no_device = cldn_hip_device_count() <= 0;
-  if (no_device) {
-    std::free(p);
-    return;
-  }
+  // decided per pointer, not per process: a block the cache knows is page-locked, anything else came from malloc (a process
+  // without a GPU) -- two separately evaluated "is there a device" answers could disagree (runtime already torn down at exit)
   PinnedCache& c = pinnedCache();
   {
     std::lock_guard<std::mutex> lock(c.mutex);
     auto it = c.capacity.find(p);
-    if (it != c.capacity.end() && c.idle_bytes + it->second <= PinnedCache::kMaxIdleBytes) {
+    if (it == c.capacity.end()) {
+      std::free(p);
+      return;
+    }
+    if (c.idle_bytes + it->second <= PinnedCache::kMaxIdleBytes) {
       c.idle.emplace(it->second, p);
       c.idle_bytes += it->second;
       return;
     }
-    if (it != c.capacity.end()) c.capacity.erase(it);
+    c.capacity.erase(it);
   }
   cldn_hip_host_free(p);
 }

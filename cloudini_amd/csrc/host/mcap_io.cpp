@@ -12,6 +12,7 @@ size_t ZSTD_compress(void* dst, size_t dstCapacity, const void* src, size_t srcS
 size_t ZSTD_decompress(void* dst, size_t dstCapacity, const void* src, size_t compressedSize);
 size_t ZSTD_compressBound(size_t srcSize);
 unsigned ZSTD_isError(size_t code);
+unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize);  // zstd.h: 0ULL - 1 = unknown, 0ULL - 2 = error
 // LZ4 frame format (liblz4): MCAP's "lz4" chunks are frames, not blocks
 size_t LZ4F_compressFrameBound(size_t srcSize, const void* preferences);
 size_t LZ4F_compressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const void* preferences);
@@ -22,6 +23,9 @@ size_t LZ4F_decompress(void* ctx, void* dst, size_t* dstSize, const void* src, s
 }
 
 namespace cloudini_amd {
+namespace {
+constexpr unsigned long long kZstdContentSizeUnknown = 0ULL - 1, kZstdContentSizeError = 0ULL - 2;
+}
 
 const char* const kPointCloud2SchemaName = "sensor_msgs/msg/PointCloud2";
 const char* const kCompressedPointCloud2SchemaName = "point_cloud_interfaces/msg/CompressedPointCloud2";
@@ -151,7 +155,13 @@ std::vector<uint8_t> lz4FrameDecompress(const uint8_t* src, size_t n, size_t exp
 McapFile::McapFile(const std::string& path) : image_(readFile(path)) {
   if (image_.size() < 16 + 9 || std::memcmp(image_.data(), kMagic, 8) != 0) bad(path + " does not begin with the MCAP magic");
   if (std::memcmp(image_.data() + image_.size() - 8, kMagic, 8) != 0) bad(path + " does not end with the MCAP magic (truncated?)");
-  parseRecords(image_.data() + 8, image_.data() + image_.size() - 8, false);
+  try {
+    parseRecords(image_.data() + 8, image_.data() + image_.size() - 8, false);
+  } catch (const std::bad_alloc&) {
+    bad("out of memory while reading " + path);
+  } catch (const std::length_error&) {
+    bad("out of memory while reading " + path);
+  }
 }
 
 void McapFile::parseRecords(const uint8_t* p, const uint8_t* end, bool in_chunk) {
@@ -215,11 +225,17 @@ void McapFile::parseRecords(const uint8_t* p, const uint8_t* end, bool in_chunk)
           parseRecords(c.p, c.p + n, true);
         } else {
           std::vector<uint8_t> raw;
+          // the record's own claim is not trusted with an allocation: bounded, and checked against the compressed frame
+          if (usize > kMcapMaxChunkBytes) bad("chunk claims " + std::to_string(usize) + " uncompressed bytes (limit " + std::to_string(kMcapMaxChunkBytes) + ")");
           if (comp == "zstd") {
+            const unsigned long long fcs = ZSTD_getFrameContentSize(c.p, n);
+            if (fcs == kZstdContentSizeError || (fcs != kZstdContentSizeUnknown && fcs != usize)) bad("corrupt zstd chunk");
+            if (fcs == kZstdContentSizeUnknown && usize / 4096u > n + 64u) bad("corrupt zstd chunk");  // (no frame expands that far)
             raw.resize(usize);
             const size_t r = ZSTD_decompress(raw.data(), raw.size(), c.p, n);
             if (ZSTD_isError(r) || r != usize) bad("corrupt zstd chunk");
           } else if (comp == "lz4") {
+            if (usize / 256u > n + 64u) bad("corrupt lz4 chunk");  // (LZ4 expands by at most 255 x)
             raw = lz4FrameDecompress(c.p, n, usize);
           } else {
             bad("chunk compression '" + comp + "' is not supported");
@@ -250,22 +266,32 @@ void McapFile::parseRecords(const uint8_t* p, const uint8_t* end, bool in_chunk)
 // writer
 // -----------------------------------------------------------------------------------------------------------------
 McapWriter::McapWriter(const std::string& path, const std::string& profile, McapCompression compression, size_t chunk_size)
-    : compression_(compression), chunk_size_(chunk_size ? chunk_size : 1) {
-  FILE* f = std::fopen(path.c_str(), "wb");
-  if (!f) bad("cannot create " + path);
+    : path_(path), tmp_path_(path + ".partial"), compression_(compression), chunk_size_(chunk_size ? chunk_size : 1) {
+  FILE* f = std::fopen(tmp_path_.c_str(), "wb");
+  if (!f) bad("cannot create " + tmp_path_);
   file_ = f;
-  if (std::fwrite(kMagic, 1, 8, f) != 8) bad("write failed");
-  pos_ = 8;
-  Rec h(OP_HEADER);
-  h.str(profile);
-  h.str("cloudini_amd");
-  put(h.done());
+  try {
+    if (std::fwrite(kMagic, 1, 8, f) != 8) bad("write failed");
+    pos_ = 8;
+    Rec h(OP_HEADER);
+    h.str(profile);
+    h.str("cloudini_amd");
+    put(h.done());
+  } catch (...) {
+    std::fclose(f);
+    file_ = nullptr;
+    std::remove(tmp_path_.c_str());
+    throw;
+  }
 }
 
+// Only close() finalizes. A writer that is destroyed without it (an exception on the way) leaves nothing behind: a bag
+// with a footer would look complete while it misses every message behind the failure.
 McapWriter::~McapWriter() {
-  try {
-    close();
-  } catch (...) {
+  if (file_) {
+    std::fclose(static_cast<FILE*>(file_));
+    file_ = nullptr;
+    std::remove(tmp_path_.c_str());
   }
 }
 
@@ -317,6 +343,7 @@ void McapWriter::writeMessage(uint16_t channel_id, uint32_t sequence, uint64_t l
   r.u64(publish_time);
   r.raw(data, size);
   const auto& rec = r.done();
+  chunk_msgs_[channel_id].emplace_back(log_time, (uint64_t)chunk_.size());  // MessageIndex: offset of the record in the uncompressed chunk
   chunk_.insert(chunk_.end(), rec.begin(), rec.end());
   if (!chunk_has_msg_) {
     chunk_t0_ = chunk_t1_ = log_time;
@@ -363,8 +390,23 @@ void McapWriter::flushChunk() {
   r.u64(body.size());
   r.raw(body.data(), body.size());
   const auto& rec = r.done();
-  ChunkIndex ci{chunk_t0_, chunk_t1_, pos_, rec.size(), body.size(), chunk_.size()};
+  ChunkIndex ci{chunk_t0_, chunk_t1_, pos_, rec.size(), body.size(), chunk_.size(), {}, 0};
   put(rec);
+  // one MessageIndex record per channel with messages in the chunk, right behind it (ascending channel ids)
+  const uint64_t index_start = pos_;
+  for (const auto& kv : chunk_msgs_) {
+    Rec mi(OP_MESSAGE_INDEX);
+    mi.u16(kv.first);
+    mi.u32((uint32_t)(kv.second.size() * 16u));
+    for (const auto& e : kv.second) {
+      mi.u64(e.first);
+      mi.u64(e.second);
+    }
+    ci.message_index_offsets[kv.first] = pos_;
+    put(mi.done());
+  }
+  ci.message_index_length = pos_ - index_start;
+  chunk_msgs_.clear();
   chunk_index_.push_back(ci);
   chunk_.clear();
   chunk_has_msg_ = false;
@@ -374,6 +416,19 @@ void McapWriter::flushChunk() {
 void McapWriter::close() {
   if (closed_ || !file_) return;
   closed_ = true;
+  try {
+    finish();
+  } catch (...) {  // a failed write leaves no file (and no open handle)
+    if (file_) {
+      std::fclose(static_cast<FILE*>(file_));
+      file_ = nullptr;
+    }
+    std::remove(tmp_path_.c_str());
+    throw;
+  }
+}
+
+void McapWriter::finish() {
   flushChunk();
   {
     Rec r(OP_DATA_END);
@@ -403,8 +458,12 @@ void McapWriter::close() {
       r.u64(ci.end_time);
       r.u64(ci.offset);
       r.u64(ci.length);
-      r.u32(0u);  // message_index_offsets: empty map (no message index records are written)
-      r.u64(0u);  // message_index_length
+      r.u32((uint32_t)(ci.message_index_offsets.size() * 10u));  // map<u16 channel, u64 offset of its MessageIndex record>
+      for (const auto& kv : ci.message_index_offsets) {
+        r.u16(kv.first);
+        r.u64(kv.second);
+      }
+      r.u64(ci.message_index_length);
       r.str(compression_ == McapCompression::Zstd ? "zstd" : compression_ == McapCompression::Lz4 ? "lz4" : "");
       r.u64(ci.compressed_size);
       r.u64(ci.uncompressed_size);
@@ -448,7 +507,14 @@ void McapWriter::close() {
   FILE* f = static_cast<FILE*>(file_);
   const bool ok = std::fwrite(kMagic, 1, 8, f) == 8;
   file_ = nullptr;
-  if (std::fclose(f) != 0 || !ok) bad("write failed");
+  if (std::fclose(f) != 0 || !ok) {
+    std::remove(tmp_path_.c_str());
+    bad("write failed");
+  }
+  if (std::rename(tmp_path_.c_str(), path_.c_str()) != 0) {
+    std::remove(tmp_path_.c_str());
+    bad("cannot move " + tmp_path_ + " to " + path_);
+  }
 }
 
 // -----------------------------------------------------------------------------------------------------------------

@@ -50,8 +50,9 @@ struct FinishArgs {
   uint32_t epoch;                     // != 0, changes with every call
   uint32_t* ticket;                   // zero at launch
   uint32_t use_ticket;
-  uint32_t test_timeout;              // test hook (CLDN_HIP_TEST_FINISH_TIMEOUT): without the ticket the launch reports ST_FINISH_TIMEOUT at once
-  uint32_t copy_mode;                 // fin_copy: 0 one unit per lane and two loads, 1 neighbour's load by DPP, 2 ... and two rows per iteration
+  uint32_t test_timeout;              // test hook (cldn_hip_debug_finish_timeout_once): without the ticket the launch reports ST_FINISH_TIMEOUT at once
+  uint32_t copy_mode;                 // fin_copy: 1 = the round-3 loop (one unit per lane, both source units loaded by the lane);
+                                      // anything else = neighbour's unit by DPP, two rows in flight, non-temporal accesses (default)
   uint32_t ablate;                    // profiling only: 1 no copy, 2 no section body (wrong output)
   unsigned long long* trace;          // profiling only (CLDN_HIP_FINISH_TRACE): [n_chunks][16] wall_clock64() stamps of the leaders' phases
   uint32_t order;                     // fused Palette: 0 even chunks section first, odd chunks copy first; 1 all section first; 2 all copy first

@@ -11,8 +11,11 @@
 //               records ("" / "zstd" / "lz4" frame compression) or outside; messages in FILE order (the order
 //               McapReader::readMessages takes by default). Index and summary records are not needed and skipped.
 //   McapWriter  Header, Schema / Channel records, Messages in chunks of <= chunk_size uncompressed bytes, Metadata, DataEnd, a
-//               summary section (Schemas, Channels, ChunkIndexes, Statistics, SummaryOffsets) and the Footer. Message index
-//               records are not written (readers fall back to reading the chunks; the spec makes them optional).
+//               summary section (Schemas, Channels, ChunkIndexes, Statistics, SummaryOffsets) and the Footer. Round 5: one
+//               MessageIndex record per channel behind every chunk ((log_time, offset of the Message record inside the
+//               uncompressed chunk)), their places in the ChunkIndex's message_index_offsets -- indexed readers pick the
+//               chunks to read from that map. The file is written under "<path>.partial" and renamed by close(): a
+//               conversion that fails leaves no well-formed file that is silently missing its tail.
 //   transcodeMcap  the converter: schemas and channels duplicated with the point-cloud schema swapped, metadata copied,
 //               PointCloud2 (or CompressedPointCloud2) messages through the batched GPU pipeline, everything else copied.
 #pragma once
@@ -67,6 +70,9 @@ class McapFile {
   std::vector<uint8_t> image_;
   std::vector<std::vector<uint8_t>> chunks_;
 };
+// (McapFile keeps the file image and every decompressed chunk until it is destroyed: messages point into them. A chunk that
+// claims more than kMcapMaxChunkBytes uncompressed bytes, or more than its compressed frame can hold, is refused.)
+constexpr uint64_t kMcapMaxChunkBytes = 1ull << 30;
 
 enum class McapCompression { None, Lz4, Zstd };
 
@@ -83,11 +89,16 @@ class McapWriter {
  private:
   struct ChunkIndex {
     uint64_t start_time, end_time, offset, length, compressed_size, uncompressed_size;
+    std::map<uint16_t, uint64_t> message_index_offsets;  // channel -> file offset of its MessageIndex record
+    uint64_t message_index_length = 0;
   };
   void flushChunk();
+  void finish();
   void put(const std::vector<uint8_t>& record);
   void* file_ = nullptr;
+  std::string path_, tmp_path_;
   uint64_t pos_ = 0;
+  std::map<uint16_t, std::vector<std::pair<uint64_t, uint64_t>>> chunk_msgs_;  // open chunk: channel -> (log_time, offset)
   McapCompression compression_;
   size_t chunk_size_;
   std::vector<uint8_t> chunk_;  // uncompressed records of the open chunk

@@ -98,6 +98,66 @@ int main(int argc, char** argv) {
     }
     CHECK(threw);
   }
+  if (argc > 2 && std::string(argv[2]) == "abandon") {
+    // a writer that is destroyed without close() (an exception on the way) leaves neither the file nor its ".partial"
+    const std::string path = dir + "/abandoned.mcap";
+    {
+      McapWriter w(path, "ros2", McapCompression::None, 700);
+      const std::vector<uint8_t> p = payload(1);
+      McapChannel a{3, 0, "/x", "cdr", {}};
+      w.addChannel(a);
+      for (uint32_t i = 0; i < 20; ++i) w.writeMessage(3, i, i, i, p.data(), p.size());
+    }
+    FILE* f1 = std::fopen(path.c_str(), "rb");
+    FILE* f2 = std::fopen((path + ".partial").c_str(), "rb");
+    CHECK(f1 == nullptr && f2 == nullptr);
+    std::printf("abandoned writer left nothing\n");
+    // a chunk record that claims 4 GiB of uncompressed bytes behind a 20-byte zstd frame: refused before anything is allocated
+    const std::string big = dir + "/big.mcap";
+    FILE* fp = std::fopen(big.c_str(), "wb");
+    const uint8_t magic[8] = {0x89, 'M', 'C', 'A', 'P', '0', '\r', '\n'};
+    std::fwrite(magic, 1, 8, fp);
+    auto rec = [&](uint8_t op, const std::vector<uint8_t>& body) {
+      std::fputc(op, fp);
+      const uint64_t n = body.size();
+      std::fwrite(&n, 8, 1, fp);
+      std::fwrite(body.data(), 1, body.size(), fp);
+    };
+    auto u32 = [](std::vector<uint8_t>& v, uint32_t x) { for (int k = 0; k < 4; ++k) v.push_back((uint8_t)(x >> (8 * k))); };
+    auto u64 = [](std::vector<uint8_t>& v, uint64_t x) { for (int k = 0; k < 8; ++k) v.push_back((uint8_t)(x >> (8 * k))); };
+    std::vector<uint8_t> h;
+    u32(h, 0);
+    u32(h, 0);
+    rec(0x01, h);
+    std::vector<uint8_t> c;
+    u64(c, 0);
+    u64(c, 0);
+    u64(c, 4ull << 30);  // uncompressed_size
+    u32(c, 0);
+    u32(c, 4);
+    c.insert(c.end(), {'z', 's', 't', 'd'});
+    u64(c, 20);
+    for (int k = 0; k < 20; ++k) c.push_back((uint8_t)k);
+    rec(0x06, c);
+    std::vector<uint8_t> e;
+    u32(e, 0);
+    rec(0x0F, e);
+    std::vector<uint8_t> ft;
+    u64(ft, 0);
+    u64(ft, 0);
+    u32(ft, 0);
+    rec(0x02, ft);
+    std::fwrite(magic, 1, 8, fp);
+    std::fclose(fp);
+    bool refused = false;
+    try {
+      McapFile g(big);
+    } catch (const std::runtime_error& ex) {
+      refused = std::string(ex.what()).find("chunk") != std::string::npos;
+    }
+    CHECK(refused);
+    std::printf("oversized chunk refused\n");
+  }
   std::printf("all checks passed\n");
   return 0;
 }

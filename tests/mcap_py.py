@@ -119,6 +119,11 @@ def read(path):
                 assert comp == "", "the Python reader takes uncompressed chunks only"
                 assert usize == n2
                 walk(recs, off + 9 + (len(body) - n2), "chunk")
+            elif op == MESSAGE_INDEX:
+                ch = c.take("H")
+                nb = c.take("I")
+                assert nb % 16 == 0 and nb == len(body) - 6
+                r.setdefault("message_index", []).append((off, 9 + n, ch, [c.take("QQ") for _ in range(nb // 16)]))
             elif op == METADATA:
                 r["metadata"].append((c.s(), c.m()))
             elif op == DATA_END:
@@ -127,11 +132,13 @@ def read(path):
             elif op == CHUNK_INDEX:
                 t0, t1, coff, clen = c.take("QQQQ")
                 mio = c.take("I")
-                c.i += mio
+                assert mio % 10 == 0
+                offs = dict(c.take("HQ") for _ in range(mio // 10))
                 mil = c.take("Q")
                 comp = c.s()
                 csize, usize = c.take("QQ")
                 r["summary"].setdefault("chunk_index", []).append((t0, t1, coff, clen, mil, comp, csize, usize))
+                r["summary"].setdefault("chunk_index_message_offsets", []).append(offs)
             elif op == STATISTICS:
                 mc, sc, cc, ac, mdc, chc, t0, t1 = c.take("QHIIIIQQ")
                 n3 = c.take("I")

@@ -318,8 +318,9 @@ def test_one_codec_many_shapes_interleaved_with_decode(oracle):
 def test_finish_timeout_is_retried_through_the_ticket_order():
     """k_finish waits for the records of the workgroups in front of it in dispatch order; when that wait runs out
     (ST_FINISH_TIMEOUT) a call with host outputs is redone once with the ticket counter (include/cloudini_hip.h,
-    cldn_hip_codec_finish_retries). CLDN_HIP_TEST_FINISH_TIMEOUT makes the first attempt report the timeout: the bytes must
-    be those of an undisturbed call, one retry counted, and later calls of the codec go straight through tickets."""
+    cldn_hip_codec_finish_retries). The debug call cldn_hip_debug_finish_timeout_once (outside the boundary) makes the first
+    attempt report the timeout: the bytes must be those of an undisturbed call, one retry counted, and later calls of the
+    codec go straight through tickets."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
         import sys, numpy as np
@@ -327,15 +328,16 @@ def test_finish_timeout_is_retried_through_the_ticket_order():
         from cloudini_amd import native, synth
         info, data = synth.lidar_xyzi(150000, seed=5)
         codec = native.Codec(native.Plan(info))
+        if len(sys.argv) > 1:
+            assert native.lib().cldn_hip_debug_finish_timeout_once(codec._h) == 0
         a = codec.encode_host([data])[0][0]
         b = codec.encode_host([data])[0][0]
         print(codec.finish_retries(), int(np.array_equal(a, b)), a.size, int(a.view(np.uint8).sum()))
         codec.close()
     """ % ROOT)
     outs = []
-    for env_extra in ({}, {"CLDN_HIP_TEST_FINISH_TIMEOUT": "1"}):
-        env = dict(os.environ, **env_extra)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    for extra in ([], ["hook"]):
+        r = subprocess.run([sys.executable, "-c", code] + extra, capture_output=True, text=True, timeout=600, env=dict(os.environ))
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout.strip().splitlines()[-1].split())
     assert outs[0][0] == "0" and outs[1][0] == "1", outs   # one call redone, the second one takes tickets at once

@@ -10,6 +10,7 @@ this image does not have -- nor any sample bag. What can be pinned here:
     the schema of the cloud topics is swapped -- and back again.
 Against the mcap library itself the parity is UNPINNED."""
 import os
+import struct
 import subprocess
 
 import numpy as np
@@ -70,6 +71,35 @@ def test_cpp_writer_and_reader_round_trip_and_python_reads_the_file(tmp_path):
     for g, start, length in s["offsets"]:
         inside = [x for x in f["records"] if x[3] == "summary" and start <= x[1] < start + length]
         assert inside and all(x[0] == g for x in inside) and sum(x[2] for x in inside) == length
+    # round 5: MessageIndex records behind every chunk -- one per channel with messages in it, every (log_time, offset) pointing
+    # at a Message record of that channel inside the uncompressed chunk -- and their places in the ChunkIndex records
+    raw = open(str(tmp_path / "rt_none.mcap"), "rb").read()
+    mi = f["message_index"]
+    chunks = f["chunks"]
+    seen = 0
+    for k, (coff, clen, _t0, _t1, usize, _comp, n2) in enumerate(chunks):
+        nxt = chunks[k + 1][0] if k + 1 < len(chunks) else None
+        mine = [m for m in mi if m[0] >= coff + clen and (nxt is None or m[0] < nxt)]
+        body0 = coff + clen - n2                      # where the chunk's (uncompressed) records begin in the file
+        assert s["chunk_index_message_offsets"][k] == {m[2]: m[0] for m in mine}
+        assert s["chunk_index"][k][4] == sum(m[1] for m in mine)     # message_index_length
+        assert [m[2] for m in mine] == sorted({m[2] for m in mine})
+        for _off, _len, ch, entries in mine:
+            for lt, o in entries:
+                assert raw[body0 + o] == mcap_py.MESSAGE
+                got_ch, _seq, got_lt = struct.unpack_from("<HIQ", raw, body0 + o + 9)
+                assert (got_ch, got_lt) == (ch, lt) and o < usize
+                seen += 1
+    assert seen == 60
+    assert not os.path.exists(str(tmp_path / "rt_none.mcap.partial"))
+
+
+def test_cpp_writer_that_is_not_closed_leaves_no_file(tmp_path):
+    """only close() finalizes; a writer destroyed on the way (an exception in the conversion) must not leave a
+    well-formed bag that silently misses its tail. A reader given a chunk that claims 4 GiB must refuse it, not allocate it."""
+    exe = _build(tmp_path, "mcap_roundtrip")
+    r = subprocess.run([exe, str(tmp_path), "abandon"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "abandoned writer left nothing" in r.stdout and "oversized chunk refused" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("chunked", [None, 7])
