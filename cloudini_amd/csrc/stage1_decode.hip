@@ -16,6 +16,7 @@
 #include "stage1_decode_wave.h"
 #include "stage1_decode_stream.h"
 #include "stage1_decode_sections_w.h"
+#include "stage1_decode_automaton.h"
 
 #include "cloudini_hip.h"
 #include "stage1_launch.h"
@@ -310,7 +311,11 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       // layouts with varints AND raw fields: the stream kernel finds the points from their form (FORM instantiation);
       // CLDN_HIP_STREAM_BITMAP=1 keeps k_mark_token_ends' bitmap in front of it (A/B switch)
       static const bool force_bitmap = getenv("CLDN_HIP_STREAM_BITMAP") != nullptr;
-      const bool form = stream_ok && !all_raw && !force_bitmap;
+      // round 5: forms of at most 16 states get their token ends from k_mark_ends_automaton (stage1_decode_automaton.h) and
+      // the stream kernel's bitmap mode; CLDN_HIP_FORM_KERNEL=1 keeps the round-4 FORM instantiation (A/B switch)
+      static const bool form_kernel = getenv("CLDN_HIP_FORM_KERNEL") != nullptr;
+      const bool automaton = stream_ok && !all_raw && !force_bitmap && !form_kernel && automaton_states(P) != 0u && L.token_ends != nullptr;
+      const bool form = stream_ok && !all_raw && !force_bitmap && !automaton;
       // streams of fixed-size tokens only (lossless floats, raw copies; <= 8 fields): nothing to find, k_decode_fixed.
       // CLDN_HIP_NO_FIXED_DECODE=1: the stream kernel (A/B switch)
       static const bool no_fixed_dec = getenv("CLDN_HIP_NO_FIXED_DECODE") != nullptr;
@@ -318,7 +323,11 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       if (!no_fixed_dec && all_raw && P.n_ops <= kFxMaxOps && P.n_gorilla == 0u)
         for (uint32_t k = 0; k < P.n_ops; ++k) fixed_bytes += P.ops[k].size;
       const bool bitmap = !(stream_ok && all_raw) && !form && fixed_bytes == 0u;
-      if (bitmap) {
+      if (bitmap && automaton) {
+        hipLaunchKernelGGL(k_mark_ends_automaton, dim3(L.n_chunks), dim3(kMaWaves * 64u), 0, L.stream, P, L.streams,
+                           reinterpret_cast<const DecChunk*>(L.chunks), L.token_ends, L.reg_end);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_mark_ends_automaton");
+      } else if (bitmap) {
         hipLaunchKernelGGL(k_mark_token_ends, dim3(L.n_chunks), dim3(kMtThreads), 0, L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), L.token_ends, L.reg_end);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_mark_token_ends");
