@@ -138,7 +138,10 @@ __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ st
                                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ last_end) {
   constexpr uint32_t kTable = 1u << HASH_BITS;
   __shared__ __attribute__((aligned(16))) uint32_t data[SUB / 4u + 8u];  // the sub-range (+ slack for the straddling dword reads)
-  __shared__ uint32_t table[kTable];                // position inside the sub-range + 1; 0 = free
+  // position inside the sub-range + 1; 0 = free. (Round 5, measured and dropped: 16-bit entries -- 12.3 KB of LDS per wave,
+  // 13 waves per CU instead of 9 -- with a store / read back / store-again loop in place of the 32-bit atomicMax: byte-equal
+  // blocks, 8 % SLOWER (2.43 -> 2.62 ms on 32 x 1 M XYZI): the step's extra LDS round trip costs more than the waves return)
+  __shared__ uint32_t table[kTable];
   const uint32_t lane = threadIdx.x;
   const uint32_t total = sub_first[n_chunks];
   for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) {

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
   for (uint32_t a = 0; a < NFA; ++a) {
     const FpSection sct = reinterpret_cast<const FpSection*>(misc + 72)[a < n_fold ? a : 0u];
     fs_off[a] = sct.field_off;
-    fs_bpv[a] = sct.bpv;
+    fs_bpv[a] = SM != 0 ? 2u : sct.bpv;  // (store modes: the one field is a 16-bit one)
     fs_count[a] = sct.count;
     fs_bits[a] = a < n_fold ? sct.bits : 0u;
     fs_ioff[a] = a < n_fold ? sct.index_off : 0u;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
               }
             } else if (one_u16) {
               *reinterpret_cast<uint16_t*>(pt + fs_off[0]) = (uint16_t)pv[0];
-            } else {
+            } else if (SM == 0) {  // (store modes: at most the one 16-bit field above -- the launcher has checked the layout)
 #pragma unroll
               for (uint32_t a = 0; a < NFA; ++a) {
                 if (a >= n_fold) break;  // uniform

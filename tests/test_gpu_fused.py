@@ -354,3 +354,78 @@ def test_chunk_table_holds_the_reference_payloads(oracle, case):
     with pytest.raises(native.CloudiniHipError):
         codec.frame_chunks_device(0, 1 << 40)
     codec.close()
+
+
+def test_wide_route_through_the_other_entry_points(oracle):
+    """Round 5: a schema beyond the launch-argument plan (WIDE route, stage1_wide.h) through the entry points the fuzz family
+    does not take: device-resident calls, the chunk table + cldn_hip_frame_chunks, LZ4 blocks on the device (both parameter
+    sets), chunk ranges with forced modes -- the same bytes as the one-call host path, which test_gpu_fuzz.py pins to the
+    oracle."""
+    import ctypes as C
+    import torch
+    import cases
+    from cloudini_amd import native
+    info, data = cases.very_wide_schema(9010)          # 33000 points: two chunks
+    step = info.point_step
+    n = data.size // step
+    want, want_modes = oracle.encode_stage1(info, data, return_modes=True)
+    dev = torch.device("cuda", 0)
+    codec = native.Codec(native.Plan(info))
+    # device-resident encode + decode with the encoder's chunk sizes
+    d_in = torch.from_numpy(data).to(dev)
+    cap = codec.plan.stage1_bound(n)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(2, dtype=torch.int64, device=dev)
+    d_sizes = torch.zeros(2, dtype=torch.int32, device=dev)
+    cp = np.array([n], dtype=np.uint64)
+    codec.encode_device(d_in.data_ptr(), cp, d_out.data_ptr(), cap, d_off.data_ptr(), d_sizes.data_ptr(), 0)
+    codec.synchronize()
+    codec.status()
+    offs = d_off.cpu().numpy().astype(np.uint64)
+    assert int(offs[1]) == want.size and np.array_equal(d_out[: want.size].cpu().numpy(), want)
+    d_dec = torch.full((data.size,), 0xC3, dtype=torch.uint8, device=dev)
+    codec.decode_device(d_out.data_ptr(), offs, cp, d_dec.data_ptr(), data.size, d_sizes.data_ptr())
+    codec.synchronize()
+    codec.status()
+    assert np.array_equal(d_dec.cpu().numpy(), oracle.decode_stage1(info, want, n, fill=0xC3))
+    # chunk table, then its framing
+    table = codec.encode_chunks_device(d_in.data_ptr(), cp)
+    codec.synchronize()
+    codec.status()
+    payloads, _segs, not_contiguous = _read_chunk_table(table, torch)
+    assert not_contiguous == 0 and table.segments_per_chunk == 1
+    o, k = 0, 0
+    while o < want.size:
+        size = int.from_bytes(want[o:o + 4].tobytes(), "little")
+        assert np.array_equal(payloads[k], want[o + 4:o + 4 + size])
+        o += 4 + size
+        k += 1
+    assert k == len(payloads) == 2
+    codec.frame_chunks_device(d_out.data_ptr(), cap, d_off.data_ptr())
+    codec.synchronize()
+    codec.status()
+    assert np.array_equal(d_out[: want.size].cpu().numpy(), want)
+    # chunk ranges with the modes committed on the head
+    codec.force_modes(want_modes)
+    a, _, _ = codec.encode_host([data[: 32768 * step]])
+    b, _, _ = codec.encode_host([data[32768 * step:]])
+    assert np.array_equal(np.concatenate([a[0], b[0]]), want)
+    codec.force_modes(None)
+    # stage 2 on the device: blocks equal the serial model's and decode to the payloads
+    lz4 = C.CDLL("/usr/lib/x86_64-linux-gnu/liblz4.so.1")
+    for stage2, params in ((1, (8192, 11, 1024)), (2, (4096, 10, 512))):
+        codec.set_stage2(stage2)
+        streams, _sz, _m = codec.encode_host([data])
+        o, k = 0, 0
+        while o < streams[0].size:
+            size = int.from_bytes(streams[0][o:o + 4].tobytes(), "little")
+            block = np.ascontiguousarray(streams[0][o + 4:o + 4 + size])
+            assert np.array_equal(block, oracle.lz4_model(payloads[k].tobytes(), *params)), (stage2, k)
+            out = C.create_string_buffer(max(1, payloads[k].size))
+            assert lz4.LZ4_decompress_safe(block.ctypes.data_as(C.c_char_p), out, int(block.size), int(payloads[k].size)) == payloads[k].size
+            assert out.raw[: payloads[k].size] == payloads[k].tobytes()
+            o += 4 + size
+            k += 1
+        assert k == 2
+    codec.set_stage2(0)
+    codec.close()
