@@ -324,8 +324,12 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         for (uint32_t k = 0; k < P.n_ops; ++k) fixed_bytes += P.ops[k].size;
       const bool bitmap = !(stream_ok && all_raw) && !form && fixed_bytes == 0u;
       if (bitmap && automaton) {
-        hipLaunchKernelGGL(k_mark_ends_automaton, dim3(L.n_chunks), dim3(kMaWaves * 64u), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), L.token_ends, L.reg_end);
+        if (automaton_states(P) <= 8u)
+          hipLaunchKernelGGL(k_mark_ends_automaton<uint32_t>, dim3(L.n_chunks), dim3(kMaWaves * 64u), 0, L.stream, P, L.streams,
+                             reinterpret_cast<const DecChunk*>(L.chunks), L.token_ends, L.reg_end);
+        else
+          hipLaunchKernelGGL(k_mark_ends_automaton<uint64_t>, dim3(L.n_chunks), dim3(kMaWaves * 64u), 0, L.stream, P, L.streams,
+                             reinterpret_cast<const DecChunk*>(L.chunks), L.token_ends, L.reg_end);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_mark_ends_automaton");
       } else if (bitmap) {
         hipLaunchKernelGGL(k_mark_token_ends, dim3(L.n_chunks), dim3(kMtThreads), 0, L.stream, P, L.streams,

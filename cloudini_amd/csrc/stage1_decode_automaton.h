@@ -51,10 +51,22 @@ __device__ __forceinline__ uint64_t ma_compose(uint64_t a, uint64_t b, uint32_t 
   return r;
 }
 
+// ... of at most 8 states: eight 4-bit fields of one dword (v_bfe_u32 with a register offset does the look-up)
+__device__ __forceinline__ uint32_t ma_compose(uint32_t a, uint32_t b, uint32_t S) {
+  uint32_t r = 0u;
+  for (uint32_t s = 0; s < S; ++s) {  // uniform
+    const uint32_t t = (b >> (4u * s)) & 15u;
+    r |= ((a >> (4u * t)) & 15u) << (4u * s);
+  }
+  return r;
+}
+#define MA_DPP32(X, CTRL, RMASK, BC, OLD) ((uint32_t)__builtin_amdgcn_update_dpp((int)(OLD), (int)(X), CTRL, RMASK, 0xf, BC))
 #define MA_DPP64(X, CTRL, RMASK, BC, OLD)                                                                                  \
   ((((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)((OLD) >> 32), (int)(uint32_t)((X) >> 32), CTRL, RMASK, 0xf, BC)) << 32) | \
    (uint64_t)(uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(OLD), (int)(uint32_t)(X), CTRL, RMASK, 0xf, BC))
 
+// MAP = uint32_t: forms of at most 8 states; uint64_t: of at most 16
+template <typename MAP>
 __global__ __launch_bounds__(kMaWaves * 64) void k_mark_ends_automaton(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                                        const DecChunk* __restrict__ chunks,
                                                                        uint32_t* __restrict__ token_ends, uint32_t* __restrict__ reg_end) {
@@ -123,8 +135,9 @@ __global__ __launch_bounds__(kMaWaves * 64) void k_mark_ends_automaton(const Dev
   const uint8_t* t4 = &T4[0][0];
 
   const uint32_t n_pieces = (src_size + kMaPiece - 1u) / kMaPiece;
-  uint64_t ident = 0ull;
-  for (uint32_t s = 0; s < 16u; ++s) ident |= (uint64_t)s << (4u * s);
+  constexpr bool W64 = sizeof(MAP) == 8;
+  MAP ident = 0;
+  for (uint32_t s = 0; s < (W64 ? 16u : 8u); ++s) ident |= (MAP)s << (4u * s);
 
   for (uint32_t p = wave; p < n_pieces; p += kMaWaves) {
     // ---- my 32 bytes (the lane that holds the payload's end reads them one by one; lanes behind it read nothing)
@@ -152,18 +165,20 @@ __global__ __launch_bounds__(kMaWaves * 64) void k_mark_ends_automaton(const Dev
     for (int k = 0; k < 8; ++k) msb |= (__builtin_amdgcn_udot4(w[k] & 0x80808080u, 0x08040201u, 0u, false) >> 7) << (4 * k);
 
     // ---- my map: where each start state is behind my 32 bytes
-    uint64_t F = 0ull;
+    MAP F = 0;
     for (uint32_t s = 0; s < S; ++s) {  // uniform
       uint32_t st = s;
 #pragma unroll
       for (int g = 0; g < 8; ++g) st = t4[(((msb >> (4 * g)) & 15u) << 4) | st] & 15u;
-      F |= (uint64_t)st << (4u * s);
+      F |= (MAP)st << (4u * s);
     }
     // ---- inclusive scan under composition: X_l = F_l o ... o F_0
-    uint64_t X = F;
+    MAP X = F;
 #define MA_STEP(CTRL, RMASK, BC)                                    \
   {                                                                 \
-    const uint64_t o = MA_DPP64(X, CTRL, RMASK, BC, ident);         \
+    MAP o;                                                          \
+    if constexpr (W64) o = MA_DPP64(X, CTRL, RMASK, BC, ident);     \
+    else o = MA_DPP32(X, CTRL, RMASK, BC, ident);                   \
     X = ma_compose(X, o, S);                                        \
   }
     MA_STEP(0x111, 0xf, false)   // row_shr:1 (lanes without a source compose with the identity: `old` operand)
@@ -173,10 +188,15 @@ __global__ __launch_bounds__(kMaWaves * 64) void k_mark_ends_automaton(const Dev
     MA_STEP(0x142, 0xa, false)   // row_bcast:15 -> rows 1, 3
     MA_STEP(0x143, 0xc, false)   // row_bcast:31 -> rows 2, 3
 #undef MA_STEP
-    const uint64_t total = (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(X >> 32), 63)) << 32) |
-                           (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)X, 63);
-    // map in front of my bytes: lane l - 1's inclusive map, the identity for lane 0
-    const uint64_t G = MA_DPP64(X, 0x138, 0xf, false, ident);  // wave_shr:1
+    MAP total, G;  // the piece's map; the map in front of my bytes: lane l - 1's inclusive map, the identity for lane 0
+    if constexpr (W64) {
+      total = (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(X >> 32), 63)) << 32) |
+              (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)X, 63);
+      G = MA_DPP64(X, 0x138, 0xf, false, ident);  // wave_shr:1
+    } else {
+      total = (uint32_t)__builtin_amdgcn_readlane((int)X, 63);
+      G = MA_DPP32(X, 0x138, 0xf, false, ident);
+    }
 
     // ---- the state in front of the piece: one hop of the chain
     uint32_t s_in = 0u;

@@ -267,6 +267,29 @@ def region_overflow(n=70000, seed=71, lanes=3, with_u16=False, pad=0):
     return info, pack(info, cols, n)
 
 
+def raw_fields_between_varints(n_raw_f32, n_u8=0, n=45000, seed=81):
+    """Round 5: x y z (lossy varints) + n_raw_f32 FLOAT32 fields without resolution (FieldEncoderCopy: raw bytes) + n_u8 UINT8
+    fields -- point forms of 3 + 4 * n_raw_f32 + n_u8 states for the byte automaton of the decoder
+    (stage1_decode_automaton.h: at most 8 states in a dword, at most 16 in a 64-bit word, beyond that the FORM kernel)."""
+    rs = np.random.RandomState(seed)
+    _, xyz = synth.lidar_xyz(n, seed=seed)
+    p = xyz.view(np.float32).reshape(n, 3).copy()
+    p[rs.randint(0, n, 40)] = np.nan
+    fields = [("x", 0, F.FLOAT32, 0.001), ("y", 4, F.FLOAT32, 0.001), ("z", 8, F.FLOAT32, 0.001)]
+    cols = {"x": p[:, 0], "y": p[:, 1], "z": p[:, 2]}
+    off = 12
+    for k in range(n_raw_f32):
+        fields.append((f"r{k}", off, F.FLOAT32, None))
+        cols[f"r{k}"] = rs.randint(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)  # any bytes, MSBs included
+        off += 4
+    for k in range(n_u8):
+        fields.append((f"b{k}", off, F.UINT8, None))
+        cols[f"b{k}"] = rs.randint(0, 256, n).astype(np.uint8)
+        off += 1
+    info = make_info(fields, off + (4 - off % 4) % 4, n)
+    return info, pack(info, cols, n)
+
+
 def padded_fourth_lane(kind, n=90000, seed=61):
     """Real-world layouts whose fused FloatN encoder has its 4th lane one dword further: PCL PointXYZI (x y z pad
     intensity@16, 32-byte points) and an Ouster-style 48-byte point with five integer channels behind the floats."""
@@ -477,6 +500,11 @@ def encode_cases(small=False):
     out.append(("region_overflow3_u16", *region_overflow(lanes=3, seed=73, with_u16=True)))
     out.append(("region_overflow3_u16_unaligned", *region_overflow(lanes=3, seed=74, with_u16=True, pad=1)))
     out.append(("region_overflow4_unaligned", *region_overflow(n=40000, lanes=4, seed=75, pad=2)))
+    out.append(("raw_form_7_states", *raw_fields_between_varints(1)))
+    out.append(("raw_form_8_states", *raw_fields_between_varints(1, 1, seed=82)))
+    out.append(("raw_form_11_states", *raw_fields_between_varints(2, seed=83)))
+    out.append(("raw_form_16_states", *raw_fields_between_varints(3, 1, seed=84)))
+    out.append(("raw_form_17_states", *raw_fields_between_varints(3, 2, n=20000, seed=85)))
     out.append(("pcl_xyzi_step32", *padded_fourth_lane("pcl_xyzi")))
     out.append(("ouster_step48", *padded_fourth_lane("ouster")))
     out.extend(stride_variants())
