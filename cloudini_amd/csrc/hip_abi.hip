@@ -222,6 +222,12 @@ struct cldn_hip_codec {
   uint32_t last_n_chunks = 0;
   // timing
   std::vector<hipEvent_t> events;  // 5 per timing slot
+  // decode: the route counters of an earlier call, copied back asynchronously (like the encoder's mode hint): when every chunk's
+  // section was a small Palette the point kernel found by itself, the next call does not launch the section pre-kernels
+  PinnedBuf h_dec_stats;
+  hipEvent_t ev_dec_stats = nullptr;
+  uint32_t dec_stats_chunks = 0;     // chunks of the call whose copy is in flight (0 = none)
+  bool dec_palette_hint = false;
   hipEvent_t dec_events[4] = {nullptr, nullptr, nullptr, nullptr};  // the last decode call's (timing enabled)
   bool dec_events_valid = false;
   std::vector<uint8_t> slot_valid;
@@ -607,6 +613,8 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   c->h_modes.release();
   c->h_last_modes.release();
   if (c->ev_last_modes) (void)hipEventDestroy(c->ev_last_modes);
+  c->h_dec_stats.release();
+  if (c->ev_dec_stats) (void)hipEventDestroy(c->ev_dec_stats);
   for (hipEvent_t& ev : c->events)
     if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t& ev : c->dec_events)
@@ -1604,6 +1612,12 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
     L.wide = &c->wide_desc;
     L.wide_state = c->d_wide_state.p;
   }
+  if (c->dec_stats_chunks && c->ev_dec_stats && hipEventQuery(c->ev_dec_stats) == hipSuccess) {  // an earlier call's counters have landed
+    const uint32_t* hs = (const uint32_t*)c->h_dec_stats.p;
+    c->dec_palette_hint = hs[4] == c->dec_stats_chunks && hs[2] == 0u && hs[3] == 0u;  // all folded by the guess, nothing serial
+    c->dec_stats_chunks = 0;
+  }
+  L.palette_hint = c->dec_palette_hint ? 1u : 0u;
   L.events = c->dec_events[0] ? c->dec_events : nullptr;
   if (L.events) {
     (void)hipEventRecord(L.events[0], c->stream);
@@ -1614,6 +1628,12 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
   if (L.events) {
     (void)hipEventRecord(L.events[3], c->stream);
     c->dec_events_valid = true;
+  }
+  if (n_chunks && c->plan.uses_v5 && c->dec_stats_chunks == 0 && c->h_dec_stats.ensure(64) == CLDN_HIP_OK) {  // (no copy in flight)
+    if (!c->ev_dec_stats) HIP_TRY(hipEventCreateWithFlags(&c->ev_dec_stats, hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(c->h_dec_stats.p, (const uint32_t*)c->d_status.p + 8, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->ev_dec_stats, c->stream));
+    c->dec_stats_chunks = n_chunks;
   }
 
   if (out_loc == CLDN_HIP_DEVICE) return CLDN_HIP_OK;

@@ -19,6 +19,10 @@ namespace cldn {
 // decode statistics behind the status word (uint32 indexes into the codec's status buffer): chunks whose regular
 // stream / sections went through the parallel kernels, and chunks / section sets the serial kernel had to do
 constexpr uint32_t kStatFastRegular = 8, kStatFastSections = 9, kStatSerialChunks = 10, kStatSerialSections = 11;
+// round 5: chunks whose sections the point kernel folded as small Palettes found from the end of the payload (not taken from
+// columns): when that was every chunk of a call, the codec's next call skips the kernels that locate sections and decode them
+// into columns (hip_abi.hip: dec_palette_hint)
+constexpr uint32_t kStatFoldedByGuess = 12;
 
 struct DecChunk {
   uint64_t src_off;   // offset of the payload inside the batch's stream buffer

@@ -191,7 +191,8 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       }
       // sections that are no small palettes go to dense columns first (every point is then written once)
       static const bool no_cols = getenv("CLDN_HIP_NO_DECODE_COLS") != nullptr;  // A/B switch
-      bool cols = !no_cols && !many && nf != 0u && L.cols[0] != nullptr && L.sec_cols != nullptr;
+      static const bool no_hint = getenv("CLDN_HIP_NO_PALETTE_HINT") != nullptr;  // A/B switch
+      bool cols = !no_cols && !many && nf != 0u && L.cols[0] != nullptr && L.sec_cols != nullptr && !(L.palette_hint && !no_hint && pk != 0);
       for (uint32_t a = 0; a < P.n_adaptive && cols; ++a) cols = P.adaptive[a].bpv <= 4u && L.cols[a] != nullptr;
       if (cols) {
         {

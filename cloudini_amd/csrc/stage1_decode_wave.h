@@ -617,6 +617,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     sec_done[c] = folded ? 2u : 0u;
     if (!redo) atomicAdd(&status[kStatFastRegular], 1u);
     if (folded) atomicAdd(&status[kStatFastSections], 1u);
+    if (folded && !from_cols) atomicAdd(&status[kStatFoldedByGuess], 1u);
   }
 }
 

@@ -99,6 +99,9 @@ struct DecodeLaunch {
   uint32_t* done_cnt;             // [n_chunks]
   uint8_t* out;                       // device: decoded AoS points
   uint32_t* status;
+  uint32_t palette_hint;              // the codec's last decode call folded every chunk's section as a small Palette found by
+                                      // the point kernel's own guess: the kernels that locate sections and decode them into columns
+                                      // are not launched (a chunk that is different after all goes to k_decode_tail's section decoders)
   hipEvent_t* events;                 // 4 events (start, before / behind the regular-stream kernel, end) or NULL
   // WIDE route: the serial decoder with the plan in device memory (schemas beyond the launch-argument plan)
   const WidePlan* wide;               // host copy of the descriptor, or NULL

@@ -459,3 +459,33 @@ def test_decode_with_the_chunk_sizes_given(oracle):
     assert np.array_equal(d_dec.cpu().numpy(), oracle.decode_stage1(info5, stream, 320000))
     c5.close()
     codec.close()
+
+
+def test_palette_hint_of_an_earlier_call_never_changes_bytes(oracle):
+    """Round 5: when every chunk of a decode call had its section folded as a small Palette the point kernel found by itself,
+    the codec's next call does not launch the kernels that locate sections and decode them into columns (a launch hint, like
+    the encoder's mode hint). The same codec then gets streams whose sections are NOT Palettes: same bytes as the oracle."""
+    from cloudini_amd import native
+    info, pal = synth.lidar_xyzi(100_000, seed=3)                    # intensity: 256 levels -> Palette
+    rs = np.random.RandomState(9)
+    noisy = pal.copy().reshape(-1, info.point_step)
+    noisy[:, 12:14] = rs.randint(0, 256, (noisy.shape[0], 2)).astype(np.uint8)   # intensity: 65536 levels -> DeltaVarint
+    noisy = noisy.reshape(-1)
+    ring = pal.copy().reshape(-1, info.point_step)
+    ring[:, 12:14] = (np.arange(ring.shape[0]) % 64).astype(np.uint16).view(np.uint8).reshape(-1, 2)  # -> DeltaRle
+    ring = ring.reshape(-1)
+    codec = native.Codec(native.Plan(info))
+    n = pal.size // info.point_step
+    streams = {k: oracle.encode_stage1(info, d) for k, d in (("pal", pal), ("noisy", noisy), ("ring", ring))}
+    wants = {k: oracle.decode_stage1(info, s, n, fill=0x77) for k, s in streams.items()}
+    for k in ("pal", "pal", "pal", "noisy", "noisy", "pal", "ring", "pal", "pal", "noisy"):
+        out = np.full(pal.size, 0x77, dtype=np.uint8)
+        got = codec.decode_host([streams[k]], [n], out=out)[0]
+        assert np.array_equal(got, wants[k]), k
+        codec.synchronize()
+    # a batch that mixes them
+    out = np.full(3 * pal.size, 0x77, dtype=np.uint8)
+    got = codec.decode_host([streams["pal"], streams["noisy"], streams["ring"]], [n, n, n], out=out)
+    for g, k in zip(got, ("pal", "noisy", "ring")):
+        assert np.array_equal(g, wants[k]), k
+    codec.close()
