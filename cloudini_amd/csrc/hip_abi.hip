@@ -1372,8 +1372,7 @@ int cldn_hip_viz_preprocess(cldn_hip_codec_t* c, const void* points, int points_
     d_out = (uint8_t*)c->d_out.p;
   }
   const uint64_t cap = viz_table_capacity(n_points);
-  if ((rc = c->d_viz_keys.ensure((size_t)cap * 8u)) != CLDN_HIP_OK) return rc;
-  if ((rc = c->d_viz_first.ensure((size_t)cap * 4u)) != CLDN_HIP_OK) return rc;
+  if ((rc = c->d_viz_keys.ensure((size_t)cap * 16u)) != CLDN_HIP_OK) return rc;  // {key, first index, pad} per slot
   if ((rc = c->d_viz_slot.ensure((size_t)n_points * 4u)) != CLDN_HIP_OK) return rc;
   if ((rc = c->d_viz_blocks.ensure((size_t)((n_points + 1023u) / 1024u) * 4u + 16u)) != CLDN_HIP_OK) return rc;
   if ((rc = c->d_viz_total.ensure(16)) != CLDN_HIP_OK) return rc;
@@ -1385,7 +1384,7 @@ int cldn_hip_viz_preprocess(cldn_hip_codec_t* c, const void* points, int points_
   L.xyz_offset = xyz_offset;
   L.inv_res = 1.0f / resolution;  // const float inv_res = 1.0f / xyz_res (ros_msg_utils.cpp:272)
   L.keys = (unsigned long long*)c->d_viz_keys.p;
-  L.first = (uint32_t*)c->d_viz_first.p;
+  L.first = nullptr;  // (round 5: inside the table's entries)
   L.slot_of = (uint32_t*)c->d_viz_slot.p;
   L.block_count = (uint32_t*)c->d_viz_blocks.p;
   L.total = (unsigned long long*)c->d_viz_total.p;

@@ -5,7 +5,7 @@
 // "first occurrence wins, survivors keep their order". The same result without the serial walk:
 //   k_viz_insert   every finite point inserts its key into an open-addressing table in HBM (64-bit CAS on the key)
 //                  and lowers the slot's first-occurrence index with atomicMin -- the primitive of the Palette
-//                  section encoder, at cloud scale
+//                  section encoder, at cloud scale (round 5: behind a per-workgroup LDS table, 16-byte entries)
 //   k_viz_count    a point survives iff it is the first occurrence of its slot; survivors per 1024-point block
 //   k_viz_offsets  exclusive scan of the block counts (one workgroup) -> output position of every block, total
 //   k_viz_gather   block-local ranks (ballot + popcount) and the copy of the surviving points, order preserved
@@ -40,34 +40,70 @@ __device__ __forceinline__ uint64_t viz_key(float fx, float fy, float fz, float 
 
 __device__ __forceinline__ bool viz_finite(float f) { return (__float_as_uint(f) & 0x7f800000u) != 0x7f800000u; }
 
-__global__ __launch_bounds__(256) void k_viz_insert(const uint8_t* __restrict__ points, uint64_t n, uint32_t step,
-                                                    uint32_t xyz_off, float inv_res, unsigned long long* keys,
-                                                    uint32_t* first, uint64_t cap_mask, uint32_t* __restrict__ slot_of) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Round 5: (1) a table entry is ONE 16-byte record {key, first index, pad} -- the compare-and-swap on the key and the atomicMin
+// on the index touch the same line (two random HBM lines per point before); (2) the points of a workgroup (1024 consecutive
+// ones) first meet in an LDS table: only the workgroup's first occurrence of a voxel goes to the table in HBM, every other point
+// of the workgroup is dropped at once (a point of the same voxel with a lower index exists). Lidar points that share a voxel
+// are neighbours in memory (adjacent columns of the scan), so at coarse resolutions most duplicates never leave the CU.
+constexpr int kVizInsertThreads = 1024;
+constexpr uint32_t kVizLocalSlots = 2048;  // LDS: 16 KiB of keys + 8 KiB of first indexes
+
+__global__ __launch_bounds__(kVizInsertThreads) void k_viz_insert(const uint8_t* __restrict__ points, uint64_t n, uint32_t step,
+                                                                  uint32_t xyz_off, float inv_res, unsigned long long* tab,
+                                                                  uint64_t cap_mask, uint32_t* __restrict__ slot_of) {
+  __shared__ unsigned long long lkeys[kVizLocalSlots];
+  __shared__ uint32_t lfirst[kVizLocalSlots];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t k = tid; k < kVizLocalSlots; k += kVizInsertThreads) {
+    lkeys[k] = kVizFree;
+    lfirst[k] = 0xffffffffu;
+  }
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * kVizInsertThreads + tid;
+  bool valid = i < n;
+  uint64_t key = 0;
+  if (valid) {
+    const uint8_t* p = points + i * step + xyz_off;
+    const float fx = viz_load_f32(p), fy = viz_load_f32(p + 4), fz = viz_load_f32(p + 8);
+    valid = viz_finite(fx) && viz_finite(fy) && viz_finite(fz);
+    if (valid) key = viz_key(fx, fy, fz, inv_res);
+  }
+  const uint64_t hash = key * 0x9E3779B97F4A7C15ull;
+  uint32_t ls = 0u;
+  if (valid) {
+    ls = (uint32_t)(hash >> 40) & (kVizLocalSlots - 1u);
+    for (;;) {  // (2048 slots for at most 1024 keys: the table cannot fill)
+      unsigned long long k = lkeys[ls];
+      if (k == kVizFree) k = atomicCAS(&lkeys[ls], kVizFree, (unsigned long long)key);
+      if (k == kVizFree || k == key) break;
+      ls = (ls + 1u) & (kVizLocalSlots - 1u);
+    }
+    atomicMin(&lfirst[ls], tid);
+  }
+  __syncthreads();
   if (i >= n) return;
-  const uint8_t* p = points + i * step + xyz_off;
-  const float fx = viz_load_f32(p), fy = viz_load_f32(p + 4), fz = viz_load_f32(p + 8);
-  if (!viz_finite(fx) || !viz_finite(fy) || !viz_finite(fz)) {
-    slot_of[i] = 0xffffffffu;  // dropped
+  if (!valid || lfirst[ls] != tid) {
+    slot_of[i] = 0xffffffffu;  // dropped: not finite, or not the workgroup's first point of its voxel
     return;
   }
-  const uint64_t key = viz_key(fx, fy, fz, inv_res);
-  uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> 20;
+  uint64_t h = hash >> 20;
   for (;;) {
     h &= cap_mask;
-    unsigned long long k = keys[h];
-    if (k == kVizFree) k = atomicCAS(&keys[h], kVizFree, (unsigned long long)key);
+    unsigned long long k = tab[2u * h];
+    if (k == kVizFree) k = atomicCAS(&tab[2u * h], kVizFree, (unsigned long long)key);
     if (k == kVizFree || k == key) break;
     ++h;
   }
-  if (first[h] > (uint32_t)i) atomicMin(&first[h], (uint32_t)i);
+  uint32_t* first = reinterpret_cast<uint32_t*>(&tab[2u * h + 1u]);
+  if (*first > (uint32_t)i) atomicMin(first, (uint32_t)i);
   slot_of[i] = (uint32_t)h;
 }
 
+// (`first` = the table as 32-bit words: slot s keeps its first-occurrence index in word 4 s + 2)
 __device__ __forceinline__ bool viz_survives(uint64_t i, uint64_t n, const uint32_t* slot_of, const uint32_t* first) {
   if (i >= n) return false;
   const uint32_t s = slot_of[i];
-  return s != 0xffffffffu && first[s] == (uint32_t)i;
+  return s != 0xffffffffu && first[4u * (size_t)s + 2u] == (uint32_t)i;
 }
 
 __global__ __launch_bounds__(kVizBlock) void k_viz_count(uint64_t n, const uint32_t* __restrict__ slot_of,
@@ -155,19 +191,20 @@ int viz_launch(const VizLaunch& L) {
     return 0;
   }
   const uint64_t cap = viz_table_capacity(L.n_points);
-  if ((e = hipMemsetAsync(L.keys, 0xff, cap * sizeof(unsigned long long), L.stream)) != hipSuccess) return viz_fail(e, "hipMemsetAsync(viz keys)");
-  if ((e = hipMemsetAsync(L.first, 0xff, cap * sizeof(uint32_t), L.stream)) != hipSuccess) return viz_fail(e, "hipMemsetAsync(viz first)");
+  if ((e = hipMemsetAsync(L.keys, 0xff, cap * 16u, L.stream)) != hipSuccess) return viz_fail(e, "hipMemsetAsync(viz table)");
   const uint32_t n_blocks = (uint32_t)((L.n_points + kVizBlock - 1) / kVizBlock);
-  hipLaunchKernelGGL(k_viz_insert, dim3((uint32_t)((L.n_points + 255) / 256)), dim3(256), 0, L.stream, L.points, L.n_points,
-                     L.point_step, L.xyz_offset, L.inv_res, L.keys, L.first, cap - 1, L.slot_of);
+  static_assert(kVizInsertThreads == kVizBlock, "one grid shape");
+  const uint32_t* first_words = reinterpret_cast<const uint32_t*>(L.keys);
+  hipLaunchKernelGGL(k_viz_insert, dim3(n_blocks), dim3(kVizInsertThreads), 0, L.stream, L.points, L.n_points, L.point_step,
+                     L.xyz_offset, L.inv_res, L.keys, cap - 1, L.slot_of);
   if ((e = hipGetLastError()) != hipSuccess) return viz_fail(e, "k_viz_insert");
-  hipLaunchKernelGGL(k_viz_count, dim3(n_blocks), dim3(kVizBlock), 0, L.stream, L.n_points, L.slot_of, L.first,
+  hipLaunchKernelGGL(k_viz_count, dim3(n_blocks), dim3(kVizBlock), 0, L.stream, L.n_points, L.slot_of, first_words,
                      L.block_count);
   if ((e = hipGetLastError()) != hipSuccess) return viz_fail(e, "k_viz_count");
   hipLaunchKernelGGL(k_viz_offsets, dim3(1), dim3(1024), 0, L.stream, L.block_count, n_blocks, L.total);
   if ((e = hipGetLastError()) != hipSuccess) return viz_fail(e, "k_viz_offsets");
   hipLaunchKernelGGL(k_viz_gather, dim3(n_blocks), dim3(kVizBlock), 0, L.stream, L.points, L.n_points, L.point_step,
-                     L.slot_of, L.first, L.block_count, L.out);
+                     L.slot_of, first_words, L.block_count, L.out);
   if ((e = hipGetLastError()) != hipSuccess) return viz_fail(e, "k_viz_gather");
   return 0;
 }

@@ -49,6 +49,20 @@ def test_c_abi_exports_every_declared_symbol():
     assert hip.cldn_hip_abi_version() == 1
 
 
+@pytest.mark.parametrize("seed", cases.VERY_WIDE_SEEDS[::5])
+def test_plans_of_any_size_are_accepted_without_a_gpu(oracle, seed):
+    """Round 5 (no compute, runs without a GPU): cldn_hip_plan_create takes schemas beyond the launch-argument plan -- 65-200
+    fields, points of 1-4 KiB -- and answers the reference's capacity bound and adaptive-field count for them."""
+    from cloudini_amd import native
+    info, data = cases.very_wide_schema(seed)
+    plan = native.Plan(info)
+    n = data.size // info.point_step
+    for pts in (0, 1, n, 32768, 32769):
+        assert plan.stage1_bound(pts) == oracle.stage1_bound(info, pts), (seed, pts)
+    assert plan.adaptive_fields == oracle.adaptive_field_count(info)
+    assert plan.point_step == info.point_step
+
+
 @pytest.mark.parametrize("name,info", INFOS, ids=[i[0] for i in INFOS])
 def test_header_bytes_match_reference(reflib, name, info):
     assert api.EncodeHeader(info) == reflib.header(info)
