@@ -779,11 +779,6 @@ size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output,
       if (b.capacity() > kStagingKeepBytes) std::vector<uint8_t>().swap(b);
     }
   } trim{tl_stage1, tl_stage2};
-  if (!direct) {
-    if (tl_stage1.size() < bound) tl_stage1.resize(bound);
-    s1 = tl_stage1.data();
-    s1_cap = tl_stage1.size();
-  }
   impl_->chunk_sizes.resize(n_chunks);
   if (info_.compression_opt == CompressionOption::LZ4 && amd_detail::deviceLz4()) {
     // stage 2 on the device as well: the codec writes [u32 size][LZ4 block] per chunk straight
@@ -798,6 +793,11 @@ size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output,
                                CLDN_HIP_HOST, offsets, impl_->chunk_sizes.data(), nullptr) != CLDN_HIP_OK)
       throw std::runtime_error(cldn_hip_last_error());
     return written + static_cast<size_t>(offsets[1]);
+  }
+  if (!direct) {  // (sized only here: the device-LZ4 branch above never stages stage-1 bytes on the host)
+    if (tl_stage1.size() < bound) tl_stage1.resize(bound);
+    s1 = tl_stage1.data();
+    s1_cap = tl_stage1.size();
   }
   const unsigned workers = (info_.use_threads && n_chunks > 1) ? std::min<unsigned>(stage2Threads(), unsigned(n_chunks)) : 1u;
   if (!direct && workers > 1u && n_chunks >= kPipelineMinChunks && pipelineGroups(workers) >= 2u)
