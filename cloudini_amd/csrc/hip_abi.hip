@@ -1072,7 +1072,7 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
     }
     const uint64_t out_stride = (lz4_block_bound(chunk_bound) + 255u) & ~uint64_t(255);
     if ((rc = c->d_lz_matches.ensure((size_t)max_subs * lz_mm * sizeof(LzMatch))) != CLDN_HIP_OK) return rc;
-    if ((rc = c->d_lz_counts.ensure((size_t)(max_subs * 4u + n_chunks + 1u) * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_lz_counts.ensure((size_t)(max_subs * 5u + n_chunks + 1u) * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_lz_slots.ensure((size_t)n_chunks * out_stride)) != CLDN_HIP_OK) return rc;
     if ((rc = c->d_lz_segs.ensure((size_t)n_chunks * sizeof(Seg))) != CLDN_HIP_OK) return rc;
     Lz4Launch Z;
@@ -1088,7 +1088,8 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
     Z.last_end = Z.counts + max_subs;
     Z.anchor_in = Z.last_end + max_subs;
     Z.sub_size = Z.anchor_in + max_subs;
-    Z.sub_first = Z.sub_size + max_subs;
+    Z.sub_chunk = Z.sub_size + max_subs;
+    Z.sub_first = Z.sub_chunk + max_subs;
     Z.out_slots = (uint8_t*)c->d_lz_slots.p;
     Z.out_stride = out_stride;
     Z.out_segs = (Seg*)c->d_lz_segs.p;

@@ -25,6 +25,7 @@
 // [u32 size][block] exactly as it frames stage-1 payloads.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -37,6 +38,15 @@ namespace cldn {
 namespace {
 
 constexpr uint32_t kLzHashMul = 2654435761u;
+#ifndef CLDN_LZ_ALIGNBYTE
+#define CLDN_LZ_ALIGNBYTE 1
+#endif
+#ifndef CLDN_LZ_DEFER
+#define CLDN_LZ_DEFER 1
+#endif
+#ifndef CLDN_LZ_GRID_ALL
+#define CLDN_LZ_GRID_ALL 1
+#endif
 
 __device__ __forceinline__ uint32_t lz_wave_excl_scan(uint32_t x, uint32_t lane, uint32_t* total) {
   uint32_t incl = x;
@@ -67,7 +77,11 @@ __device__ __forceinline__ uint32_t lz_put_ext(uint8_t* o, uint32_t x) {
 __device__ __forceinline__ uint32_t lz_lds_u32(const uint32_t* base, uint32_t byte_off) {
   const uint32_t i = byte_off >> 2;
   const uint32_t lo = base[i], hi = base[i + 1u];
+#if CLDN_LZ_ALIGNBYTE
+  return __builtin_amdgcn_alignbyte(hi, lo, byte_off);  // (v_alignbyte_b32 uses the two low bits of the shift)
+#else
   return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> ((byte_off & 3u) * 8u));
+#endif
 }
 
 }  // namespace
@@ -135,7 +149,8 @@ template <uint32_t SUB, uint32_t HASH_BITS, uint32_t MAX_MATCHES>
 __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ stream, const uint64_t* __restrict__ chunk_dst,
                                                   const uint32_t* __restrict__ chunk_payload, uint32_t n_chunks,
                                                   const uint32_t* __restrict__ sub_first, LzMatch* __restrict__ matches,
-                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ last_end) {
+                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ last_end,
+                                                  uint32_t* __restrict__ sub_chunk) {
   constexpr uint32_t kTable = 1u << HASH_BITS;
   __shared__ __attribute__((aligned(16))) uint32_t data[SUB / 4u + 8u];  // the sub-range (+ slack for the straddling dword reads)
   // position inside the sub-range + 1; 0 = free. (Round 5, measured and dropped: 16-bit entries -- 12.3 KB of LDS per wave,
@@ -214,6 +229,46 @@ __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ st
         const uint64_t okmask = __ballot(ok);
         const uint64_t openmask = __ballot(going);
         uint32_t cur = 0u;
+#if CLDN_LZ_DEFER
+        // the step's matches are chosen by a scalar loop that only looks at lengths; the records are then written by the
+        // chosen lanes themselves, side by side (one store instruction per step instead of one per match)
+        uint64_t taken = 0ull;
+        uint32_t n_taken = 0u;
+        uint32_t my_len = len;
+        while (count + n_taken < MAX_MATCHES && cur < 64u) {
+          const uint64_t mask = okmask & (~0ull << cur);
+          if (mask == 0ull) break;
+          const uint32_t f = (uint32_t)__builtin_ctzll(mask);
+          uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f);
+          const uint32_t pm = (uint32_t)i + f;
+          if ((openmask >> f) & 1ull) {  // 64 bytes per compare
+            const uint32_t cf = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)f) - 1u;
+            const uint32_t ml = end_limit - pm;
+            while (L < ml) {
+              const uint32_t q = L + lane;
+              const bool differ = q >= ml || bytes[pm + q] != bytes[cf + q];
+              const uint64_t d = __ballot(differ);
+              const uint32_t same = d ? (uint32_t)__builtin_ctzll(d) : 64u;
+              L += same;
+              if (same < 64u) break;
+            }
+            if (lane == f) my_len = L;
+          }
+          taken |= 1ull << f;
+          ++n_taken;
+          lend = s + pm + L;
+          cur = f + L;
+        }
+        if ((taken >> lane) & 1ull) {
+          const uint32_t k = count + (uint32_t)__builtin_popcountll(taken & ((1ull << lane) - 1ull));
+          LzMatch rec;
+          rec.pos = s + (uint32_t)p;
+          rec.len = (uint16_t)my_len;  // <= kLzSubBytes
+          rec.off = (uint16_t)((uint32_t)p - (cand - 1u));
+          out[k] = rec;
+        }
+        count += n_taken;
+#else
         while (count < MAX_MATCHES && cur < 64u) {
           const uint64_t mask = okmask & (~0ull << cur);
           if (mask == 0ull) break;
@@ -243,12 +298,14 @@ __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ st
           lend = s + pm + L;
           cur = f + L;
         }
+#endif
         i += (int32_t)max(64u, cur);
       }
     }
     if (lane == 0u) {
       counts[idx] = count;
       last_end[idx] = lend;  // 0 = no match (a match never ends at 0)
+      sub_chunk[idx] = c;    // (the kernels behind this one do not search again)
     }
   }
 }
@@ -274,11 +331,12 @@ __device__ __forceinline__ void lz_seq_fields(const LzMatch* __restrict__ list, 
 __global__ __launch_bounds__(64) void k_lz4_sizes(uint32_t n_chunks, const uint32_t* __restrict__ sub_first,
                                                   const LzMatch* __restrict__ matches, const uint32_t* __restrict__ counts,
                                                   const uint32_t* __restrict__ last_end, uint32_t* __restrict__ anchor_in,
-                                                  uint32_t* __restrict__ sub_size, uint32_t max_matches) {
+                                                  uint32_t* __restrict__ sub_size, uint32_t max_matches,
+                                                  const uint32_t* __restrict__ sub_chunk) {
   const uint32_t lane = threadIdx.x;
   const uint32_t total = sub_first[n_chunks];
   for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
-    const uint32_t c = lz_chunk_of(sub_first, n_chunks, idx);
+    const uint32_t c = sub_chunk[idx];
     const uint32_t first = sub_first[c];
     uint32_t a = 0u;
     for (uint32_t j = idx; j > first;) {  // (uniform; usually one step)
@@ -310,17 +368,40 @@ __global__ __launch_bounds__(64) void k_lz4_sizes(uint32_t n_chunks, const uint3
 // per sub-range: its sequences (headers and match fields by their lanes) and every LITERAL byte that lies inside the
 // sub-range, whichever sequence it belongs to -- its own, or the next one of the chunk (the bytes behind the sub-range's
 // last match; that sequence may be the block's last, literals-only one). All copies are local: 8 KiB per wave at most.
-__global__ __launch_bounds__(64) void k_lz4_emit(const uint8_t* __restrict__ stream, const uint64_t* __restrict__ chunk_dst,
-                                                 const uint32_t* __restrict__ chunk_payload, uint32_t n_chunks,
-                                                 const uint32_t* __restrict__ sub_first, const LzMatch* __restrict__ matches,
-                                                 const uint32_t* __restrict__ counts, const uint32_t* __restrict__ last_end,
-                                                 const uint32_t* __restrict__ anchor_in, const uint32_t* __restrict__ sub_size,
-                                                 uint8_t* __restrict__ out_slots, uint64_t out_stride, Seg* __restrict__ out_segs,
-                                                 uint32_t sub_bytes, uint32_t max_matches) {
-  const uint32_t lane = threadIdx.x;
-  const uint32_t total = sub_first[n_chunks];
-  for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
-    const uint32_t c = lz_chunk_of(sub_first, n_chunks, idx);
+struct LzEmitArgs {
+  const uint8_t* stream;
+  const uint64_t* chunk_dst;
+  const uint32_t* chunk_payload;
+  uint32_t n_chunks;
+  const uint32_t* sub_first;
+  const LzMatch* matches;
+  const uint32_t* counts;
+  const uint32_t* last_end;
+  const uint32_t* anchor_in;
+  const uint32_t* sub_size;
+  const uint32_t* sub_chunk;  // [sub-range] -> chunk (k_lz4_match wrote it)
+  uint8_t* out_slots;
+  uint64_t out_stride;
+  Seg* out_segs;
+  uint32_t sub_bytes, max_matches;
+};
+
+// sub-range idx (of chunk c) straight from and to global memory: every lane moves the literals of its own sequence
+__device__ __forceinline__ void lz_emit_direct(const LzEmitArgs& A, uint32_t idx, uint32_t c, uint32_t lane) {
+  const uint8_t* __restrict__ stream = A.stream;
+  const uint64_t* __restrict__ chunk_dst = A.chunk_dst;
+  const uint32_t* __restrict__ chunk_payload = A.chunk_payload;
+  const uint32_t* __restrict__ sub_first = A.sub_first;
+  const LzMatch* __restrict__ matches = A.matches;
+  const uint32_t* __restrict__ counts = A.counts;
+  const uint32_t* __restrict__ last_end = A.last_end;
+  const uint32_t* __restrict__ anchor_in = A.anchor_in;
+  const uint32_t* __restrict__ sub_size = A.sub_size;
+  uint8_t* __restrict__ out_slots = A.out_slots;
+  const uint64_t out_stride = A.out_stride;
+  Seg* __restrict__ out_segs = A.out_segs;
+  const uint32_t sub_bytes = A.sub_bytes, max_matches = A.max_matches;
+  {
     const uint32_t first = sub_first[c], end = sub_first[c + 1u];
     const uint32_t n = chunk_payload[c];
     const uint32_t s = (idx - first) * sub_bytes;
@@ -443,6 +524,240 @@ __global__ __launch_bounds__(64) void k_lz4_emit(const uint8_t* __restrict__ str
   }
 }
 
+__global__ __launch_bounds__(64) void k_lz4_emit(const LzEmitArgs A) {
+  const uint32_t total = A.sub_first[A.n_chunks];
+  for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) lz_emit_direct(A, idx, A.sub_chunk[idx], threadIdx.x);
+}
+
+// k_lz4_emit_lds (round 5): the same bytes as lz_emit_direct, moved through LDS. The direct kernel's lanes read and write
+// their own literal runs with scattered 4-byte accesses (64 different lines per instruction: the texture addresser is what
+// it waits for); here the sub-range's input is staged with whole-line loads, the sequences are assembled in an LDS image
+// of the output span the wave owns, and the image leaves in 16-byte units.
+// What a sub-range writes (offsets in the chunk's block):
+//   A  token + literal-length bytes of its first sequence              -> straight to global (1-3 bytes)
+//   B  [before + |A| + skip, before + sub_size): its sequences without the literals that lie in earlier sub-ranges
+//   C  the literals behind its last match (they belong to the chunk's NEXT sequence, whose header -- the gap between
+//      B and C -- is written by that sequence's owner)
+// B, the gap and C are one contiguous span: the LDS image covers it; a span beyond the image (literal-length fields of
+// kilobytes) goes through lz_emit_direct.
+template <uint32_t SUB>
+__global__ __launch_bounds__(64) void k_lz4_emit_lds(const LzEmitArgs A) {
+  constexpr uint32_t kImg = SUB + 320u;  // bytes of the output image (a span is SUB - matches + their extension bytes + the gap)
+  __shared__ __attribute__((aligned(16))) uint32_t in32[SUB / 4u + 8u];
+  __shared__ __attribute__((aligned(16))) uint32_t img32[kImg / 4u];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t total = A.sub_first[A.n_chunks];
+  for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
+    const uint32_t c = A.sub_chunk[idx];
+    const uint32_t first = A.sub_first[c], end = A.sub_first[c + 1u];
+    const uint32_t n = A.chunk_payload[c];
+    const uint32_t s = (idx - first) * SUB;
+    const uint32_t e = n - s < SUB ? n : s + SUB;
+    const uint8_t* in = A.stream + A.chunk_dst[c] + 4u;
+    uint8_t* out = A.out_slots + (size_t)c * A.out_stride;
+    // ---- the sub-range's bytes: requested first, stored to LDS once the bookkeeping below is through
+    constexpr uint32_t kRounds = SUB / 16u / 64u;
+    const uint32_t bytes = e - s;
+    const uint32_t full = bytes >> 4;
+    uint4 w[kRounds];
+#pragma unroll
+    for (uint32_t r = 0; r < kRounds; ++r) {
+      const uint32_t i = r * 64u + lane;
+      w[r] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < full) __builtin_memcpy(&w[r], in + s + 16u * i, 16);
+    }
+    uint32_t before = 0u, all = 0u, tail_anchor = 0u;
+    for (uint32_t j = first + lane; j < end; j += 64u) {
+      const uint32_t sz = A.sub_size[j];
+      all += sz;
+      before += j < idx ? sz : 0u;
+      tail_anchor = max(tail_anchor, A.last_end[j]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      before += (uint32_t)__shfl_xor((int)before, d);
+      all += (uint32_t)__shfl_xor((int)all, d);
+      tail_anchor = max(tail_anchor, (uint32_t)__shfl_xor((int)tail_anchor, d));
+    }
+    const LzMatch* list = A.matches + (size_t)idx * A.max_matches;
+    const uint32_t m = A.counts[idx];
+    const uint32_t a_in = A.anchor_in[idx];
+    const uint32_t my_size = A.sub_size[idx];
+    const uint32_t t0 = m ? A.last_end[idx] : s;
+    // region C: where the bytes behind my last match go
+    uint32_t c_at = 0u;
+    if (t0 < e) {
+      uint32_t nxt = end;
+      for (uint32_t j0 = idx + 1u; j0 < end && nxt == end; j0 += 64u) {
+        const uint32_t j = j0 + lane;
+        const uint64_t has = __ballot(j < end && A.counts[j] != 0u);
+        if (has) nxt = j0 + (uint32_t)__builtin_ctzll(has);
+      }
+      uint32_t a2, dst0;
+      if (nxt < end) {
+        a2 = A.anchor_in[nxt];
+        const LzMatch r0 = A.matches[(size_t)nxt * A.max_matches];
+        dst0 = before + my_size + 1u + lz_ext_bytes(r0.pos - a2);
+      } else {
+        a2 = tail_anchor;
+        dst0 = all + 1u + lz_ext_bytes(n - a2);
+      }
+      c_at = dst0 + (t0 - a2);
+    }
+    // the span [W0, W1) and the gap [G0, G1) inside it that is not mine
+    uint32_t W0, W1, G0 = 0u, G1 = 0u;
+    if (m) {
+      const LzMatch r0 = list[0];
+      const uint32_t lit0 = r0.pos - a_in;
+      const uint32_t skip0 = a_in < s ? min(lit0, s - a_in) : 0u;
+      W0 = before + 1u + lz_ext_bytes(lit0) + skip0;
+      W1 = before + my_size;
+      if (t0 < e) {
+        G0 = W1;
+        G1 = c_at;
+        W1 = c_at + (e - t0);
+      }
+    } else {
+      W0 = c_at;
+      W1 = c_at + (e - t0);
+    }
+    const uint32_t pad = (uint32_t)((uintptr_t)(out + W0) & 15u);
+    __syncthreads();  // (the previous sub-range's LDS contents are done with)
+    if (W1 - W0 + pad > kImg) {  // (uniform)
+      lz_emit_direct(A, idx, c, lane);
+      continue;
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kRounds; ++r) reinterpret_cast<uint4*>(in32)[r * 64u + lane] = w[r];
+    if (lane < (bytes & 15u)) reinterpret_cast<uint8_t*>(in32)[(full << 4) + lane] = in[s + (full << 4) + lane];
+    __syncthreads();
+    const uint8_t* inb = reinterpret_cast<const uint8_t*>(in32);
+    uint8_t* img = reinterpret_cast<uint8_t*>(img32);
+    // block offset x <-> image byte x - W0 + pad; payload position q <-> inb[q - s]
+    const uint32_t ib = pad - W0;  // (wraps; x + ib is the image byte)
+    // nb bytes inb[sb ...] -> img[db ...], all by this lane: bytes up to a dword boundary of the image, dwords (the source
+    // through v_alignbyte), the last bytes
+    auto copy_lane = [&](uint32_t sb, uint32_t db, uint32_t nb, uint32_t wmax_hint) __attribute__((always_inline)) {
+      (void)wmax_hint;
+      uint32_t head = min((4u - (db & 3u)) & 3u, nb);
+      for (uint32_t k = 0; k < 3u; ++k)
+        if (k < head) img[db + k] = inb[sb + k];
+      sb += head;
+      db += head;
+      nb -= head;
+      const uint32_t words = nb >> 2;
+      uint32_t wmax = words;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d));
+      uint32_t lo = in32[sb >> 2];
+      for (uint32_t k = 0; k < wmax; ++k) {
+        if (k < words) {
+          const uint32_t hi = in32[(sb >> 2) + k + 1u];
+          img32[(db >> 2) + k] = __builtin_amdgcn_alignbyte(hi, lo, sb);
+          lo = hi;
+        }
+      }
+      const uint32_t done = words << 2;
+      for (uint32_t k = 0; k < 3u; ++k)
+        if (done + k < nb) img[db + done + k] = inb[sb + done + k];
+    };
+    // the same by the whole wave (one run)
+    auto copy_wave = [&](uint32_t sb, uint32_t db, uint32_t nb) __attribute__((always_inline)) {
+      const uint32_t head = min((4u - (db & 3u)) & 3u, nb);
+      if (lane < head) img[db + lane] = inb[sb + lane];
+      sb += head;
+      db += head;
+      nb -= head;
+      const uint32_t words = nb >> 2;
+      for (uint32_t k = lane; k < words; k += 64u) {
+        const uint32_t si = (sb >> 2) + k;
+        img32[(db >> 2) + k] = __builtin_amdgcn_alignbyte(in32[si + 1u], in32[si], sb);
+      }
+      const uint32_t done = words << 2;
+      if (lane < nb - done) img[db + done + lane] = inb[sb + done + lane];
+    };
+
+    // ---- my sequences
+    uint32_t run = before;
+    for (uint32_t j0 = 0; j0 < m; j0 += 64u) {
+      const uint32_t j = j0 + lane;
+      uint32_t lit = 0u, ml = 0u, anchor = 0u, size = 0u;
+      LzMatch r;
+      r.pos = 0u;
+      r.len = 4u;
+      r.off = 0u;
+      if (j < m) {
+        lz_seq_fields(list, j, a_in, lit, ml, anchor, r);
+        size = 1u + lz_ext_bytes(lit) + lit + 2u + lz_ext_bytes(ml);
+      }
+      uint32_t tile_total;
+      const uint32_t at = run + lz_wave_excl_scan(size, lane, &tile_total);
+      const uint32_t lit_at = at + 1u + lz_ext_bytes(lit);
+      if (j < m) {
+        const uint8_t token = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (ml < 15u ? ml : 15u));
+        if (j == 0u) {  // region A
+          uint8_t* o = out + at;
+          *o++ = token;
+          if (lit >= 15u) (void)lz_put_ext(o, lit);
+        } else {
+          uint8_t* o = img + (at + ib);
+          *o++ = token;
+          if (lit >= 15u) (void)lz_put_ext(o, lit);
+        }
+        uint8_t* o = img + (lit_at + lit + ib);
+        *o++ = (uint8_t)(r.off & 0xffu);
+        *o++ = (uint8_t)(r.off >> 8);
+        if (ml >= 15u) (void)lz_put_ext(o, ml);
+      }
+      constexpr uint32_t kLaneLit = 128u;
+      const uint32_t skip = (j < m && anchor < s) ? min(lit, s - anchor) : 0u;  // (only sequence 0 can start before s)
+      const uint32_t clit = j < m ? lit - skip : 0u;
+      const uint32_t sb = j < m ? anchor + skip - s : 0u;
+      const uint32_t db = j < m ? lit_at + skip + ib : 0u;
+      copy_lane(sb, db, clit <= kLaneLit ? clit : 0u, 0u);
+      uint64_t long_runs = __ballot(clit > kLaneLit);
+      while (long_runs) {
+        const int q = __builtin_ctzll(long_runs);
+        long_runs &= long_runs - 1ull;
+        copy_wave((uint32_t)__builtin_amdgcn_readlane((int)sb, q), (uint32_t)__builtin_amdgcn_readlane((int)db, q),
+                  (uint32_t)__builtin_amdgcn_readlane((int)clit, q));
+      }
+      run += tile_total;
+    }
+    // ---- region C
+    if (t0 < e) copy_wave(t0 - s, c_at + ib, e - t0);
+    __syncthreads();
+    // ---- the image leaves: whole 16-byte units where all 16 bytes are mine, byte by byte at the span's ends and the gap
+    {
+      const uint32_t img_end = pad + (W1 - W0);
+      const uint32_t g0 = G1 > G0 ? G0 + ib : 0u, g1 = G1 > G0 ? G1 + ib : 0u;  // the gap in image bytes
+      uint8_t* gbase = out + W0 - pad;                                          // (16-byte aligned)
+      const uint32_t units = (img_end + 15u) >> 4;
+      for (uint32_t u = lane; u < units; u += 64u) {
+        const uint32_t b0 = u << 4, b1 = b0 + 16u;
+        const bool whole = b0 >= pad && b1 <= img_end && (g1 <= b0 || g0 >= b1);
+        if (whole) {
+          *reinterpret_cast<uint4*>(gbase + b0) = reinterpret_cast<const uint4*>(img32)[u];
+        } else {
+          for (uint32_t k = b0; k < b1; ++k)
+            if (k >= pad && k < img_end && !(k >= g0 && k < g1)) gbase[k] = img[k];
+        }
+      }
+    }
+    // ---- the last sub-range of the chunk also writes the header of the last sequence and the block's size
+    if (idx + 1u == end && lane == 0u) {
+      const uint32_t lit = n - tail_anchor;
+      uint8_t* o = out + all;
+      *o = (uint8_t)((lit < 15u ? lit : 15u) << 4);
+      if (lit >= 15u) (void)lz_put_ext(o + 1u, lit);
+      Seg sg;
+      sg.off = 0u;
+      sg.size = all + 1u + lz_ext_bytes(lit) + lit;
+      A.out_segs[c] = sg;
+    }
+  }
+}
+
 int lz4_launch(const Lz4Launch& L) {
   if (L.n_chunks == 0u) return CLDN_HIP_OK;
   hipError_t e;
@@ -452,19 +767,42 @@ int lz4_launch(const Lz4Launch& L) {
                      L.out_segs, sub_bytes);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_plan");
   // one wave per sub-range, at most `max_subs` of them: workgroups beyond the real number find nothing to do
+#if CLDN_LZ_GRID_ALL
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(L.max_subs, 1u << 20);
+#else
   const uint32_t grid = (uint32_t)std::min<uint64_t>(L.max_subs, 256u * (L.fast ? 32u : 16u));
+#endif
   if (L.fast)
     hipLaunchKernelGGL((k_lz4_match<kLzFastSubBytes, kLzFastHashBits, kLzFastMaxMatches>), dim3(grid), dim3(64), 0, L.stream, L.stage1,
-                       L.chunk_dst, L.chunk_payload, L.n_chunks, L.sub_first, L.matches, L.counts, L.last_end);
+                       L.chunk_dst, L.chunk_payload, L.n_chunks, L.sub_first, L.matches, L.counts, L.last_end, L.sub_chunk);
   else
     hipLaunchKernelGGL((k_lz4_match<kLzSubBytes, kLzHashBits, kLzMaxMatches>), dim3(grid), dim3(64), 0, L.stream, L.stage1, L.chunk_dst,
-                       L.chunk_payload, L.n_chunks, L.sub_first, L.matches, L.counts, L.last_end);
+                       L.chunk_payload, L.n_chunks, L.sub_first, L.matches, L.counts, L.last_end, L.sub_chunk);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_match");
   hipLaunchKernelGGL(k_lz4_sizes, dim3(grid), dim3(64), 0, L.stream, L.n_chunks, L.sub_first, L.matches, L.counts, L.last_end,
-                     L.anchor_in, L.sub_size, max_matches);
+                     L.anchor_in, L.sub_size, max_matches, L.sub_chunk);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_sizes");
-  hipLaunchKernelGGL(k_lz4_emit, dim3(grid), dim3(64), 0, L.stream, L.stage1, L.chunk_dst, L.chunk_payload, L.n_chunks, L.sub_first,
-                     L.matches, L.counts, L.last_end, L.anchor_in, L.sub_size, L.out_slots, L.out_stride, L.out_segs, sub_bytes, max_matches);
+  LzEmitArgs A;
+  A.stream = L.stage1;
+  A.chunk_dst = L.chunk_dst;
+  A.chunk_payload = L.chunk_payload;
+  A.n_chunks = L.n_chunks;
+  A.sub_first = L.sub_first;
+  A.matches = L.matches;
+  A.counts = L.counts;
+  A.last_end = L.last_end;
+  A.anchor_in = L.anchor_in;
+  A.sub_size = L.sub_size;
+  A.sub_chunk = L.sub_chunk;
+  A.out_slots = L.out_slots;
+  A.out_stride = L.out_stride;
+  A.out_segs = L.out_segs;
+  A.sub_bytes = sub_bytes;
+  A.max_matches = max_matches;
+  static const bool direct = getenv("CLDN_HIP_LZ4_EMIT_DIRECT") != nullptr;  // (the kernel of rounds 3-4, for A/B runs)
+  if (direct) hipLaunchKernelGGL(k_lz4_emit, dim3(grid), dim3(64), 0, L.stream, A);
+  else if (L.fast) hipLaunchKernelGGL(k_lz4_emit_lds<kLzFastSubBytes>, dim3(grid), dim3(64), 0, L.stream, A);
+  else hipLaunchKernelGGL(k_lz4_emit_lds<kLzSubBytes>, dim3(grid), dim3(64), 0, L.stream, A);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_emit");
   return CLDN_HIP_OK;
 }

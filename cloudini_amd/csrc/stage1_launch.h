@@ -172,10 +172,11 @@ struct Lz4Launch {
   uint64_t max_subs;              // upper bound of the sub-ranges of the batch (payload bound / sub-range bytes + n_chunks)
   uint32_t* sub_first;            // [n_chunks + 1]: compact sub-range numbering
   LzMatch* matches;               // [max_subs * kLzMaxMatches] (fast: kLzFastMaxMatches)
-  uint32_t* counts;               // [max_subs] and the three arrays behind it: last_end, anchor_in, sub_size
+  uint32_t* counts;               // [max_subs] and the four arrays behind it: last_end, anchor_in, sub_size, sub_chunk
   uint32_t* last_end;
   uint32_t* anchor_in;
   uint32_t* sub_size;
+  uint32_t* sub_chunk;            // [max_subs]: chunk of a sub-range
   uint8_t* out_slots;             // [n_chunks * out_stride]: the blocks
   uint64_t out_stride;
   Seg* out_segs;                  // [n_chunks]: {0, block size}
