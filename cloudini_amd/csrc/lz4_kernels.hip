@@ -194,113 +194,86 @@ __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ st
       const int32_t last_start = min((int32_t)(e - s) - 4, (int32_t)n - 12 - (int32_t)s);  // last position a match may start at
       const uint32_t end_limit = min(e, n - 5u) - s;                                        // where a match ends at the latest
       const uint8_t* bytes = reinterpret_cast<const uint8_t*>(data);
+      // One step = 64 consecutive positions. (Round 5: the scalar unit of the CU was what this loop waited for -- 113 scalar
+      // instructions per step against 58 vector ones, `SQ_INSTS_SALU`: the per-lane work is now predicated vector code
+      // without exec-mask changes, matches still open after the lanes' rounds are finished in front of the selection, and
+      // the selection loop only reads lengths.)
       int32_t i = 0;
-      while (i <= last_start && count < MAX_MATCHES) {
+      uint32_t room = MAX_MATCHES;  // records the list still takes
+      while (i <= last_start) {
         const int32_t p = i + (int32_t)lane;
         const bool active = p <= last_start;
-        const uint32_t seq = lz_lds_u32(data, active ? (uint32_t)p : 0u);
+        // (a lane behind the last position repeats it: the same look-up, the same table entry written again -- no hit)
+        const uint32_t pc = (uint32_t)min(p, last_start);
+        const uint32_t seq = lz_lds_u32(data, pc);
         const uint32_t h = (seq * kLzHashMul) >> (32u - HASH_BITS);
-        const uint32_t cand = active ? table[h] : 0u;
-        const bool ok = cand != 0u && lz_lds_u32(data, cand - 1u) == seq;
-        // every hit extends its own match, 4 bytes per round, up to kLaneRounds rounds; what is still open then is
-        // finished by the whole wave when (and if) the match is taken
+        const uint32_t cand = table[h];
+        const uint32_t cm1 = cand != 0u ? cand - 1u : 0u;
+        const uint32_t vseq = lz_lds_u32(data, cm1);  // (read by every lane: no exec-mask change)
+        const bool ok = (int)active & (int)(cand != 0u) & (int)(vseq == seq);
+        // every hit extends its own match, 4 bytes per round, up to kLaneRounds rounds
         constexpr uint32_t kLaneRounds = 3u;
-        const uint32_t maxlen = ok ? end_limit - (uint32_t)p : 0u;
-        uint32_t len = ok ? 4u : 0u;
+        const uint32_t maxlen = ok ? end_limit - pc : 0u;
+        uint32_t len = ok ? min(4u, maxlen) : 0u;
         bool going = ok && len < maxlen;
         for (uint32_t r = 0; r < kLaneRounds; ++r) {
           if (__ballot(going) == 0ull) break;
-          if (going) {
-            const uint32_t x = lz_lds_u32(data, (uint32_t)p + len) ^ lz_lds_u32(data, cand - 1u + len);
-            if (x) {
-              len += (uint32_t)__builtin_ctz(x) >> 3;
-              going = false;
-            } else {
-              len += 4u;
-            }
-            if (len >= maxlen) {
-              len = maxlen;
-              going = false;
-            }
-          }
+          const uint32_t x = lz_lds_u32(data, pc + len) ^ lz_lds_u32(data, cm1 + len);
+          const uint32_t adv = x ? (uint32_t)__builtin_ctz(x) >> 3 : 4u;
+          const uint32_t nl = min(len + adv, maxlen);
+          const bool on = going && x == 0u && nl < maxlen;
+          len = going ? nl : len;
+          going = on;
         }
         // (the lanes have read the table: the LDS operations of a wave are performed in order)
-        if (active) atomicMax(&table[h], (uint32_t)p + 1u);
+        atomicMax(&table[h], pc + 1u);
         const uint64_t okmask = __ballot(ok);
-        const uint64_t openmask = __ballot(going);
-        uint32_t cur = 0u;
-#if CLDN_LZ_DEFER
-        // the step's matches are chosen by a scalar loop that only looks at lengths; the records are then written by the
-        // chosen lanes themselves, side by side (one store instruction per step instead of one per match)
-        uint64_t taken = 0ull;
-        uint32_t n_taken = 0u;
-        uint32_t my_len = len;
-        while (count + n_taken < MAX_MATCHES && cur < 64u) {
-          const uint64_t mask = okmask & (~0ull << cur);
-          if (mask == 0ull) break;
-          const uint32_t f = (uint32_t)__builtin_ctzll(mask);
+        // what is still open is finished by the whole wave, 64 bytes per compare
+        for (uint64_t om = __ballot(going); om != 0ull; om &= om - 1ull) {
+          const uint32_t f = (uint32_t)__builtin_ctzll(om);
           uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f);
+          const uint32_t cf = (uint32_t)__builtin_amdgcn_readlane((int)cm1, (int)f);
           const uint32_t pm = (uint32_t)i + f;
-          if ((openmask >> f) & 1ull) {  // 64 bytes per compare
-            const uint32_t cf = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)f) - 1u;
-            const uint32_t ml = end_limit - pm;
-            while (L < ml) {
-              const uint32_t q = L + lane;
-              const bool differ = q >= ml || bytes[pm + q] != bytes[cf + q];
-              const uint64_t d = __ballot(differ);
-              const uint32_t same = d ? (uint32_t)__builtin_ctzll(d) : 64u;
-              L += same;
-              if (same < 64u) break;
-            }
-            if (lane == f) my_len = L;
+          const uint32_t ml = end_limit - pm;
+          while (L < ml) {
+            const uint32_t q = L + lane;
+            const bool differ = q >= ml || bytes[pm + q] != bytes[cf + q];
+            const uint64_t d = __ballot(differ);
+            const uint32_t same = d ? (uint32_t)__builtin_ctzll(d) : 64u;
+            L += same;
+            if (same < 64u) break;
           }
+          if (lane == f) len = L;
+        }
+        // the step's matches, greedily in position order: a scalar loop over the lengths; the records are then written by
+        // the chosen lanes themselves, side by side
+        uint64_t taken = 0ull, mask = okmask;
+        uint32_t n_taken = 0u, cur = 0u;
+        while (mask != 0ull && n_taken < room) {
+          const uint32_t f = (uint32_t)__builtin_ctzll(mask);
+          const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f);
           taken |= 1ull << f;
           ++n_taken;
-          lend = s + pm + L;
           cur = f + L;
+          if (cur >= 64u) break;
+          mask = okmask & (~0ull << cur);
         }
-        if ((taken >> lane) & 1ull) {
-          const uint32_t k = count + (uint32_t)__builtin_popcountll(taken & ((1ull << lane) - 1ull));
-          LzMatch rec;
-          rec.pos = s + (uint32_t)p;
-          rec.len = (uint16_t)my_len;  // <= kLzSubBytes
-          rec.off = (uint16_t)((uint32_t)p - (cand - 1u));
-          out[k] = rec;
-        }
-        count += n_taken;
-#else
-        while (count < MAX_MATCHES && cur < 64u) {
-          const uint64_t mask = okmask & (~0ull << cur);
-          if (mask == 0ull) break;
-          const uint32_t f = (uint32_t)__builtin_ctzll(mask);
-          uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f);
-          const uint32_t cf = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)f) - 1u;
-          const uint32_t pm = (uint32_t)i + f;
-          if ((openmask >> f) & 1ull) {  // 64 bytes per compare
-            const uint32_t ml = end_limit - pm;
-            while (L < ml) {
-              const uint32_t q = L + lane;
-              const bool differ = q >= ml || bytes[pm + q] != bytes[cf + q];
-              const uint64_t d = __ballot(differ);
-              const uint32_t same = d ? (uint32_t)__builtin_ctzll(d) : 64u;
-              L += same;
-              if (same < 64u) break;
-            }
-          }
-          if (lane == 0u) {
+        if (n_taken != 0u) {
+          lend = s + (uint32_t)i + cur;
+          if ((taken >> lane) & 1ull) {
+            const uint32_t k = (MAX_MATCHES - room) + __builtin_amdgcn_mbcnt_hi((uint32_t)(taken >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)taken, 0u));
             LzMatch rec;
-            rec.pos = s + pm;
-            rec.len = (uint16_t)L;  // <= kLzSubBytes
-            rec.off = (uint16_t)(pm - cf);
-            out[count] = rec;
+            rec.pos = s + pc;
+            rec.len = (uint16_t)len;  // <= kLzSubBytes
+            rec.off = (uint16_t)(pc - cm1);
+            out[k] = rec;
           }
-          ++count;
-          lend = s + pm + L;
-          cur = f + L;
+          room -= n_taken;
+          if (room == 0u) break;
         }
-#endif
         i += (int32_t)max(64u, cur);
       }
+      count = MAX_MATCHES - room;
     }
     if (lane == 0u) {
       counts[idx] = count;
