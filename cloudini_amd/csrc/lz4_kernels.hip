@@ -198,9 +198,11 @@ __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ st
       // instructions per step against 58 vector ones, `SQ_INSTS_SALU`: the per-lane work is now predicated vector code
       // without exec-mask changes, matches still open after the lanes' rounds are finished in front of the selection, and
       // the selection loop only reads lengths.)
+      // (A step yields 16 matches at most -- they do not overlap and have 4 bytes or more --, and a step is only parsed
+      // while the list has room for 16: the selection loop needs no check of its own.)
+      static_assert(MAX_MATCHES >= 16u, "a step may take 16 matches");
       int32_t i = 0;
-      uint32_t room = MAX_MATCHES;  // records the list still takes
-      while (i <= last_start) {
+      while (i <= last_start && count + 16u <= MAX_MATCHES) {
         const int32_t p = i + (int32_t)lane;
         const bool active = p <= last_start;
         // (a lane behind the last position repeats it: the same look-up, the same table entry written again -- no hit)
@@ -245,35 +247,31 @@ __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ st
           }
           if (lane == f) len = L;
         }
-        // the step's matches, greedily in position order: a scalar loop over the lengths; the records are then written by
-        // the chosen lanes themselves, side by side
-        uint64_t taken = 0ull, mask = okmask;
-        uint32_t n_taken = 0u, cur = 0u;
-        while (mask != 0ull && n_taken < room) {
-          const uint32_t f = (uint32_t)__builtin_ctzll(mask);
-          const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f);
-          taken |= 1ull << f;
-          ++n_taken;
-          cur = f + L;
-          if (cur >= 64u) break;
-          mask = okmask & (~0ull << cur);
-        }
-        if (n_taken != 0u) {
+        // the step's matches, greedily in position order: a scalar loop over the lengths (rem = the hits at and behind
+        // lane `cur`, shifted down by cur); the records are then written by the chosen lanes themselves, side by side
+        uint32_t cur = 0u;
+        if (okmask != 0ull) {
+          uint64_t taken = 0ull, rem = okmask;
+          do {
+            const uint32_t f = cur + (uint32_t)__builtin_ctzll(rem);
+            const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)f);
+            taken |= 1ull << f;
+            cur = f + L;
+            rem = cur < 64u ? okmask >> cur : 0ull;
+          } while (rem != 0ull);
           lend = s + (uint32_t)i + cur;
           if ((taken >> lane) & 1ull) {
-            const uint32_t k = (MAX_MATCHES - room) + __builtin_amdgcn_mbcnt_hi((uint32_t)(taken >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)taken, 0u));
+            const uint32_t k = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(taken >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)taken, 0u));
             LzMatch rec;
             rec.pos = s + pc;
             rec.len = (uint16_t)len;  // <= kLzSubBytes
             rec.off = (uint16_t)(pc - cm1);
             out[k] = rec;
           }
-          room -= n_taken;
-          if (room == 0u) break;
+          count += (uint32_t)__builtin_popcountll(taken);
         }
         i += (int32_t)max(64u, cur);
       }
-      count = MAX_MATCHES - room;
     }
     if (lane == 0u) {
       counts[idx] = count;

@@ -16,7 +16,8 @@
  *     the sub-range end and the block's end rules). All 64 positions are then entered into the table (the highest
  *     position wins a slot). The step's matches are taken greedily in position order: the first hit, then the first hit
  *     at or behind its end, and so on. The cursor moves by 64, or behind the last match taken if that reaches further;
- *   - at most `max_matches` matches per sub-range (the rest of the sub-range is literals);
+ *   - a step yields 16 matches at most (they do not overlap, 4 bytes or more each), and a step is only parsed while the
+ *     list of `max_matches` has room for 16 (the rest of the sub-range is literals);
  *   - sequences are then emitted over the whole block from the ordered list of matches.
  */
 #include <stdint.h>
@@ -54,7 +55,7 @@ static uint32_t lz4m_parse(const uint8_t* in, uint32_t n, uint32_t s, uint32_t e
   const uint32_t end_limit = e < n - 5u ? e : n - 5u; /* a match ends here at the latest */
   uint32_t count = 0u;
   int64_t i = s;
-  while (i <= last_start && count < max_matches) {
+  while (i <= last_start && count + 16u <= max_matches) {
     uint32_t len[64], cf[64];
     for (int l = 0; l < 64; ++l) { /* every lane looks at the table as it was BEFORE the step */
       const int64_t p = i + l;
@@ -78,7 +79,7 @@ static uint32_t lz4m_parse(const uint8_t* in, uint32_t n, uint32_t s, uint32_t e
       table[h] = (uint16_t)(p - s + 1);
     }
     uint32_t cur = 0u;
-    for (uint32_t l = 0; l < 64u && count < max_matches; ++l) {
+    for (uint32_t l = 0; l < 64u; ++l) {
       if (l < cur || len[l] == 0u) continue;
       m[count].pos = (uint32_t)(i + l);
       m[count].len = len[l];

@@ -14,8 +14,9 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def oracle():
-    from oracle.binding import Oracle
-    return Oracle()
+    from oracle import binding
+    binding.build()  # (make: a no-op unless a source of the C restatement is newer than the library)
+    return binding.Oracle()
 
 
 @pytest.fixture(scope="session")
