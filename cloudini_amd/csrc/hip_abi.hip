@@ -170,14 +170,14 @@ struct cldn_hip_codec {
   DevBuf d_ranks[kMaxAdaptive];
   DevBuf d_dec_meta, d_pre_ptrs;
   DevBuf d_dec_cols[8];       // decode: dense columns of the adaptive fields that k_decode_points takes its integer fields from
-  // stage 2 on the device (cldn_hip_codec_set_stage2): the stage-1 streams stay in d_s1, LZ4 blocks go to d_lz_slots
+  // stage 2 on the device (cldn_hip_codec_set_stage2): the stage-1 streams stay in d_s1, the LZ4 blocks go straight into the output
   // chunk table of the last cldn_hip_encode_stage1_chunks call (cldn_hip_frame_chunks frames it)
   bool ct_valid = false;
   uint32_t ct_n_chunks = 0, ct_n_clouds = 0, ct_segs_per_chunk = 0;
   uint64_t ct_slot_stride = 0, ct_need = 0;
   size_t ct_segs_off = 0, ct_anchor_off = 0;
   int stage2 = 0;
-  DevBuf d_s1, d_s1_offsets, d_lz_matches, d_lz_counts, d_lz_slots, d_lz_segs, d_payload2, d_dst2;
+  DevBuf d_s1, d_s1_offsets, d_lz_matches, d_lz_counts, d_payload2, d_dst2;
   DevBuf d_finrec;            // k_finish look-back records (rec, rec2), cleared only when (re)allocated
   int decode_fill = CLDN_HIP_FILL_KEEP;  // cldn_hip_codec_set_decode_fill
   DevBuf d_dec_bits;          // k_mark_token_ends: token-end bitmap of the streams of a decode call
@@ -590,7 +590,7 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   (void)guard.enter(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec, &c->d_dec_rec, &c->d_dec_bits, &c->d_dec_secs, &c->d_s1, &c->d_s1_offsets,
-                    &c->d_lz_matches, &c->d_lz_counts, &c->d_lz_slots, &c->d_lz_segs, &c->d_payload2, &c->d_dst2,
+                    &c->d_lz_matches, &c->d_lz_counts, &c->d_payload2, &c->d_dst2,
                     &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_pre_ptrs, &c->d_dec_cols[0], &c->d_dec_cols[1], &c->d_dec_cols[2], &c->d_dec_cols[3], &c->d_dec_cols[4], &c->d_dec_cols[5], &c->d_dec_cols[6], &c->d_dec_cols[7],
                     &c->d_viz_keys, &c->d_viz_first,
                     &c->d_viz_slot, &c->d_viz_blocks, &c->d_viz_total, &c->d_pieces};
@@ -1055,9 +1055,7 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   if (rc != CLDN_HIP_OK) return rc;
   const void* d_sizes = c->d_payload.p;  // what chunk_sizes reports
   if (lz4 && n_chunks) {
-    // stage 2 on the device: an LZ4 block per chunk payload (lz4_kernels.hip), framed by k_finish like the payloads were
-    uint64_t chunk_bound = (uint64_t)kPointsPerChunk * c->plan.ref_max_point_bytes;
-    if (c->plan.uses_v5) chunk_bound += (uint64_t)c->plan.fields.size() * 32u + 1024u;
+    // stage 2 on the device: an LZ4 block per chunk payload (lz4_kernels.hip), written straight into the framed streams
     // every chunk has ceil(payload / 16 KiB) sub-ranges; the payloads of the batch are bounded by need_s1
     const uint32_t lz_sub = lz4_fast ? kLzFastSubBytes : kLzSubBytes, lz_mm = lz4_fast ? kLzFastMaxMatches : kLzMaxMatches;
     uint64_t max_subs = need_s1 / lz_sub + n_chunks;
@@ -1070,11 +1068,8 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
       HIP_TRY(hipStreamSynchronize(c->stream));
       if (total_s1 <= need_s1) max_subs = total_s1 / lz_sub + n_chunks;  // (every chunk's last sub-range may be partial)
     }
-    const uint64_t out_stride = (lz4_block_bound(chunk_bound) + 255u) & ~uint64_t(255);
     if ((rc = c->d_lz_matches.ensure((size_t)max_subs * lz_mm * sizeof(LzMatch))) != CLDN_HIP_OK) return rc;
-    if ((rc = c->d_lz_counts.ensure((size_t)(max_subs * 5u + n_chunks + 1u) * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
-    if ((rc = c->d_lz_slots.ensure((size_t)n_chunks * out_stride)) != CLDN_HIP_OK) return rc;
-    if ((rc = c->d_lz_segs.ensure((size_t)n_chunks * sizeof(Seg))) != CLDN_HIP_OK) return rc;
+    if ((rc = c->d_lz_counts.ensure((size_t)(max_subs * 7u + 2u * n_chunks + 1u) * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
     Lz4Launch Z;
     Z.stream = c->stream;
     Z.stage1 = (const uint8_t*)c->d_s1.p;
@@ -1089,38 +1084,20 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
     Z.anchor_in = Z.last_end + max_subs;
     Z.sub_size = Z.anchor_in + max_subs;
     Z.sub_chunk = Z.sub_size + max_subs;
-    Z.sub_first = Z.sub_chunk + max_subs;
-    Z.out_slots = (uint8_t*)c->d_lz_slots.p;
-    Z.out_stride = out_stride;
-    Z.out_segs = (Seg*)c->d_lz_segs.p;
+    Z.before = Z.sub_chunk + max_subs;
+    Z.next_pos = Z.before + max_subs;
+    Z.block_size = Z.next_pos + max_subs;
+    Z.sub_first = Z.block_size + n_chunks;
+    // the blocks go straight into the framed streams: [u32 size][block] per chunk, positions from a scan of the block sizes
+    Z.cloud_first_chunk = (const uint32_t*)c->d_cloud_first.p;
+    Z.n_clouds = n_clouds;
+    Z.block_dst = (uint64_t*)c->d_dst2.p;
+    Z.block_sizes_out = (uint32_t*)c->d_payload2.p;
+    Z.stream_offsets = (uint64_t*)c->d_offsets.p;
+    Z.out = d_outp;
+    Z.out_capacity = out_capacity;
+    Z.status = (uint32_t*)c->d_status.p;
     if ((rc = lz4_launch(Z)) != CLDN_HIP_OK) return rc;
-    if (++c->finish_epoch == 0u) {  // wrapped: old records could carry the new tags
-      HIP_TRY(hipMemsetAsync(c->d_finrec.p, 0, c->d_finrec.cap, c->stream));
-      c->finish_epoch = 1u;
-    }
-    FrameLaunch F;
-    F.stream = c->stream;
-    F.chunks = (const ChunkDesc*)c->d_chunks.p;
-    F.n_chunks = n_chunks;
-    F.cloud_first_chunk = (const uint32_t*)c->d_cloud_first.p;
-    F.n_clouds = n_clouds;
-    F.slots = (const uint8_t*)c->d_lz_slots.p;
-    F.slot_stride = out_stride;
-    F.segs = (const Seg*)c->d_lz_segs.p;
-    F.segs_per_chunk = 1u;
-    F.rec = (unsigned long long*)c->d_finrec.p;
-    F.anchor = (unsigned long long*)((uint8_t*)c->d_status.p + z_anchor2);
-    F.epoch = c->finish_epoch;
-    F.ticket = (uint32_t*)c->d_status.p + 41;
-    F.use_ticket = c->force_ticket ? 1u : 0u;
-    F.test_timeout = 0u;
-    F.chunk_payload = (uint32_t*)c->d_payload2.p;
-    F.chunk_dst = (uint64_t*)c->d_dst2.p;
-    F.stream_offsets = (uint64_t*)c->d_offsets.p;
-    F.out = d_outp;
-    F.out_capacity = out_capacity;
-    F.status = (uint32_t*)c->d_status.p;
-    if ((rc = stage1_launch_frame(F)) != CLDN_HIP_OK) return rc;
     d_sizes = c->d_payload2.p;
   } else if (lz4) {
     HIP_TRY(hipMemsetAsync(c->d_offsets.p, 0, (size_t)(n_clouds + 1) * sizeof(uint64_t), c->stream));

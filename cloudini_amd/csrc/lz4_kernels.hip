@@ -110,10 +110,9 @@ __device__ __forceinline__ uint32_t lz_chunk_of(const uint32_t* __restrict__ sub
 }
 
 // one workgroup: sub_first[c] = sub-ranges of the chunks before c (sub_first[n_chunks] = all of them)
-// (a chunk without a byte of payload has no sub-range and no wave below: its block, the single token 0x00, is written here)
+// (a chunk without a byte of payload has no sub-range and no wave below: its block, the single token 0x00, is written by k_lz4_offsets)
 __global__ __launch_bounds__(1024) void k_lz4_plan(const uint32_t* __restrict__ chunk_payload, uint32_t n_chunks,
-                                                   uint32_t* __restrict__ sub_first, uint8_t* __restrict__ out_slots,
-                                                   uint64_t out_stride, Seg* __restrict__ out_segs, uint32_t sub_bytes) {
+                                                   uint32_t* __restrict__ sub_first, uint32_t sub_bytes) {
   __shared__ uint32_t wtot[16];
   __shared__ uint32_t carry;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -122,13 +121,6 @@ __global__ __launch_bounds__(1024) void k_lz4_plan(const uint32_t* __restrict__ 
   for (uint32_t base = 0; base < n_chunks; base += 1024u) {
     const uint32_t c = base + tid;
     const uint32_t mine = c < n_chunks ? (chunk_payload[c] + sub_bytes - 1u) / sub_bytes : 0u;
-    if (c < n_chunks && mine == 0u) {
-      out_slots[(size_t)c * out_stride] = 0u;
-      Seg sg;
-      sg.off = 0u;
-      sg.size = 1u;
-      out_segs[c] = sg;
-    }
     uint32_t wsum;
     const uint32_t excl = lz_wave_excl_scan(mine, lane, &wsum);
     if (lane == 0u) wtot[wave] = wsum;
@@ -351,9 +343,12 @@ struct LzEmitArgs {
   const uint32_t* anchor_in;
   const uint32_t* sub_size;
   const uint32_t* sub_chunk;  // [sub-range] -> chunk (k_lz4_match wrote it)
-  uint8_t* out_slots;
-  uint64_t out_stride;
-  Seg* out_segs;
+  const uint32_t* before;      // [sub-range]: bytes of the sequences of the chunk's earlier sub-ranges (k_lz4_layout)
+  const uint32_t* next_pos;    // [sub-range]: where the chunk's next match behind the sub-range starts (none: the payload size)
+  const uint32_t* block_size;  // [chunk] (k_lz4_layout)
+  const uint64_t* block_dst;   // [chunk]: where [u32 size][block] goes in `out` (k_lz4_offsets)
+  uint8_t* out;                // the framed streams themselves
+  uint64_t out_capacity;
   uint32_t sub_bytes, max_matches;
 };
 
@@ -368,9 +363,6 @@ __device__ __forceinline__ void lz_emit_direct(const LzEmitArgs& A, uint32_t idx
   const uint32_t* __restrict__ last_end = A.last_end;
   const uint32_t* __restrict__ anchor_in = A.anchor_in;
   const uint32_t* __restrict__ sub_size = A.sub_size;
-  uint8_t* __restrict__ out_slots = A.out_slots;
-  const uint64_t out_stride = A.out_stride;
-  Seg* __restrict__ out_segs = A.out_segs;
   const uint32_t sub_bytes = A.sub_bytes, max_matches = A.max_matches;
   {
     const uint32_t first = sub_first[c], end = sub_first[c + 1u];
@@ -378,7 +370,8 @@ __device__ __forceinline__ void lz_emit_direct(const LzEmitArgs& A, uint32_t idx
     const uint32_t s = (idx - first) * sub_bytes;
     const uint32_t e = n - s < sub_bytes ? n : s + sub_bytes;
     const uint8_t* in = stream + chunk_dst[c] + 4u;
-    uint8_t* out = out_slots + (size_t)c * out_stride;
+    if (A.block_dst[c] + 4ull + A.block_size[c] > A.out_capacity) return;  // (k_lz4_offsets raised ST_OUT_OVERFLOW)
+    uint8_t* out = A.out + A.block_dst[c] + 4u;
     // bytes of the sequences before mine / of all sequences; where the last match of the chunk ends
     uint32_t before = 0u, all = 0u, tail_anchor = 0u;
     for (uint32_t j = first + lane; j < end; j += 64u) {
@@ -487,10 +480,6 @@ __device__ __forceinline__ void lz_emit_direct(const LzEmitArgs& A, uint32_t idx
       uint8_t* o = out + all;
       *o = (uint8_t)((lit < 15u ? lit : 15u) << 4);
       if (lit >= 15u) (void)lz_put_ext(o + 1u, lit);
-      Seg sg;
-      sg.off = 0u;
-      sg.size = all + 1u + lz_ext_bytes(lit) + lit;
-      out_segs[c] = sg;
     }
   }
 }
@@ -525,7 +514,8 @@ __global__ __launch_bounds__(64) void k_lz4_emit_lds(const LzEmitArgs A) {
     const uint32_t s = (idx - first) * SUB;
     const uint32_t e = n - s < SUB ? n : s + SUB;
     const uint8_t* in = A.stream + A.chunk_dst[c] + 4u;
-    uint8_t* out = A.out_slots + (size_t)c * A.out_stride;
+    if (A.block_dst[c] + 4ull + A.block_size[c] > A.out_capacity) continue;  // (k_lz4_offsets raised ST_OUT_OVERFLOW)
+    uint8_t* out = A.out + A.block_dst[c] + 4u;                               // the block goes straight into the framed stream
     // ---- the sub-range's bytes: requested first, stored to LDS once the bookkeeping below is through
     constexpr uint32_t kRounds = SUB / 16u / 64u;
     const uint32_t bytes = e - s;
@@ -537,44 +527,17 @@ __global__ __launch_bounds__(64) void k_lz4_emit_lds(const LzEmitArgs A) {
       w[r] = make_uint4(0u, 0u, 0u, 0u);
       if (i < full) __builtin_memcpy(&w[r], in + s + 16u * i, 16);
     }
-    uint32_t before = 0u, all = 0u, tail_anchor = 0u;
-    for (uint32_t j = first + lane; j < end; j += 64u) {
-      const uint32_t sz = A.sub_size[j];
-      all += sz;
-      before += j < idx ? sz : 0u;
-      tail_anchor = max(tail_anchor, A.last_end[j]);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      before += (uint32_t)__shfl_xor((int)before, d);
-      all += (uint32_t)__shfl_xor((int)all, d);
-      tail_anchor = max(tail_anchor, (uint32_t)__shfl_xor((int)tail_anchor, d));
-    }
     const LzMatch* list = A.matches + (size_t)idx * A.max_matches;
     const uint32_t m = A.counts[idx];
     const uint32_t a_in = A.anchor_in[idx];
     const uint32_t my_size = A.sub_size[idx];
+    const uint32_t before = A.before[idx];
     const uint32_t t0 = m ? A.last_end[idx] : s;
-    // region C: where the bytes behind my last match go
-    uint32_t c_at = 0u;
-    if (t0 < e) {
-      uint32_t nxt = end;
-      for (uint32_t j0 = idx + 1u; j0 < end && nxt == end; j0 += 64u) {
-        const uint32_t j = j0 + lane;
-        const uint64_t has = __ballot(j < end && A.counts[j] != 0u);
-        if (has) nxt = j0 + (uint32_t)__builtin_ctzll(has);
-      }
-      uint32_t a2, dst0;
-      if (nxt < end) {
-        a2 = A.anchor_in[nxt];
-        const LzMatch r0 = A.matches[(size_t)nxt * A.max_matches];
-        dst0 = before + my_size + 1u + lz_ext_bytes(r0.pos - a2);
-      } else {
-        a2 = tail_anchor;
-        dst0 = all + 1u + lz_ext_bytes(n - a2);
-      }
-      c_at = dst0 + (t0 - a2);
-    }
+    // region C: where the bytes behind my last match go. They are literals of the chunk's next sequence (the block's last
+    // one if no match follows): its anchor is my last match's end -- or my own anchor if I have no match --, its header
+    // follows my sequences
+    const uint32_t a2 = m ? t0 : a_in;
+    const uint32_t c_at = before + my_size + 1u + lz_ext_bytes(A.next_pos[idx] - a2) + (t0 - a2);
     // the span [W0, W1) and the gap [G0, G1) inside it that is not mine
     uint32_t W0, W1, G0 = 0u, G1 = 0u;
     if (m) {
@@ -715,17 +678,110 @@ __global__ __launch_bounds__(64) void k_lz4_emit_lds(const LzEmitArgs A) {
         }
       }
     }
-    // ---- the last sub-range of the chunk also writes the header of the last sequence and the block's size
+    // ---- the last sub-range of the chunk also writes the header of the last sequence
     if (idx + 1u == end && lane == 0u) {
-      const uint32_t lit = n - tail_anchor;
-      uint8_t* o = out + all;
+      const uint32_t lit = n - a2;
+      uint8_t* o = out + before + my_size;
       *o = (uint8_t)((lit < 15u ? lit : 15u) << 4);
       if (lit >= 15u) (void)lz_put_ext(o + 1u, lit);
-      Seg sg;
-      sg.off = 0u;
-      sg.size = all + 1u + lz_ext_bytes(lit) + lit;
-      A.out_segs[c] = sg;
     }
+  }
+}
+
+// one wave per chunk: before[] (exclusive sum of the sub-ranges' sequence bytes), next_pos[] (the first match behind each
+// sub-range) and the size of the chunk's block
+__global__ __launch_bounds__(64) void k_lz4_layout(const uint32_t* __restrict__ chunk_payload, const uint32_t* __restrict__ sub_first,
+                                                  const LzMatch* __restrict__ matches, const uint32_t* __restrict__ counts,
+                                                  const uint32_t* __restrict__ last_end, const uint32_t* __restrict__ sub_size,
+                                                  uint32_t* __restrict__ before, uint32_t* __restrict__ next_pos,
+                                                  uint32_t* __restrict__ block_size, uint32_t max_matches) {
+  const uint32_t c = blockIdx.x, lane = threadIdx.x;
+  const uint32_t first = sub_first[c], end = sub_first[c + 1u];
+  const uint32_t n = chunk_payload[c];
+  uint32_t run = 0u, tail = 0u;
+  for (uint32_t j0 = first; j0 < end; j0 += 64u) {
+    const uint32_t j = j0 + lane;
+    const uint32_t sz = j < end ? sub_size[j] : 0u;
+    uint32_t tot;
+    const uint32_t excl = lz_wave_excl_scan(sz, lane, &tot);
+    if (j < end) before[j] = run + excl;
+    run += tot;
+    tail = max(tail, j < end ? last_end[j] : 0u);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) tail = max(tail, (uint32_t)__shfl_xor((int)tail, d));
+  // backwards: the first match of the nearest later sub-range that has one
+  uint32_t carry = n;
+  for (uint32_t t = (end - first + 63u) / 64u; t-- > 0u;) {
+    const uint32_t j = first + t * 64u + lane;
+    uint32_t v = (j < end && counts[j] != 0u) ? matches[(size_t)j * max_matches].pos : 0xffffffffu;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {  // inclusive suffix minimum
+      const uint32_t o = (uint32_t)__shfl_down((int)v, d);
+      if (lane + (uint32_t)d < 64u) v = min(v, o);
+    }
+    const uint32_t behind = (uint32_t)__shfl_down((int)v, 1);
+    if (j < end) next_pos[j] = min(lane < 63u ? behind : 0xffffffffu, carry);
+    carry = min(carry, (uint32_t)__shfl((int)v, 0));
+  }
+  if (lane == 0u) {
+    const uint32_t lit = n - tail;  // the block's last sequence: literals only
+    block_size[c] = first == end ? 1u : run + 1u + lz_ext_bytes(lit) + lit;
+  }
+}
+
+// one workgroup: where every chunk's [u32 size][block] goes (the chunks of the batch back to back, as k_finish lays the
+// stage-1 streams out), the size headers, the stream offsets of the clouds; a chunk that does not fit raises
+// ST_OUT_OVERFLOW and is not written
+__global__ __launch_bounds__(1024) void k_lz4_offsets(const uint32_t* __restrict__ block_size, const uint32_t* __restrict__ sub_first,
+                                                     uint32_t n_chunks, const uint32_t* __restrict__ cloud_first_chunk, uint32_t n_clouds,
+                                                     uint64_t* __restrict__ block_dst, uint32_t* __restrict__ chunk_sizes,
+                                                     uint64_t* __restrict__ stream_offsets, uint8_t* __restrict__ out,
+                                                     uint64_t out_capacity, uint32_t* __restrict__ status) {
+  __shared__ unsigned long long wtot[16];
+  __shared__ unsigned long long carry;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0u) carry = 0ull;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_chunks; base += 1024u) {
+    const uint32_t c = base + tid;
+    const uint32_t bs = c < n_chunks ? block_size[c] : 0u;
+    const unsigned long long mine = c < n_chunks ? 4ull + bs : 0ull;
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long o = (unsigned long long)__shfl_up((long long)incl, d);
+      if (lane >= (uint32_t)d) incl += o;
+    }
+    if (lane == 63u) wtot[wave] = incl;
+    __syncthreads();
+    unsigned long long dst = carry + incl - mine;
+    for (uint32_t w = 0; w < wave; ++w) dst += wtot[w];
+    if (c < n_chunks) {
+      block_dst[c] = dst;
+      chunk_sizes[c] = bs;
+      if (dst + mine > out_capacity) {
+        atomicOr(status, (uint32_t)ST_OUT_OVERFLOW);
+      } else {
+        uint8_t* o = out + dst;
+        o[0] = (uint8_t)bs;
+        o[1] = (uint8_t)(bs >> 8);
+        o[2] = (uint8_t)(bs >> 16);
+        o[3] = (uint8_t)(bs >> 24);
+        if (sub_first[c] == sub_first[c + 1u]) o[4] = 0u;  // a chunk without a byte of payload: the single token 0x00
+      }
+    }
+    __syncthreads();
+    if (tid == 1023u) carry = dst + mine;
+    __syncthreads();
+  }
+  __threadfence_block();
+  __syncthreads();
+  // stream offset of a cloud = where its first chunk goes; a cloud without chunks: where the next one's does
+  const unsigned long long total = carry;
+  for (uint32_t k = tid; k <= n_clouds; k += 1024u) {
+    const uint32_t fc = k < n_clouds ? cloud_first_chunk[k] : n_chunks;
+    stream_offsets[k] = fc < n_chunks ? block_dst[fc] : total;
   }
 }
 
@@ -734,8 +790,7 @@ int lz4_launch(const Lz4Launch& L) {
   hipError_t e;
   const uint32_t sub_bytes = L.fast ? kLzFastSubBytes : kLzSubBytes;
   const uint32_t max_matches = L.fast ? kLzFastMaxMatches : kLzMaxMatches;
-  hipLaunchKernelGGL(k_lz4_plan, dim3(1), dim3(1024), 0, L.stream, L.chunk_payload, L.n_chunks, L.sub_first, L.out_slots, L.out_stride,
-                     L.out_segs, sub_bytes);
+  hipLaunchKernelGGL(k_lz4_plan, dim3(1), dim3(1024), 0, L.stream, L.chunk_payload, L.n_chunks, L.sub_first, sub_bytes);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_plan");
   // one wave per sub-range, at most `max_subs` of them: workgroups beyond the real number find nothing to do
 #if CLDN_LZ_GRID_ALL
@@ -753,6 +808,12 @@ int lz4_launch(const Lz4Launch& L) {
   hipLaunchKernelGGL(k_lz4_sizes, dim3(grid), dim3(64), 0, L.stream, L.n_chunks, L.sub_first, L.matches, L.counts, L.last_end,
                      L.anchor_in, L.sub_size, max_matches, L.sub_chunk);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_sizes");
+  hipLaunchKernelGGL(k_lz4_layout, dim3(L.n_chunks), dim3(64), 0, L.stream, L.chunk_payload, L.sub_first, L.matches, L.counts, L.last_end,
+                     L.sub_size, L.before, L.next_pos, L.block_size, max_matches);
+  if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_layout");
+  hipLaunchKernelGGL(k_lz4_offsets, dim3(1), dim3(1024), 0, L.stream, L.block_size, L.sub_first, L.n_chunks, L.cloud_first_chunk, L.n_clouds,
+                     L.block_dst, L.block_sizes_out, L.stream_offsets, L.out, L.out_capacity, L.status);
+  if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_offsets");
   LzEmitArgs A;
   A.stream = L.stage1;
   A.chunk_dst = L.chunk_dst;
@@ -765,9 +826,12 @@ int lz4_launch(const Lz4Launch& L) {
   A.anchor_in = L.anchor_in;
   A.sub_size = L.sub_size;
   A.sub_chunk = L.sub_chunk;
-  A.out_slots = L.out_slots;
-  A.out_stride = L.out_stride;
-  A.out_segs = L.out_segs;
+  A.before = L.before;
+  A.next_pos = L.next_pos;
+  A.block_size = L.block_size;
+  A.block_dst = L.block_dst;
+  A.out = L.out;
+  A.out_capacity = L.out_capacity;
   A.sub_bytes = sub_bytes;
   A.max_matches = max_matches;
   static const bool direct = getenv("CLDN_HIP_LZ4_EMIT_DIRECT") != nullptr;  // (the kernel of rounds 3-4, for A/B runs)

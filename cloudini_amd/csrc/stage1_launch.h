@@ -172,14 +172,23 @@ struct Lz4Launch {
   uint64_t max_subs;              // upper bound of the sub-ranges of the batch (payload bound / sub-range bytes + n_chunks)
   uint32_t* sub_first;            // [n_chunks + 1]: compact sub-range numbering
   LzMatch* matches;               // [max_subs * kLzMaxMatches] (fast: kLzFastMaxMatches)
-  uint32_t* counts;               // [max_subs] and the four arrays behind it: last_end, anchor_in, sub_size, sub_chunk
+  uint32_t* counts;               // [max_subs] and the arrays behind it: last_end, anchor_in, sub_size, sub_chunk, before, next_pos
   uint32_t* last_end;
   uint32_t* anchor_in;
   uint32_t* sub_size;
   uint32_t* sub_chunk;            // [max_subs]: chunk of a sub-range
-  uint8_t* out_slots;             // [n_chunks * out_stride]: the blocks
-  uint64_t out_stride;
-  Seg* out_segs;                  // [n_chunks]: {0, block size}
+  uint32_t* before;               // [max_subs]: sequence bytes of the chunk's earlier sub-ranges
+  uint32_t* next_pos;             // [max_subs]: the chunk's next match behind the sub-range
+  uint32_t* block_size;           // [n_chunks]: bytes of the chunk's LZ4 block
+  // the blocks are written straight into the framed streams (round 5: no slots, no second framing pass)
+  const uint32_t* cloud_first_chunk;  // [n_clouds + 1]
+  uint32_t n_clouds;
+  uint64_t* block_dst;            // [n_chunks]: where [u32 size][block] of a chunk begins in `out`
+  uint32_t* block_sizes_out;      // [n_chunks]: what chunk_sizes reports
+  uint64_t* stream_offsets;       // [n_clouds + 1]
+  uint8_t* out;
+  uint64_t out_capacity;
+  uint32_t* status;
 };
 int lz4_launch(const Lz4Launch& L);
 
