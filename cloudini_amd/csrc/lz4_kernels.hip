@@ -193,6 +193,8 @@ __global__ __launch_bounds__(64) void k_lz4_match(const uint8_t* __restrict__ st
       // (A step yields 16 matches at most -- they do not overlap and have 4 bytes or more --, and a step is only parsed
       // while the list has room for 16: the selection loop needs no check of its own.)
       static_assert(MAX_MATCHES >= 16u, "a step may take 16 matches");
+      // (Measured and dropped: the next step's look-ups -- 4 bytes, table entry, verify read -- issued while this step's matches
+      // are selected: no change, 1.53 ms either way for 8 KiB windows.)
       int32_t i = 0;
       while (i <= last_start && count + 16u <= MAX_MATCHES) {
         const int32_t p = i + (int32_t)lane;
