@@ -224,3 +224,42 @@ def test_host_mirror_full_streams_match_the_reference(reflib, seed):
     want_dec, _ = reflib.decode(want, max(1, data.size), fill=0x42)
     got_dec, got_info = api.PointcloudDecoder().decode_stream(want, fill=0x42)
     assert np.array_equal(got_dec[: n * info.point_step], want_dec[: n * info.point_step]), seed
+
+
+# ---- device LZ4 on the random schemas: every chunk's block equals the serial model's (oracle/lz4_model.c), both modes ----
+
+_LZ4_PARAMS = {1: (8192, 11, 1024), 2: (4096, 10, 512)}  # CLDN_HIP_STAGE2_LZ4, CLDN_HIP_STAGE2_LZ4_FAST (stage1_launch.h)
+_LZ4_SEEDS = list(range(1000, 1040 + int(os.environ.get("CLDN_FUZZ_EXTRA", "0")) // 20))
+
+
+@pytest.mark.parametrize("seed", _LZ4_SEEDS)
+def test_random_schema_with_device_lz4(oracle, seed):
+    """The stage-1 streams of random schemas hold everything from noise (random 64-bit integers) to long repeats
+    (constant fields, raw copies of padded structures): literal runs of kilobytes, matches that fill a sub-range, lists
+    that run full. Blocks byte-equal to the model, sizes and stream offsets consistent."""
+    from cloudini_amd import native
+    info, data = _random_case(seed)
+    n = data.size // info.point_step
+    want = oracle.encode_stage1(info, data)
+    payloads, o = [], 0
+    while o < want.size:
+        size = int.from_bytes(want[o:o + 4].tobytes(), "little")
+        payloads.append(want[o + 4:o + 4 + size])
+        o += 4 + size
+    codec = native.Codec(native.Plan(info))
+    half = data[: (n // 2) * info.point_step]
+    for stage2 in (1, 2):
+        codec.set_stage2(stage2)
+        streams, chunk_sizes, _modes = codec.encode_host([data, half, data])
+        assert np.array_equal(streams[0], streams[2]), (seed, stage2)
+        blocks, o = [], 0
+        while o < streams[0].size:
+            size = int.from_bytes(streams[0][o:o + 4].tobytes(), "little")
+            blocks.append(streams[0][o + 4:o + 4 + size])
+            o += 4 + size
+        assert o == streams[0].size and len(blocks) == len(payloads), (seed, stage2)
+        assert [b.size for b in blocks] == [int(x) for x in chunk_sizes[: len(blocks)]], (seed, stage2)
+        for k, (block, payload) in enumerate(zip(blocks, payloads)):
+            model = oracle.lz4_model(payload, *_LZ4_PARAMS[stage2])
+            assert block.size == model.size and np.array_equal(block, model), (seed, stage2, k)
+    codec.close()
