@@ -503,6 +503,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
           if (lane < maxpt) cpt[lane * 8u + b8] = 0xffffu;
           if (64u + lane < maxpt) cpt[(64u + lane) * 8u + b8] = 0xffffu;
         }
+        if (maxpt <= 64u) {  // (uniform) points of at most 64 bytes: one candidate per lane, no second set to carry along
+          while (__ballot(x0 < kSwPiece) != 0ull) {
+            if (x0 < kSwPiece) {
+              const uint32_t bk = x0 >> 7;
+              if (bk != pb0) cpt[lane * 8u + bk] = (uint16_t)((x0 & 127u) | (c0 << 7));
+              pb0 = bk;
+              x0 = jt[x0];
+              if (GOR && x0 != 0xffffu && (x0 & 0x8000u)) x0 = 0xfffeu;  // the window changes behind this point: rounds
+              ++c0;
+            }
+          }
+        } else
         while (__ballot(x0 < kSwPiece || x1 < kSwPiece) != 0ull) {  // (the two rounds of candidates side by side)
           if (x0 < kSwPiece) {
             const uint32_t bk = x0 >> 7;
