@@ -654,6 +654,7 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
           break;
         }
         size_t used = 0;
+        bool exhausted = false;
         const auto t_read = Clock::now();
         if (source.concurrent() && io_threads > 1) {
           // tickets in input order by this thread, the messages themselves by the team
@@ -661,13 +662,18 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
           uint64_t t;
           while (tickets.size() < batch && source.claim(t)) tickets.push_back(t);
           used = tickets.size();
+          exhausted = used < batch;
           if (b->in.size() < used) b->in.resize(used);
           parallelFor(used, io_threads, [&](size_t i) { source.fetch(tickets[i], b->in[i]); });
         } else {
           while (used < batch) {
             if (b->in.size() <= used) b->in.emplace_back();
-            if (!source.next(b->in[used])) break;  // the source refills the Message (and reuses its page-locked capacity)
+            if (!source.next(b->in[used])) {  // the source refills the Message (and reuses its page-locked capacity)
+              exhausted = true;
+              break;
+            }
             ++used;
+            if (source.submitNow()) break;  // (the source will wait for the sink: what it delivered must be on its way)
           }
         }
         seconds_read += since(t_read);
@@ -678,7 +684,7 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
         b->in.resize(used);
         b->seq = seq++;
         to_gpu.push(b);
-        if (used < batch) break;  // the source is exhausted
+        if (exhausted) break;
       }
     } catch (...) {
       reader_error = std::current_exception();

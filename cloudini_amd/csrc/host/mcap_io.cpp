@@ -4,7 +4,11 @@
 #include "cloudini_amd/mcap_io.hpp"
 
 #include <cstdio>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <stdexcept>
 
 extern "C" {
@@ -147,6 +151,27 @@ std::vector<uint8_t> lz4FrameDecompress(const uint8_t* src, size_t n, size_t exp
   return out;
 }
 
+// the records of a compressed chunk. The record's own size claim is not trusted with an allocation: bounded, and checked
+// against the compressed frame
+std::vector<uint8_t> decompressChunk(const std::string& comp, const uint8_t* p, uint64_t n, uint64_t usize) {
+  std::vector<uint8_t> raw;
+  if (usize > kMcapMaxChunkBytes) bad("chunk claims " + std::to_string(usize) + " uncompressed bytes (limit " + std::to_string(kMcapMaxChunkBytes) + ")");
+  if (comp == "zstd") {
+    const unsigned long long fcs = ZSTD_getFrameContentSize(p, n);
+    if (fcs == kZstdContentSizeError || (fcs != kZstdContentSizeUnknown && fcs != usize)) bad("corrupt zstd chunk");
+    if (fcs == kZstdContentSizeUnknown && usize / 4096u > n + 64u) bad("corrupt zstd chunk");  // (no frame expands that far)
+    raw.resize(usize);
+    const size_t r = ZSTD_decompress(raw.data(), raw.size(), p, n);
+    if (ZSTD_isError(r) || r != usize) bad("corrupt zstd chunk");
+  } else if (comp == "lz4") {
+    if (usize / 256u > n + 64u) bad("corrupt lz4 chunk");  // (LZ4 expands by at most 255 x)
+    raw = lz4FrameDecompress(p, n, usize);
+  } else {
+    bad("chunk compression '" + comp + "' is not supported");
+  }
+  return raw;
+}
+
 }  // namespace
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -224,22 +249,7 @@ void McapFile::parseRecords(const uint8_t* p, const uint8_t* end, bool in_chunk)
           if (n != usize) bad("uncompressed chunk whose sizes disagree");
           parseRecords(c.p, c.p + n, true);
         } else {
-          std::vector<uint8_t> raw;
-          // the record's own claim is not trusted with an allocation: bounded, and checked against the compressed frame
-          if (usize > kMcapMaxChunkBytes) bad("chunk claims " + std::to_string(usize) + " uncompressed bytes (limit " + std::to_string(kMcapMaxChunkBytes) + ")");
-          if (comp == "zstd") {
-            const unsigned long long fcs = ZSTD_getFrameContentSize(c.p, n);
-            if (fcs == kZstdContentSizeError || (fcs != kZstdContentSizeUnknown && fcs != usize)) bad("corrupt zstd chunk");
-            if (fcs == kZstdContentSizeUnknown && usize / 4096u > n + 64u) bad("corrupt zstd chunk");  // (no frame expands that far)
-            raw.resize(usize);
-            const size_t r = ZSTD_decompress(raw.data(), raw.size(), c.p, n);
-            if (ZSTD_isError(r) || r != usize) bad("corrupt zstd chunk");
-          } else if (comp == "lz4") {
-            if (usize / 256u > n + 64u) bad("corrupt lz4 chunk");  // (LZ4 expands by at most 255 x)
-            raw = lz4FrameDecompress(c.p, n, usize);
-          } else {
-            bad("chunk compression '" + comp + "' is not supported");
-          }
+          std::vector<uint8_t> raw = decompressChunk(comp, c.p, n, usize);
           chunks_.push_back(std::move(raw));
           parseRecords(chunks_.back().data(), chunks_.back().data() + chunks_.back().size(), true);
         }
@@ -260,6 +270,162 @@ void McapFile::parseRecords(const uint8_t* p, const uint8_t* end, bool in_chunk)
         break;  // message / chunk / attachment indexes, attachments, statistics, summary offsets, unknown opcodes: skipped
     }
   }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// streaming reader
+// -----------------------------------------------------------------------------------------------------------------
+McapStream::McapStream(const std::string& path) : path_(path) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) bad("cannot open " + path);
+  file_ = f;
+  try {
+    if (std::fseek(f, 0, SEEK_END) != 0) bad("cannot seek in " + path);
+    const long n = std::ftell(f);
+    if (n < 16 + 9) bad(path + " does not begin with the MCAP magic");
+    size_ = (uint64_t)n;
+    uint8_t magic[8];
+    if (std::fseek(f, n - 8, SEEK_SET) != 0 || std::fread(magic, 1, 8, f) != 8) bad("short read of " + path);
+    const bool tail_ok = std::memcmp(magic, kMagic, 8) == 0;
+    std::rewind(f);
+    readExact(magic, 8, "the magic");
+    if (std::memcmp(magic, kMagic, 8) != 0) bad(path + " does not begin with the MCAP magic");
+    if (!tail_ok) bad(path + " does not end with the MCAP magic (truncated?)");
+    size_ -= 8;  // (records end in front of the closing magic)
+    Record r;
+    if (!next(r) || r.op != OP_HEADER) bad("the file does not begin with a Header record");
+    Cur c{r.data, r.data + r.size};
+    profile = c.str();
+    library = c.str();
+  } catch (...) {
+    std::fclose(f);
+    file_ = nullptr;
+    throw;
+  }
+}
+
+McapStream::~McapStream() {
+  if (file_) std::fclose((FILE*)file_);
+}
+
+void McapStream::readExact(void* dst, size_t n, const char* what) {
+  if (n != 0 && std::fread(dst, 1, n, (FILE*)file_) != n) bad(std::string("short read of ") + what);
+  pos_ += n;
+}
+
+bool McapStream::next(Record& r) {
+  try {
+    for (;;) {
+      if (ended_) return false;
+      if (in_chunk_) {
+        if (chunk_at_ == chunk_.size()) {
+          in_chunk_ = false;
+          continue;
+        }
+        if (chunk_.size() - chunk_at_ < 9) bad("record header cut short");
+        const uint8_t op = chunk_[chunk_at_];
+        uint64_t len;
+        std::memcpy(&len, &chunk_[chunk_at_ + 1], 8);
+        chunk_at_ += 9;
+        if (len > chunk_.size() - chunk_at_) bad("record longer than what is left of the file");
+        if (op == OP_CHUNK) bad("chunk inside a chunk");
+        r.op = op;
+        r.data = chunk_.data() + chunk_at_;
+        r.size = (size_t)len;
+        chunk_at_ += (size_t)len;
+        if (op == OP_DATA_END || op == OP_FOOTER) {
+          ended_ = true;
+          return false;
+        }
+        return true;
+      }
+      if (pos_ >= size_) {  // (a file without DataEnd / Footer: McapFile reads such a file to its end too)
+        ended_ = true;
+        return false;
+      }
+      if (size_ - pos_ < 9) bad("record header cut short");
+      uint8_t head[9];
+      readExact(head, 9, "a record header");
+      uint64_t len;
+      std::memcpy(&len, head + 1, 8);
+      if (len > size_ - pos_) bad("record longer than what is left of the file");
+      if (head[0] == OP_DATA_END || head[0] == OP_FOOTER) {  // the summary section behind DataEnd is not needed
+        ended_ = true;
+        return false;
+      }
+      // (a record of the data section is at most a chunk: a length beyond the chunk limit and its frame's overhead is not
+      // trusted with an allocation)
+      if (len > kMcapMaxChunkBytes + (1ull << 20)) bad("record of " + std::to_string(len) + " bytes (limit " + std::to_string(kMcapMaxChunkBytes) + ")");
+      rec_.resize((size_t)len);
+      readExact(rec_.data(), (size_t)len, "a record");
+      if (head[0] != OP_CHUNK) {
+        r.op = head[0];
+        r.data = rec_.data();
+        r.size = (size_t)len;
+        return true;
+      }
+      Cur c{rec_.data(), rec_.data() + rec_.size()};
+      c.u64();  // message_start_time
+      c.u64();  // message_end_time
+      const uint64_t usize = c.u64();
+      c.u32();  // uncompressed_crc (0 = not computed; not checked)
+      const std::string comp = c.str();
+      const uint64_t n = c.u64();
+      c.need(n);
+      if (comp.empty()) {
+        if (n != usize) bad("uncompressed chunk whose sizes disagree");
+        chunk_.assign(c.p, c.p + n);
+      } else {
+        chunk_ = decompressChunk(comp, c.p, n, usize);
+      }
+      chunk_at_ = 0;
+      in_chunk_ = true;
+    }
+  } catch (const std::bad_alloc&) {
+    bad("out of memory while reading " + path_);
+  } catch (const std::length_error&) {
+    bad("out of memory while reading " + path_);
+  }
+}
+
+McapSchema McapStream::parseSchema(const Record& r) {
+  Cur c{r.data, r.data + r.size};
+  McapSchema s;
+  s.id = c.u16();
+  s.name = c.str();
+  s.encoding = c.str();
+  const uint32_t n = c.u32();
+  c.need(n);
+  s.data.assign(c.p, c.p + n);
+  return s;
+}
+McapChannel McapStream::parseChannel(const Record& r) {
+  Cur c{r.data, r.data + r.size};
+  McapChannel ch;
+  ch.id = c.u16();
+  ch.schema_id = c.u16();
+  ch.topic = c.str();
+  ch.message_encoding = c.str();
+  ch.metadata = c.map();
+  return ch;
+}
+McapMetadata McapStream::parseMetadata(const Record& r) {
+  Cur c{r.data, r.data + r.size};
+  McapMetadata md;
+  md.name = c.str();
+  md.entries = c.map();
+  return md;
+}
+McapMessage McapStream::parseMessage(const Record& r) {
+  Cur c{r.data, r.data + r.size};
+  McapMessage m;
+  m.channel_id = c.u16();
+  m.sequence = c.u32();
+  m.log_time = c.u64();
+  m.publish_time = c.u64();
+  m.data = c.p;
+  m.size = (size_t)(c.end - c.p);
+  return m;
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -522,98 +688,230 @@ void McapWriter::finish() {
 // -----------------------------------------------------------------------------------------------------------------
 namespace {
 
-// the point-cloud messages of the bag, in file order; name = index into McapFile::messages
+// What the reader thread (McapSource::next) and the writer thread (McapSink::write) of the pipeline share: the output file
+// and the messages read but not written yet, in file order -- point clouds on their way through the GPU pipeline (header
+// fields only) and the other messages that lie between them (whole). A message that is not a point cloud and has no cloud
+// in front of it goes straight to the output: what waits is bounded by the batches the pipeline keeps in flight.
+struct McapFlow {
+  McapFlow(McapStream& in_, McapWriter& out_, bool decode, McapTranscodeStats& stats_)
+      : in(in_), out(out_), stats(stats_),
+        from(decode ? kCompressedPointCloud2SchemaName : kPointCloud2SchemaName),
+        to(decode ? kPointCloud2SchemaName : kCompressedPointCloud2SchemaName),
+        to_text(decode ? kPointCloud2SchemaText : kCompressedPointCloud2SchemaText) {}
+  struct Item {
+    bool cloud = false;
+    uint64_t id = 0;
+    McapMessage head;           // (data / size: of the input message)
+    std::vector<uint8_t> body;  // messages copied through
+  };
+  McapStream& in;
+  McapWriter& out;
+  McapTranscodeStats& stats;
+  const std::string from, to;
+  const char* to_text;
+  std::mutex mutex;  // `out`, `pending`, `stats`
+  std::condition_variable drained;
+  std::deque<Item> pending;
+  size_t clouds_pending = 0;
+  // bytes of the copied-through messages that wait behind a cloud. Beyond kHoldBytes the source asks the pipeline to hand
+  // its batch on (MessageSource::submitNow) and its next call waits until the sink has written enough of them
+  size_t held_bytes = 0;
+  static constexpr size_t kHoldBytes = 64u << 20;
+  bool failed = false;  // the sink gave up: nothing waits any more
+  uint64_t written = 0;  // messages the sink has written (progress, for the wait above)
+  uint64_t next_id = 0;
+  std::map<uint16_t, bool> schema_is_cloud;   // schema id -> carries the message type to convert
+  std::map<uint16_t, uint16_t> channel_schema;
+
+  // reads on until a point-cloud message turns up (true: `m` is it, its bytes in `bytes`, already queued) or the data
+  // section ends (false). Everything else is handed on as it comes.
+  bool nextCloud(McapMessage& m, std::vector<uint8_t>& bytes, std::string& name) {
+    {
+      // (the clouds delivered so far are on their way -- submitNow() was true after the last one --, so the sink will get to
+      // them; a pipeline that has failed never does: no progress for a minute ends the wait with an error of its own, behind
+      // which transcodePointClouds rethrows the first one)
+      std::unique_lock<std::mutex> lock(mutex);
+      uint64_t seen = written;
+      int idle = 0;
+      while (!drained.wait_for(lock, std::chrono::seconds(1), [&] { return held_bytes <= kHoldBytes || clouds_pending == 0 || failed; })) {
+        idle = written == seen ? idle + 1 : 0;
+        seen = written;
+        if (idle >= 60) bad("the converter stopped taking messages");
+      }
+    }
+    McapStream::Record r;
+    while (in.next(r)) {
+      switch (r.op) {
+        case OP_SCHEMA: {
+          McapSchema s = McapStream::parseSchema(r);
+          if (s.id == 0) break;
+          const bool is_cloud = s.name == from;
+          if (is_cloud) {  // the schema of the converted messages (duplicateSchemasAndChannels, mcap_converter.cpp:59-125)
+            s.name = to;
+            s.data.assign(to_text, to_text + std::strlen(to_text));
+          }
+          std::lock_guard<std::mutex> lock(mutex);
+          if (schema_is_cloud.find(s.id) == schema_is_cloud.end()) out.addSchema(s);  // (a repeated record: same content)
+          schema_is_cloud[s.id] = is_cloud;
+          break;
+        }
+        case OP_CHANNEL: {
+          const McapChannel ch = McapStream::parseChannel(r);
+          std::lock_guard<std::mutex> lock(mutex);
+          if (channel_schema.find(ch.id) == channel_schema.end()) out.addChannel(ch);
+          channel_schema[ch.id] = ch.schema_id;
+          break;
+        }
+        case OP_METADATA: {
+          const McapMetadata md = McapStream::parseMetadata(r);
+          std::lock_guard<std::mutex> lock(mutex);
+          out.addMetadata(md);
+          break;
+        }
+        case OP_MESSAGE: {
+          m = McapStream::parseMessage(r);
+          std::lock_guard<std::mutex> lock(mutex);
+          ++stats.messages;
+          const auto ch = channel_schema.find(m.channel_id);
+          if (ch == channel_schema.end()) bad("message on a channel the file does not declare");
+          const auto sc = schema_is_cloud.find(ch->second);
+          if (sc != schema_is_cloud.end() && sc->second) {
+            Item it;
+            it.cloud = true;
+            it.id = next_id++;
+            it.head = m;
+            it.head.data = nullptr;
+            name = std::to_string(it.id);
+            pending.push_back(std::move(it));
+            ++clouds_pending;
+            bytes.resize(m.size);
+            if (m.size) std::memcpy(bytes.data(), m.data, m.size);
+            return true;
+          }
+          if (clouds_pending == 0) {
+            out.writeMessage(m.channel_id, m.sequence, m.log_time, m.publish_time, m.data, m.size);
+          } else {
+            Item it;
+            it.head = m;
+            it.head.data = nullptr;
+            it.body.assign(m.data, m.data + m.size);
+            held_bytes += it.body.size();
+            stats.peak_held_bytes = std::max<uint64_t>(stats.peak_held_bytes, held_bytes);
+            pending.push_back(std::move(it));
+          }
+          break;
+        }
+        default:
+          break;  // indexes, attachments, statistics, unknown opcodes: skipped (as McapFile does)
+      }
+    }
+    return false;
+  }
+  // (mutex held) the messages in front of the next cloud leave
+  void flushCopies() {
+    while (!pending.empty() && !pending.front().cloud) {
+      const Item& it = pending.front();
+      out.writeMessage(it.head.channel_id, it.head.sequence, it.head.log_time, it.head.publish_time, it.body.data(), it.body.size());
+      held_bytes -= it.body.size();
+      pending.pop_front();
+    }
+    drained.notify_all();
+  }
+};
+
 class McapSource : public MessageSource {
  public:
-  McapSource(const McapFile& file, const std::vector<size_t>& picks) : file_(file), picks_(picks) {}
+  explicit McapSource(McapFlow& flow) : flow_(flow) {}
+  // the first cloud was read ahead (to know whether the pipeline is needed at all)
+  void pushBack(std::string name, std::vector<uint8_t> bytes) {
+    have_first_ = true;
+    first_name_ = std::move(name);
+    first_bytes_ = std::move(bytes);
+  }
+  bool submitNow() const override {
+    std::lock_guard<std::mutex> lock(flow_.mutex);
+    return flow_.held_bytes > McapFlow::kHoldBytes;
+  }
   bool next(Message& out) override {
-    if (at_ >= picks_.size()) return false;
-    const size_t idx = picks_[at_++];
-    const McapMessage& m = file_.messages[idx];
-    out.name = std::to_string(idx);
-    out.bytes.resize(m.size);
-    if (m.size) std::memcpy(out.bytes.data(), m.data, m.size);
+    if (have_first_) {
+      have_first_ = false;
+      out.name = first_name_;
+      out.bytes.resize(first_bytes_.size());
+      if (!first_bytes_.empty()) std::memcpy(out.bytes.data(), first_bytes_.data(), first_bytes_.size());
+      first_bytes_ = std::vector<uint8_t>();
+      return true;
+    }
+    McapMessage m;
+    if (!flow_.nextCloud(m, scratch_, out.name)) return false;
+    out.bytes.resize(scratch_.size());
+    if (!scratch_.empty()) std::memcpy(out.bytes.data(), scratch_.data(), scratch_.size());
     return true;
   }
 
  private:
-  const McapFile& file_;
-  const std::vector<size_t>& picks_;
-  size_t at_ = 0;
+  McapFlow& flow_;
+  bool have_first_ = false;
+  std::string first_name_;
+  std::vector<uint8_t> first_bytes_, scratch_;
 };
 
 // converted messages arrive in input order; every other message of the bag is copied through in front of the converted
 // message that follows it in the file
 class McapSink : public MessageSink {
  public:
-  McapSink(const McapFile& file, McapWriter& writer, const std::vector<bool>& is_cloud, McapTranscodeStats& stats)
-      : file_(file), writer_(writer), is_cloud_(is_cloud), stats_(stats) {}
+  explicit McapSink(McapFlow& flow) : flow_(flow) {}
   void write(const std::string& name, const uint8_t* data, size_t size) override {
-    const size_t idx = (size_t)std::stoull(name);
-    copyUpTo(idx);
-    const McapMessage& m = file_.messages[idx];
-    writer_.writeMessage(m.channel_id, m.sequence, m.log_time, m.publish_time, data, size);
-    stats_.input_bytes += m.size;
-    stats_.output_bytes += size;
-    ++stats_.converted;
-    next_ = idx + 1;
-  }
-  void copyUpTo(size_t idx) {
-    for (; next_ < idx; ++next_) {
-      if (is_cloud_[next_]) continue;  // (cannot happen: converted messages arrive in order)
-      const McapMessage& m = file_.messages[next_];
-      writer_.writeMessage(m.channel_id, m.sequence, m.log_time, m.publish_time, m.data, m.size);
+    const uint64_t id = std::stoull(name);
+    std::lock_guard<std::mutex> lock(flow_.mutex);
+    try {
+      flow_.flushCopies();
+      if (flow_.pending.empty() || flow_.pending.front().id != id) bad("converted messages arrived out of order");
+      const McapMessage& h = flow_.pending.front().head;
+      flow_.out.writeMessage(h.channel_id, h.sequence, h.log_time, h.publish_time, data, size);
+      flow_.stats.input_bytes += h.size;
+      flow_.stats.output_bytes += size;
+      ++flow_.stats.converted;
+      ++flow_.written;
+      flow_.pending.pop_front();
+      --flow_.clouds_pending;
+      flow_.flushCopies();
+    } catch (...) {
+      flow_.failed = true;
+      flow_.drained.notify_all();
+      throw;
     }
   }
 
  private:
-  const McapFile& file_;
-  McapWriter& writer_;
-  const std::vector<bool>& is_cloud_;
-  McapTranscodeStats& stats_;
-  size_t next_ = 0;
+  McapFlow& flow_;
 };
 
 }  // namespace
 
 McapTranscodeStats transcodeMcap(const std::string& file_in, const std::string& file_out, TranscodeOptions options,
                                  McapCompression mcap_compression) {
-  const McapFile in(file_in);
+  McapStream in(file_in);
   McapTranscodeStats stats;
-  stats.messages = in.messages.size();
-  const std::string from = options.decode ? kCompressedPointCloud2SchemaName : kPointCloud2SchemaName;
-  const std::string to = options.decode ? kPointCloud2SchemaName : kCompressedPointCloud2SchemaName;
-  const char* to_text = options.decode ? kPointCloud2SchemaText : kCompressedPointCloud2SchemaText;
   // no need to compress twice (mcap_converter.cpp:199-202)
   if (!options.decode && mcap_compression == McapCompression::Zstd) options.compression = Cloudini::CompressionOption::NONE;
 
   McapWriter out(file_out, in.profile, mcap_compression);
-  for (const auto& kv : in.schemas) {  // ascending ids, like duplicateSchemasAndChannels
-    McapSchema s = kv.second;
-    if (s.name == from) {
-      s.name = to;
-      s.data.assign(to_text, to_text + std::strlen(to_text));
-    }
-    out.addSchema(s);
+  McapFlow flow(in, out, options.decode, stats);
+  McapSource source(flow);
+  McapSink sink(flow);
+  // up to the first point cloud nothing needs the pipeline (a bag without one is copied without a GPU)
+  McapMessage first;
+  std::vector<uint8_t> first_bytes;
+  std::string first_name;
+  if (flow.nextCloud(first, first_bytes, first_name)) {
+    source.pushBack(std::move(first_name), std::move(first_bytes));
+    stats.pipeline = transcodePointClouds(source, sink, options);
   }
-  for (const auto& kv : in.channels) out.addChannel(kv.second);
-  for (const McapMetadata& m : in.metadata) out.addMetadata(m);
-
-  std::vector<bool> is_cloud(in.messages.size(), false);
-  std::vector<size_t> picks;
-  for (size_t i = 0; i < in.messages.size(); ++i) {
-    const auto ch = in.channels.find(in.messages[i].channel_id);
-    if (ch == in.channels.end()) bad("message on a channel the file does not declare");
-    const auto sc = in.schemas.find(ch->second.schema_id);
-    if (sc != in.schemas.end() && sc->second.name == from) {
-      is_cloud[i] = true;
-      picks.push_back(i);
-    }
+  {
+    std::lock_guard<std::mutex> lock(flow.mutex);
+    flow.flushCopies();
+    if (!flow.pending.empty()) bad("point clouds were read but not converted");
   }
-  McapSource source(in, picks);
-  McapSink sink(in, out, is_cloud, stats);
-  if (!picks.empty()) stats.pipeline = transcodePointClouds(source, sink, options);
-  sink.copyUpTo(in.messages.size());
   out.close();
   return stats;
 }

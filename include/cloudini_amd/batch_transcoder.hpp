@@ -85,6 +85,10 @@ class MessageSource {
     (void)ticket;
     (void)out;
   }
+  // Optional: true right after a next() = "hand the batch on as it is" -- a source that holds other data back until the
+  // messages it has delivered come out of the sink (the container converter: everything that lies between two point
+  // clouds of a bag) asks for this before its next() waits for the sink.
+  virtual bool submitNow() const { return false; }
 };
 
 class MessageSink {

@@ -10,6 +10,9 @@
 //   McapFile    reads a whole file: Header, Schema / Channel / Message / Metadata records of the data section, inside Chunk
 //               records ("" / "zstd" / "lz4" frame compression) or outside; messages in FILE order (the order
 //               McapReader::readMessages takes by default). Index and summary records are not needed and skipped.
+//   McapStream  (round 5) the same records one after the other, straight from the file: one record -- or one decompressed
+//               chunk -- in memory at a time. transcodeMcap reads through it: a bag of many gigabytes is converted in the
+//               memory of a few batches, like the reference's converter streams through McapReader.
 //   McapWriter  Header, Schema / Channel records, Messages in chunks of <= chunk_size uncompressed bytes, Metadata, DataEnd, a
 //               summary section (Schemas, Channels, ChunkIndexes, Statistics, SummaryOffsets) and the Footer. Round 5: one
 //               MessageIndex record per channel behind every chunk ((log_time, offset of the Message record inside the
@@ -70,9 +73,41 @@ class McapFile {
   std::vector<uint8_t> image_;
   std::vector<std::vector<uint8_t>> chunks_;
 };
-// (McapFile keeps the file image and every decompressed chunk until it is destroyed: messages point into them. A chunk that
-// claims more than kMcapMaxChunkBytes uncompressed bytes, or more than its compressed frame can hold, is refused.)
+// (McapFile keeps the file image and every decompressed chunk until it is destroyed: messages point into them -- small
+// files, tests, tools. A chunk that claims more than kMcapMaxChunkBytes uncompressed bytes, or more than its compressed
+// frame can hold, is refused.)
 constexpr uint64_t kMcapMaxChunkBytes = 1ull << 30;
+
+// The records of the data section in file order, one at a time (Chunk records are opened: their records follow). What a
+// Record points at is valid until the next call. Ends (false) at DataEnd / the Footer. Throws std::runtime_error like McapFile.
+class McapStream {
+ public:
+  explicit McapStream(const std::string& path);  // opens, checks both magics, reads the Header record
+  ~McapStream();
+  McapStream(const McapStream&) = delete;
+  McapStream& operator=(const McapStream&) = delete;
+  struct Record {
+    uint8_t op = 0;
+    const uint8_t* data = nullptr;
+    size_t size = 0;
+  };
+  bool next(Record& r);
+  std::string profile, library;
+  // parsers of the record bodies McapFile also understands
+  static McapSchema parseSchema(const Record& r);
+  static McapChannel parseChannel(const Record& r);
+  static McapMetadata parseMetadata(const Record& r);
+  static McapMessage parseMessage(const Record& r);  // (data points into the record)
+
+ private:
+  void readExact(void* dst, size_t n, const char* what);
+  void* file_ = nullptr;
+  std::string path_;
+  uint64_t pos_ = 0, size_ = 0;
+  std::vector<uint8_t> rec_, chunk_;
+  size_t chunk_at_ = 0;
+  bool in_chunk_ = false, ended_ = false;
+};
 
 enum class McapCompression { None, Lz4, Zstd };
 
@@ -114,6 +149,7 @@ class McapWriter {
 
 struct McapTranscodeStats {
   uint64_t messages = 0, converted = 0, input_bytes = 0, output_bytes = 0;
+  uint64_t peak_held_bytes = 0;  // most bytes of copied-through messages that waited for a point cloud in front of them
   TranscodeStats pipeline;
 };
 

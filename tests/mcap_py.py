@@ -22,13 +22,26 @@ def _rec(op: int, body: bytes) -> bytes:
     return struct.pack("<BQ", op, len(body)) + body
 
 
-def write(path, profile, schemas, channels, messages, metadata=(), chunk_messages=None):
+def write(path, profile, schemas, channels, messages, metadata=(), chunk_messages=None, declare_late=False):
     """schemas: [(id, name, encoding, data)], channels: [(id, schema_id, topic, encoding, [(k, v)])],
-    messages: [(channel, seq, log, pub, bytes)]; chunk_messages: messages per (uncompressed) chunk, None = no chunks."""
+    messages: [(channel, seq, log, pub, bytes)]; chunk_messages: messages per (uncompressed) chunk, None = no chunks.
+    declare_late: a Schema / Channel record stands right in front of the first message that needs it (wherever in the
+    file that is) instead of at the file's beginning."""
     out = [MAGIC, _rec(HEADER, _s(profile) + _s("mcap_py"))]
-    decl = b"".join(_rec(SCHEMA, struct.pack("<H", i) + _s(n) + _s(e) + struct.pack("<I", len(d)) + d) for i, n, e, d in schemas)
-    decl += b"".join(_rec(CHANNEL, struct.pack("<HH", i, s) + _s(t) + _s(e) + _map(m)) for i, s, t, e, m in channels)
-    msgs = [_rec(MESSAGE, struct.pack("<HIQQ", c, q, lt, pt) + d) for c, q, lt, pt, d in messages]
+    srec = {i: _rec(SCHEMA, struct.pack("<H", i) + _s(n) + _s(e) + struct.pack("<I", len(d)) + d) for i, n, e, d in schemas}
+    crec = {i: (s, _rec(CHANNEL, struct.pack("<HH", i, s) + _s(t) + _s(e) + _map(m))) for i, s, t, e, m in channels}
+    decl = b"" if declare_late else b"".join(srec.values()) + b"".join(r for _, r in crec.values())
+    msgs, seen_s, seen_c = [], set(), set()
+    for c, q, lt, pt, d in messages:
+        pre = b""
+        if declare_late and c not in seen_c:
+            sid = crec[c][0]
+            if sid not in seen_s and sid in srec:
+                pre += srec[sid]
+                seen_s.add(sid)
+            pre += crec[c][1]
+            seen_c.add(c)
+        msgs.append(pre + _rec(MESSAGE, struct.pack("<HIQQ", c, q, lt, pt) + d))
     if chunk_messages is None:
         out.append(decl)
         out.extend(msgs)

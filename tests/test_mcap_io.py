@@ -119,11 +119,19 @@ def test_cpp_reader_takes_what_python_wrote(tmp_path, chunked):
     assert [l for l in lines if l.startswith("metadata")] == ["metadata m 1"]
     got = [l for l in lines if l.startswith("message")]
     assert got == [f"message {c} {q} {lt} {pt} {len(d)} {_fnv(d)}" for c, q, lt, pt, d in msgs]
+    # McapStream (record by record, a chunk at a time) reads the same -- also with the declarations in the middle of the file
+    late = str(tmp_path / "late.mcap")
+    mcap_py.write(late, "ros2", schemas, channels, msgs, metadata=[("m", [("k", "v")])], chunk_messages=chunked, declare_late=True)
+    for f in (path, late):
+        rs = subprocess.run([exe, f, "stream"], capture_output=True, text=True, timeout=60)
+        assert rs.returncode == 0 and rs.stdout == subprocess.run([exe, f], capture_output=True, text=True, timeout=60).stdout, rs.stdout + rs.stderr
+    assert rs.stdout == r.stdout
     # a file cut short is an error, not a crash
     cut = str(tmp_path / "cut.mcap")
     open(cut, "wb").write(open(path, "rb").read()[:-20])
-    r = subprocess.run([exe, cut], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 1 and r.stdout.startswith("error MCAP:")
+    for mode in ([], ["stream"]):
+        r = subprocess.run([exe, cut] + mode, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and r.stdout.startswith("error MCAP:")
 
 
 @pytest.mark.gpu
@@ -179,3 +187,71 @@ def test_a_bag_goes_through_the_tool_and_back(tmp_path, reflib):
     assert subprocess.run([tool, src, z, "--mcap-compression", "zstd"], capture_output=True, timeout=300).returncode == 0
     assert subprocess.run([tool, z, l, "--decode", "--mcap-compression", "lz4"], capture_output=True, timeout=300).returncode == 0
     assert os.path.getsize(z) < os.path.getsize(src) and os.path.getsize(l) > os.path.getsize(z)
+
+
+@pytest.mark.gpu
+def test_a_bag_is_streamed_not_loaded(tmp_path, reflib):
+    """transcodeMcap reads through McapStream (round 5): a chunk at a time, the messages that are not point clouds written
+    as they come. Channels declared in the middle of the file; order and bytes as in the input; and the resident memory of
+    the tool does not follow the size of the bag."""
+    from cloudini_amd import synth
+    from test_host_api import _cdr_pointcloud2
+    tool = os.path.join(LIB, "cloudini_batch_transcode")
+    pc2 = "sensor_msgs/msg/PointCloud2"
+    schemas = [(1, pc2, "ros2msg", b"x"), (2, "sensor_msgs/msg/Image", "ros2msg", b"y")]
+    channels = [(1, 2, "/camera", "cdr", []), (2, 1, "/lidar", "cdr", []), (3, 2, "/camera2", "cdr", []), (4, 1, "/lidar2", "cdr", [])]
+    clouds = []
+    for k in range(6):
+        info, data = synth.lidar_xyzi(20000 + 1000 * k, seed=30 + k)
+        clouds.append(_cdr_pointcloud2(info, data, stamp=(1700000000 + k, k)).tobytes())
+
+    def bag(path, image_bytes, images_between):
+        rs = np.random.RandomState(5)
+        msgs, t = [], 10
+        for k, c in enumerate(clouds):
+            for j in range(images_between):
+                msgs.append((1 if k < 3 else 3, len(msgs), t, t, rs.bytes(16) + bytes(image_bytes - 16))); t += 1
+            msgs.append((2 if k < 4 else 4, len(msgs), t, t, c)); t += 1
+        for j in range(images_between):
+            msgs.append((3, len(msgs), t, t, rs.bytes(16) + bytes(image_bytes - 16))); t += 1
+        mcap_py.write(path, "ros2", schemas, channels, msgs, chunk_messages=3, declare_late=True)
+        return msgs
+
+    def run(src, dst):
+        # the tool reports its own high-water mark (CLDN_DEBUG_MEM: VmHWM of /proc/self/status, in kB). getrusage's
+        # ru_maxrss of a child is no use here: it starts from the resident size of the process that forked it.
+        r = subprocess.run([tool, src, dst, "--resolution", "0.001", "--compression", "zstd", "--mcap-compression", "none", "--batch", "2"],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, CLDN_DEBUG_MEM="1"))
+        assert r.returncode == 0, r.stdout + r.stderr
+        hwm = [int(line.split()[1]) for line in r.stderr.splitlines() if line.startswith("VmHWM")]
+        assert len(hwm) == 1
+        import json
+        return hwm[0], json.loads(r.stdout.strip().splitlines()[-1])
+
+    small, mid, big = str(tmp_path / "small.mcap"), str(tmp_path / "mid.mcap"), str(tmp_path / "big.mcap")
+    msgs = bag(small, 64, 2)
+    run(small, str(tmp_path / "small_out.mcap"))
+    f = mcap_py.read(str(tmp_path / "small_out.mcap"))
+    assert f["channels"] == {c[0]: (c[1], c[2], c[3], c[4]) for c in channels}
+    assert f["schemas"][1][0] == "point_cloud_interfaces/msg/CompressedPointCloud2" and f["schemas"][2][0] == "sensor_msgs/msg/Image"
+    assert len(f["messages"]) == len(msgs)
+    for (ch, seq, lt, pt, data), (ch0, seq0, lt0, pt0, data0) in zip(f["messages"], msgs):
+        assert (ch, seq, lt, pt) == (ch0, seq0, lt0, pt0)
+        if ch0 in (1, 3):
+            assert data == data0
+        else:
+            assert data == reflib.ros_compress(np.frombuffer(data0, dtype=np.uint8), 0.001, 2).tobytes()  # ZSTD
+    # the same clouds between 7 x 40 and 7 x 80 images of 1 MiB: bags of 290 and 590 MB. What the tool holds at most is 64 MB
+    # of copied-through messages plus what lies between two clouds; a reader that keeps the file image and its chunks
+    # would need the size of the bag, twice. (The runtime's own footprint -- page-locked staging, the HIP libraries --
+    # is in both runs: the difference is what follows the bag.)
+    bag(mid, 1 << 20, 40)
+    rss_mid, st_mid = run(mid, str(tmp_path / "mid_out.mcap"))
+    os.remove(str(tmp_path / "mid_out.mcap"))
+    bag(big, 1 << 20, 80)
+    rss_big, st_big = run(big, str(tmp_path / "big_out.mcap"))
+    grown = os.path.getsize(big) - os.path.getsize(mid)
+    assert grown > 250e6 and os.path.getsize(str(tmp_path / "big_out.mcap")) > 500e6
+    assert st_big["messages"] == 6 + 7 * 80 and st_big["converted"] == 6
+    assert st_mid["peak_held_bytes"] <= (64 + 40 + 1) << 20 and st_big["peak_held_bytes"] <= (64 + 80 + 1) << 20
+    assert (rss_big - rss_mid) * 1024 < 0.25 * grown, (rss_mid, rss_big, grown)

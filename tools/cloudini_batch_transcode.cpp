@@ -55,10 +55,18 @@ int main(int argc, char** argv) {
     if (in_path.size() > 5 && in_path.compare(in_path.size() - 5, 5, ".mcap") == 0) {
       const cloudini_amd::McapTranscodeStats ms = cloudini_amd::transcodeMcap(in_path, argv[2], opt, mcap_comp);
       std::printf("{\"messages\": %llu, \"converted\": %llu, \"input_bytes\": %llu, \"output_bytes\": %llu, \"points\": %llu, "
-                  "\"seconds_total\": %.6f, \"gpu_batches\": %llu}\n",
+                  "\"seconds_total\": %.6f, \"gpu_batches\": %llu, \"peak_held_bytes\": %llu}\n",
                   (unsigned long long)ms.messages, (unsigned long long)ms.converted, (unsigned long long)ms.input_bytes,
                   (unsigned long long)ms.output_bytes, (unsigned long long)ms.pipeline.points, ms.pipeline.seconds_total,
-                  (unsigned long long)ms.pipeline.gpu_batches);
+                  (unsigned long long)ms.pipeline.gpu_batches, (unsigned long long)ms.peak_held_bytes);
+      if (std::getenv("CLDN_DEBUG_MEM")) {  // diagnostics: the process's memory high-water marks
+        if (FILE* f = std::fopen("/proc/self/status", "r")) {
+          char line[256];
+          while (std::fgets(line, sizeof line, f))
+            if (!std::strncmp(line, "VmHWM", 5) || !std::strncmp(line, "Rss", 3) || !std::strncmp(line, "VmPeak", 6)) std::fputs(line, stderr);
+          std::fclose(f);
+        }
+      }
       return 0;
     }
     cloudini_amd::DirectorySource source(argv[1]);
