@@ -177,7 +177,7 @@ struct cldn_hip_codec {
   uint64_t ct_slot_stride = 0, ct_need = 0;
   size_t ct_segs_off = 0, ct_anchor_off = 0;
   int stage2 = 0;
-  DevBuf d_s1, d_s1_offsets, d_lz_matches, d_lz_counts, d_payload2, d_dst2;
+  DevBuf d_s1, d_s1_offsets, d_lz_matches, d_lz_counts, d_payload2, d_dst2, d_dec_split;
   DevBuf d_finrec;            // k_finish look-back records (rec, rec2), cleared only when (re)allocated
   int decode_fill = CLDN_HIP_FILL_KEEP;  // cldn_hip_codec_set_decode_fill
   DevBuf d_dec_bits;          // k_mark_token_ends: token-end bitmap of the streams of a decode call
@@ -590,7 +590,7 @@ void cldn_hip_codec_destroy(cldn_hip_codec_t* c) {
   (void)guard.enter(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf* bufs[] = {&c->d_in, &c->d_out, &c->d_slots, &c->d_chunks, &c->d_cloud_first, &c->d_finrec, &c->d_dec_rec, &c->d_dec_bits, &c->d_dec_secs, &c->d_s1, &c->d_s1_offsets,
-                    &c->d_lz_matches, &c->d_lz_counts, &c->d_payload2, &c->d_dst2,
+                    &c->d_lz_matches, &c->d_lz_counts, &c->d_payload2, &c->d_dst2, &c->d_dec_split,
                     &c->d_payload, &c->d_dst, &c->d_offsets, &c->d_modes, &c->d_status, &c->d_dec_meta, &c->d_pre_ptrs, &c->d_dec_cols[0], &c->d_dec_cols[1], &c->d_dec_cols[2], &c->d_dec_cols[3], &c->d_dec_cols[4], &c->d_dec_cols[5], &c->d_dec_cols[6], &c->d_dec_cols[7],
                     &c->d_viz_keys, &c->d_viz_first,
                     &c->d_viz_slot, &c->d_viz_blocks, &c->d_viz_total, &c->d_pieces};
@@ -1595,6 +1595,17 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
     c->dec_stats_chunks = 0;
   }
   L.palette_hint = c->dec_palette_hint ? 1u : 0u;
+  // small batches: the point kernel's pieces spread over several workgroups per chunk (SPLIT launches) want their workspace
+  if (!c->plan.wide && wp_split_parts(n_chunks) > 1u) {
+    uint64_t chunk_bound = (uint64_t)kPointsPerChunk * c->plan.ref_max_point_bytes;
+    if (c->plan.uses_v5) chunk_bound += (uint64_t)c->plan.fields.size() * 32u + 1024u;
+    const uint64_t maxp = chunk_bound / 1024u + 3u;
+    if (maxp <= 4096u) {
+      if ((rc = c->d_dec_split.ensure(wp_split_bytes(n_chunks, (uint32_t)maxp))) != CLDN_HIP_OK) return rc;
+      L.wp_split = c->d_dec_split.p;
+      L.wp_maxp = (uint32_t)maxp;
+    }
+  }
   L.events = c->dec_events[0] ? c->dec_events : nullptr;
   if (L.events) {
     (void)hipEventRecord(L.events[0], c->stream);

@@ -234,11 +234,25 @@ int stage1_launch_decode(const DecodeLaunch& L) {
 #define LAUNCH_POINTS_W(NOPS_, NF_, NW_, WPE_)                                                                            \
   hipLaunchKernelGGL((k_decode_points_w<NOPS_, NF_, NW_, WPE_>), dim3(L.n_chunks), dim3(NW_ * 64), (WpLds<NOPS_, NF_, NW_>::kTotal), \
                      L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done,   \
-                     L.uses_v5, L.status, c0, c1, L.reg_end_pre, sc, fill_zero, dcols)
+                     L.uses_v5, L.status, c0, c1, L.reg_end_pre, sc, fill_zero, dcols, WpSplit{})
 #define LAUNCH_POINTS_W_SM(NOPS_, NF_, SM_)                                                                               \
   hipLaunchKernelGGL((k_decode_points_w<NOPS_, NF_, 16, 8, SM_>), dim3(L.n_chunks), dim3(16 * 64), (WpLds<NOPS_, NF_, 16>::kTotal), \
                      L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done,   \
-                     L.uses_v5, L.status, c0, c1, L.reg_end_pre, sc, fill_zero, dcols)
+                     L.uses_v5, L.status, c0, c1, L.reg_end_pre, sc, fill_zero, dcols, WpSplit{})
+// SPLIT launches (small batches): counts, PASS 1, carries, PASS 2
+#define LAUNCH_POINTS_SPLIT(NOPS_, NF_, SM_)                                                                              \
+  {                                                                                                                      \
+    hipLaunchKernelGGL(k_wp_counts, dim3(L.n_chunks), dim3(1024), 0, L.stream, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), \
+                       wsp, (uint32_t)(NOPS_ + 1));                                                                      \
+    hipLaunchKernelGGL((k_decode_points_w<NOPS_, NF_, 16, 8, SM_, 1>), dim3(L.n_chunks, split_parts), dim3(16 * 64),      \
+                       (WpLds<NOPS_, NF_, 16>::kTotal), L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), \
+                       L.out, L.reg_end, L.sec_done, L.uses_v5, L.status, c0, c1, L.reg_end_pre, sc, fill_zero, dcols, wsp); \
+    hipLaunchKernelGGL(k_wp_carry<NOPS_>, dim3(L.n_chunks), dim3(64), 0, L.stream, L.streams,                            \
+                       reinterpret_cast<const DecChunk*>(L.chunks), wsp);                                                \
+    hipLaunchKernelGGL((k_decode_points_w<NOPS_, NF_, 16, 8, SM_, 2>), dim3(L.n_chunks, split_parts), dim3(16 * 64),      \
+                       (WpLds<NOPS_, NF_, 16>::kTotal), L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), \
+                       L.out, L.reg_end, L.sec_done, L.uses_v5, L.status, c0, c1, L.reg_end_pre, sc, fill_zero, dcols, wsp); \
+  }
 #define LAUNCH_POINTS_ANY(NOPS_, NF_)                      \
   {                                                        \
     if (pk == 0) LAUNCH_POINTS(NOPS_, NF_);                \
@@ -262,8 +276,36 @@ int stage1_launch_decode(const DecodeLaunch& L) {
             sm = 2;
         }
       }
+      // SPLIT launches for batches that do not fill the chip (CLDN_HIP_NO_SPLIT_DECODE=1: A/B switch; CLDN_HIP_SPLIT_PARTS=n)
+      static const bool no_split = getenv("CLDN_HIP_NO_SPLIT_DECODE") != nullptr;
+      static const int parts_env = getenv("CLDN_HIP_SPLIT_PARTS") ? atoi(getenv("CLDN_HIP_SPLIT_PARTS")) : 0;
+      const uint32_t split_parts = no_split || L.wp_split == nullptr || pk != 16 || nf > 1u ? 1u
+                                   : (parts_env > 0 ? (uint32_t)std::min(parts_env, 16) : wp_split_parts(L.n_chunks));
+      WpSplit wsp = {};
+      if (split_parts > 1u) {
+        uint8_t* w = (uint8_t*)L.wp_split;
+        wsp.maxp = L.wp_maxp;
+        wsp.flags = (uint32_t*)w;
+        w += ((size_t)L.n_chunks * 16u + 255u) & ~size_t(255);
+        wsp.t0 = (uint32_t*)w;
+        w += (size_t)L.n_chunks * L.wp_maxp * 4u;
+        wsp.agg = (int32_t*)w;
+        w += (size_t)L.n_chunks * L.wp_maxp * 20u;
+        wsp.carry = (int32_t*)w;
+      }
       ev_before();
-      if (P.n_ops == 3u && sm == 1) {
+      if (split_parts > 1u && P.n_ops == 3u && sm == 1) {
+        if (nf == 0u) LAUNCH_POINTS_SPLIT(3, 0, 1)
+        else LAUNCH_POINTS_SPLIT(3, 1, 1)
+      } else if (split_parts > 1u && P.n_ops == 3u && sm == 2) {
+        LAUNCH_POINTS_SPLIT(3, 1, 2)
+      } else if (split_parts > 1u && P.n_ops == 3u && sm == 0) {
+        if (nf == 0u) LAUNCH_POINTS_SPLIT(3, 0, 0)
+        else LAUNCH_POINTS_SPLIT(3, 1, 0)
+      } else if (split_parts > 1u && P.n_ops == 4u && sm == 0) {
+        if (nf == 0u) LAUNCH_POINTS_SPLIT(4, 0, 0)
+        else LAUNCH_POINTS_SPLIT(4, 1, 0)
+      } else if (P.n_ops == 3u && sm == 1) {
         if (nf == 0u) LAUNCH_POINTS_W_SM(3, 0, 1);
         else LAUNCH_POINTS_W_SM(3, 1, 1);
       } else if (P.n_ops == 3u && sm == 2) {
@@ -280,6 +322,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         else LAUNCH_POINTS_W(4, 8, 16, 8);
       }
 #undef LAUNCH_POINTS_ANY
+#undef LAUNCH_POINTS_SPLIT
 #undef LAUNCH_POINTS_W_SM
 #undef LAUNCH_POINTS_W
 #undef LAUNCH_POINTS

@@ -135,7 +135,24 @@ __device__ __forceinline__ bool wp_tokens(const uint32_t* wbuf, uint32_t byte0, 
   return bad;
 }
 
-template <int NOPS, int NF, int NW, int WPE = 8, int SM = 0>
+// SPLIT launches (round 5, small batches: fewer chunks than the chip has room for): the pieces of a chunk are spread over
+// gridDim.y workgroups and the two chains are replaced by three light kernels' results in global memory --
+//   k_wp_counts   t0[piece] = token ends in front of the piece (the popcounts of chain 1, one block scan per chunk)
+//   PASS 1        this kernel up to the pieces' aggregates: agg[piece] = {value of every lane behind the piece relative to
+//                 its start, reset flags} (what chain 2 would combine)
+//   k_wp_carry    carry[piece] = the values in front of the piece (a segmented scan of the aggregates, one wave per chunk)
+//   PASS 2        this kernel from its first byte to its stores, T0 and the carry read instead of waited for.
+// About 1.5 x the arithmetic of the chained launch, but no piece waits for another one: a lone cloud's 31 chunks are 5456
+// pieces on 256 CUs instead of 31 chains of 176 hops.
+struct WpSplit {
+  uint32_t* t0;       // [chunk * maxp + piece]
+  int32_t* agg;       // [(chunk * maxp + piece) * (NOPS + 1)]
+  int32_t* carry;     // [(chunk * maxp + piece) * NOPS]
+  uint32_t* flags;    // [chunk * 4]: irregular, palette index out of range, end of the regular stream, workgroups done
+  uint32_t maxp;      // pieces a chunk may have (more: the chunk is left to the kernels behind)
+};
+
+template <int NOPS, int NF, int NW, int WPE = 8, int SM = 0, int PASS = 0>
 #ifndef CLDN_WP_SGPR
 #define CLDN_WP_SGPR 0
 #endif
@@ -148,7 +165,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     const DevPlan plan, const uint8_t* __restrict__ streams, const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
     uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done, uint32_t uses_v5, uint32_t* __restrict__ status,
     const uint8_t* __restrict__ col0, const uint8_t* __restrict__ col1, const uint32_t* __restrict__ reg_end_pre,
-    const uint8_t* __restrict__ sec_cols, uint32_t fill_zero, const DecColumns many) {
+    const uint8_t* __restrict__ sec_cols, uint32_t fill_zero, const DecColumns many, const WpSplit sp) {
   using L = WpLds<NOPS, NF, NW>;
   using G = WpGeom<NOPS>;
   constexpr int T = NW * 64;
@@ -275,14 +292,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
   };
 
   uint32_t b[4], bh[4];  // my unit of the piece; the halo's two units (every lane asks for unit lane & 1: no branch)
-  uint32_t p = wave;
+  constexpr bool SPLIT = PASS != 0;
+  const uint32_t p_step = SPLIT ? gridDim.y * (uint32_t)NW : (uint32_t)NW;
+  uint32_t p = SPLIT ? blockIdx.y * (uint32_t)NW + wave : wave;
+  if (SPLIT && n_pieces > sp.maxp) {  // (uniform; a payload beyond what the plan allows: the serial decoder raises the errors)
+    if (PASS == 2 && blockIdx.y == 0u && tid == 0) {
+      reg_end[c] = kDecRedo;
+      sec_done[c] = 0u;
+    }
+    return;
+  }
+  const size_t sp_base = SPLIT ? (size_t)c * sp.maxp : 0u;
   if (n_pieces) {        // (no payload: nothing may be read)
     load_unit(min(p, n_pieces) * kWpPiece + lane * 16u, b);
     load_unit((min(p, n_pieces) + 1u) * kWpPiece + (lane & 1u) * 16u, bh);
   }
   bool gave_up = false;
   __builtin_amdgcn_s_setprio(1);  // (waves that poll a record step down to 0)
-  for (; p < n_pieces; p += NW) {
+  for (; p < n_pieces; p += p_step) {
     // ---- bytes -> LDS, token ends
     *reinterpret_cast<uint4*>(wbuf + lane * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
     if (lane < 2u) *reinterpret_cast<uint4*>(wbuf + kWpPiece / 4u + lane * 4u) = make_uint4(bh[0], bh[1], bh[2], bh[3]);
@@ -299,13 +326,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     const uint32_t tb = incl - cl;
     // my next piece's bytes are requested now (b, bh are free)
     {
-      const uint32_t pn = min(p + (uint32_t)NW, n_pieces);
+      const uint32_t pn = min(p + p_step, n_pieces);
       load_unit(pn * kWpPiece + lane * 16u, b);
       load_unit((pn + 1u) * kWpPiece + (lane & 1u) * 16u, bh);
     }
     // ---- chain 1: token ends in front of the piece
     uint32_t T0 = 0u;
-    if (p != 0u) {
+    if constexpr (SPLIT) {
+      T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.t0[sp_base + p]);
+    } else if (p != 0u) {
       const unsigned long long* r = trec + ((p - 1u) & (kWpRing - 1u));
       unsigned long long x = wp_rec_load(r);
       if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p) {  // not there yet: poll at low priority
@@ -325,7 +354,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
       T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T0);
     }
     if (gave_up) break;  // uniform
-    if (lane == 0u) wp_rec_store(trec + (p & (kWpRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (T0 + cnt));
+    if (!SPLIT && lane == 0u) wp_rec_store(trec + (p & (kWpRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (T0 + cnt));
     if (T0 >= target) break;  // the regular stream ended in front of this piece (sections; uniform)
     if (T0 + cnt >= target) {  // uniform: the end that closes the last point lies in this piece
       const uint32_t want = target - T0;  // its 1-based rank among the piece's ends
@@ -410,6 +439,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
       }
     }
     if (__ballot(irregular) != 0ull && lane == 0u) misc[0] = 1u;
+    if constexpr (PASS == 1) {  // the piece's aggregate leaves; k_wp_carry combines them
+      if (lane <= (uint32_t)NOPS) {
+        int32_t v = (int32_t)bs_fl;
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) v = lane == (uint32_t)o ? bs[o] : v;
+        sp.agg[(sp_base + p) * (size_t)(NOPS + 1) + lane] = v;
+      }
+      wp_wave_sync();  // the next piece's bytes and list overwrite this one's
+      continue;
+    }
     // ---- the points' integer fields are requested now (a column value, or the dword that holds a folded Palette's
     // index), rows and fields side by side: they arrive while the wave waits for its carry and converts
     uint32_t raw[NFA][ROWS];
@@ -444,7 +483,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     int32_t carry[NOPS];
 #pragma unroll
     for (int o = 0; o < NOPS; ++o) carry[o] = 0;
-    if (p != 0u) {
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int o = 0; o < NOPS; ++o) carry[o] = __builtin_amdgcn_readfirstlane(sp.carry[(sp_base + p) * (size_t)NOPS + (size_t)o]);
+    } else if (p != 0u) {
       const unsigned long long* r = vrec + (size_t)((p - 1u) & (kWpRing - 1u)) * NOPS + min(lane, (uint32_t)NOPS - 1u);
       unsigned long long x = wp_rec_load(r);
       if (__ballot((uint32_t)(x >> 32) != p) != 0ull) {  // not there yet: poll at low priority
@@ -464,7 +506,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
       for (int o = 0; o < NOPS; ++o) carry[o] = __builtin_amdgcn_readlane((int)(uint32_t)x, o);
     }
     if (gave_up) break;  // uniform
-    {
+    if constexpr (!SPLIT) {
       uint32_t mine = 0u;
 #pragma unroll
       for (int o = 0; o < NOPS; ++o) {
@@ -609,6 +651,27 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     misc[0] = 1u;
   }
   __syncthreads();
+  if constexpr (PASS == 1) return;  // (what PASS 1 found irregular PASS 2 finds again)
+  if constexpr (PASS == 2) {
+    // the chunk's verdict is given by the last of its workgroups to get here (flags in global memory: k_wp_counts reset them)
+    if (tid == 0) {
+      uint32_t* fl = sp.flags + (size_t)c * 4u;
+      if (misc[0] != 0u) atomicOr(fl + 0, 1u);
+      if (misc[1] != 0u) atomicOr(fl + 1, 1u);
+      if (misc[2] != 0xffffffffu) atomicMin(fl + 2, misc[2]);
+      __threadfence();
+      const uint32_t done = atomicAdd(fl + 3, 1u);
+      if (done + 1u == gridDim.y) {
+        __threadfence();
+        misc[0] = __hip_atomic_load(fl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        misc[1] = __hip_atomic_load(fl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        misc[2] = __hip_atomic_load(fl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        misc[3] = 2u;  // not the last one
+      }
+    }
+    if (tid != 0 || misc[3] == 2u) return;
+  }
   if (tid == 0) {
     const uint32_t pos = misc[2];
     const bool redo = misc[0] != 0u || pos == 0xffffffffu;
@@ -618,6 +681,94 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     if (!redo) atomicAdd(&status[kStatFastRegular], 1u);
     if (folded) atomicAdd(&status[kStatFastSections], 1u);
     if (folded && !from_cols) atomicAdd(&status[kStatFoldedByGuess], 1u);
+  }
+}
+
+// ---- the two light kernels of a SPLIT launch ----------------------------------------------------------------------------
+// grid = n_chunks, 1024 threads: the token ends of every piece of the chunk (the same masks as k_decode_points_w's), one
+// exclusive scan -> t0; the chunk's flags reset, its aggregates zeroed (pieces behind the regular stream write none)
+__global__ __launch_bounds__(1024) void k_wp_counts(const uint8_t* __restrict__ streams, const DecChunk* __restrict__ chunks,
+                                                   const WpSplit sp, uint32_t agg_stride) {
+  __shared__ uint32_t scan[40];
+  __shared__ uint32_t carry_sh;
+  const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const DecChunk dc = chunks[c];
+  if (tid < 4u) sp.flags[(size_t)c * 4u + tid] = tid == 2u ? 0xffffffffu : 0u;
+  if (!dc.valid) return;
+  const uint8_t* src = streams + dc.src_off;
+  const uint32_t src_size = dc.src_size;
+  const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
+  const uint8_t* src_al = src - a0;
+  const uint32_t vend = a0 + src_size;
+  const uint32_t n_pieces = src_size ? (vend + kWpPiece - 1u) / kWpPiece : 0u;
+  if (n_pieces > sp.maxp) return;
+  uint32_t* t0 = sp.t0 + (size_t)c * sp.maxp;
+  for (uint32_t p = wave; p < n_pieces; p += 16u) {
+    const uint32_t v0 = p * kWpPiece + lane * 16u;
+    const bool ok = v0 < vend;
+    const uint4 w = *reinterpret_cast<const uint4*>(src_al + (ok ? v0 : 0u));
+    const uint32_t b[4] = {ok ? w.x : 0xffffffffu, ok ? w.y : 0xffffffffu, ok ? w.z : 0xffffffffu, ok ? w.w : 0xffffffffu};
+    uint32_t ends = wp_ends16(b);
+    if (p * kWpPiece < a0 || (p + 1u) * kWpPiece > vend) {  // uniform: the payload's first / last piece
+      const uint32_t lo = a0 > v0 ? min(a0 - v0, 16u) : 0u;
+      const uint32_t hi = vend > v0 ? min(vend - v0, 16u) : 0u;
+      ends &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+    }
+    const uint32_t cnt = wave_sum((uint32_t)__builtin_popcount(ends));
+    if (lane == 0u) t0[p] = cnt;
+  }
+  for (size_t i = tid; i < (size_t)n_pieces * agg_stride; i += 1024u) sp.agg[(size_t)c * sp.maxp * agg_stride + i] = 0;
+  if (tid == 0) carry_sh = 0u;
+  __threadfence_block();
+  __syncthreads();
+  for (uint32_t base = 0; base < n_pieces; base += 1024u) {
+    const uint32_t p = base + tid;
+    const uint32_t mine = p < n_pieces ? t0[p] : 0u;
+    uint32_t total;
+    const uint32_t excl = block_exclusive_scan<1024>(mine, scan, &total);  // (barriers inside)
+    const uint32_t before = carry_sh;
+    __syncthreads();
+    if (p < n_pieces) t0[p] = before + excl;
+    if (tid == 0) carry_sh = before + total;
+    __syncthreads();
+  }
+}
+
+// grid = n_chunks, one wave: carry[piece] = what chain 2 hands a piece = the segmented running combination of the aggregates
+// of the pieces in front of it (a set reset flag: the aggregate replaces the running value)
+template <int NOPS>
+__global__ __launch_bounds__(64) void k_wp_carry(const uint8_t* __restrict__ streams, const DecChunk* __restrict__ chunks, const WpSplit sp) {
+  const uint32_t c = blockIdx.x, lane = threadIdx.x;
+  const DecChunk dc = chunks[c];
+  if (!dc.valid) return;
+  const uint32_t a0 = (uint32_t)((uintptr_t)(streams + dc.src_off) & 15u);
+  const uint32_t vend = a0 + dc.src_size;
+  const uint32_t n_pieces = dc.src_size ? (vend + kWpPiece - 1u) / kWpPiece : 0u;
+  if (n_pieces > sp.maxp) return;
+  const int32_t* agg = sp.agg + (size_t)c * sp.maxp * (NOPS + 1);
+  int32_t* carry = sp.carry + (size_t)c * sp.maxp * NOPS;
+  int32_t run[NOPS];
+#pragma unroll
+  for (int o = 0; o < NOPS; ++o) run[o] = 0;
+  for (uint32_t base = 0; base < n_pieces; base += 64u) {
+    const uint32_t p = base + lane;
+    int32_t inc[NOPS];
+    uint32_t fin = 0u;
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) inc[o] = p < n_pieces ? agg[(size_t)p * (NOPS + 1) + o] : 0;
+    if (p < n_pieces) fin = (uint32_t)agg[(size_t)p * (NOPS + 1) + NOPS];
+    wp_seg_scan<NOPS>(inc, fin);
+    int32_t pub[NOPS];  // the values behind piece p
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) pub[o] = (fin & (1u << o)) ? inc[o] : (int32_t)((uint32_t)run[o] + (uint32_t)inc[o]);
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) {
+      const int32_t prev = __shfl_up(pub[o], 1);
+      if (p < n_pieces) carry[(size_t)p * NOPS + o] = lane == 0u ? run[o] : prev;
+    }
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) run[o] = __builtin_amdgcn_readlane(pub[o], 63);
   }
 }
 

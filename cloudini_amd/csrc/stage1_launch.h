@@ -106,7 +106,21 @@ struct DecodeLaunch {
   // WIDE route: the serial decoder with the plan in device memory (schemas beyond the launch-argument plan)
   const WidePlan* wide;               // host copy of the descriptor, or NULL
   void* wide_state;                   // device [n_chunks * n_ops * 16]: the decoder's per-op state
+  // SPLIT launches of the point kernel (small batches; stage1_decode_wave.h): NULL = never split
+  void* wp_split;                     // device [wp_split_bytes(n_chunks, wp_maxp)]
+  uint32_t wp_maxp;                   // pieces of 1 KiB a chunk's payload may have
 };
+// bytes of the SPLIT workspace: per piece t0 (4) + aggregates (5 x 4) + carries (4 x 4), per chunk 4 flag words
+inline size_t wp_split_bytes(uint32_t n_chunks, uint32_t maxp) { return (size_t)n_chunks * maxp * 40u + (size_t)n_chunks * 16u + 256u; }
+// workgroups per chunk of a SPLIT launch (1 = the chained launch). Measured (device-resident decode, n x 1 M XYZI points /
+// 130 k-point Velodyne clouds): a split launch costs about 1.5 x the arithmetic, three more launches and a prologue per
+// workgroup -- it wins up to about 64 chunks (one cloud 0.093 -> 0.072 ms, one Velodyne cloud 0.153 -> 0.088) and loses
+// from about 100 on (124 chunks 0.095 -> 0.111, 496 chunks 0.16 -> 0.39 ms)
+inline uint32_t wp_split_parts(uint32_t n_chunks) {
+  if (n_chunks == 0u || n_chunks > 64u) return 1u;
+  const uint32_t parts = 256u / n_chunks;
+  return parts > 16u ? 16u : (parts < 2u ? 2u : parts);
+}
 
 constexpr size_t kDecChunkBytes = 48;
 

@@ -489,3 +489,48 @@ def test_palette_hint_of_an_earlier_call_never_changes_bytes(oracle):
     for g, k in zip(got, ("pal", "noisy", "ring")):
         assert np.array_equal(g, wants[k]), k
     codec.close()
+
+
+@pytest.mark.parametrize("switch", ["CLDN_HIP_NO_SPLIT_DECODE=1", "CLDN_HIP_SPLIT_PARTS=2", "CLDN_HIP_SPLIT_PARTS=16"])
+def test_chained_and_split_launches_of_the_point_kernel_agree(switch):
+    """Small batches take the SPLIT launches of k_decode_points_w (round 5: the pieces of a chunk over several workgroups,
+    token counts and carries through global memory); batches that fill the chip keep the chained launch. The switches are
+    read once per process: every schema family and the marker / ragged / padded cases again in a process of its own with
+    the other launch shape forced, against the oracle."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import cases
+        from oracle import binding
+        from cloudini_amd import native, synth
+        orc = binding.Oracle()
+        todo = [(n, i, d) for n, i, d in cases.encode_cases(small=False)]
+        for k, gen in enumerate((synth.lidar_xyzi, synth.lidar_xyz, synth.velodyne_xyzir)):
+            info, data = gen(130048 + 777 * k, seed=20 + k)
+            f32 = data.view(np.uint8).reshape(-1, info.point_step)[:, :4].copy().view(np.float32)
+            f32[::1013] = np.nan                       # markers: the lanes reset inside pieces
+            d2 = data.view(np.uint8).reshape(-1, info.point_step).copy()
+            d2[:, :4] = f32.view(np.uint8).reshape(-1, 4)
+            todo.append((gen.__name__ + "_nan", info, d2.reshape(-1)))
+        bad = 0
+        for name, info, data in todo:
+            step = info.point_step
+            n = data.size // step
+            codec = native.Codec(native.Plan(info))
+            stream = orc.encode_stage1(info, data)
+            out = np.full(max(1, data.size), 0x5A, dtype=np.uint8)
+            got = codec.decode_host([stream, stream], [n, n], out=np.concatenate([out, out]))
+            want = orc.decode_stage1(info, stream, n, fill=0x5A)
+            if not (np.array_equal(got[0], want) and np.array_equal(got[1], want)):
+                bad += 1
+                print("MISMATCH", name)
+            codec.close()
+        print("checked", len(todo), "bad", bad)
+    """ % (root, os.path.join(root, "tests")))
+    key, val = switch.split("=")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **{key: val}))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1].split()
+    assert last[0] == "checked" and int(last[1]) > 30 and last[3] == "0", r.stdout[-2000:]
