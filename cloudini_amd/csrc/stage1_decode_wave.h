@@ -226,8 +226,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
   __syncthreads();
 
   bool from_cols = false;
-  const uint32_t reg_size = fp_setup<NOPS, NF, T>(plan, src, src_size, n, uses_v5, c, reg_end_pre, sec_cols, misc, pal, &from_cols);
-  const uint32_t n_fold = misc[64];
+  // (PASS 1 of a SPLIT launch only sums: where the sections begin and what is folded into the stores is PASS 2's business)
+  const uint32_t reg_size = PASS == 1 ? 0xffffffffu
+                                      : fp_setup<NOPS, NF, T>(plan, src, src_size, n, uses_v5, c, reg_end_pre, sec_cols, misc, pal, &from_cols);
+  const uint32_t n_fold = PASS == 1 ? 0u : misc[64];
 
   // folded Palette sections / columns: parameters in (uniform) registers
   uint32_t fs_off[NFA], fs_bpv[NFA], fs_count[NFA], fs_bits[NFA], fs_ioff[NFA];
