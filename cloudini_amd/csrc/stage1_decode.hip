@@ -197,7 +197,9 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       if (cols) {
         {
           static const int lw = getenv("CLDN_HIP_LOCATE_WAVES") ? atoi(getenv("CLDN_HIP_LOCATE_WAVES")) : 0;  // A/B switch
-          const bool wide = lw >= 16;  // (16 waves per chunk measured slower on C3 / C4 / C5: 0.452 / 0.572 / 0.140 against 0.433 / 0.552 / 0.137 ms)
+          // (16 waves per chunk measured slower on C3 / C4 / C5: 0.452 / 0.572 / 0.140 against 0.433 / 0.552 / 0.137 ms; small
+          // batches -- the ones that take the SPLIT launches -- have CUs to spare: 4 -> 16 waves per chunk)
+          const bool wide = lw >= 16 || (lw == 0 && L.n_chunks <= 64u);
           if (wide) hipLaunchKernelGGL(k_locate_sections<16>, dim3(L.n_chunks), dim3(1024), 0, L.stream, P, L.streams,
                            reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u);
           else hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
