@@ -132,6 +132,7 @@ def _stats_ms(times):
 def e2e_figures(info, cloud, dev, budget_s: float):
     """End-to-end figures for ONE cloud of the workload per call, every call synchronous (never `value`):
       device_resident   cldn_hip_encode_stage1, input and output in HBM
+      device_resident_decode  cldn_hip_decode_stage1 of that stream, input and output in HBM
       pinned_host       the same call with HOST tags on pinned memory (H2D + kernels + D2H)
       pageable_host     ... on pageable memory
       host_mirror_decode_*  Cloudini::PointcloudDecoder::decode of the stream the encoder leg produced, next to the
@@ -176,6 +177,20 @@ def e2e_figures(info, cloud, dev, budget_s: float):
         codec.encode_device(d_in.data_ptr(), cp, d_out.data_ptr(), cap, d_off.data_ptr())
         codec.synchronize()
     out["device_resident"] = timed(dev_call)
+    # ... and back: the stream that call left in HBM decoded into HBM (chunk sizes from the encoder), one cloud per call
+    n_chunks_1 = (pts + 32767) // 32768
+    d_sizes = torch.zeros(max(1, n_chunks_1), dtype=torch.int32, device=dev)
+    codec.encode_device(d_in.data_ptr(), cp, d_out.data_ptr(), cap, d_off.data_ptr(), d_sizes.data_ptr(), 0)
+    codec.synchronize()
+    offs_dev = d_off.cpu().numpy().astype(np.uint64)
+    d_dec = torch.zeros(d_in.numel(), dtype=torch.uint8, device=dev)
+
+    def dev_decode_call():
+        codec.decode_device(d_out.data_ptr(), offs_dev, cp, d_dec.data_ptr(), d_dec.numel(), d_sizes.data_ptr())
+        codec.synchronize()
+    out["device_resident_decode"] = timed(dev_decode_call)
+    out["device_resident_decode"]["bit_exact_round_trip"] = bool(torch.equal(d_dec, d_in)) if not any(f.resolution for f in info.fields) else None
+    out["device_resident_decode"]["note"] = "batches of at most 64 chunks take the SPLIT launches of the point decoder (round 5)"
 
     offs = np.zeros(2, dtype=np.uint64)
     src_pin = torch.from_numpy(cloud).pin_memory()
