@@ -281,7 +281,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       // SPLIT launches for batches that do not fill the chip (CLDN_HIP_NO_SPLIT_DECODE=1: A/B switch; CLDN_HIP_SPLIT_PARTS=n)
       static const bool no_split = getenv("CLDN_HIP_NO_SPLIT_DECODE") != nullptr;
       static const int parts_env = getenv("CLDN_HIP_SPLIT_PARTS") ? atoi(getenv("CLDN_HIP_SPLIT_PARTS")) : 0;
-      const uint32_t split_parts = no_split || L.wp_split == nullptr || pk != 16 || nf > 1u ? 1u
+      const uint32_t split_parts = no_split || L.wp_split == nullptr || pk != 16 ? 1u
                                    : (parts_env > 0 ? (uint32_t)std::min(parts_env, 16) : wp_split_parts(L.n_chunks));
       WpSplit wsp = {};
       if (split_parts > 1u) {
@@ -303,10 +303,14 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         LAUNCH_POINTS_SPLIT(3, 1, 2)
       } else if (split_parts > 1u && P.n_ops == 3u && sm == 0) {
         if (nf == 0u) LAUNCH_POINTS_SPLIT(3, 0, 0)
-        else LAUNCH_POINTS_SPLIT(3, 1, 0)
+        else if (nf == 1u) LAUNCH_POINTS_SPLIT(3, 1, 0)
+        else if (nf == 2u) LAUNCH_POINTS_SPLIT(3, 2, 0)
+        else LAUNCH_POINTS_SPLIT(3, 8, 0)
       } else if (split_parts > 1u && P.n_ops == 4u && sm == 0) {
         if (nf == 0u) LAUNCH_POINTS_SPLIT(4, 0, 0)
-        else LAUNCH_POINTS_SPLIT(4, 1, 0)
+        else if (nf == 1u) LAUNCH_POINTS_SPLIT(4, 1, 0)
+        else if (nf == 2u) LAUNCH_POINTS_SPLIT(4, 2, 0)
+        else LAUNCH_POINTS_SPLIT(4, 8, 0)
       } else if (P.n_ops == 3u && sm == 1) {
         if (nf == 0u) LAUNCH_POINTS_W_SM(3, 0, 1);
         else LAUNCH_POINTS_W_SM(3, 1, 1);

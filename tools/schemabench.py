@@ -50,7 +50,7 @@ for name, (fields, step, cols) in layouts.items():
         continue
     info = cases.make_info(fields, step, n, enc=EncodingOptions.LOSSLESS) if "lossless" in name else cases.make_info(fields, step, n)
     data = cases.pack(info, cols, n)
-    n_clouds = 16
+    n_clouds = int(os.environ.get("SCHEMABENCH_CLOUDS", "16"))
     d_points = torch.from_numpy(np.concatenate([data] * n_clouds)).to(dev)
     plan = native.Plan(info)
     codec = native.Codec(plan, device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
