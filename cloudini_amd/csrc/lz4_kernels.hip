@@ -9,20 +9,25 @@
 //
 // The algorithm is deterministic and restated serially in oracle/lz4_model.c (the GPU tests ask for byte equality):
 //   k_lz4_plan    sub-ranges per chunk -> compact numbering (one scan).
-//   k_lz4_match   one wave per 8 KiB sub-range of a chunk's payload: the sub-range is staged in LDS next to a hash table
-//                 of its own positions (2048 entries, atomicMax = the most recent position wins; 4096 entries: ratio 0.883 instead of
-//                 0.894 on 1 M-point XYZI clouds, and 28 % slower for the LDS they take), so every byte the
-//                 parser touches is an LDS access. Per step the 64 lanes look at 64 consecutive positions: every lane
-//                 with a verified 4-byte hit extends its own match (4 bytes per round; the whole wave finishes what is
-//                 still open after 3 rounds), all 64 positions enter the table, and the step's matches are taken greedily
-//                 in position order. Matches never leave their sub-range; output = the ordered list of (position,
-//                 length, offset) per sub-range.
+//   k_lz4_match   one wave per 8 KiB sub-range of a chunk's payload (CLDN_HIP_STAGE2_LZ4_FAST: 4 KiB): the sub-range is
+//                 staged in LDS next to a hash table of its own positions (2048 / 1024 entries, atomicMax = the most recent
+//                 position wins), so every byte the parser touches is an LDS access. Per step the 64 lanes look at 64
+//                 consecutive positions: every lane with a verified 4-byte hit extends its own match (4 bytes per round; the
+//                 whole wave finishes what is still open after 3 rounds), all 64 positions enter the table, and the step's
+//                 matches are taken greedily in position order (a scalar loop over lengths; the chosen lanes write their
+//                 records side by side). Matches never leave their sub-range; a step is only parsed while the list has room
+//                 for the 16 matches a step can yield. Round 5: the loop is predicated vector code -- the CU's scalar unit
+//                 was what the round-4 version waited for.
 //   k_lz4_sizes   per sub-range: bytes of its sequences (a sequence's literals start where the previous match ended,
 //                 whichever sub-range that was in).
-//   k_lz4_emit    per sub-range: headers and match fields by lanes; every literal byte is copied by the wave of the
-//                 sub-range it lies in, so no wave ever moves more than 8 KiB however long a literal run is.
-// The compressed chunks are left in per-chunk slots of their worst-case size; k_finish (stage1_finish.h) frames them as
-// [u32 size][block] exactly as it frames stage-1 payloads.
+//   k_lz4_layout  per chunk: the sequence bytes in front of every sub-range, the first match behind it, the block's size.
+//   k_lz4_offsets one scan over the chunks: where every [u32 size][block] goes in the caller's output, the size headers, the
+//                 stream offsets of the clouds (what k_finish does for stage-1 payloads).
+//   k_lz4_emit_lds  per sub-range: the sub-range staged in LDS, its sequences assembled in an LDS image of the output span it
+//                 owns, 16-byte stores STRAIGHT INTO THE FRAMED STREAMS (round 5: no block slots, no second framing pass).
+//                 Every literal byte is copied by the wave of the sub-range it lies in, however long a literal run is.
+//                 k_lz4_emit (CLDN_HIP_LZ4_EMIT_DIRECT=1) is the round-3 kernel without the LDS image: the fallback for a
+//                 span that does not fit the image, and the A/B reference.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -38,15 +43,6 @@ namespace cldn {
 namespace {
 
 constexpr uint32_t kLzHashMul = 2654435761u;
-#ifndef CLDN_LZ_ALIGNBYTE
-#define CLDN_LZ_ALIGNBYTE 1
-#endif
-#ifndef CLDN_LZ_DEFER
-#define CLDN_LZ_DEFER 1
-#endif
-#ifndef CLDN_LZ_GRID_ALL
-#define CLDN_LZ_GRID_ALL 1
-#endif
 
 __device__ __forceinline__ uint32_t lz_wave_excl_scan(uint32_t x, uint32_t lane, uint32_t* total) {
   uint32_t incl = x;
@@ -77,11 +73,7 @@ __device__ __forceinline__ uint32_t lz_put_ext(uint8_t* o, uint32_t x) {
 __device__ __forceinline__ uint32_t lz_lds_u32(const uint32_t* base, uint32_t byte_off) {
   const uint32_t i = byte_off >> 2;
   const uint32_t lo = base[i], hi = base[i + 1u];
-#if CLDN_LZ_ALIGNBYTE
   return __builtin_amdgcn_alignbyte(hi, lo, byte_off);  // (v_alignbyte_b32 uses the two low bits of the shift)
-#else
-  return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> ((byte_off & 3u) * 8u));
-#endif
 }
 
 }  // namespace
@@ -795,11 +787,8 @@ int lz4_launch(const Lz4Launch& L) {
   hipLaunchKernelGGL(k_lz4_plan, dim3(1), dim3(1024), 0, L.stream, L.chunk_payload, L.n_chunks, L.sub_first, sub_bytes);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_plan");
   // one wave per sub-range, at most `max_subs` of them: workgroups beyond the real number find nothing to do
-#if CLDN_LZ_GRID_ALL
+  // (round 5: one workgroup per sub-range -- the dispatcher balances them; 8192 looping workgroups ran 1.68 rounds)
   const uint32_t grid = (uint32_t)std::min<uint64_t>(L.max_subs, 1u << 20);
-#else
-  const uint32_t grid = (uint32_t)std::min<uint64_t>(L.max_subs, 256u * (L.fast ? 32u : 16u));
-#endif
   if (L.fast)
     hipLaunchKernelGGL((k_lz4_match<kLzFastSubBytes, kLzFastHashBits, kLzFastMaxMatches>), dim3(grid), dim3(64), 0, L.stream, L.stage1,
                        L.chunk_dst, L.chunk_payload, L.n_chunks, L.sub_first, L.matches, L.counts, L.last_end, L.sub_chunk);
