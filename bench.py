@@ -297,6 +297,19 @@ def e2e_figures(info, cloud, dev, budget_s: float):
                 want, _y = ref.decode(stream, cloud.size)
                 legd["decodes_through_reference_to_the_same_points"] = bool(np.array_equal(back, want))
             out["host_mirror_LZ4_device"] = legd
+            api.set_device_lz4(2)  # the FAST parameters (CLDN_HIP_STAGE2_LZ4_FAST: 4 KiB windows, blocks ~3 % larger)
+            try:
+                legf = timed(mirror_call)
+                fast_stream = hout[: size_box[0]].copy()
+            finally:
+                api.set_device_lz4(False)
+            legf["bytes"] = int(size_box[0])
+            legf["stage2_threads"] = 0
+            legf["bracket"] = leg["bracket"] + "; CLOUDINI_AMD_DEVICE_LZ4=2: LZ4 blocks written by the GPU, 4 KiB windows"
+            if ref is not None:
+                back, _y = ref.decode(fast_stream, cloud.size)
+                legf["decodes_through_reference_to_the_same_points"] = bool(np.array_equal(back, want))
+            out["host_mirror_LZ4_device_fast"] = legf
     return out
 
 

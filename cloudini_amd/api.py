@@ -137,9 +137,10 @@ def device_lz4() -> bool:
     return bool(lib().cldn_amd_device_lz4())
 
 
-def set_device_lz4(on: bool) -> bool:
-    """LZ4 streams with stage 2 on the GPU (valid LZ4 blocks, not lz4's own bytes). Returns the value in effect."""
-    return bool(lib().cldn_amd_set_device_lz4(1 if on else 0))
+def set_device_lz4(on) -> int:
+    """LZ4 streams with stage 2 on the GPU (valid LZ4 blocks, not lz4's own bytes): False / 0 off, True / 1 on, 2 = the FAST
+    parameters (4 KiB windows). Returns the level in effect."""
+    return int(lib().cldn_amd_set_device_lz4(int(on)))
 
 
 def _device_list(devices):

@@ -144,10 +144,10 @@ CLDN_EXPORT int64_t cldn_amd_decode_directory(const char* in_dir, const char* ou
   return cldn_amd_decode_directory_on(in_dir, out_dir, batch_messages, nullptr, 0, stats_out);
 }
 
-CLDN_EXPORT int cldn_amd_device_lz4(void) { return Cloudini::amd_detail::deviceLz4() ? 1 : 0; }
+CLDN_EXPORT int cldn_amd_device_lz4(void) { return Cloudini::amd_detail::deviceLz4Level(); }
 CLDN_EXPORT int cldn_amd_set_device_lz4(int on) {
-  Cloudini::amd_detail::setDeviceLz4(on != 0);
-  return Cloudini::amd_detail::deviceLz4() ? 1 : 0;
+  Cloudini::amd_detail::setDeviceLz4Level(on);
+  return Cloudini::amd_detail::deviceLz4Level();
 }
 
 CLDN_EXPORT uint32_t cldn_amd_stage2_threads(void) { return Cloudini::amd_detail::stage2Threads(); }

@@ -787,7 +787,8 @@ size_t PointcloudEncoder::encode(ConstBufferView cloud_data, BufferView& output,
       cldn_hip_codec_t* codec;
       ~Reset() { (void)cldn_hip_codec_set_stage2(codec, CLDN_HIP_STAGE2_NONE); }  // the codec goes back to the pool
     } reset{impl_->codec};
-    if (cldn_hip_codec_set_stage2(impl_->codec, CLDN_HIP_STAGE2_LZ4) != CLDN_HIP_OK) throw std::runtime_error(cldn_hip_last_error());
+    const int lz_mode = amd_detail::deviceLz4Level() >= 2 ? CLDN_HIP_STAGE2_LZ4_FAST : CLDN_HIP_STAGE2_LZ4;
+    if (cldn_hip_codec_set_stage2(impl_->codec, lz_mode) != CLDN_HIP_OK) throw std::runtime_error(cldn_hip_last_error());
     uint64_t offsets[2] = {0, 0};
     if (cldn_hip_encode_stage1(impl_->codec, cloud_data.data(), CLDN_HIP_HOST, &points, 1, dst + written, output.size() - written,
                                CLDN_HIP_HOST, offsets, impl_->chunk_sizes.data(), nullptr) != CLDN_HIP_OK)
@@ -998,16 +999,21 @@ namespace amd_detail {
 namespace {
 std::atomic<int> g_device_lz4{-1};  // -1: not decided yet (environment)
 }
-bool deviceLz4() {
+// 0 = the host pool (liblz4's own bytes), 1 = CLDN_HIP_STAGE2_LZ4, 2 = CLDN_HIP_STAGE2_LZ4_FAST (4 KiB windows: about 1.7 x the
+// speed, blocks about 3 % larger)
+int deviceLz4Level() {
   int v = g_device_lz4.load();
   if (v < 0) {
     const char* e = std::getenv("CLOUDINI_AMD_DEVICE_LZ4");
-    v = (e && std::atoi(e) != 0) ? 1 : 0;
+    const int x = e ? std::atoi(e) : 0;
+    v = x >= 2 ? 2 : (x == 1 ? 1 : 0);
     g_device_lz4.store(v);
   }
-  return v != 0;
+  return v;
 }
+bool deviceLz4() { return deviceLz4Level() != 0; }
 void setDeviceLz4(bool on) { g_device_lz4.store(on ? 1 : 0); }
+void setDeviceLz4Level(int level) { g_device_lz4.store(level >= 2 ? 2 : (level == 1 ? 1 : 0)); }
 
 void encodeStage1Batch(const EncodingInfo& info, const uint8_t* const* cloud_ptrs, const uint64_t* cloud_points,
                        uint32_t n_clouds, const std::function<uint8_t*(uint64_t)>& grow, std::vector<uint64_t>& stream_offsets,

@@ -38,6 +38,8 @@ void walkCompressedChunks(Cloudini::ConstBufferView data, uint64_t points, std::
 // LZ4 streams with stage 2 on the device (cldn_hip_codec_set_stage2): off unless CLOUDINI_AMD_DEVICE_LZ4=1 or the setter
 bool deviceLz4();
 void setDeviceLz4(bool on);
+int deviceLz4Level();            // 0 host pool, 1 CLDN_HIP_STAGE2_LZ4, 2 CLDN_HIP_STAGE2_LZ4_FAST
+void setDeviceLz4Level(int level);
 
 uint32_t decompressChunkTo(Cloudini::CompressionOption opt, const uint8_t* src, size_t size, uint8_t* dst, size_t dst_cap);
 // worst-case stage-1 bytes of one 32768-point chunk of this schema (without its [u32 size])
