@@ -6,7 +6,9 @@
 //   cloudini_batch_transcode <in_dir> <out_dir> --decode [--batch 64]      (CompressedPointCloud2 -> PointCloud2)
 //   ... --devices 0,1,2,3   spreads the batches over these GPUs (one GPU stage per entry; "0,0" = two stages on GPU 0)
 //   cloudini_batch_transcode <in.mcap> <out.mcap> [...same options] [--mcap-compression none|lz4|zstd]
-//       a bag: point-cloud messages converted, everything else copied (McapConverter, tools/src/mcap_converter.cpp:141-300)
+//       a bag: point-cloud messages converted, everything else copied (McapConverter, tools/src/mcap_converter.cpp:141-300);
+//       read as a stream, a chunk at a time. CLDN_DEBUG_MEM=1 prints the process's memory high-water marks to stderr
+//       (VmHWM of /proc/self/status; tests/test_mcap_io.py checks that they do not follow the size of the bag).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
