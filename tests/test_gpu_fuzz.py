@@ -74,7 +74,11 @@ def _random_case(seed, wide=False):
 
 import os
 
-_SEEDS = list(range(1000, 1100 + int(os.environ.get("CLDN_FUZZ_EXTRA", "0"))))  # 1082 once caught an uncovered-field bug
+# CLDN_FUZZ_EXTRA extra seeds per test (tools/runs/r5_fuzz.sh: 30000); CLDN_FUZZ_BASE: where the extra seeds begin (default:
+# right behind the fixed ones -- another value runs a campaign over other schemas)
+_EXTRA = int(os.environ.get("CLDN_FUZZ_EXTRA", "0"))
+_BASE = int(os.environ.get("CLDN_FUZZ_BASE", "0"))
+_SEEDS = list(range(1000, 1100)) + list(range(_BASE or 1100, (_BASE or 1100) + _EXTRA))  # 1082 once caught an uncovered-field bug
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
@@ -156,7 +160,7 @@ def test_very_wide_schema_through_the_host_mirror(reflib, seed):
     assert np.array_equal(got_dec[: n * info.point_step], want_dec[: n * info.point_step]), seed
 
 
-_CORRUPT_SEEDS = list(range(3000, 3080 + int(os.environ.get("CLDN_FUZZ_EXTRA", "0"))))
+_CORRUPT_SEEDS = list(range(3000, 3080)) + list(range(_BASE + 2000 if _BASE else 3080, (_BASE + 2000 if _BASE else 3080) + _EXTRA))
 
 
 @pytest.mark.parametrize("seed", _CORRUPT_SEEDS)
@@ -229,7 +233,7 @@ def test_host_mirror_full_streams_match_the_reference(reflib, seed):
 # ---- device LZ4 on the random schemas: every chunk's block equals the serial model's (oracle/lz4_model.c), both modes ----
 
 _LZ4_PARAMS = {1: (8192, 11, 1024), 2: (4096, 10, 512)}  # CLDN_HIP_STAGE2_LZ4, CLDN_HIP_STAGE2_LZ4_FAST (stage1_launch.h)
-_LZ4_SEEDS = list(range(1000, 1040 + int(os.environ.get("CLDN_FUZZ_EXTRA", "0")) // 20))
+_LZ4_SEEDS = list(range(1000, 1040)) + list(range(_BASE or 1040, (_BASE or 1040) + _EXTRA // 20))
 
 
 @pytest.mark.parametrize("seed", _LZ4_SEEDS)
