@@ -633,6 +633,12 @@ __device__ __forceinline__ uint32_t dv_tokens_tile(const uint8_t* __restrict__ s
         continue;
       }
     }
+    if (x == 0ull && lencont != 0u) {
+      // an overlong zero (0x80 0x00, ...): decodeVarint (encoding_utils.hpp:139-141) rejects every zero it is handed -- only the
+      // single byte 0x00 in front of it is the NaN marker (src/field_decoder.cpp:58-62). The serial decoder raises the error.
+      misc[0] = 1u;
+      continue;
+    }
     store(kl, x, pos + tid * 8u + j + 1u);
   }
   __syncthreads();
@@ -1216,6 +1222,9 @@ __device__ __forceinline__ void dv_stream2(OpAt op_at, uint32_t n_ops, const uin
                 marks &= ~(1u << j);
               }
             }
+            // an overlong zero (a varint token of two or more bytes whose value bits are all 0) is no NaN marker: decodeVarint
+            // rejects it (encoding_utils.hpp:139-141; the marker is the single byte 0x00, src/field_decoder.cpp:58-62)
+            if (((marks >> j) & 1u) && lencont != 0u) misc[0] = 1u;
             if (g + 1u == target) misc[1] = pos + tid * BPT + (uint32_t)j + 1u;
           }
           ++g;

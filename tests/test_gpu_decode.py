@@ -145,6 +145,36 @@ def test_overlong_tokens_decode_like_the_reference(oracle, pad_to):
     codec.close()
 
 
+@pytest.mark.parametrize("length", [2, 3, 5])
+@pytest.mark.parametrize("gen", ["xyz", "xyzi", "velodyne"])
+def test_overlong_zero_in_a_float_lane_is_rejected(oracle, gen, length):
+    """A varint token of two or more bytes whose value bits are all 0 (0x80 0x00, ...) is not the NaN marker -- that is the
+    single byte 0x00 in front of decodeVarint (src/field_decoder.cpp:58-62) -- and decodeVarint rejects every zero it is
+    handed (encoding_utils.hpp:139-141). The wave kernel hands such a chunk back; the tile kernels behind it used to take
+    the zero for a marker and accept the stream (found by the fuzz campaign's second seed range, round 5)."""
+    from cloudini_amd import native
+    info, data = {"xyz": synth.lidar_xyz, "xyzi": synth.lidar_xyzi, "velodyne": synth.velodyne_xyzir}[gen](40000, seed=9)
+    n = 40000
+    chunks = _split_chunks(oracle.encode_stage1(info, data))
+    for ci in (0, len(chunks) - 1):                      # a full chunk, the ragged last one
+        ch = chunks[ci]
+        n_reg = (32768 if ci == 0 else n - 32768) * (3 if gen == "xyz" else 4)   # tokens of the regular stream (V5: sections follow)
+        ends = np.nonzero((ch & 0x80) == 0)[0][:n_reg]
+        starts = np.concatenate([[0], ends[:-1] + 1])
+        cand = np.nonzero((ends - starts + 1 == 1) & (ch[starts] != 0))[0]
+        k = int(cand[len(cand) // 2])                    # a one-byte token in the middle of the stream
+        bad = [c.copy() for c in chunks]
+        bad[ci] = np.concatenate([ch[:starts[k]], np.array([0x80] * (length - 1) + [0x00], dtype=np.uint8), ch[ends[k] + 1:]])
+        s = _reframe(bad)
+        with pytest.raises(Exception):
+            oracle.decode_stage1(info, s, n, fill=0x11)
+        codec = native.Codec(native.Plan(info))
+        with pytest.raises(native.CloudiniHipError) as e:
+            codec.decode_host([s], [n], out=np.full(n * info.point_step, 0x11, dtype=np.uint8))
+        assert e.value.code == -6
+        codec.close()
+
+
 def test_marker_inside_integer_token_stream_is_rejected(oracle):
     """V4 wire with an integer field: a 0x00 byte where an integer varint is expected is corrupt data
     (decodeVarint rejects value 0); the parallel path must hand the chunk to the serial checks."""
