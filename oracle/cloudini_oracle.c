@@ -912,6 +912,11 @@ static int op_decode(op_t* op, rd_t* r, uint8_t* point) {
             if ((e = rd_bits(r, &lo, &hi, &have, meaningful)) < 0) return e;
             const uint64_t bits = take_bits(&lo, &hi, &have, meaningful);
             const int trailing = 64 - stored - meaningful;
+            /* HARDENING beyond the reference: leading + meaningful > 64 makes field_decoder.hpp:283-285 shift a 64-bit word by
+             * uint8_t(64 - leading - meaningful) = 192..255 bits -- undefined behaviour (x86 takes the count modulo 64 and
+             * goes on with a window of "248 trailing bits"). No encoder writes such a token; every decoder of this
+             * repository rejects it. (One of 998 011 damaged streams of tools/dev/oracle_vs_ref_campaign.py: the only
+             * disagreement between this file and the compiled reference.) */
             if (trailing < 0) return ORC_ERR_CORRUPT;
             x = trailing >= 64 ? 0 : (bits << trailing);
             op->prev_leading = stored;
