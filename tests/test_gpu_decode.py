@@ -175,6 +175,59 @@ def test_overlong_zero_in_a_float_lane_is_rejected(oracle, gen, length):
         codec.close()
 
 
+@pytest.mark.parametrize("layout", ["scalar_lossy", "varint_and_raw"])
+def test_overlong_zero_in_scalar_and_mixed_layouts_is_rejected(oracle, layout):
+    """The same rule on the other decode routes: scalar lossy floats and 64-bit integers (the stream kernel in MSB mode, behind
+    it the 64-bit tile kernel), and a varint next to a raw field (byte automaton + bitmap mode, behind it the tile kernel
+    with the end bitmap)."""
+    from cloudini_amd import native
+    from cloudini_amd.schema import FieldType as F
+    n = 9000
+    rs = np.random.RandomState(4)
+    if layout == "scalar_lossy":
+        fields = [("t", 0, F.FLOAT64, 1e-6), ("a", 8, F.FLOAT32, 0.01), ("k", 12, F.INT64, None)]
+        step = 20
+        cols = {"t": np.cumsum(rs.uniform(0, 1e-3, n)) + 1.7e9, "a": np.cumsum(rs.normal(0, 0.05, n)).astype(np.float32),
+                "k": np.cumsum(rs.randint(-50, 50, n)).astype(np.int64)}
+        n_ops, victim = 3, 1
+    else:
+        fields = [("x", 0, F.FLOAT32, 0.001), ("rgb", 4, F.FLOAT32, None)]
+        step = 8
+        cols = {"x": np.cumsum(rs.normal(0, 0.01, n)).astype(np.float32), "rgb": rs.randint(0, 1 << 24, n).astype(np.uint32).view(np.float32)}
+        n_ops, victim = 2, 0
+    info = cases.make_info(fields, step, n, version=4)
+    data = cases.pack(info, cols, n)
+    s0 = oracle.encode_stage1(info, data)
+    assert np.array_equal(oracle.decode_stage1(info, s0, n, fill=0x11), oracle.decode_stage1(info, s0, n, fill=0x11))
+    ch = _split_chunks(s0)[0]
+    # walk the points: token k of a point is a varint unless it is the raw field of the second layout (4 bytes)
+    pos, hit = 0, None
+    for pt in range(n):
+        for op in range(n_ops):
+            if layout == "varint_and_raw" and op == 1:
+                pos += 4
+                continue
+            start = pos
+            while ch[pos] & 0x80:
+                pos += 1
+            pos += 1
+            if hit is None and pt > n // 2 and op == victim and pos - start == 1 and ch[start] != 0:
+                hit = start
+        if hit is not None:
+            break
+    assert hit is not None
+    for length in (2, 4):
+        bad = np.concatenate([ch[:hit], np.array([0x80] * (length - 1) + [0x00], dtype=np.uint8), ch[hit + 1:]])
+        s = _reframe([bad])
+        with pytest.raises(Exception):
+            oracle.decode_stage1(info, s, n, fill=0x11)
+        codec = native.Codec(native.Plan(info))
+        with pytest.raises(native.CloudiniHipError) as e:
+            codec.decode_host([s], [n], out=np.full(n * step, 0x11, dtype=np.uint8))
+        assert e.value.code == -6
+        codec.close()
+
+
 def test_marker_inside_integer_token_stream_is_rejected(oracle):
     """V4 wire with an integer field: a 0x00 byte where an integer varint is expected is corrupt data
     (decodeVarint rejects value 0); the parallel path must hand the chunk to the serial checks."""
