@@ -1599,7 +1599,7 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
   if (!c->plan.wide && wp_split_parts(n_chunks) > 1u) {
     uint64_t chunk_bound = (uint64_t)kPointsPerChunk * c->plan.ref_max_point_bytes;
     if (c->plan.uses_v5) chunk_bound += (uint64_t)c->plan.fields.size() * 32u + 1024u;
-    const uint64_t maxp = chunk_bound / 1024u + 3u;
+    const uint64_t maxp = chunk_bound / 992u + 3u;  // (kWpPiece, stage1_decode_wave.h: pieces of 62 units)
     if (maxp <= 4096u) {
       if ((rc = c->d_dec_split.ensure(wp_split_bytes(n_chunks, (uint32_t)maxp))) != CLDN_HIP_OK) return rc;
       L.wp_split = c->d_dec_split.p;

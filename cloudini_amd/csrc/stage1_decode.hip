@@ -151,7 +151,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       // round 4: the barrier-free kernel (stage1_decode_wave.h) is the default; CLDN_HIP_POINT_KERNEL=tiles brings the
       // tile kernel back (A/B in the same binary), =w8 runs it with 8 waves per workgroup instead of 16
       static const char* pk_env = getenv("CLDN_HIP_POINT_KERNEL");
-      static const int pk = pk_env == nullptr ? 16 : (strcmp(pk_env, "tiles") == 0 ? 0 : (strcmp(pk_env, "w8") == 0 ? 8 : (strcmp(pk_env, "w8o6") == 0 ? 86 : (strcmp(pk_env, "w12o6") == 0 ? 126 : 16))));
+      static const int pk = pk_env == nullptr ? 16 : (strcmp(pk_env, "tiles") == 0 ? 0 : 16);
       uint32_t nf = (L.uses_v5 && P.n_adaptive <= kFastPalFields) ? P.n_adaptive : 0u;
       // round 4: 3..8 integer channels (all of 2 or 4 bytes): their sections go to dense columns side by side in front of the
       // point kernel (stage1_decode_sections_w.h), which merges them -- every point is written once
@@ -258,9 +258,6 @@ int stage1_launch_decode(const DecodeLaunch& L) {
 #define LAUNCH_POINTS_ANY(NOPS_, NF_)                      \
   {                                                        \
     if (pk == 0) LAUNCH_POINTS(NOPS_, NF_);                \
-    else if (pk == 8) LAUNCH_POINTS_W(NOPS_, NF_, 8, 8);   \
-    else if (pk == 86) LAUNCH_POINTS_W(NOPS_, NF_, 8, 6);  \
-    else if (pk == 126) LAUNCH_POINTS_W(NOPS_, NF_, 12, 6); \
     else LAUNCH_POINTS_W(NOPS_, NF_, 16, 8);               \
   }
       // store-mode instantiations of the two headline layouts (XYZ, XYZ + one 16-bit field): the layout facts the kernel

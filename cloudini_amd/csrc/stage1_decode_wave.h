@@ -1,56 +1,56 @@
-// stage1_decode_wave.h -- k_decode_points_w: the barrier-free point decoder (round 4). Same job and same interface as
-// k_decode_points (stage1_decode_fast.h): chunks whose regular stream is one fused FloatN encoder (3 or 4 int32-delta
-// varint tokens per point; FieldDecoderFloatN_Lossy::decode, src/field_decoder.cpp:43-86; decodeVarint,
-// include/cloudini_lib/encoding_utils.hpp:98-148), Palette sections folded in / integer fields taken from columns.
+// stage1_decode_wave.h -- k_decode_points_w: the barrier-free point decoder (round 4; token path rebuilt in round 6). Chunks whose
+// regular stream is one fused FloatN encoder (3 or 4 int32-delta varint tokens per point; FieldDecoderFloatN_Lossy::decode,
+// src/field_decoder.cpp:43-86; decodeVarint, include/cloudini_lib/encoding_utils.hpp:98-148), Palette sections folded in /
+// integer fields taken from columns.
 //
-// k_decode_points walks a chunk in tiles of 8 KiB with five workgroup barriers per tile. Here a chunk's payload is cut
-// into PIECES of 1 KiB at fixed (16-byte aligned) addresses and ONE WAVE decodes a piece from its first byte to its
-// last store without meeting a barrier; the waves of the workgroup take the pieces round robin. What a piece needs
-// from the pieces in front of it are two small things, handed from wave to wave through tagged LDS records:
-//   chain 1  T0 = how many token ends lie in front of the piece (known as soon as a piece's bytes are loaded: one
-//            v_dot4 per dword turns the MSBs into an end mask, popcount, one DPP scan). It tells which of the piece's
-//            ends close a point (end number e closes a point iff (e + 1) % NOPS == 0) and which points those are. A
-//            piece OWNS the points that begin behind such an end (and piece 0 owns point 0); their bytes may reach
-//            into the next piece (32 bytes of halo).
+// A chunk's payload is cut into PIECES of 62 aligned 16-byte units (992 bytes) at fixed addresses and ONE WAVE decodes a piece
+// from its first byte to its last store without meeting a barrier; the waves of the workgroup take the pieces round robin. Lanes
+// 1..62 hold the piece's units, lane 0 the unit in FRONT of it (a token that ends in lane 1 may begin there; lane l takes what
+// it needs of lane l - 1 by DPP), lane 63 the first unit of the NEXT piece (the halo: the last point a piece owns may end there).
+//   phase V  (round 6) BYTE-PARALLEL token values. A token is owned by the unit its LAST byte lies in. Per lane: the four dwords'
+//            7-bit groups are packed once (28 bits per dword); for each of the 16 byte positions the 4 groups that end there are
+//            one v_alignbit of two packed dwords, the token's length comes from the 3 end flags below the position through a
+//            v_perm table look-up, one shift leaves the token's value u = zigzag + 1. The value goes to LDS slot
+//            (ends in front of the lane) + (ends below the position): the piece's tokens lie in stream order, one dword each,
+//            and positions that end no token write to a per-lane dummy word (v_bfi on the address: no exec changes). Nothing is
+//            parsed serially, no point-start list, no per-token find-first-set / funnel shift chain as in rounds 4-5.
+//   chain 1  T0 = how many token ends lie in front of the piece (popcount + one DPP scan; known before phase V ends). A piece OWNS
+//            the points whose FIRST token ends in it: point j of the piece has its tokens in slots k0 + NOPS * j + o, with
+//            k0 = (-T0) mod NOPS; the last of them may be halo tokens (at most NOPS - 1, within 4 * (NOPS - 1) bytes).
+//   phase B  one point per lane: NOPS slot reads -> zigzag -> DPP prefix sums (a DPP segmented scan when a row holds a NaN
+//            marker, u == 0) -> values relative to the piece's start.
 //   chain 2  the running values in front of the piece's first point (int32 per lane of the FloatN encoder, NaN markers
-//            reset a lane). A piece needs them only for its last step: it decodes all its tokens and scans the deltas
-//            (DPP prefix sums; a DPP segmented scan when a row holds a marker) relative to its own start, publishes
-//            its aggregate, and adds the carry right before the conversion to float and the stores.
-// Every record is one aligned 8-byte LDS word {tag = piece + 1, value}: no ordering between LDS operations is assumed.
+//            reset a lane). A piece publishes its aggregate and adds the carry right before the conversion to float and
+//            the stores. A lane stores its own point, so a store instruction covers 64 consecutive points.
+// Every chain record is one aligned 8-byte LDS word {tag = piece + 1, value}: no ordering between LDS operations is assumed.
 // A wave waits only for the piece in front of its own, which belongs to the neighbouring wave at the same step of its
 // loop -- all waves of a workgroup are resident, so the waits cannot deadlock; they are bounded all the same.
-// Inside a piece the work is row-shaped like in the piece kernel of the encoder: phase A writes where every owned point
-// starts into a wave-private list (which ends close points: a 256-entry lookup table per phase), phase B takes 64
-// consecutive points per row, ONE POINT PER LANE: 4-5 LDS dwords -> NOPS tokens in registers -> scan -> values. A lane
-// stores its own point, so a store instruction covers 64 consecutive points and nothing is staged or transposed.
-// Irregular chunks (a token longer than 4 bytes, an overlong zero, a short stream) are handed back exactly like
-// k_decode_points does (reg_end = kDecRedo -> k_decode_varint / the serial decoder raise the errors).
+// Irregular chunks are handed back (reg_end = kDecRedo -> k_decode_varint / the serial decoder decode them or raise the errors):
+// a token longer than 4 bytes, a 0x00 byte that ends a token of more than one byte (an overlong zero -- decodeVarint rejects
+// it -- or another non-canonical form the encoder never writes), a short stream. Both are seen on the units' end / zero masks.
 #pragma once
 
 namespace cldn {
 
-constexpr uint32_t kWpPiece = 1024u;       // bytes of stream per piece: one aligned 16-byte unit per lane
-constexpr uint32_t kWpHalo = 32u;          // a point that starts at the piece's last byte has at most 4 * 4 + 3 bytes more
-constexpr uint32_t kWpRing = 64u;          // chain records (slot = piece % kWpRing, tagged)
+constexpr uint32_t kWpUnits = 62u;                // owned 16-byte units per piece: lanes 1..62 (lane 0: the unit in front, lane 63: the halo)
+constexpr uint32_t kWpPiece = kWpUnits * 16u;     // bytes of stream per piece
+constexpr uint32_t kWpSlots = 1024u;              // token slots per wave: <= 992 owned tokens + <= 16 of the halo unit
+constexpr uint32_t kWpRing = 64u;                 // chain records (slot = piece % kWpRing, tagged)
 constexpr uint32_t kWpSpinLimit = 1u << 18;
-#ifndef CLDN_WP_SLEEP
-#define CLDN_WP_SLEEP 4
-#endif
-constexpr int kWpSleep = CLDN_WP_SLEEP;   // x 64 cycles between two polls of a record
+constexpr int kWpSleep = 4;                       // x 64 cycles between two polls of a record
 
 template <int NOPS>
 struct WpGeom {
-  static constexpr uint32_t kMaxPts = kWpPiece / NOPS + 2u;             // points a piece can own
-  static constexpr uint32_t kRows = (kMaxPts + 63u) / 64u;               // 6 (3 lanes), 5 (4 lanes)
-  static constexpr uint32_t kListBytes = (kMaxPts * 2u + 15u) & ~15u;
-  static constexpr uint32_t kWaveBytes = kWpPiece + kWpHalo + kListBytes;  // bytes, halo, list of point starts
+  static constexpr uint32_t kMaxPts = (kWpPiece + (uint32_t)NOPS - 1u) / (uint32_t)NOPS;  // points a piece can own
+  static constexpr uint32_t kRows = (kMaxPts + 63u) / 64u;                                  // 6 (3 lanes), 4 (4 lanes)
 };
 
 template <int NOPS, int NF, int NW>
 struct WpLds {
-  static constexpr uint32_t kLutOff = (uint32_t)NW * WpGeom<NOPS>::kWaveBytes;   // u16 [NOPS][256]
-  static constexpr uint32_t kTrecOff = kLutOff + (uint32_t)NOPS * 512u;          // u64 [kWpRing]
-  static constexpr uint32_t kVrecOff = kTrecOff + kWpRing * 8u;                  // u64 [kWpRing][NOPS]
+  static constexpr uint32_t kValsOff = 0u;                                       // u32 [NW][kWpSlots]
+  static constexpr uint32_t kDummyOff = (uint32_t)NW * kWpSlots * 4u;            // u32 [64]: where positions that end no token write
+  static constexpr uint32_t kTrecOff = kDummyOff + 256u;                         // u64 [kWpRing]
+  static constexpr uint32_t kVrecOff = kTrecOff + kWpRing * 8u;                  // u64 [kWpRing][NOPS]: running values behind a piece
   static constexpr uint32_t kPalOff = kVrecOff + kWpRing * (uint32_t)NOPS * 8u;
   static constexpr uint32_t kMiscOff = kPalOff + (uint32_t)(NF > 2 ? 0 : NF) * kFastPalEntries * 4u;  // (NF > 2: columns only, nothing is folded)
   static constexpr uint32_t kTotal = kMiscOff + 512u;
@@ -63,6 +63,30 @@ __device__ __forceinline__ uint32_t wp_ends16(const uint32_t (&b)[4]) {
   uint32_t hi = __builtin_amdgcn_udot4(b[2] & 0x80808080u, 0x08040201u, 0u, false);
   hi = __builtin_amdgcn_udot4(b[3] & 0x80808080u, 0x80402010u, hi, false);
   return ~((lo >> 7) | (hi << 1)) & 0xffffu;  // (the sums are 128 x the masks of the bytes that CONTINUE)
+}
+
+// bit j = byte j of the 16 is NOT 0x00 (same gather; (x & 0x7f) + 0x7f carries into the MSB of a byte with value bits)
+__device__ __forceinline__ uint32_t wp_nonzero16(const uint32_t (&b)[4]) {
+  uint32_t nz[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) nz[k] = (((b[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | b[k]) & 0x80808080u;
+  uint32_t lo = __builtin_amdgcn_udot4(nz[0], 0x08040201u, 0u, false);
+  lo = __builtin_amdgcn_udot4(nz[1], 0x80402010u, lo, false);
+  uint32_t hi = __builtin_amdgcn_udot4(nz[2], 0x08040201u, 0u, false);
+  hi = __builtin_amdgcn_udot4(nz[3], 0x80402010u, hi, false);
+  return ((lo >> 7) | (hi << 1)) & 0xffffu;
+}
+
+// the four 7-bit groups of a dword side by side: byte 0's group in bits 0..6, byte 3's in bits 21..27
+__device__ __forceinline__ uint32_t wp_pack7(uint32_t w) {
+  const uint32_t lo = w & 0x7f7f7f7fu;
+  const uint32_t x1 = lo - ((lo & 0x7f007f00u) >> 1);  // 7-bit groups -> 14-bit groups
+  return x1 - __umul24(x1 >> 16, 49152u);              // -> 28 bits
+}
+
+// value of lane l - 1 (wave_shr:1; lane 0 reads 0)
+__device__ __forceinline__ uint32_t wp_from_lane_below(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true);
 }
 
 // compiler-level ordering of a wave's own LDS traffic (the hardware keeps a wave's LDS operations in order)
@@ -101,38 +125,29 @@ __device__ __forceinline__ void wp_seg_scan(int32_t (&inc)[NOPS], uint32_t& fin)
 #undef WP_SEG_STEP
 }
 
-// The NOPS tokens of the point that starts at byte `byte0` of the wave's LDS copy -> deltas (0x80000000 = the NaN marker:
-// no token of at most 4 bytes decodes to it). Returns true when a token is irregular (no end within 4 bytes -- the chunk
-// goes to the 64-bit kernel -- or an overlong zero, which decodeVarint rejects); *zero: a token's value bits were all 0.
-template <int NOPS>
-__device__ __forceinline__ bool wp_tokens(const uint32_t* wbuf, uint32_t byte0, int32_t (&dlt)[NOPS], bool* zero) {
-  const uint32_t di = byte0 >> 2, sh = (byte0 & 3u) * 8u;
-  uint32_t d[NOPS + 1];
-#pragma unroll
-  for (int k = 0; k <= NOPS; ++k) d[k] = wbuf[di + (uint32_t)k];
-  uint32_t W[NOPS];  // W[k] = bytes [4k, 4k + 4) behind the current token's start
-#pragma unroll
-  for (int k = 0; k < NOPS; ++k) W[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
-  bool bad = false, z = false;
-#pragma unroll
-  for (int o = 0; o < NOPS; ++o) {
-    const uint32_t w = W[0];
-    const uint32_t t = ~w & 0x80808080u;                        // the bytes that can end the token
-    const uint32_t lo = w & ((t ^ (t - 1u)) & 0x7f7f7f7fu);     // value bits of the bytes up to the first of them
-    const uint32_t x1 = lo - ((lo & 0x7f007f00u) >> 1);         // 7-bit groups -> 14-bit groups
-    const uint32_t u = x1 - __umul24(x1 >> 16, 49152u);         // -> one value (< 2^28)
-    bad = bad || t == 0u || (lo == 0u && (w & 0x80u) != 0u);
-    z = z || lo == 0u;
-    const uint32_t u1 = u - 1u;
-    dlt[o] = (int32_t)((u1 >> 1) ^ (0u - (u1 & 1u)));           // u == 0 -> 0x80000000
-    if (o + 1 < NOPS) {
-      const uint32_t adv = (uint32_t)__ffs((int)t);             // bits of this token: 8, 16, 24, 32
-#pragma unroll
-      for (int k = 0; k + 1 < NOPS - o; ++k) W[k] = (uint32_t)(((((uint64_t)W[k + 1]) << 32) | W[k]) >> adv);
-    }
-  }
-  *zero = z;
-  return bad;
+// phase V, byte position I of the lane's unit: the value of the token that ends there (if one does) -> its slot.
+//   pk_lo / pk_hi  the packed groups of dword I / 4 - 1 and I / 4 as one 56-bit number (low / high dword)
+//   e20            end flags: bit 4 + j = byte j of the unit, bits 0..3 = the four bytes in front of it
+//   addr           LDS byte address of the slot of the lane's next token; advanced when position I ends one
+//   dummy          LDS byte address of the lane's dummy word
+// The 4 groups that end with byte I are bits 7j + 7 .. 7j + 34 of the 56-bit number (j = I % 4): one v_alignbit leaves them in
+// bits 4..31. The token has 1 + (continuation bytes right below I, at most 3) bytes: a v_perm look-up turns the three end flags
+// below I into the shift that drops the groups of other tokens (32 - 7 * length; length 4 also when the token is longer --
+// such chunks are handed back).
+//   ev             the ends of the unit that are tokens of the payload (bit j = byte j)
+template <int I>
+__device__ __forceinline__ void wp_value_at(const uint32_t (&pk_lo)[4], const uint32_t (&pk_hi)[4], uint32_t e20, uint32_t ev,
+                                            uint32_t& addr, uint32_t dummy) {
+  constexpr int K = I / 4, J = I % 4;
+  const uint32_t x = __builtin_amdgcn_alignbit(pk_hi[K], pk_lo[K], 7 * J + 3);
+  const uint32_t below = __builtin_amdgcn_ubfe(e20, I + 1, 3);  // bit 2: byte I - 1 ends a token, bit 1: I - 2, bit 0: I - 3
+  const uint32_t sh = __builtin_amdgcn_perm(0x19191919u, 0x12120b04u, below);  // {4, 11, 18, 18, 25, 25, 25, 25}[below]
+  const uint32_t u = x >> (sh & 31u);
+  const uint32_t is_end = (uint32_t)__builtin_amdgcn_sbfe((int)ev, I, 1);  // all ones: byte I ends a token
+  uint32_t where;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(where) : "v"(is_end), "v"(addr), "v"(dummy));  // is_end ? addr : dummy
+  *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(where) = u;
+  asm("v_mad_i32_i24 %0, %1, -4, %0" : "+v"(addr) : "v"(is_end));  // + 4 behind an end
 }
 
 // SPLIT launches (round 5, small batches: fewer chunks than the chip has room for): the pieces of a chunk are spread over
@@ -153,15 +168,7 @@ struct WpSplit {
 };
 
 template <int NOPS, int NF, int NW, int WPE = 8, int SM = 0, int PASS = 0>
-#ifndef CLDN_WP_SGPR
-#define CLDN_WP_SGPR 0
-#endif
-#if CLDN_WP_SGPR
-#define CLDN_WP_SGPR_ATTR __attribute__((amdgpu_num_sgpr(CLDN_WP_SGPR)))
-#else
-#define CLDN_WP_SGPR_ATTR
-#endif
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) CLDN_WP_SGPR_ATTR void k_decode_points_w(
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_decode_points_w(
     const DevPlan plan, const uint8_t* __restrict__ streams, const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
     uint32_t* __restrict__ reg_end, uint8_t* __restrict__ sec_done, uint32_t uses_v5, uint32_t* __restrict__ status,
     const uint8_t* __restrict__ col0, const uint8_t* __restrict__ col1, const uint32_t* __restrict__ reg_end_pre,
@@ -175,7 +182,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
   constexpr uint32_t NFA = MANY ? 1 : (NF ? NF : 1);  // array extents (NF == 0: nothing is ever folded)
   constexpr uint32_t ROWS = G::kRows;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint16_t* lut = reinterpret_cast<uint16_t*>(smem + L::kLutOff);
   unsigned long long* trec = reinterpret_cast<unsigned long long*>(smem + L::kTrecOff);
   unsigned long long* vrec = reinterpret_cast<unsigned long long*>(smem + L::kVrecOff);
   uint32_t* pal = reinterpret_cast<uint32_t*>(smem + L::kPalOff);
@@ -186,6 +192,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CLDN_WP_PROF
+  const unsigned long long wp_t0 = __builtin_readcyclecounter();
+#endif
   const DecChunk dc = chunks[c];
   if (!dc.valid) {
     if (tid == 0) sec_done[c] = 0u;
@@ -208,21 +217,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     misc[64] = 0u;           // fp_setup: sections folded in
   }
   for (uint32_t i = tid; i < kWpRing * (1u + NOPS) * 2u; i += T) reinterpret_cast<uint32_t*>(trec)[i] = 0u;  // tags: none
-  // which ends of a byte's end mask close points when the first k0 of them do not: entry = mask | (next k0) << 8
-  for (uint32_t e = tid; e < (uint32_t)NOPS * 256u; e += T) {
-    uint32_t k = e >> 8, sel = 0u;
-    for (uint32_t bit = 0; bit < 8u; ++bit) {
-      if ((e >> bit) & 1u) {
-        if (k == 0u) {
-          sel |= 1u << bit;
-          k = (uint32_t)NOPS - 1u;
-        } else {
-          --k;
-        }
-      }
-    }
-    lut[e] = (uint16_t)(sel | (k << 8));
-  }
   __syncthreads();
 
   bool from_cols = false;
@@ -273,17 +267,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
                       fs_off[0] == 16u && ((uintptr_t)base & 15u) == 0u;
 
   // ---------------------------------------------------------------------------------------------------------
-  // pieces. v = payload offset + a0 (a0 = misalignment of the payload): piece p holds v in [p, p + 1) * 1024
+  // pieces. v = payload offset + a0 (a0 = misalignment of the payload): piece p owns v in [p, p + 1) * 1008
   // ---------------------------------------------------------------------------------------------------------
   const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
   const uint8_t* src_al = src - a0;
   const uint32_t vend = a0 + src_size;
   const uint32_t n_pieces = src_size ? (vend + kWpPiece - 1u) / kWpPiece : 0u;
-  uint32_t* wbuf = reinterpret_cast<uint32_t*>(smem + wave * G::kWaveBytes);
-  uint16_t* plist = reinterpret_cast<uint16_t*>(smem + wave * G::kWaveBytes + kWpPiece + kWpHalo);
+  const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+  const uint32_t vals_lds = smem_lds + L::kValsOff + wave * (kWpSlots * 4u);  // LDS byte address of the wave's token slots
+  const uint32_t* vals = reinterpret_cast<const uint32_t*>(smem + L::kValsOff + wave * (kWpSlots * 4u));
+  const uint32_t dummy_lds = smem_lds + L::kDummyOff + lane * 4u;
 
   // an aligned unit that holds at least one payload byte lies in a mapped page; anything else is not touched (0xff:
-  // bytes that continue a token and end none)
+  // bytes that continue a token and end none). Lane l holds unit 62 p + l - 1 (piece 0, lane 0: v0 wraps -- not touched)
   auto load_unit = [&](uint32_t v0, uint32_t(&u)[4]) __attribute__((always_inline)) {
     const bool ok = v0 < vend;
     const uint4 w = *reinterpret_cast<const uint4*>(src_al + (ok ? v0 : 0u));
@@ -293,7 +289,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     u[3] = ok ? w.w : 0xffffffffu;
   };
 
-  uint32_t b[4], bh[4];  // my unit of the piece; the halo's two units (every lane asks for unit lane & 1: no branch)
+  uint32_t b[4];   // my unit
   constexpr bool SPLIT = PASS != 0;
   const uint32_t p_step = SPLIT ? gridDim.y * (uint32_t)NW : (uint32_t)NW;
   uint32_t p = SPLIT ? blockIdx.y * (uint32_t)NW + wave : wave;
@@ -305,33 +301,83 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     return;
   }
   const size_t sp_base = SPLIT ? (size_t)c * sp.maxp : 0u;
-  if (n_pieces) {        // (no payload: nothing may be read)
-    load_unit(min(p, n_pieces) * kWpPiece + lane * 16u, b);
-    load_unit((min(p, n_pieces) + 1u) * kWpPiece + (lane & 1u) * 16u, bh);
-  }
+  if (n_pieces) load_unit(min(p, n_pieces) * kWpPiece + lane * 16u - 16u, b);  // (no payload: nothing may be read)
+  __builtin_amdgcn_s_waitcnt(0);  // (everything asked for so far is waited for HERE: a wait at the loop's top would also wait for every piece's stores)
   bool gave_up = false;
+#ifdef CLDN_WP_PROF
+  unsigned long long wp_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long wp_tl = __builtin_readcyclecounter();
+  const unsigned long long wp_tstart = wp_tl;
+  uint32_t wp_np = 0;
+#define WP_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); wp_acc[i] += t_ - wp_tl; wp_tl = t_; }
+#else
+#define WP_T(i)
+#endif
   __builtin_amdgcn_s_setprio(1);  // (waves that poll a record step down to 0)
   for (; p < n_pieces; p += p_step) {
-    // ---- bytes -> LDS, token ends
-    *reinterpret_cast<uint4*>(wbuf + lane * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
-    if (lane < 2u) *reinterpret_cast<uint4*>(wbuf + kWpPiece / 4u + lane * 4u) = make_uint4(bh[0], bh[1], bh[2], bh[3]);
-    const uint32_t v0 = p * kWpPiece + lane * 16u;
-    uint32_t ends = wp_ends16(b);
-    if (p * kWpPiece < a0 || (p + 1u) * kWpPiece > vend) {  // uniform: the payload's first / last piece
-      const uint32_t lo = a0 > v0 ? min(a0 - v0, 16u) : 0u;
-      const uint32_t hi = vend > v0 ? min(vend - v0, 16u) : 0u;
-      ends &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+    // ---- token ends of my unit; the ends that are tokens of the payload (ev); their numbers
+    const uint32_t v0 = p * kWpPiece + lane * 16u - 16u;
+    if (p == 0u) {  // uniform. What lies in front of the payload: token ends, value bits 0
+      if (lane == 0u) b[0] = b[1] = b[2] = b[3] = 0u;
+      if (lane == 1u) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) b[k] = a0 >= 4u * k + 4u ? 0u : (a0 > 4u * k ? b[k] & (0xffffffffu << (8u * (a0 - 4u * k))) : b[k]);
+      }
     }
-    const uint32_t cl = (uint32_t)__builtin_popcount(ends);
+    const uint32_t eraw = wp_ends16(b);
+    uint32_t ev = lane != 0u ? eraw : 0u;  // (lane 0's tokens are the piece's in front)
+    if (p == 0u || p * kWpPiece + 1008u > vend) {  // uniform: the payload's first / last piece
+      const uint32_t lo = p == 0u && lane == 1u ? a0 : 0u;
+      const uint32_t hi = lane != 0u && vend > v0 ? min(vend - v0, 16u) : 0u;
+      ev &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+    }
+    const uint32_t evc = lane < 63u ? ev : 0u;  // (the halo's tokens are the next piece's: written, not counted or checked)
+    const uint32_t cl = (uint32_t)__builtin_popcount(evc);
     const uint32_t incl = wave_inclusive_scan(cl);
     const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    const uint32_t tb = incl - cl;
-    // my next piece's bytes are requested now (b, bh are free)
+    const uint32_t tb = incl - cl;  // (lane 63: cnt -- the halo's tokens follow the piece's)
+    WP_T(0)
+    // ---- phase V: every token's value -> its slot
+    const uint32_t e20 = (wp_from_lane_below(eraw) >> 12) | (eraw << 4);
+    uint32_t flaws;  // bit j: byte j of my unit gives the chunk back (see the head of the file)
     {
-      const uint32_t pn = min(p + p_step, n_pieces);
-      load_unit(pn * kWpPiece + lane * 16u, b);
-      load_unit((pn + 1u) * kWpPiece + (lane & 1u) * 16u, bh);
+      const uint32_t c20 = ~e20;  // bit 4 + j: byte j continues a token
+      const uint32_t run2 = c20 & (c20 << 1);
+      const uint32_t run4 = run2 & (run2 << 2);                     // bit i: bytes i - 3 .. i of the 20 continue
+      const uint32_t longer = e20 & (run4 << 1);                    // an end behind four of them: a token of 5 bytes or more
+      const uint32_t zero_end = (~wp_nonzero16(b) & 0xffffu) << 4;  // 0x00 bytes ...
+      flaws = ((longer | (zero_end & (c20 << 1))) >> 4) & evc;      // ... behind a byte that continues
     }
+    {
+      uint32_t pk[4], pk_lo[4], pk_hi[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pk[k] = wp_pack7(b[k]);
+      const uint32_t pk_front = wp_from_lane_below(pk[3]);
+      load_unit(min(p + p_step, n_pieces) * kWpPiece + lane * 16u - 16u, b);  // my next piece's bytes are requested now (b is free)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pk_lo[k] = (pk[k] << 28) | (k ? pk[k ? k - 1 : 0] : pk_front);
+        pk_hi[k] = pk[k] >> 4;
+      }
+      uint32_t addr = vals_lds + tb * 4u;
+      wp_value_at<0>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<1>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<2>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<3>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<4>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<5>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<6>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<7>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<8>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<9>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<10>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<11>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<12>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<13>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<14>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_value_at<15>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+    }
+    WP_T(1)
     // ---- chain 1: token ends in front of the piece
     uint32_t T0 = 0u;
     if constexpr (SPLIT) {
@@ -345,7 +391,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
           __builtin_amdgcn_s_sleep(kWpSleep);
           x = wp_rec_load(r);
           if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) == p) break;
-          if ((spins & 63u) == 0u && (spins >= kWpSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
+          if ((spins & 63u) == 0u && (spins >= kWpSpinLimit || __hip_atomic_load(&misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u)) {
             gave_up = true;
             break;
           }
@@ -360,33 +406,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     if (T0 >= target) break;  // the regular stream ended in front of this piece (sections; uniform)
     if (T0 + cnt >= target) {  // uniform: the end that closes the last point lies in this piece
       const uint32_t want = target - T0;  // its 1-based rank among the piece's ends
+      uint32_t keep = tb + cl < want ? 0xffffu : 0u;  // my unit's bytes up to the regular stream's last one
       if (tb < want && want <= tb + cl) {
-        uint32_t m = ends;
+        uint32_t m = evc;
         for (uint32_t k = tb + 1u; k < want; ++k) m &= m - 1u;
-        misc[2] = v0 + (uint32_t)__builtin_ctz(m) + 1u - a0;
+        const uint32_t last = (uint32_t)__builtin_ctz(m);
+        misc[2] = v0 + last + 1u - a0;
+        keep = (2u << last) - 1u;
       }
+      flaws &= keep;  // (what lies behind it are sections, not tokens)
     }
-    // ---- phase A: where the points this piece owns begin
-    const uint32_t A0 = T0 / (uint32_t)NOPS;
-    const uint32_t r0 = T0 - A0 * (uint32_t)NOPS;
-    const uint32_t extra = p == 0u ? 1u : 0u;             // piece 0 owns point 0 (list entry 0)
-    const uint32_t q_first = A0 + 1u - extra;             // < n (T0 < target)
-    const uint32_t npts = min((r0 + cnt) / (uint32_t)NOPS + extra, n - q_first);
-    {
-      const uint32_t x = r0 + tb;                         // <= 1026
-      const uint32_t a = NOPS == 4 ? (x >> 2) : ((x * 21846u) >> 16);  // x / NOPS
-      const uint32_t k0 = (uint32_t)NOPS - 1u - (x - a * (uint32_t)NOPS);
-      const uint32_t e0 = lut[k0 * 256u + (ends & 0xffu)];
-      const uint32_t e1 = lut[(e0 >> 8) * 256u + (ends >> 8)];
-      uint32_t sel = (e0 & 0xffu) | ((e1 & 0xffu) << 8);
-      uint32_t j = a + extra;
-      while (sel) {
-        plist[j] = (uint16_t)(lane * 16u + (uint32_t)__builtin_ctz(sel) + 1u);
-        ++j;
-        sel &= sel - 1u;
-      }
-      if (extra && lane == 0u) plist[0] = (uint16_t)a0;
-    }
+    WP_T(2)
+    // ---- the points this piece owns: those whose first token ends in it. Point j: slots k0 + NOPS * j + o
+    const uint32_t q_first = (T0 + (uint32_t)NOPS - 1u) / (uint32_t)NOPS;  // <= n (T0 < target)
+    const uint32_t k0 = q_first * (uint32_t)NOPS - T0;
+    const uint32_t npts = cnt > k0 ? min((cnt - k0 + (uint32_t)NOPS - 1u) / (uint32_t)NOPS, n - q_first) : 0u;
     wp_wave_sync();
     // ---- phase B, first half: tokens -> values relative to the piece's start. bs = running value behind the rows so far
     int32_t val[ROWS][NOPS];
@@ -395,7 +429,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     uint32_t bs_fl = 0u;
 #pragma unroll
     for (int o = 0; o < NOPS; ++o) bs[o] = 0;
-    bool irregular = false;
+    const bool irregular = flaws != 0u;
 #pragma unroll
     for (uint32_t r = 0; r < ROWS; ++r) {
 #pragma unroll
@@ -403,11 +437,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
       if (r * 64u < npts) {  // uniform
         const uint32_t j = r * 64u + lane;
         const bool have = j < npts;
-        const uint32_t byte0 = have ? (uint32_t)plist[j] : 0u;
+        const uint32_t s0 = have ? k0 + (uint32_t)NOPS * j : 0u;
         int32_t dlt[NOPS];
-        bool zero;
-        const bool bad = wp_tokens<NOPS>(wbuf, byte0, dlt, &zero);
-        irregular = irregular || (have && bad);
+        bool zero = false;
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) {
+          const uint32_t u = vals[s0 + (uint32_t)o];
+          zero = zero || u == 0u;
+          const uint32_t u1 = u - 1u;
+          dlt[o] = (int32_t)((u1 >> 1) ^ (0u - (u1 & 1u)));  // u == 0 (the NaN marker) -> 0x80000000, which no token of <= 4 bytes gives
+        }
         if (__ballot(have && zero) == 0ull) {  // no marker in this row (the rule for lidar data): DPP prefix sums
 #pragma unroll
           for (int o = 0; o < NOPS; ++o) {
@@ -481,6 +520,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
         }
       }
     }
+    WP_T(3)
     // ---- chain 2: the values in front of the piece
     int32_t carry[NOPS];
 #pragma unroll
@@ -497,7 +537,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
           __builtin_amdgcn_s_sleep(kWpSleep);
           x = wp_rec_load(r);
           if (__ballot((uint32_t)(x >> 32) != p) == 0ull) break;
-          if ((spins & 63u) == 0u && (spins >= kWpSpinLimit || *(volatile uint32_t*)&misc[3] != 0u)) {
+          if ((spins & 63u) == 0u && (spins >= kWpSpinLimit || __hip_atomic_load(&misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u)) {
             gave_up = true;
             break;
           }
@@ -518,6 +558,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
       if (lane < (uint32_t)NOPS)
         wp_rec_store(vrec + (size_t)(p & (kWpRing - 1u)) * NOPS + lane, ((unsigned long long)(p + 1u) << 32) | mine);
     }
+    // The bytes of my next piece were requested long ago: naming them here puts the wait for them IN FRONT of this piece's
+    // stores. Left to the top of the loop it becomes s_waitcnt vmcnt(0) -- the compiler cannot count the stores of a variable
+    // number of rows -- and every piece would begin by waiting for the write acknowledgements of the piece before.
+    // The same for the dwords that hold the points' Palette indexes / column values: ONE wait here instead of an
+    // s_waitcnt vmcnt(0) per row behind the row before's stores (the waitcnt pass loses count across the rows' branches).
+    asm volatile("" ::"v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+#pragma unroll
+    for (uint32_t a = 0; a < NFA; ++a)
+#pragma unroll
+      for (uint32_t r = 0; r < ROWS; ++r) asm volatile("" : "+v"(raw[a][r]));
+    WP_T(4)
     // ---- phase B, second half: values -> floats -> the points. A lane stores its own point.
     const bool piece_flags = bs_fl != 0u;  // uniform: a marker somewhere in the piece
 #pragma unroll
@@ -557,7 +608,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
             pv[a] = pal[a * kFastPalEntries + (idx & (kFastPalEntries - 1u))];
           }
         }
+#ifdef CLDN_WP_ABL
+        if (have && (!(CLDN_WP_ABL & 1) || f[0] == 1234567.0f)) {  // (ablation 1: nothing is stored)
+#else
         if (have) {
+#endif
           uint8_t* pt = base + __umul24(q, step);  // (q < 32768, step <= 1024)
           if (full16) {
             *reinterpret_cast<float4*>(pt) = make_float4(f[0], f[1], f[2], __uint_as_float(pv[0] & 0xffffu));
@@ -647,7 +702,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
       }
     }
     wp_wave_sync();  // the next piece's bytes and list overwrite this one's
+    WP_T(5)
+#ifdef CLDN_WP_PROF
+    ++wp_np;
+#endif
   }
+#ifdef CLDN_WP_PROF
+  if (PASS == 0 && lane == 0u && (c == 0u || c == 700u) && (wave == 0u || wave == 7u || wave == 15u)) {
+    const unsigned long long t_ = __builtin_readcyclecounter();
+    printf("chunk %u wave %u pieces %u: start %llu total %llu prologue %llu | counts %llu V %llu chain1 %llu B1 %llu chain2 %llu B2 %llu\n", c, wave, wp_np,
+           wp_t0, t_ - wp_t0, wp_tstart - wp_t0, wp_acc[0], wp_acc[1], wp_acc[2], wp_acc[3], wp_acc[4], wp_acc[5]);
+  }
+#endif
   if (gave_up && lane == 0u) {
     misc[3] = 1u;
     misc[0] = 1u;
@@ -708,7 +774,7 @@ __global__ __launch_bounds__(1024) void k_wp_counts(const uint8_t* __restrict__ 
   uint32_t* t0 = sp.t0 + (size_t)c * sp.maxp;
   for (uint32_t p = wave; p < n_pieces; p += 16u) {
     const uint32_t v0 = p * kWpPiece + lane * 16u;
-    const bool ok = v0 < vend;
+    const bool ok = v0 < vend && lane < kWpUnits;  // (here lane l < 62 counts unit l of the piece)
     const uint4 w = *reinterpret_cast<const uint4*>(src_al + (ok ? v0 : 0u));
     const uint32_t b[4] = {ok ? w.x : 0xffffffffu, ok ? w.y : 0xffffffffu, ok ? w.z : 0xffffffffu, ok ? w.w : 0xffffffffu};
     uint32_t ends = wp_ends16(b);

@@ -24,6 +24,10 @@ for name, make, n_clouds in cases:
             datas = [gen(data.size // info.point_step, seed=42 + k)[1] for k in range(distinct)]
     plan = native.Plan(info)
     codec = native.Codec(plan, device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    if os.environ.get("DECBENCH_FILL_ZERO", "0") != "0":  # CLDN_HIP_FILL_ZERO: bytes no field covers may be written as 0
+        codec.set_decode_fill(True)
+    if os.environ.get("DECBENCH_CLOUDS") and n_clouds > 1:
+        n_clouds = int(os.environ["DECBENCH_CLOUDS"])
     step = info.point_step
     n = data.size // step
     host = np.concatenate([datas[k % len(datas)] for k in range(n_clouds)])

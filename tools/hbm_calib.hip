@@ -10,7 +10,8 @@
 // and several grid sizes (workgroups per CU).
 //
 // build: hipcc --offload-arch=gfx950 -O3 tools/hbm_calib.hip -o cloudini_amd/lib/hbm_calib   (cloudini_amd/build.py does it)
-// run:   cloudini_amd/lib/hbm_calib [GiB per buffer, default 1] [piece]   (piece: only the piece kernel's own shape)
+// run:   cloudini_amd/lib/hbm_calib [GiB per buffer, default 1] [piece | points14]   (piece: only the piece kernel's own shape;
+//        points14: the point decoder's store shape)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -109,6 +110,28 @@ __global__ __launch_bounds__(256) void k_piece_shape(const v4* __restrict__ pts,
   }
 }
 
+// ---- the point decoder's store shape (round 6) -----------------------------------------------------------------------------
+// 16-byte points of which a decoder in KEEP mode (the bytes no field covers are left alone, as the reference's decoder leaves
+// them) writes 12 + 2: every 32-byte sector of the output is written partially. FULL: the same points as whole 16-byte stores
+// (CLDN_HIP_FILL_ZERO). READ: a third of a unit is read per point alongside (the encoded stream: ~6.5 B per point).
+template <bool FULL, bool READ>
+__global__ void k_points14(const v4* __restrict__ in, uint8_t* __restrict__ o, size_t n_points, float x, float* __restrict__ sink) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  v4 s = {0, 0, 0, 0};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_points; i += stride) {
+    if (READ && (i % 5u) < 2u) s += in[i / 5u * 2u + i % 5u];  // 2 units per 5 points: 6.4 B per point
+    uint8_t* pt = o + i * 16u;
+    if (FULL) {
+      *reinterpret_cast<v4*>(pt) = v4{x, x, x, s.x};
+    } else {
+      typedef float v3 __attribute__((ext_vector_type(3)));
+      *reinterpret_cast<v3*>(pt) = v3{x, x, s.x};
+      *reinterpret_cast<uint16_t*>(pt + 12) = (uint16_t)i;
+    }
+  }
+  if (s.y == 123.456f) sink[blockIdx.x] = s.y;
+}
+
 template <class F>
 static void run(const char* name, double bytes, int threads, int wg_per_cu, int cus, F launch) {
   hipEvent_t e0, e1;
@@ -180,6 +203,19 @@ int main(int argc, char** argv) {
           hipLaunchKernelGGL((k_piece_shape<true, false>), dim3(g), dim3(256), lds, 0, a, (uint8_t*)o, colp, n_pieces, out_pp, (uint32_t)lds / 4u);
         });
       }
+    }
+    return 0;
+  }
+  if (argc > 2 && !strcmp(argv[2], "points14")) {
+    // 32 M points of 16 bytes (the bench line's decode leg): what the store pattern alone costs
+    const size_t n_pts = 32000000;
+    if (n_pts * 16u > bytes) { fprintf(stderr, "buffer too small\n"); return 1; }
+    const int wv[] = {2, 4, 8};
+    for (int w : wv) {
+      run("12+2 of 16", 16.0 * n_pts, 1024, w, cus, [&](int g, int th) { hipLaunchKernelGGL((k_points14<false, false>), dim3(g), dim3(th), 0, 0, a, (uint8_t*)o, n_pts, 1.0f, s); });
+      run("16 of 16", 16.0 * n_pts, 1024, w, cus, [&](int g, int th) { hipLaunchKernelGGL((k_points14<true, false>), dim3(g), dim3(th), 0, 0, a, (uint8_t*)o, n_pts, 1.0f, s); });
+      run("12+2, +read", 22.4 * n_pts, 1024, w, cus, [&](int g, int th) { hipLaunchKernelGGL((k_points14<false, true>), dim3(g), dim3(th), 0, 0, a, (uint8_t*)o, n_pts, 1.0f, s); });
+      run("16, +read", 22.4 * n_pts, 1024, w, cus, [&](int g, int th) { hipLaunchKernelGGL((k_points14<true, true>), dim3(g), dim3(th), 0, 0, a, (uint8_t*)o, n_pts, 1.0f, s); });
     }
     return 0;
   }
