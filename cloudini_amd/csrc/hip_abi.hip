@@ -1062,43 +1062,52 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
     // the match lists take as many bytes as the payloads they describe: sized from the worst-case stage-1 bound that is
     // gigabytes for a large batch (32 x 1 M XYZI points: 1.3 GB for 207 MB of payload). Beyond 256 MB the call waits for
     // stage 1 and sizes them from the bytes it really wrote (one 8-byte read; the wait is ~5 % of what the LZ4 stage takes)
+    bool stage1_failed = false;
     if (max_subs * lz_mm * sizeof(LzMatch) > (256ull << 20)) {
       uint64_t total_s1 = 0;
+      uint32_t st1 = 0;  // the status word travels with the total: behind a stage 1 that gave up (ST_FINISH_TIMEOUT: k_finish
+                         // returned before it wrote offsets, payload sizes and positions) the total is a stale number
       HIP_TRY(hipMemcpyAsync(&total_s1, (const uint64_t*)c->d_s1_offsets.p + n_clouds, sizeof(total_s1), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(&st1, c->d_status.p, sizeof(st1), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
-      if (total_s1 <= need_s1) max_subs = total_s1 / lz_sub + n_chunks;  // (every chunk's last sub-range may be partial)
+      stage1_failed = st1 != 0u;
+      if (!stage1_failed && total_s1 <= need_s1) max_subs = total_s1 / lz_sub + n_chunks;  // (every chunk's last sub-range may be partial)
     }
-    if ((rc = c->d_lz_matches.ensure((size_t)max_subs * lz_mm * sizeof(LzMatch))) != CLDN_HIP_OK) return rc;
-    if ((rc = c->d_lz_counts.ensure((size_t)(max_subs * 7u + 2u * n_chunks + 1u) * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
-    Lz4Launch Z;
-    Z.stream = c->stream;
-    Z.stage1 = (const uint8_t*)c->d_s1.p;
-    Z.chunk_dst = (const uint64_t*)c->d_dst.p;
-    Z.chunk_payload = (const uint32_t*)c->d_payload.p;
-    Z.n_chunks = n_chunks;
-    Z.fast = lz4_fast ? 1u : 0u;
-    Z.max_subs = max_subs;
-    Z.matches = (LzMatch*)c->d_lz_matches.p;
-    Z.counts = (uint32_t*)c->d_lz_counts.p;
-    Z.last_end = Z.counts + max_subs;
-    Z.anchor_in = Z.last_end + max_subs;
-    Z.sub_size = Z.anchor_in + max_subs;
-    Z.sub_chunk = Z.sub_size + max_subs;
-    Z.before = Z.sub_chunk + max_subs;
-    Z.next_pos = Z.before + max_subs;
-    Z.block_size = Z.next_pos + max_subs;
-    Z.sub_first = Z.block_size + n_chunks;
-    // the blocks go straight into the framed streams: [u32 size][block] per chunk, positions from a scan of the block sizes
-    Z.cloud_first_chunk = (const uint32_t*)c->d_cloud_first.p;
-    Z.n_clouds = n_clouds;
-    Z.block_dst = (uint64_t*)c->d_dst2.p;
-    Z.block_sizes_out = (uint32_t*)c->d_payload2.p;
-    Z.stream_offsets = (uint64_t*)c->d_offsets.p;
-    Z.out = d_outp;
-    Z.out_capacity = out_capacity;
-    Z.status = (uint32_t*)c->d_status.p;
-    if ((rc = lz4_launch(Z)) != CLDN_HIP_OK) return rc;
-    d_sizes = c->d_payload2.p;
+    if (stage1_failed) {  // no LZ4 stage over stale sizes: the status handling of the caller (ticket retry / error) takes it from here
+      HIP_TRY(hipMemsetAsync(c->d_offsets.p, 0, (size_t)(n_clouds + 1) * sizeof(uint64_t), c->stream));
+    } else {
+      if ((rc = c->d_lz_matches.ensure((size_t)max_subs * lz_mm * sizeof(LzMatch))) != CLDN_HIP_OK) return rc;
+      if ((rc = c->d_lz_counts.ensure((size_t)(max_subs * 7u + 2u * n_chunks + 1u) * sizeof(uint32_t))) != CLDN_HIP_OK) return rc;
+      Lz4Launch Z;
+      Z.stream = c->stream;
+      Z.stage1 = (const uint8_t*)c->d_s1.p;
+      Z.chunk_dst = (const uint64_t*)c->d_dst.p;
+      Z.chunk_payload = (const uint32_t*)c->d_payload.p;
+      Z.n_chunks = n_chunks;
+      Z.fast = lz4_fast ? 1u : 0u;
+      Z.max_subs = max_subs;
+      Z.matches = (LzMatch*)c->d_lz_matches.p;
+      Z.counts = (uint32_t*)c->d_lz_counts.p;
+      Z.last_end = Z.counts + max_subs;
+      Z.anchor_in = Z.last_end + max_subs;
+      Z.sub_size = Z.anchor_in + max_subs;
+      Z.sub_chunk = Z.sub_size + max_subs;
+      Z.before = Z.sub_chunk + max_subs;
+      Z.next_pos = Z.before + max_subs;
+      Z.block_size = Z.next_pos + max_subs;
+      Z.sub_first = Z.block_size + n_chunks;
+      // the blocks go straight into the framed streams: [u32 size][block] per chunk, positions from a scan of the block sizes
+      Z.cloud_first_chunk = (const uint32_t*)c->d_cloud_first.p;
+      Z.n_clouds = n_clouds;
+      Z.block_dst = (uint64_t*)c->d_dst2.p;
+      Z.block_sizes_out = (uint32_t*)c->d_payload2.p;
+      Z.stream_offsets = (uint64_t*)c->d_offsets.p;
+      Z.out = d_outp;
+      Z.out_capacity = out_capacity;
+      Z.status = (uint32_t*)c->d_status.p;
+      if ((rc = lz4_launch(Z)) != CLDN_HIP_OK) return rc;
+      d_sizes = c->d_payload2.p;
+    }
   } else if (lz4) {
     HIP_TRY(hipMemsetAsync(c->d_offsets.p, 0, (size_t)(n_clouds + 1) * sizeof(uint64_t), c->stream));
   }

@@ -669,7 +669,7 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
           while (used < batch) {
             if (b->in.size() <= used) b->in.emplace_back();
             if (!source.next(b->in[used])) {  // the source refills the Message (and reuses its page-locked capacity)
-              exhausted = true;
+              exhausted = !source.more();  // (more(): not the end -- hand on what there is, then ask again)
               break;
             }
             ++used;
@@ -679,7 +679,8 @@ TranscodeStats transcodePointClouds(MessageSource& source, MessageSink& sink, co
         seconds_read += since(t_read);
         if (used == 0) {
           free_q.push(b);
-          break;
+          if (exhausted) break;
+          continue;  // (the source only asked for what is in flight to be waited for)
         }
         b->in.resize(used);
         b->seq = seq++;

@@ -714,8 +714,10 @@ struct McapFlow {
   std::deque<Item> pending;
   size_t clouds_pending = 0;
   // bytes of the copied-through messages that wait behind a cloud. Beyond kHoldBytes the source asks the pipeline to hand
-  // its batch on (MessageSource::submitNow) and its next call waits until the sink has written enough of them
+  // its batch on (MessageSource::submitNow after a cloud; in the middle of a run of other messages nextCloud() gives up
+  // with `yielded` set and MessageSource::more() says so) and its next call waits until the sink has written enough of them
   size_t held_bytes = 0;
+  bool yielded = false;  // the last nextCloud() returned false because of kHoldBytes, not because the data ended
   static constexpr size_t kHoldBytes = 64u << 20;
   bool failed = false;  // the sink gave up: nothing waits any more
   uint64_t written = 0;  // messages the sink has written (progress, for the wait above)
@@ -726,6 +728,7 @@ struct McapFlow {
   // reads on until a point-cloud message turns up (true: `m` is it, its bytes in `bytes`, already queued) or the data
   // section ends (false). Everything else is handed on as it comes.
   bool nextCloud(McapMessage& m, std::vector<uint8_t>& bytes, std::string& name) {
+    yielded = false;
     {
       // (the clouds delivered so far are on their way -- submitNow() was true after the last one --, so the sink will get to
       // them; a pipeline that has failed never does: no progress for a minute ends the wait with an error of its own, behind
@@ -798,6 +801,13 @@ struct McapFlow {
             held_bytes += it.body.size();
             stats.peak_held_bytes = std::max<uint64_t>(stats.peak_held_bytes, held_bytes);
             pending.push_back(std::move(it));
+            if (held_bytes > kHoldBytes) {
+              // enough is held back behind clouds that may still sit in a batch the pipeline has not handed on (sparse clouds,
+              // a lidar topic that ends early, an odd count against --batch): hand control back -- the pipeline submits what
+              // it has, the next call waits at the top until the sink has caught up
+              yielded = true;
+              return false;
+            }
           }
           break;
         }
@@ -832,6 +842,7 @@ class McapSource : public MessageSource {
     std::lock_guard<std::mutex> lock(flow_.mutex);
     return flow_.held_bytes > McapFlow::kHoldBytes;
   }
+  bool more() const override { return flow_.yielded; }  // (reader thread only, like nextCloud)
   bool next(Message& out) override {
     if (have_first_) {
       have_first_ = false;

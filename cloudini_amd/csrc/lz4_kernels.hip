@@ -103,8 +103,12 @@ __device__ __forceinline__ uint32_t lz_chunk_of(const uint32_t* __restrict__ sub
 
 // one workgroup: sub_first[c] = sub-ranges of the chunks before c (sub_first[n_chunks] = all of them)
 // (a chunk without a byte of payload has no sub-range and no wave below: its block, the single token 0x00, is written by k_lz4_offsets)
+// max_subs: what the match lists and the per-sub-range arrays hold. The plan never numbers a sub-range beyond it (chunks that
+// would need more get none, ST_OUT_OVERFLOW is raised): sizes that do not fit the workspace -- stale ones, say, read behind a
+// stage 1 that gave up -- cannot make the kernels below write out of bounds.
 __global__ __launch_bounds__(1024) void k_lz4_plan(const uint32_t* __restrict__ chunk_payload, uint32_t n_chunks,
-                                                   uint32_t* __restrict__ sub_first, uint32_t sub_bytes) {
+                                                   uint32_t* __restrict__ sub_first, uint32_t sub_bytes, uint32_t max_subs,
+                                                   uint32_t* __restrict__ status) {
   __shared__ uint32_t wtot[16];
   __shared__ uint32_t carry;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -119,12 +123,15 @@ __global__ __launch_bounds__(1024) void k_lz4_plan(const uint32_t* __restrict__ 
     __syncthreads();
     uint32_t before = carry;
     for (uint32_t w = 0; w < wave; ++w) before += wtot[w];
-    if (c < n_chunks) sub_first[c] = before + excl;
+    if (c < n_chunks) sub_first[c] = min(before + excl, max_subs);
     __syncthreads();
     if (tid == 1023u) carry = before + excl + mine;
     __syncthreads();
   }
-  if (tid == 0u) sub_first[n_chunks] = carry;
+  if (tid == 0u) {
+    sub_first[n_chunks] = min(carry, max_subs);
+    if (carry > max_subs) atomicOr(status, ST_OUT_OVERFLOW);
+  }
 }
 
 // workgroups of one wave; every workgroup takes the sub-ranges blockIdx.x, blockIdx.x + gridDim.x, ...
@@ -784,7 +791,8 @@ int lz4_launch(const Lz4Launch& L) {
   hipError_t e;
   const uint32_t sub_bytes = L.fast ? kLzFastSubBytes : kLzSubBytes;
   const uint32_t max_matches = L.fast ? kLzFastMaxMatches : kLzMaxMatches;
-  hipLaunchKernelGGL(k_lz4_plan, dim3(1), dim3(1024), 0, L.stream, L.chunk_payload, L.n_chunks, L.sub_first, sub_bytes);
+  hipLaunchKernelGGL(k_lz4_plan, dim3(1), dim3(1024), 0, L.stream, L.chunk_payload, L.n_chunks, L.sub_first, sub_bytes,
+                     (uint32_t)std::min<uint64_t>(L.max_subs, 0xffffffffu), L.status);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_plan");
   // one wave per sub-range, at most `max_subs` of them: workgroups beyond the real number find nothing to do
   // (round 5: one workgroup per sub-range -- the dispatcher balances them; 8192 looping workgroups ran 1.68 rounds)

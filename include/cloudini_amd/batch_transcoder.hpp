@@ -89,6 +89,10 @@ class MessageSource {
   // messages it has delivered come out of the sink (the container converter: everything that lies between two point
   // clouds of a bag) asks for this before its next() waits for the sink.
   virtual bool submitNow() const { return false; }
+  // Optional: asked after a next() that returned false. true = this is NOT the end: the source has read as much as it is
+  // willing to hold back behind the messages it has delivered; the pipeline hands on what it has collected (also a batch
+  // that is not full) and calls next() again, which may then wait for the sink.
+  virtual bool more() const { return false; }
 };
 
 class MessageSink {

@@ -97,3 +97,54 @@ def test_full_size_configs_match_the_reference_itself(reflib, name):
     out = np.full(data.size, 0x3C, dtype=np.uint8)
     assert np.array_equal(codec.decode_host([want], [n], out=out)[0], ref_dec)
     codec.close()
+
+
+def test_batch_beyond_4_gib(reflib):
+    """One call over more than 2^32 input bytes (missing 4): 30 x 10 M-point XYZI clouds = 4.8 GB of points
+    (the reference has no such limit: size_t throughout, src/cloudini.cpp:522-560). Four distinct clouds against the compiled
+    reference, the other 26 as copies of them; encode and decode device resident (the batch never exists in host memory).
+    Byte offsets beyond 2^32 occur in the input, in the decoded output and in the chunk table's first_point * point_step."""
+    import torch
+    from cloudini_amd import native
+    dev = torch.device("cuda", 0)
+    n = 10_000_000
+    n_clouds, n_distinct = 30, 4
+    made = [synth.lidar_xyzi(n, seed=42 + k) for k in range(n_distinct)]
+    info = made[0][0]
+    step = info.point_step
+    assert n_clouds * n * step > (1 << 32)
+    want = [reflib.encode_stage1(info, d) for _i, d in made]
+    codec = native.Codec(native.Plan(info), device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    d_distinct = [torch.from_numpy(d).to(dev) for _i, d in made]
+    d_points = torch.empty(n_clouds * n * step, dtype=torch.uint8, device=dev)
+    for k in range(n_clouds):
+        d_points[k * n * step:(k + 1) * n * step] = d_distinct[k % n_distinct]
+    cloud_points = np.full(n_clouds, n, dtype=np.uint64)
+    cap = codec.plan.stage1_bound(n) * n_clouds
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(n_clouds + 1, dtype=torch.int64, device=dev)
+    n_chunks = n_clouds * ((n + 32767) // 32768)
+    d_sizes = torch.zeros(n_chunks, dtype=torch.int32, device=dev)
+    codec.encode_device(d_points.data_ptr(), cloud_points, d_out.data_ptr(), cap, d_off.data_ptr(), d_sizes.data_ptr(), 0)
+    codec.synchronize()
+    codec.status()
+    offs = d_off.cpu().numpy().astype(np.uint64)
+    assert int(offs[-1]) == sum(len(want[k % n_distinct]) for k in range(n_clouds))
+    d_want = [torch.from_numpy(w).to(dev) for w in want]
+    for k in range(n_clouds):
+        a, b = int(offs[k]), int(offs[k + 1])
+        assert b - a == len(want[k % n_distinct]), k
+        assert torch.equal(d_out[a:b], d_want[k % n_distinct]), k
+    # and back: the decode of the batch against the reference's decode of the four distinct streams
+    ref_dec = []
+    for k in range(n_distinct):
+        full = reflib.encode(info, made[k][1])
+        ref_dec.append(torch.from_numpy(reflib.decode(full, n * step, fill=0x00)[0]).to(dev))
+    d_dec = torch.zeros(n_clouds * n * step, dtype=torch.uint8, device=dev)   # (KEEP mode over zeros = the reference over fill 0)
+    codec.decode_device(d_out.data_ptr(), offs, cloud_points, d_dec.data_ptr(), n_clouds * n * step, d_sizes.data_ptr())
+    codec.synchronize()
+    codec.status()
+    for k in range(n_clouds):
+        assert torch.equal(d_dec[k * n * step:(k + 1) * n * step], ref_dec[k % n_distinct]), k
+    assert codec.decode_stats()[2] == 0
+    codec.close()

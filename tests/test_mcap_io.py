@@ -255,3 +255,44 @@ def test_a_bag_is_streamed_not_loaded(tmp_path, reflib):
     assert st_big["messages"] == 6 + 7 * 80 and st_big["converted"] == 6
     assert st_mid["peak_held_bytes"] <= (64 + 40 + 1) << 20 and st_big["peak_held_bytes"] <= (64 + 80 + 1) << 20
     assert (rss_big - rss_mid) * 1024 < 0.25 * grown, (rss_mid, rss_big, grown)
+
+
+@pytest.mark.gpu
+def test_a_cloud_in_a_partial_batch_does_not_hold_the_rest_of_the_bag(tmp_path, reflib):
+    """A point cloud that sits in a batch which is not full (default --batch 64: three clouds never fill one) followed by far
+    more than 64 MB of other messages -- a lidar topic that ends early. The source must hand its partial batch on when the
+    held-back messages pass the limit (MessageSource::more), not buffer everything up to the end of the bag."""
+    import json
+    from cloudini_amd import synth
+    from test_host_api import _cdr_pointcloud2
+    tool = os.path.join(LIB, "cloudini_batch_transcode")
+    pc2 = "sensor_msgs/msg/PointCloud2"
+    schemas = [(1, pc2, "ros2msg", b"x"), (2, "sensor_msgs/msg/Image", "ros2msg", b"y")]
+    channels = [(1, 2, "/camera", "cdr", []), (2, 1, "/lidar", "cdr", [])]
+    rs = np.random.RandomState(11)
+    msgs, t = [], 10
+    clouds = []
+    for k in range(3):
+        info, data = synth.lidar_xyzi(15000 + 500 * k, seed=70 + k)
+        clouds.append(_cdr_pointcloud2(info, data, stamp=(1700000100 + k, k)).tobytes())
+    image = 1 << 20
+    for k, n_images in enumerate((2, 150, 90)):  # cloud 0, 2 images, cloud 1, 150 MB of images, cloud 2, 90 MB of images, end
+        msgs.append((2, len(msgs), t, t, clouds[k])); t += 1
+        for j in range(n_images):
+            msgs.append((1, len(msgs), t, t, rs.bytes(16) + bytes(image - 16))); t += 1
+    src, dst = str(tmp_path / "sparse.mcap"), str(tmp_path / "sparse_out.mcap")
+    mcap_py.write(src, "ros2", schemas, channels, msgs, chunk_messages=4)
+    r = subprocess.run([tool, src, dst, "--resolution", "0.001", "--compression", "zstd", "--mcap-compression", "none"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    st = json.loads(r.stdout.strip().splitlines()[-1])
+    assert st["messages"] == len(msgs) and st["converted"] == 3
+    assert st["peak_held_bytes"] <= (64 + 2) << 20, st  # (the limit plus the message that crossed it), not 150 MB
+    f = mcap_py.read(dst)
+    assert len(f["messages"]) == len(msgs)
+    for (ch, seq, lt, pt, data), (ch0, seq0, lt0, pt0, data0) in zip(f["messages"], msgs):
+        assert (ch, seq, lt, pt) == (ch0, seq0, lt0, pt0)
+        if ch0 == 1:
+            assert data == data0
+        else:
+            assert data == reflib.ros_compress(np.frombuffer(data0, dtype=np.uint8), 0.001, 2).tobytes()
