@@ -187,6 +187,7 @@ struct cldn_hip_codec {
   uint32_t finish_epoch = 0;  // tag of this call's records
   bool force_ticket = false;      // k_finish waited in vain once (ST_FINISH_TIMEOUT): from then on its workgroups take tickets
   bool test_timeout_once = false; // cldn_hip_debug_finish_timeout_once: the next encode call's first attempt reports the timeout
+  uint32_t test_split_parts = 0;  // cldn_hip_debug_decode_split: 0 = by the batch's size, 1 = chained launch, 2..16 = workgroups per chunk
   uint32_t finish_retries = 0;    // calls redone through the ticket path
   DevBuf d_pieces;  // piece table of the piece kernel (stage1_fused.h)
   uint32_t n_pieces = 0;
@@ -662,6 +663,17 @@ __attribute__((visibility("default"))) int cldn_hip_debug_finish_timeout_once(cl
   return CLDN_HIP_OK;
 }
 
+// Test hook, outside the boundary like the one above: which launch shape the point decoder takes (tests/test_gpu_decode.py
+// runs every schema family through the chained and the SPLIT launches whatever the batch's size). parts: 0 = decided by the
+// number of chunks (the default), 1 = the chained launch, 2..16 = a SPLIT launch with that many workgroups per chunk. Bytes
+// never depend on it. (Rounds 4-5 read environment variables in the decode path for this.)
+__attribute__((visibility("default"))) int cldn_hip_debug_decode_split(cldn_hip_codec_t* c, uint32_t parts) {
+  if (!c) return fail(CLDN_HIP_ERR_ARG, "codec is NULL");
+  if (parts > 16u) return fail(CLDN_HIP_ERR_ARG, "at most 16 workgroups per chunk");
+  c->test_split_parts = parts;
+  return CLDN_HIP_OK;
+}
+
 int cldn_hip_codec_decode_ms(cldn_hip_codec_t* c, float ms[2]) {
   if (!c || !ms) return fail(CLDN_HIP_ERR_ARG, "NULL argument");
   if (!c->dec_events_valid) return fail(CLDN_HIP_ERR_ARG, "no timed decode call (cldn_hip_codec_enable_timing first)");
@@ -831,9 +843,9 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   const uint8_t* variant_ptr = points_loc == CLDN_HIP_DEVICE ? (const uint8_t*)points : nullptr;
   const bool wide = c->plan.wide;  // stage1_wide.h: the plan's arrays live in device memory, one segment per chunk
   const uint32_t piece_pts = (c->pipeline == 1 || wide) ? 0u : stage1_piece_points(plan, variant_ptr);
-  static const bool intra_env0 = getenv("CLDN_HIP_INTRA") && atoi(getenv("CLDN_HIP_INTRA")) != 0;  // A/B switch
+  static const bool intra_env0 = dev_env_int("CLDN_HIP_INTRA", 0) != 0;  // A/B switch
   const bool intra_env = intra_env0 || table != nullptr;  // chunk tables want one regular segment per chunk
-  static const bool quad_major_env = !(getenv("CLDN_HIP_QUAD_MAJOR") && atoi(getenv("CLDN_HIP_QUAD_MAJOR")) == 0);
+  static const bool quad_major_env = dev_env_int("CLDN_HIP_QUAD_MAJOR", 1) != 0;
   int rc = upload_batch_shape(c, cloud_points, n_clouds, piece_pts, piece_pts != 0u && intra_env && quad_major_env, &n_chunks, &n_points);
   if (rc != CLDN_HIP_OK) return rc;
   if (n_points && !points && !cloud_ptrs) return fail(CLDN_HIP_ERR_ARG, "points is NULL");
@@ -862,8 +874,8 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   // Sub-chunks: the regular stream of a chunk is produced as `subs` independent sub-streams (one workgroup each)
   // that the compaction kernel concatenates; this multiplies the parallelism of small batches at no extra work.
   uint32_t subs = 1;
-  if (const char* e = getenv("CLDN_HIP_SUBCHUNKS")) {
-    subs = (uint32_t)atoi(e);
+  if (const int forced = dev_env_int("CLDN_HIP_SUBCHUNKS", 0)) {
+    subs = (uint32_t)forced;
   } else {
     while (subs < 32u && (uint64_t)n_chunks * subs < 6000u) subs *= 2u;
   }
@@ -1146,7 +1158,7 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
     return CLDN_HIP_OK;
   }
 
-  if (const char* dump = getenv("CLDN_HIP_DEBUG_DUMP")) {  // diagnostics: segment table of the last call
+  if (const char* dump = dev_env("CLDN_HIP_DEBUG_DUMP")) {  // diagnostics: segment table of the last call
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<Seg> hs((size_t)n_chunks * segs_per_chunk);
     std::vector<ChunkDesc> hc(n_chunks);
@@ -1605,7 +1617,8 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
   }
   L.palette_hint = c->dec_palette_hint ? 1u : 0u;
   // small batches: the point kernel's pieces spread over several workgroups per chunk (SPLIT launches) want their workspace
-  if (!c->plan.wide && wp_split_parts(n_chunks) > 1u) {
+  L.wp_parts = c->test_split_parts == 0u ? wp_split_parts(n_chunks) : c->test_split_parts;
+  if (!c->plan.wide && L.wp_parts > 1u) {
     uint64_t chunk_bound = (uint64_t)kPointsPerChunk * c->plan.ref_max_point_bytes;
     if (c->plan.uses_v5) chunk_bound += (uint64_t)c->plan.fields.size() * 32u + 1024u;
     const uint64_t maxp = chunk_bound / 992u + 3u;  // (kWpPiece, stage1_decode_wave.h: pieces of 62 units)

@@ -485,10 +485,12 @@ __device__ __forceinline__ void lz_emit_direct(const LzEmitArgs& A, uint32_t idx
   }
 }
 
+#ifdef CLDN_DEV  // (the round-3 emit kernel: an A/B reference of the development build, CLDN_HIP_LZ4_EMIT_DIRECT=1)
 __global__ __launch_bounds__(64) void k_lz4_emit(const LzEmitArgs A) {
   const uint32_t total = A.sub_first[A.n_chunks];
   for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) lz_emit_direct(A, idx, A.sub_chunk[idx], threadIdx.x);
 }
+#endif
 
 // k_lz4_emit_lds (round 5): the same bytes as lz_emit_direct, moved through LDS. The direct kernel's lanes read and write
 // their own literal runs with scattered 4-byte accesses (64 different lines per instruction: the texture addresser is what
@@ -833,9 +835,12 @@ int lz4_launch(const Lz4Launch& L) {
   A.out_capacity = L.out_capacity;
   A.sub_bytes = sub_bytes;
   A.max_matches = max_matches;
-  static const bool direct = getenv("CLDN_HIP_LZ4_EMIT_DIRECT") != nullptr;  // (the kernel of rounds 3-4, for A/B runs)
+#ifdef CLDN_DEV
+  static const bool direct = dev_env("CLDN_HIP_LZ4_EMIT_DIRECT") != nullptr;  // (the kernel of rounds 3-4, for A/B runs)
   if (direct) hipLaunchKernelGGL(k_lz4_emit, dim3(grid), dim3(64), 0, L.stream, A);
-  else if (L.fast) hipLaunchKernelGGL(k_lz4_emit_lds<kLzFastSubBytes>, dim3(grid), dim3(64), 0, L.stream, A);
+  else
+#endif
+  if (L.fast) hipLaunchKernelGGL(k_lz4_emit_lds<kLzFastSubBytes>, dim3(grid), dim3(64), 0, L.stream, A);
   else hipLaunchKernelGGL(k_lz4_emit_lds<kLzSubBytes>, dim3(grid), dim3(64), 0, L.stream, A);
   if ((e = hipGetLastError()) != hipSuccess) return launch_fail(e, "k_lz4_emit");
   return CLDN_HIP_OK;

@@ -17,6 +17,7 @@
 #include "stage1_decode_stream.h"
 #include "stage1_decode_sections_w.h"
 #include "stage1_decode_automaton.h"
+#include "stage1_decode_dv.h"
 
 #include "cloudini_hip.h"
 #include "stage1_launch.h"
@@ -106,7 +107,7 @@ int stage1_launch_decode_unframed(const DevPlan& plan, hipStream_t stream, const
 // DeltaVarint sections into columns: k_sections_dv_cols (round 4), or the stream kernel's section mode (CLDN_HIP_DV_COLS=0: A/B switch)
 // 0 = the stream kernel's section mode, 1 = k_sections_dv_cols as a launch of its own, 2 (default) = inside k_sections_w's launch
 static int dv_cols_kernel() {
-  static const int mode = getenv("CLDN_HIP_DV_COLS") ? atoi(getenv("CLDN_HIP_DV_COLS")) : 2;
+  static const int mode = dev_env_int("CLDN_HIP_DV_COLS", 2);
   return mode;
 }
 
@@ -136,13 +137,13 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     // regular streams made of varint tokens only go through the parallel kernel; the general kernel then decodes
     // the V5 sections (and whole chunks the fast kernel handed back)
     const DevPlan& P = *L.plan;
-    static const bool no_fast = getenv("CLDN_HIP_NO_FAST_DECODE") != nullptr;  // A/B switch
+    static const bool no_fast = dev_env("CLDN_HIP_NO_FAST_DECODE") != nullptr;  // A/B switch
     bool fast = !no_fast && P.all_varint && P.n_ops <= 8u;  // no regular ops at all (integer-only V5 cloud) is fine too
     bool all_qf32 = true;
     for (uint32_t k = 0; k < P.n_ops; ++k) all_qf32 = all_qf32 && P.ops[k].kind == OP_QF32;
     // FloatN streams (3 or 4 int32-delta tokens per point): point-parallel kernel with the Palette sections folded in;
     // it hands irregular chunks back (reg_end = kDecRedo) and k_decode_varint redoes only those
-    static const bool no_points = getenv("CLDN_HIP_NO_POINT_DECODE") != nullptr;  // A/B switch
+    static const bool no_points = dev_env("CLDN_HIP_NO_POINT_DECODE") != nullptr;  // A/B switch
     const bool points_kernel = fast && !no_points && all_qf32 && (P.n_ops == 3u || P.n_ops == 4u) && P.n_gorilla == 0u;
     bool stream_cols = false;  // the stream kernel stores the integer fields with the points (columns in front of it)
     bool many_used = false;  // the point kernel merged the columns of 3..8 integer channels (chunks it left: the old section kernels)
@@ -150,12 +151,12 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       // NF: Palette sections the launch can fold into the point pass (sizes its LDS)
       // round 4: the barrier-free kernel (stage1_decode_wave.h) is the default; CLDN_HIP_POINT_KERNEL=tiles brings the
       // tile kernel back (A/B in the same binary), =w8 runs it with 8 waves per workgroup instead of 16
-      static const char* pk_env = getenv("CLDN_HIP_POINT_KERNEL");
+      static const char* pk_env = dev_env("CLDN_HIP_POINT_KERNEL");
       static const int pk = pk_env == nullptr ? 16 : (strcmp(pk_env, "tiles") == 0 ? 0 : 16);
       uint32_t nf = (L.uses_v5 && P.n_adaptive <= kFastPalFields) ? P.n_adaptive : 0u;
       // round 4: 3..8 integer channels (all of 2 or 4 bytes): their sections go to dense columns side by side in front of the
       // point kernel (stage1_decode_sections_w.h), which merges them -- every point is written once
-      static const bool no_many = getenv("CLDN_HIP_NO_SECTIONS_W") != nullptr;  // A/B switch
+      static const bool no_many = dev_env("CLDN_HIP_NO_SECTIONS_W") != nullptr;  // A/B switch
       bool many = !no_many && pk != 0 && L.uses_v5 && P.n_adaptive > kFastPalFields && P.n_adaptive <= kSoMaxFields && L.dsec != nullptr &&
                   L.sec_cols != nullptr && L.reg_end_pre != nullptr;
       for (uint32_t a = 0; a < P.n_adaptive && many; ++a) many = P.adaptive[a].bpv <= 4u && L.cols[a] != nullptr;
@@ -165,7 +166,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         nf = 8u;
         many_used = true;
         hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u, 0u);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
         DecChunk* dsec = reinterpret_cast<DecChunk*>(L.dsec);
         hipLaunchKernelGGL(k_section_offsets, dim3(L.n_chunks), dim3(kSoThreads), 0, L.stream, P, L.streams,
@@ -190,29 +191,37 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_sections_done");
       }
       // sections that are no small palettes go to dense columns first (every point is then written once)
-      static const bool no_cols = getenv("CLDN_HIP_NO_DECODE_COLS") != nullptr;  // A/B switch
-      static const bool no_hint = getenv("CLDN_HIP_NO_PALETTE_HINT") != nullptr;  // A/B switch
+      static const bool no_cols = dev_env("CLDN_HIP_NO_DECODE_COLS") != nullptr;  // A/B switch
+      static const bool no_hint = dev_env("CLDN_HIP_NO_PALETTE_HINT") != nullptr;  // A/B switch
       bool cols = !no_cols && !many && nf != 0u && L.cols[0] != nullptr && L.sec_cols != nullptr && !(L.palette_hint && !no_hint && pk != 0);
       for (uint32_t a = 0; a < P.n_adaptive && cols; ++a) cols = P.adaptive[a].bpv <= 4u && L.cols[a] != nullptr;
       if (cols) {
         {
-          static const int lw = getenv("CLDN_HIP_LOCATE_WAVES") ? atoi(getenv("CLDN_HIP_LOCATE_WAVES")) : 0;  // A/B switch
+          static const int lw = dev_env_int("CLDN_HIP_LOCATE_WAVES", 0);  // A/B switch
           // (16 waves per chunk measured slower on C3 / C4 / C5: 0.452 / 0.572 / 0.140 against 0.433 / 0.552 / 0.137 ms; small
           // batches -- the ones that take the SPLIT launches -- have CUs to spare: 4 -> 16 waves per chunk)
           const bool wide = lw >= 16 || (lw == 0 && L.n_chunks <= 64u);
           if (wide) hipLaunchKernelGGL(k_locate_sections<16>, dim3(L.n_chunks), dim3(1024), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u, 1u);
           else hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u, 1u);
         }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
-        static const bool no_scf = getenv("CLDN_HIP_NO_FAST_COLS") != nullptr;  // A/B switch
+        static const bool no_scf = dev_env("CLDN_HIP_NO_FAST_COLS") != nullptr;  // A/B switch
         const bool scf = !no_scf && P.n_adaptive == 1u && L.slice_rec != nullptr && L.slices_done != nullptr;
+        if (scf && P.adaptive[0].bpv <= 4u) {
+          // round 6: a DeltaVarint section by the point decoder's machinery, one workgroup of 16 waves per chunk
+          // (stage1_decode_dv.h); chunks it hands back (long tokens, other modes) go on to the kernels below
+          hipLaunchKernelGGL(k_section_dv_w, dim3(L.n_chunks), dim3(kDvWaves * 64u), (DvwLds::kTotal), L.stream, P, L.streams,
+                             reinterpret_cast<const DecChunk*>(L.chunks), L.cols[0], (const uint32_t*)L.reg_end_pre, L.sec_cols,
+                             (const uint32_t*)L.slices_done);
+          if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_dv_w");
+        }
         if (scf) {
           // workgroups per chunk: one when the batch has chunks enough to fill the chip (C3, 512 chunks: 0.404 / 0.400 /
           // 0.402 / 0.404 ms with 1 / 2 / 4 / 8; workgroups that find nothing to share cost C4 about 20 us per
           // 1024 of them), more for a single cloud's few chunks
-          static const int parts_env = getenv("CLDN_HIP_SCF_PARTS") ? atoi(getenv("CLDN_HIP_SCF_PARTS")) : 0;  // A/B switch
+          static const int parts_env = dev_env_int("CLDN_HIP_SCF_PARTS", 0);  // A/B switch
           uint32_t parts = parts_env > 0 ? (uint32_t)parts_env : (512u + L.n_chunks - 1u) / L.n_chunks;
           parts = std::min<uint32_t>(std::max<uint32_t>(parts, 1u), kScfMaxParts);
           hipLaunchKernelGGL(k_sections_cols_fast, dim3(L.n_chunks * parts), dim3(kScfThreads), 0, L.stream, P, L.streams,
@@ -233,6 +242,11 @@ int stage1_launch_decode(const DecodeLaunch& L) {
   hipLaunchKernelGGL((k_decode_points<NOPS_, NF_>), dim3(L.n_chunks), dim3(kFpThreads), (FpLds<NOPS_, NF_>::kTotal), L.stream, \
                      P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done, L.uses_v5,  \
                      L.status, c0, c1, L.reg_end_pre, sc, fill_zero)
+#ifdef CLDN_DEV  // (CLDN_HIP_POINT_KERNEL=tiles: the round-3 tile kernel, an A/B reference of the development build)
+#define LAUNCH_POINTS_TILES(NOPS_, NF_) if (pk == 0) LAUNCH_POINTS(NOPS_, NF_); else
+#else
+#define LAUNCH_POINTS_TILES(NOPS_, NF_)
+#endif
 #define LAUNCH_POINTS_W(NOPS_, NF_, NW_, WPE_)                                                                            \
   hipLaunchKernelGGL((k_decode_points_w<NOPS_, NF_, NW_, WPE_>), dim3(L.n_chunks), dim3(NW_ * 64), (WpLds<NOPS_, NF_, NW_>::kTotal), \
                      L.stream, P, L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.sec_done,   \
@@ -257,12 +271,12 @@ int stage1_launch_decode(const DecodeLaunch& L) {
   }
 #define LAUNCH_POINTS_ANY(NOPS_, NF_)                      \
   {                                                        \
-    if (pk == 0) LAUNCH_POINTS(NOPS_, NF_);                \
-    else LAUNCH_POINTS_W(NOPS_, NF_, 16, 8);               \
+    LAUNCH_POINTS_TILES(NOPS_, NF_)                        \
+    LAUNCH_POINTS_W(NOPS_, NF_, 16, 8);                    \
   }
       // store-mode instantiations of the two headline layouts (XYZ, XYZ + one 16-bit field): the layout facts the kernel
       // otherwise keeps as uniform flags are checked here. CLDN_HIP_NO_STORE_MODES=1: A/B switch
-      static const bool no_sm = getenv("CLDN_HIP_NO_STORE_MODES") != nullptr;
+      static const bool no_sm = dev_env("CLDN_HIP_NO_STORE_MODES") != nullptr;
       int sm = 0;
       if (!no_sm && pk == 16 && P.n_ops == 3u && nf <= 1u) {
         bool ok = ((P.point_step | P.ops[0].offset) & 3u) == 0u && P.ops[0].offset != 0xffffffffu &&
@@ -275,11 +289,9 @@ int stage1_launch_decode(const DecodeLaunch& L) {
             sm = 2;
         }
       }
-      // SPLIT launches for batches that do not fill the chip (CLDN_HIP_NO_SPLIT_DECODE=1: A/B switch; CLDN_HIP_SPLIT_PARTS=n)
-      static const bool no_split = getenv("CLDN_HIP_NO_SPLIT_DECODE") != nullptr;
-      static const int parts_env = getenv("CLDN_HIP_SPLIT_PARTS") ? atoi(getenv("CLDN_HIP_SPLIT_PARTS")) : 0;
-      const uint32_t split_parts = no_split || L.wp_split == nullptr || pk != 16 ? 1u
-                                   : (parts_env > 0 ? (uint32_t)std::min(parts_env, 16) : wp_split_parts(L.n_chunks));
+      // SPLIT launches for batches that do not fill the chip (L.wp_parts: wp_split_parts(n_chunks), or what the test hook
+      // cldn_hip_debug_decode_split asked for)
+      const uint32_t split_parts = L.wp_split == nullptr || pk != 16 ? 1u : std::max(1u, L.wp_parts);
       WpSplit wsp = {};
       if (split_parts > 1u) {
         uint8_t* w = (uint8_t*)L.wp_split;
@@ -325,6 +337,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         else LAUNCH_POINTS_W(4, 8, 16, 8);
       }
 #undef LAUNCH_POINTS_ANY
+#undef LAUNCH_POINTS_TILES
 #undef LAUNCH_POINTS_SPLIT
 #undef LAUNCH_POINTS_W_SM
 #undef LAUNCH_POINTS_W
@@ -335,7 +348,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     // Behind k_decode_points, for plans whose sections it can fold, the rest is normally idle: one launch covers it
     // (plans with more adaptive fields keep the separate kernels: their Palette chunks really run k_decode_sections_small,
     // which wants its own, smaller LDS footprint)
-    static const bool no_tail = getenv("CLDN_HIP_NO_DECODE_TAIL") != nullptr;  // A/B switch
+    static const bool no_tail = dev_env("CLDN_HIP_NO_DECODE_TAIL") != nullptr;  // A/B switch
     const bool sections_any = L.uses_v5 && P.n_adaptive > 0u;
     if (points_kernel && !no_tail && (!sections_any || P.n_adaptive <= kFastPalFields)) {
       const uint32_t lds = sections_any ? std::max<uint32_t>(std::max<uint32_t>((uint32_t)Dv2Lds<4, false, 16>::kTotal, kSmallSecLds), (uint32_t)DecSecLds::kTotal)
@@ -348,24 +361,24 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     }
     // regular streams with raw (FieldEncoderCopy) fields between the varints: k_mark_token_ends lays out where the tokens
     // end, the 64-bit token kernel takes the ends from there (the plan says whether the stream has that form)
-    static const bool no_mixed = getenv("CLDN_HIP_NO_MIXED_DECODE") != nullptr;  // A/B switch
+    static const bool no_mixed = dev_env("CLDN_HIP_NO_MIXED_DECODE") != nullptr;  // A/B switch
     const bool mixed = !fast && !no_fast && !no_mixed && P.varint_and_raw != 0u && L.token_ends != nullptr;
     if (mixed) {
-      static const bool no_stream_mixed = getenv("CLDN_HIP_NO_STREAM_KERNEL") != nullptr;  // A/B switch
+      static const bool no_stream_mixed = dev_env("CLDN_HIP_NO_STREAM_KERNEL") != nullptr;  // A/B switch
       const bool stream_ok = !no_stream_mixed && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes;
       bool all_raw = true;  // points of a fixed size: the stream kernel needs no bitmap
       for (uint32_t k = 0; k < P.n_ops; ++k) all_raw = all_raw && (P.ops[k].kind == OP_COPY || P.ops[k].kind == OP_XOR32 || P.ops[k].kind == OP_XOR64);
       // layouts with varints AND raw fields: the stream kernel finds the points from their form (FORM instantiation);
       // CLDN_HIP_STREAM_BITMAP=1 keeps k_mark_token_ends' bitmap in front of it (A/B switch)
-      static const bool force_bitmap = getenv("CLDN_HIP_STREAM_BITMAP") != nullptr;
+      static const bool force_bitmap = dev_env("CLDN_HIP_STREAM_BITMAP") != nullptr;
       // round 5: forms of at most 16 states get their token ends from k_mark_ends_automaton (stage1_decode_automaton.h) and
       // the stream kernel's bitmap mode; CLDN_HIP_FORM_KERNEL=1 keeps the round-4 FORM instantiation (A/B switch)
-      static const bool form_kernel = getenv("CLDN_HIP_FORM_KERNEL") != nullptr;
+      static const bool form_kernel = dev_env("CLDN_HIP_FORM_KERNEL") != nullptr;
       const bool automaton = stream_ok && !all_raw && !force_bitmap && !form_kernel && automaton_states(P) != 0u && L.token_ends != nullptr;
       const bool form = stream_ok && !all_raw && !force_bitmap && !automaton;
       // streams of fixed-size tokens only (lossless floats, raw copies; <= 8 fields): nothing to find, k_decode_fixed.
       // CLDN_HIP_NO_FIXED_DECODE=1: the stream kernel (A/B switch)
-      static const bool no_fixed_dec = getenv("CLDN_HIP_NO_FIXED_DECODE") != nullptr;
+      static const bool no_fixed_dec = dev_env("CLDN_HIP_NO_FIXED_DECODE") != nullptr;
       uint32_t fixed_bytes = 0u;
       if (!no_fixed_dec && all_raw && P.n_ops <= kFxMaxOps && P.n_gorilla == 0u)
         for (uint32_t k = 0; k < P.n_ops; ++k) fixed_bytes += P.ops[k].size;
@@ -410,13 +423,13 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     } else if (fast) {
       // round 4: general streams of varint tokens go through the barrier-free stream kernel first (stage1_decode_stream.h);
       // the tile kernel behind it only redoes the chunks it hands back. CLDN_HIP_NO_STREAM_KERNEL=1: A/B switch
-      static const bool no_stream = getenv("CLDN_HIP_NO_STREAM_KERNEL") != nullptr;
+      static const bool no_stream = dev_env("CLDN_HIP_NO_STREAM_KERNEL") != nullptr;
       const bool stream_kernel = !no_stream && !points_kernel && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes;
       // round 4: the integer fields of such a stream (1..8 of 2 / 4 bytes) go to dense columns FIRST -- the sections are
       // found by counting token ends (k_locate_sections), sized and decoded side by side -- and the stream kernel stores them
       // with the points: every point is written once (DDS layout with 1 us stamps: the ring column behind the points cost
       // 0.17 of 0.74 ms). Chunks whose sections did not all arrive take the passes below. CLDN_HIP_NO_STREAM_COLS=1: A/B switch
-      static const bool no_stream_cols = getenv("CLDN_HIP_NO_STREAM_COLS") != nullptr;
+      static const bool no_stream_cols = dev_env("CLDN_HIP_NO_STREAM_COLS") != nullptr;
       stream_cols = stream_kernel && !no_stream_cols && L.uses_v5 && P.n_adaptive >= 1u && P.n_adaptive <= kSoMaxFields && L.dsec != nullptr &&
                     L.sec_cols != nullptr && L.reg_end_pre != nullptr && L.slices_done != nullptr;
       for (uint32_t a = 0; a < P.n_adaptive && stream_cols; ++a) stream_cols = P.adaptive[a].bpv <= 4u && L.cols[a] != nullptr;
@@ -424,7 +437,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         DecColumns dcols = {};
         for (uint32_t a = 0; a < 8u; ++a) dcols.p[a] = L.cols[a];
         hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 1u);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 1u, 0u);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
         DecChunk* dsec = reinterpret_cast<DecChunk*>(L.dsec);
         hipLaunchKernelGGL(k_section_offsets, dim3(L.n_chunks), dim3(kSoThreads), 0, L.stream, P, L.streams,
@@ -473,7 +486,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     }
     // round 4: streams with ONE Gorilla-coded field (FLOAT64 without resolution, wire version >= 4: the reference's own DDS
     // sample layout) next to varints and raw fields: MODE 2 of the stream kernel; CLDN_HIP_NO_GORILLA_KERNEL=1: A/B switch
-    static const bool no_gor = getenv("CLDN_HIP_NO_GORILLA_KERNEL") != nullptr;
+    static const bool no_gor = dev_env("CLDN_HIP_NO_GORILLA_KERNEL") != nullptr;
     if (!fast && !no_fast && !no_gor && P.n_gorilla >= 1u && P.n_ops >= 2u && P.n_ops <= kSwMaxOps && P.max_regular_bytes <= kSwMaxPointBytes) {
       bool ok = true;
       for (uint32_t k = 0; k < P.n_ops && ok; ++k) {
@@ -493,7 +506,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
     const bool fast_sections = fast && L.uses_v5 && P.n_adaptive > 0u;
     // round 4: the sections of a chunk side by side (stage1_decode_sections_w.h): sized without decoding, then one
     // workgroup per (chunk, field); chunks it does not finish stay with the kernels below. CLDN_HIP_NO_SECTIONS_W=1: A/B switch
-    static const bool no_sw = getenv("CLDN_HIP_NO_SECTIONS_W") != nullptr;
+    static const bool no_sw = dev_env("CLDN_HIP_NO_SECTIONS_W") != nullptr;
     // (stream_cols: the sections went out with the points; what is left -- irregular chunks -- takes the two launches below)
     bool sections_w = fast_sections && !no_sw && !many_used && !stream_cols && L.dsec != nullptr && P.n_adaptive <= kSoMaxFields;
     for (uint32_t a = 0; a < P.n_adaptive && sections_w; ++a) sections_w = P.adaptive[a].bpv <= 4u;

@@ -194,7 +194,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                          const DecChunk* __restrict__ chunks, uint32_t n_ops,
                                                          uint32_t* __restrict__ reg_end_pre, uint8_t* __restrict__ sec_cols,
-                                                         uint32_t* __restrict__ slices_done, uint32_t keep_guess) {
+                                                         uint32_t* __restrict__ slices_done, uint32_t keep_guess, uint32_t try_dv) {
   __shared__ uint32_t wcnt[NW];
   __shared__ uint32_t found, pal_sh[2];
   const uint32_t c = blockIdx.x;
@@ -273,6 +273,61 @@ __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan,
         slices_done[c] = 3u << 24;
       }
       return;
+    }
+    // A lone DeltaVarint section (round 6; rgba of a depth camera) is found from the end too: [0][n varints] closes the
+    // payload, so its mode byte is the (n + 1)-th byte with a clear MSB counted from the payload's end -- if that byte is
+    // a 0 behind at least n * n_ops bytes of regular stream, that is the guess (C3: the section is a quarter of the payload,
+    // the count from the front reads the other three). Like the guesses above it is verified by where the point kernel's
+    // tokens end; a miss costs the tiles read here and goes on to the count below.
+    if (closed && n_ops != 0u && try_dv != 0u) {
+      __syncthreads();  // (cand is read above)
+      if (tid == 0u) cand[0] = 0xffffffffu;
+      constexpr uint32_t TILE = T * 64u;  // bytes per step: four units per thread, thread 0 the LAST 64 bytes of the tile
+      uint32_t seen = 0u, hi = src_size;  // ends behind the tile; the tile is [hi - TILE, hi)   (uniform)
+      while (hi >= TILE + 16u) {          // (a tile that would touch the payload's first bytes: no guess)
+        const uint32_t mine = hi - (tid + 1u) * 64u;  // my 64 bytes
+        uint32_t e4[4], cnt4 = 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {  // unit u = bytes [mine + 48 - 16 u, + 16): u = 0 is the last one
+          uint4 w;
+          __builtin_memcpy(&w, src + mine + 48u - 16u * u, 16);
+          const uint32_t bb[4] = {w.x, w.y, w.z, w.w};
+          e4[u] = fp_ends16(bb);
+          cnt4 += (uint32_t)__builtin_popcount(e4[u]);
+        }
+        uint32_t in_tile;
+        const uint32_t behind = block_exclusive_scan<(int)T>(cnt4, scan_tmp, &in_tile);  // ends of the tile behind my bytes (barriers inside)
+        if (seen + in_tile >= n + 1u) {  // uniform: the wanted end lies in this tile
+          const uint32_t want = n + 1u - seen;  // its rank counted from the tile's end, 1-based
+          if (behind < want && want <= behind + cnt4) {
+            uint32_t k = want - behind;
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+              const uint32_t cu = (uint32_t)__builtin_popcount(e4[u]);
+              if (k != 0u && k <= cu) {
+                uint32_t m = e4[u];
+                for (; k > 1u; --k) m &= ~(0x80000000u >> __builtin_clz(m));  // drop the ends behind the wanted one
+                cand[0] = mine + 48u - 16u * u + (31u - (uint32_t)__builtin_clz(m));
+                k = 0u;
+              } else if (k != 0u) {
+                k -= cu;
+              }
+            }
+          }
+          break;
+        }
+        seen += in_tile;
+        hi -= TILE;
+      }
+      __syncthreads();
+      const uint32_t at = cand[0];
+      if (at != 0xffffffffu && at >= n * n_ops && src[at] == 0u) {  // uniform
+        if (tid == 0) {
+          reg_end_pre[c] = at;
+          slices_done[c] = 0u;  // (mode byte 0 in the top byte, no slice done)
+        }
+        return;
+      }
     }
   }
   const uint32_t part = (((src_size + 15u) / 16u + (NW - 1u)) / NW) * 16u;  // bytes per wave, multiple of 16
@@ -406,6 +461,7 @@ __global__ __launch_bounds__(kScfThreads) void k_sections_cols_fast(const DevPla
   const uint32_t part = blockIdx.x % parts;
   const uint32_t tid = threadIdx.x;
   if (part != 0u && (slices_done[c] >> 24) != 0u) return;  // only DeltaVarint sections are shared
+  if (sec_cols[c]) return;  // k_section_dv_w (round 6) has decoded the chunk's section
   const DecChunk dc = chunks[c];
   if (!dc.valid || plan.n_adaptive != 1u || plan.adaptive[0].bpv > 4u) return;
   const uint8_t* src = streams + dc.src_off;

@@ -150,6 +150,45 @@ __device__ __forceinline__ void wp_value_at(const uint32_t (&pk_lo)[4], const ui
   asm("v_mad_i32_i24 %0, %1, -4, %0" : "+v"(addr) : "v"(is_end));  // + 4 behind an end
 }
 
+// phase V for one unit: the packed groups of the unit's four dwords (pk) -> the values of the tokens that end in the unit, each
+// into its slot (addr: the slot of the unit's first token)
+__device__ __forceinline__ void wp_scatter16(const uint32_t (&pk)[4], uint32_t e20, uint32_t ev, uint32_t addr, uint32_t dummy) {
+  uint32_t pk_lo[4], pk_hi[4];
+  const uint32_t pk_front = wp_from_lane_below(pk[3]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    pk_lo[k] = (pk[k] << 28) | (k ? pk[k ? k - 1 : 0] : pk_front);
+    pk_hi[k] = pk[k] >> 4;
+  }
+  wp_value_at<0>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<1>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<2>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<3>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<4>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<5>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<6>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<7>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<8>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<9>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<10>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<11>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<12>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<13>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<14>(pk_lo, pk_hi, e20, ev, addr, dummy);
+  wp_value_at<15>(pk_lo, pk_hi, e20, ev, addr, dummy);
+}
+
+// the bytes of a unit that hand the chunk back (see the head of the file): the end of a token of 5 bytes or more, a 0x00 byte
+// behind a byte that continues a token. e20: the end flags of the unit and of the four bytes in front of it; ev: the ends asked about
+__device__ __forceinline__ uint32_t wp_flaws16(const uint32_t (&b)[4], uint32_t e20, uint32_t ev) {
+  const uint32_t c20 = ~e20;  // bit 4 + j: byte j continues a token
+  const uint32_t run2 = c20 & (c20 << 1);
+  const uint32_t run4 = run2 & (run2 << 2);                     // bit i: bytes i - 3 .. i of the 20 continue
+  const uint32_t longer = e20 & (run4 << 1);                    // an end behind four of them: a token of 5 bytes or more
+  const uint32_t zero_end = (~wp_nonzero16(b) & 0xffffu) << 4;  // 0x00 bytes ...
+  return ((longer | (zero_end & (c20 << 1))) >> 4) & ev;        // ... behind a byte that continues
+}
+
 // SPLIT launches (round 5, small batches: fewer chunks than the chip has room for): the pieces of a chunk are spread over
 // gridDim.y workgroups and the two chains are replaced by three light kernels' results in global memory --
 //   k_wp_counts   t0[piece] = token ends in front of the piece (the popcounts of chain 1, one block scan per chunk)
@@ -339,43 +378,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     WP_T(0)
     // ---- phase V: every token's value -> its slot
     const uint32_t e20 = (wp_from_lane_below(eraw) >> 12) | (eraw << 4);
-    uint32_t flaws;  // bit j: byte j of my unit gives the chunk back (see the head of the file)
+    uint32_t flaws = wp_flaws16(b, e20, evc);  // bit j: byte j of my unit gives the chunk back (see the head of the file)
     {
-      const uint32_t c20 = ~e20;  // bit 4 + j: byte j continues a token
-      const uint32_t run2 = c20 & (c20 << 1);
-      const uint32_t run4 = run2 & (run2 << 2);                     // bit i: bytes i - 3 .. i of the 20 continue
-      const uint32_t longer = e20 & (run4 << 1);                    // an end behind four of them: a token of 5 bytes or more
-      const uint32_t zero_end = (~wp_nonzero16(b) & 0xffffu) << 4;  // 0x00 bytes ...
-      flaws = ((longer | (zero_end & (c20 << 1))) >> 4) & evc;      // ... behind a byte that continues
-    }
-    {
-      uint32_t pk[4], pk_lo[4], pk_hi[4];
+      uint32_t pk[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) pk[k] = wp_pack7(b[k]);
-      const uint32_t pk_front = wp_from_lane_below(pk[3]);
       load_unit(min(p + p_step, n_pieces) * kWpPiece + lane * 16u - 16u, b);  // my next piece's bytes are requested now (b is free)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        pk_lo[k] = (pk[k] << 28) | (k ? pk[k ? k - 1 : 0] : pk_front);
-        pk_hi[k] = pk[k] >> 4;
-      }
-      uint32_t addr = vals_lds + tb * 4u;
-      wp_value_at<0>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<1>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<2>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<3>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<4>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<5>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<6>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<7>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<8>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<9>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<10>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<11>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<12>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<13>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<14>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
-      wp_value_at<15>(pk_lo, pk_hi, e20, ev, addr, dummy_lds);
+      wp_scatter16(pk, e20, ev, vals_lds + tb * 4u, dummy_lds);
     }
     WP_T(1)
     // ---- chain 1: token ends in front of the piece

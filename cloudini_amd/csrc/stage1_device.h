@@ -2,10 +2,25 @@
 #pragma once
 
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <hip/hip_runtime.h>
 
 namespace cldn {
+
+// A/B and profiling switches (the CLDN_HIP_* environment variables the development rounds used) exist only in a build with
+// -DCLDN_DEV (tools/dev/variants2.sh): the shipped library reads none of them -- every `dev_env(...)` below is a constant
+// null pointer there, the branch behind it is folded away, and no environment variable can change what the kernels write.
+#ifdef CLDN_DEV
+inline const char* dev_env(const char* name) { return getenv(name); }
+inline int dev_env_int(const char* name, int otherwise) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : otherwise;
+}
+#else
+constexpr const char* dev_env(const char*) { return nullptr; }
+constexpr int dev_env_int(const char*, int otherwise) { return otherwise; }
+#endif
 
 constexpr uint32_t kPointsPerChunk = 32768;  // detail::kPointsPerChunk, src/codec_common.hpp:28
 constexpr uint32_t kProbePoints = 4096;      // kAdaptiveModeProbePoints, src/v5_codec.cpp:76

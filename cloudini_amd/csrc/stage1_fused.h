@@ -31,9 +31,6 @@ __host__ __device__ constexpr uint32_t fused_region_bytes(int lanes) {
 // Round 5: the instantiations without a TAIL op size the region for 3 bytes per token (18.3 KB per workgroup instead of 30.4:
 // more workgroups per CU). A piece whose tokens do not fit -- deltas of 2^20 ticks and more on average, i.e. noise over
 // kilometres at 1 mm -- is written by fused_slow_piece straight from the input instead (same bytes, slowly).
-#ifndef CLDN_FUSED_SMALL_REGION
-#define CLDN_FUSED_SMALL_REGION 1
-#endif
 __host__ __device__ constexpr uint32_t fused_region_cap_small(int lanes) {
   return (fused_piece_points(lanes) * 3u * (uint32_t)lanes + 15u) & ~15u;
 }
@@ -46,21 +43,8 @@ __host__ __device__ constexpr uint32_t fused_region_bytes_tail(int lanes) {
 
 // ceil(bits / 7) for bits < 2^16 on the full-rate 24-bit multiply-add (groups7's 32-bit product becomes a v_mad_u64_u32,
 // which issues at a quarter of the rate)
-#ifndef CLDN_FUSED_MAD24
-#define CLDN_FUSED_MAD24 1
-#endif
-#ifndef CLDN_FUSED_OR2_ALWAYS
-#define CLDN_FUSED_OR2_ALWAYS 1
-#endif
-#ifndef CLDN_FUSED_HOIST_COLS
-#define CLDN_FUSED_HOIST_COLS 2
-#endif
 __device__ __forceinline__ uint32_t groups7_u24(uint32_t bits) {
-#if CLDN_FUSED_MAD24
   return (__umul24(bits, 37u) + 222u) >> 8;
-#else
-  return groups7(bits);
-#endif
 }
 
 // value of lane l-1; lane 0 receives `carry` (wave_shr:1 leaves lane 0 untouched, so it keeps the `old` operand)
@@ -108,11 +92,7 @@ __device__ __forceinline__ void lds_or4(uint8_t* region, uint32_t off, uint32_t 
   const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
   uint32_t* w = reinterpret_cast<uint32_t*>(region + (off & ~3u));
   atomicOr(w, lo);
-#if CLDN_FUSED_OR2_ALWAYS
   atomicOr(w + 1, hi);  // (a zero OR costs an LDS cycle; the test around it a compare, two exec-mask instructions and a branch)
-#else
-  if (hi) atomicOr(w + 1, hi);
-#endif
 }
 // token of <= 5 bytes (w1 holds byte 4)
 __device__ __forceinline__ void lds_or5(uint8_t* region, uint32_t off, uint32_t w0, uint32_t w1, uint32_t len) {
@@ -240,7 +220,7 @@ template <int LANES, int LOADW, bool UNAL, int L3, bool TAIL>
 __device__ __forceinline__ void fused_body(const DevPlan& plan, const FusedArgs& A) {
   constexpr uint32_t ROWS = fused_piece_rows(LANES);
   constexpr uint32_t PIECE = fused_piece_points(LANES);
-  constexpr bool SMALL = !TAIL && CLDN_FUSED_SMALL_REGION;  // 3 bytes per token, overflowing pieces go to the slow path below
+  constexpr bool SMALL = !TAIL;  // 3 bytes per token, overflowing pieces go to the slow path below
   constexpr uint32_t REGION = TAIL ? fused_region_bytes_tail(LANES) : (SMALL ? fused_region_bytes_small(LANES) : fused_region_bytes(LANES));
   constexpr uint32_t CAP = REGION - 32u;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -374,7 +354,7 @@ __device__ __forceinline__ void fused_body(const DevPlan& plan, const FusedArgs&
   };
   // the first fields' arguments are worked out once (round 5: the row loop fetched the plan entry with scalar loads and
   // decoded it again for every row -- 45 SALU instructions and a scalar-cache round trip per row and field)
-  constexpr uint32_t kHoistCols = CLDN_FUSED_HOIST_COLS;
+  constexpr uint32_t kHoistCols = 2;
   uint32_t hc_off[kHoistCols ? kHoistCols : 1], hc_rel[kHoistCols ? kHoistCols : 1], hc_bpv[kHoistCols ? kHoistCols : 1];
   bool hc_in[kHoistCols ? kHoistCols : 1];
   uint8_t* hc_ptr[kHoistCols ? kHoistCols : 1];

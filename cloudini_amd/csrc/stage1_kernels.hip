@@ -2057,7 +2057,7 @@ uint32_t stage1_piece_slot_stride(const DevPlan& plan, const uint8_t* points) {
 // instantiations without a TAIL op that prefetch at most 5 dwords per point: the 64-VGPR kernel (8 waves per SIMD)
 template <int LL, int WW, bool UU, int L3>
 static void launch_fused_variant(dim3 grid, dim3 block, uint32_t lds, hipStream_t stream, const DevPlan& plan, const FusedArgs& A) {
-  if constexpr (WW <= 5 && CLDN_FUSED_SMALL_REGION != 0)
+  if constexpr (WW <= 5)
     hipLaunchKernelGGL((k_encode_fused_w8<LL, WW, UU, L3>), grid, block, lds, stream, plan, A);
   else
     hipLaunchKernelGGL((k_encode_fused<LL, WW, UU, L3>), grid, block, lds, stream, plan, A);
@@ -2071,7 +2071,7 @@ static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piec
   A.points_end = L.points_end;
   A.pieces = L.pieces + piece0;
   A.cols = L.cols;
-  static const uint32_t ablate_f = getenv("CLDN_HIP_ABLATE") ? (uint32_t)atoi(getenv("CLDN_HIP_ABLATE")) : 0u;  // profiling only
+  static const uint32_t ablate_f = (uint32_t)dev_env_int("CLDN_HIP_ABLATE", 0);  // profiling only
   A.ablate = ablate_f;
   A.slots = L.slots;
   A.slot_stride = L.slot_stride;
@@ -2079,7 +2079,7 @@ static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piec
   A.segs = L.segs;
   A.segs_per_chunk = L.segs_per_chunk;
   // mode probe next to the pieces: fields of 2 and 4 bytes (the distinct-value structure has to fit the launch's LDS)
-  static const bool probe_in_piece_env = !(getenv("CLDN_HIP_PROBE_IN_PIECE") && atoi(getenv("CLDN_HIP_PROBE_IN_PIECE")) == 0);  // A/B switch
+  static const bool probe_in_piece_env = dev_env_int("CLDN_HIP_PROBE_IN_PIECE", 1) != 0;  // A/B switch
   bool probe_here = probe_in_piece_env && piece0 == 0u && L.plan->n_adaptive != 0u && !L.modes_forced && L.n_clouds != 0u &&
                     (uint64_t)L.n_clouds * L.plan->n_adaptive < (1u << 20);
   for (uint32_t a = 0; a < L.plan->n_adaptive && probe_here; ++a) probe_here = L.plan->adaptive[a].bpv <= 4u;
@@ -2103,7 +2103,7 @@ static int launch_fused(const EncodeLaunch& L, hipStream_t stream, uint32_t piec
     if (top.kind == OP_GORILLA64) A.tail_windows = reinterpret_cast<const uint16_t*>(L.pre.p[top.type]);
   }
   const uint32_t region = v.tail >= 0 ? fused_region_bytes_tail(v.lanes)
-                                      : (CLDN_FUSED_SMALL_REGION ? fused_region_bytes_small(v.lanes) : fused_region_bytes(v.lanes));
+                                      : fused_region_bytes_small(v.lanes);
   uint32_t lds = 16u + kFusedWaves * region;
   // the probe workgroups of the launch share its LDS size: a 16-bit field needs its 8 KiB value bitmap, a 32-bit field a
   // hash table of 6144 slots (24.8 KB: above the 18.3 KB of four 3-byte-per-token regions -- such launches keep 6
@@ -2157,7 +2157,7 @@ static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c
   uint8_t* flags = L.fallback_flags + (size_t)c0 * na;
   ColumnPtrs rank_cols;
   for (int a = 0; a < kMaxAdaptive; ++a) rank_cols.p[a] = reinterpret_cast<uint8_t*>(L.ranks[a]);
-  static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
+  static const bool no_fast = dev_env("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
   // One launch per kernel type covers all the fields of that type (grid.y): the fields are independent and every one of
   // these kernels is latency-bound at one workgroup per chunk, so a schema with five integer channels gets five times
   // the workgroups in flight instead of five launches in a row.
@@ -2192,7 +2192,7 @@ static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c
   {
     // 512-thread workgroups (two bitmap words and two groups of 32 values per thread): four of them fit a CU, so a batch
     // of up to 1024 chunks is one generation (C2: sections 0.066 -> 0.062 ms); CLDN_HIP_PAL32_THREADS=1024 is the A/B switch
-    static const bool pal1024 = getenv("CLDN_HIP_PAL32_THREADS") && atoi(getenv("CLDN_HIP_PAL32_THREADS")) == 1024;
+    static const bool pal1024 = dev_env_int("CLDN_HIP_PAL32_THREADS", 0) == 1024;
     if (pal1024)
       hipLaunchKernelGGL((k_section_palette32<uint16_t, kS2Threads>), dim3(nch, pal16.n), dim3(kS2Threads), Pal32<uint16_t>::kLds, stream, SEC_ARGS(pal16), rank_cols, L.status);
     else
@@ -2233,7 +2233,7 @@ extern "C" __attribute__((visibility("default"))) int cldn_hip_debug_finish_trac
 
 // bytes per point of a regular stream made of fixed-size encoders only (XOR-coded floats, raw copies), 0 otherwise
 static uint32_t fixed_point_bytes(const DevPlan& P) {
-  static const bool off = getenv("CLDN_HIP_NO_FIXED_ENCODE") != nullptr;  // A/B switch
+  static const bool off = dev_env("CLDN_HIP_NO_FIXED_ENCODE") != nullptr;  // A/B switch
   if (off || P.n_ops == 0u || P.n_gorilla != 0u) return 0u;
   uint32_t bytes = 0u;
   for (uint32_t k = 0; k < P.n_ops; ++k) {
@@ -2337,7 +2337,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   if (L.wide) return launch_encode_wide(L);
   // CLDN_HIP_FINISH (A/B switch): 0 = the round-2 kernels (k_chunk_offsets + k_compact), 1 = k_finish without the fused
   // Palette section, 2 (default) = k_finish with it where the schema allows
-  static const int finish_mode = getenv("CLDN_HIP_FINISH") ? atoi(getenv("CLDN_HIP_FINISH")) : 2;
+  static const int finish_mode = dev_env_int("CLDN_HIP_FINISH", 2);
   // the field whose Palette sections k_finish builds itself: the first 2- or 4-byte adaptive field that may commit Palette
   uint32_t fused_field = kNoFusedField;
   if (finish_mode >= 2 && L.n_chunks && !L.chunks_only) {
@@ -2371,7 +2371,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     const uint64_t total = 4ull * L.n_chunks + (uint64_t)pb * total_points;
     // without integer columns every size is known here: the kernel writes the framed streams themselves (an output that is too
     // small takes the slot path, whose k_finish reports it). CLDN_HIP_NO_FIXED_DIRECT=1: A/B switch
-    static const bool no_direct = getenv("CLDN_HIP_NO_FIXED_DIRECT") != nullptr;
+    static const bool no_direct = dev_env("CLDN_HIP_NO_FIXED_DIRECT") != nullptr;
     const bool direct = !no_direct && !L.chunks_only && finish_mode != 0 && L.plan->n_adaptive == 0u && total <= L.out_capacity;
     hipLaunchKernelGGL(k_encode_fixed, dim3(L.n_chunks, kPointsPerChunk / 256u), dim3(256), 0, L.stream, *L.plan, L.points, L.chunks,
                        L.slots, L.slot_stride, L.segs, L.segs_per_chunk, L.subs, L.sub_points, L.sub_stride, pb, L.cols,
@@ -2391,7 +2391,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   } else if (L.n_chunks) {
     int l3 = 3;
     const int lanes = floatn_lanes(*L.plan, L.points, &l3);
-    static const uint32_t ablate = getenv("CLDN_HIP_ABLATE") ? (uint32_t)atoi(getenv("CLDN_HIP_ABLATE")) : 0u;  // profiling only
+    static const uint32_t ablate = (uint32_t)dev_env_int("CLDN_HIP_ABLATE", 0);  // profiling only
     const bool unal = lanes && floatn_unaligned(*L.plan, L.points);
     const int loadw = lanes ? floatn_loadw(*L.plan, lanes, unal, l3) : 0;
     // LDS: ring, scan scratch and one staging area per adaptive field that can be staged (at most kStagedCols)
@@ -2429,7 +2429,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
   if (L.events) (void)hipEventRecord(L.events[2], L.stream);
   const uint32_t na = L.plan->n_adaptive;
   if (na && L.n_chunks) {
-    static const bool no_fast = getenv("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
+    static const bool no_fast = dev_env("CLDN_HIP_NO_FAST_SECTIONS") != nullptr;  // A/B switch: general kernels only
     if (!L.modes_forced && !modes_probed) {
       if (!no_fast) {
         hipLaunchKernelGGL(k_probe_fast, dim3(L.n_clouds, na), dim3(kS2Threads), kProbeLds, L.stream, *L.plan, L.chunks,
@@ -2475,16 +2475,16 @@ int stage1_launch_encode(const EncodeLaunch& L) {
       F.anchor = L.fin_anchor;
       F.epoch = L.fin_epoch;
       F.ticket = L.fin_ticket;
-      static const uint32_t use_ticket = getenv("CLDN_HIP_FINISH_TICKET") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_TICKET")) : 0u;
-      static const uint32_t order = getenv("CLDN_HIP_FINISH_ORDER") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_ORDER")) : 0u;  // A/B switch
+      static const uint32_t use_ticket = (uint32_t)dev_env_int("CLDN_HIP_FINISH_TICKET", 0);
+      static const uint32_t order = (uint32_t)dev_env_int("CLDN_HIP_FINISH_ORDER", 0);  // A/B switch
       F.use_ticket = (use_ticket || L.use_ticket) ? 1u : 0u;
       F.test_timeout = L.test_timeout;
       F.order = order;
-      static const uint32_t copy_mode = getenv("CLDN_HIP_FINISH_COPY") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_COPY")) : 0u;  // A/B switch
-      static const uint32_t fin_ablate = getenv("CLDN_HIP_FINISH_ABLATE") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_ABLATE")) : 0u;  // profiling only
+      static const uint32_t copy_mode = (uint32_t)dev_env_int("CLDN_HIP_FINISH_COPY", 0);  // A/B switch
+      static const uint32_t fin_ablate = (uint32_t)dev_env_int("CLDN_HIP_FINISH_ABLATE", 0);  // profiling only
       F.copy_mode = copy_mode;
       F.trace = nullptr;
-      static const bool fin_trace = getenv("CLDN_HIP_FINISH_TRACE") != nullptr;  // profiling only
+      static const bool fin_trace = dev_env("CLDN_HIP_FINISH_TRACE") != nullptr;  // profiling only
       if (fin_trace) F.trace = stage1_finish_trace_buffer(L.n_chunks);
       F.ablate = fin_ablate;
       F.chunk_payload = L.chunk_payload;
@@ -2502,9 +2502,9 @@ int stage1_launch_encode(const EncodeLaunch& L) {
         F.fuse_col = L.cols.p[fused_field];
         F.fuse_first = L.ranks[fused_field];
         // small batches: 1024-thread workgroups (a chunk's Palette section is latency-bound: twice the threads, 0.6x the time)
-        static const uint32_t big_at = getenv("CLDN_HIP_FINISH_1024_BELOW") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_1024_BELOW")) : 200u;  // A/B switch
+        static const uint32_t big_at = (uint32_t)dev_env_int("CLDN_HIP_FINISH_1024_BELOW", 200);  // A/B switch
         const bool big = L.n_chunks < big_at;
-        static const uint32_t splits_env = getenv("CLDN_HIP_FINISH_SPLITS") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_SPLITS")) : 0u;  // A/B switch
+        static const uint32_t splits_env = (uint32_t)dev_env_int("CLDN_HIP_FINISH_SPLITS", 0);  // A/B switch
         const uint32_t splits = splits_env ? splits_env : (big ? 4u : (L.n_chunks >= 512u ? 1u : 2u));
         F.splits = splits;
         const bool u16 = L.plan->adaptive[fused_field].bpv == 2u;
@@ -2519,7 +2519,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
       } else {
         const uint32_t splits = L.n_chunks >= 1024u ? 1u : (L.n_chunks >= 256u ? 4u : 16u);
         F.splits = splits;
-        static const uint32_t ldspad = getenv("CLDN_HIP_FINISH_LDSPAD") ? (uint32_t)atoi(getenv("CLDN_HIP_FINISH_LDSPAD")) : 0u;  // experiment: occupancy
+        static const uint32_t ldspad = (uint32_t)dev_env_int("CLDN_HIP_FINISH_LDSPAD", 0);  // experiment: occupancy
         hipLaunchKernelGGL((k_finish<256, 0>), dim3(L.n_chunks * splits), dim3(256), ldspad, L.stream, F);
       }
       if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_finish");
@@ -2527,6 +2527,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     if (L.events) (void)hipEventRecord(L.events[4], L.stream);
     return CLDN_HIP_OK;
   }
+#ifdef CLDN_DEV  // (CLDN_HIP_FINISH=0: the round-2 kernels, an A/B reference of the development build)
   hipLaunchKernelGGL(k_chunk_offsets<1024>, dim3(1), dim3(1024), 0, L.stream, L.segs, L.segs_per_chunk, L.n_chunks,
                      L.cloud_first_chunk, L.n_clouds, L.chunk_payload, L.chunk_dst, L.stream_offsets);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_chunk_offsets");
@@ -2537,6 +2538,7 @@ int stage1_launch_encode(const EncodeLaunch& L) {
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_compact");
   }
   if (L.events) (void)hipEventRecord(L.events[4], L.stream);
+#endif
   return CLDN_HIP_OK;
 }
 

@@ -109,6 +109,7 @@ struct DecodeLaunch {
   // SPLIT launches of the point kernel (small batches; stage1_decode_wave.h): NULL = never split
   void* wp_split;                     // device [wp_split_bytes(n_chunks, wp_maxp)]
   uint32_t wp_maxp;                   // pieces (992 bytes) a chunk's payload may have
+  uint32_t wp_parts;                  // workgroups per chunk of the point decoder's launch (1 = chained; wp_split_parts or the test hook)
 };
 // bytes of the SPLIT workspace: per piece t0 (4) + aggregates (5 x 4) + carries (4 x 4), per chunk 4 flag words
 inline size_t wp_split_bytes(uint32_t n_chunks, uint32_t maxp) { return (size_t)n_chunks * maxp * 40u + (size_t)n_chunks * 16u + 256u; }

@@ -264,8 +264,11 @@ int cldn_hip_codec_status(cldn_hip_codec_t* codec);
  * runs out the launch reports ST_FINISH_TIMEOUT. A call with HOST outputs is then redone ONCE with the order taken from a
  * ticket counter (an atomic per workgroup, 11 us per 1000 chunks: independent of the dispatch order), and the codec keeps
  * the ticket order from then on; a call with DEVICE outputs cannot be redone by the library: cldn_hip_codec_status returns
- * CLDN_HIP_ERR_DEVICE, the codec switches to tickets, the caller repeats the call. CLDN_HIP_FINISH_TICKET=1 selects the
- * ticket order from the start. Returns the number of calls this codec has redone. */
+ * CLDN_HIP_ERR_DEVICE, the codec switches to tickets, the caller repeats the call. The ticket order is not the default
+ * because it is not free: measured on the 32 x 1 M-point batch (round 6, same box, profiles/r06_d_finish_ticket.txt) k_finish
+ * takes 0.137 instead of 0.127 ms with it, the framed step 0.292 instead of 0.282 ms. (The development build, -DCLDN_DEV,
+ * selects it from the start with CLDN_HIP_FINISH_TICKET=1; the shipped library reads no such variable.) Returns the number of
+ * calls this codec has redone. */
 uint32_t cldn_hip_codec_finish_retries(const cldn_hip_codec_t* codec);
 
 /* Optional instrumentation for bench.py's roofline line: with n_slots > 0 every encode call records HIP

@@ -574,46 +574,61 @@ def test_palette_hint_of_an_earlier_call_never_changes_bytes(oracle):
     codec.close()
 
 
-@pytest.mark.parametrize("switch", ["CLDN_HIP_NO_SPLIT_DECODE=1", "CLDN_HIP_SPLIT_PARTS=2", "CLDN_HIP_SPLIT_PARTS=16"])
-def test_chained_and_split_launches_of_the_point_kernel_agree(switch):
+@pytest.mark.parametrize("parts", [1, 2, 16])
+def test_chained_and_split_launches_of_the_point_kernel_agree(oracle, parts):
     """Small batches take the SPLIT launches of k_decode_points_w (round 5: the pieces of a chunk over several workgroups,
-    token counts and carries through global memory); batches that fill the chip keep the chained launch. The switches are
-    read once per process: every schema family and the marker / ragged / padded cases again in a process of its own with
-    the other launch shape forced, against the oracle."""
-    import os, subprocess, sys, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import sys, numpy as np
-        sys.path.insert(0, %r); sys.path.insert(0, %r)
-        import cases
-        from oracle import binding
-        from cloudini_amd import native, synth
-        orc = binding.Oracle()
-        todo = [(n, i, d) for n, i, d in cases.encode_cases(small=False)]
-        for k, gen in enumerate((synth.lidar_xyzi, synth.lidar_xyz, synth.velodyne_xyzir)):
-            info, data = gen(130048 + 777 * k, seed=20 + k)
-            f32 = data.view(np.uint8).reshape(-1, info.point_step)[:, :4].copy().view(np.float32)
-            f32[::1013] = np.nan                       # markers: the lanes reset inside pieces
-            d2 = data.view(np.uint8).reshape(-1, info.point_step).copy()
-            d2[:, :4] = f32.view(np.uint8).reshape(-1, 4)
-            todo.append((gen.__name__ + "_nan", info, d2.reshape(-1)))
-        bad = 0
-        for name, info, data in todo:
-            step = info.point_step
-            n = data.size // step
-            codec = native.Codec(native.Plan(info))
-            stream = orc.encode_stage1(info, data)
-            out = np.full(max(1, data.size), 0x5A, dtype=np.uint8)
-            got = codec.decode_host([stream, stream], [n, n], out=np.concatenate([out, out]))
-            want = orc.decode_stage1(info, stream, n, fill=0x5A)
-            if not (np.array_equal(got[0], want) and np.array_equal(got[1], want)):
-                bad += 1
-                print("MISMATCH", name)
-            codec.close()
-        print("checked", len(todo), "bad", bad)
-    """ % (root, os.path.join(root, "tests")))
-    key, val = switch.split("=")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **{key: val}))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    last = r.stdout.strip().splitlines()[-1].split()
-    assert last[0] == "checked" and int(last[1]) > 30 and last[3] == "0", r.stdout[-2000:]
+    token counts and carries through global memory); batches that fill the chip keep the chained launch. The debug call
+    cldn_hip_debug_decode_split (outside the boundary of include/cloudini_hip.h; rounds 4-5 read environment variables for
+    this, which the shipped library no longer does) forces one shape: every schema family and the marker / ragged / padded
+    cases with the chained launch and with 2 and 16 workgroups per chunk, against the oracle."""
+    from cloudini_amd import native
+    todo = [(n, i, d) for n, i, d in cases.encode_cases(small=False)]
+    for k, gen in enumerate((synth.lidar_xyzi, synth.lidar_xyz, synth.velodyne_xyzir)):
+        info, data = gen(130048 + 777 * k, seed=20 + k)
+        f32 = data.view(np.uint8).reshape(-1, info.point_step)[:, :4].copy().view(np.float32)
+        f32[::1013] = np.nan                       # markers: the lanes reset inside pieces
+        d2 = data.view(np.uint8).reshape(-1, info.point_step).copy()
+        d2[:, :4] = f32.view(np.uint8).reshape(-1, 4)
+        todo.append((gen.__name__ + "_nan", info, d2.reshape(-1)))
+    assert len(todo) > 30
+    for name, info, data in todo:
+        step = info.point_step
+        n = data.size // step
+        codec = native.Codec(native.Plan(info))
+        assert native.lib().cldn_hip_debug_decode_split(codec._h, parts) == 0
+        stream = oracle.encode_stage1(info, data)
+        out = np.full(max(1, data.size), 0x5A, dtype=np.uint8)
+        got = codec.decode_host([stream, stream], [n, n], out=np.concatenate([out, out]))
+        want = oracle.decode_stage1(info, stream, n, fill=0x5A)
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want), name
+        codec.close()
+
+
+def test_a_wrong_delta_varint_guess_from_the_end_is_found_out(oracle):
+    """k_locate_sections guesses a lone DeltaVarint section from the payload's end (round 6): the (n + 1)-th byte with a clear MSB
+    counted from the end is taken for the mode byte if it is 0. Here that byte IS 0 -- a NaN marker of the regular stream -- while
+    the section is a short Rle one: k_section_dv_w decodes n "tokens" of regular stream into the column, the point kernel finds
+    the regular stream ending elsewhere, and the chunk's sections must be redone from the right place."""
+    from cloudini_amd import native
+    hits = 0
+    for n in range(3000, 3400):
+        info, data = synth.lidar_xyzi(n, seed=n)
+        a = data.reshape(n, info.point_step).copy()
+        a[:, 0:4] = np.frombuffer(np.float32(np.nan).tobytes(), np.uint8)          # every x is NaN: a marker byte per point
+        a[:, 12:14] = np.repeat(np.arange((n + 99) // 100, dtype=np.uint16), 100)[:n].view(np.uint8).reshape(n, 2) * 0 + \
+            np.repeat((np.arange((n + 99) // 100) % 7 * 1000).astype(np.uint16), 100)[:n].view(np.uint8).reshape(n, 2)  # runs of 100: Rle / DeltaRle
+        cloud = a.reshape(-1)
+        stream, modes = oracle.encode_stage1(info, cloud, return_modes=True)
+        payload = stream[4:]
+        ends = np.nonzero((payload & 0x80) == 0)[0]
+        if len(ends) < n + 1 or payload[ends[-(n + 1)]] != 0 or ends[-(n + 1)] < 3 * n:
+            continue   # the guess would not fire for this cloud
+        hits += 1
+        codec = native.Codec(native.Plan(info))
+        out = np.full(cloud.size, 0x5A, dtype=np.uint8)
+        got = codec.decode_host([stream], [n], out=out)[0]
+        assert np.array_equal(got, oracle.decode_stage1(info, stream, n, fill=0x5A)), (n, list(modes))
+        codec.close()
+        if hits >= 6:
+            break
+    assert hits >= 3
