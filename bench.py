@@ -189,6 +189,26 @@ def e2e_figures(info, cloud, dev, budget_s: float):
         codec.decode_device(d_out.data_ptr(), offs_dev, cp, d_dec.data_ptr(), d_dec.numel(), d_sizes.data_ptr())
         codec.synchronize()
     out["device_resident_decode"] = timed(dev_decode_call)
+
+    # first call of a FRESH codec (the ROS plugins construct an encoder / a decoder per message,
+    # cloudini_publisher_plugin.cpp:53-55): workspaces cold, no mode / Palette hint from an earlier call. Codec creation
+    # (cldn_hip_codec_create: stream, status words) is outside the bracket, everything the call allocates is inside.
+    def first_call(direction):
+        ts = []
+        for _ in range(3):
+            c2 = native.Codec(plan, device=dev.index)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            if direction == "encode":
+                c2.encode_device(d_in.data_ptr(), cp, d_out.data_ptr(), cap, d_off.data_ptr())
+            else:
+                c2.decode_device(d_out.data_ptr(), offs_dev, cp, d_dec.data_ptr(), d_dec.numel(), d_sizes.data_ptr())
+            c2.synchronize()
+            ts.append(time.perf_counter() - t0)
+            c2.close()
+        return _stats_ms(ts)
+    out["first_call"] = {"encode": first_call("encode"), "decode": first_call("decode"),
+                         "note": "fresh codec per call: device workspaces are allocated inside the bracket (hipMalloc), no hints"}
     out["device_resident_decode"]["bit_exact_round_trip"] = bool(torch.equal(d_dec, d_in)) if not any(f.resolution for f in info.fields) else None
     out["device_resident_decode"]["note"] = "batches of at most 64 chunks take the SPLIT launches of the point decoder (round 5)"
 
@@ -379,6 +399,32 @@ def leg_roofline(alg_bytes: float, kernel: str, kernel_ms: float, whole_ms: floa
     return {"bound": "hbm", "algorithmic_bytes": alg_bytes, "bytes_counted": what, "kernel": kernel, "kernel_ms": kernel_ms,
             "kernel_GBps": k, "frac": None if k is None else k / HBM_PEAK_GBPS, "whole_leg_ms": whole_ms, "whole_leg_GBps": w,
             "whole_leg_frac": None if w is None else w / HBM_PEAK_GBPS, "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+
+
+def store_pattern_calibration(n_points: int):
+    """Round 6: what the decode leg's STORE PATTERN alone costs on this box (tools/hbm_calib.hip, mode points14: plain grid-stride
+    kernels, no arithmetic). A decoder that leaves the bytes no field covers alone (KEEP, the reference's behaviour) writes 12 + 2
+    of every 16-byte XYZI point: every 32-byte sector of the output is written partially and the memory side has to merge it.
+    `keep_ms` is that pattern with the encoded stream's bytes read alongside, `full_ms` the same points as whole 16-byte stores
+    (CLDN_HIP_FILL_ZERO). decode.roofline.kernel_ms is to be read against keep_ms, decode.fill_zero_ms_per_step against full_ms."""
+    exe = os.path.join(ROOT, "cloudini_amd", "lib", "hbm_calib")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "1", "points14", str(int(n_points))], capture_output=True, text=True, timeout=120)
+        best = {}
+        for line in r.stdout.splitlines():
+            for key, tag in (("12+2, +read", "keep_ms"), ("16, +read", "full_ms"), ("12+2 of 16", "keep_store_only_ms"), ("16 of 16", "full_store_only_ms")):
+                if line.startswith(key):
+                    ms = float(line.split("best")[1].split("ms")[0])
+                    best[tag] = min(best.get(tag, 1e9), ms)
+        if not best:
+            return None
+        best["what"] = ("tools/hbm_calib.hip points14: 12 + 2 of every 16 bytes written (keep) / whole 16-byte stores (full), "
+                        f"{int(n_points)} points, with / without 6.4 bytes per point read alongside; best of 9 runs and 3 grid sizes")
+        return best
+    except Exception as exc:  # a calibration that fails must never cost the line
+        return {"error": repr(exc)}
 
 
 def decode_kernel_name(info) -> str:
@@ -756,6 +802,8 @@ def main():
         decode["roofline"] = leg_roofline(total_out + points_local * step, decode_kernel_name(info),
                                           float(np.median([k["regular_kernel"] for k in dec_kernel_ms])), dec_ms,
                                           "stream bytes read + point bytes written")
+        if rank == 0 and args.workload == "c2":
+            decode["store_pattern"] = store_pattern_calibration(points_local)
     # extra (not `value`): stage 1 WITHOUT the framing -- cldn_hip_encode_stage1_chunks leaves every chunk's payload as one
     # run of its slot (the reference's own stage-1 / stage-2 boundary is a buffer per chunk, src/cloudini.cpp:590-614);
     # a device-side stage 2 or any other consumer on the GPU starts from there. Same steps, same bracket; the table is
@@ -933,7 +981,12 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "read_only_GBps": points_local * step / (regular_ms * 1e-3) / 1e9,
                          "read_only_frac": points_local * step / (regular_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "whole_stage1_GBps": points_local * (step + out_bpp) / (device_ms * 1e-3) / 1e9},
+                         "whole_stage1_GBps": points_local * (step + out_bpp) / (device_ms * 1e-3) / 1e9,
+                         # `value` times the WHOLE framed step (piece kernel + sections + k_finish + the gaps between the
+                         # launches): its algorithmic bytes over ms_per_step. `frac` above describes the dominant kernel alone.
+                         "whole_step_ms": ms_per_step,
+                         "whole_step_GBps": points_local * (step + out_bpp) / (ms_per_step * 1e-3) / 1e9,
+                         "whole_step_frac": points_local * (step + out_bpp) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         }
         if args.cpu_baseline_seconds > 0 and world == 1:
             result["cpu_baseline"] = cpu_baseline(info, distinct[0], args.cpu_baseline_seconds)

@@ -10,7 +10,7 @@
 // and several grid sizes (workgroups per CU).
 //
 // build: hipcc --offload-arch=gfx950 -O3 tools/hbm_calib.hip -o cloudini_amd/lib/hbm_calib   (cloudini_amd/build.py does it)
-// run:   cloudini_amd/lib/hbm_calib [GiB per buffer, default 1] [piece | points14]   (piece: only the piece kernel's own shape;
+// run:   cloudini_amd/lib/hbm_calib [GiB per buffer, default 1] [piece | points14 [points]]   (piece: only the piece kernel's own shape;
 //        points14: the point decoder's store shape)
 #include <hip/hip_runtime.h>
 
@@ -208,8 +208,9 @@ int main(int argc, char** argv) {
   }
   if (argc > 2 && !strcmp(argv[2], "points14")) {
     // 32 M points of 16 bytes (the bench line's decode leg): what the store pattern alone costs
-    const size_t n_pts = 32000000;
+    const size_t n_pts = argc > 3 ? (size_t)atoll(argv[3]) : 32000000;
     if (n_pts * 16u > bytes) { fprintf(stderr, "buffer too small\n"); return 1; }
+    printf("points %zu\n", n_pts);
     const int wv[] = {2, 4, 8};
     for (int w : wv) {
       run("12+2 of 16", 16.0 * n_pts, 1024, w, cus, [&](int g, int th) { hipLaunchKernelGGL((k_points14<false, false>), dim3(g), dim3(th), 0, 0, a, (uint8_t*)o, n_pts, 1.0f, s); });
