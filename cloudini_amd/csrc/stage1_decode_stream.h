@@ -467,7 +467,102 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         *changed = chg;
         return rel;
       };
+      // MODE 2 (round 6): the same table OP-OUTER / BYTE-INNER. The sixteen candidate points of a lane advance together, one
+      // op at a time: what kind of token the op writes is decided once per op (not once per byte and op), the sixteen Gorilla
+      // look-ups of an op are in flight together, and the run of varints a point begins with costs one pass over the end bits:
+      // the k-th end at or behind byte i + 1 is the k-th end behind byte i unless byte i ends a token itself (then it is the
+      // next one). Points whose leading varints do not end within 64 bytes of the lane's first byte get no entry (the chunk
+      // goes to the serial decoder if such a point is real: tokens of more than 10 bytes are malformed anyway).
+      [[maybe_unused]] auto make_jt_gor = [&](uint32_t st) __attribute__((always_inline)) {
+        // rel of the sixteen candidates: four to a register, one byte each (a point advances by at most 64 bytes in its leading
+        // varints and by at most 10 per op behind them: < 256)
+        uint32_t relp[4] = {0u, 0u, 0u, 0u};
+        auto rel_get = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t { return (relp[i >> 2] >> ((i & 3u) * 8u)) & 0xffu; };
+        auto rel_add = [&](uint32_t i, uint32_t d) __attribute__((always_inline)) { relp[i >> 2] += d << ((i & 3u) * 8u); };
+        uint32_t okm = 0xffffu, chgm = 0u;
+        const uint32_t k0 = (uint32_t)__builtin_ctzll(gor_ops | raw_ops | (1ull << n_ops));  // varints a point begins with (uniform)
+        if (k0 != 0u) {
+          uint64_t m = (((uint64_t)R[1]) << 32) | R[0];
+          for (uint32_t j = 1; j < k0; ++j) m &= m - 1ull;  // uniform trip count
+#pragma unroll
+          for (uint32_t i = 0; i < 16u; ++i) {
+            // the lowest set bit of m: the k0-th token end at or behind byte i
+            if (m == 0ull) okm &= ~(1u << i);
+            rel_add(i, m ? (uint32_t)__builtin_ctzll(m) + 1u : 64u);
+            if ((R[0] >> i) & 1u) m &= m - 1ull;
+          }
+        } else {
+          relp[0] = 0x03020100u;
+          relp[1] = 0x07060504u;
+          relp[2] = 0x0b0a0908u;
+          relp[3] = 0x0f0e0d0cu;
+        }
+        for (uint32_t o = k0; o < n_ops; ++o) {  // uniform
+          if ((gor_ops >> o) & 1ull) {
+            const uint32_t sto = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)o);
+            const uint32_t m10 = 64u - ((sto >> 8) & 0xffu) - (sto & 0xffu);
+            const uint32_t len10 = (2u + m10 + 7u) >> 3;
+            const bool have_win = (sto >> 16) != 0u;  // (no window yet: the serial decoder raises the error)
+#pragma unroll
+            for (uint32_t h = 0; h < 16u; h += 8u) {  // eight look-ups in flight
+              uint32_t w[8];
+#pragma unroll
+              for (uint32_t i = 0; i < 8u; ++i) {
+                const uint32_t bp = lane * 16u + rel_get(h + i);
+                w[i] = __builtin_amdgcn_alignbit(wbuf[(bp >> 2) + 1u], wbuf[bp >> 2], (bp & 3u) * 8u);
+              }
+#pragma unroll
+              for (uint32_t i = 0; i < 8u; ++i) {
+                const uint32_t sl = (w[i] >> 2) & 31u, m = ((w[i] >> 7) & 63u) + 1u;
+                const uint32_t nst = 0x10000u | (sl << 8) | ((64u - sl - m) & 0xffu);
+                const bool t0 = (w[i] & 1u) == 0u, t10 = (w[i] & 3u) == 1u, t11 = (w[i] & 3u) == 3u;
+                uint32_t len = t0 ? 1u : (t10 ? len10 : (m + 20u) >> 3);
+                if (p == 0u && lane * 16u + h + i == a0) len = 8u;  // the chunk's first value: raw bits
+                else {
+                  if ((t10 && !have_win) || (t11 && sl + m > 64u)) okm &= ~(1u << (h + i));
+                  if (t11 && nst != sto) chgm |= 1u << (h + i);
+                }
+                rel_add(h + i, len);
+              }
+            }
+          } else if ((raw_ops >> o) & 1ull) {
+            const uint32_t sz = (uint32_t)__builtin_amdgcn_readlane((int)size_l, (int)o) * 0x01010101u;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) relp[k] += sz;
+          } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 16u; ++i) {
+              const uint32_t rl = rel_get(i);
+              const uint32_t idx = rl >> 5, sh = rl & 31u;
+              const uint32_t elo = idx == 0u ? R[0] : (idx == 1u ? R[1] : (idx == 2u ? R[2] : (idx == 3u ? R[3] : 0u)));
+              const uint32_t ehi = idx == 0u ? R[1] : (idx == 1u ? R[2] : (idx == 2u ? R[3] : 0u));
+              const uint32_t e = __builtin_amdgcn_alignbit(ehi, elo, sh) & 0x3ffu;  // a varint has 10 bytes at most
+              if (e == 0u) okm &= ~(1u << i);
+              rel_add(i, e ? (uint32_t)__builtin_ctz(e) + 1u : 1u);
+            }
+          }
+        }
+        uint32_t packed[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) {
+          const uint32_t x = lane * 16u + i;        // byte of the piece
+          const uint32_t len = rel_get(i) - i;
+          const uint32_t end = x + len;             // (v-space, relative to the piece)
+          const bool ok = ((okm >> i) & 1u) != 0u && len <= kSwMaxPointBytes && p * kSwPiece + x >= a0 && p * kSwPiece + end <= vend;
+          uint32_t jv = ok ? end : 0xffffu;
+          if (ok && ((chgm >> i) & 1u)) jv |= 0x8000u;
+          if (i & 1u) packed[i >> 1] |= jv << 16;
+          else packed[i >> 1] = jv;
+        }
+        uint4* dst = reinterpret_cast<uint4*>(jt + lane * 16u);
+        dst[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        dst[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+      };
       auto make_jt = [&](uint32_t st) __attribute__((always_inline)) {
+        if constexpr (GOR) {
+          make_jt_gor(st);
+          return;
+        }
         uint32_t packed[8];
 #pragma unroll
         for (uint32_t i = 0; i < 16u; ++i) {
