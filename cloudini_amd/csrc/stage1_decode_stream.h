@@ -203,6 +203,11 @@ __device__ __forceinline__ uint64_t sw_gorilla(const uint32_t* wbuf, uint32_t bp
 // {entry, points, window}), then the table is built for that window and one lane follows the jumps; a point whose '11'
 // token changes the window ends the round -- the table is rebuilt for the new window from there. The token's value bits
 // are XOR differences: the op joins the XOR-coded ones in both walks.
+#ifdef CLDN_SW_TRACE
+#define SW_T(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_[k] += t_ - tl_; tl_ = t_; }
+#else
+#define SW_T(k)
+#endif
 template <int NW, int MODE>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 6 : 8, 8))) void k_decode_stream_w(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                              const DecChunk* __restrict__ chunks, uint8_t* __restrict__ out,
@@ -369,6 +374,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   const unsigned long long copy_ops = __ballot(kind_l == OP_COPY);                      // no state at all
   const unsigned long long int_ops = __ballot(kind_l == OP_INT);                        // a marker is an error there
   const unsigned long long narrow_ops = __ballot(kind_l == OP_QF32 || (kind_l == OP_INT && size_l <= 4u));  // 32 bits of the running value are all that is used
+  // FORM modes keep the first walk's values in LDS for the second (round 6) when they fit where the jump table was: 4 bytes per
+  // value of a narrow op, 8 otherwise. Lane o: the bytes per point of the ops in front of op o.
+  uint32_t vpre_l = 0u, vtot = 0u;
+  if constexpr (FORM) {
+    const uint32_t vs = lane < n_ops ? (((narrow_ops >> lane) & 1ull) ? 4u : 8u) : 0u;
+    const uint32_t incl = wave_inclusive_scan(vs);
+    vpre_l = incl - vs;
+    vtot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  }
   uint64_t run_l = 0ull;  // lane o: op o's running value (behind the last point handled so far)
   uint32_t st_last = 0u;  // MODE 2, lane o: op o's Gorilla window behind the piece this wave handled last
 
@@ -379,8 +393,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
     load_unit((min(p, n_pieces) + 1u) * kSwPiece + min(lane, 5u) * 16u, bh);
   }
   bool gave_up = false;
+#ifdef CLDN_SW_TRACE
+  unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = 0;
+  uint32_t trn_ = 0;
+#endif
   __builtin_amdgcn_s_setprio(1);
   for (; p < n_pieces; p += NW) {
+#ifdef CLDN_SW_TRACE
+    if (p == wave) tl_ = __builtin_amdgcn_s_memtime();
+#endif
+    SW_T(7)
     // ---- bytes and end bits -> LDS
     *reinterpret_cast<uint4*>(wbuf + lane * 4u) = make_uint4(b[0], b[1], b[2], b[3]);
     if (lane < 6u) *reinterpret_cast<uint4*>(wbuf + kSwPiece / 4u + lane * 4u) = make_uint4(bh[0], bh[1], bh[2], bh[3]);
@@ -583,9 +605,32 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       };
       // MODE 2: the table is built for the window this wave saw last (windows change rarely: the guess is right for all but a
       // few pieces); a piece whose guess was wrong, or whose own '11' tokens change the window, is redone in rounds below
-      const uint32_t st_pred = GOR ? st_last : 0u;
+      SW_T(0)
+      uint32_t st_pred = GOR ? st_last : 0u;
+      if constexpr (GOR) {
+        // a newer guess than this wave's own last piece: the window behind the NEWEST piece in front of this one that has
+        // published (lane l looks at piece p - 1 - l). A wave's first piece has no guess of its own: it waits until piece 0
+        // -- where a chunk's windows settle -- has published, instead of building a table for "no window" that is thrown away.
+        if (p != 0u) {
+          const uint32_t back = min(min(p, (uint32_t)NW), kSwRing - 1u);
+          for (uint32_t spins = 0;; ++spins) {
+            const uint32_t q = p - 1u - min(lane, back - 1u);  // (a piece in front of mine)
+            const unsigned long long x = wp_rec_load(trec + (q & (kSwRing - 1u)));
+            const unsigned long long have = __ballot(lane < back && (uint32_t)(x >> 32) == q + 1u);
+            if (have != 0ull) {
+              const uint32_t q1 = p - 1u - (uint32_t)__builtin_ctzll(have);
+              const unsigned long long xg = wp_rec_load(grec + (size_t)(q1 & (kSwRing - 1u)) * kSwMaxOps + min(lane, n_ops - 1u));
+              if (__ballot(lane < n_ops && (uint32_t)(xg >> 32) != q1 + 1u) == 0ull) st_pred = lane < n_ops ? (uint32_t)xg : 0u;
+              break;
+            }
+            if (p >= (uint32_t)NW || spins >= 4096u) break;  // (only a wave's first piece waits; bounded: the guess is a guess)
+            __builtin_amdgcn_s_sleep(kWpSleep);
+          }
+        }
+      }
       make_jt(st_pred);
       wp_wave_sync();
+      SW_T(1)
       // ---- the first lanes follow the jumps from their byte: where the next piece is entered, and after how many points.
       // On the way a candidate leaves a checkpoint in every 128-byte block it passes: its first point there and how many
       // came before -- the owner of the true entry then lists its points eight blocks side by side.
@@ -633,6 +678,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         ex[1] = x1;
         ec[1] = c1;
       }
+      SW_T(2)
       // ---- chain 1: {entry offset, points in front} of the piece (MODE 2: and the window at its entry)
       uint32_t entry = a0, pts0 = 0u, st = 0u;  // (st: lane o = window of op o)
       if (p != 0u) {
@@ -658,6 +704,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         pts0 = rv >> 8;
         if (GOR) st = lane < n_ops ? (uint32_t)xg : 0u;
       }
+      SW_T(3)
       if (gave_up) break;
       // (entry 0xff: the piece in front could not be left through a well-formed point -- malformed, or only the bytes
       // behind the regular stream's end; either way nothing starts here)
@@ -890,15 +937,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       return bad;
     };
 
+    SW_T(4)
     // ---- first walk: every op's aggregate over the piece (lane o: op o)
     uint64_t agg_l = 0ull;
     uint32_t aggf_l = 0u;  // lane o: op o was reset inside the piece (a marker)
     bool irregular = false;
+    // values kept for the second walk: op o's from byte npad * vpre(o) of the table's place on, the rows' marker masks behind them
+    const uint32_t npad = (npts + 1u) & ~1u;
+    const uint32_t n_rows = (npts + 63u) >> 6;
+    uint8_t* vbase = wmem + L::kJumpOff;
+    const uint32_t marks_off = (npad * vtot + 7u) & ~7u;
+    const bool keep = FORM && marks_off + n_rows * n_ops * 8u <= (n_rounds == 1u ? L::kWaveBytes - L::kJumpOff : L::kCheckOff - L::kJumpOff);  // (uniform)
     for (uint32_t r = 0; r * 64u < npts; ++r) {  // uniform
       const uint32_t j = r * 64u + lane;
       const bool have = j < npts;
       const uint32_t byte0 = have ? (uint32_t)plist[j] : 0u;
       const bool bad = walk(j, byte0, have, [&](uint32_t o, uint64_t v, bool mk) __attribute__((always_inline)) {
+        if (keep) {
+          const uint32_t vo = npad * (uint32_t)__builtin_amdgcn_readlane((int)vpre_l, (int)o);
+          if (have) {
+            if ((narrow_ops >> o) & 1ull) *reinterpret_cast<uint32_t*>(vbase + vo + j * 4u) = (uint32_t)v;
+            else *reinterpret_cast<uint64_t*>(vbase + vo + j * 8u) = v;
+          }
+          const unsigned long long mks = __ballot(mk);
+          if (lane == 0u) *reinterpret_cast<unsigned long long*>(vbase + marks_off + (r * n_ops + o) * 8u) = mks;
+        }
         if ((copy_ops >> o) & 1ull) return;
         uint64_t tot;
         bool reset = false;
@@ -932,6 +995,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       irregular = irregular || (have && bad);
     }
     if (__ballot(irregular) != 0ull && lane == 0u) misc[0] = 1u;
+    SW_T(5)
     // ---- chain 2: the running values in front of the piece (lane o: {tag, lo}, {tag | reset, hi} of op o)
     if (p != 0u) {
       const unsigned long long* r = vrec + ((size_t)((p - 1u) & (kSwRing - 1u)) * kSwMaxOps + min(lane, n_ops - 1u)) * 2u;
@@ -963,13 +1027,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         wp_rec_store(w + 1, ((unsigned long long)(p + 1u) << 32) | (incl_l >> 32));
       }
     }
+    SW_T(6)
     // ---- second walk: values, converted and stored; a lane stores its own point
     for (uint32_t r = 0; r * 64u < npts; ++r) {  // uniform
       const uint32_t j = r * 64u + lane;
       const bool have = j < npts;
       const uint32_t byte0 = have ? (uint32_t)plist[j] : 0u;
       uint8_t* pt = base + __umul24(q_first + (have ? j : 0u), step);  // (q < 2^16, step <= 1024)
-      walk(j, byte0, have, [&](uint32_t o, uint64_t v, bool mk) __attribute__((always_inline)) {
+      auto emit = [&](uint32_t o, uint64_t v, bool mk) __attribute__((always_inline)) {
         const DevOp& op = plan.ops[ob + o];
         const uint32_t off = op.offset;
         const uint32_t kind = op.kind;
@@ -1029,7 +1094,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
             st_raw(pt + off, cur, op.size);
           }
         }
-      });
+      };
+      if (keep) {
+        for (uint32_t o = 0; o < n_ops; ++o) {  // uniform
+          const uint32_t vo = npad * (uint32_t)__builtin_amdgcn_readlane((int)vpre_l, (int)o);
+          uint64_t v = 0ull;
+          if (have) {
+            if ((narrow_ops >> o) & 1ull) v = (uint64_t)(int64_t)(int32_t)*reinterpret_cast<const uint32_t*>(vbase + vo + j * 4u);
+            else v = *reinterpret_cast<const uint64_t*>(vbase + vo + j * 8u);
+          }
+          const unsigned long long mks = *reinterpret_cast<const unsigned long long*>(vbase + marks_off + (r * n_ops + o) * 8u);
+          emit(o, v, ((mks >> lane) & 1ull) != 0ull);
+        }
+      } else {
+        walk(j, byte0, have, emit);
+      }
       if (n_cols != 0u) {  // (uniform) the point's column values: all requested before the first one is stored
         const uint32_t q = q_first + (have ? j : 0u);
         uint32_t cv[8];
@@ -1049,7 +1128,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       }
     }
     wp_wave_sync();
+#ifdef CLDN_SW_TRACE
+    ++trn_;
+#endif
   }
+#ifdef CLDN_SW_TRACE
+  if (MODE == 2 && lane == 0u && (c == 0u || c == 300u) && (wave == 0u || wave == 5u || wave == 11u))
+    printf("chunk %u wave %u pieces %u: A %llu jt %llu chase %llu wait1 %llu list %llu walk1 %llu wait2 %llu walk2 %llu\n", c, wave, trn_, tr_[0], tr_[1], tr_[2],
+           tr_[3], tr_[4], tr_[5], tr_[6], tr_[7]);
+#endif
   if (gave_up && lane == 0u) {
     misc[3] = 1u;
     misc[0] = 1u;
