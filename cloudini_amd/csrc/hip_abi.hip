@@ -229,6 +229,8 @@ struct cldn_hip_codec {
   hipEvent_t ev_dec_stats = nullptr;
   uint32_t dec_stats_chunks = 0;     // chunks of the call whose copy is in flight (0 = none)
   bool dec_palette_hint = false;
+  bool dec_stats_seen = false;       // one copy of the counters has landed
+  uint32_t dec_call_index = 0;
   hipEvent_t dec_events[4] = {nullptr, nullptr, nullptr, nullptr};  // the last decode call's (timing enabled)
   bool dec_events_valid = false;
   std::vector<uint8_t> slot_valid;
@@ -1015,6 +1017,12 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   L.chunk_payload = (uint32_t*)c->d_payload.p;
   L.chunk_dst = (uint64_t*)c->d_dst.p;
   L.stream_offsets = lz4 ? (uint64_t*)c->d_s1_offsets.p : (uint64_t*)c->d_offsets.p;
+  // device-resident outputs: the kernels write the caller's stream_offsets / chunk_sizes arrays themselves (no copy behind
+  // the call: a device-to-device copy of a few bytes costs a launch, 3-5 us of a 50 us call)
+  const bool direct_offsets = out_loc == CLDN_HIP_DEVICE && !lz4 && !table && stream_offsets != nullptr && ((uintptr_t)stream_offsets & 7u) == 0u;
+  const bool direct_sizes = out_loc == CLDN_HIP_DEVICE && !lz4 && !table && chunk_sizes != nullptr && ((uintptr_t)chunk_sizes & 3u) == 0u;
+  if (direct_offsets) L.stream_offsets = stream_offsets;
+  if (direct_sizes) L.chunk_payload = chunk_sizes;
   L.modes = (uint8_t*)c->d_modes.p;
   L.modes_forced = false;
   if (!wide && c->last_modes_count && c->ev_last_modes && hipEventQuery(c->ev_last_modes) == hipSuccess) {
@@ -1125,7 +1133,9 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
   }
   // remember this call's modes for the next call's launch hint (no synchronisation: the copy is only looked at
   // once its event has fired)
-  if (!wide && n_adaptive && n_clouds && (size_t)n_clouds * n_adaptive <= 65536u && c->last_modes_count == 0) {
+  // (a hint that is in place is refreshed with every 16th call only: it decides the launch shape, never a byte)
+  if (!wide && n_adaptive && n_clouds && (size_t)n_clouds * n_adaptive <= 65536u && c->last_modes_count == 0 &&
+      (!c->hint_valid || (c->call_index & 15u) == 0u)) {
     if (!c->ev_last_modes) HIP_TRY(hipEventCreateWithFlags(&c->ev_last_modes, hipEventDisableTiming));
     if (c->h_last_modes.ensure((size_t)n_clouds * n_adaptive) == CLDN_HIP_OK) {  // no copy in flight: buffer is free
       HIP_TRY(hipMemcpyAsync(c->h_last_modes.p, c->d_modes.p, (size_t)n_clouds * n_adaptive, hipMemcpyDeviceToHost,
@@ -1182,10 +1192,10 @@ static int encode_stage1_once(cldn_hip_codec_t* c, const void* points, int point
 
   const size_t modes_bytes = (size_t)n_clouds * n_adaptive;
   if (out_loc == CLDN_HIP_DEVICE) {
-    if (stream_offsets)
+    if (stream_offsets && !direct_offsets)
       HIP_TRY(hipMemcpyAsync(stream_offsets, c->d_offsets.p, (size_t)(n_clouds + 1) * sizeof(uint64_t),
                              hipMemcpyDeviceToDevice, c->stream));
-    if (chunk_sizes && n_chunks)
+    if (chunk_sizes && n_chunks && !direct_sizes)
       HIP_TRY(hipMemcpyAsync(chunk_sizes, d_sizes, (size_t)n_chunks * sizeof(uint32_t),
                              hipMemcpyDeviceToDevice, c->stream));
     if (modes && modes_bytes)
@@ -1496,14 +1506,26 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
   // tables: [stream_offsets u64 | cloud_first_point u64 | cloud_first_chunk u32] (n_clouds + 1 entries each)
   const size_t ne = (size_t)n_clouds + 1;
   const size_t table_bytes = ne * 8 + ne * 8 + ne * 4;
-  const uint32_t slot = c->dec_stage_next++ % (uint32_t)cldn_hip_codec::kDecStageRing;
-  PinnedBuf& stage = c->h_dec_stage[slot];
-  if (c->dec_stage_ev[slot]) HIP_TRY(hipEventSynchronize(c->dec_stage_ev[slot]));  // its last upload has left the buffer
-  else HIP_TRY(hipEventCreateWithFlags(&c->dec_stage_ev[slot], hipEventDisableTiming));
-  if ((rc = stage.ensure(table_bytes)) != CLDN_HIP_OK) return rc;
-  uint64_t* h_so = (uint64_t*)stage.p;
-  uint64_t* h_fp = h_so + ne;
-  uint32_t* h_fc = (uint32_t*)(h_fp + ne);
+  // calls of a few clouds (one cloud per call: the subscriber's shape) pass the tables as a kernel argument: no upload
+  const bool inline_tables = n_clouds <= kDecInlineClouds;
+  uint64_t inl_so[kDecInlineClouds + 1], inl_fp[kDecInlineClouds + 1];
+  uint32_t inl_fc[kDecInlineClouds + 1];
+  uint32_t slot = 0;
+  uint64_t* h_so = inl_so;
+  uint64_t* h_fp = inl_fp;
+  uint32_t* h_fc = inl_fc;
+  PinnedBuf* stage_p = nullptr;
+  if (!inline_tables) {
+    slot = c->dec_stage_next++ % (uint32_t)cldn_hip_codec::kDecStageRing;
+    PinnedBuf& stage = c->h_dec_stage[slot];
+    if (c->dec_stage_ev[slot]) HIP_TRY(hipEventSynchronize(c->dec_stage_ev[slot]));  // its last upload has left the buffer
+    else HIP_TRY(hipEventCreateWithFlags(&c->dec_stage_ev[slot], hipEventDisableTiming));
+    if ((rc = stage.ensure(table_bytes)) != CLDN_HIP_OK) return rc;
+    stage_p = &stage;
+    h_so = (uint64_t*)stage.p;
+    h_fp = h_so + ne;
+    h_fc = (uint32_t*)(h_fp + ne);
+  }
   const uint64_t base_off = stream_offsets[0];
   uint64_t fp = 0;
   uint32_t fc = 0;
@@ -1526,8 +1548,10 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
         (rc = c->d_dec_cols[a].ensure((size_t)n_points * plan.adaptive[a].bpv + 64)) != CLDN_HIP_OK)
       return rc;
   uint8_t* meta = (uint8_t*)c->d_dec_meta.p;
-  HIP_TRY(hipMemcpyAsync(meta, stage.p, table_bytes, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipEventRecord(c->dec_stage_ev[slot], c->stream));
+  if (!inline_tables) {
+    HIP_TRY(hipMemcpyAsync(meta, stage_p->p, table_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->dec_stage_ev[slot], c->stream));
+  }
 
   const uint8_t* d_streams = (const uint8_t*)streams + base_off;
   if (streams_loc == CLDN_HIP_HOST) {
@@ -1558,6 +1582,11 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
   L.stream_offsets = (const uint64_t*)meta;
   L.cloud_first_point = (const uint64_t*)(meta + ne * 8);
   L.cloud_first_chunk = (const uint32_t*)(meta + ne * 16);
+  if (inline_tables) {
+    L.h_stream_offsets = h_so;
+    L.h_cloud_first_point = h_fp;
+    L.h_cloud_first_chunk = h_fc;
+  }
   L.n_clouds = n_clouds;
   L.n_chunks = n_chunks;
   L.chunks = meta + ((table_bytes + 63) & ~size_t(63));
@@ -1614,6 +1643,7 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
     const uint32_t* hs = (const uint32_t*)c->h_dec_stats.p;
     c->dec_palette_hint = hs[4] == c->dec_stats_chunks && hs[2] == 0u && hs[3] == 0u;  // all folded by the guess, nothing serial
     c->dec_stats_chunks = 0;
+    c->dec_stats_seen = true;
   }
   L.palette_hint = c->dec_palette_hint ? 1u : 0u;
   // small batches: the point kernel's pieces spread over several workgroups per chunk (SPLIT launches) want their workspace
@@ -1634,12 +1664,15 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
     (void)hipEventRecord(L.events[1], c->stream);  // (recorded again in front of the regular-stream kernel, if the call has one)
     (void)hipEventRecord(L.events[2], c->stream);
   }
+  ++c->dec_call_index;
   if ((rc = stage1_launch_decode(L)) != CLDN_HIP_OK) return rc;
   if (L.events) {
     (void)hipEventRecord(L.events[3], c->stream);
     c->dec_events_valid = true;
   }
-  if (n_chunks && c->plan.uses_v5 && c->dec_stats_chunks == 0 && c->h_dec_stats.ensure(64) == CLDN_HIP_OK) {  // (no copy in flight)
+  // (the counters of every 16th call are enough once one copy has landed: the hint picks a launch shape, never a byte)
+  if (n_chunks && c->plan.uses_v5 && c->dec_stats_chunks == 0 && (!c->dec_stats_seen || (c->dec_call_index & 15u) == 0u) &&
+      c->h_dec_stats.ensure(64) == CLDN_HIP_OK) {  // (no copy in flight)
     if (!c->ev_dec_stats) HIP_TRY(hipEventCreateWithFlags(&c->ev_dec_stats, hipEventDisableTiming));
     HIP_TRY(hipMemcpyAsync(c->h_dec_stats.p, (const uint32_t*)c->d_status.p + 8, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->ev_dec_stats, c->stream));

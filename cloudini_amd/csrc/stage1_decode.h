@@ -34,19 +34,33 @@ struct DecChunk {
                       // points until the payload is empty, n_points = the points the output buffer has room for
 };
 
+// The three per-cloud tables of a call (stream offsets, first point, first chunk; n_clouds + 1 entries each) for calls of a
+// few clouds travel as a kernel argument: no upload in front of the call (round 6: one cloud per call is the ROS plugins' shape)
+struct DecTablesArg {
+  uint32_t n;  // 0: the tables are in device memory
+  uint32_t fc[kDecInlineClouds + 1];
+  uint64_t so[kDecInlineClouds + 1];
+  uint64_t fp[kDecInlineClouds + 1];
+};
+#define DEC_TABLES(T, stream_offsets, cloud_first_point, cloud_first_chunk)                                             \
+  auto so_at = [&](uint32_t i) __attribute__((always_inline)) -> uint64_t { return T.n ? T.so[i] : stream_offsets[i]; };     \
+  auto fp_at = [&](uint32_t i) __attribute__((always_inline)) -> uint64_t { return T.n ? T.fp[i] : cloud_first_point[i]; };  \
+  auto fc_at = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t { return T.n ? T.fc[i] : cloud_first_chunk[i]; };
+
 // grid = ceil(n_clouds / 64), one thread per cloud
 __global__ void k_walk_chunks(const uint8_t* __restrict__ streams, const uint64_t* __restrict__ stream_offsets,
                               const uint64_t* __restrict__ cloud_first_point, const uint32_t* __restrict__ cloud_first_chunk,
-                              uint32_t n_clouds, DecChunk* __restrict__ out, uint32_t* __restrict__ status) {
+                              uint32_t n_clouds, DecChunk* __restrict__ out, uint32_t* __restrict__ status, const DecTablesArg T) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_clouds) return;
-  uint64_t pos = stream_offsets[k];
-  const uint64_t end = stream_offsets[k + 1];
-  const uint64_t n_points = cloud_first_point[k + 1] - cloud_first_point[k];
+  DEC_TABLES(T, stream_offsets, cloud_first_point, cloud_first_chunk)
+  uint64_t pos = so_at(k);
+  const uint64_t end = so_at(k + 1);
+  const uint64_t n_points = fp_at(k + 1) - fp_at(k);
   uint64_t remaining = n_points;
-  uint32_t c = cloud_first_chunk[k];
-  const uint32_t c_end = cloud_first_chunk[k + 1];
-  uint64_t first = cloud_first_point[k];
+  uint32_t c = fc_at(k);
+  const uint32_t c_end = fc_at(k + 1);
+  uint64_t first = fp_at(k);
   bool bad = false;
   while (pos < end) {
     if (remaining == 0 || c >= c_end) { bad = true; break; }  // more chunks than declared points
@@ -72,7 +86,7 @@ __global__ void k_walk_chunks(const uint8_t* __restrict__ streams, const uint64_
   if (bad) {
     atomicOr(status, (uint32_t)ST_CORRUPT);
     for (; c < c_end; ++c) out[c].valid = 0;
-    for (uint32_t q = cloud_first_chunk[k]; q < c_end; ++q) out[q].valid = 0;
+    for (uint32_t q = fc_at(k); q < c_end; ++q) out[q].valid = 0;
   }
 }
 
@@ -84,15 +98,16 @@ __global__ __launch_bounds__(256) void k_build_chunks(const uint8_t* __restrict_
                                                       const uint64_t* __restrict__ cloud_first_point,
                                                       const uint32_t* __restrict__ cloud_first_chunk,
                                                       const uint32_t* __restrict__ chunk_sizes, DecChunk* __restrict__ out,
-                                                      uint32_t* __restrict__ status) {
+                                                      uint32_t* __restrict__ status, const DecTablesArg T) {
   __shared__ unsigned long long wtot[4];
   __shared__ unsigned long long carry;
   __shared__ uint32_t bad_l;
   const uint32_t k = blockIdx.x;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint64_t begin = stream_offsets[k], end = stream_offsets[k + 1];
-  const uint64_t n_points = cloud_first_point[k + 1] - cloud_first_point[k];
-  const uint32_t c0 = cloud_first_chunk[k], c1 = cloud_first_chunk[k + 1];
+  DEC_TABLES(T, stream_offsets, cloud_first_point, cloud_first_chunk)
+  const uint64_t begin = so_at(k), end = so_at(k + 1);
+  const uint64_t n_points = fp_at(k + 1) - fp_at(k);
+  const uint32_t c0 = fc_at(k), c1 = fc_at(k + 1);
   if (tid == 0) {
     carry = 0ull;
     bad_l = 0u;
@@ -125,7 +140,7 @@ __global__ __launch_bounds__(256) void k_build_chunks(const uint8_t* __restrict_
       d.src_off = pos + 4ull;
       d.src_size = size;
       d.n_points = (uint32_t)(n_points - p0 < kPointsPerChunk ? n_points - p0 : kPointsPerChunk);
-      d.first_point = cloud_first_point[k] + p0;
+      d.first_point = fp_at(k) + p0;
       d.cloud = k;
       d.valid = 1u;
       out[c] = d;

@@ -117,14 +117,24 @@ int stage1_launch_decode(const DecodeLaunch& L) {
   // timing (cldn_hip_codec_decode_ms): events in front of / behind the kernel that decodes the regular streams
   auto ev_before = [&]() { if (L.events) (void)hipEventRecord(L.events[1], L.stream); };
   auto ev_after = [&]() { if (L.events) (void)hipEventRecord(L.events[2], L.stream); };
+  DecTablesArg T;
+  memset(&T, 0, sizeof(T));
+  if (L.h_stream_offsets != nullptr && L.n_clouds <= kDecInlineClouds) {
+    T.n = L.n_clouds;
+    for (uint32_t k = 0; k <= L.n_clouds; ++k) {
+      T.so[k] = L.h_stream_offsets[k];
+      T.fp[k] = L.h_cloud_first_point[k];
+      T.fc[k] = L.h_cloud_first_chunk[k];
+    }
+  }
   if (L.chunk_sizes) {
     hipLaunchKernelGGL(k_build_chunks, dim3(L.n_clouds), dim3(256), 0, L.stream, L.streams, L.stream_offsets, L.cloud_first_point,
-                       L.cloud_first_chunk, L.chunk_sizes, reinterpret_cast<DecChunk*>(L.chunks), L.status);
+                       L.cloud_first_chunk, L.chunk_sizes, reinterpret_cast<DecChunk*>(L.chunks), L.status, T);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_build_chunks");
   } else {
     hipLaunchKernelGGL(k_walk_chunks, dim3((L.n_clouds + 63u) / 64u), dim3(64), 0, L.stream, L.streams, L.stream_offsets,
                        L.cloud_first_point, L.cloud_first_chunk, L.n_clouds, reinterpret_cast<DecChunk*>(L.chunks),
-                       L.status);
+                       L.status, T);
     if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_walk_chunks");
   }
   if (L.n_chunks && L.wide) {  // schemas beyond the launch-argument plan: the serial decoder with the plan in device memory

@@ -23,6 +23,7 @@ constexpr int dev_env_int(const char*, int otherwise) { return otherwise; }
 #endif
 
 constexpr uint32_t kPointsPerChunk = 32768;  // detail::kPointsPerChunk, src/codec_common.hpp:28
+constexpr uint32_t kDecInlineClouds = 8;      // decode calls of at most this many clouds pass their per-cloud tables as a kernel argument
 constexpr uint32_t kProbePoints = 4096;      // kAdaptiveModeProbePoints, src/v5_codec.cpp:76
 // Limits of the launch-argument plan (DevPlan travels to the kernels by value: 64 ops * 32 B + 64 adaptive fields * 8 B plus
 // the column pointer table stay below the 4 KB a launch may carry). Schemas beyond them -- the reference has no limits,

@@ -80,6 +80,9 @@ struct DecodeLaunch {
   const uint64_t* stream_offsets;     // device [n_clouds + 1]
   const uint64_t* cloud_first_point;  // device [n_clouds + 1]
   const uint32_t* cloud_first_chunk;  // device [n_clouds + 1]
+  const uint64_t* h_stream_offsets;   // host copies of the three tables: calls of a few clouds pass them as a kernel argument
+  const uint64_t* h_cloud_first_point;  // (then the device pointers above may be NULL)
+  const uint32_t* h_cloud_first_chunk;
   uint32_t n_clouds;
   uint32_t n_chunks;
   void* chunks;                       // device [n_chunks] DecChunk (48 bytes each)
