@@ -557,29 +557,46 @@ struct Pal32 {
 
 // ranks of values [i0, i0 + cnt) (cnt <= 32) packed BITS bits each into BITS dwords at `out` (any byte alignment: the
 // stores are unaligned dword / dwordx4 stores, which gfx950 performs natively)
-template <typename RawT, uint32_t BITS>
+template <typename RawT, uint32_t BITS, bool AHEAD = false>
 __device__ __forceinline__ void pal32_pack(const Pal32<RawT>& p, const RawT* col, uint32_t i0, uint32_t n, uint32_t cnt,
                                            uint8_t* out) {
   using P = Pal32<RawT>;
   uint32_t w[BITS];
 #pragma unroll
   for (uint32_t k = 0; k < BITS; ++k) w[k] = 0u;
+  // AHEAD (the 1024-thread workgroups of small batches, 128 VGPRs): the four groups of 8 values are requested together,
+  // without a branch (round 6: a conditional load per group cost one memory latency each -- 4.5 us of a one-cloud call's
+  // k_finish); elements behind the chunk's end are read and ignored. The 512-thread workgroups of large batches have 64
+  // VGPRs and enough chunks in flight to hide the latency: one group at a time.
+  Grp8<RawT> grp[AHEAD ? 4 : 1];
+  if constexpr (AHEAD) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) grp[g] = grp8_load<RawT>(col, i0 + 8u * g < n ? i0 + 8u * g : i0);
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    RawT v[8];
+    uint32_t v[8];
+    if constexpr (AHEAD) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (RawT)0;
-    if (i0 + 8u * g < n) load8<RawT>(col, i0 + 8u * g, n, v);
+      for (int j = 0; j < 8; ++j) v[j] = grp[g].get(j);
+    } else {
+      RawT rv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rv[j] = (RawT)0;
+      if (i0 + 8u * g < n) load8<RawT>(col, i0 + 8u * g, n, rv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (uint32_t)rv[j];
+    }
     typename P::Word tw[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) tw[j] = p.tab[P::home((uint32_t)v[j])];  // independent reads
+    for (int j = 0; j < 8; ++j) tw[j] = p.tab[P::home(v[j])];  // independent reads
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t e = (uint32_t)(8 * g + j);
       uint32_t x = 0u;
       if (e < cnt) {
-        const bool hit = tw[j] != P::kFree && P::key_of(tw[j]) == (uint32_t)v[j];
-        x = hit ? P::low_of(tw[j]) : p.find_rank((uint32_t)v[j], tw[j]);
+        const bool hit = tw[j] != P::kFree && P::key_of(tw[j]) == v[j];
+        x = hit ? P::low_of(tw[j]) : p.find_rank(v[j], tw[j]);
       }
       const uint32_t bit = e * BITS;
       w[bit >> 5] |= x << (bit & 31u);
@@ -760,18 +777,18 @@ __device__ __forceinline__ void pal32_pack_chunk(const Pal32<RawT>& p, const Raw
     if (bits != 0u && cnt != 0u) {
       uint8_t* o = idx_out + (size_t)grp * bits * 4u;
       switch (bits) {  // block-uniform
-        case 1: pal32_pack<RawT, 1>(p, col, i0, n, cnt, o); break;
-        case 2: pal32_pack<RawT, 2>(p, col, i0, n, cnt, o); break;
-        case 3: pal32_pack<RawT, 3>(p, col, i0, n, cnt, o); break;
-        case 4: pal32_pack<RawT, 4>(p, col, i0, n, cnt, o); break;
-        case 5: pal32_pack<RawT, 5>(p, col, i0, n, cnt, o); break;
-        case 6: pal32_pack<RawT, 6>(p, col, i0, n, cnt, o); break;
-        case 7: pal32_pack<RawT, 7>(p, col, i0, n, cnt, o); break;
-        case 8: pal32_pack<RawT, 8>(p, col, i0, n, cnt, o); break;
-        case 9: pal32_pack<RawT, 9>(p, col, i0, n, cnt, o); break;
-        case 10: pal32_pack<RawT, 10>(p, col, i0, n, cnt, o); break;
-        case 11: pal32_pack<RawT, 11>(p, col, i0, n, cnt, o); break;
-        default: pal32_pack<RawT, 12>(p, col, i0, n, cnt, o); break;  // U <= kS2PalCapacity = 3072: <= 12 bits
+        case 1: pal32_pack<RawT, 1, T == 1024>(p, col, i0, n, cnt, o); break;
+        case 2: pal32_pack<RawT, 2, T == 1024>(p, col, i0, n, cnt, o); break;
+        case 3: pal32_pack<RawT, 3, T == 1024>(p, col, i0, n, cnt, o); break;
+        case 4: pal32_pack<RawT, 4, T == 1024>(p, col, i0, n, cnt, o); break;
+        case 5: pal32_pack<RawT, 5, T == 1024>(p, col, i0, n, cnt, o); break;
+        case 6: pal32_pack<RawT, 6, T == 1024>(p, col, i0, n, cnt, o); break;
+        case 7: pal32_pack<RawT, 7, T == 1024>(p, col, i0, n, cnt, o); break;
+        case 8: pal32_pack<RawT, 8, T == 1024>(p, col, i0, n, cnt, o); break;
+        case 9: pal32_pack<RawT, 9, T == 1024>(p, col, i0, n, cnt, o); break;
+        case 10: pal32_pack<RawT, 10, T == 1024>(p, col, i0, n, cnt, o); break;
+        case 11: pal32_pack<RawT, 11, T == 1024>(p, col, i0, n, cnt, o); break;
+        default: pal32_pack<RawT, 12, T == 1024>(p, col, i0, n, cnt, o); break;  // U <= kS2PalCapacity = 3072: <= 12 bits
       }
     }
   }
