@@ -68,10 +68,10 @@ int stage1_configure_decode() {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)DecSecLds::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_sections_cols)");
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_stream_w<12, 1>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)SwLds<12, true>::kTotal);
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)SwLds<12, 1>::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_stream_w form)");
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_stream_w<12, 2>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)SwLds<12, true>::kTotal);
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)SwLds<12, 2>::kTotal);
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_decode_stream_w gorilla)");
   return CLDN_HIP_OK;
 }
@@ -412,7 +412,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
                            reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, fixed_bytes);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_fixed");
       } else if (form) {
-        hipLaunchKernelGGL((k_decode_stream_w<12, 1>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, true>::kTotal), L.stream, P,
+        hipLaunchKernelGGL((k_decode_stream_w<12, 1>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, 1>::kTotal), L.stream, P,
                            L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{}, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (form)");
       } else if (stream_ok) {
@@ -506,7 +506,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
       }
       if (ok) {
         ev_before();
-        hipLaunchKernelGGL((k_decode_stream_w<12, 2>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, true>::kTotal), L.stream, P,
+        hipLaunchKernelGGL((k_decode_stream_w<12, 2>), dim3(L.n_chunks), dim3(12 * 64), (SwLds<12, 2>::kTotal), L.stream, P,
                            L.streams, reinterpret_cast<const DecChunk*>(L.chunks), L.out, L.reg_end, L.status, (const uint32_t*)nullptr, 0u, DecColumns{}, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (uint8_t*)nullptr);
         ev_after();
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_decode_stream_w (gorilla)");

@@ -26,22 +26,29 @@ constexpr uint32_t kSwListEntries = 1032u;  // points a piece can own (one op of
 constexpr uint32_t kSwSpinLimit = 1u << 18;
 constexpr uint32_t kSwMaxRounds = 40u;      // MODE 2: window changes inside one piece (a chunk's first stamps settle through several)
 
-template <int NW, bool FORM = false>
+template <int NW, int MODE = 0>
 struct SwLds {
+  static constexpr bool FORM = MODE != 0;
+  static constexpr bool GOR = MODE == 2;
+  static constexpr uint32_t kRing = GOR ? 16u : kSwRing;                      // chain records (a piece waits for the one in front only)
   static constexpr uint32_t kBytesOff = 0;                                    // per wave: [piece][halo]
   static constexpr uint32_t kEndsOff = kSwPiece + kSwHalo;                    // u16 [64 + 6] + pad: end bits of the units
   static constexpr uint32_t kListOff = kEndsOff + 160u;                       // u16 [kSwListEntries] (FORM: a point has 2 bytes at least)
   static constexpr uint32_t kListEntries = FORM ? kSwPiece / 2u + 8u : kSwListEntries;
   static constexpr uint32_t kJumpOff = (kListOff + kListEntries * 2u + 15u) & ~15u;  // FORM: u16 [kSwPiece]: where the point that starts at a byte ends
-  static constexpr uint32_t kCheckOff = kJumpOff + (FORM ? kSwPiece * 2u : 0u);      // FORM: u16 [kSwMaxPointBytes][8]: a candidate's first point in every 128-byte block
-  static constexpr uint32_t kWaveBytes = kCheckOff + (FORM ? kSwMaxPointBytes * 16u : 0u);
-  static_assert(kSwMaxRounds * kSwMaxOps * 4u + (kSwMaxRounds + 1u) * 2u <= kSwMaxPointBytes * 16u, "MODE 2 keeps its rounds where MODE 1 keeps its checkpoints");
-  static constexpr uint32_t kLutOff = (uint32_t)NW * kWaveBytes;              // u16 [kSwMaxOps][256]
-  static constexpr uint32_t kTrecOff = kLutOff + kSwMaxOps * 512u;            // u64 [kSwRing]
-  static constexpr uint32_t kVrecOff = kTrecOff + kSwRing * 8u;               // u64 [kSwRing][kSwMaxOps][2]: {tag, lo}, {tag, hi} of the value behind the piece
-  static constexpr uint32_t kGrecOff = kVrecOff + kSwRing * kSwMaxOps * 16u;  // u64 [kSwRing][kSwMaxOps]: {tag, Gorilla window of op o behind the piece} (MODE 2)
-  static constexpr uint32_t kMiscOff = kGrecOff + kSwRing * kSwMaxOps * 8u;
+  // MODE 1: u16 [kSwMaxPointBytes][8]: a candidate's first point in every 128-byte block. MODE 2: u16 [kSwPiece]: where the
+  // FOURTH point from a byte ends (round 6: candidates and the list follow the jumps four points at a time); a piece that is
+  // redone in rounds keeps its rounds there instead
+  static constexpr uint32_t kCheckOff = kJumpOff + (FORM ? kSwPiece * 2u : 0u);
+  static constexpr uint32_t kWaveBytes = kCheckOff + (GOR ? kSwPiece * 2u : (FORM ? kSwMaxPointBytes * 16u : 0u));
+  static_assert(kSwMaxRounds * kSwMaxOps * 4u + (kSwMaxRounds + 1u) * 2u <= kSwMaxPointBytes * 16u, "MODE 2 keeps its rounds where the fourth-point table is");
+  static constexpr uint32_t kLutOff = (uint32_t)NW * kWaveBytes;              // u16 [kSwMaxOps][256] (MODE 0 only)
+  static constexpr uint32_t kTrecOff = kLutOff + (FORM ? 0u : kSwMaxOps * 512u);  // u64 [kRing]
+  static constexpr uint32_t kVrecOff = kTrecOff + kRing * 8u;                 // u64 [kRing][kSwMaxOps][2]: {tag, lo}, {tag, hi} of the value behind the piece
+  static constexpr uint32_t kGrecOff = kVrecOff + kRing * kSwMaxOps * 16u;    // u64 [kRing][kSwMaxOps]: {tag, Gorilla window of op o behind the piece} (MODE 2)
+  static constexpr uint32_t kMiscOff = kGrecOff + kRing * kSwMaxOps * 8u;
   static constexpr uint32_t kTotal = kMiscOff + 256u;
+  static_assert(!GOR || 2u * kTotal <= 160u * 1024u, "two workgroups per CU");
 };
 
 #define SW_DPP64(X, CTRL, RMASK, BC)                                                                                  \
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
                                                              const uint32_t* __restrict__ reg_end_pre, uint8_t* __restrict__ sec_done) {
   constexpr bool FORM = MODE != 0;
   constexpr bool GOR = MODE == 2;
-  using L = SwLds<NW, FORM>;
+  using L = SwLds<NW, MODE>;
   constexpr int T = NW * 64;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t* lut = reinterpret_cast<uint16_t*>(smem + L::kLutOff);
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   }
   for (uint32_t i = tid; i < (L::kMiscOff - L::kTrecOff) / 4u; i += T) reinterpret_cast<uint32_t*>(trec)[i] = 0u;
   // which ends of a byte's end mask close points when the first k0 of them do not: entry = mask | (next k0) << 8
-  for (uint32_t e = tid; e < n_ops * 256u; e += T) {
+  for (uint32_t e = tid; !FORM && e < n_ops * 256u; e += T) {
     uint32_t k = e >> 8, sel = 0u;
     for (uint32_t bit = 0; bit < 8u; ++bit) {
       if ((e >> bit) & 1u) {
@@ -326,7 +333,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
   uint16_t* ebuf = reinterpret_cast<uint16_t*>(wmem + L::kEndsOff);
   uint16_t* plist = reinterpret_cast<uint16_t*>(wmem + L::kListOff);
   uint16_t* jt = reinterpret_cast<uint16_t*>(wmem + L::kJumpOff);    // (FORM)
-  uint16_t* cpt = reinterpret_cast<uint16_t*>(wmem + L::kCheckOff);  // (FORM)
+  uint16_t* cpt = reinterpret_cast<uint16_t*>(wmem + L::kCheckOff);  // (MODE 1)
+  uint16_t* hop4 = reinterpret_cast<uint16_t*>(wmem + L::kCheckOff); // (MODE 2)
   uint32_t* rstate = reinterpret_cast<uint32_t*>(wmem + L::kCheckOff);        // (MODE 2, instead of the checkpoints) [kSwMaxRounds][kSwMaxOps]: windows of round r
   uint16_t* rstart = reinterpret_cast<uint16_t*>(wmem + L::kCheckOff + kSwMaxRounds * kSwMaxOps * 4u);  // [kSwMaxRounds + 1]: first point of round r
 
@@ -495,7 +503,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       // the k-th end at or behind byte i + 1 is the k-th end behind byte i unless byte i ends a token itself (then it is the
       // next one). Points whose leading varints do not end within 64 bytes of the lane's first byte get no entry (the chunk
       // goes to the serial decoder if such a point is real: tokens of more than 10 bytes are malformed anyway).
-      [[maybe_unused]] auto make_jt_gor = [&](uint32_t st) __attribute__((always_inline)) {
+      [[maybe_unused]] auto make_jt_gor = [&](uint32_t st, bool with_hop4) __attribute__((always_inline)) {
         // rel of the sixteen candidates: four to a register, one byte each (a point advances by at most 64 bytes in its leading
         // varints and by at most 10 per op behind them: < 256)
         uint32_t relp[4] = {0u, 0u, 0u, 0u};
@@ -579,10 +587,48 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         uint4* dst = reinterpret_cast<uint4*>(jt + lane * 16u);
         dst[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
         dst[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
+        if (!with_hop4) return;  // (uniform)
+        // hop4[x] = where the FOURTH point from byte x ends, if the four points x, x1, x2, x3 are well formed, begin inside the
+        // piece and none of them changes the window (0xffff otherwise: single steps take over). Three rounds of sixteen
+        // independent look-ups; candidates and the list then follow the stream four points at a time.
+        wp_wave_sync();
+        uint32_t good = 0u;  // bit i: the chain from byte i is intact so far
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) {
+          const uint32_t jv = (packed[i >> 1] >> ((i & 1u) * 16u)) & 0xffffu;
+          if (jv < kSwPiece) good |= 1u << i;  // (0xffff and flagged entries are >= 0x8000)
+        }
+#pragma unroll
+        for (uint32_t r = 1; r < 4u; ++r) {
+          uint32_t nxt[8];
+#pragma unroll
+          for (uint32_t i = 0; i < 16u; ++i) {
+            const uint32_t cur = (packed[i >> 1] >> ((i & 1u) * 16u)) & 0xffffu;
+            const uint32_t e = jt[((good >> i) & 1u) ? cur : 0u];
+            if (i & 1u) nxt[i >> 1] |= e << 16;
+            else nxt[i >> 1] = e;
+          }
+#pragma unroll
+          for (uint32_t i = 0; i < 16u; ++i) {
+            const uint32_t e = (nxt[i >> 1] >> ((i & 1u) * 16u)) & 0xffffu;
+            // steps 1, 2: the next point must begin inside the piece; step 3: any well-formed end (it may lie in the next piece)
+            const bool ok = r < 3u ? e < kSwPiece : e < 0x8000u;
+            if (!ok) good &= ~(1u << i);
+          }
+#pragma unroll
+          for (uint32_t k = 0; k < 8u; ++k) packed[k] = nxt[k];
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 16u; ++i) {
+          if (((good >> i) & 1u) == 0u) packed[i >> 1] |= 0xffffu << ((i & 1u) * 16u);
+        }
+        uint4* hd = reinterpret_cast<uint4*>(hop4 + lane * 16u);
+        hd[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        hd[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
       };
-      auto make_jt = [&](uint32_t st) __attribute__((always_inline)) {
+      auto make_jt = [&](uint32_t st, bool with_hop4) __attribute__((always_inline)) {
         if constexpr (GOR) {
-          make_jt_gor(st);
+          make_jt_gor(st, with_hop4);
           return;
         }
         uint32_t packed[8];
@@ -612,14 +658,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         // published (lane l looks at piece p - 1 - l). A wave's first piece has no guess of its own: it waits until piece 0
         // -- where a chunk's windows settle -- has published, instead of building a table for "no window" that is thrown away.
         if (p != 0u) {
-          const uint32_t back = min(min(p, (uint32_t)NW), kSwRing - 1u);
+          const uint32_t back = min(min(p, (uint32_t)NW), L::kRing - 1u);
           for (uint32_t spins = 0;; ++spins) {
             const uint32_t q = p - 1u - min(lane, back - 1u);  // (a piece in front of mine)
-            const unsigned long long x = wp_rec_load(trec + (q & (kSwRing - 1u)));
+            const unsigned long long x = wp_rec_load(trec + (q & (L::kRing - 1u)));
             const unsigned long long have = __ballot(lane < back && (uint32_t)(x >> 32) == q + 1u);
             if (have != 0ull) {
               const uint32_t q1 = p - 1u - (uint32_t)__builtin_ctzll(have);
-              const unsigned long long xg = wp_rec_load(grec + (size_t)(q1 & (kSwRing - 1u)) * kSwMaxOps + min(lane, n_ops - 1u));
+              const unsigned long long xg = wp_rec_load(grec + (size_t)(q1 & (L::kRing - 1u)) * kSwMaxOps + min(lane, n_ops - 1u));
               if (__ballot(lane < n_ops && (uint32_t)(xg >> 32) != q1 + 1u) == 0ull) st_pred = lane < n_ops ? (uint32_t)xg : 0u;
               break;
             }
@@ -628,7 +674,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
           }
         }
       }
-      make_jt(st_pred);
+      make_jt(st_pred, true);
       wp_wave_sync();
       SW_T(1)
       // ---- the first lanes follow the jumps from their byte: where the next piece is entered, and after how many points.
@@ -636,7 +682,26 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       // came before -- the owner of the true entry then lists its points eight blocks side by side.
       const uint32_t maxpt = min(plan.max_regular_bytes, kSwMaxPointBytes);  // candidates: entry offsets [0, maxpt)
       uint32_t ex[2] = {0xffffu, 0xffffu}, ec[2] = {0u, 0u};
-      {
+      if constexpr (GOR) {
+        // (round 6) four points per step through hop4, single steps where it has no entry (the piece's last points, a point
+        // that changes the window: 0xfffe, a malformed one: 0xffff); no checkpoints -- the list follows hop4 as well
+#pragma unroll
+        for (uint32_t set = 0; set < 2u; ++set) {
+          if (set == 1u && maxpt <= 64u) break;  // (uniform)
+          uint32_t x = set * 64u + lane < maxpt ? set * 64u + lane : 0xffffu, cn = 0u;
+          while (__ballot(x < kSwPiece) != 0ull) {
+            const bool act = x < kSwPiece;
+            const uint32_t xa = act ? x : 0u;
+            const uint32_t h = hop4[xa], e = jt[xa];
+            const uint32_t single = e == 0xffffu ? 0xffffu : ((e & 0x8000u) ? 0xfffeu : e);
+            const uint32_t nx = h != 0xffffu ? h : single;
+            cn += act ? (h != 0xffffu ? 4u : 1u) : 0u;
+            x = act ? nx : x;
+          }
+          ex[set] = x;
+          ec[set] = cn;
+        }
+      } else {
         uint32_t x0 = lane < maxpt ? lane : 0xffffu, x1 = 64u + lane < maxpt ? 64u + lane : 0xffffu;
         uint32_t c0 = 0u, c1 = 0u, pb0 = 0xffu, pb1 = 0xffu;
         for (uint32_t b8 = 0; b8 < 8u; ++b8) {
@@ -682,8 +747,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       // ---- chain 1: {entry offset, points in front} of the piece (MODE 2: and the window at its entry)
       uint32_t entry = a0, pts0 = 0u, st = 0u;  // (st: lane o = window of op o)
       if (p != 0u) {
-        const unsigned long long* r = trec + ((p - 1u) & (kSwRing - 1u));
-        const unsigned long long* rg = grec + (size_t)((p - 1u) & (kSwRing - 1u)) * kSwMaxOps + min(lane, n_ops - 1u);
+        const unsigned long long* r = trec + ((p - 1u) & (L::kRing - 1u));
+        const unsigned long long* rg = grec + (size_t)((p - 1u) & (L::kRing - 1u)) * kSwMaxOps + min(lane, n_ops - 1u);
         unsigned long long x = wp_rec_load(r), xg = GOR ? wp_rec_load(rg) : 0ull;
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p || (GOR && __ballot((uint32_t)(xg >> 32) != p) != 0ull)) {
           __builtin_amdgcn_s_setprio(0);
@@ -716,8 +781,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       if (!rounds_needed) {
         const uint32_t out_entry = (dead || my_exit >= 0xfffeu) ? 0xffu : my_exit - kSwPiece;
         const uint32_t pts1 = dead ? pts0 : min(pts0 + my_cnt, n);
-        if (lane == 0u) wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
-        if (GOR && lane < n_ops) wp_rec_store(grec + (size_t)(p & (kSwRing - 1u)) * kSwMaxOps + lane, ((unsigned long long)(p + 1u) << 32) | st);
+        if (lane == 0u) wp_rec_store(trec + (p & (L::kRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
+        if (GOR && lane < n_ops) wp_rec_store(grec + (size_t)(p & (L::kRing - 1u)) * kSwMaxOps + lane, ((unsigned long long)(p + 1u) << 32) | st);
         st_last = st;
         if (pts0 >= n) stop = true;
         else if (dead) {
@@ -727,10 +792,69 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
           q_first = pts0;
           npts = min(my_cnt, n - pts0);
           st_first = st;
-          // ---- the points' first bytes, in order: lane b lists the points that begin in block b, from the entry's checkpoint
+          // ---- the points' first bytes, in order
           wp_wave_sync();
           bool broken = false;
-          if (lane < 8u) {
+          if constexpr (GOR) {
+            // (round 6) lanes 0..3 take the points 4k + lane: lane r makes r single steps from the entry, then all four follow
+            // hop4; where it has no entry the rest is listed by single steps from the lowest point a lane stopped at
+            uint32_t x = entry, j = lane;
+            bool go = lane < 4u;
+#pragma unroll
+            for (uint32_t s4 = 0; s4 < 3u; ++s4) {
+              const uint32_t e = jt[go && x < kSwPiece ? x : 0u];
+              if (lane > s4) x = (x < kSwPiece && e < 0x8000u) ? e : 0xffffu;  // (a flagged or malformed point, or one in the next piece: the tail walk sorts it out)
+            }
+            uint32_t stop_j = 0xffffu, stop_x = 0u;  // where this lane's hops ended: point stop_j begins at stop_x
+            if (go && (x >= kSwPiece || j >= npts)) {
+              go = false;  // (nothing of mine in this piece; a lane in front of me stops at its point and the tail walk continues)
+            }
+            while (__ballot(go) != 0ull) {
+              if (go) {
+                plist[j] = (uint16_t)x;
+                const uint32_t h = hop4[x];
+                if (h != 0xffffu && h < kSwPiece && j + 4u < npts) {
+                  x = h;
+                  j += 4u;
+                } else {
+                  stop_j = j;
+                  stop_x = x;
+                  go = false;
+                }
+              }
+            }
+            // the lowest stop: from there on single steps (the points of the lanes that went further are listed again, same values)
+            uint32_t sj = stop_j;
+            sj = min(sj, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffu, (int)sj, 0x111, 0xf, 0xf, false));  // row_shr:1
+            sj = min(sj, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffu, (int)sj, 0x112, 0xf, 0xf, false));  // row_shr:2
+            const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)sj, 3);  // min over lanes 0..3
+            if (tj != 0xffffu) {
+              const unsigned long long owner = __ballot(lane < 4u && stop_j == tj);
+              uint32_t wx = (uint32_t)__builtin_amdgcn_readlane((int)stop_x, (int)__builtin_ctzll(owner)), wj = tj;
+              if (lane == 0u) {
+                while (wj < npts) {
+                  plist[wj] = (uint16_t)wx;
+                  const uint32_t e = jt[wx];
+                  if (e == 0xffffu) {
+                    broken = true;  // (the candidates' walk counted the points up to here only)
+                    break;
+                  }
+                  ++wj;
+                  wx = e & 0x7fffu;
+                  if (wx >= kSwPiece) break;
+                }
+                if (wj < npts) broken = true;
+              }
+            } else if (lane == 0u) {
+              broken = true;  // (npts != 0: some lane has listed a point)
+            }
+            // behind the chunk's last point: the sections
+            if (lane == 0u && !broken && pts0 + npts == n) {
+              const uint32_t e = jt[plist[npts - 1u]];
+              if (e == 0xffffu) broken = true;
+              else misc[2] = p * kSwPiece + (e & 0x7fffu) - a0;
+            }
+          } else if (lane < 8u) {
             const uint32_t ck = cpt[entry * 8u + lane];
             if (ck != 0xffffu) {
               uint32_t x = lane * 128u + (ck & 127u), j = ck >> 7;
@@ -760,7 +884,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         for (;;) {
           if (rounds != 0u || __ballot(st != st_pred) != 0ull) {
             wp_wave_sync();
-            make_jt(st);
+            make_jt(st, false);
           }
           wp_wave_sync();
           if (lane == 0u) rstart[rounds] = (uint16_t)j;
@@ -823,15 +947,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
           pts1 = pts0 + j;
           out_entry = xcur >= kSwPiece ? xcur - kSwPiece : 0xffu;
         }
-        if (lane == 0u) wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
-        if (lane < n_ops) wp_rec_store(grec + (size_t)(p & (kSwRing - 1u)) * kSwMaxOps + lane, ((unsigned long long)(p + 1u) << 32) | st);
+        if (lane == 0u) wp_rec_store(trec + (p & (L::kRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
+        if (lane < n_ops) wp_rec_store(grec + (size_t)(p & (L::kRing - 1u)) * kSwMaxOps + lane, ((unsigned long long)(p + 1u) << 32) | st);
         st_last = st;
       }
     } else {
       // ---- chain 1: token ends in front of the piece
       uint32_t T0 = 0u;
       if (p != 0u) {
-        const unsigned long long* r = trec + ((p - 1u) & (kSwRing - 1u));
+        const unsigned long long* r = trec + ((p - 1u) & (L::kRing - 1u));
         unsigned long long x = wp_rec_load(r);
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p) {
           __builtin_amdgcn_s_setprio(0);
@@ -849,7 +973,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
       }
       if (gave_up) break;
-      if (lane == 0u) wp_rec_store(trec + (p & (kSwRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (T0 + cnt));
+      if (lane == 0u) wp_rec_store(trec + (p & (L::kRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (T0 + cnt));
       if (T0 >= target) stop = true;
       if (!stop) {
       if (T0 + cnt >= target) {
@@ -998,7 +1122,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
     SW_T(5)
     // ---- chain 2: the running values in front of the piece (lane o: {tag, lo}, {tag | reset, hi} of op o)
     if (p != 0u) {
-      const unsigned long long* r = vrec + ((size_t)((p - 1u) & (kSwRing - 1u)) * kSwMaxOps + min(lane, n_ops - 1u)) * 2u;
+      const unsigned long long* r = vrec + ((size_t)((p - 1u) & (L::kRing - 1u)) * kSwMaxOps + min(lane, n_ops - 1u)) * 2u;
       unsigned long long xl = wp_rec_load(r), xh = wp_rec_load(r + 1);
       if (__ballot((uint32_t)(xl >> 32) != p || (uint32_t)(xh >> 32) != p) != 0ull) {
         __builtin_amdgcn_s_setprio(0);
@@ -1022,7 +1146,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
     {
       const uint64_t incl_l = ((xor_ops >> lane) & 1ull) ? (run_l ^ agg_l) : (aggf_l ? agg_l : run_l + agg_l);
       if (lane < n_ops) {
-        unsigned long long* w = vrec + ((size_t)(p & (kSwRing - 1u)) * kSwMaxOps + lane) * 2u;
+        unsigned long long* w = vrec + ((size_t)(p & (L::kRing - 1u)) * kSwMaxOps + lane) * 2u;
         wp_rec_store(w, ((unsigned long long)(p + 1u) << 32) | (incl_l & 0xffffffffull));
         wp_rec_store(w + 1, ((unsigned long long)(p + 1u) << 32) | (incl_l >> 32));
       }
