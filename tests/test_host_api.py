@@ -49,6 +49,21 @@ def test_c_abi_exports_every_declared_symbol():
     assert hip.cldn_hip_abi_version() == 1
 
 
+def test_shipped_libraries_read_only_the_production_environment_variables():
+    """The default build carries no development switch: libcloudini_hip.so names no CLDN_HIP_*
+    variable at all (dev_env() is a constant outside -DCLDN_DEV builds), the host mirror names its three CLOUDINI_AMD_*
+    settings and the transcoder's timing print; the superseded kernel generations are not in the device code."""
+    libdir = os.path.join(ROOT, "cloudini_amd", "lib")
+    hip = open(os.path.join(libdir, "libcloudini_hip.so"), "rb").read()
+    host = open(os.path.join(libdir, "libcloudini_amd.so"), "rb").read()
+    names = lambda blob: sorted({m.decode() for m in re.findall(rb"(?:CLDN|CLOUDINI)_[A-Z0-9_]{3,}(?=\x00)", blob)})
+    assert [n for n in names(hip) if n.startswith(("CLDN_HIP_", "CLOUDINI_AMD_"))] == []
+    assert [n for n in names(host) if n.startswith(("CLDN_", "CLOUDINI_AMD_"))] == [
+        "CLDN_HOST_TIMING", "CLOUDINI_AMD_DEVICE_LZ4", "CLOUDINI_AMD_PIPELINE", "CLOUDINI_AMD_STAGE2_THREADS"]
+    for dead in (b"k_compact", b"k_chunk_offsets", b"10k_lz4_emitE", b"15k_decode_pointsI"):
+        assert dead not in hip, dead
+
+
 @pytest.mark.parametrize("seed", cases.VERY_WIDE_SEEDS[::5])
 def test_plans_of_any_size_are_accepted_without_a_gpu(oracle, seed):
     """Round 5 (no compute, runs without a GPU): cldn_hip_plan_create takes schemas beyond the launch-argument plan -- 65-200
