@@ -1809,22 +1809,29 @@ __global__ __launch_bounds__(kSecThreads) void k_probe_modes(const DevPlan plan,
   if (threadIdx.x == 0) modes[cloud * plan.n_adaptive + a] = (uint8_t)mode;
 }
 
-// k_encode_sections: grid = (n_chunks, n_adaptive)
+// k_encode_sections: the safety net behind the fast section kernels. grid = min(n_chunks * n_adaptive, kSecGrid) workgroups
+// that take the (chunk, field) pairs round robin (round 6: the kernel's 119 KB of LDS allow one workgroup per CU anyway, and
+// with the fused Palette nearly every pair is a check and nothing else: a thousand 1024-thread workgroups that return at
+// once cost 8 us of dispatch on the 32-cloud batch)
+constexpr uint32_t kSecGrid = 256;
 __global__ __launch_bounds__(kSecThreads) void k_encode_sections(const DevPlan plan, const ChunkDesc* __restrict__ chunks,
                                                                  const ColumnPtrs cols, const uint8_t* __restrict__ modes,
                                                                  uint8_t* __restrict__ slots, uint64_t slot_stride,
                                                                  uint64_t reg_stride, Seg* __restrict__ segs,
                                                                  uint32_t segs_per_chunk, const ColumnPtrs rank_cols,
                                                                  uint32_t subs, const uint8_t* __restrict__ handled_flags,
-                                                                 uint32_t fused_field) {
+                                                                 uint32_t fused_field, uint32_t n_chunks) {
   constexpr int T = kSecThreads;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const SecLds l = sec_lds_carve(smem);
-  const uint32_t c = blockIdx.x, a = blockIdx.y;
-  if (handled_flags[(size_t)c * plan.n_adaptive + a]) return;  // a fast-path kernel already wrote this section
+  const uint32_t n_pairs = n_chunks * plan.n_adaptive;
+  for (uint32_t w = blockIdx.x; w < n_pairs; w += gridDim.x) {  // (every test below is uniform over the workgroup)
+  const uint32_t a = w / n_chunks, c = w - a * n_chunks;
+  if (handled_flags[(size_t)c * plan.n_adaptive + a]) continue;  // a fast-path kernel already wrote this section
   const ChunkDesc cd = chunks[c];
   // k_finish builds the Palette sections of this field itself (any number of distinct values)
-  if (a == fused_field && modes[cd.cloud * plan.n_adaptive + a] == 1u) return;
+  if (a == fused_field && modes[cd.cloud * plan.n_adaptive + a] == 1u) continue;
+  __syncthreads();  // (the pair this workgroup did before is through with the LDS)
   const uint32_t n = cd.n_points;
   const uint32_t bpv = plan.adaptive[a].bpv, type = plan.adaptive[a].type;
   const uint8_t* col = cols.p[a] + (size_t)cd.first_point * bpv;
@@ -1854,6 +1861,7 @@ __global__ __launch_bounds__(kSecThreads) void k_encode_sections(const DevPlan p
     s.off = sec_off + kPaletteIndexOffset;
     s.size = size_b;
     segs[(size_t)c * segs_per_chunk + subs + 1u + 2u * a] = s;
+  }
   }
 }
 
@@ -2204,8 +2212,8 @@ static int launch_sections(const EncodeLaunch& L, hipStream_t stream, uint32_t c
     hipLaunchKernelGGL(k_section_palette<uint64_t>, dim3(nch, pal64.n), dim3(kS2Threads), kS2PalLds, stream, SEC_ARGS(pal64));
 #undef SEC_ARGS
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_palette");
-  hipLaunchKernelGGL(k_encode_sections, dim3(nch, na), dim3(kSecThreads), kSecLdsTotal, stream, *L.plan, chunks, L.cols,
-                     L.modes, slots, L.slot_stride, L.reg_stride, segs, L.segs_per_chunk, rank_cols, L.subs, flags, fused_field);
+  hipLaunchKernelGGL(k_encode_sections, dim3(std::min<uint32_t>(nch * na, kSecGrid)), dim3(kSecThreads), kSecLdsTotal, stream, *L.plan, chunks, L.cols,
+                     L.modes, slots, L.slot_stride, L.reg_stride, segs, L.segs_per_chunk, rank_cols, L.subs, flags, fused_field, nch);
   if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_encode_sections");
   return CLDN_HIP_OK;
 }
