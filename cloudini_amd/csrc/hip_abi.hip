@@ -230,6 +230,7 @@ struct cldn_hip_codec {
   uint32_t dec_stats_chunks = 0;     // chunks of the call whose copy is in flight (0 = none)
   bool dec_palette_hint = false;
   bool dec_stats_seen = false;       // one copy of the counters has landed
+  uint32_t dec_dv_hint = 0;          // 1: the last counters showed no DeltaVarint section decoded by k_section_dv_w, 2: every chunk's (stage1_launch.h)
   uint32_t dec_call_index = 0;
   hipEvent_t dec_events[4] = {nullptr, nullptr, nullptr, nullptr};  // the last decode call's (timing enabled)
   bool dec_events_valid = false;
@@ -1642,10 +1643,13 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
   if (c->dec_stats_chunks && c->ev_dec_stats && hipEventQuery(c->ev_dec_stats) == hipSuccess) {  // an earlier call's counters have landed
     const uint32_t* hs = (const uint32_t*)c->h_dec_stats.p;
     c->dec_palette_hint = hs[4] == c->dec_stats_chunks && hs[2] == 0u && hs[3] == 0u;  // all folded by the guess, nothing serial
+    // (kStatDvChunks = word 13, kStatDvMode = word 14: no chunk with a DeltaVarint section / every chunk's decoded by k_section_dv_w)
+    c->dec_dv_hint = hs[6] == 0u ? 1u : (hs[5] == c->dec_stats_chunks && hs[2] == 0u && hs[3] == 0u ? 2u : 0u);
     c->dec_stats_chunks = 0;
     c->dec_stats_seen = true;
   }
   L.palette_hint = c->dec_palette_hint ? 1u : 0u;
+  L.dv_hint = c->dec_dv_hint;
   // small batches: the point kernel's pieces spread over several workgroups per chunk (SPLIT launches) want their workspace
   L.wp_parts = c->test_split_parts == 0u ? wp_split_parts(n_chunks) : c->test_split_parts;
   if (!c->plan.wide && L.wp_parts > 1u) {
@@ -1670,8 +1674,8 @@ int cldn_hip_decode_stage1_sized(cldn_hip_codec_t* c, const void* streams, int s
     (void)hipEventRecord(L.events[3], c->stream);
     c->dec_events_valid = true;
   }
-  // (the counters of every 16th call are enough once one copy has landed: the hint picks a launch shape, never a byte)
-  if (n_chunks && c->plan.uses_v5 && c->dec_stats_chunks == 0 && (!c->dec_stats_seen || (c->dec_call_index & 15u) == 0u) &&
+  // (the counters of every 4th call are enough once one copy has landed: the hints pick a launch shape, never a byte)
+  if (n_chunks && c->plan.uses_v5 && c->dec_stats_chunks == 0 && (!c->dec_stats_seen || (c->dec_call_index & 3u) == 0u) &&
       c->h_dec_stats.ensure(64) == CLDN_HIP_OK) {  // (no copy in flight)
     if (!c->ev_dec_stats) HIP_TRY(hipEventCreateWithFlags(&c->ev_dec_stats, hipEventDisableTiming));
     HIP_TRY(hipMemcpyAsync(c->h_dec_stats.p, (const uint32_t*)c->d_status.p + 8, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

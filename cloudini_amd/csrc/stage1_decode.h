@@ -23,6 +23,12 @@ constexpr uint32_t kStatFastRegular = 8, kStatFastSections = 9, kStatSerialChunk
 // columns): when that was every chunk of a call, the codec's next call skips the kernels that locate sections and decode them
 // into columns (hip_abi.hip: dec_palette_hint)
 constexpr uint32_t kStatFoldedByGuess = 12;
+// round 6: chunks whose lone DeltaVarint section k_section_dv_w decoded. All of a call's chunks: the codec's next calls do not
+// launch k_sections_cols_fast (it would find nothing to do); no chunk with a DeltaVarint section at all (kStatDvMode): they do
+// not launch k_section_dv_w. Both are accelerators in
+// front of k_decode_sections_cols, which decodes whatever is left whichever was launched (hip_abi.hip: dec_dv_hint)
+constexpr uint32_t kStatDvChunks = 13;
+constexpr uint32_t kStatDvMode = 14;  // chunks whose section k_locate_sections found to begin with mode byte 0 (whoever decodes it)
 
 struct DecChunk {
   uint64_t src_off;   // offset of the payload inside the batch's stream buffer

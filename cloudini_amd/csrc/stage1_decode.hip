@@ -176,7 +176,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         nf = 8u;
         many_used = true;
         hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u, 0u);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u, 0u, L.status);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
         DecChunk* dsec = reinterpret_cast<DecChunk*>(L.dsec);
         hipLaunchKernelGGL(k_section_offsets, dim3(L.n_chunks), dim3(kSoThreads), 0, L.stream, P, L.streams,
@@ -212,22 +212,23 @@ int stage1_launch_decode(const DecodeLaunch& L) {
           // batches -- the ones that take the SPLIT launches -- have CUs to spare: 4 -> 16 waves per chunk)
           const bool wide = lw >= 16 || (lw == 0 && L.n_chunks <= 64u);
           if (wide) hipLaunchKernelGGL(k_locate_sections<16>, dim3(L.n_chunks), dim3(1024), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u, 1u);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u, 1u, L.status);
           else hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u, 1u);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 0u, 1u, L.status);
         }
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
         static const bool no_scf = dev_env("CLDN_HIP_NO_FAST_COLS") != nullptr;  // A/B switch
         const bool scf = !no_scf && P.n_adaptive == 1u && L.slice_rec != nullptr && L.slices_done != nullptr;
-        if (scf && P.adaptive[0].bpv <= 4u) {
+        if (scf && P.adaptive[0].bpv <= 4u && L.dv_hint != 1u) {
           // round 6: a DeltaVarint section by the point decoder's machinery, one workgroup of 16 waves per chunk
-          // (stage1_decode_dv.h); chunks it hands back (long tokens, other modes) go on to the kernels below
+          // (stage1_decode_dv.h); chunks it hands back (long tokens, other modes) go on to the kernels below.
+          // (dv_hint 1: the codec's last calls had no such section -- the launch would find nothing to do)
           hipLaunchKernelGGL(k_section_dv_w, dim3(L.n_chunks), dim3(kDvWaves * 64u), (DvwLds::kTotal), L.stream, P, L.streams,
                              reinterpret_cast<const DecChunk*>(L.chunks), L.cols[0], (const uint32_t*)L.reg_end_pre, L.sec_cols,
-                             (const uint32_t*)L.slices_done);
+                             (const uint32_t*)L.slices_done, L.status);
           if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_section_dv_w");
         }
-        if (scf) {
+        if (scf && !(L.dv_hint == 2u && P.adaptive[0].bpv <= 4u)) {  // (dv_hint 2: k_section_dv_w took every chunk of the last calls)
           // workgroups per chunk: one when the batch has chunks enough to fill the chip (C3, 512 chunks: 0.404 / 0.400 /
           // 0.402 / 0.404 ms with 1 / 2 / 4 / 8; workgroups that find nothing to share cost C4 about 20 us per
           // 1024 of them), more for a single cloud's few chunks
@@ -447,7 +448,7 @@ int stage1_launch_decode(const DecodeLaunch& L) {
         DecColumns dcols = {};
         for (uint32_t a = 0; a < 8u; ++a) dcols.p[a] = L.cols[a];
         hipLaunchKernelGGL(k_locate_sections<4>, dim3(L.n_chunks), dim3(256), 0, L.stream, P, L.streams,
-                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 1u, 0u);
+                           reinterpret_cast<const DecChunk*>(L.chunks), P.n_ops, L.reg_end_pre, L.sec_cols, L.slices_done, 1u, 0u, L.status);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(e, "k_locate_sections");
         DecChunk* dsec = reinterpret_cast<DecChunk*>(L.dsec);
         hipLaunchKernelGGL(k_section_offsets, dim3(L.n_chunks), dim3(kSoThreads), 0, L.stream, P, L.streams,

@@ -36,7 +36,8 @@ struct DvwLds {
 
 __global__ __launch_bounds__(kDvWaves * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_section_dv_w(
     const DevPlan plan, const uint8_t* __restrict__ streams, const DecChunk* __restrict__ chunks, uint8_t* __restrict__ col0,
-    const uint32_t* __restrict__ reg_end_pre, uint8_t* __restrict__ sec_cols, const uint32_t* __restrict__ slices_done) {
+    const uint32_t* __restrict__ reg_end_pre, uint8_t* __restrict__ sec_cols, const uint32_t* __restrict__ slices_done,
+    uint32_t* __restrict__ status) {
   using L = DvwLds;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   unsigned long long* trec = reinterpret_cast<unsigned long long*>(smem + L::kTrecOff);
@@ -247,7 +248,10 @@ __global__ __launch_bounds__(kDvWaves * 64) __attribute__((amdgpu_waves_per_eu(8
   if (gave_up && lane == 0u) __hip_atomic_store(&misc[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (__ballot(irregular) != 0ull && lane == 0u) misc[0] = 1u;
   __syncthreads();
-  if (tid == 0u && misc[0] == 0u && __hip_atomic_load(&misc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u && misc[2] == n) sec_cols[c] = 1u;  // every point has its value: the chunk is done
+  if (tid == 0u && misc[0] == 0u && __hip_atomic_load(&misc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u && misc[2] == n) {
+    sec_cols[c] = 1u;  // every point has its value: the chunk is done
+    atomicAdd(&status[kStatDvChunks], 1u);
+  }
 }
 
 }  // namespace cldn

@@ -194,7 +194,8 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan, const uint8_t* __restrict__ streams,
                                                          const DecChunk* __restrict__ chunks, uint32_t n_ops,
                                                          uint32_t* __restrict__ reg_end_pre, uint8_t* __restrict__ sec_cols,
-                                                         uint32_t* __restrict__ slices_done, uint32_t keep_guess, uint32_t try_dv) {
+                                                         uint32_t* __restrict__ slices_done, uint32_t keep_guess, uint32_t try_dv,
+                                                         uint32_t* __restrict__ status) {
   __shared__ uint32_t wcnt[NW];
   __shared__ uint32_t found, pal_sh[2];
   const uint32_t c = blockIdx.x;
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan,
         if (tid == 0) {
           reg_end_pre[c] = at;
           slices_done[c] = 0u;  // (mode byte 0 in the top byte, no slice done)
+          atomicAdd(&status[kStatDvMode], 1u);
         }
         return;
       }
@@ -419,6 +421,7 @@ __global__ __launch_bounds__(NW * 64) void k_locate_sections(const DevPlan plan,
     reg_end_pre[c] = found;
     // the section's mode byte in the top byte: the workgroups of k_sections_cols_fast that have nothing to do leave on it
     slices_done[c] = (found < src_size ? (uint32_t)src[found] : 0xffu) << 24;
+    if (found < src_size && src[found] == 0u) atomicAdd(&status[kStatDvMode], 1u);
   }
 }
 
@@ -460,7 +463,10 @@ __global__ __launch_bounds__(kScfThreads) void k_sections_cols_fast(const DevPla
   const uint32_t c = blockIdx.x / parts;
   const uint32_t part = blockIdx.x % parts;
   const uint32_t tid = threadIdx.x;
-  if (part != 0u && (slices_done[c] >> 24) != 0u) return;  // only DeltaVarint sections are shared
+  {  // (the mode byte k_locate_sections left: a Palette section, or no section found, is nothing to share)
+    const uint32_t mb = slices_done[c] >> 24;
+    if (part != 0u && mb != 0u && mb != 2u && mb != 3u) return;
+  }
   if (sec_cols[c]) return;  // k_section_dv_w (round 6) has decoded the chunk's section
   const DecChunk dc = chunks[c];
   if (!dc.valid || plan.n_adaptive != 1u || plan.adaptive[0].bpv > 4u) return;
@@ -603,7 +609,10 @@ __global__ __launch_bounds__(kScfThreads) void k_sections_cols_fast(const DevPla
     return;
   }
 
-  if ((mode == 2u || mode == 3u) && part == 0u) {
+  if (mode == 2u || mode == 3u) {
+    // (round 6) every workgroup of the chunk parses the run table -- a section of at most 4 KiB -- and fills its share of the
+    // values: one lidar cloud per call has 4 chunks on 256 CUs, and the fill of 32768 values by 256 threads was the longest
+    // kernel of the call (26 us)
     if (src_size - off < 4u) return;
     const uint32_t runs = (uint32_t)src[off] | ((uint32_t)src[off + 1u] << 8) | ((uint32_t)src[off + 2u] << 16) | ((uint32_t)src[off + 3u] << 24);
     off += 4u;
@@ -730,7 +739,7 @@ __global__ __launch_bounds__(kScfThreads) void k_sections_cols_fast(const DevPla
     if (flags[0]) return;
     // fill: a thread owns 8 consecutive values -- one search for the first, a walk along the table for the rest, and
     // one 16/32-byte store
-    for (uint32_t i0 = tid * 8u; i0 < n; i0 += kScfThreads * 8u) {
+    for (uint32_t i0 = (part * kScfThreads + tid) * 8u; i0 < n; i0 += parts * kScfThreads * 8u) {
       uint32_t lo = 0u, hi = runs;  // last r with r_start[r] <= i0
       while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -765,7 +774,9 @@ __global__ __launch_bounds__(kScfThreads) void k_sections_cols_fast(const DevPla
         }
       }
     }
-    if (tid == 0) sec_cols[c] = 1u;
+    // the last of the chunk's workgroups to get here marks the column complete (the counter: the low bits of slices_done)
+    __syncthreads();
+    if (tid == 0 && (atomicAdd(slices_done + c, 1u) & 0xffffffu) + 1u == parts) sec_cols[c] = 1u;
   }
 }
 

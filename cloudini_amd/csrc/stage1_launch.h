@@ -85,6 +85,7 @@ struct DecodeLaunch {
   const uint32_t* h_cloud_first_chunk;
   uint32_t n_clouds;
   uint32_t n_chunks;
+  uint32_t dv_hint;                   // what the codec's earlier calls saw: 1 = no chunk had a lone DeltaVarint section, 2 = every chunk had, 0 = unknown / mixed
   void* chunks;                       // device [n_chunks] DecChunk (48 bytes each)
   uint32_t* reg_end;                  // device [n_chunks]: end of the regular stream per chunk (fast path)
   uint8_t* sec_done;                  // device [n_chunks]: 1 = sections decoded by k_decode_sections
