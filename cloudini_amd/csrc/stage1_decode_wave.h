@@ -37,7 +37,20 @@ constexpr uint32_t kWpPiece = kWpUnits * 16u;     // bytes of stream per piece
 constexpr uint32_t kWpSlots = 1024u;              // token slots per wave: <= 992 owned tokens + <= 16 of the halo unit
 constexpr uint32_t kWpRing = 64u;                 // chain records (slot = piece % kWpRing, tagged)
 constexpr uint32_t kWpSpinLimit = 1u << 18;
-constexpr int kWpSleep = 4;                       // x 64 cycles between two polls of a record
+#ifndef CLDN_WP_SLEEP
+#define CLDN_WP_SLEEP 4
+#endif
+constexpr int kWpSleep = CLDN_WP_SLEEP;                       // x 64 cycles between two polls of a record
+#ifndef CLDN_WP_BOOST
+#define CLDN_WP_BOOST 1
+#endif
+#if CLDN_WP_BOOST
+#define WP_BOOST(P) __builtin_amdgcn_s_setprio(P)
+#define WP_BOOST_BACK() __builtin_amdgcn_s_setprio(3)
+#else
+#define WP_BOOST(P)
+#define WP_BOOST_BACK() __builtin_amdgcn_s_setprio(1)
+#endif
 
 template <int NOPS>
 struct WpGeom {
@@ -392,6 +405,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
     if constexpr (SPLIT) {
       T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.t0[sp_base + p]);
     } else if (p != 0u) {
+      // (the hop from the record's arrival to this piece's own record is what every piece behind waits for: it runs at the
+      // highest priority -- among eight waves of equal priority on a SIMD its few instructions took 2 k cycles)
+      WP_BOOST(3);
       const unsigned long long* r = trec + ((p - 1u) & (kWpRing - 1u));
       unsigned long long x = wp_rec_load(r);
       if ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) != p) {  // not there yet: poll at low priority
@@ -405,13 +421,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
             break;
           }
         }
-        __builtin_amdgcn_s_setprio(1);
+        WP_BOOST_BACK();
       }
       T0 = (uint32_t)x;
       T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T0);
     }
     if (gave_up) break;  // uniform
     if (!SPLIT && lane == 0u) wp_rec_store(trec + (p & (kWpRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (T0 + cnt));
+    if (!SPLIT) WP_BOOST(1);
     if (T0 >= target) break;  // the regular stream ended in front of this piece (sections; uniform)
     if (T0 + cnt >= target) {  // uniform: the end that closes the last point lies in this piece
       const uint32_t want = target - T0;  // its 1-based rank among the piece's ends
@@ -538,6 +555,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
 #pragma unroll
       for (int o = 0; o < NOPS; ++o) carry[o] = __builtin_amdgcn_readfirstlane(sp.carry[(sp_base + p) * (size_t)NOPS + (size_t)o]);
     } else if (p != 0u) {
+      WP_BOOST(3);
       const unsigned long long* r = vrec + (size_t)((p - 1u) & (kWpRing - 1u)) * NOPS + min(lane, (uint32_t)NOPS - 1u);
       unsigned long long x = wp_rec_load(r);
       if (__ballot((uint32_t)(x >> 32) != p) != 0ull) {  // not there yet: poll at low priority
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
             break;
           }
         }
-        __builtin_amdgcn_s_setprio(1);
+        WP_BOOST_BACK();
       }
 #pragma unroll
       for (int o = 0; o < NOPS; ++o) carry[o] = __builtin_amdgcn_readlane((int)(uint32_t)x, o);
@@ -566,6 +584,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
       }
       if (lane < (uint32_t)NOPS)
         wp_rec_store(vrec + (size_t)(p & (kWpRing - 1u)) * NOPS + lane, ((unsigned long long)(p + 1u) << 32) | mine);
+      WP_BOOST(1);
     }
     // The bytes of my next piece were requested long ago: naming them here puts the wait for them IN FRONT of this piece's
     // stores. Left to the top of the loop it becomes s_waitcnt vmcnt(0) -- the compiler cannot count the stores of a variable

@@ -10,8 +10,8 @@
 // and several grid sizes (workgroups per CU).
 //
 // build: hipcc --offload-arch=gfx950 -O3 tools/hbm_calib.hip -o cloudini_amd/lib/hbm_calib   (cloudini_amd/build.py does it)
-// run:   cloudini_amd/lib/hbm_calib [GiB per buffer, default 1] [piece | points14 [points]]   (piece: only the piece kernel's own shape;
-//        points14: the point decoder's store shape)
+// run:   cloudini_amd/lib/hbm_calib [GiB per buffer, default 1] [piece | points14 [points] | shapes]   (piece: only the piece kernel's own shape;
+//        points14: the point decoder's store shape on the bench line's batch; shapes: the store shapes of the other configs' decode legs)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -132,6 +132,33 @@ __global__ void k_points14(const v4* __restrict__ in, uint8_t* __restrict__ o, s
   if (s.y == 123.456f) sink[blockIdx.x] = s.y;
 }
 
+// ---- the other configs' store shapes (round 6): what a decoder that leaves uncovered bytes alone writes per point ----------------
+//   KIND 0  C1 / C5: packed 12-byte XYZ points, one 12-byte store (every byte covered)
+//   KIND 1  C3: 32-byte points, x y z at 0 (12 bytes) + rgba at 16 (4 bytes): half of every 32-byte sector
+//   KIND 2  C3 with CLDN_HIP_FILL_ZERO: two 16-byte stores
+//   KIND 3  C4: packed 18-byte points, x y z intensity (one unaligned 16-byte store) + ring (2 bytes): every byte covered
+template <int KIND>
+__global__ void k_points_shape(uint8_t* __restrict__ o, size_t n_points, float x) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  typedef float v3 __attribute__((ext_vector_type(3)));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_points; i += stride) {
+    if (KIND == 0) {
+      *reinterpret_cast<v3*>(o + i * 12u) = v3{x, x, x};
+    } else if (KIND == 1) {
+      *reinterpret_cast<v3*>(o + i * 32u) = v3{x, x, x};
+      *reinterpret_cast<uint32_t*>(o + i * 32u + 16u) = (uint32_t)i;
+    } else if (KIND == 2) {
+      reinterpret_cast<v4*>(o + i * 32u)[0] = v4{x, x, x, 0.0f};
+      reinterpret_cast<v4*>(o + i * 32u)[1] = v4{x, 0.0f, 0.0f, 0.0f};
+    } else {
+      const v4 q = {x, x, x, x};
+      __builtin_memcpy(o + i * 18u, &q, 16);
+      const uint16_t r = (uint16_t)i;
+      __builtin_memcpy(o + i * 18u + 16u, &r, 2);
+    }
+  }
+}
+
 template <class F>
 static void run(const char* name, double bytes, int threads, int wg_per_cu, int cus, F launch) {
   hipEvent_t e0, e1;
@@ -217,6 +244,27 @@ int main(int argc, char** argv) {
       run("16 of 16", 16.0 * n_pts, 1024, w, cus, [&](int g, int th) { hipLaunchKernelGGL((k_points14<true, false>), dim3(g), dim3(th), 0, 0, a, (uint8_t*)o, n_pts, 1.0f, s); });
       run("12+2, +read", 22.4 * n_pts, 1024, w, cus, [&](int g, int th) { hipLaunchKernelGGL((k_points14<false, true>), dim3(g), dim3(th), 0, 0, a, (uint8_t*)o, n_pts, 1.0f, s); });
       run("16, +read", 22.4 * n_pts, 1024, w, cus, [&](int g, int th) { hipLaunchKernelGGL((k_points14<true, true>), dim3(g), dim3(th), 0, 0, a, (uint8_t*)o, n_pts, 1.0f, s); });
+    }
+    return 0;
+  }
+  if (argc > 2 && !strcmp(argv[2], "shapes")) {
+    // the decode legs of the other BASELINE configs: bytes the decoder writes, per point, with no arithmetic and no input
+    struct { const char* name; int kind; size_t pts; double step; double written; } sh[] = {
+        {"C1 12 of 12", 0, 16777216, 12, 12}, {"C3 12+4 of 32", 1, 16384000, 32, 16}, {"C3 32 of 32", 2, 16384000, 32, 32},
+        {"C4 16+2 of 18", 3, 33292288, 18, 18}, {"C5 12 of 12", 0, 10000000, 12, 12}};
+    const int wv[] = {2, 4, 8};
+    for (auto& q : sh) {
+      if (q.pts * q.step > bytes) { fprintf(stderr, "buffer too small\n"); return 1; }
+      for (int w : wv) {
+        char nm[64];
+        snprintf(nm, sizeof(nm), "%s", q.name);
+        const size_t np = q.pts;
+        // (the rate printed counts the bytes the decoder is credited with: the whole points)
+        if (q.kind == 0) run(nm, q.step * np, 1024, w, cus, [&](int g, int th) { hipLaunchKernelGGL((k_points_shape<0>), dim3(g), dim3(th), 0, 0, (uint8_t*)o, np, 1.0f); });
+        if (q.kind == 1) run(nm, q.step * np, 1024, w, cus, [&](int g, int th) { hipLaunchKernelGGL((k_points_shape<1>), dim3(g), dim3(th), 0, 0, (uint8_t*)o, np, 1.0f); });
+        if (q.kind == 2) run(nm, q.step * np, 1024, w, cus, [&](int g, int th) { hipLaunchKernelGGL((k_points_shape<2>), dim3(g), dim3(th), 0, 0, (uint8_t*)o, np, 1.0f); });
+        if (q.kind == 3) run(nm, q.step * np, 1024, w, cus, [&](int g, int th) { hipLaunchKernelGGL((k_points_shape<3>), dim3(g), dim3(th), 0, 0, (uint8_t*)o, np, 1.0f); });
+      }
     }
     return 0;
   }
