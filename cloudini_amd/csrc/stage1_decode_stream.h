@@ -210,6 +210,14 @@ __device__ __forceinline__ uint64_t sw_gorilla(const uint32_t* wbuf, uint32_t bp
 // {entry, points, window}), then the table is built for that window and one lane follows the jumps; a point whose '11'
 // token changes the window ends the round -- the table is rebuilt for the new window from there. The token's value bits
 // are XOR differences: the op joins the XOR-coded ones in both walks.
+#ifndef CLDN_SW_BOOST
+#define CLDN_SW_BOOST 1
+#endif
+#if CLDN_SW_BOOST
+#define SW_PRIO_HOP() __builtin_amdgcn_s_setprio(3)
+#else
+#define SW_PRIO_HOP() __builtin_amdgcn_s_setprio(1)
+#endif
 #ifdef CLDN_SW_TRACE
 #define SW_T(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_[k] += t_ - tl_; tl_ = t_; }
 #else
@@ -746,6 +754,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
       SW_T(2)
       // ---- chain 1: {entry offset, points in front} of the piece (MODE 2: and the window at its entry)
       uint32_t entry = a0, pts0 = 0u, st = 0u;  // (st: lane o = window of op o)
+      SW_PRIO_HOP();  // (round 6: from a record's arrival to this piece's own record at the highest priority, as in k_decode_points_w)
       if (p != 0u) {
         const unsigned long long* r = trec + ((p - 1u) & (L::kRing - 1u));
         const unsigned long long* rg = grec + (size_t)((p - 1u) & (L::kRing - 1u)) * kSwMaxOps + min(lane, n_ops - 1u);
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
               break;
             }
           }
-          __builtin_amdgcn_s_setprio(1);
+          SW_PRIO_HOP();
         }
         const uint32_t rv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
         entry = rv & 0xffu;
@@ -783,6 +792,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         const uint32_t pts1 = dead ? pts0 : min(pts0 + my_cnt, n);
         if (lane == 0u) wp_rec_store(trec + (p & (L::kRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
         if (GOR && lane < n_ops) wp_rec_store(grec + (size_t)(p & (L::kRing - 1u)) * kSwMaxOps + lane, ((unsigned long long)(p + 1u) << 32) | st);
+        __builtin_amdgcn_s_setprio(1);
         st_last = st;
         if (pts0 >= n) stop = true;
         else if (dead) {
@@ -949,6 +959,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         }
         if (lane == 0u) wp_rec_store(trec + (p & (L::kRing - 1u)), ((unsigned long long)(p + 1u) << 32) | (pts1 << 8) | out_entry);
         if (lane < n_ops) wp_rec_store(grec + (size_t)(p & (L::kRing - 1u)) * kSwMaxOps + lane, ((unsigned long long)(p + 1u) << 32) | st);
+        __builtin_amdgcn_s_setprio(1);
         st_last = st;
       }
     } else {
@@ -1121,6 +1132,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
     if (__ballot(irregular) != 0ull && lane == 0u) misc[0] = 1u;
     SW_T(5)
     // ---- chain 2: the running values in front of the piece (lane o: {tag, lo}, {tag | reset, hi} of op o)
+    SW_PRIO_HOP();
     if (p != 0u) {
       const unsigned long long* r = vrec + ((size_t)((p - 1u) & (L::kRing - 1u)) * kSwMaxOps + min(lane, n_ops - 1u)) * 2u;
       unsigned long long xl = wp_rec_load(r), xh = wp_rec_load(r + 1);
@@ -1136,7 +1148,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
             break;
           }
         }
-        __builtin_amdgcn_s_setprio(1);
+        SW_PRIO_HOP();
       }
       run_l = (xh << 32) | (xl & 0xffffffffull);
     } else {
@@ -1151,6 +1163,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MODE ? 
         wp_rec_store(w + 1, ((unsigned long long)(p + 1u) << 32) | (incl_l >> 32));
       }
     }
+    __builtin_amdgcn_s_setprio(1);
     SW_T(6)
     // ---- second walk: values, converted and stored; a lane stores its own point
     for (uint32_t r = 0; r * 64u < npts; ++r) {  // uniform
