@@ -574,6 +574,49 @@ def test_palette_hint_of_an_earlier_call_never_changes_bytes(oracle):
     codec.close()
 
 
+def test_launch_hints_of_earlier_calls_never_change_bytes(oracle):
+    """Round 6: the counters behind the launch hints are read back with every 4th decode call / 16th encode call only, and two
+    more hints ride on them (dec_dv_hint: which of the DeltaVarint accelerators a call launches; the encoder's mode hint picks the
+    fused Palette). ONE codec sees long runs of streams whose integer field takes each of the four modes, then single calls in
+    turn: whatever the hints say at that moment, bytes and modes are the oracle's."""
+    from cloudini_amd import native
+    info, pal = synth.lidar_xyzi(100_000, seed=5)                    # intensity: 256 levels -> Palette
+    n = pal.size // info.point_step
+    rs = np.random.RandomState(19)
+
+    def with_field(values_u16):
+        a = pal.copy().reshape(-1, info.point_step)
+        a[:, 12:14] = values_u16.astype(np.uint16).view(np.uint8).reshape(-1, 2)
+        return a.reshape(-1)
+    clouds = {"pal": pal,
+              "noisy": with_field(rs.randint(0, 65536, n)),          # -> DeltaVarint
+              "ring": with_field(np.arange(n) % 64),                 # -> DeltaRle
+              "const": with_field(np.repeat(rs.randint(0, 65536, n // 500 + 1), 500)[:n])}   # steps of 500 equal values -> Rle
+    streams, modes, wants = {}, {}, {}
+    for k, d in clouds.items():
+        streams[k], modes[k] = oracle.encode_stage1(info, d, return_modes=True)
+        wants[k] = oracle.decode_stage1(info, streams[k], n, fill=0x3C)
+    assert len({int(m[0]) for m in modes.values()}) == 4, modes     # the four modes are all there
+    codec = native.Codec(native.Plan(info))
+    order = ["pal"] * 6 + ["noisy"] * 6 + ["ring"] * 6 + ["const"] * 6 + ["noisy"] * 6 + ["pal"] * 6 + ["pal", "noisy", "ring", "const"] * 3
+    for i, k in enumerate(order):
+        out = np.full(pal.size, 0x3C, dtype=np.uint8)
+        got = codec.decode_host([streams[k]], [n], out=out)[0]
+        assert np.array_equal(got, wants[k]), (i, k)
+    enc_order = ["pal"] * 18 + ["noisy"] * 18 + ["ring"] * 3 + ["pal"] * 2 + ["ring"] * 18 + ["const"] * 17 + ["pal", "noisy", "ring", "const"] * 5
+    for i, k in enumerate(enc_order):
+        got, _sizes, got_modes = codec.encode_host([clouds[k]])
+        assert np.array_equal(got[0], streams[k]), (i, k)
+        assert list(got_modes[0]) == list(modes[k]), (i, k)
+    # and both directions interleaved on the one codec
+    for i, k in enumerate(["noisy", "pal", "ring", "const"] * 4):
+        got, _sizes, _m = codec.encode_host([clouds[k]])
+        assert np.array_equal(got[0], streams[k]), (i, k)
+        out = np.full(pal.size, 0x3C, dtype=np.uint8)
+        assert np.array_equal(codec.decode_host([got[0]], [n], out=out)[0], wants[k]), (i, k)
+    codec.close()
+
+
 @pytest.mark.parametrize("parts", [1, 2, 16])
 def test_chained_and_split_launches_of_the_point_kernel_agree(oracle, parts):
     """Small batches take the SPLIT launches of k_decode_points_w (round 5: the pieces of a chunk over several workgroups,
