@@ -582,6 +582,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, 8)
         const uint32_t pre = (bs_fl & (1u << o)) ? (uint32_t)bs[o] : (uint32_t)carry[o] + (uint32_t)bs[o];
         mine = lane == (uint32_t)o ? pre : mine;
       }
+#ifdef CLDN_WP_HOPDELAY  // (experiment: how much of the kernel is the chain? every hop of chain 2 made CLDN_WP_HOPDELAY x 64 cycles longer)
+      __builtin_amdgcn_s_sleep(CLDN_WP_HOPDELAY);
+#endif
       if (lane < (uint32_t)NOPS)
         wp_rec_store(vrec + (size_t)(p & (kWpRing - 1u)) * NOPS + lane, ((unsigned long long)(p + 1u) << 32) | mine);
       WP_BOOST(1);
