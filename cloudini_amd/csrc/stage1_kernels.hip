@@ -1024,17 +1024,37 @@ __global__ __launch_bounds__(kGorThreads) void k_gorilla_windows(const DevPlan p
   uint16_t* out = win_out + (size_t)blockIdx.x * kGorWinStride;
 
   uint32_t win_lead = 255u, win_trail = 0u;
+  // (round 6) a pass's 16 values per thread are requested up front, without a branch around any load (the two conditional
+  // loads per point -- the value and its predecessor, each with a conditional third dword -- drained the memory pipe sixteen
+  // times per pass and fetched every line twice); the predecessor is the neighbouring lane's value (DPP), a wave's first lane
+  // takes it from the last lane of the wave in front (LDS, one barrier per pass)
+  __shared__ unsigned long long wlast[kGorPPT * (kGorThreads / 64u) + 1u];  // [1 + k * 8 + wave]: value of that wave's lane 63; [0]: the pass in front
+  if (tid == 0u) wlast[0] = 0ull;
   for (uint32_t p0 = 0; p0 < n; p0 += kGorPass) {
+    uint64_t cur[kGorPPT];
 #pragma unroll
     for (uint32_t k = 0; k < kGorPPT; ++k) {
       const uint32_t i = p0 + k * kGorThreads + tid;
-      uint64_t x = 0u;
-      if (i < n) {
-        const uint8_t* q = base + (size_t)i * step;
-        const uint64_t cur = gor_load64(q, points_end);
-        const uint64_t prev = i ? gor_load64(q - step, points_end) : 0u;
-        x = i ? (cur ^ prev) : 0u;
-      }
+      const uint8_t* q8 = base + (size_t)(i < n ? i : n - 1u) * step;  // (lanes behind the chunk: a valid address, the value is not used)
+      const uint32_t mis = (uint32_t)((uintptr_t)q8 & 3u);
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(q8 - mis);
+      const bool third = reinterpret_cast<const uint8_t*>(q + 2) < points_end;  // (a dword is read only if it holds a byte of the buffer)
+      const uint32_t d0 = q[0], d1 = q[1], d2r = q[third ? 2 : 0];
+      const uint32_t d2 = third ? d2r : 0u;
+      cur[k] = (((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, mis)) << 32) | __builtin_amdgcn_alignbyte(d1, d0, mis);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kGorPPT; ++k)
+      if (lane == 63u) wlast[1u + k * (kGorThreads / 64u) + wave] = cur[k];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kGorPPT; ++k) {
+      const uint32_t i = p0 + k * kGorThreads + tid;
+      const uint64_t front = wlast[k * (kGorThreads / 64u) + wave];  // (lane 63 of the wave in front; [0]: the last value of the pass before)
+      const uint32_t plo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)front, (int)(uint32_t)cur[k], 0x138, 0xf, 0xf, false);          // wave_shr:1
+      const uint32_t phi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(front >> 32), (int)(uint32_t)(cur[k] >> 32), 0x138, 0xf, 0xf, false);
+      const uint64_t prev = (((uint64_t)phi) << 32) | plo;
+      const uint64_t x = (i < n && i != 0u) ? (cur[k] ^ prev) : 0ull;
       const bool counts = x != 0u;  // may open a window
       const uint32_t lead = x ? (uint32_t)__builtin_clzll(x) : 64u;
       const uint32_t trail = x ? (uint32_t)__builtin_ctzll(x) : 0u;
@@ -1047,6 +1067,7 @@ __global__ __launch_bounds__(kGorThreads) void k_gorilla_windows(const DevPlan p
       if (lane == 63u) bmin[k * (kGorThreads / 64u) + wave] = ml | (mt << 8);
     }
     __syncthreads();
+    if (tid == kGorThreads - 1u) wlast[0] = cur[kGorPPT - 1u];  // (read again behind the next pass's barrier)
     if (tid < 64u) {
       const uint32_t np = min(kGorPass, n - p0);
       const uint32_t my_bmin0 = lane < NB ? bmin[lane] : 0xffffu;
