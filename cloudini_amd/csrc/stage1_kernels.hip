@@ -494,16 +494,20 @@ __device__ __forceinline__ bool col_staged(const DevPlan& plan, uint32_t a, int 
 }
 
 // bytes [rel, rel + 8) of the dwords loaded for one point (rel + field size <= 4 * LOADW, guaranteed by the host)
+// (three dwords: an 8-byte field at an offset that is no multiple of 4 spans them. Rounds 2-5 took two and shifted -- the top
+// 1..3 bytes of such a field were lost; found by round 6's fuzz range 900000+, seed 923696: a UINT64 field at offset 25)
 template <int LOADW>
 __device__ __forceinline__ uint64_t field_from_regs(const FloatVec<LOADW>& pt, uint32_t rel) {
   const uint32_t di = rel >> 2;
-  uint32_t lo = 0u, hi = 0u;
+  uint32_t d0 = 0u, d1 = 0u, d2 = 0u;
 #pragma unroll
   for (int k = 0; k < LOADW; ++k) {
-    if ((uint32_t)k == di) lo = __float_as_uint(pt.v[k]);
-    if ((uint32_t)k == di + 1u) hi = __float_as_uint(pt.v[k]);
+    if ((uint32_t)k == di) d0 = __float_as_uint(pt.v[k]);
+    if ((uint32_t)k == di + 1u) d1 = __float_as_uint(pt.v[k]);
+    if ((uint32_t)k == di + 2u) d2 = __float_as_uint(pt.v[k]);
   }
-  return ((((uint64_t)hi) << 32) | lo) >> ((rel & 3u) * 8u);
+  const uint32_t mis = rel & 3u;
+  return (((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, mis)) << 32) | __builtin_amdgcn_alignbyte(d1, d0, mis);
 }
 
 // UNAL: points are not 4-byte aligned (odd point_step / offset / base, e.g. packed 18-byte points): every lane loads

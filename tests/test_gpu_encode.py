@@ -107,6 +107,34 @@ def test_all_schema_families(oracle, name, info, data):
     check_encode(oracle, info, [data])
 
 
+@pytest.mark.parametrize("ftype", [FieldType.UINT64, FieldType.INT64])
+@pytest.mark.parametrize("off64,lanes", [(25, 4), (17, 3), (18, 3), (19, 3), (21, 4), (23, 4), (24, 4)])
+def test_a_64_bit_integer_field_at_an_odd_offset_keeps_its_top_bytes(oracle, ftype, off64, lanes):
+    """Round 6, fuzz seed 923696 (a range no earlier campaign had run): a UINT64 field at offset 25 behind four float lanes. The
+    piece kernel takes such a field from the dwords it loaded for the point; for an 8-byte field at an offset that is no multiple of
+    4 that is THREE dwords -- rounds 2-5 took two, and the field's top 1..3 bytes never reached its column (values of 2^40 and more
+    came out truncated: a shorter, wrong DeltaVarint section). Every misalignment, both pipelines, large and small values,
+    and the decoder on the way back."""
+    from cloudini_amd import native
+    n = 70_001
+    rs = np.random.RandomState(off64 * 7 + lanes)
+    fields = [(f"f{k}", 4 + 4 * k, FieldType.FLOAT32, 0.01) for k in range(lanes)]
+    fields.append(("big", off64, ftype, None))
+    step = off64 + 8 + 3
+    cols = {f"f{k}": np.cumsum(rs.normal(0, 0.01, n)).astype(np.float32) for k in range(lanes)}
+    big = rs.randint(0 if ftype == FieldType.UINT64 else -2**62, 2**62, n, dtype=np.int64)
+    big[::7] = rs.randint(0, 100, big[::7].size)          # small values between the large ones
+    cols["big"] = big.astype(np.uint64 if ftype == FieldType.UINT64 else np.int64)
+    info = cases.make_info(fields, step, n)
+    data = cases.pack(info, cols, n)
+    streams = check_encode(oracle, info, [data])
+    codec = native.Codec(native.Plan(info))
+    out = np.full(data.size, 0xA5, dtype=np.uint8)
+    got = codec.decode_host([streams[0]], [n], out=out)[0]
+    assert np.array_equal(got, oracle.decode_stage1(info, streams[0], n, fill=0xA5))
+    codec.close()
+
+
 def test_known_answer_vectors_gpu():
     from cloudini_amd import native
     for name, info, data, payload in cases.kat_vectors():
