@@ -135,6 +135,37 @@ def test_a_64_bit_integer_field_at_an_odd_offset_keeps_its_top_bytes(oracle, fty
     codec.close()
 
 
+@pytest.mark.parametrize("lanes", [3, 4])
+@pytest.mark.parametrize("ftype", [FieldType.UINT16, FieldType.INT32, FieldType.UINT32, FieldType.INT64, FieldType.UINT64])
+def test_integer_fields_at_every_offset_around_the_loaded_window(oracle, lanes, ftype):
+    """An enumeration next to the fuzz campaigns (round 6): the piece kernel loads up to eight dwords per point behind the first float
+    lane and takes integer fields that lie inside them from registers, others from memory. One full-range integer field at EVERY
+    byte offset from right behind the float lanes to beyond the window, for 2-, 4- and 8-byte types: the field's bytes must reach
+    its section whole wherever it lies (inside, straddling the window's end, outside; aligned or not)."""
+    from cloudini_amd import native
+    n = 9000
+    size = {FieldType.UINT16: 2, FieldType.INT32: 4, FieldType.UINT32: 4, FieldType.INT64: 8, FieldType.UINT64: 8}[ftype]
+    npt = {FieldType.UINT16: np.uint16, FieldType.INT32: np.int32, FieldType.UINT32: np.uint32, FieldType.INT64: np.int64,
+           FieldType.UINT64: np.uint64}[ftype]
+    rs = np.random.RandomState(lanes * 100 + size)
+    ii = np.iinfo(npt)
+    for first in (0, 2):                       # the float lanes 4-byte aligned, or not
+        for off in range(first + 4 * lanes, first + 42):
+            fields = [(f"f{k}", first + 4 * k, FieldType.FLOAT32, 0.001) for k in range(lanes)] + [("v", off, ftype, None)]
+            step = off + size + int(rs.randint(0, 4))
+            cols = {f"f{k}": np.cumsum(rs.normal(0, 0.01, n)).astype(np.float32) for k in range(lanes)}
+            cols["v"] = rs.randint(max(ii.min, -2**62), min(ii.max, 2**62), n, dtype=np.int64).astype(npt)
+            info = cases.make_info(fields, step, n)
+            data = cases.pack(info, cols, n)
+            want = oracle.encode_stage1(info, data)
+            codec = native.Codec(native.Plan(info))
+            got, _sizes, _modes = codec.encode_host([data])
+            assert np.array_equal(got[0], want), (lanes, int(ftype), first, off, step)
+            out = np.full(data.size, 0x11, dtype=np.uint8)
+            assert np.array_equal(codec.decode_host([want], [n], out=out)[0], oracle.decode_stage1(info, want, n, fill=0x11)), (lanes, int(ftype), first, off)
+            codec.close()
+
+
 def test_known_answer_vectors_gpu():
     from cloudini_amd import native
     for name, info, data, payload in cases.kat_vectors():
