@@ -53,6 +53,22 @@ def test_very_wide_schemas_match_reference(oracle, reflib, seed):
     assert np.array_equal(oracle.decode_stage1(info, want, n, fill=0x5A), want_dec), seed
 
 
+@pytest.mark.parametrize("seed", list(range(7000, 7200)))
+def test_corner_schemas_match_reference(oracle, reflib, seed):
+    """The dense corner-case generator of tests/test_gpu_fuzz.py (round 6: integer fields packed behind 3 or 4 float lanes at every
+    alignment, half of them 64-bit, full-range values): the checker itself against the compiled reference on the seeds the GPU
+    test runs, both ways."""
+    import test_gpu_fuzz
+    info, data = test_gpu_fuzz._corner_case(seed)
+    n = len(data) // info.point_step
+    want = reflib.encode_stage1(info, data)
+    got = oracle.encode_stage1(info, data)
+    assert np.array_equal(got, want), seed
+    full = reflib.encode(info, data)
+    want_dec, _yaml = reflib.decode(full, len(data), fill=0x5A)
+    assert np.array_equal(oracle.decode_stage1(info, want, n, fill=0x5A), want_dec), seed
+
+
 def test_reference_mode_bytes(oracle):
     """Per-chunk mode bytes pinned by test_field_encoders.cpp:590-674."""
     for name, info, data, modes in cases.reference_int_sequences():
