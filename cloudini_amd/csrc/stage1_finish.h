@@ -410,7 +410,7 @@ __global__ __launch_bounds__(T, (T == 1024 ? 4 : 8)) __attribute__((amdgpu_num_s
   }
   const unsigned long long dst0 = L.base;
   if (A.trace != nullptr && tid == 0u && leader) A.trace[(size_t)c * 16u + 2u] = wall_clock64();
-  if (wave == 0u) fin_layout(L, n_segs, s_a, s_b, (uint32_t)((dst0 + 4ull) & 15ull), lane);
+  if (wave == 0u) fin_layout(L, n_segs, s_a, s_b, (uint32_t)(((uintptr_t)A.out + dst0 + 4ull) & 15ull), lane);  // (the ADDRESS decides: `out` may have any alignment)
   __syncthreads();
   if (A.trace != nullptr && tid == 0u && leader) A.trace[(size_t)c * 16u + 7u] = wall_clock64();
   const uint32_t payload = L.payload;

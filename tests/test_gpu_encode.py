@@ -166,6 +166,67 @@ def test_integer_fields_at_every_offset_around_the_loaded_window(oracle, lanes, 
             codec.close()
 
 
+@pytest.mark.parametrize("mis_in,mis_out", [(0, 1), (0, 2), (0, 8), (1, 0), (2, 3), (3, 5), (0, 4), (2, 12)])
+def test_device_buffers_at_any_address(oracle, mis_in, mis_out):
+    """Round 6 (found by the corner-case campaign's device-resident leg): `out` at a device address that is no multiple of 16 --
+    k_finish laid its copy items out by the stream OFFSET, not by the address, and misplaced bytes. The BASELINE shapes with input,
+    stream and decoded output at odd device addresses, batches of ragged clouds, outputs written in place by the kernels."""
+    import torch
+    from cloudini_amd import native
+    dev = torch.device("cuda", 0)
+    for make in (lambda: synth.lidar_xyzi(70_001, seed=5), lambda: synth.lidar_xyz(40_000, seed=6), lambda: synth.velodyne_xyzir(50_000, seed=7),
+                 lambda: synth.depthcam_xyzrgba(320, 200, seed=8)):
+        info, data = make()
+        step = info.point_step
+        n = data.size // step
+        cuts = [0, n // 3, n // 3, n - 1, n]                       # ragged clouds, one of them empty, one of one point
+        parts = [data[a * step:b * step] for a, b in zip(cuts[:-1], cuts[1:])]
+        wants = [oracle.encode_stage1(info, q) for q in parts]
+        npts = np.array([len(q) // step for q in parts], dtype=np.uint64)
+        plan = native.Plan(info)
+        codec = native.Codec(plan, device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
+        cap = int(sum(plan.stage1_bound(int(k)) for k in npts))
+        d_in = torch.zeros(data.size + 16, dtype=torch.uint8, device=dev)
+        d_in[mis_in:mis_in + data.size] = torch.from_numpy(data).to(dev)
+        d_out = torch.zeros(cap + 32, dtype=torch.uint8, device=dev)
+        d_off = torch.zeros(len(parts) + 1, dtype=torch.int64, device=dev)
+        n_chunks = int(sum((int(k) + 32767) // 32768 for k in npts))
+        d_sizes = torch.zeros(max(1, n_chunks), dtype=torch.int32, device=dev)
+        for _ in range(2):                                          # (the second call runs with the first one's hints)
+            codec.encode_device(d_in.data_ptr() + mis_in, npts, d_out.data_ptr() + mis_out, cap, d_off.data_ptr(), d_sizes.data_ptr(), 0)
+            codec.status()
+            offs = d_off.cpu().numpy().astype(np.uint64)
+            got = d_out[mis_out:mis_out + int(offs[-1])].cpu().numpy()
+            assert [int(offs[k + 1] - offs[k]) for k in range(len(parts))] == [w.size for w in wants]
+            assert np.array_equal(got, np.concatenate(wants)), (info.point_step, mis_in, mis_out)
+        d_dec = torch.full((data.size + 16,), 0x42, dtype=torch.uint8, device=dev)
+        codec.decode_device(d_out.data_ptr() + mis_out, offs, npts, d_dec.data_ptr() + mis_in, data.size, d_sizes.data_ptr())
+        codec.status()
+        want_dec = np.concatenate([oracle.decode_stage1(info, w, int(k), fill=0x42) for w, k in zip(wants, npts)])
+        assert np.array_equal(d_dec[mis_in:mis_in + data.size].cpu().numpy(), want_dec), (info.point_step, mis_in, mis_out)
+        codec.close()
+    # LZ4 blocks on the device written at an odd address: the same bytes as at an aligned one (stage 2 of the same codec setting)
+    info, data = synth.lidar_xyzi(70_001, seed=5)
+    n = data.size // info.point_step
+    plan = native.Plan(info)
+    for level in (1, 2):
+        codec = native.Codec(plan, device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
+        codec.set_stage2(level)
+        cap = plan.stage2_bound(n, level)
+        d_in = torch.zeros(data.size + 16, dtype=torch.uint8, device=dev)
+        d_in[mis_in:mis_in + data.size] = torch.from_numpy(data).to(dev)
+        outs = []
+        for mo in (0, mis_out):
+            d_out = torch.zeros(cap + 32, dtype=torch.uint8, device=dev)
+            d_off = torch.zeros(2, dtype=torch.int64, device=dev)
+            codec.encode_device(d_in.data_ptr() + mis_in, np.array([n], dtype=np.uint64), d_out.data_ptr() + mo, cap, d_off.data_ptr(), 0, 0)
+            codec.status()
+            total = int(d_off.cpu().numpy()[1])
+            outs.append(d_out[mo:mo + total].cpu().numpy())
+        assert outs[0].size > 0 and np.array_equal(outs[0], outs[1]), (level, mis_in, mis_out)
+        codec.close()
+
+
 def test_known_answer_vectors_gpu():
     from cloudini_amd import native
     for name, info, data, payload in cases.kat_vectors():
