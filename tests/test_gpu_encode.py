@@ -205,6 +205,28 @@ def test_device_buffers_at_any_address(oracle, mis_in, mis_out):
         want_dec = np.concatenate([oracle.decode_stage1(info, w, int(k), fill=0x42) for w, k in zip(wants, npts)])
         assert np.array_equal(d_dec[mis_in:mis_in + data.size].cpu().numpy(), want_dec), (info.point_step, mis_in, mis_out)
         codec.close()
+    # the size arrays themselves at addresses the kernels cannot write in place (stream_offsets 4 bytes off an 8-byte boundary, chunk_sizes
+    # 2 bytes off a 4-byte one): filled by a copy behind the kernels instead -- same values
+    info, data = synth.lidar_xyzi(70_001, seed=5)
+    n = data.size // info.point_step
+    plan = native.Plan(info)
+    codec = native.Codec(plan, device=0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    want = oracle.encode_stage1(info, data)
+    d_in = torch.from_numpy(data).to(dev)
+    d_out = torch.zeros(plan.stage1_bound(n), dtype=torch.uint8, device=dev)
+    d_meta = torch.zeros(256, dtype=torch.uint8, device=dev)
+    for off_mis, size_mis in ((4, 0), (0, 2), (4, 2), (0, 0)):
+        d_meta.zero_()
+        codec.encode_device(d_in.data_ptr(), np.array([n], dtype=np.uint64), d_out.data_ptr(), d_out.numel(), d_meta.data_ptr() + off_mis,
+                            d_meta.data_ptr() + 64 + size_mis, 0)
+        codec.status()
+        meta = d_meta.cpu().numpy()
+        offs = meta[off_mis:off_mis + 16].copy().view(np.uint64)
+        sizes = meta[64 + size_mis:64 + size_mis + 12].copy().view(np.uint32)
+        assert int(offs[0]) == 0 and int(offs[1]) == want.size, (off_mis, size_mis, offs)
+        assert int(sizes.astype(np.uint64).sum()) + 4 * 3 == want.size, (off_mis, size_mis, sizes)
+        assert np.array_equal(d_out[:want.size].cpu().numpy(), want)
+    codec.close()
     # LZ4 blocks on the device written at an odd address: the same bytes as at an aligned one (stage 2 of the same codec setting)
     info, data = synth.lidar_xyzi(70_001, seed=5)
     n = data.size // info.point_step
