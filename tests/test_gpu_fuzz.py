@@ -314,6 +314,62 @@ def test_corrupted_streams_decode_like_the_oracle(oracle, seed):
     codec.close()
 
 
+def _damaged_case(seed):
+    """Round 6: damage on streams of DIVERSE schemas (the test above draws its random schemas from 100 seeds only): the schema from
+    the random generator (even seeds) or the dense corner-case generator (odd seeds) at this very seed, then a flip / truncation /
+    insertion / deletion, now and then aimed at a chunk's last bytes (where its sections lie)."""
+    rs = np.random.RandomState(seed + 77)
+    info, data = _corner_case(seed) if seed & 1 else _random_case(seed)
+    return rs, info, data
+
+
+def _damage(rs, s):
+    kind = rs.randint(0, 5)
+    s = s.copy()
+    if kind == 0:
+        for _ in range(int(rs.randint(1, 4))):
+            s[rs.randint(0, len(s))] ^= np.uint8(1 << rs.randint(0, 8))
+    elif kind == 1:
+        s = s[: rs.randint(1, len(s))]
+    elif kind == 2:
+        pos = rs.randint(4, len(s))
+        s = np.concatenate([s[:pos], rs.randint(0, 256, int(rs.randint(1, 4))).astype(np.uint8), s[pos:]])
+    elif kind == 3:
+        pos = rs.randint(4, len(s) - 1)
+        s = np.concatenate([s[:pos], s[pos + 1:]])
+    else:  # the first chunk's tail: its sections
+        size = int(s[0]) | int(s[1]) << 8 | int(s[2]) << 16 | int(s[3]) << 24
+        end = min(len(s), 4 + size)
+        pos = max(4, end - 1 - int(rs.randint(0, min(64, max(1, end - 4)))))
+        s[pos] = np.uint8(rs.randint(0, 256))
+    return s
+
+
+@pytest.mark.parametrize("seed", list(range(9000, 9200)) + list(range((_BASE or 9200) + 9_000_000, (_BASE or 9200) + 9_000_000 + _EXTRA // 10)))
+def test_damaged_streams_of_diverse_schemas_decode_like_the_oracle(oracle, seed):
+    from cloudini_amd import native
+    rs, info, data = _damaged_case(seed)
+    n = data.size // info.point_step
+    s = oracle.encode_stage1(info, data)
+    if len(s) < 8:
+        pytest.skip("empty stream")
+    s = _damage(rs, s)
+    try:
+        want = oracle.decode_stage1(info, s, n, fill=0xE1)
+    except Exception:
+        want = None
+    codec = native.Codec(native.Plan(info))
+    out = np.full(max(1, data.size), 0xE1, dtype=np.uint8)
+    if want is None:
+        with pytest.raises(native.CloudiniHipError) as e:
+            codec.decode_host([s], [n], out=out)
+        assert e.value.code == -6, seed
+    else:
+        got = codec.decode_host([s], [n], out=out)[0]
+        assert np.array_equal(got, want), seed
+    codec.close()
+
+
 @pytest.mark.parametrize("seed", list(range(7000, 7040)))
 def test_host_mirror_full_streams_match_the_reference(reflib, seed):
     """PointcloudEncoder / PointcloudDecoder of the host mirror (header, chunk framing, NONE / LZ4 / ZSTD, with and

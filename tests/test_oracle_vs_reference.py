@@ -69,6 +69,30 @@ def test_corner_schemas_match_reference(oracle, reflib, seed):
     assert np.array_equal(oracle.decode_stage1(info, want, n, fill=0x5A), want_dec), seed
 
 
+def test_damaged_streams_of_diverse_schemas_match_reference(oracle, reflib):
+    """The seeds tests/test_gpu_fuzz.py::test_damaged_streams_of_diverse_schemas_decode_like_the_oracle runs by default: the checker's
+    accept / reject decision and bytes against the compiled reference's."""
+    import test_gpu_fuzz
+    for seed in range(9000, 9200):
+        rs, info, data = test_gpu_fuzz._damaged_case(seed)
+        n = data.size // info.point_step
+        s = oracle.encode_stage1(info, data)
+        if len(s) < 8:
+            continue
+        s = test_gpu_fuzz._damage(rs, s)
+        try:
+            a = oracle.decode_stage1(info, s, n, fill=0xE1)
+        except Exception:
+            a = None
+        try:
+            b = reflib.decode_noheader(info.copy(width=n, height=1), s, fill=0xE1)
+        except Exception:
+            b = None
+        assert (a is None) == (b is None), seed
+        if a is not None:
+            assert np.array_equal(a, b), seed
+
+
 def test_reference_mode_bytes(oracle):
     """Per-chunk mode bytes pinned by test_field_encoders.cpp:590-674."""
     for name, info, data, modes in cases.reference_int_sequences():
