@@ -163,7 +163,7 @@ def test_corner_schema(oracle, seed):
         # every cloud commits its own modes and starts its own delta chains
         rs = np.random.RandomState(seed)
         step = info.point_step
-        cuts = sorted({0, n} | {int(c) for c in rs.randint(0, n + 1, 3)})
+        cuts = sorted({0, n} | {int(c) for c in rs.randint(0, n + 1, 11 if seed % 9 == 0 else 3)})  # (more than 8 clouds: the decoder's tables are uploaded, not passed as a kernel argument)
         parts = [data[a * step:b * step] for a, b in zip(cuts[:-1], cuts[1:])] + [data[:0], data[:step]]
         wants = [oracle.encode_stage1(info, q) for q in parts]
         got_streams, _sizes, _modes = codec.encode_host(parts)
@@ -199,6 +199,23 @@ def test_corner_schema(oracle, seed):
                             d_sizes.data_ptr())
         codec.status()
         assert np.array_equal(d_dec[mis_in:mis_in + data.size].cpu().numpy(), oracle.decode_stage1(info, want, n, fill=0x6D)), (seed, "device decode")
+    if seed % 7 == 0:
+        # the CHUNK-TABLE entry points (cldn_hip_encode_stage1_chunks: intra-chunk placement, sections appended behind the regular
+        # stream; cldn_hip_frame_chunks frames the table later, here at an odd output address)
+        import torch
+        dev = torch.device("cuda", 0)
+        d_pts = torch.from_numpy(data).to(dev)
+        mis = int(seed // 7 % 16)
+        cap = plan.stage1_bound(n)
+        d_out = torch.zeros(cap + 32, dtype=torch.uint8, device=dev)
+        d_off = torch.zeros(2, dtype=torch.int64, device=dev)
+        for _round in range(2):
+            codec.encode_chunks_device(d_pts.data_ptr(), np.array([n], dtype=np.uint64))
+            codec.frame_chunks_device(d_out.data_ptr() + mis, cap, d_off.data_ptr())
+            codec.status()
+            total = int(d_off.cpu().numpy()[1])
+            assert total == want.size, (seed, "chunk table", total, want.size)
+            assert np.array_equal(d_out[mis:mis + total].cpu().numpy(), want), (seed, "chunk table + framing", mis)
     codec.close()
 
 
