@@ -100,64 +100,10 @@ def test_random_schema(oracle, seed):
     codec.close()
 
 
-def _corner_case(seed):
-    """Round 6, after seed 923696: schemas of the shape the piece kernel treats specially, drawn densely -- 3 or 4 leading lossy
-    floats, then a few integer fields (half of them 64-bit) packed with gaps of 0..3 bytes so that they land inside, across and
-    behind the kernel's loaded window at every alignment, mostly full-range values; now and then a double or a byte behind."""
-    rs = np.random.RandomState(seed)
-    n = int(rs.choice([4097, 9000, 33000]))
-    lanes = int(rs.choice([3, 4]))
-    off = int(rs.choice([0, 0, 1, 2, 4]))
-    fields, cols = [], {}
-    for k in range(lanes):
-        fields.append((f"f{k}", off, F.FLOAT32, float(rs.choice([0.001, 0.01, 0.0005]))))
-        cols[f"f{k}"] = np.cumsum(rs.normal(0, 0.01, n)).astype(np.float32)
-        off += 4 + (int(rs.choice([0, 0, 0, 4])) if k == lanes - 2 else 0)   # (now and then the padded fourth lane of PCL / Ouster points)
-    for i in range(int(rs.randint(1, 5))):
-        t = F(int(rs.choice([9, 10, 9, 10, 5, 6, 3, 4])))
-        off += int(rs.choice([0, 0, 1, 2, 3]))
-        ii = np.iinfo(_NP[t])
-        kind = rs.randint(0, 5)
-        if kind <= 2:
-            v = rs.randint(max(ii.min, -2**62), min(ii.max, 2**62), n, dtype=np.int64)
-        elif kind == 3:
-            v = rs.randint(0, 100, n)
-        else:
-            v = np.arange(n) % 77
-        fields.append((f"i{i}", off, t, None))
-        cols[f"i{i}"] = v.astype(_NP[t])
-        off += _SIZE[t]
-    if rs.rand() < 0.3:
-        off += int(rs.choice([0, 1, 3]))
-        fields.append(("d", off, F.FLOAT64, None if rs.rand() < 0.5 else 1e-6))
-        cols["d"] = (rs.uniform(0, 1, n) + 1.6e9).astype(np.float64)
-        off += 8
-    if rs.rand() < 0.3:
-        fields.append(("b", off, F.UINT8, None))
-        cols["b"] = rs.randint(0, 256, n).astype(np.uint8)
-        off += 1
-    step = off + int(rs.choice([0, 0, 1, 3, 8]))
-    info = cases.make_info(fields, step, n, enc=EncodingOptions.LOSSY, version=int(rs.choice([5, 5, 5, 4])))
-    return info, cases.pack(info, cols, n)
-
-
-# (5007720: `out` at an address that is no multiple of 16 -- k_finish laid its copy items out by the stream offset and lost a
-# 16-byte unit where the two disagreed about a segment's head across an item boundary; found by this generator's campaign)
-@pytest.mark.parametrize("seed", list(range(7000, 7200)) + [5007720] + list(range((_BASE or 7200) + 5_000_000, (_BASE or 7200) + 5_000_000 + _EXTRA // 10)))
-def test_corner_schema(oracle, seed):
+def _other_entry_points(oracle, codec, plan, info, data, want, n, seed):
+    """The legs behind the single-cloud host call (round 6): ragged batches, device-resident buffers at odd addresses, the
+    chunk-table entry points, CLDN_HIP_FILL_ZERO -- each for a share of the seeds."""
     from cloudini_amd import native
-    info, data = _corner_case(seed)
-    n = data.size // info.point_step
-    want, want_modes = oracle.encode_stage1(info, data, return_modes=True)
-    plan = native.Plan(info)
-    codec = native.Codec(plan)
-    streams, _sizes, modes = codec.encode_host([data])
-    assert np.array_equal(streams[0], want), (seed, [(f.name, int(f.type), f.offset, f.resolution) for f in info.fields], info.point_step, info.version)
-    if plan.adaptive_fields:
-        assert list(modes[0]) == list(want_modes)
-    out = np.full(max(1, data.size), 0x6D, dtype=np.uint8)
-    got = codec.decode_host([want], [n], out=out)[0]
-    assert np.array_equal(got, oracle.decode_stage1(info, want, n, fill=0x6D)), seed
     if seed % 3 == 0:
         # the same points as a ragged BATCH through the same codec (a cloud that ends inside a chunk, an empty one, one point):
         # every cloud commits its own modes and starts its own delta chains
@@ -216,6 +162,98 @@ def test_corner_schema(oracle, seed):
             total = int(d_off.cpu().numpy()[1])
             assert total == want.size, (seed, "chunk table", total, want.size)
             assert np.array_equal(d_out[mis:mis + total].cpu().numpy(), want), (seed, "chunk table + framing", mis)
+    if seed % 11 == 0:
+        # CLDN_HIP_FILL_ZERO: the bytes of a point that no field covers may come out as 0 instead of keeping the buffer's content --
+        # every covered byte is the oracle's, every uncovered one is the buffer's old byte or 0
+        c2 = native.Codec(plan)
+        c2.set_decode_fill(True)
+        out = np.full(max(1, data.size), 0xE7, dtype=np.uint8)
+        got = c2.decode_host([want], [n], out=out)[0].reshape(n, info.point_step)
+        ref = oracle.decode_stage1(info, want, n, fill=0xE7).reshape(n, info.point_step)
+        covered = np.zeros(info.point_step, dtype=bool)
+        for f in info.fields:
+            covered[f.offset:f.offset + _SIZE[F(int(f.type))]] = True
+        assert np.array_equal(got[:, covered], ref[:, covered]), (seed, "fill zero: covered bytes")
+        unc = got[:, ~covered]
+        assert np.all((unc == 0xE7) | (unc == 0)), (seed, "fill zero: uncovered bytes")
+        c2.close()
+
+
+def _corner_case(seed):
+    """Round 6, after seed 923696: schemas of the shape the piece kernel treats specially, drawn densely -- 3 or 4 leading lossy
+    floats, then a few integer fields (half of them 64-bit) packed with gaps of 0..3 bytes so that they land inside, across and
+    behind the kernel's loaded window at every alignment, mostly full-range values; now and then a double or a byte behind."""
+    rs = np.random.RandomState(seed)
+    n = int(rs.choice([4097, 9000, 33000]))
+    lanes = int(rs.choice([3, 4]))
+    off = int(rs.choice([0, 0, 1, 2, 4]))
+    fields, cols = [], {}
+    for k in range(lanes):
+        fields.append((f"f{k}", off, F.FLOAT32, float(rs.choice([0.001, 0.01, 0.0005]))))
+        cols[f"f{k}"] = np.cumsum(rs.normal(0, 0.01, n)).astype(np.float32)
+        off += 4 + (int(rs.choice([0, 0, 0, 4])) if k == lanes - 2 else 0)   # (now and then the padded fourth lane of PCL / Ouster points)
+    for i in range(int(rs.randint(1, 5))):
+        t = F(int(rs.choice([9, 10, 9, 10, 5, 6, 3, 4])))
+        off += int(rs.choice([0, 0, 1, 2, 3]))
+        ii = np.iinfo(_NP[t])
+        kind = rs.randint(0, 5)
+        if kind <= 2:
+            v = rs.randint(max(ii.min, -2**62), min(ii.max, 2**62), n, dtype=np.int64)
+        elif kind == 3:
+            v = rs.randint(0, 100, n)
+        else:
+            v = np.arange(n) % 77
+        fields.append((f"i{i}", off, t, None))
+        cols[f"i{i}"] = v.astype(_NP[t])
+        off += _SIZE[t]
+    if rs.rand() < 0.3:
+        off += int(rs.choice([0, 1, 3]))
+        fields.append(("d", off, F.FLOAT64, None if rs.rand() < 0.5 else 1e-6))
+        cols["d"] = (rs.uniform(0, 1, n) + 1.6e9).astype(np.float64)
+        off += 8
+    if rs.rand() < 0.3:
+        fields.append(("b", off, F.UINT8, None))
+        cols["b"] = rs.randint(0, 256, n).astype(np.uint8)
+        off += 1
+    step = off + int(rs.choice([0, 0, 1, 3, 8]))
+    info = cases.make_info(fields, step, n, enc=EncodingOptions.LOSSY, version=int(rs.choice([5, 5, 5, 4])))
+    return info, cases.pack(info, cols, n)
+
+
+# (5007720: `out` at an address that is no multiple of 16 -- k_finish laid its copy items out by the stream offset and lost a
+# 16-byte unit where the two disagreed about a segment's head across an item boundary; found by this generator's campaign)
+@pytest.mark.parametrize("seed", list(range(7000, 7200)) + [5007720] + list(range((_BASE or 7200) + 5_000_000, (_BASE or 7200) + 5_000_000 + _EXTRA // 10)))
+def test_corner_schema(oracle, seed):
+    from cloudini_amd import native
+    info, data = _corner_case(seed)
+    n = data.size // info.point_step
+    want, want_modes = oracle.encode_stage1(info, data, return_modes=True)
+    plan = native.Plan(info)
+    codec = native.Codec(plan)
+    streams, _sizes, modes = codec.encode_host([data])
+    assert np.array_equal(streams[0], want), (seed, [(f.name, int(f.type), f.offset, f.resolution) for f in info.fields], info.point_step, info.version)
+    if plan.adaptive_fields:
+        assert list(modes[0]) == list(want_modes)
+    out = np.full(max(1, data.size), 0x6D, dtype=np.uint8)
+    got = codec.decode_host([want], [n], out=out)[0]
+    assert np.array_equal(got, oracle.decode_stage1(info, want, n, fill=0x6D)), seed
+    _other_entry_points(oracle, codec, plan, info, data, want, n, seed)
+    codec.close()
+
+
+@pytest.mark.parametrize("seed", list(range(11000, 11100)) + list(range((_BASE or 11100) + 11_000_000, (_BASE or 11100) + 11_000_000 + _EXTRA // 10)))
+def test_random_schema_through_the_other_entry_points(oracle, seed):
+    """The random generator's schemas (every kernel route: generic regular streams, fixed-size streams, lossless floats, ...) through
+    the same legs as the corner cases."""
+    from cloudini_amd import native
+    info, data = _random_case(seed)
+    n = data.size // info.point_step
+    want = oracle.encode_stage1(info, data)
+    plan = native.Plan(info)
+    codec = native.Codec(plan)
+    streams, _sizes, _modes = codec.encode_host([data])
+    assert np.array_equal(streams[0], want), seed
+    _other_entry_points(oracle, codec, plan, info, data, want, n, seed * 3 if seed % 3 else seed)  # (every seed takes the batch leg or more)
     codec.close()
 
 
