@@ -210,14 +210,7 @@ __device__ __forceinline__ uint64_t sw_gorilla(const uint32_t* wbuf, uint32_t bp
 // {entry, points, window}), then the table is built for that window and one lane follows the jumps; a point whose '11'
 // token changes the window ends the round -- the table is rebuilt for the new window from there. The token's value bits
 // are XOR differences: the op joins the XOR-coded ones in both walks.
-#ifndef CLDN_SW_BOOST
-#define CLDN_SW_BOOST 1
-#endif
-#if CLDN_SW_BOOST
-#define SW_PRIO_HOP() __builtin_amdgcn_s_setprio(3)
-#else
-#define SW_PRIO_HOP() __builtin_amdgcn_s_setprio(1)
-#endif
+#define SW_PRIO_HOP() __builtin_amdgcn_s_setprio(3)  // (chain hops at the highest wave priority, as in k_decode_points_w)
 #ifdef CLDN_SW_TRACE
 #define SW_T(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr_[k] += t_ - tl_; tl_ = t_; }
 #else

@@ -37,20 +37,10 @@ constexpr uint32_t kWpPiece = kWpUnits * 16u;     // bytes of stream per piece
 constexpr uint32_t kWpSlots = 1024u;              // token slots per wave: <= 992 owned tokens + <= 16 of the halo unit
 constexpr uint32_t kWpRing = 64u;                 // chain records (slot = piece % kWpRing, tagged)
 constexpr uint32_t kWpSpinLimit = 1u << 18;
-#ifndef CLDN_WP_SLEEP
-#define CLDN_WP_SLEEP 4
-#endif
-constexpr int kWpSleep = CLDN_WP_SLEEP;                       // x 64 cycles between two polls of a record
-#ifndef CLDN_WP_BOOST
-#define CLDN_WP_BOOST 1
-#endif
-#if CLDN_WP_BOOST
+constexpr int kWpSleep = 4;                       // x 64 cycles between two polls of a record (64 / 128 cycles: no difference, round 6)
+// the hop from a chain record's arrival to the piece's own record runs at the highest wave priority (round 6: C4 -3 %, C5 -2 %)
 #define WP_BOOST(P) __builtin_amdgcn_s_setprio(P)
 #define WP_BOOST_BACK() __builtin_amdgcn_s_setprio(3)
-#else
-#define WP_BOOST(P)
-#define WP_BOOST_BACK() __builtin_amdgcn_s_setprio(1)
-#endif
 
 template <int NOPS>
 struct WpGeom {

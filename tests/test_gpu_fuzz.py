@@ -443,6 +443,24 @@ def test_host_mirror_full_streams_match_the_reference(reflib, seed):
     assert np.array_equal(got_dec[: n * info.point_step], want_dec[: n * info.point_step]), seed
 
 
+@pytest.mark.parametrize("seed", list(range(7000, 7060)) + list(range((_BASE or 7060) + 13_000_000, (_BASE or 7060) + 13_000_000 + _EXTRA // 50)))
+def test_host_mirror_corner_streams_match_the_reference(reflib, seed):
+    """The same through the host mirror for the dense corner cases (round 6): the full stream -- header, framing, NONE / LZ4 / ZSTD --
+    equals the compiled reference's, and decodes to the same points."""
+    from cloudini_amd import api
+    from cloudini_amd.schema import CompressionOption
+    rs = np.random.RandomState(seed)
+    info, data = _corner_case(seed)
+    info = info.copy(compression_opt=CompressionOption(int(rs.choice([0, 1, 2]))), use_threads=bool(rs.randint(0, 2)))
+    want = reflib.encode(info, data)
+    got = api.PointcloudEncoder(info).encode(data)
+    assert np.array_equal(got, want), (seed, int(info.compression_opt), info.use_threads)
+    n = data.size // info.point_step
+    want_dec, _ = reflib.decode(want, max(1, data.size), fill=0x42)
+    got_dec, got_info = api.PointcloudDecoder().decode_stream(want, fill=0x42)
+    assert np.array_equal(got_dec[: n * info.point_step], want_dec[: n * info.point_step]), seed
+
+
 # ---- device LZ4 on the random schemas: every chunk's block equals the serial model's (oracle/lz4_model.c), both modes ----
 
 _LZ4_PARAMS = {1: (8192, 11, 1024), 2: (4096, 10, 512)}  # CLDN_HIP_STAGE2_LZ4, CLDN_HIP_STAGE2_LZ4_FAST (stage1_launch.h)
