@@ -162,6 +162,25 @@ def _other_entry_points(oracle, codec, plan, info, data, want, n, seed):
             total = int(d_off.cpu().numpy()[1])
             assert total == want.size, (seed, "chunk table", total, want.size)
             assert np.array_equal(d_out[mis:mis + total].cpu().numpy(), want), (seed, "chunk table + framing", mis)
+    if seed % 13 == 0 and n > 32768:
+        # the CHUNK-RANGE sharding of one cloud (the multi-GPU path of one large cloud): the modes are probed on the
+        # cloud's head, every rank encodes its contiguous range of whole chunks with cldn_hip_codec_force_modes, the concatenation
+        # is the single-GPU stream
+        from cloudini_amd import sharding
+        step = info.point_step
+        world = 2 + seed // 13 % 3
+        modes = None
+        if plan.adaptive_fields:
+            codec.force_modes(None)
+            modes = codec.encode_host([data[: min(n, sharding.PROBE_POINTS) * step]])[2][0]
+            codec.force_modes(modes)
+        parts = []
+        for r in range(world):
+            p0, cnt = sharding.shard_chunks(n, world, r)
+            if cnt:
+                parts.append(codec.encode_host([data[p0 * step:(p0 + cnt) * step]])[0][0])
+        codec.force_modes(None)
+        assert np.array_equal(np.concatenate(parts), want), (seed, "chunk-range shards", world)
     if seed % 11 == 0:
         # CLDN_HIP_FILL_ZERO: the bytes of a point that no field covers may come out as 0 instead of keeping the buffer's content --
         # every covered byte is the oracle's, every uncovered one is the buffer's old byte or 0
