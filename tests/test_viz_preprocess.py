@@ -65,6 +65,73 @@ def test_oracle_matches_reference(oracle, reflib, name, info, data, xyz_off, res
     assert width == len(want) // info.point_step and height == 1 or data.size == 0
 
 
+def _viz_random(seed):
+    """Round 6: random clouds for the pre-filter -- point step, triple offset, resolution, cluster structure (so that voxels hold
+    from one to thousands of points), NaN / Inf / huge values sprinkled in. (info, data, xyz_offset, resolution)"""
+    import os
+    rs = np.random.RandomState(seed)
+    n = int(rs.choice([1, 63, 1025, 20_000, 70_001, 300_000]))
+    off = int(rs.choice([0, 0, 1, 2, 4, 7]))
+    extra = int(rs.choice([0, 0, 2, 4, 6, 20]))
+    step = off + 12 + extra
+    res = float(rs.choice([0.001, 0.01, 0.05, 0.25, 1.0]))
+    kind = rs.randint(0, 4)
+    if kind == 0:
+        xyz = rs.uniform(-50, 50, (n, 3))
+    elif kind == 1:                                              # a few hundred clusters, tight
+        c = rs.uniform(-20, 20, (max(1, n // 200), 3))
+        xyz = c[rs.randint(0, len(c), n)] + rs.normal(0, res * 0.7, (n, 3))
+    elif kind == 2:                                              # a scan line: neighbours share voxels
+        t = np.arange(n) * 1e-3
+        xyz = np.stack([np.cos(t) * 10, np.sin(t) * 10, t * 0.01], axis=1)
+    else:                                                        # a grid hit many times
+        xyz = np.round(rs.uniform(-3, 3, (n, 3)) / (res * 2)) * (res * 2)
+    xyz = xyz.astype(np.float32)
+    k = max(1, n // 100)
+    if rs.rand() < 0.6:
+        xyz[rs.randint(0, n, k), rs.randint(0, 3, k)] = np.nan
+    if rs.rand() < 0.3:
+        xyz[rs.randint(0, n, k), rs.randint(0, 3, k)] = rs.choice([np.inf, -np.inf, 3e9, -3e9, 2.5e6, 1e19], k).astype(np.float32)
+    fields = [("x", off, F.FLOAT32, res), ("y", off + 4, F.FLOAT32, res), ("z", off + 8, F.FLOAT32, res)]
+    cols = {"x": xyz[:, 0], "y": xyz[:, 1], "z": xyz[:, 2]}
+    if extra >= 2:
+        fields.append(("i", off + 12, F.UINT16, None))
+        cols["i"] = rs.randint(0, 65536, n).astype(np.uint16)
+    info = cases.make_info(fields, step, n)
+    return info, cases.pack(info, cols, n), off, res
+
+
+@pytest.mark.parametrize("seed", list(range(100, 160)))
+def test_oracle_matches_reference_on_random_clouds(oracle, reflib, seed):
+    info, data, off, res = _viz_random(seed)
+    want, _res_after, _w, _h = reflib.viz_preprocess(info, data)
+    assert np.array_equal(oracle.viz_preprocess(data, info.point_step, off, res), want), seed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(100, 160)) + list(range(20_000, 20_000 + int(__import__("os").environ.get("CLDN_FUZZ_EXTRA", "0")) // 50)))
+def test_gpu_matches_oracle_on_random_clouds(oracle, seed):
+    """... host buffers, and device-resident ones at odd addresses."""
+    import torch
+    from cloudini_amd import native
+    info, data, off, res = _viz_random(seed)
+    step = info.point_step
+    n = data.size // step
+    want = oracle.viz_preprocess(data, step, off, res)
+    codec = native.Codec(native.Plan(synth.lidar_xyz(1)[0]))
+    got = codec.viz_preprocess_host(data, step, off, res)
+    assert got.size == want.size and np.array_equal(got, want), (seed, got.size // step, want.size // step)
+    dev = torch.device("cuda", 0)
+    mi, mo = seed % 4, seed // 4 % 4
+    d_in = torch.zeros(data.size + 8, dtype=torch.uint8, device=dev)
+    d_in[mi:mi + data.size] = torch.from_numpy(data).to(dev)
+    d_out = torch.zeros(data.size + 8, dtype=torch.uint8, device=dev)
+    kept = codec.viz_preprocess_device(d_in.data_ptr() + mi, n, step, off, res, d_out.data_ptr() + mo, data.size)
+    codec.synchronize()
+    assert kept * step == want.size and np.array_equal(d_out[mo:mo + kept * step].cpu().numpy(), want), (seed, "device resident")
+    codec.close()
+
+
 def test_reference_no_triple_is_a_noop(reflib):
     """No geometry triple (offsets not consecutive / resolutions differ / fewer than 3 fields) -> untouched."""
     n = 100
