@@ -113,7 +113,10 @@ int cldn_hip_codec_device(const cldn_hip_codec_t* codec); /* device the codec wa
  *   chunk_sizes    [total chunks] payload size of every chunk, batch order (optional, may be NULL)
  *   modes          [n_clouds * adaptive_fields] committed V5 adaptive-int mode per cloud and field
  *                  (0 DeltaVarint, 1 Palette, 2 Rle, 3 DeltaRle; src/v5_codec.cpp:33-38) (optional)
- * stream_offsets / chunk_sizes / modes live where `out` lives (out_loc). */
+ * stream_offsets / chunk_sizes / modes live where `out` lives (out_loc).
+ * Alignment: `points` and `out` may have ANY byte alignment, host or device (a stream often follows a header of odd length;
+ * tests/test_gpu_encode.py::test_device_buffers_at_any_address). Device-resident stream_offsets (8-byte aligned) and chunk_sizes
+ * (4-byte aligned) are written by the kernels in place; at other alignments they are filled by a copy behind the kernels. */
 int cldn_hip_encode_stage1(cldn_hip_codec_t* codec, const void* points, int points_loc,
                            const uint64_t* cloud_points, uint32_t n_clouds, void* out, uint64_t out_capacity,
                            int out_loc, uint64_t* stream_offsets, uint32_t* chunk_sizes, uint8_t* modes);
