@@ -206,6 +206,7 @@ int cldn_hip_codec_pipeline(cldn_hip_codec_t* codec, int mode, const void* point
  *   cloud_points   HOST array [n_clouds] (width*height of each cloud)
  *   points_out     sum_k cloud_points[k] * point_step bytes; bytes not covered by a field keep their
  *                  previous content (src/field_decoder.cpp:72-76)
+ * `streams` and `points_out` may have any byte alignment, host or device.
  * Returns CLDN_HIP_ERR_CORRUPT for malformed input when out_loc == HOST; with DEVICE outputs the status is
  * reported by the next cldn_hip_codec_status() call. */
 int cldn_hip_decode_stage1(cldn_hip_codec_t* codec, const void* streams, int streams_loc,
